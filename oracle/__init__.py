@@ -1,0 +1,315 @@
+"""CPU oracle for the waveflow flow-density hot path -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this package.  The product (waveflow_amd/) never does.
+
+The arithmetic lives in wf_oracle.c (fp64 tables, fp32 evaluation, reference
+operation order).  This module adds
+  * a ctypes binding,
+  * the NumPy restatement of the reference's one-off orthogonalisation of the
+    B basis (splines/ortho_splines.py:43-161 + splines/bsplines_jax.py:98-106),
+    which the reference itself does in NumPy (np.dot / np.linalg.pinv),
+  * a small model description that mirrors model_factory.get_waveflow_model /
+    get_model / benchmark_tests.get_model.
+
+Parity pin: see the header of wf_oracle.c.
+"""
+import ctypes
+import functools
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libwf_oracle.so")
+
+KIND_M, KIND_I, KIND_B = 0, 1, 2
+MAX_D, MAX_BC = 16, 4
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "wf_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libwf_oracle.so"])
+    return _LIB_PATH
+
+
+class _BC(ctypes.Structure):
+    _fields_ = [("n", ctypes.c_int), ("nd", ctypes.c_int * MAX_BC), ("val", ctypes.c_float * MAX_BC)]
+
+
+class _Spline(ctypes.Structure):
+    _fields_ = [("k", ctypes.c_int), ("nb", ctypes.c_int), ("n_mesh", ctypes.c_int),
+                ("tab", ctypes.c_void_p), ("left", _BC), ("right", _BC)]
+
+
+class _Model(ctypes.Structure):
+    _fields_ = [("D", ctypes.c_int), ("hidden", ctypes.c_int), ("n_layers", ctypes.c_int),
+                ("layer_kind", ctypes.c_int), ("box_kind", ctypes.c_int), ("box_L", ctypes.c_float),
+                ("i_reg", ctypes.c_float), ("isp", _Spline), ("prior_kind", ctypes.c_int),
+                ("normal_offset", ctypes.c_float), ("psp", _Spline), ("psp_plain", ctypes.c_void_p),
+                ("ob_to_b", ctypes.c_void_p), ("n_constr_left", ctypes.c_int),
+                ("constr_left", ctypes.c_int * MAX_D)]
+
+
+@functools.lru_cache(None)
+def lib():
+    L = ctypes.CDLL(build())
+    L.wfo_table.restype = ctypes.c_int
+    L.wfo_table.argtypes = [ctypes.c_int] * 5 + [ctypes.c_void_p]
+    L.wfo_knots.restype = ctypes.c_int
+    L.wfo_eval.restype = ctypes.c_int
+    L.wfo_eval.argtypes = [ctypes.POINTER(_Model), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
+                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    L.wfo_imade_direct.restype = ctypes.c_int
+    L.wfo_imade_direct.argtypes = [ctypes.POINTER(_Model), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    L.wfo_flow_direct.restype = ctypes.c_int
+    L.wfo_flow_direct.argtypes = [ctypes.POINTER(_Model), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                  ctypes.c_void_p, ctypes.c_void_p]
+    L.wfo_rqs.restype = ctypes.c_int
+    L.wfo_rqs.argtypes = [ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                          ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                          ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]
+    return L
+
+
+# ---------------------------------------------------------------- tables
+@functools.lru_cache(None)
+def table(kind, k, n_internal, n_mesh=2000):
+    """fp64 [4][n_bases][n_mesh]: derivative orders 0..3 (isplines_jax.py:113, bsplines_jax.py:75, msplines_jax.py:91)."""
+    L = lib()
+    nb = L.wfo_table(kind, k, n_internal, n_mesh, 0, None)
+    out = np.zeros((4, nb, n_mesh))
+    for nd in range(4):
+        L.wfo_table(kind, k, n_internal, n_mesh, nd, out[nd].ctypes.data)
+    out.setflags(write=False)
+    return out
+
+
+def gram_schmidt_l2r(imat, ovlp=None):
+    """ortho_splines.py:140-161"""
+    mat = np.copy(imat)
+    N, M = mat.shape
+    if ovlp is None:
+        ovlp = np.dot(mat.T, mat)
+    omat = np.zeros((N, M))
+    omat[:, 0] = mat[:, 0] / np.sqrt(ovlp[0, 0])
+    for i in range(M - 1):
+        vec = ovlp[i, (i + 1):]
+        mat[:, (i + 1):] -= np.outer(mat[:, i], vec) / ovlp[i, i]
+        ovlp[(i + 1):, (i + 1):] -= np.outer(vec, vec) / ovlp[i, i]
+        omat[:, i + 1] = mat[:, i + 1] / np.sqrt(ovlp[i + 1, i + 1])
+    return omat
+
+
+def symm_ortho2v(v1, v2):
+    """ortho_splines.py:115-137"""
+    ovlp = np.dot(v1, v2)
+    assert 0 <= ovlp <= 1
+    s1 = 1. / np.sqrt(1 + ovlp)
+    s2 = 1. / np.sqrt(1 - ovlp)
+    a1 = 0.5 * (s1 + s2)
+    a2 = 0.5 * (s1 - s2)
+    return a1 * v1 + a2 * v2, a2 * v1 + a1 * v2
+
+
+def gram_schmidt_symm(imat):
+    """ortho_splines.py:43-112 (even number of vectors only, as the reference)."""
+    mat = np.copy(imat)
+    N, M = mat.shape
+    npair = int(M // 2)
+    if M % 2:
+        raise ValueError("odd number of bases: the reference exits (ortho_splines.py:61-63)")
+    ovlp = np.dot(mat.T, mat)
+    omat = np.zeros((N, M))
+    matR = np.zeros((N, 2 * npair))
+    ovlpR = np.zeros((2 * npair, 2 * npair))
+    ind_j = np.concatenate([np.arange(0, 2 * npair - 1, 2), np.arange(1, 2 * npair, 2)])
+    ind_k = np.concatenate([np.arange(M - 1, M - npair - 1, -1), np.arange(0, npair)])
+    matR[:, ind_j] = mat[:, ind_k]
+    ovlpR[:, ind_j] = ovlp[:, ind_k]
+    ovlpR[ind_j, :] = ovlpR[ind_k, :]
+    matL = np.zeros((N, M))
+    ovlpL = np.zeros((M, M))
+    ind_jL = np.concatenate([ind_j, np.array([M - 1])])
+    ind_kL = np.concatenate([np.arange(0, npair), np.arange(M - 1, M - npair - 1, -1), np.array([npair])])
+    matL[:, ind_jL] = mat[:, ind_kL]
+    ovlpL[:, ind_jL] = ovlp[:, ind_kL]
+    ovlpL[ind_jL, :] = ovlpL[ind_kL, :]
+    matL = gram_schmidt_l2r(matL, ovlpL)
+    matR = gram_schmidt_l2r(matR, ovlpR)
+    for i in range(npair):
+        o1, o2 = symm_ortho2v(matL[:, 2 * i], matR[:, 2 * i])
+        omat[:, i] = o1
+        omat[:, M - i - 1] = o2
+    c = np.sqrt(N)
+    for i in range(M):
+        omat[:, i] = omat[:, i] * c
+    return omat
+
+
+@functools.lru_cache(None)
+def ortho_b(k, n_internal, n_mesh=2000):
+    """bsplines_jax.py:88-116: returns (plain B [4][nb][n_mesh], orthogonal B [4][nb][n_mesh], b_to_ob, ob_to_b), fp64."""
+    Bt = table(KIND_B, k, n_internal, n_mesh)
+    ob0 = gram_schmidt_symm(Bt[0].T).T
+    ob0 = ob0 / np.sqrt((ob0 ** 2).sum(-1)[0] / n_mesh)
+    b_to_ob = ob0 @ np.linalg.pinv(Bt[0])
+    ob_to_b = Bt[0] @ np.linalg.pinv(ob0)
+    OB = np.stack([ob0] + [b_to_ob @ Bt[nd] for nd in range(1, 4)])
+    return Bt, OB, b_to_ob, ob_to_b
+
+
+# ---------------------------------------------------------------- model description
+class Model:
+    """Mirror of the reference's factory arguments (model_factory.py:96-146, benchmark_tests.py:50-78)."""
+
+    def __init__(self, D, n_layers, layer_kind="imade", box=None, box_L=1.0, i_k=5, i_knots=16, i_reg=0.0,
+                 i_left=None, i_right=None, prior="waveflow", p_k=5, p_knots=16, p_left=None, p_right=None,
+                 constr_left=(), normal_offset=0.0, n_mesh=2000, hidden=64):
+        self.D, self.n_layers, self.hidden = D, n_layers, hidden
+        self.keep = []
+        m = _Model()
+        m.D, m.hidden, m.n_layers = D, hidden, n_layers
+        m.layer_kind = {"imade": 0, "made": 1}[layer_kind]
+        m.box_kind = {None: 0, "mean": 1, "first": 2}[box]
+        m.box_L = box_L
+        m.i_reg = i_reg
+        self.i_nb = self.p_nb = 0
+        if layer_kind == "imade":
+            tab = np.ascontiguousarray(table(KIND_I, i_k, i_knots, n_mesh), dtype=np.float32)
+            self.keep.append(tab)
+            self.i_tab = tab
+            self._spline(m.isp, i_k, tab, {0: 0.0} if i_left is None else i_left, {0: 1.0} if i_right is None else i_right, n_mesh)
+            self.i_nb = tab.shape[1]
+        m.prior_kind = {"waveflow": 0, "mflow": 1, "uniform": 2, "normal": 3}[prior]
+        m.normal_offset = normal_offset
+        if prior == "waveflow":
+            Bt, OB, b2o, o2b = ortho_b(p_k, p_knots, n_mesh)
+            ob32 = np.ascontiguousarray(OB, dtype=np.float32)
+            b32 = np.ascontiguousarray(Bt, dtype=np.float32)
+            o2b32 = np.ascontiguousarray(o2b, dtype=np.float32)
+            self.keep += [ob32, b32, o2b32]
+            self._spline(m.psp, p_k, ob32, {0: 0} if p_left is None else p_left, {0: 0} if p_right is None else p_right, n_mesh)
+            m.psp_plain = b32.ctypes.data
+            m.ob_to_b = o2b32.ctypes.data
+            self.p_nb = ob32.shape[1]
+        elif prior == "mflow":
+            tab = np.ascontiguousarray(table(KIND_M, p_k, p_knots, n_mesh), dtype=np.float32)
+            self.keep.append(tab)
+            self._spline(m.psp, p_k, tab, {0: 0} if p_left is None else p_left, {0: 0} if p_right is None else p_right, n_mesh)
+            self.p_nb = tab.shape[1]
+        m.n_constr_left = len(constr_left)
+        for i, c in enumerate(constr_left):
+            m.constr_left[i] = int(c)
+        self.c = m
+
+    @staticmethod
+    def _spline(s, k, tab, left, right, n_mesh):
+        s.k, s.nb, s.n_mesh = k, tab.shape[1], n_mesh
+        s.tab = tab.ctypes.data
+        for bc, d in ((s.left, left), (s.right, right)):
+            bc.n = len(d)
+            for i, (nd, val) in enumerate(d.items()):
+                bc.nd[i], bc.val[i] = int(nd), float(val)
+
+    # ---- parameter bookkeeping (pytree leaf order of the reference checkpoint)
+    def net_sizes(self, n_out, with_zero=True):
+        D, H = self.D, self.hidden
+        s = [D * H, H, H * H, H, H * n_out * D, n_out * D]
+        if with_zero:
+            s.append(D * n_out)
+        return s
+
+    def layer_param_count(self):
+        return sum(self.net_sizes(self.i_nb)) if self.c.layer_kind == 0 else sum(self.net_sizes(2, with_zero=False))
+
+    def n_params(self):
+        n = self.n_layers * self.layer_param_count()
+        if self.c.prior_kind in (0, 1):
+            n += sum(self.net_sizes(self.p_nb))
+        return n
+
+    def init_params(self, seed=0):
+        """Seeded init with the reference's distributions (model_factory.py:25-28, 84); NOT JAX's threefry stream."""
+        rng = np.random.default_rng(seed)
+        out = []
+
+        def net(n_out, with_zero=True):
+            D, H = self.D, self.hidden
+            for fan_in, shape in ((D, (D, H)), (D, (H,)), (H, (H, H)), (H, (H,)), (H, (H, n_out * D)), (H, (n_out * D,))):
+                b = 1.0 / np.sqrt(fan_in)
+                out.append(rng.uniform(-b, b, size=shape).astype(np.float32).reshape(-1))
+            if with_zero:
+                out.append(rng.uniform(-0.5, 0.5, size=(D, n_out)).astype(np.float32).reshape(-1))
+
+        for _ in range(self.n_layers):
+            net(self.i_nb) if self.c.layer_kind == 0 else net(2, with_zero=False)
+        if self.c.prior_kind in (0, 1):
+            net(self.p_nb)
+        return np.concatenate(out)
+
+    # ---- evaluation
+    def _eval(self, params, x, mode, return_u, return_idx, threads):
+        params = np.ascontiguousarray(params, dtype=np.float32)
+        assert params.size == self.n_params(), (params.size, self.n_params())
+        x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1, self.D)
+        B = x.shape[0]
+        out = np.zeros(B, np.float32)
+        u = np.zeros((B, self.D), np.float32) if return_u else None
+        idx = np.zeros((B, self.n_layers + 1, self.D, 2), np.int32) if return_idx else None
+        rc = lib().wfo_eval(ctypes.byref(self.c), params.ctypes.data, x.ctypes.data, B, mode, out.ctypes.data,
+                            u.ctypes.data if return_u else None, idx.ctypes.data if return_idx else None, threads)
+        if rc:
+            raise RuntimeError(f"wfo_eval rc={rc}")
+        res = [out]
+        if return_u:
+            res.append(u)
+        if return_idx:
+            res.append(idx)
+        return res[0] if len(res) == 1 else tuple(res)
+
+    def log_pdf(self, params, x, return_u=False, return_idx=False, threads=1):
+        return self._eval(params, x, 0, return_u, return_idx, threads)
+
+    def psi(self, params, x, return_u=False, return_idx=False, threads=1):
+        return self._eval(params, x, 1, return_u, return_idx, threads)
+
+    def imade_direct(self, layer_params, u):
+        layer_params = np.ascontiguousarray(layer_params, dtype=np.float32)
+        u = np.ascontiguousarray(u, dtype=np.float32).reshape(-1, self.D)
+        B = u.shape[0]
+        y = np.zeros_like(u)
+        ld = np.zeros(B, np.float32)
+        idx = np.zeros((B, self.D, 2), np.int32)
+        lib().wfo_imade_direct(ctypes.byref(self.c), layer_params.ctypes.data, u.ctypes.data, B, y.ctypes.data,
+                               ld.ctypes.data, idx.ctypes.data)
+        return y, ld, idx
+
+    def flow_direct(self, params, x):
+        params = np.ascontiguousarray(params, dtype=np.float32)
+        x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1, self.D)
+        u = np.zeros_like(x)
+        ld = np.zeros(x.shape[0], np.float32)
+        lib().wfo_flow_direct(ctypes.byref(self.c), params.ctypes.data, x.ctypes.data, x.shape[0], u.ctypes.data,
+                              ld.ctypes.data)
+        return u, ld
+
+
+def he_model(box_L=10.0):
+    """vqmc.create_train_state (vqmc.py:123-134) with the shipped He settings (vqmc.py:30-34)."""
+    return Model(D=2, n_layers=3, layer_kind="imade", box="mean", box_L=box_L, i_k=6, i_knots=23, i_reg=0.05,
+                 i_left={0: 0}, i_right={0: 1}, prior="waveflow", p_k=6, p_knots=23, p_left={0: 0}, p_right={0: 0},
+                 constr_left=(0,))
+
+
+def rqs(x, uw, uh, ud, inverse=False, left=0.0, right=1.0, bottom=0.0, top=1.0):
+    """neural_splines.py:74-184 for one scalar (parity unpinned)."""
+    uw = np.ascontiguousarray(uw, np.float32); uh = np.ascontiguousarray(uh, np.float32); ud = np.ascontiguousarray(ud, np.float32)
+    o, l, b = ctypes.c_float(), ctypes.c_float(), ctypes.c_int()
+    rc = lib().wfo_rqs(float(x), uw.ctypes.data, uh.ctypes.data, ud.ctypes.data, len(uw), int(inverse), left, right, bottom,
+                       top, ctypes.byref(o), ctypes.byref(l), ctypes.byref(b))
+    assert rc == 0
+    return o.value, l.value, b.value
