@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""bench.py -- flow log-prob evals/s of the He (2 e-, 1-D box) waveflow model on MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic walkers per GPU:
+    log_pdf launch  ->  fp64 block sums [sum, sum^2, n] of the batch  ->  (N>1) one RCCL all-reduce of those
+    3 doubles (the <E_L> site of vqmc.py:196).
+Walkers shard over ranks with no exchange of coordinates (weak scaling, B per GPU fixed).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic work per eval for the He config
+FLOP_PER_EVAL = 63232          # dense conditioner: 3 x 15872 + 15616
+BYTES_PER_EVAL = 12            # 2 x fp32 in + 1 x fp32 out
+PEAK_F32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak
+PEAK_HBM_GBS = 8000.0
+
+
+def he_model(kernel):
+    from waveflow_amd import checkpoint, model_factory
+    flat = np.load(os.path.join(ROOT, "tests", "golden", "he_checkpoint.npz"))["flat"]
+    init_fun = model_factory.get_waveflow_model(2, base_spline_degree=6, i_spline_degree=6, n_prior_internal_knots=23,
+                                                n_i_internal_knots=23, i_spline_reg=0.05, i_spline_reverse_fun_tol=1e-6,
+                                                n_flow_layers=3, box_size=10, xu_coord_type="mean")
+    params, psi, log_pdf, _ = init_fun(0, 2)
+    model = log_pdf.model
+    model.set_params(flat)
+    model.set_kernel(kernel)
+    return model, flat
+
+
+def walkers(B, seed):
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.rand(B, 2, generator=g) * 2 - 1) * 10.0
+    return torch.sort(x, dim=-1).values.contiguous()
+
+
+def cpu_baseline(flat, x_host, budget_s=12.0):
+    """The oracle (port of the reference algorithm) on the host cores, on a bounded sample of the same walkers."""
+    import oracle
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    om = oracle.he_model(10.0)
+    n0 = 4096
+    t = time.perf_counter()
+    om.log_pdf(flat, x_host[:n0], threads=cores)
+    dt = time.perf_counter() - t
+    n = int(min(x_host.shape[0], max(n0, n0 * budget_s / max(dt, 1e-6))))
+    t = time.perf_counter()
+    om.log_pdf(flat, x_host[:n], threads=cores)
+    dt = time.perf_counter() - t
+    return {"value": n / dt, "unit": "evals/s", "cores": cores, "kind": "port",
+            "sample": f"first {n} of the benchmark's walkers, oracle/wf_oracle.c with OpenMP over walkers, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=1 << 20, help="walkers per GPU")
+    ap.add_argument("--kernel", default="auto", choices=["auto", "scalar", "mfma"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    model, flat = he_model(args.kernel)
+    B = args.batch
+    x_host = walkers(B, 1234 + rank)
+    x = x_host.to(dev)
+    lp = torch.empty(B, device=dev, dtype=torch.float32)
+
+    from waveflow_amd import _lib
+    import ctypes
+    L = _lib.lib()
+    ws = torch.empty(int(L.wf_block_sums_workspace_bytes(B)), device=dev, dtype=torch.uint8)
+    sums = torch.zeros(3, device=dev, dtype=torch.float64)
+    stream = torch.cuda.current_stream(dev)
+    sp = ctypes.c_void_p(stream.cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+
+    def step(i=None):
+        if i is not None:
+            ev0[i].record(stream)
+        _lib.check(L.wf_logpdf_fwd(model._h, P(x), B, P(lp), None, None, sp), "wf_logpdf_fwd")
+        if i is not None:
+            ev1[i].record(stream)
+        _lib.check(L.wf_block_sums(P(lp), B, P(sums), P(ws), ws.numel(), sp), "wf_block_sums")
+        if world > 1:
+            dist.all_reduce(sums)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    fence()
+    dt = time.perf_counter() - t0
+
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+    mean_logp = float((sums[0] / sums[2]).item())
+
+    if rank == 0:
+        evals = B * world * args.steps
+        value = evals / dt
+        k_evals_s = B / (kern_ms * 1e-3)
+        out = {
+            "metric": "flow log-prob evals/sec", "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "1D He-like 2e- box L=10 (shipped He checkpoint: 3 IMADE layers k=6/23 knots + B-spline prior), "
+                                   f"log_pdf over {B} sorted U(-L,L)^2 walkers per GPU, + fp64 block sums"
+                                   + (" + 1 RCCL all-reduce of 3 doubles" if world > 1 else ""),
+                       "walkers_per_gpu": B, "kernel": args.kernel, "mean_logp": mean_logp},
+            "roofline": {"bound": "mfma", "achieved": k_evals_s * FLOP_PER_EVAL / 1e12, "peak": PEAK_F32_MATRIX_TFLOPS,
+                         "unit": "TFLOP/s", "frac": k_evals_s * FLOP_PER_EVAL / 1e12 / PEAK_F32_MATRIX_TFLOPS, "traffic": None,
+                         "kernel": "log_pdf", "kernel_ms": kern_ms, "flop_per_eval": FLOP_PER_EVAL},
+            "hbm": {"achieved": k_evals_s * BYTES_PER_EVAL / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": k_evals_s * BYTES_PER_EVAL / 1e9 / PEAK_HBM_GBS, "bytes_per_eval": BYTES_PER_EVAL},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(flat, x_host.numpy())
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

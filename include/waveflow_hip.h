@@ -1,0 +1,165 @@
+/*
+ * waveflow_hip.h -- C ABI of libwaveflow_hip.so (MI355X / gfx950).
+ *
+ * The reference (aspuru-guzik-group/waveflow) is pure Python/JAX and has no FFI;
+ * its boundary for the flow-density hot path is three closure protocols
+ * (SURVEY.md §8b).  Each entry point below names the reference closure(s) it
+ * replaces (paths relative to /root/reference/waveflow).  The Python package
+ * waveflow_amd re-creates those closures on top of this ABI (ctypes binding:
+ * waveflow_amd/_lib.py; the stub a reference maintainer would add is shown in
+ * INTEGRATION.md).
+ *
+ * Conventions
+ *   - plain C types only; every function returns 0 (WF_OK) or a negative
+ *     wf_status, never throws;  wf_strerror() gives the text;
+ *   - the caller owns every buffer; `*_dev` pointers are device (HBM) pointers,
+ *     row-major, fp32 unless stated; `stream` is a hipStream_t passed as void*
+ *     (NULL = the default stream); launches are asynchronous on that stream;
+ *   - the library owns wf_model (wf_model_create / wf_model_destroy).  A model
+ *     is immutable during a launch: concurrent launches on different streams
+ *     are safe, wf_model_set_params must not run concurrently with launches
+ *     that use the model;
+ *   - there is no CPU fallback: on a machine without a gfx950 device every
+ *     device entry point returns WF_ERR_NO_DEVICE.
+ */
+#ifndef WAVEFLOW_HIP_H
+#define WAVEFLOW_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WF_ABI_VERSION 1
+#define WF_MAX_DIM 16
+#define WF_MAX_BC 4
+
+typedef enum {
+    WF_OK = 0,
+    WF_ERR_INVALID = -1,      /* bad argument / inconsistent descriptor                */
+    WF_ERR_UNSUPPORTED = -2,  /* valid in the reference, not built here */
+    WF_ERR_HIP = -3,          /* a HIP runtime call failed (wf_last_hip_error())         */
+    WF_ERR_NO_DEVICE = -4,    /* no gfx950 device visible                               */
+    WF_ERR_NOMEM = -5,
+    WF_ERR_NUMERIC = -6       /* table build: singular Gram matrix, odd basis count ...  */
+} wf_status;
+
+/* spline families: splines/msplines_jax.py, isplines_jax.py, bsplines_jax.py */
+typedef enum { WF_SPLINE_M = 0, WF_SPLINE_I = 1, WF_SPLINE_B = 2, WF_SPLINE_OB = 3 } wf_spline_kind;
+/* bijector layers: flows/bijections/made.py:44-105 (IMADE), :7-41 (MADE) */
+typedef enum { WF_LAYER_IMADE = 0, WF_LAYER_MADE = 1 } wf_layer_kind;
+/* BoxTransformLayer xu_coord_type: made.py:156-183 ('mean'), :118-137 ('first') */
+typedef enum { WF_BOX_NONE = 0, WF_BOX_MEAN = 1, WF_BOX_FIRST = 2 } wf_box_kind;
+/* density heads: wavefunctions.py:9-112 (Waveflow), flows/distributions.py:116-194 (MFlow),
+ * :67-112 (Flow) with Uniform (:26-41, prior_support=(0,1)) or Normal(offset) (:8-23) priors */
+typedef enum { WF_PRIOR_WAVEFLOW = 0, WF_PRIOR_MFLOW = 1, WF_PRIOR_UNIFORM = 2, WF_PRIOR_NORMAL = 3 } wf_prior_kind;
+/* which device kernel evaluates the model */
+typedef enum { WF_KERNEL_AUTO = 0, WF_KERNEL_SCALAR = 1, WF_KERNEL_MFMA = 2 } wf_kernel_kind;
+
+/* constraints_dict_{left,right}: {n_derivative: value} in insertion order
+ * (isplines_jax.py:158-194, bsplines_jax.py:173-199, msplines_jax.py:156-184) */
+typedef struct {
+    int32_t n;
+    int32_t n_derivative[WF_MAX_BC];
+    float value[WF_MAX_BC];
+} wf_bc;
+
+/* Everything model_factory.get_waveflow_model (model_factory.py:121-146), get_model (:96-116) and
+ * benchmark_tests.get_model (benchmark_tests.py:50-78) close over. */
+typedef struct {
+    int32_t n_dim;              /* input_dim D (>= 2: hidden degrees are arange(64) % (D-1), model_factory.py:15) */
+    int32_t hidden;             /* 64, model_factory.py:72 */
+    int32_t n_flow_layers;      /* (IMADE|MADE, Reverse) pairs */
+    int32_t layer_kind;         /* wf_layer_kind */
+    int32_t box_kind;           /* wf_box_kind */
+    float box_size;             /* box_side */
+    int32_t i_degree;           /* IMADE spline_degree */
+    int32_t i_knots;            /* IMADE n_internal_knots */
+    float i_reg;                /* spline_regularization, made.py:68 */
+    wf_bc i_left, i_right;      /* IMADE constraints */
+    int32_t prior_kind;         /* wf_prior_kind */
+    int32_t p_degree, p_knots;  /* prior spline degree / n_internal_knots */
+    wf_bc p_left, p_right;      /* prior constraints */
+    float normal_offset;        /* Normal(offset) */
+    int32_t n_constrained_left; /* constrained_dimension_indices_left, model_factory.py:124-129 */
+    int32_t constrained_left[WF_MAX_DIM];
+    int32_t n_mesh;             /* n_spline_base_mesh_points (2000) */
+} wf_model_desc;
+
+typedef struct wf_model wf_model;
+
+/* -- host-only ----------------------------------------------------------------------------- */
+
+/* Basis tables, replaces the one-off table build in ISpline_fun/BSpline_fun/MSpline_fun.init_fun
+ * (isplines_jax.py:106-131, bsplines_jax.py:68-116, msplines_jax.py:84-108 -> splines_np.py:42-137,
+ * ortho_splines.py:43-161).  out: fp64 [4][n_bases][n_mesh] (derivative orders 0..3).  For
+ * WF_SPLINE_OB, b_to_ob / ob_to_b ([n_bases][n_bases], may be NULL) receive the change-of-basis
+ * matrices.  Returns n_bases (> 0) or a negative wf_status; with out == NULL only returns n_bases. */
+int wf_tables_build(int kind, int degree, int n_internal_knots, int n_mesh, double* out, double* b_to_ob,
+                    double* ob_to_b);
+
+const char* wf_strerror(int status);
+int wf_abi_version(void);
+/* last hipError_t seen by this thread (as int) and its string */
+int wf_last_hip_error(void);
+const char* wf_last_hip_error_string(void);
+/* number of visible gfx950 devices (0 if none / no driver) */
+int wf_device_count(void);
+
+/* -- model ---------------------------------------------------------------------------------- */
+
+/* Builds tables, masks and device buffers on `device`.  Replaces init_fun(rng, input_dim) of
+ * Waveflow / MFlow / Flow (wavefunctions.py:13-31, distributions.py:118-137, :89-93) minus the
+ * random parameter draw. */
+int wf_model_create(const wf_model_desc* desc, int device, wf_model** out);
+void wf_model_destroy(wf_model* m);
+
+/* number of fp32 parameters = pytree leaves of the reference's `params`, flattened in leaf order:
+ * per flow layer W0[D,64] b0[64] W1[64,64] b1[64] W2[64,D*nb] b2[D*nb] zero[D,nb] (MADE: no zero,
+ * nb = 2), then the prior net in the same order (WAVEFLOW / MFLOW priors only). */
+int64_t wf_model_param_count(const wf_model* m);
+int wf_model_n_bases(const wf_model* m, int which /* 0 = flow-layer spline, 1 = prior spline */);
+
+/* Uploads parameters (host pointer, flat leaf order) and re-derives the device-side masked /
+ * MFMA-permuted weight images.  Synchronous with respect to `stream`. */
+int wf_model_set_params(wf_model* m, const float* flat_host, int64_t n, void* stream);
+
+/* select the kernel used by the *_fwd entry points (default WF_KERNEL_AUTO) */
+int wf_model_set_kernel(wf_model* m, int kernel_kind);
+
+/* -- device entry points (the hot path) ----------------------------------------------------- */
+
+/* log_pdf(params, inputs[, return_sample]) of Waveflow (wavefunctions.py:33-52), MFlow
+ * (distributions.py:139-163), Flow (distributions.py:95-102).
+ *   x_dev   [B][D]   walker coordinates
+ *   logp_dev[B]
+ *   u_dev   [B][D] or NULL: the latent sample (`return_sample=True`), after the prior's clip
+ *   bin_idx_dev [B][n_flow_layers+1][D][2] int32 or NULL: (x_l, x_r) = (floor, ceil)(u*(n_mesh-1))
+ *           of every table lookup (isplines_jax.py:47-48), debug / parity output */
+int wf_logpdf_fwd(const wf_model* m, const float* x_dev, int64_t B, float* logp_dev, float* u_dev,
+                  int32_t* bin_idx_dev, void* stream);
+
+/* psi(params, inputs) of Waveflow (wavefunctions.py:54-71); WF_PRIOR_WAVEFLOW models only. */
+int wf_psi_fwd(const wf_model* m, const float* x_dev, int64_t B, float* psi_dev, float* u_dev,
+               int32_t* bin_idx_dev, void* stream);
+
+/* Serial(...).direct_fun (bijections.py:452-460): u[B][D], logdet[B] of the whole bijector stack. */
+int wf_flow_fwd(const wf_model* m, const float* x_dev, int64_t B, float* u_dev, float* logdet_dev, void* stream);
+
+/* One bijector layer's direct_fun (IMADE made.py:66-81 / MADE made.py:21-27), without the
+ * following Reverse: y[B][D], logdet[B]; bin_idx_dev [B][D][2] or NULL (IMADE only). */
+int wf_layer_fwd(const wf_model* m, int layer, const float* u_in_dev, int64_t B, float* y_dev, float* logdet_dev,
+                 int32_t* bin_idx_dev, void* stream);
+
+/* Local block sums for the VQMC expectation (vqmc.py:196: the batch mean is the only reduction over
+ * walkers): out_dev[3] (fp64) = { sum v, sum v^2, count } over v[B]; deterministic (fixed-order) reduction.
+ * The caller all-reduces these three doubles across ranks (RCCL) -- see waveflow_amd/distributed.py. */
+int wf_block_sums(const float* v_dev, int64_t B, double* out_dev, void* workspace_dev, int64_t workspace_bytes,
+                  void* stream);
+int64_t wf_block_sums_workspace_bytes(int64_t B);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WAVEFLOW_HIP_H */

@@ -1,0 +1,38 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return {n[:-4]: np.load(os.path.join(GOLDEN, n)) for n in os.listdir(GOLDEN) if n.endswith(".npz")}
+
+
+@pytest.fixture(scope="session")
+def he_flat(golden):
+    return golden["he_checkpoint"]["flat"]
+
+
+def he_grid(L=10.0, ngrid=100):
+    """helpers.py:52-58: the 100x100 grid the reference evaluates psi on."""
+    y, x = np.meshgrid(np.linspace(-L, L, ngrid), np.linspace(-L, L, ngrid))
+    coords = np.stack([x, y], axis=-1).reshape(-1, 2)
+    inv = (coords[:, 0] > coords[:, 1]).astype(np.int64)
+    return coords, np.sort(coords, axis=-1), (-1.0) ** inv
+
+
+def sorted_walkers(B, D, L, seed):
+    """SURVEY §8d C3/C4 inputs: U(-L, L)^D sorted ascending per row, fp32."""
+    g = np.random.default_rng(seed)
+    return np.sort(g.uniform(-L, L, size=(B, D)).astype(np.float32), axis=-1)

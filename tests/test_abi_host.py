@@ -1,0 +1,79 @@
+"""C-ABI surface and host logic (no GPU needed)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle
+from waveflow_amd import _lib, checkpoint, core, flows, model_factory
+from conftest import ROOT
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "waveflow_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(wf_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 15
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert declared == set(_lib.EXPORTS)
+    assert _lib.lib().wf_abi_version() == 1
+
+
+def test_desc_struct_matches_header_layout():
+    # 4-byte fields only; guards against drift between _lib.ModelDesc and wf_model_desc
+    assert ctypes.sizeof(_lib.BC) == 4 + 4 * 4 + 4 * 4
+    assert ctypes.sizeof(_lib.ModelDesc) == 4 * 9 + 2 * 36 + 4 * 3 + 2 * 36 + 4 + 4 + 16 * 4 + 4
+
+
+def test_strerror_and_no_device_is_loud():
+    L = _lib.lib()
+    assert b"no gfx950" in L.wf_strerror(-4)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    d = _lib.ModelDesc()
+    h = ctypes.c_void_p()
+    assert L.wf_model_create(ctypes.byref(d), 0, ctypes.byref(h)) == _lib.ERR_NO_DEVICE
+    init_fun = model_factory.get_waveflow_model(2)
+    with pytest.raises(_lib.WfError):
+        init_fun(0, 2)
+
+
+def test_param_tree_layout_matches_reference_checkpoint(he_flat):
+    """Leaf order / shapes of the He checkpoint: 3 x [(W0,b0),(W1,b1),(W2,b2),zero] + prior."""
+    init_fun = model_factory.get_waveflow_model(2, base_spline_degree=6, i_spline_degree=6, n_prior_internal_knots=23,
+                                                n_i_internal_knots=23, i_spline_reg=0.05, n_flow_layers=3, box_size=10)
+    g = flows.as_generator(0)
+    tparams = init_fun.transformation.init_params(g, 2)
+    sparams = init_fun.sp.init_params(g, 2, 23 + 6 - 1)
+    tree = (tparams, sparams)
+    shapes = [tuple(a.shape) for a in core.tree_leaves(tree)]
+    per_layer = [(2, 64), (64,), (64, 64), (64,), (64, 58), (58,), (2, 29)]
+    assert shapes == per_layer * 3 + [(2, 64), (64,), (64, 64), (64,), (64, 56), (56,), (2, 28)]
+    assert core.flatten_params(tree).size == he_flat.size == 32588
+    assert tparams[0] == () and tparams[2] == ()  # Box and Reverse carry no params
+    rebuilt = checkpoint.unflatten_like(tree, he_flat)
+    assert np.array_equal(core.flatten_params(rebuilt), he_flat)
+    assert oracle.he_model().n_params() == he_flat.size
+
+
+def test_serial_parsing():
+    mt = model_factory.get_masked_transform()
+    s = flows.Serial(flows.BoxTransformLayer(3.0), flows.IMADE(mt, 5, 16), flows.Reverse(), flows.IMADE(mt, 5, 16), flows.Reverse())
+    box, layers = flows.parse_serial(s.spec)
+    assert box.box_side == 3.0 and len(layers) == 2
+    d = flows._desc(2, layers, box=box)
+    assert (d.n_flow_layers, d.box_kind, d.i_degree, d.i_knots, d.i_right.n, d.i_right.value[0]) == (2, 1, 5, 16, 1, 1.0)
+    assert flows.parse_serial(flows.Serial(flows.Reverse(), flows.IMADE(mt, 5, 16)).spec) is None
+    with pytest.raises(NotImplementedError):
+        flows.IMADE(model_factory.get_masked_transform(allow_negative_params=True))
+
+
+def test_inversion_count():
+    from waveflow_amd.utils.coordinates import get_num_inversion_count
+    c = np.array([[1.0, 2.5, 2.0, -3.0], [0.0, -1.5, 2.0, -3.0], [0.0, 1.0, 2.0, 3.0]])
+    assert get_num_inversion_count(c).tolist() == [4, 4, 0]

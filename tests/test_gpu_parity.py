@@ -1,0 +1,281 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the reference's golden outputs."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import he_grid, sorted_walkers
+
+pytestmark = pytest.mark.gpu
+
+# fp32 log-prob tolerance from BASELINE.json north_star: 1e-5 relative.  log_pdf values are O(1..10);
+# the absolute floor covers |logp| < 1 (tanh / exp / log implementations differ between libm and ocml).
+RTOL, ATOL = 1e-5, 2e-5
+KERNELS = ["scalar", "mfma"]
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def close(a, b, rtol=RTOL, atol=ATOL):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    err = np.abs(a - b)
+    bad = err > atol + rtol * np.abs(b)
+    assert not bad.any(), f"{bad.sum()} of {bad.size} outside tolerance; max abs err {err.max():.3e}"
+
+
+def he_models(he_flat, kernel):
+    from waveflow_amd import checkpoint, model_factory
+    init_fun = model_factory.get_waveflow_model(2, base_spline_degree=6, i_spline_degree=6, n_prior_internal_knots=23,
+                                                n_i_internal_knots=23, i_spline_reg=0.05, i_spline_reverse_fun_tol=1e-6,
+                                                n_flow_layers=3, box_size=10, xu_coord_type="mean")
+    params, psi, log_pdf, sample = init_fun(0, 2)
+    params = checkpoint.unflatten_like(params, he_flat)
+    try:
+        log_pdf.model.set_kernel(kernel)
+    except Exception as e:  # kernel kind not built
+        pytest.skip(str(e))
+    return params, psi, log_pdf, oracle.he_model(10.0)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_he_checkpoint_vs_reference_golden_grid(golden, he_flat, kernel):
+    params, psi, log_pdf, om = he_models(he_flat, kernel)
+    g = golden["he_golden"]
+    coords, srt, sign = he_grid()
+    val = psi(params, srt.astype(np.float32)) * sign
+    err = np.abs(val - g["psi_grid"])
+    assert err.max() < 2.5e-5, err.max()
+    close(val, om.psi(he_flat, srt) * sign, rtol=2e-5, atol=2e-6)
+    for nm in ("onproton", "random"):
+        c = g[nm + "_coord"]
+        s = (-1.0) ** (c[:, 0] > c[:, 1])
+        assert np.abs(psi(params, np.sort(c, -1)) * s - g[nm + "_values"]).max() < 1e-5
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_he_logpdf_vs_oracle_samples_and_uniform_walkers(golden, he_flat, kernel):
+    params, psi, log_pdf, om = he_models(he_flat, kernel)
+    # C2: the 250 reference samples + 6 grid rows (batch 256)
+    sp = np.sort(golden["he_golden"]["sample_points"], -1)
+    x = np.concatenate([sp, he_grid()[1][[0, 99, 4950, 5050, 9900, 9999]]]).astype(np.float32)
+    assert x.shape == (256, 2)
+    lp, u = log_pdf(params, x, return_sample=True)
+    lpo, uo = om.log_pdf(he_flat, x, return_u=True)
+    close(lp, lpo)
+    close(u, uo, rtol=0, atol=2e-6)
+    # uniform sorted walkers (C3 inputs, small batch so the oracle finishes in seconds)
+    x = sorted_walkers(20000, 2, 10.0, 1234)
+    lp = log_pdf(params, x)
+    lpo = om.log_pdf(he_flat, x, threads=8)
+    close(lp, lpo)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_bin_indices_bit_exact_per_layer(he_flat, kernel):
+    """Injected identical fp32 inputs to one layer => identical (floor, ceil) table indices."""
+    params, psi, log_pdf, om = he_models(he_flat, kernel)
+    model = log_pdf.model
+    g = np.random.default_rng(7)
+    u = g.uniform(0, 1, size=(4096, 2)).astype(np.float32)
+    u[:6] = [[0.0, 1.0], [1.0, 0.0], [0.5, 0.5], [1.0 / 1999, 1998.0 / 1999], [1e-7, 1 - 1e-7], [0.25, 0.75]]
+    per_layer = om.layer_param_count()
+    for l in range(3):
+        y, ld, idx = model.layer(l, u, return_bin_idx=True)
+        yo, ldo, idxo = om.imade_direct(he_flat[l * per_layer:(l + 1) * per_layer], u)
+        assert np.array_equal(idx, idxo)
+        close(y, yo, rtol=0, atol=2e-6)
+        close(ld, ldo, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_end_to_end_bin_index_mismatch_rate(he_flat, kernel):
+    params, psi, log_pdf, om = he_models(he_flat, kernel)
+    x = sorted_walkers(8192, 2, 10.0, 5)
+    lp, u, idx = log_pdf.model.log_pdf(x, return_sample=True, return_bin_idx=True)
+    lpo, uo, idxo = om.log_pdf(he_flat, x, return_u=True, return_idx=True, threads=8)
+    # layer 0 sees bit-identical inputs (box transform is elementwise IEEE arithmetic)
+    assert np.array_equal(idx[:, 0], idxo[:, 0])
+    # deeper layers see inputs that differ in the last ulp (tanh/exp): an index may flip at a mesh boundary
+    rate = (idx != idxo).any(axis=(2, 3)).mean(axis=0)
+    assert rate.max() < 5e-3, rate
+    close(lp, lpo)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("B", [0, 1, 63, 64, 255, 257, 1000])
+def test_ragged_and_empty_batches(he_flat, kernel, B):
+    params, psi, log_pdf, om = he_models(he_flat, kernel)
+    x = sorted_walkers(max(B, 1), 2, 10.0, 11)[:B]
+    lp = log_pdf(params, x)
+    assert lp.shape == (B,)
+    if B:
+        close(lp, om.log_pdf(he_flat, x))
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_single_walker_promotion(he_flat, kernel):
+    """wavefunctions.py:35-36: a 1-D input is one walker."""
+    params, psi, log_pdf, om = he_models(he_flat, kernel)
+    x = np.array([-1.5, 2.0], np.float32)
+    assert log_pdf(params, x).shape == (1,)
+    close(psi(params, x), om.psi(he_flat, x[None]))
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_torch_device_tensors_and_streams(he_flat, kernel):
+    torch = _torch()
+    params, psi, log_pdf, om = he_models(he_flat, kernel)
+    xn = sorted_walkers(5000, 2, 10.0, 3)
+    x = torch.from_numpy(xn).cuda()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        lp = log_pdf(params, x)
+    s.synchronize()
+    assert lp.is_cuda and lp.dtype == torch.float32
+    close(lp.cpu().numpy(), om.log_pdf(he_flat, xn, threads=8))
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("D,box,layers,k,kn", [(2, "first", 2, 5, 16), (3, "mean", 2, 5, 16), (4, "mean", 1, 3, 9), (8, "mean", 3, 6, 23)])
+def test_waveflow_other_shapes_vs_oracle(kernel, D, box, layers, k, kn):
+    """C4 (8-electron chain) and smaller shapes: no reference system exists, parity is vs the oracle only."""
+    from waveflow_amd import model_factory, flatten_params
+    init_fun = model_factory.get_waveflow_model(D, base_spline_degree=k, i_spline_degree=k, n_prior_internal_knots=kn,
+                                                n_i_internal_knots=kn, i_spline_reg=0.05, n_flow_layers=layers, box_size=10.0,
+                                                xu_coord_type=box)
+    params, psi, log_pdf, _ = init_fun(42, D)
+    try:
+        log_pdf.model.set_kernel(kernel)
+    except Exception as e:
+        pytest.skip(str(e))
+    flat = flatten_params(params)
+    constr = tuple(range(0, D - 1)) if box == "mean" else tuple(range(1, D))
+    om = oracle.Model(D=D, n_layers=layers, box=box, box_L=10.0, i_k=k, i_knots=kn, i_reg=0.05, i_left={0: 0}, i_right={0: 1},
+                      prior="waveflow", p_k=k, p_knots=kn, p_left={0: 0}, p_right={0: 0}, constr_left=constr)
+    x = sorted_walkers(3000, D, 10.0, 1234)
+    close(log_pdf(params, x), om.log_pdf(flat, x, threads=8), rtol=2e-5, atol=5e-5)
+    ps, pso = psi(params, x), om.psi(flat, x, threads=8)
+    close(ps, pso, rtol=5e-5, atol=1e-6 * np.abs(pso).max())
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_mflow_and_flow_density_heads_vs_oracle(golden, kernel):
+    """C1 (double_circles): MFlow / IFlow / Flow log_pdf.  Parity unpinned in the reference (no saved params)."""
+    from waveflow_amd import flows, model_factory, flatten_params
+    import os
+    from conftest import GOLDEN
+    X = np.load(os.path.join(GOLDEN, "circles_x256.npy")).astype(np.float32)
+    mt = model_factory.get_masked_transform
+    # MFlow, "8-bin": k=5, 9 internal knots; prior M-spline k=3, 15 knots (benchmark_tests.py:65-71)
+    init = flows.MFlow(flows.Serial(*(flows.IMADE(mt(), spline_degree=5, n_internal_knots=9, spline_regularization=0.05,
+                                                  reverse_fun_tol=1e-6), flows.Reverse()) * 3),
+                       mt(), spline_degree=3, n_internal_knots=15)
+    params, log_pdf, _ = init(0, 2)
+    try:
+        log_pdf.model.set_kernel(kernel)
+    except Exception as e:
+        pytest.skip(str(e))
+    om = oracle.Model(D=2, n_layers=3, i_k=5, i_knots=9, i_reg=0.05, prior="mflow", p_k=3, p_knots=15)
+    close(log_pdf(params, X), om.log_pdf(flatten_params(params), X))
+    lp, u = log_pdf(params, X, return_sample=True)
+    close(u, om.log_pdf(flatten_params(params), X, return_u=True)[1], rtol=0, atol=2e-6)
+    # get_model defaults: no boundary constraints at all (model_factory.py:96-99)
+    init = model_factory.get_model(n_flow_layers=2, i_spline_reg=0.02)
+    params, log_pdf, _ = init(1, 2)
+    log_pdf.model.set_kernel(kernel)
+    om = oracle.Model(D=2, n_layers=2, i_k=5, i_knots=15, i_reg=0.02, i_left={}, i_right={}, prior="mflow", p_k=5, p_knots=15,
+                      p_left={}, p_right={})
+    close(log_pdf(params, X), om.log_pdf(flatten_params(params), X))
+    # IFlow: IMADE + Uniform prior with support clip (benchmark_tests.py:59-63)
+    init = flows.Flow(flows.Serial(*(flows.IMADE(mt(), spline_degree=5, n_internal_knots=15, spline_regularization=0.1,
+                                                 reverse_fun_tol=1e-6), flows.Reverse()) * 2), flows.Uniform(), prior_support=(0.0, 1.0))
+    params, log_pdf, _ = init(2, 2)
+    log_pdf.model.set_kernel(kernel)
+    om = oracle.Model(D=2, n_layers=2, i_k=5, i_knots=15, i_reg=0.1, prior="uniform")
+    close(log_pdf(params, X), om.log_pdf(flatten_params(params), X))
+    # Flow: affine MADE + Normal(-0.5) (benchmark_tests.py:53-57)
+    init = flows.Flow(flows.Serial(*(flows.MADE(mt(return_simple_masked_transform=True)), flows.Reverse()) * 3), flows.Normal(-0.5))
+    params, log_pdf, _ = init(3, 2)
+    log_pdf.model.set_kernel(kernel)
+    om = oracle.Model(D=2, n_layers=3, layer_kind="made", prior="normal", normal_offset=-0.5)
+    close(log_pdf(params, X), om.log_pdf(flatten_params(params), X))
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_general_boundary_constraint_dicts(kernel):
+    """tests/test_boundary_constraints.py:30-31 style dicts: {0:0, 2:0, 3:0} left, {0:0} right on the prior."""
+    from waveflow_amd import flows, model_factory, wavefunctions, flatten_params
+    mt = model_factory.get_masked_transform
+    left, right = {0: 0, 2: 0, 3: 0}, {0: 0, 1: 0}
+    init = wavefunctions.Waveflow(
+        flows.Serial(flows.BoxTransformLayer(2.0), flows.IMADE(mt(), 5, 16, 0.01, 1e-6, {0: 0.0, 1: 0.0}, {0: 1.0, 1: 0.0}), flows.Reverse()),
+        mt(allow_negative_params=True), 5, 16, constraints_dict_left=left, constraints_dict_right=right,
+        constrained_dimension_indices_left=[0], set_nn_output_grad_to_zero=False)
+    params, psi, log_pdf, _ = init(5, 2)
+    try:
+        log_pdf.model.set_kernel(kernel)
+    except Exception as e:
+        pytest.skip(str(e))
+    om = oracle.Model(D=2, n_layers=1, box="mean", box_L=2.0, i_k=5, i_knots=16, i_reg=0.01, i_left={0: 0.0, 1: 0.0},
+                      i_right={0: 1.0, 1: 0.0}, prior="waveflow", p_k=5, p_knots=16, p_left=left, p_right=right, constr_left=(0,))
+    x = sorted_walkers(2000, 2, 2.0, 9)
+    flat = flatten_params(params)
+    close(log_pdf(params, x), om.log_pdf(flat, x), rtol=2e-5, atol=5e-5)
+    pso = om.psi(flat, x)
+    close(psi(params, x), pso, rtol=5e-5, atol=1e-6 * np.abs(pso).max())
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_full_size_properties(he_flat, kernel):
+    """BASELINE size (2^20 walkers): properties that need no oracle at that size."""
+    torch = _torch()
+    params, psi, log_pdf, om = he_models(he_flat, kernel)
+    B = 1 << 20
+    xn = sorted_walkers(B, 2, 10.0, 1234)
+    x = torch.from_numpy(xn).cuda()
+    lp = log_pdf(params, x)
+    ps = psi(params, x)
+    assert torch.isfinite(lp).all() and torch.isfinite(ps).all()
+    # log_pdf == log(psi^2) up to the 1e-7 floors (wavefunctions.py:46-52 vs :61-71)
+    mask = ps.abs() > 1e-2
+    d = (torch.log(ps[mask].double() ** 2) - lp[mask].double()).abs().max().item()
+    assert d < 1e-3, d
+    # idempotence / batch-order independence: a permuted batch gives the permuted result, bit for bit
+    perm = torch.randperm(B, device="cuda", generator=torch.Generator(device="cuda").manual_seed(0))
+    lp2 = log_pdf(params, x[perm])
+    assert torch.equal(lp2, lp[perm])
+    # a strided sub-sample agrees with the oracle
+    sel = np.arange(0, B, 4099)
+    close(lp[torch.from_numpy(sel).cuda()].cpu().numpy(), om.log_pdf(he_flat, xn[sel]))
+    # Monte-Carlo normalisation: E_uniform[psi^2] * area(sorted simplex = (2L)^2/2) ~= 1
+    est = (ps.double() ** 2).mean().item() * (20.0 ** 2) / 2
+    assert abs(est - 1.0) < 0.02, est
+    # deterministic fp64 block sums (the <E_L> reduction site, vqmc.py:196)
+    sums = log_pdf.model.block_sums(lp).cpu().numpy()
+    ref = lp.double().cpu().numpy()
+    assert sums[2] == B
+    assert abs(sums[0] - ref.sum()) < 1e-6 * abs(ref.sum()) and abs(sums[1] - (ref ** 2).sum()) < 1e-6 * (ref ** 2).sum()
+    assert np.array_equal(sums, log_pdf.model.block_sums(lp).cpu().numpy())
+
+
+def test_abi_error_paths(he_flat):
+    import ctypes
+    from waveflow_amd import _lib
+    params, psi, log_pdf, om = he_models(he_flat, "scalar")
+    m = log_pdf.model
+    L = _lib.lib()
+    assert L.wf_logpdf_fwd(m._h, None, 10, None, None, None, None) == -1          # null buffers
+    assert L.wf_model_set_params(m._h, he_flat.ctypes.data, he_flat.size - 1, None) == -1   # wrong count
+    with pytest.raises(ValueError):
+        log_pdf(params, np.zeros((4, 3), np.float32))
+    # psi on a model without the Waveflow head
+    from waveflow_amd import model_factory
+    p2, lp2, _ = model_factory.get_model(n_flow_layers=1)(0, 2)
+    assert L.wf_psi_fwd(lp2.model._h, None, 0, None, None, None, None) == -1
+    # unsupported: more than 32 bases per dimension with the scalar kernel is reported, not silently wrong
+    d = _lib.ModelDesc()
+    d.n_dim, d.hidden, d.n_flow_layers, d.n_mesh, d.i_degree, d.i_knots, d.prior_kind = 2, 64, 1, 2000, 6, 80, _lib.PRIOR_UNIFORM
+    h = ctypes.c_void_p()
+    assert L.wf_model_create(ctypes.byref(d), 0, ctypes.byref(h)) == -2

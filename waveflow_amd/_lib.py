@@ -1,0 +1,112 @@
+"""ctypes binding of libwaveflow_hip.so (include/waveflow_hip.h).  No fallback: if the library
+is missing or a call fails, an exception is raised."""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libwaveflow_hip.so")
+
+WF_MAX_DIM, WF_MAX_BC = 16, 4
+SPLINE_M, SPLINE_I, SPLINE_B, SPLINE_OB = 0, 1, 2, 3
+LAYER_IMADE, LAYER_MADE = 0, 1
+BOX_NONE, BOX_MEAN, BOX_FIRST = 0, 1, 2
+PRIOR_WAVEFLOW, PRIOR_MFLOW, PRIOR_UNIFORM, PRIOR_NORMAL = 0, 1, 2, 3
+KERNEL_AUTO, KERNEL_SCALAR, KERNEL_MFMA = 0, 1, 2
+ERR_NO_DEVICE = -4
+
+
+class WfError(RuntimeError):
+    def __init__(self, status, what):
+        self.status = status
+        L = lib()
+        msg = L.wf_strerror(status).decode()
+        if status == -3:
+            msg += ": " + L.wf_last_hip_error_string().decode()
+        super().__init__(f"{what}: {msg} (status {status})")
+
+
+class BC(ctypes.Structure):
+    _fields_ = [("n", ctypes.c_int32), ("n_derivative", ctypes.c_int32 * WF_MAX_BC), ("value", ctypes.c_float * WF_MAX_BC)]
+
+    @classmethod
+    def from_dict(cls, d):
+        bc = cls()
+        d = {} if d is None else d
+        if len(d) > WF_MAX_BC:
+            raise ValueError("at most %d boundary constraints per side" % WF_MAX_BC)
+        bc.n = len(d)
+        for i, (nd, v) in enumerate(d.items()):
+            bc.n_derivative[i] = int(nd)
+            bc.value[i] = float(v)
+        return bc
+
+
+class ModelDesc(ctypes.Structure):
+    _fields_ = [("n_dim", ctypes.c_int32), ("hidden", ctypes.c_int32), ("n_flow_layers", ctypes.c_int32),
+                ("layer_kind", ctypes.c_int32), ("box_kind", ctypes.c_int32), ("box_size", ctypes.c_float),
+                ("i_degree", ctypes.c_int32), ("i_knots", ctypes.c_int32), ("i_reg", ctypes.c_float),
+                ("i_left", BC), ("i_right", BC), ("prior_kind", ctypes.c_int32), ("p_degree", ctypes.c_int32),
+                ("p_knots", ctypes.c_int32), ("p_left", BC), ("p_right", BC), ("normal_offset", ctypes.c_float),
+                ("n_constrained_left", ctypes.c_int32), ("constrained_left", ctypes.c_int32 * WF_MAX_DIM),
+                ("n_mesh", ctypes.c_int32)]
+
+
+EXPORTS = ["wf_abi_version", "wf_strerror", "wf_last_hip_error", "wf_last_hip_error_string", "wf_device_count",
+           "wf_tables_build", "wf_model_create", "wf_model_destroy", "wf_model_param_count", "wf_model_n_bases",
+           "wf_model_set_params", "wf_model_set_kernel", "wf_logpdf_fwd", "wf_psi_fwd", "wf_flow_fwd", "wf_layer_fwd",
+           "wf_block_sums", "wf_block_sums_workspace_bytes"]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not built; run `python -m waveflow_amd.build` (hipcc, gfx950). "
+                          "There is no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64, f32p = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p
+    L.wf_abi_version.restype = i32
+    L.wf_strerror.restype = ctypes.c_char_p
+    L.wf_strerror.argtypes = [i32]
+    L.wf_last_hip_error.restype = i32
+    L.wf_last_hip_error_string.restype = ctypes.c_char_p
+    L.wf_device_count.restype = i32
+    L.wf_tables_build.restype = i32
+    L.wf_tables_build.argtypes = [i32, i32, i32, i32, vp, vp, vp]
+    L.wf_model_create.restype = i32
+    L.wf_model_create.argtypes = [ctypes.POINTER(ModelDesc), i32, ctypes.POINTER(vp)]
+    L.wf_model_destroy.restype = None
+    L.wf_model_destroy.argtypes = [vp]
+    L.wf_model_param_count.restype = i64
+    L.wf_model_param_count.argtypes = [vp]
+    L.wf_model_n_bases.restype = i32
+    L.wf_model_n_bases.argtypes = [vp, i32]
+    L.wf_model_set_params.restype = i32
+    L.wf_model_set_params.argtypes = [vp, f32p, i64, vp]
+    L.wf_model_set_kernel.restype = i32
+    L.wf_model_set_kernel.argtypes = [vp, i32]
+    for name in ("wf_logpdf_fwd", "wf_psi_fwd"):
+        f = getattr(L, name)
+        f.restype = i32
+        f.argtypes = [vp, vp, i64, vp, vp, vp, vp]
+    L.wf_flow_fwd.restype = i32
+    L.wf_flow_fwd.argtypes = [vp, vp, i64, vp, vp, vp]
+    L.wf_layer_fwd.restype = i32
+    L.wf_layer_fwd.argtypes = [vp, i32, vp, i64, vp, vp, vp, vp]
+    L.wf_block_sums.restype = i32
+    L.wf_block_sums.argtypes = [vp, i64, vp, vp, i64, vp]
+    L.wf_block_sums_workspace_bytes.restype = i64
+    L.wf_block_sums_workspace_bytes.argtypes = [i64]
+    if L.wf_abi_version() != 1:
+        raise ImportError("libwaveflow_hip ABI version mismatch")
+    _lib = L
+    return L
+
+
+def check(status, what):
+    if status < 0:
+        raise WfError(status, what)
+    return status

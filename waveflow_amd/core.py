@@ -1,0 +1,185 @@
+"""Host-side handle on a wf_model (include/waveflow_hip.h) plus pytree helpers.
+
+PyTorch is used only as plumbing: device buffers, the current HIP stream, torch.distributed.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+
+def tree_leaves(tree, out=None):
+    """Leaves in JAX pytree order for nested tuples / lists (depth first, left to right)."""
+    if out is None:
+        out = []
+    if isinstance(tree, (tuple, list)):
+        for t in tree:
+            tree_leaves(t, out)
+    elif tree is not None:
+        out.append(tree)
+    return out
+
+
+def flatten_params(tree):
+    """-> contiguous float32 host vector in leaf order."""
+    leaves = tree_leaves(tree)
+    parts = []
+    for a in leaves:
+        if hasattr(a, "detach"):  # torch tensor
+            a = a.detach().to("cpu").numpy()
+        parts.append(np.asarray(a, dtype=np.float32).reshape(-1))
+    if not parts:
+        return np.zeros(0, np.float32)
+    return np.ascontiguousarray(np.concatenate(parts))
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class DeviceModel:
+    """Owns one wf_model on one GPU."""
+
+    def __init__(self, desc, device=None):
+        torch = _torch()
+        L = _lib.lib()
+        if not torch.cuda.is_available():
+            raise _lib.WfError(_lib.ERR_NO_DEVICE, "wf_model_create")
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device = int(device)
+        self.desc = desc
+        h = ctypes.c_void_p()
+        _lib.check(L.wf_model_create(ctypes.byref(desc), self.device, ctypes.byref(h)), "wf_model_create")
+        self._h = h
+        self.n_params = int(L.wf_model_param_count(h))
+        self.i_nb = int(L.wf_model_n_bases(h, 0))
+        self.p_nb = int(L.wf_model_n_bases(h, 1))
+        self._flat = None
+        self.D = int(desc.n_dim)
+        self.n_layers = int(desc.n_flow_layers)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                _lib.lib().wf_model_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    # ---- parameters
+    def set_params(self, flat):
+        flat = np.ascontiguousarray(flat, dtype=np.float32).reshape(-1)
+        if flat.size != self.n_params:
+            raise ValueError(f"expected {self.n_params} parameters, got {flat.size}")
+        _lib.check(_lib.lib().wf_model_set_params(self._h, flat.ctypes.data, flat.size, self._stream()), "wf_model_set_params")
+        self._flat = flat.copy()
+
+    def ensure_params(self, tree):
+        """Upload `tree` unless it equals what the device already holds."""
+        flat = flatten_params(tree)
+        if self._flat is None or flat.size != self._flat.size or not np.array_equal(flat, self._flat):
+            self.set_params(flat)
+
+    def set_kernel(self, kind):
+        kind = {"auto": _lib.KERNEL_AUTO, "scalar": _lib.KERNEL_SCALAR, "mfma": _lib.KERNEL_MFMA}.get(kind, kind)
+        _lib.check(_lib.lib().wf_model_set_kernel(self._h, int(kind)), "wf_model_set_kernel")
+
+    # ---- plumbing
+    def _stream(self):
+        torch = _torch()
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _to_dev(self, x):
+        """-> (float32 contiguous cuda tensor [B, D], converter for outputs)"""
+        torch = _torch()
+        was_numpy = not hasattr(x, "detach")
+        t = torch.as_tensor(np.asarray(x, dtype=np.float32)) if was_numpy else x
+        squeeze = t.dim() == 1  # wavefunctions.py:35-36 promotes a single walker to [1, D]
+        if squeeze:
+            t = t[None]
+        if t.dim() != 2 or t.shape[1] != self.D:
+            raise ValueError(f"expected inputs of shape [B, {self.D}], got {tuple(t.shape)}")
+        t = t.to(device=f"cuda:{self.device}", dtype=torch.float32).contiguous()
+        back = (lambda o: o.cpu().numpy()) if was_numpy else (lambda o: o)
+        return t, back
+
+    def _new(self, shape, dtype=None):
+        torch = _torch()
+        return torch.empty(shape, device=f"cuda:{self.device}", dtype=dtype or torch.float32)
+
+    @staticmethod
+    def _p(t):
+        return ctypes.c_void_p(t.data_ptr()) if t is not None and t.numel() > 0 else None
+
+    # ---- hot path
+    def _eval(self, fn, x, return_sample, return_bin_idx):
+        torch = _torch()
+        t, back = self._to_dev(x)
+        B = t.shape[0]
+        out = self._new((B,))
+        u = self._new((B, self.D)) if return_sample else None
+        idx = self._new((B, self.n_layers + 1, self.D, 2), torch.int32) if return_bin_idx else None
+        if idx is not None:
+            idx.zero_()
+        _lib.check(fn(self._h, self._p(t), B, self._p(out), self._p(u), self._p(idx), self._stream()), fn.__name__)
+        res = [back(out)]
+        if return_sample:
+            res.append(back(u))
+        if return_bin_idx:
+            res.append(back(idx))
+        return res[0] if len(res) == 1 else tuple(res)
+
+    def log_pdf(self, x, return_sample=False, return_bin_idx=False):
+        return self._eval(_lib.lib().wf_logpdf_fwd, x, return_sample, return_bin_idx)
+
+    def psi(self, x, return_sample=False, return_bin_idx=False):
+        return self._eval(_lib.lib().wf_psi_fwd, x, return_sample, return_bin_idx)
+
+    def flow(self, x):
+        t, back = self._to_dev(x)
+        B = t.shape[0]
+        u, ld = self._new((B, self.D)), self._new((B,))
+        _lib.check(_lib.lib().wf_flow_fwd(self._h, self._p(t), B, self._p(u), self._p(ld), self._stream()), "wf_flow_fwd")
+        return back(u), back(ld)
+
+    def layer(self, l, u_in, return_bin_idx=False):
+        torch = _torch()
+        t, back = self._to_dev(u_in)
+        B = t.shape[0]
+        y, ld = self._new((B, self.D)), self._new((B,))
+        idx = self._new((B, self.D, 2), torch.int32) if return_bin_idx else None
+        if idx is not None:
+            idx.zero_()
+        _lib.check(_lib.lib().wf_layer_fwd(self._h, int(l), self._p(t), B, self._p(y), self._p(ld), self._p(idx), self._stream()),
+                   "wf_layer_fwd")
+        if return_bin_idx:
+            return back(y), back(ld), back(idx)
+        return back(y), back(ld)
+
+    def block_sums(self, v):
+        """fp64 [sum v, sum v^2, count] on the device (deterministic order)."""
+        torch = _torch()
+        L = _lib.lib()
+        v = v.contiguous()
+        ws = torch.empty(int(L.wf_block_sums_workspace_bytes(v.numel())), device=v.device, dtype=torch.uint8)
+        out = torch.empty(3, device=v.device, dtype=torch.float64)
+        _lib.check(L.wf_block_sums(self._p(v), v.numel(), self._p(out), self._p(ws), ws.numel(), self._stream()), "wf_block_sums")
+        return out
+
+
+def build_tables(kind, degree, n_internal_knots, n_mesh=2000):
+    """Host-only: fp64 [4][n_bases][n_mesh] (+ (b_to_ob, ob_to_b) for kind == SPLINE_OB)."""
+    L = _lib.lib()
+    nb = _lib.check(L.wf_tables_build(kind, degree, n_internal_knots, n_mesh, None, None, None), "wf_tables_build")
+    out = np.zeros((4, nb, n_mesh))
+    if kind == _lib.SPLINE_OB:
+        b2o, o2b = np.zeros((nb, nb)), np.zeros((nb, nb))
+        _lib.check(L.wf_tables_build(kind, degree, n_internal_knots, n_mesh, out.ctypes.data, b2o.ctypes.data, o2b.ctypes.data),
+                   "wf_tables_build")
+        return out, b2o, o2b
+    _lib.check(L.wf_tables_build(kind, degree, n_internal_knots, n_mesh, out.ctypes.data, None, None), "wf_tables_build")
+    return out

@@ -1,0 +1,78 @@
+// wf_internal.h -- declarations shared by the translation units of libwaveflow_hip.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "../../include/waveflow_hip.h"
+
+namespace wf {
+
+// ---- wf_tables.cpp (host, fp64)
+std::vector<double> make_knots(int kind, int k, int n_internal);
+int n_bases_of(int kind, int k, int n_internal);
+int build_raw_table(int kind, int k, int n_internal, int n_mesh, double* out);
+int build_ortho_b(int k, int n_internal, int n_mesh, const double* Bt, double* ob, double* b_to_ob, double* ob_to_b);
+
+// ---- device-side model image (wf_model.cpp fills it, kernels read it)
+constexpr int kHidden = 64;      // MaskedDense width, model_factory.py:72
+constexpr int kMaxLayers = 16;   // flow layers
+constexpr int kMaxNets = kMaxLayers + 1;
+
+// One conditioner net (masked weights, reference layout; scalar kernel)
+struct NetPlain {
+    const float* W0;  // [D][64]   W0 * mask0
+    const float* b0;  // [64]
+    const float* W1t; // [64 out][64 in]  (W1 * mask1) transposed: row j = weights into hidden unit j
+    const float* b1;  // [64]
+    const float* W2t; // [D][NBP][64]  (W2 * mask2) transposed and regrouped: row (d, j) = weights of output column j*D+d
+    const float* b2;  // [D][NBP]
+};
+
+// One conditioner net in MFMA operand order (see wf_kernels_mfma.hip)
+struct NetMfma {
+    const float* image;  // LDS image of this net, `image_floats` floats
+    int image_floats;
+};
+
+struct SplineDev {
+    const float* tab;    // [2 or 4][n_mesh][NBP] fp32, mesh-major ("dense rows"); order nd, then mesh point, then basis
+    int nb;              // real number of bases
+    int nbp;             // padded row length (32 or 64)
+    int n_mesh;
+    int degree;
+    // boundary-condition constants: for constraint p, prev[p][j] = T[nd_p][j or nb-1-j][end], value[p]
+    int n_left, n_right;
+    int left_nd[WF_MAX_BC], right_nd[WF_MAX_BC];
+    float left_val[WF_MAX_BC], right_val[WF_MAX_BC];
+    float left_prev[WF_MAX_BC][WF_MAX_BC], right_prev[WF_MAX_BC][WF_MAX_BC];
+    float left_value[WF_MAX_BC], right_value[WF_MAX_BC];
+};
+
+struct ModelDev {
+    int D;
+    int n_layers;
+    int layer_kind;
+    int box_kind;
+    float box_L;
+    float i_reg;
+    int prior_kind;
+    float normal_offset;
+    unsigned constrained_mask;    // bit d set: d in constrained_dimension_indices_left
+    SplineDev isp;                // flow-layer I-spline (IMADE)
+    SplineDev psp;                // prior spline: orthogonal-B (WAVEFLOW) or M (MFLOW)
+    const float* ob_to_b;         // [nb][nbp] fp32 (WAVEFLOW): row a = ob_to_b[a][:]
+    NetPlain nets[kMaxNets];      // flow layers 0..n_layers-1, then the prior net
+    NetMfma mnets[kMaxNets];
+};
+
+// ---- kernel launchers (wf_kernels_*.hip).  mode: 0 = log_pdf, 1 = psi, 2 = flow only (u, logdet)
+int launch_scalar(const ModelDev& md, const ModelDev* md_dev, int mode, const float* x, int64_t B, float* out, float* u,
+                  int32_t* idx, void* stream);
+int launch_scalar_layer(const ModelDev& md, const ModelDev* md_dev, int layer, const float* u_in, int64_t B, float* y,
+                        float* logdet, int32_t* idx, void* stream);
+int launch_block_sums(const float* v, int64_t B, double* out, void* ws, int64_t ws_bytes, void* stream);
+int64_t block_sums_ws_bytes(int64_t B);
+
+void set_hip_error(int e);
+
+}  // namespace wf

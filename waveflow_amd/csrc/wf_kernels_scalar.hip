@@ -1,0 +1,489 @@
+// wf_kernels_scalar.hip -- "one lane = one walker" evaluation kernel (gfx950).
+//
+// This is the correctness-first kernel: it keeps the reference's operation order (sequential
+// fp32 sums, j-ascending spline sums, the exact floor/ceil index arithmetic) so that it can be
+// compared with the CPU oracle almost bit for bit.  Weights are wave-uniform, so hipcc turns
+// their loads into scalar (s_load) instructions and every FMA takes its weight from an SGPR;
+// the per-walker vectors that need runtime indexing live in thread-private LDS columns.
+// The throughput kernel is wf_kernels_mfma.hip; this one also serves configurations that one
+// does not cover.
+//
+// Reference functions restated (paths relative to /root/reference/waveflow):
+//   X_cached lerp ............ splines/isplines_jax.py:45-56, msplines_jax.py:30-41, bsplines_jax.py:19-30
+//   ispline / bspline sum .... isplines_jax.py:69-79, bsplines_jax.py:42-45
+//   remove_bias .............. isplines_jax.py:196-202, msplines_jax.py:186-192
+//   enforce_boundary_cond. ... isplines_jax.py:158-194, bsplines_jax.py:173-199, msplines_jax.py:156-184
+//   conditioner .............. model_factory.py:21-35, 56-70
+//   IMADE / MADE direct ...... flows/bijections/made.py:66-81, :21-27
+//   BoxTransformLayer ........ made.py:118-137, :156-183
+//   Reverse / Serial ......... flows/bijections/bijections.py:337-340, :452-457
+//   Waveflow log_pdf / psi ... wavefunctions.py:33-71;  MFlow / Flow log_pdf: flows/distributions.py:139-163, :95-102
+#include <hip/hip_runtime.h>
+
+#include "wf_internal.h"
+
+namespace wf {
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int NBP = 32;
+constexpr int H = kHidden;
+
+#define SCR(j) scr[(j) * kBlock + threadIdx.x]
+
+struct Lerp {
+    int il, ir;   // wrapped + clamped gather indices
+    int xl, xr;   // as computed (reported as "bin index")
+    float dx, n;
+};
+
+__device__ __forceinline__ int wrap_clamp(int i, int n) {
+    if (i < 0) i += n;  // jnp indexing: negative indices wrap once ...
+    return min(max(i, 0), n - 1);  // ... and out-of-bounds gathers clamp
+}
+
+__device__ __forceinline__ Lerp make_lerp(float x, int n_mesh) {
+    Lerp L;
+    const int n_points = n_mesh - 1;
+    const float xs = x * (float)n_points;
+    L.xl = (int)floorf(xs);
+    L.xr = (int)ceilf(xs);
+    L.il = wrap_clamp(L.xl, n_mesh);
+    L.ir = wrap_clamp(L.xr, n_mesh);
+    L.dx = x - (float)L.xl / (float)n_points;
+    L.n = (float)n_points;
+    return L;
+}
+
+// sum_j c_j * X_cached(x, j), j ascending; c_j = SCR(row0 + j); tab = one derivative order, [n_mesh][NBP]
+__device__ __forceinline__ float spline_dot(const float* __restrict__ tab, const Lerp& L, const float* scr, int row0, int nb) {
+    const float4* rl = reinterpret_cast<const float4*>(tab + (size_t)L.il * NBP);
+    const float4* rr = reinterpret_cast<const float4*>(tab + (size_t)L.ir * NBP);
+    float acc = 0.0f;
+#pragma unroll
+    for (int q = 0; q < NBP / 4; ++q) {
+        const float4 a = rl[q], b = rr[q];
+        const float yl[4] = {a.x, a.y, a.z, a.w}, yr[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = 4 * q + e;
+            if (j < nb) {
+                const float slope = (yr[e] - yl[e]) * L.n;
+                const float y = yl[e] + slope * L.dx;
+                acc = acc + SCR(row0 + j) * y;
+            }
+        }
+    }
+    return acc;
+}
+
+// kind: WF_SPLINE_I / _M / _B
+__device__ __forceinline__ void enforce_bc(const SplineDev& s, int kind, float* scr, int row0) {
+    const int nb = s.nb;
+    for (int p = 0; p < s.n_left; ++p) {
+        const int nd = s.left_nd[p];
+        float sum = 0.0f;
+        for (int j = 0; j < nd; ++j) sum = sum + s.left_prev[p][j] * SCR(row0 + j);
+        SCR(row0 + nd) = (s.left_val[p] - sum) / s.left_value[p];
+    }
+    for (int p = 0; p < s.n_right; ++p) {
+        const int nd = s.right_nd[p];
+        if (kind == WF_SPLINE_I && nd == 0) {
+            SCR(row0 + nb - 1) = 0.0f;
+            continue;
+        }
+        float sum = 0.0f;
+        for (int j = 0; j < nd; ++j) sum = sum + s.right_prev[p][j] * SCR(row0 + nb - 1 - j);
+        SCR(row0 + nb - nd - 1) = (s.right_val[p] - sum) / s.right_value[p];
+    }
+    float ss = 0.0f;
+    if (kind == WF_SPLINE_B) {
+        for (int j = 0; j < nb; ++j) ss = ss + SCR(row0 + j) * SCR(row0 + j);
+        ss = sqrtf(ss);
+    } else {
+        for (int j = 0; j < nb; ++j) ss = ss + SCR(row0 + j);
+    }
+    for (int j = 0; j < nb; ++j) SCR(row0 + j) = SCR(row0 + j) / ss;
+}
+
+__device__ __forceinline__ void remove_bias(int kind, int k, int nb, float* scr) {
+    for (int i = 0; i < k; ++i) {
+        const int a = kind == WF_SPLINE_I ? i + 1 : i;
+        const int b = kind == WF_SPLINE_I ? nb - (i + 2) : nb - (i + 1);
+        SCR(a) = SCR(a) * (float)(i + 1) / (float)k;
+        SCR(b) = SCR(b) * (float)(i + 1) / (float)k;
+    }
+    float ss = 0.0f;
+    for (int j = 0; j < nb; ++j) ss = ss + SCR(j);
+    for (int j = 0; j < nb; ++j) SCR(j) = SCR(j) / ss;
+}
+
+// two masked tanh layers; result h[64] in registers
+template <int D>
+__device__ __forceinline__ void hidden_layers(const NetPlain& net, const float (&x)[D], float* scr, float (&h)[H]) {
+    const float* __restrict__ W0 = net.W0;
+    const float* __restrict__ b0 = net.b0;
+    for (int j = 0; j < H; ++j) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int a = 0; a < D; ++a) acc = __builtin_fmaf(x[a], W0[a * H + j], acc);
+        SCR(j) = tanhf(acc + b0[j]);
+    }
+#pragma unroll
+    for (int a = 0; a < H; ++a) h[a] = SCR(a);
+    const float* __restrict__ W1t = net.W1t;
+    const float* __restrict__ b1 = net.b1;
+    for (int j = 0; j < H; ++j) {
+        const float* __restrict__ w = W1t + j * H;
+        float acc = 0.0f;
+#pragma unroll
+        for (int a = 0; a < H; ++a) acc = __builtin_fmaf(h[a], w[a], acc);
+        SCR(j) = tanhf(acc + b1[j]);
+    }
+#pragma unroll
+    for (int a = 0; a < H; ++a) h[a] = SCR(a);
+}
+
+__device__ __forceinline__ float out_unit(const NetPlain& net, const float (&h)[H], int d, int j) {
+    const float* __restrict__ w = net.W2t + ((size_t)d * NBP + j) * H;
+    float acc = 0.0f;
+#pragma unroll
+    for (int a = 0; a < H; ++a) acc = __builtin_fmaf(h[a], w[a], acc);
+    return acc + net.b2[d * NBP + j];
+}
+
+// calculate_bijection_params for dimension d into SCR(0..nb)
+__device__ __forceinline__ void bijection_params(const NetPlain& net, const float (&h)[H], int d, int nb, bool sigmoid, float* scr) {
+    float ss = 0.0f;
+    for (int j = 0; j < nb; ++j) {
+        float v = out_unit(net, h, d, j);
+        if (sigmoid) v = 1.0f / (1.0f + expf(-v));
+        SCR(j) = v;
+        ss = ss + v;
+    }
+    for (int j = 0; j < nb; ++j) SCR(j) = SCR(j) / ss;
+}
+
+template <int D>
+__device__ __forceinline__ float imade_direct(const ModelDev& md, const NetPlain& net, const float (&x)[D], float (&y)[D],
+                                              float* scr, int32_t* idx) {
+    float h[H];
+    hidden_layers<D>(net, x, scr, h);
+    const SplineDev& sp = md.isp;
+    const int nb = sp.nb;
+    const float* tab0 = sp.tab;
+    const float* tab1 = sp.tab + (size_t)sp.n_mesh * NBP;
+    float ld = 0.0f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        bijection_params(net, h, d, nb, true, scr);
+        for (int j = 0; j < nb; ++j) SCR(j) = SCR(j) + md.i_reg;
+        remove_bias(WF_SPLINE_I, sp.degree, nb, scr);
+        enforce_bc(sp, WF_SPLINE_I, scr, 0);
+        const Lerp L = make_lerp(x[d], sp.n_mesh);
+        if (idx) { idx[2 * d] = L.xl; idx[2 * d + 1] = L.xr; }
+        y[d] = spline_dot(tab0, L, scr, 0, nb);
+        const float dy = spline_dot(tab1, L, scr, 0, nb);
+        ld = ld + logf(dy + 1e-7f);
+    }
+    return ld;
+}
+
+template <int D>
+__device__ __forceinline__ float made_direct(const NetPlain& net, const float (&x)[D], float (&y)[D], float* scr) {
+    float h[H];
+    hidden_layers<D>(net, x, scr, h);
+    float ls = 0.0f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const float lw = out_unit(net, h, d, 0), bias = out_unit(net, h, d, 1);
+        y[d] = (x[d] - bias) * expf(-lw);
+        ls = ls + lw;
+    }
+    return -ls;
+}
+
+template <int D>
+__device__ __forceinline__ float box_direct(const ModelDev& md, const float (&x)[D], float (&u)[D]) {
+    const float L = md.box_L, tol = 1e-7f;
+    if (md.box_kind == WF_BOX_MEAN) {
+        float s = 0.0f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) s = s + x[d];
+        const float mean = s / (float)D;
+        const float l = mean - x[0];
+        const float w = x[D - 1] - x[0];
+        float space_left = 2 * L, ld = 0.0f;
+#pragma unroll
+        for (int i = 0; i < D - 1; ++i) {
+            const float diff = x[i + 1] - x[i];
+            u[i] = diff / (space_left + tol);
+            ld = ld - logf(space_left + tol);
+            space_left = space_left - diff;
+        }
+        u[D - 1] = (mean + L - l) / (2 * L - w + tol);
+        return ld - logf(2 * L - w + tol);
+    }
+    u[0] = (x[0] + L) / (2 * L);
+    float ls = 0.0f;
+#pragma unroll
+    for (int i = 1; i < D; ++i) u[i] = (x[i] - x[i - 1]) / (L - x[i - 1] + tol);
+#pragma unroll
+    for (int i = 0; i < D - 1; ++i) ls = ls + logf(L - x[i] + tol);
+    return -logf(2 * L) - ls;
+}
+
+__device__ __forceinline__ float clip01(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void k_eval(const ModelDev* __restrict__ mdp, int mode, const float* __restrict__ xg, int64_t B,
+                                                 float* __restrict__ out, float* __restrict__ u_out, int32_t* __restrict__ idx_out) {
+    __shared__ float scr[2 * NBP * kBlock];
+    const ModelDev& md = *mdp;
+    const int idx_stride = (md.n_layers + 1) * D * 2;
+    for (int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x; b < B; b += (int64_t)gridDim.x * kBlock) {
+        float cur[D], nxt[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) cur[d] = xg[b * D + d];
+        int32_t* idx = idx_out ? idx_out + b * idx_stride : nullptr;
+        float logdet = 0.0f;
+        if (md.box_kind != WF_BOX_NONE) {
+            logdet = logdet + box_direct<D>(md, cur, nxt);
+#pragma unroll
+            for (int d = 0; d < D; ++d) cur[d] = nxt[d];
+        }
+        for (int l = 0; l < md.n_layers; ++l) {
+            float ld;
+            if (md.layer_kind == WF_LAYER_IMADE) ld = imade_direct<D>(md, md.nets[l], cur, nxt, scr, idx ? idx + l * D * 2 : nullptr);
+            else ld = made_direct<D>(md.nets[l], cur, nxt, scr);
+            logdet = logdet + ld;
+#pragma unroll
+            for (int d = 0; d < D; ++d) cur[d] = nxt[D - 1 - d];  // Reverse
+        }
+        float result = logdet;
+        if (mode != 2) {
+            if (md.prior_kind == WF_PRIOR_WAVEFLOW) {
+                const NetPlain& net = md.nets[md.n_layers];
+                const SplineDev& sp = md.psp;
+                const int nb = sp.nb;
+                float h[H];
+                hidden_layers<D>(net, cur, scr, h);
+                float lp = 0.0f, prod = 1.0f;
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    bijection_params(net, h, d, nb, false, scr);
+                    enforce_bc(sp, WF_SPLINE_B, scr, 0);
+                    cur[d] = clip01(cur[d]);
+                    // BSpline_fun.apply_fun: c = w @ ob_to_b; c /= |c|  (bsplines_jax.py:134-135)
+                    float ss = 0.0f;
+                    for (int j = 0; j < nb; ++j) {
+                        float acc = 0.0f;
+                        for (int a = 0; a < nb; ++a) acc = acc + SCR(a) * md.ob_to_b[a * NBP + j];
+                        SCR(NBP + j) = acc;
+                        ss = ss + acc * acc;
+                    }
+                    const float nrm = sqrtf(ss);
+                    for (int j = 0; j < nb; ++j) SCR(NBP + j) = SCR(NBP + j) / nrm;
+                    const Lerp L = make_lerp(cur[d], sp.n_mesh);
+                    if (idx) { idx[(md.n_layers * D + d) * 2] = L.xl; idx[(md.n_layers * D + d) * 2 + 1] = L.xr; }
+                    float v = spline_dot(sp.tab, L, scr, NBP, nb);
+                    const bool constrained = (md.constrained_mask >> d) & 1u;
+                    if (mode == 0) {
+                        float pr = v * v;
+                        if (constrained) pr = pr / 2;
+                        lp = lp + logf(pr + 1e-7f);
+                    } else {
+                        if (constrained) v = v / sqrtf(2.0f);
+                        prod = prod * v;
+                    }
+                }
+                result = mode == 0 ? lp + logdet : prod * expf(0.5f * logdet);
+            } else if (md.prior_kind == WF_PRIOR_MFLOW) {
+                const NetPlain& net = md.nets[md.n_layers];
+                const SplineDev& sp = md.psp;
+                const int nb = sp.nb;
+                float h[H];
+                hidden_layers<D>(net, cur, scr, h);
+                float lp = 0.0f;
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    bijection_params(net, h, d, nb, true, scr);
+                    remove_bias(WF_SPLINE_M, sp.degree, nb, scr);
+                    enforce_bc(sp, WF_SPLINE_M, scr, 0);
+                    cur[d] = clip01(cur[d]);
+                    const Lerp L = make_lerp(cur[d], sp.n_mesh);
+                    if (idx) { idx[(md.n_layers * D + d) * 2] = L.xl; idx[(md.n_layers * D + d) * 2 + 1] = L.xr; }
+                    const float v = spline_dot(sp.tab, L, scr, 0, nb);
+                    lp = lp + logf(v + 1e-7f);
+                }
+                result = lp + logdet;
+            } else if (md.prior_kind == WF_PRIOR_UNIFORM) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) cur[d] = clip01(cur[d]);
+                result = 0.0f + logdet;
+            } else {
+                float lp = 0.0f;
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    const float z = cur[d] + md.normal_offset;
+                    lp = lp + (1.8378770664093453f + z * z) / -2.0f;
+                }
+                result = lp + logdet;
+            }
+        }
+        out[b] = result;
+        if (u_out) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) u_out[b * D + d] = cur[d];
+        }
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void k_layer(const ModelDev* __restrict__ mdp, int layer, const float* __restrict__ ug, int64_t B,
+                                                  float* __restrict__ yg, float* __restrict__ ldg, int32_t* __restrict__ idx_out) {
+    __shared__ float scr[2 * NBP * kBlock];
+    const ModelDev& md = *mdp;
+    for (int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x; b < B; b += (int64_t)gridDim.x * kBlock) {
+        float cur[D], nxt[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) cur[d] = ug[b * D + d];
+        float ld;
+        if (md.layer_kind == WF_LAYER_IMADE) ld = imade_direct<D>(md, md.nets[layer], cur, nxt, scr, idx_out ? idx_out + b * D * 2 : nullptr);
+        else ld = made_direct<D>(md.nets[layer], cur, nxt, scr);
+        ldg[b] = ld;
+#pragma unroll
+        for (int d = 0; d < D; ++d) yg[b * D + d] = nxt[d];
+    }
+}
+
+// deterministic fp64 block sums: stage 1 one partial pair per block, stage 2 one block
+constexpr int kSumBlock = 256;
+constexpr int kSumMaxBlocks = 1024;
+
+__device__ __forceinline__ void block_reduce2(double& a, double& b, double* sm) {
+    // fixed-order tree in LDS: result independent of scheduling
+    sm[threadIdx.x] = a;
+    sm[kSumBlock + threadIdx.x] = b;
+    __syncthreads();
+    for (int s = kSumBlock / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            sm[threadIdx.x] += sm[threadIdx.x + s];
+            sm[kSumBlock + threadIdx.x] += sm[kSumBlock + threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    a = sm[0];
+    b = sm[kSumBlock];
+}
+
+__global__ __launch_bounds__(kSumBlock) void k_sums_stage1(const float* __restrict__ v, int64_t B, double* __restrict__ partial) {
+    __shared__ double sm[2 * kSumBlock];
+    double s = 0.0, q = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kSumBlock + threadIdx.x; i < B; i += (int64_t)gridDim.x * kSumBlock) {
+        const double x = (double)v[i];
+        s += x;
+        q += x * x;
+    }
+    block_reduce2(s, q, sm);
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = s;
+        partial[2 * blockIdx.x + 1] = q;
+    }
+}
+
+__global__ __launch_bounds__(kSumBlock) void k_sums_stage2(const double* __restrict__ partial, int n_blocks, int64_t B, double* __restrict__ out) {
+    __shared__ double sm[2 * kSumBlock];
+    double s = 0.0, q = 0.0;
+    for (int i = threadIdx.x; i < n_blocks; i += kSumBlock) {
+        s += partial[2 * i];
+        q += partial[2 * i + 1];
+    }
+    block_reduce2(s, q, sm);
+    if (threadIdx.x == 0) {
+        out[0] = s;
+        out[1] = q;
+        out[2] = (double)B;
+    }
+}
+
+int sums_blocks(int64_t B) {
+    int64_t n = (B + kSumBlock - 1) / kSumBlock;
+    if (n < 1) n = 1;
+    if (n > kSumMaxBlocks) n = kSumMaxBlocks;
+    return (int)n;
+}
+
+int grid_for(int64_t B) {
+    int64_t n = (B + kBlock - 1) / kBlock;
+    const int64_t cap = 256 * 8;  // 256 CUs, grid-stride beyond that
+    if (n > cap) n = cap;
+    return (int)n;
+}
+
+template <int D>
+int launch_eval_d(const ModelDev* mdp, int mode, const float* x, int64_t B, float* out, float* u, int32_t* idx, hipStream_t s) {
+    hipLaunchKernelGGL(k_eval<D>, dim3(grid_for(B)), dim3(kBlock), 0, s, mdp, mode, x, B, out, u, idx);
+    return 0;
+}
+
+template <int D>
+int launch_layer_d(const ModelDev* mdp, int layer, const float* u_in, int64_t B, float* y, float* ld, int32_t* idx, hipStream_t s) {
+    hipLaunchKernelGGL(k_layer<D>, dim3(grid_for(B)), dim3(kBlock), 0, s, mdp, layer, u_in, B, y, ld, idx);
+    return 0;
+}
+
+int finish_launch() {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_hip_error((int)e);
+        return WF_ERR_HIP;
+    }
+    return WF_OK;
+}
+
+}  // namespace
+
+#define WF_DISPATCH_D(D_, CALL)                      \
+    switch (D_) {                                    \
+        case 2: CALL(2); break;                      \
+        case 3: CALL(3); break;                      \
+        case 4: CALL(4); break;                      \
+        case 5: CALL(5); break;                      \
+        case 6: CALL(6); break;                      \
+        case 7: CALL(7); break;                      \
+        case 8: CALL(8); break;                      \
+        default: return WF_ERR_UNSUPPORTED;          \
+    }
+
+int launch_scalar(const ModelDev& md, const ModelDev* md_dev, int mode, const float* x, int64_t B, float* out, float* u, int32_t* idx,
+                  void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+#define CALL(DD) launch_eval_d<DD>(md_dev, mode, x, B, out, u, idx, s)
+    WF_DISPATCH_D(md.D, CALL)
+#undef CALL
+    return finish_launch();
+}
+
+int launch_scalar_layer(const ModelDev& md, const ModelDev* md_dev, int layer, const float* u_in, int64_t B, float* y, float* logdet,
+                        int32_t* idx, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+#define CALL(DD) launch_layer_d<DD>(md_dev, layer, u_in, B, y, logdet, idx, s)
+    WF_DISPATCH_D(md.D, CALL)
+#undef CALL
+    return finish_launch();
+}
+
+int64_t block_sums_ws_bytes(int64_t) { return (int64_t)kSumMaxBlocks * 2 * sizeof(double); }
+
+int launch_block_sums(const float* v, int64_t B, double* out, void* ws, int64_t, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = sums_blocks(B);
+    double* partial = (double*)ws;
+    hipLaunchKernelGGL(k_sums_stage1, dim3(nb), dim3(kSumBlock), 0, s, v, B, partial);
+    hipLaunchKernelGGL(k_sums_stage2, dim3(1), dim3(kSumBlock), 0, s, (const double*)partial, nb, B, out);
+    return finish_launch();
+}
+
+}  // namespace wf

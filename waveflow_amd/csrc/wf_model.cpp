@@ -1,0 +1,488 @@
+// wf_model.cpp -- wf_model: host-side model build (tables, masks, device images) and the C ABI.
+//
+// Reference behaviour mirrored here (paths relative to /root/reference/waveflow):
+//   masks / MaskedDense / tiling ........ model_factory.py:8-35, 72-82
+//   parameter pytree order .............. wavefunctions.py:110, distributions.py:192, made.py:38,102
+//   table dtype ......................... jnp.array(np.load(...)) => fp32 (isplines_jax.py:131)
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "wf_internal.h"
+
+namespace wf {
+
+static thread_local int g_last_hip = 0;
+void set_hip_error(int e) { g_last_hip = e; }
+
+#define WF_HIP(call)                                   \
+    do {                                               \
+        hipError_t e_ = (call);                        \
+        if (e_ != hipSuccess) {                        \
+            wf::set_hip_error((int)e_);                \
+            return WF_ERR_HIP;                         \
+        }                                              \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+// get_masks, model_factory.py:8-19
+static inline int deg_in(int a) { return a; }
+static inline int deg_hidden(int a, int D) { return a % (D - 1); }
+static inline int deg_out(int d) { return d - 1; }
+
+struct NetLayout {
+    int n_out;       // bases per dimension (IMADE/prior) or 2 (MADE)
+    bool has_zero;   // trailing zero_params[D][n_out] leaf (model_factory.py:84-87)
+    int64_t offset;  // offset of W0 in the flat parameter vector
+    int64_t count;
+};
+
+}  // namespace wf
+
+struct wf_model {
+    wf_model_desc desc{};
+    int device = 0;
+    int kernel_kind = WF_KERNEL_AUTO;
+    int i_nb = 0, p_nb = 0;
+    int nbp = 32;
+    std::vector<wf::NetLayout> nets;  // flow layers then (optionally) the prior net
+    int64_t n_params = 0;
+    bool params_set = false;
+    wf::ModelDev dev{};
+    std::vector<void*> allocs;
+    // device images
+    float* d_plain = nullptr;  // all NetPlain arrays, one allocation
+    int64_t plain_floats = 0;
+    std::vector<int64_t> plain_off;  // per net: offset of W0 in d_plain
+    float* d_mfma = nullptr;
+    int64_t mfma_floats = 0;
+    wf::ModelDev* d_dev = nullptr;  // device copy of `dev`
+    bool mfma_ok = false;           // the MFMA kernel covers this configuration
+};
+
+namespace wf {
+
+static int64_t plain_net_floats(int D, int nbp) {
+    return (int64_t)D * kHidden + kHidden + (int64_t)kHidden * kHidden + kHidden + (int64_t)D * nbp * kHidden + (int64_t)D * nbp;
+}
+
+static int check_bc(const wf_bc& bc, int nb) {
+    if (bc.n < 0 || bc.n > WF_MAX_BC) return WF_ERR_INVALID;
+    for (int i = 0; i < bc.n; ++i)
+        if (bc.n_derivative[i] < 0 || bc.n_derivative[i] > 3 || bc.n_derivative[i] >= nb) return WF_ERR_INVALID;
+    return WF_OK;
+}
+
+// Dense-row device table: [n_orders][n_mesh][nbp], fp32 cast of the fp64 table.
+static void pack_rows(const std::vector<double>& t64, int nb, int n_mesh, int n_orders, int nbp, std::vector<float>& out) {
+    out.assign((size_t)n_orders * n_mesh * nbp, 0.0f);
+    for (int nd = 0; nd < n_orders; ++nd)
+        for (int i = 0; i < nb; ++i)
+            for (int m = 0; m < n_mesh; ++m)
+                out[((size_t)nd * n_mesh + m) * nbp + i] = (float)t64[((size_t)nd * nb + i) * n_mesh + m];
+}
+
+// Boundary-condition constants (enforce_boundary_conditions: isplines_jax.py:158-194,
+// bsplines_jax.py:173-199, msplines_jax.py:156-184): X_cached(0.0, j, nd) == T[nd][j][0] and
+// X_cached(1.0, j, nd) == T[nd][j][n_mesh-1] in fp32.
+static void fill_bc(SplineDev& s, const wf_bc& left, const wf_bc& right, const std::vector<double>& t64, int nb, int n_mesh) {
+    auto T = [&](int nd, int j, int m) { return (float)t64[((size_t)nd * nb + j) * n_mesh + m]; };
+    s.n_left = left.n;
+    s.n_right = right.n;
+    for (int p = 0; p < left.n; ++p) {
+        const int nd = left.n_derivative[p];
+        s.left_nd[p] = nd;
+        s.left_val[p] = left.value[p];
+        for (int j = 0; j < nd; ++j) s.left_prev[p][j] = T(nd, j, 0);
+        s.left_value[p] = T(nd, nd, 0);
+    }
+    for (int p = 0; p < right.n; ++p) {
+        const int nd = right.n_derivative[p];
+        s.right_nd[p] = nd;
+        s.right_val[p] = right.value[p];
+        for (int j = 0; j < nd; ++j) s.right_prev[p][j] = T(nd, nb - j - 1, n_mesh - 1);
+        s.right_value[p] = T(nd, nb - nd - 1, n_mesh - 1);
+    }
+}
+
+template <class T>
+static int dev_alloc(wf_model* m, T** p, size_t count) {
+    void* q = nullptr;
+    WF_HIP(hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)));
+    m->allocs.push_back(q);
+    *p = (T*)q;
+    return WF_OK;
+}
+
+static int upload_table(wf_model* m, const std::vector<float>& h, const float** out) {
+    float* d = nullptr;
+    int rc = dev_alloc(m, &d, h.size());
+    if (rc) return rc;
+    WF_HIP(hipMemcpy(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    *out = d;
+    return WF_OK;
+}
+
+static int model_build(wf_model* m) {
+    const wf_model_desc& d = m->desc;
+    const int D = d.n_dim;
+    if (D < 2 || D > WF_MAX_DIM) return WF_ERR_INVALID;
+    if (d.hidden != kHidden) return WF_ERR_UNSUPPORTED;
+    if (d.n_flow_layers < 0 || d.n_flow_layers > kMaxLayers) return WF_ERR_INVALID;
+    if (d.layer_kind != WF_LAYER_IMADE && d.layer_kind != WF_LAYER_MADE) return WF_ERR_INVALID;
+    if (d.box_kind < WF_BOX_NONE || d.box_kind > WF_BOX_FIRST) return WF_ERR_INVALID;
+    if (d.prior_kind < WF_PRIOR_WAVEFLOW || d.prior_kind > WF_PRIOR_NORMAL) return WF_ERR_INVALID;
+    if (d.n_mesh < 2) return WF_ERR_INVALID;
+    if (d.n_constrained_left < 0 || d.n_constrained_left > WF_MAX_DIM) return WF_ERR_INVALID;
+
+    ModelDev& md = m->dev;
+    md = ModelDev{};
+    md.D = D;
+    md.n_layers = d.n_flow_layers;
+    md.layer_kind = d.layer_kind;
+    md.box_kind = d.box_kind;
+    md.box_L = d.box_size;
+    md.i_reg = d.i_reg;
+    md.prior_kind = d.prior_kind;
+    md.normal_offset = d.normal_offset;
+    for (int i = 0; i < d.n_constrained_left; ++i) {
+        if (d.constrained_left[i] < 0 || d.constrained_left[i] >= D) return WF_ERR_INVALID;
+        md.constrained_mask |= 1u << d.constrained_left[i];
+    }
+
+    m->nbp = 32;
+    // ---- tables
+    if (d.layer_kind == WF_LAYER_IMADE && d.n_flow_layers > 0) {
+        const int nb = n_bases_of(WF_SPLINE_I, d.i_degree, d.i_knots);
+        if (d.i_degree < 1 || d.i_knots < 2 || nb < 2) return WF_ERR_INVALID;
+        if (nb > m->nbp) return WF_ERR_UNSUPPORTED;
+        int rc = check_bc(d.i_left, nb);
+        if (rc) return rc;
+        rc = check_bc(d.i_right, nb);
+        if (rc) return rc;
+        // right constraint {0: v}: the reference supports v == 1 only (isplines_jax.py:174-179)
+        for (int p = 0; p < d.i_right.n; ++p)
+            if (d.i_right.n_derivative[p] == 0 && d.i_right.value[p] != 1.0f) return WF_ERR_INVALID;
+        std::vector<double> t64((size_t)4 * nb * d.n_mesh);
+        rc = build_raw_table(WF_SPLINE_I, d.i_degree, d.i_knots, d.n_mesh, t64.data());
+        if (rc < 0) return rc;
+        std::vector<float> rows;
+        pack_rows(t64, nb, d.n_mesh, 2, m->nbp, rows);
+        rc = upload_table(m, rows, &md.isp.tab);
+        if (rc) return rc;
+        md.isp.nb = nb; md.isp.nbp = m->nbp; md.isp.n_mesh = d.n_mesh; md.isp.degree = d.i_degree;
+        fill_bc(md.isp, d.i_left, d.i_right, t64, nb, d.n_mesh);
+        m->i_nb = nb;
+    }
+    if (d.prior_kind == WF_PRIOR_WAVEFLOW) {
+        const int nb = n_bases_of(WF_SPLINE_B, d.p_degree, d.p_knots);
+        if (d.p_degree < 1 || d.p_knots < 2 || nb < 2) return WF_ERR_INVALID;
+        if (nb > m->nbp) return WF_ERR_UNSUPPORTED;
+        int rc = check_bc(d.p_left, nb);
+        if (rc) return rc;
+        rc = check_bc(d.p_right, nb);
+        if (rc) return rc;
+        std::vector<double> b64((size_t)4 * nb * d.n_mesh), ob64((size_t)4 * nb * d.n_mesh), o2b((size_t)nb * nb);
+        rc = build_raw_table(WF_SPLINE_B, d.p_degree, d.p_knots, d.n_mesh, b64.data());
+        if (rc < 0) return rc;
+        rc = build_ortho_b(d.p_degree, d.p_knots, d.n_mesh, b64.data(), ob64.data(), nullptr, o2b.data());
+        if (rc < 0) return rc;
+        std::vector<float> rows;
+        pack_rows(ob64, nb, d.n_mesh, 1, m->nbp, rows);
+        rc = upload_table(m, rows, &md.psp.tab);
+        if (rc) return rc;
+        md.psp.nb = nb; md.psp.nbp = m->nbp; md.psp.n_mesh = d.n_mesh; md.psp.degree = d.p_degree;
+        fill_bc(md.psp, d.p_left, d.p_right, b64, nb, d.n_mesh);  // BCs use the plain-B table, bsplines_jax.py:176-189
+        std::vector<float> o2b32((size_t)nb * m->nbp, 0.0f);
+        for (int a = 0; a < nb; ++a)
+            for (int j = 0; j < nb; ++j) o2b32[(size_t)a * m->nbp + j] = (float)o2b[(size_t)a * nb + j];
+        rc = upload_table(m, o2b32, &md.ob_to_b);
+        if (rc) return rc;
+        m->p_nb = nb;
+    } else if (d.prior_kind == WF_PRIOR_MFLOW) {
+        const int nb = n_bases_of(WF_SPLINE_M, d.p_degree, d.p_knots);
+        if (d.p_degree < 2 || d.p_knots < 2 || nb < 2) return WF_ERR_INVALID;
+        if (nb > m->nbp) return WF_ERR_UNSUPPORTED;
+        int rc = check_bc(d.p_left, nb);
+        if (rc) return rc;
+        rc = check_bc(d.p_right, nb);
+        if (rc) return rc;
+        std::vector<double> t64((size_t)4 * nb * d.n_mesh);
+        rc = build_raw_table(WF_SPLINE_M, d.p_degree, d.p_knots, d.n_mesh, t64.data());
+        if (rc < 0) return rc;
+        std::vector<float> rows;
+        pack_rows(t64, nb, d.n_mesh, 1, m->nbp, rows);
+        rc = upload_table(m, rows, &md.psp.tab);
+        if (rc) return rc;
+        md.psp.nb = nb; md.psp.nbp = m->nbp; md.psp.n_mesh = d.n_mesh; md.psp.degree = d.p_degree;
+        fill_bc(md.psp, d.p_left, d.p_right, t64, nb, d.n_mesh);
+        m->p_nb = nb;
+    }
+
+    // ---- parameter layout (pytree leaf order)
+    m->nets.clear();
+    int64_t off = 0;
+    auto add_net = [&](int n_out, bool has_zero) {
+        NetLayout nl;
+        nl.n_out = n_out;
+        nl.has_zero = has_zero;
+        nl.offset = off;
+        nl.count = (int64_t)D * kHidden + kHidden + (int64_t)kHidden * kHidden + kHidden + (int64_t)kHidden * n_out * D +
+                   (int64_t)n_out * D + (has_zero ? (int64_t)D * n_out : 0);
+        off += nl.count;
+        m->nets.push_back(nl);
+    };
+    for (int l = 0; l < d.n_flow_layers; ++l) {
+        if (d.layer_kind == WF_LAYER_IMADE) add_net(m->i_nb, true);
+        else add_net(2, false);
+    }
+    if (d.prior_kind == WF_PRIOR_WAVEFLOW || d.prior_kind == WF_PRIOR_MFLOW) add_net(m->p_nb, true);
+    m->n_params = off;
+
+    // ---- device weight images
+    const int n_nets = (int)m->nets.size();
+    m->plain_floats = plain_net_floats(D, m->nbp) * n_nets;
+    int rc = dev_alloc(m, &m->d_plain, (size_t)m->plain_floats);
+    if (rc) return rc;
+    m->plain_off.assign(n_nets, 0);
+    for (int n = 0; n < n_nets; ++n) {
+        const int64_t base = plain_net_floats(D, m->nbp) * n;
+        m->plain_off[n] = base;
+        float* p = m->d_plain + base;
+        NetPlain& np = md.nets[n];
+        np.W0 = p; p += (int64_t)D * kHidden;
+        np.b0 = p; p += kHidden;
+        np.W1t = p; p += (int64_t)kHidden * kHidden;
+        np.b1 = p; p += kHidden;
+        np.W2t = p; p += (int64_t)D * m->nbp * kHidden;
+        np.b2 = p;
+    }
+    rc = dev_alloc(m, &m->d_dev, 1);
+    if (rc) return rc;
+    WF_HIP(hipMemcpy(m->d_dev, &md, sizeof(ModelDev), hipMemcpyHostToDevice));
+    return WF_OK;
+}
+
+// Re-derives the masked, transposed weight image of net n from the flat parameter vector.
+static void build_plain_image(const wf_model* m, int n, const float* flat, float* img) {
+    const int D = m->desc.n_dim, H = kHidden, nbp = m->nbp;
+    const NetLayout& nl = m->nets[n];
+    const int NO = nl.n_out * D;
+    const float* W0 = flat + nl.offset;
+    const float* b0 = W0 + (int64_t)D * H;
+    const float* W1 = b0 + H;
+    const float* b1 = W1 + (int64_t)H * H;
+    const float* W2 = b1 + H;
+    const float* b2 = W2 + (int64_t)H * NO;
+    float* o = img;
+    // W0 * mask0: [D][H]
+    for (int a = 0; a < D; ++a)
+        for (int j = 0; j < H; ++j) *o++ = deg_hidden(j, D) >= deg_in(a) ? W0[(int64_t)a * H + j] : 0.0f;
+    for (int j = 0; j < H; ++j) *o++ = b0[j];
+    // (W1 * mask1)^T: [j out][a in]
+    for (int j = 0; j < H; ++j)
+        for (int a = 0; a < H; ++a) *o++ = deg_hidden(j, D) >= deg_hidden(a, D) ? W1[(int64_t)a * H + j] : 0.0f;
+    for (int j = 0; j < H; ++j) *o++ = b1[j];
+    // (W2 * tile(mask2))^T regrouped: [d][jb][a], reference output column c = jb*D + d (model_factory.py:59-60,81)
+    for (int dd = 0; dd < D; ++dd)
+        for (int jb = 0; jb < nbp; ++jb)
+            for (int a = 0; a < H; ++a) {
+                float v = 0.0f;
+                if (jb < nl.n_out && deg_out(dd) >= deg_hidden(a, D)) v = W2[(int64_t)a * NO + (jb * D + dd)];
+                *o++ = v;
+            }
+    for (int dd = 0; dd < D; ++dd)
+        for (int jb = 0; jb < nbp; ++jb) *o++ = jb < nl.n_out ? b2[jb * D + dd] : 0.0f;
+}
+
+}  // namespace wf
+
+// ------------------------------------------------------------------------------------------ C ABI
+using namespace wf;
+
+extern "C" {
+
+int wf_abi_version(void) { return WF_ABI_VERSION; }
+
+const char* wf_strerror(int status) {
+    switch (status) {
+        case WF_OK: return "ok";
+        case WF_ERR_INVALID: return "invalid argument";
+        case WF_ERR_UNSUPPORTED: return "configuration not supported by this build";
+        case WF_ERR_HIP: return "HIP runtime error (see wf_last_hip_error_string)";
+        case WF_ERR_NO_DEVICE: return "no gfx950 device available (there is no CPU fallback)";
+        case WF_ERR_NOMEM: return "out of memory";
+        case WF_ERR_NUMERIC: return "numerical failure while building tables";
+        default: return "unknown status";
+    }
+}
+
+int wf_last_hip_error(void) { return g_last_hip; }
+const char* wf_last_hip_error_string(void) { return hipGetErrorString((hipError_t)g_last_hip); }
+
+int wf_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int good = 0;
+    for (int i = 0; i < n; ++i) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, i) == hipSuccess && std::string(p.gcnArchName).rfind("gfx950", 0) == 0) ++good;
+    }
+    return good;
+}
+
+int wf_tables_build(int kind, int degree, int n_internal_knots, int n_mesh, double* out, double* b_to_ob, double* ob_to_b) {
+    if (kind < WF_SPLINE_M || kind > WF_SPLINE_OB) return WF_ERR_INVALID;
+    if (degree < 1 || n_internal_knots < 2 || n_mesh < 2) return WF_ERR_INVALID;
+    const int nb = n_bases_of(kind, degree, n_internal_knots);
+    if (!out) return nb;
+    if (kind != WF_SPLINE_OB) return build_raw_table(kind, degree, n_internal_knots, n_mesh, out);
+    std::vector<double> b64;
+    try {
+        b64.resize((size_t)4 * nb * n_mesh);
+    } catch (const std::bad_alloc&) {
+        return WF_ERR_NOMEM;
+    }
+    int rc = build_raw_table(WF_SPLINE_B, degree, n_internal_knots, n_mesh, b64.data());
+    if (rc < 0) return rc;
+    return build_ortho_b(degree, n_internal_knots, n_mesh, b64.data(), out, b_to_ob, ob_to_b);
+}
+
+int wf_model_create(const wf_model_desc* desc, int device, wf_model** out) {
+    if (!desc || !out) return WF_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return WF_ERR_NO_DEVICE;
+    if (device < 0 || device >= n) return WF_ERR_INVALID;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return WF_ERR_NO_DEVICE;
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) return WF_ERR_NO_DEVICE;
+    DeviceGuard g(device);
+    if (!g.ok) return WF_ERR_NO_DEVICE;
+    wf_model* m = new (std::nothrow) wf_model();
+    if (!m) return WF_ERR_NOMEM;
+    m->desc = *desc;
+    m->device = device;
+    int rc;
+    try {
+        rc = model_build(m);
+    } catch (const std::bad_alloc&) {
+        rc = WF_ERR_NOMEM;
+    }
+    if (rc != WF_OK) {
+        wf_model_destroy(m);
+        return rc;
+    }
+    *out = m;
+    return WF_OK;
+}
+
+void wf_model_destroy(wf_model* m) {
+    if (!m) return;
+    DeviceGuard g(m->device);
+    for (void* p : m->allocs) (void)hipFree(p);
+    delete m;
+}
+
+int64_t wf_model_param_count(const wf_model* m) { return m ? m->n_params : WF_ERR_INVALID; }
+
+int wf_model_n_bases(const wf_model* m, int which) {
+    if (!m) return WF_ERR_INVALID;
+    return which == 0 ? m->i_nb : m->p_nb;
+}
+
+int wf_model_set_kernel(wf_model* m, int kernel_kind) {
+    if (!m || kernel_kind < WF_KERNEL_AUTO || kernel_kind > WF_KERNEL_MFMA) return WF_ERR_INVALID;
+    if (kernel_kind == WF_KERNEL_MFMA && !m->mfma_ok) return WF_ERR_UNSUPPORTED;
+    m->kernel_kind = kernel_kind;
+    return WF_OK;
+}
+
+int wf_model_set_params(wf_model* m, const float* flat_host, int64_t n, void* stream) {
+    if (!m || !flat_host) return WF_ERR_INVALID;
+    if (n != m->n_params) return WF_ERR_INVALID;
+    DeviceGuard g(m->device);
+    std::vector<float> img;
+    try {
+        img.resize((size_t)m->plain_floats);
+    } catch (const std::bad_alloc&) {
+        return WF_ERR_NOMEM;
+    }
+    for (size_t i = 0; i < m->nets.size(); ++i) build_plain_image(m, (int)i, flat_host, img.data() + m->plain_off[i]);
+    hipStream_t s = (hipStream_t)stream;
+    if (!img.empty()) WF_HIP(hipMemcpyAsync(m->d_plain, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice, s));
+    WF_HIP(hipStreamSynchronize(s));
+    m->params_set = true;
+    return WF_OK;
+}
+
+static int check_fwd(const wf_model* m, const void* x, int64_t B, const void* out) {
+    if (!m || B < 0) return WF_ERR_INVALID;
+    if (B > 0 && (!x || !out)) return WF_ERR_INVALID;
+    if (!m->params_set && m->n_params > 0) return WF_ERR_INVALID;
+    return WF_OK;
+}
+
+static int dispatch(const wf_model* m, int mode, const float* x, int64_t B, float* out, float* u, int32_t* idx, void* stream) {
+    DeviceGuard g(m->device);
+    if (B == 0) return WF_OK;
+    return launch_scalar(m->dev, m->d_dev, mode, x, B, out, u, idx, stream);
+}
+
+int wf_logpdf_fwd(const wf_model* m, const float* x_dev, int64_t B, float* logp_dev, float* u_dev, int32_t* bin_idx_dev,
+                  void* stream) {
+    int rc = check_fwd(m, x_dev, B, logp_dev);
+    if (rc) return rc;
+    return dispatch(m, 0, x_dev, B, logp_dev, u_dev, bin_idx_dev, stream);
+}
+
+int wf_psi_fwd(const wf_model* m, const float* x_dev, int64_t B, float* psi_dev, float* u_dev, int32_t* bin_idx_dev,
+               void* stream) {
+    int rc = check_fwd(m, x_dev, B, psi_dev);
+    if (rc) return rc;
+    if (m->desc.prior_kind != WF_PRIOR_WAVEFLOW) return WF_ERR_INVALID;
+    return dispatch(m, 1, x_dev, B, psi_dev, u_dev, bin_idx_dev, stream);
+}
+
+int wf_flow_fwd(const wf_model* m, const float* x_dev, int64_t B, float* u_dev, float* logdet_dev, void* stream) {
+    int rc = check_fwd(m, x_dev, B, logdet_dev);
+    if (rc) return rc;
+    if (B > 0 && !u_dev) return WF_ERR_INVALID;
+    return dispatch(m, 2, x_dev, B, logdet_dev, u_dev, nullptr, stream);
+}
+
+int wf_layer_fwd(const wf_model* m, int layer, const float* u_in_dev, int64_t B, float* y_dev, float* logdet_dev,
+                 int32_t* bin_idx_dev, void* stream) {
+    int rc = check_fwd(m, u_in_dev, B, y_dev);
+    if (rc) return rc;
+    if (layer < 0 || layer >= m->desc.n_flow_layers || (B > 0 && !logdet_dev)) return WF_ERR_INVALID;
+    DeviceGuard g(m->device);
+    if (B == 0) return WF_OK;
+    return launch_scalar_layer(m->dev, m->d_dev, layer, u_in_dev, B, y_dev, logdet_dev, bin_idx_dev, stream);
+}
+
+int64_t wf_block_sums_workspace_bytes(int64_t B) { return block_sums_ws_bytes(B); }
+
+int wf_block_sums(const float* v_dev, int64_t B, double* out_dev, void* workspace_dev, int64_t workspace_bytes, void* stream) {
+    if (B < 0 || !out_dev || (B > 0 && !v_dev)) return WF_ERR_INVALID;
+    if (workspace_bytes < block_sums_ws_bytes(B) || !workspace_dev) return WF_ERR_INVALID;
+    return launch_block_sums(v_dev, B, out_dev, workspace_dev, workspace_bytes, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,48 @@
+"""waveflow.wavefunctions call surface on the HIP path (reference: wavefunctions.py:9-112)."""
+import numpy as np
+
+from . import _lib
+from .flows import _InitFun, _not_yet, as_generator
+
+
+class Waveflow(_InitFun):
+    """init_fun(rng, input_dim) -> (params, psi, log_pdf, sample)   (wavefunctions.py:110)"""
+
+    def __init__(self, transformation, sp_transformation, spline_degree, n_internal_knots, constraints_dict_left={0: 0, 2: 0},
+                 constraints_dict_right={0: 0}, constrained_dimension_indices_left=(), constrained_dimension_indices_right=(),
+                 set_nn_output_grad_to_zero=True, n_spline_base_mesh_points=2000):
+        if set_nn_output_grad_to_zero:
+            raise NotImplementedError("set_nn_output_grad_to_zero=True (model_factory.py:64-67) is not built on the HIP path; "
+                                      "get_waveflow_model passes False (model_factory.py:143)")
+        if sp_transformation.simple or not sp_transformation.allow_negative_params:
+            raise NotImplementedError("Waveflow needs get_masked_transform(allow_negative_params=True) for the prior head")
+        if len(np.asarray(constrained_dimension_indices_right).reshape(-1)):
+            raise NotImplementedError("constrained_dimension_indices_right is unused by the reference (wavefunctions.py:48,67)")
+        self.transformation, self.sp = transformation, sp_transformation
+        self.k, self.n = spline_degree, n_internal_knots
+        self.left, self.right = dict(constraints_dict_left), dict(constraints_dict_right)
+        self.constrained_left = [int(c) for c in np.asarray(constrained_dimension_indices_left).reshape(-1)]
+        self.n_mesh = n_spline_base_mesh_points
+
+    def __call__(self, rng, input_dim):
+        g = as_generator(rng)
+        tparams = self.transformation.init_params(g, input_dim)
+        nb = self.n + self.k - 1  # bsplines_jax.py:58-65: n_knots - k - 1 with (k+1)-fold end knots
+        sparams = self.sp.init_params(g, input_dim, nb)
+        model = self.transformation.fused_model(input_dim, prior=_lib.PRIOR_WAVEFLOW, p_degree=self.k, p_knots=self.n,
+                                                p_left=self.left, p_right=self.right,
+                                                constrained_left=self.constrained_left, n_mesh=self.n_mesh)
+        if model is None:
+            raise NotImplementedError("Waveflow: the bijector stack must be [Box] + (IMADE, Reverse)*n")
+        assert model.p_nb == nb
+
+        def log_pdf(params, inputs, return_sample=False):
+            model.ensure_params(params)
+            return model.log_pdf(inputs, return_sample=return_sample)
+
+        def psi(params, inputs, log_tol=1e-7):
+            model.ensure_params(params)
+            return model.psi(inputs)
+
+        log_pdf.model = psi.model = model
+        return (tparams, sparams), psi, log_pdf, _not_yet("Waveflow.sample")
