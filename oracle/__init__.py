@@ -23,6 +23,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libwf_oracle.so")
+_LIB64_PATH = os.path.join(_HERE, "libwf_oracle64.so")
 
 KIND_M, KIND_I, KIND_B = 0, 1, 2
 MAX_D, MAX_BC = 16, 4
@@ -30,8 +31,9 @@ MAX_D, MAX_BC = 16, 4
 
 def build(force=False):
     src = os.path.join(_HERE, "wf_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libwf_oracle.so"])
+    for lp in (_LIB_PATH, _LIB64_PATH):
+        if force or not os.path.exists(lp) or os.path.getmtime(lp) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", _HERE, "-s", "-B", os.path.basename(lp)])
     return _LIB_PATH
 
 
@@ -54,8 +56,9 @@ class _Model(ctypes.Structure):
 
 
 @functools.lru_cache(None)
-def lib():
-    L = ctypes.CDLL(build())
+def lib(f64=False):
+    build()
+    L = ctypes.CDLL(_LIB64_PATH if f64 else _LIB_PATH)
     L.wfo_table.restype = ctypes.c_int
     L.wfo_table.argtypes = [ctypes.c_int] * 5 + [ctypes.c_void_p]
     L.wfo_knots.restype = ctypes.c_int
@@ -252,7 +255,7 @@ class Model:
         return np.concatenate(out)
 
     # ---- evaluation
-    def _eval(self, params, x, mode, return_u, return_idx, threads):
+    def _eval(self, params, x, mode, return_u, return_idx, threads, f64=False):
         params = np.ascontiguousarray(params, dtype=np.float32)
         assert params.size == self.n_params(), (params.size, self.n_params())
         x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1, self.D)
@@ -260,7 +263,7 @@ class Model:
         out = np.zeros(B, np.float32)
         u = np.zeros((B, self.D), np.float32) if return_u else None
         idx = np.zeros((B, self.n_layers + 1, self.D, 2), np.int32) if return_idx else None
-        rc = lib().wfo_eval(ctypes.byref(self.c), params.ctypes.data, x.ctypes.data, B, mode, out.ctypes.data,
+        rc = lib(f64).wfo_eval(ctypes.byref(self.c), params.ctypes.data, x.ctypes.data, B, mode, out.ctypes.data,
                             u.ctypes.data if return_u else None, idx.ctypes.data if return_idx else None, threads)
         if rc:
             raise RuntimeError(f"wfo_eval rc={rc}")
@@ -271,20 +274,21 @@ class Model:
             res.append(idx)
         return res[0] if len(res) == 1 else tuple(res)
 
-    def log_pdf(self, params, x, return_u=False, return_idx=False, threads=1):
-        return self._eval(params, x, 0, return_u, return_idx, threads)
+    def log_pdf(self, params, x, return_u=False, return_idx=False, threads=1, f64=False):
+        """f64=True: same algorithm, tables and parameters, fp64 arithmetic (result rounded to fp32)."""
+        return self._eval(params, x, 0, return_u, return_idx, threads, f64)
 
-    def psi(self, params, x, return_u=False, return_idx=False, threads=1):
-        return self._eval(params, x, 1, return_u, return_idx, threads)
+    def psi(self, params, x, return_u=False, return_idx=False, threads=1, f64=False):
+        return self._eval(params, x, 1, return_u, return_idx, threads, f64)
 
-    def imade_direct(self, layer_params, u):
+    def imade_direct(self, layer_params, u, f64=False):
         layer_params = np.ascontiguousarray(layer_params, dtype=np.float32)
         u = np.ascontiguousarray(u, dtype=np.float32).reshape(-1, self.D)
         B = u.shape[0]
         y = np.zeros_like(u)
         ld = np.zeros(B, np.float32)
         idx = np.zeros((B, self.D, 2), np.int32)
-        lib().wfo_imade_direct(ctypes.byref(self.c), layer_params.ctypes.data, u.ctypes.data, B, y.ctypes.data,
+        lib(f64).wfo_imade_direct(ctypes.byref(self.c), layer_params.ctypes.data, u.ctypes.data, B, y.ctypes.data,
                                ld.ctypes.data, idx.ctypes.data)
         return y, ld, idx
 

@@ -177,7 +177,27 @@ int wfo_knots(int kind, int k, int n_internal, double* t) {
 }
 
 /* ------------------------------------------------------------------ */
-/* Part 2: evaluation (fp32)                                           */
+/* Part 2: evaluation (fp32; -DWFO_F64 builds the same code in fp64 = "exact arithmetic" yardstick) */
+#ifdef WFO_F64
+typedef double real;
+#define R_FLOOR floor
+#define R_CEIL ceil
+#define R_TANH tanh
+#define R_EXP exp
+#define R_LOG log
+#define R_SQRT sqrt
+#else
+typedef float real;
+#define R_FLOOR floorf
+#define R_CEIL ceilf
+#define R_TANH tanhf
+#define R_EXP expf
+#define R_LOG logf
+#define R_SQRT sqrtf
+#endif
+/* constants keep their fp32 VALUES in both builds (JAX weak-typed Python scalars become fp32) */
+#define C(x) ((real)(x##f))
+
 /* ------------------------------------------------------------------ */
 
 #define WFO_MAX_D 16
@@ -227,72 +247,72 @@ static inline int wrap_clamp(int i, int n) {
     return i;
 }
 
-static inline float x_cached(const wfo_spline* s, int nd, int i, float x, int* idx) {
+static inline real x_cached(const wfo_spline* s, int nd, int i, real x, int* idx) {
     int n_points = s->n_mesh - 1;
-    float xs = x * (float)n_points;
-    int x_l = (int)floorf(xs);
-    int x_r = (int)ceilf(xs);
+    real xs = x * (real)n_points;
+    int x_l = (int)R_FLOOR(xs);
+    int x_r = (int)R_CEIL(xs);
     if (idx) { idx[0] = x_l; idx[1] = x_r; }
     const float* row = s->tab + ((size_t)nd * s->nb + i) * s->n_mesh;
-    float y_l = row[wrap_clamp(x_l, s->n_mesh)];
-    float y_r = row[wrap_clamp(x_r, s->n_mesh)];
-    float dx = x - (float)x_l / (float)n_points;
-    float slope = (y_r - y_l) * (float)n_points;
+    real y_l = row[wrap_clamp(x_l, s->n_mesh)];
+    real y_r = row[wrap_clamp(x_r, s->n_mesh)];
+    real dx = x - (real)x_l / (real)n_points;
+    real slope = (y_r - y_l) * (real)n_points;
     return y_l + slope * dx;
 }
 
 /* ispline/mspline/bspline with zero_border=False: sum(c[i] * X_cached(x, i)), isplines_jax.py:78 */
-static float spline_apply(const wfo_spline* s, int nd, const float* c, float x, int* idx) {
-    float acc = 0.0f;
+static real spline_apply(const wfo_spline* s, int nd, const real* c, real x, int* idx) {
+    real acc = C(0.0);
     for (int i = 0; i < s->nb; ++i) acc = acc + c[i] * x_cached(s, nd, i, x, i == 0 ? idx : 0);
     return acc;
 }
 
-static float tab_at(const float* tab, const wfo_spline* s, int nd, int i, int m) {
+static real tab_at(const float* tab, const wfo_spline* s, int nd, int i, int m) {
     return tab[((size_t)nd * s->nb + i) * s->n_mesh + m];
 }
 
 /* enforce_boundary_conditions: isplines_jax.py:158-194 (kind 1), bsplines_jax.py:173-199 (kind 2),
  * msplines_jax.py:156-184 (kind 0).  tab = the table the reference evaluates at 0.0 / 1.0
  * (plain-B table for kind 2).  X_cached(0.0, j) == T[j][0], X_cached(1.0, j) == T[j][n_mesh-1]. */
-static void enforce_bc(const wfo_spline* s, const float* tab, int kind, float* w) {
+static void enforce_bc(const wfo_spline* s, const float* tab, int kind, real* w) {
     int nb = s->nb, last = s->n_mesh - 1;
     for (int p = 0; p < s->left.n; ++p) {
         int nd = s->left.nd[p];
-        float sum = 0.0f;
+        real sum = C(0.0);
         for (int j = 0; j < nd; ++j) sum = sum + tab_at(tab, s, nd, j, 0) * w[j];
-        float value = tab_at(tab, s, nd, nd, 0);
+        real value = tab_at(tab, s, nd, nd, 0);
         w[nd] = (s->left.val[p] - sum) / value;
     }
     for (int p = 0; p < s->right.n; ++p) {
         int nd = s->right.nd[p];
-        if (kind == 1 && nd == 0) { w[nb - nd - 1] = 0.0f; continue; }   /* isplines_jax.py:174-176 */
-        float sum = 0.0f;
+        if (kind == 1 && nd == 0) { w[nb - nd - 1] = C(0.0); continue; }   /* isplines_jax.py:174-176 */
+        real sum = C(0.0);
         for (int j = 0; j < nd; ++j) sum = sum + tab_at(tab, s, nd, nb - j - 1, last) * w[nb - 1 - j];
-        float value = tab_at(tab, s, nd, nb - nd - 1, last);
+        real value = tab_at(tab, s, nd, nb - nd - 1, last);
         w[nb - nd - 1] = (s->right.val[p] - sum) / value;
     }
     if (kind == 2) {
-        float ss = 0.0f;
+        real ss = C(0.0);
         for (int j = 0; j < nb; ++j) ss = ss + w[j] * w[j];
-        float nrm = sqrtf(ss);
+        real nrm = R_SQRT(ss);
         for (int j = 0; j < nb; ++j) w[j] = w[j] / nrm;
     } else {
-        float ss = 0.0f;
+        real ss = C(0.0);
         for (int j = 0; j < nb; ++j) ss = ss + w[j];
         for (int j = 0; j < nb; ++j) w[j] = w[j] / ss;
     }
 }
 
 /* remove_bias: isplines_jax.py:196-202 (kind 1), msplines_jax.py:186-192 (kind 0) */
-static void remove_bias(int kind, int k, int nb, float* p) {
+static void remove_bias(int kind, int k, int nb, real* p) {
     for (int i = 0; i < k; ++i) {
         int a = kind == 1 ? i + 1 : i;
         int b = kind == 1 ? nb - (i + 2) : nb - (i + 1);
-        p[a] = p[a] * (float)(i + 1) / (float)k;
-        p[b] = p[b] * (float)(i + 1) / (float)k;
+        p[a] = p[a] * (real)(i + 1) / (real)k;
+        p[b] = p[b] * (real)(i + 1) / (real)k;
     }
-    float ss = 0.0f;
+    real ss = C(0.0);
     for (int j = 0; j < nb; ++j) ss = ss + p[j];
     for (int j = 0; j < nb; ++j) p[j] = p[j] / ss;
 }
@@ -304,31 +324,31 @@ static inline int deg_out(int a) { return a - 1; }
 
 /* MaskedDense stack, model_factory.py:21-35,72-82: returns raw net output o[n_out*D] (column c = j*D + d).
  * params: W0[D][H], b0[H], W1[H][H], b1[H], W2[H][n_out*D], b2[n_out*D]. */
-static const float* conditioner(const float* p, int D, int H, int n_out, const float* x, float* o) {
+static const float* conditioner(const float* p, int D, int H, int n_out, const real* x, real* o) {
     const float *W0 = p, *b0 = W0 + D * H, *W1 = b0 + H, *b1 = W1 + H * H, *W2 = b1 + H, *b2 = W2 + (size_t)H * n_out * D;
-    float h1[WFO_MAX_H], h2[WFO_MAX_H];
+    real h1[WFO_MAX_H], h2[WFO_MAX_H];
     for (int j = 0; j < H; ++j) {
-        float acc = 0.0f;
+        real acc = C(0.0);
         for (int a = 0; a < D; ++a) {
-            float m = deg_hid(j, D) >= deg_in(a) ? 1.0f : 0.0f;
+            real m = deg_hid(j, D) >= deg_in(a) ? C(1.0) : C(0.0);
             acc = acc + x[a] * (W0[a * H + j] * m);
         }
-        h1[j] = tanhf(acc + b0[j]);
+        h1[j] = R_TANH(acc + b0[j]);
     }
     for (int j = 0; j < H; ++j) {
-        float acc = 0.0f;
+        real acc = C(0.0);
         for (int a = 0; a < H; ++a) {
-            float m = deg_hid(j, D) >= deg_hid(a, D) ? 1.0f : 0.0f;
+            real m = deg_hid(j, D) >= deg_hid(a, D) ? C(1.0) : C(0.0);
             acc = acc + h1[a] * (W1[a * H + j] * m);
         }
-        h2[j] = tanhf(acc + b1[j]);
+        h2[j] = R_TANH(acc + b1[j]);
     }
     int NO = n_out * D;
     for (int c = 0; c < NO; ++c) {
         int d = c % D;                                   /* jnp.tile(masks[-1], output_shape) */
-        float acc = 0.0f;
+        real acc = C(0.0);
         for (int a = 0; a < H; ++a) {
-            float m = deg_out(d) >= deg_hid(a, D) ? 1.0f : 0.0f;
+            real m = deg_out(d) >= deg_hid(a, D) ? C(1.0) : C(0.0);
             acc = acc + h2[a] * (W2[(size_t)a * NO + c] * m);
         }
         o[c] = acc + b2[c];
@@ -338,15 +358,15 @@ static const float* conditioner(const float* p, int D, int H, int n_out, const f
 
 /* calculate_bijection_params, model_factory.py:56-70 (set_nn_output_grad_to_zero=False):
  * bij[d][j] = o[j*D + d]; optional sigmoid; bij /= bij.sum(-1).  Returns pointer past (net, zero_params). */
-static const float* bijection_params(const float* p, int D, int H, int nb, int allow_negative, const float* x,
-                                     float* bij /* [D][nb] */) {
-    float o[WFO_MAX_D * WFO_MAX_NB];
+static const float* bijection_params(const float* p, int D, int H, int nb, int allow_negative, const real* x,
+                                     real* bij /* [D][nb] */) {
+    real o[WFO_MAX_D * WFO_MAX_NB];
     const float* next = conditioner(p, D, H, nb, x, o);
     for (int d = 0; d < D; ++d) {
-        float ss = 0.0f;
+        real ss = C(0.0);
         for (int j = 0; j < nb; ++j) {
-            float v = o[j * D + d];
-            if (!allow_negative) v = 1.0f / (1.0f + expf(-v));     /* jax.nn.sigmoid */
+            real v = o[j * D + d];
+            if (!allow_negative) v = C(1.0) / (C(1.0) + R_EXP(-v));     /* jax.nn.sigmoid */
             bij[d * nb + j] = v;
             ss = ss + v;
         }
@@ -356,33 +376,33 @@ static const float* bijection_params(const float* p, int D, int H, int nb, int a
 }
 
 /* IMADE.direct_fun, made.py:66-81.  idx (optional): [D][2] bin indices of this layer. */
-static const float* imade_direct(const wfo_model* m, const float* p, const float* x, float* y, float* logdet, int* idx) {
+static const float* imade_direct(const wfo_model* m, const float* p, const real* x, real* y, real* logdet, int* idx) {
     int D = m->D, nb = m->isp.nb;
-    float bij[WFO_MAX_D * WFO_MAX_NB];
+    real bij[WFO_MAX_D * WFO_MAX_NB];
     const float* next = bijection_params(p, D, m->hidden, nb, 0, x, bij);
-    float ld = 0.0f;
+    real ld = C(0.0);
     for (int d = 0; d < D; ++d) {
-        float* w = bij + d * nb;
+        real* w = bij + d * nb;
         for (int j = 0; j < nb; ++j) w[j] = w[j] + m->i_reg;
         remove_bias(1, m->isp.k, nb, w);
         enforce_bc(&m->isp, m->isp.tab, 1, w);
         y[d] = spline_apply(&m->isp, 0, w, x[d], idx ? idx + 2 * d : 0);
-        float dy = spline_apply(&m->isp, 1, w, x[d], 0);  /* grad via defjvp -> table nd+1, isplines_jax.py:60-66 */
-        ld = ld + logf(dy + 1e-7f);
+        real dy = spline_apply(&m->isp, 1, w, x[d], 0);  /* grad via defjvp -> table nd+1, isplines_jax.py:60-66 */
+        ld = ld + R_LOG(dy + C(1e-7));
     }
     *logdet = ld;
     return next;
 }
 
 /* MADE.direct_fun, made.py:21-27 with simple_masked_transform (model_factory.py:37-51, output_shape=2) */
-static const float* made_direct(const wfo_model* m, const float* p, const float* x, float* y, float* logdet) {
+static const float* made_direct(const wfo_model* m, const float* p, const real* x, real* y, real* logdet) {
     int D = m->D;
-    float o[2 * WFO_MAX_D];
+    real o[2 * WFO_MAX_D];
     const float* next = conditioner(p, D, m->hidden, 2, x, o);
-    float ls = 0.0f;
+    real ls = C(0.0);
     for (int d = 0; d < D; ++d) {
-        float lw = o[d], bias = o[D + d];              /* jnp.split(..., 2, axis=1) */
-        y[d] = (x[d] - bias) * expf(-lw);
+        real lw = o[d], bias = o[D + d];              /* jnp.split(..., 2, axis=1) */
+        y[d] = (x[d] - bias) * R_EXP(-lw);
         ls = ls + lw;
     }
     *logdet = -ls;
@@ -390,43 +410,43 @@ static const float* made_direct(const wfo_model* m, const float* p, const float*
 }
 
 /* BoxTransformLayer, made.py:118-137 ('first') and :156-183 ('mean') */
-static void box_direct(const wfo_model* m, const float* x, float* u, float* logdet) {
+static void box_direct(const wfo_model* m, const real* x, real* u, real* logdet) {
     int D = m->D;
-    float L = m->box_L, tol = 1e-7f;
+    real L = m->box_L, tol = C(1e-7);
     if (m->box_kind == 1) {
-        float s = 0.0f;
+        real s = C(0.0);
         for (int d = 0; d < D; ++d) s = s + x[d];
-        float mean = s / (float)D;
-        float l = mean - x[0];
-        float w = x[D - 1] - x[0];
-        float space_left = 2 * L;
-        float ld = 0.0f;
+        real mean = s / (real)D;
+        real l = mean - x[0];
+        real w = x[D - 1] - x[0];
+        real space_left = 2 * L;
+        real ld = C(0.0);
         for (int i = 0; i < D - 1; ++i) {
-            float diff = x[i + 1] - x[i];
+            real diff = x[i + 1] - x[i];
             u[i] = diff / (space_left + tol);
-            ld = ld - logf(space_left + tol);
+            ld = ld - R_LOG(space_left + tol);
             space_left = space_left - diff;
         }
         u[D - 1] = (mean + L - l) / (2 * L - w + tol);
-        ld = ld - logf(2 * L - w + tol);
+        ld = ld - R_LOG(2 * L - w + tol);
         *logdet = ld;
     } else {
         u[0] = (x[0] + L) / (2 * L);
-        float ls = 0.0f;
+        real ls = C(0.0);
         for (int i = 1; i < D; ++i) u[i] = (x[i] - x[i - 1]) / (L - x[i - 1] + tol);
-        for (int i = 0; i < D - 1; ++i) ls = ls + logf(L - x[i] + tol);
-        *logdet = -logf(2 * L) - ls;
+        for (int i = 0; i < D - 1; ++i) ls = ls + R_LOG(L - x[i] + tol);
+        *logdet = -R_LOG(2 * L) - ls;
     }
 }
 
 /* Serial.feed_forward (bijections.py:452-457) over [Box], (layer, Reverse) * n_layers.
  * Returns pointer to the prior net's params.  idx: [n_layers][D][2] or NULL. */
-static const float* flow_direct(const wfo_model* m, const float* params, const float* x, float* u, float* logdet, int* idx) {
+static const float* flow_direct(const wfo_model* m, const float* params, const real* x, real* u, real* logdet, int* idx) {
     int D = m->D;
-    float cur[WFO_MAX_D], nxt[WFO_MAX_D];
-    float ld_total = 0.0f, ld;
+    real cur[WFO_MAX_D], nxt[WFO_MAX_D];
+    real ld_total = C(0.0), ld;
     if (m->box_kind) { box_direct(m, x, cur, &ld); ld_total = ld_total + ld; }
-    else memcpy(cur, x, sizeof(float) * D);
+    else memcpy(cur, x, sizeof(real) * D);
     const float* p = params;
     for (int l = 0; l < m->n_layers; ++l) {
         if (m->layer_kind == 0) p = imade_direct(m, p, cur, nxt, &ld, idx ? idx + (size_t)l * D * 2 : 0);
@@ -434,85 +454,87 @@ static const float* flow_direct(const wfo_model* m, const float* params, const f
         ld_total = ld_total + ld;
         for (int d = 0; d < D; ++d) cur[d] = nxt[D - 1 - d];      /* Reverse, bijections.py:337-340 */
     }
-    memcpy(u, cur, sizeof(float) * D);
+    memcpy(u, cur, sizeof(real) * D);
     *logdet = ld_total;
     return p;
 }
 
-static inline float clip01(float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); }
+static inline real clip01(real v) { return v < C(0.0) ? C(0.0) : (v > C(1.0) ? C(1.0) : v); }
 
 /* One walker: mode 0 = log_pdf, 1 = psi (Waveflow only). */
-static float eval_one(const wfo_model* m, const float* params, const float* x, int mode, float* u_out, int* idx) {
+static real eval_one(const wfo_model* m, const float* params, const float* xin, int mode, float* u_out, int* idx) {
     int D = m->D;
-    float u[WFO_MAX_D], logdet;
+    real u[WFO_MAX_D], logdet;
+    real x[WFO_MAX_D];
+    for (int d = 0; d < D; ++d) x[d] = (real)xin[d];
     const float* pp = flow_direct(m, params, x, u, &logdet, idx);
-    float result;
+    real result;
     if (m->prior_kind == 0) {
         /* wavefunctions.py:33-71 */
         int nb = m->psp.nb;
-        float bij[WFO_MAX_D * WFO_MAX_NB];
+        real bij[WFO_MAX_D * WFO_MAX_NB];
         bijection_params(pp, D, m->hidden, nb, 1, u, bij);
-        float lp = 0.0f, prod = 1.0f;
+        real lp = C(0.0), prod = C(1.0);
         int* pidx = idx ? idx + (size_t)m->n_layers * D * 2 : 0;
         for (int d = 0; d < D; ++d) {
-            float* w = bij + d * nb;
+            real* w = bij + d * nb;
             enforce_bc(&m->psp, m->psp_plain, 2, w);
             u[d] = clip01(u[d]);
             /* BSpline_fun.apply_fun, bsplines_jax.py:127-137 */
-            float c[WFO_MAX_NB];
-            float ss = 0.0f;
+            real c[WFO_MAX_NB];
+            real ss = C(0.0);
             for (int j = 0; j < nb; ++j) {
-                float acc = 0.0f;
+                real acc = C(0.0);
                 for (int a = 0; a < nb; ++a) acc = acc + w[a] * m->ob_to_b[a * nb + j];
                 c[j] = acc;
                 ss = ss + acc * acc;
             }
-            float nrm = sqrtf(ss);
+            real nrm = R_SQRT(ss);
             for (int j = 0; j < nb; ++j) c[j] = c[j] / nrm;
-            float v = spline_apply(&m->psp, 0, c, u[d], pidx ? pidx + 2 * d : 0);
+            real v = spline_apply(&m->psp, 0, c, u[d], pidx ? pidx + 2 * d : 0);
             int constrained = 0;
             for (int q = 0; q < m->n_constr_left; ++q) if (m->constr_left[q] == d) constrained = 1;
             if (mode == 0) {
-                float pr = v * v;
+                real pr = v * v;
                 if (constrained) pr = pr / 2;
-                lp = lp + logf(pr + 1e-7f);
+                lp = lp + R_LOG(pr + C(1e-7));
             } else {
-                if (constrained) v = v / sqrtf(2.0f);
+                if (constrained) v = v / R_SQRT(C(2.0));
                 prod = prod * v;
             }
         }
-        result = mode == 0 ? lp + logdet : prod * expf(0.5f * logdet);
+        result = mode == 0 ? lp + logdet : prod * R_EXP(C(0.5) * logdet);
     } else if (m->prior_kind == 1) {
         /* distributions.py:139-163 */
         int nb = m->psp.nb;
-        float bij[WFO_MAX_D * WFO_MAX_NB];
+        real bij[WFO_MAX_D * WFO_MAX_NB];
         bijection_params(pp, D, m->hidden, nb, 0, u, bij);
-        float lp = 0.0f;
+        real lp = C(0.0);
         int* pidx = idx ? idx + (size_t)m->n_layers * D * 2 : 0;
         for (int d = 0; d < D; ++d) {
-            float* w = bij + d * nb;
+            real* w = bij + d * nb;
             remove_bias(0, m->psp.k, nb, w);
             enforce_bc(&m->psp, m->psp.tab, 0, w);
             u[d] = clip01(u[d]);
-            float v = spline_apply(&m->psp, 0, w, u[d], pidx ? pidx + 2 * d : 0);
-            lp = lp + logf(v + 1e-7f);
+            real v = spline_apply(&m->psp, 0, w, u[d], pidx ? pidx + 2 * d : 0);
+            lp = lp + R_LOG(v + C(1e-7));
         }
         result = lp + logdet;
     } else if (m->prior_kind == 2) {
         /* Flow.log_pdf distributions.py:95-102 with Uniform + prior_support=(0,1): clip => logpdf 0 */
         for (int d = 0; d < D; ++d) u[d] = clip01(u[d]);
-        result = 0.0f + logdet;
+        result = C(0.0) + logdet;
     } else {
         /* Normal(offset): norm.logpdf(u + offset).sum(1), distributions.py:14-15 */
-        float lp = 0.0f;
+        real lp = C(0.0);
         for (int d = 0; d < D; ++d) {
             /* jax.scipy.stats.norm.logpdf: (log(2*pi*scale^2) + ((x-loc)/scale)^2) / -2 */
-            float z = u[d] + m->normal_offset;
-            lp = lp + (1.8378770664093453f + z * z) / -2.0f;
+            real z = u[d] + m->normal_offset;
+            lp = lp + (C(1.8378770664093453) + z * z) / -C(2.0);
         }
         result = lp + logdet;
     }
-    if (u_out) memcpy(u_out, u, sizeof(float) * D);
+    if (u_out) for (int d = 0; d < D; ++d) u_out[d] = (float)u[d];
     return result;
 }
 
@@ -529,7 +551,7 @@ int wfo_eval(const wfo_model* m, const float* params, const float* x, int64_t B,
         int idx_local[(8 + 1) * WFO_MAX_D * 2];
         int* idx = 0;
         if (idx_out && m->n_layers <= 8) { idx = idx_local; memset(idx, 0, sizeof(idx_local)); }
-        out[b] = eval_one(m, params, x + b * D, mode, u_out ? u_out + b * D : 0, idx);
+        out[b] = (float)eval_one(m, params, x + b * D, mode, u_out ? u_out + b * D : 0, idx);
         if (idx) for (size_t q = 0; q < istride; ++q) idx_out[b * istride + q] = idx[q];
     }
     return 0;
@@ -541,7 +563,11 @@ int wfo_imade_direct(const wfo_model* m, const float* params, const float* u, in
     int D = m->D;
     for (int64_t b = 0; b < B; ++b) {
         int idx[WFO_MAX_D * 2];
-        imade_direct(m, params, u + b * D, y + b * D, logdet + b, idx);
+        real xin[WFO_MAX_D], yo[WFO_MAX_D], ld;
+        for (int d = 0; d < D; ++d) xin[d] = (real)u[b * D + d];
+        imade_direct(m, params, xin, yo, &ld, idx);
+        for (int d = 0; d < D; ++d) y[b * D + d] = (float)yo[d];
+        logdet[b] = (float)ld;
         if (idx_out) for (int q = 0; q < 2 * D; ++q) idx_out[b * 2 * D + q] = idx[q];
     }
     return 0;
@@ -549,7 +575,14 @@ int wfo_imade_direct(const wfo_model* m, const float* params, const float* u, in
 
 /* Serial direct only (no prior): u[B][D], logdet[B]. */
 int wfo_flow_direct(const wfo_model* m, const float* params, const float* x, int64_t B, float* u, float* logdet) {
-    for (int64_t b = 0; b < B; ++b) flow_direct(m, params, x + b * m->D, u + b * m->D, logdet + b, 0);
+    int D = m->D;
+    for (int64_t b = 0; b < B; ++b) {
+        real xin[WFO_MAX_D], uo[WFO_MAX_D], ld;
+        for (int d = 0; d < D; ++d) xin[d] = (real)x[b * D + d];
+        flow_direct(m, params, xin, uo, &ld, 0);
+        for (int d = 0; d < D; ++d) u[b * D + d] = (float)uo[d];
+        logdet[b] = (float)ld;
+    }
     return 0;
 }
 

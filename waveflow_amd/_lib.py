@@ -66,6 +66,9 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} not built; run `python -m waveflow_amd.build` (hipcc, gfx950). "
                           "There is no CPU fallback.")
+    # PyTorch ships its own libamdhip64.so.7; importing torch first makes this library bind to that same
+    # HIP runtime (one runtime per process: streams and device pointers are shared with torch).
+    import torch  # noqa: F401
     L = ctypes.CDLL(LIB_PATH)
     vp, i32, i64, f32p = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p
     L.wf_abi_version.restype = i32
