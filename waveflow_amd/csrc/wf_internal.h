@@ -65,6 +65,23 @@ struct ModelDev {
     NetMfma mnets[kMaxNets];
 };
 
+// MFMA kernel's view of the model (wf_kernels_mfma.hip)
+struct MfmaDev {
+    int D, n_layers, layer_kind, box_kind, prior_kind;
+    float box_L, i_reg, normal_offset;
+    unsigned constrained_mask;
+    int i_nb, p_nb, n_mesh;
+    const float* image;        // LDS image: every net, then the constants block
+    int image_floats;
+    int net_off[kMaxNets];     // float offset of net n inside the image
+    int const_off;             // fkI[2][16], fkP[2][16], ob_to_b image [4][64][4]
+    const float* tabI;         // [n_mesh][nd 0..1][half][16] fp32, I-spline rows in accumulator order
+    const float* tabP;         // [n_mesh][half][16] fp32, prior (orthogonal-B or M) rows, nd 0
+};
+
+int launch_mfma(int D, const MfmaDev* mdev, int lds_bytes, int mode, const float* x, int64_t B, float* out, float* u,
+                int32_t* idx, void* stream);
+
 // ---- kernel launchers (wf_kernels_*.hip).  mode: 0 = log_pdf, 1 = psi, 2 = flow only (u, logdet)
 int launch_scalar(const ModelDev& md, const ModelDev* md_dev, int mode, const float* x, int64_t B, float* out, float* u,
                   int32_t* idx, void* stream);

@@ -6,6 +6,7 @@
 //   table dtype ......................... jnp.array(np.load(...)) => fp32 (isplines_jax.py:131)
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <memory>
@@ -74,6 +75,12 @@ struct wf_model {
     int64_t mfma_floats = 0;
     wf::ModelDev* d_dev = nullptr;  // device copy of `dev`
     bool mfma_ok = false;           // the MFMA kernel covers this configuration
+    wf::MfmaDev mdev{};
+    wf::MfmaDev* d_mdev = nullptr;
+    std::vector<float> mfma_consts;  // constants block of the LDS image (host copy)
+    std::vector<int> mfma_net_floats;
+    float* d_tabI = nullptr;
+    float* d_tabP = nullptr;
 };
 
 namespace wf {
@@ -139,6 +146,8 @@ static int upload_table(wf_model* m, const std::vector<float>& h, const float** 
     return WF_OK;
 }
 
+static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::vector<double>& p64, const std::vector<double>& o2b);
+
 static int model_build(wf_model* m) {
     const wf_model_desc& d = m->desc;
     const int D = d.n_dim;
@@ -167,6 +176,7 @@ static int model_build(wf_model* m) {
     }
 
     m->nbp = 32;
+    std::vector<double> keep_i64, keep_p64, keep_o2b;
     // ---- tables
     if (d.layer_kind == WF_LAYER_IMADE && d.n_flow_layers > 0) {
         const int nb = n_bases_of(WF_SPLINE_I, d.i_degree, d.i_knots);
@@ -189,6 +199,7 @@ static int model_build(wf_model* m) {
         md.isp.nb = nb; md.isp.nbp = m->nbp; md.isp.n_mesh = d.n_mesh; md.isp.degree = d.i_degree;
         fill_bc(md.isp, d.i_left, d.i_right, t64, nb, d.n_mesh);
         m->i_nb = nb;
+        keep_i64.swap(t64);
     }
     if (d.prior_kind == WF_PRIOR_WAVEFLOW) {
         const int nb = n_bases_of(WF_SPLINE_B, d.p_degree, d.p_knots);
@@ -215,6 +226,8 @@ static int model_build(wf_model* m) {
         rc = upload_table(m, o2b32, &md.ob_to_b);
         if (rc) return rc;
         m->p_nb = nb;
+        keep_p64.swap(ob64);
+        keep_o2b.swap(o2b);
     } else if (d.prior_kind == WF_PRIOR_MFLOW) {
         const int nb = n_bases_of(WF_SPLINE_M, d.p_degree, d.p_knots);
         if (d.p_degree < 2 || d.p_knots < 2 || nb < 2) return WF_ERR_INVALID;
@@ -233,6 +246,7 @@ static int model_build(wf_model* m) {
         md.psp.nb = nb; md.psp.nbp = m->nbp; md.psp.n_mesh = d.n_mesh; md.psp.degree = d.p_degree;
         fill_bc(md.psp, d.p_left, d.p_right, t64, nb, d.n_mesh);
         m->p_nb = nb;
+        keep_p64.swap(t64);
     }
 
     // ---- parameter layout (pytree leaf order)
@@ -276,7 +290,7 @@ static int model_build(wf_model* m) {
     rc = dev_alloc(m, &m->d_dev, 1);
     if (rc) return rc;
     WF_HIP(hipMemcpy(m->d_dev, &md, sizeof(ModelDev), hipMemcpyHostToDevice));
-    return WF_OK;
+    return mfma_prepare(m, keep_i64, keep_p64, keep_o2b);
 }
 
 // Re-derives the masked, transposed weight image of net n from the flat parameter vector.
@@ -309,6 +323,174 @@ static void build_plain_image(const wf_model* m, int n, const float* flat, float
             }
     for (int dd = 0; dd < D; ++dd)
         for (int jb = 0; jb < nbp; ++jb) *o++ = jb < nl.n_out ? b2[jb * D + dd] : 0.0f;
+}
+
+
+// ---------------------------------------------------------------------------- MFMA kernel images
+static inline int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+static int mfma_net_floats(int D) {
+    const int S0 = (D + 1) / 2;
+    return 128 * S0 + 64 + 4096 + 64 + (D - 1) * 2048 + 32 * D;
+}
+
+// all constraints are {0: 0} (or the I-spline's right {0: 1}): they only zero the first / last weight
+static bool bc_only_zeroes(const wf_bc& left, const wf_bc& right, bool is_I) {
+    for (int p = 0; p < left.n; ++p)
+        if (left.n_derivative[p] != 0 || left.value[p] != 0.0f) return false;
+    for (int p = 0; p < right.n; ++p) {
+        if (right.n_derivative[p] != 0) return false;
+        if (is_I ? right.value[p] != 1.0f : right.value[p] != 0.0f) return false;
+    }
+    return true;
+}
+
+// per-row factor: remove_bias scaling (isplines_jax.py:196-202 / msplines_jax.py:186-192) times the
+// 0/1 "kept by the boundary conditions" mask; 0 beyond the real bases.  Layout [half][16] in accumulator order.
+static void row_factors(int kind, bool with_remove_bias, int k, int nb, const wf_bc& left, const wf_bc& right, float* out32) {
+    std::vector<float> f(32, 0.0f);
+    for (int j = 0; j < nb; ++j) f[j] = 1.0f;
+    if (with_remove_bias)
+        for (int i = 0; i < k; ++i) {
+            const int a = kind == WF_SPLINE_I ? i + 1 : i;
+            const int b = kind == WF_SPLINE_I ? nb - (i + 2) : nb - (i + 1);
+            const float fac = (float)(i + 1) / (float)k;
+            f[a] *= fac;
+            f[b] *= fac;
+        }
+    if (left.n > 0) f[0] = 0.0f;
+    if (right.n > 0) f[nb - 1] = 0.0f;
+    for (int h = 0; h < 2; ++h)
+        for (int r = 0; r < 16; ++r) out32[h * 16 + r] = f[acc_row(r, h)];
+}
+
+// [n_mesh][n_orders][half][16]
+static void pack_rows_acc(const std::vector<double>& t64, int nb, int n_mesh, int n_orders, std::vector<float>& out) {
+    out.assign((size_t)n_mesh * n_orders * 32, 0.0f);
+    for (int m = 0; m < n_mesh; ++m)
+        for (int nd = 0; nd < n_orders; ++nd)
+            for (int h = 0; h < 2; ++h)
+                for (int r = 0; r < 16; ++r) {
+                    const int row = acc_row(r, h);
+                    if (row < nb) out[(((size_t)m * n_orders + nd) * 2 + h) * 16 + r] = (float)t64[((size_t)nd * nb + row) * n_mesh + m];
+                }
+}
+
+// LDS image of net n in MFMA operand order (wf_kernels_mfma.hip)
+static void build_mfma_image(const wf_model* m, int n, const float* flat, float* img) {
+    const int D = m->desc.n_dim, H = kHidden;
+    const int S0 = (D + 1) / 2;
+    const NetLayout& nl = m->nets[n];
+    const int NO = nl.n_out * D;
+    const float* W0 = flat + nl.offset;
+    const float* b0 = W0 + (int64_t)D * H;
+    const float* W1 = b0 + H;
+    const float* b1 = W1 + (int64_t)H * H;
+    const float* W2 = b1 + H;
+    const float* b2 = W2 + (int64_t)H * NO;
+    float* o = img;
+    // layer 0: A[i = unit 32*ob + (lane&31)][k = 2s + (lane>>5)]
+    for (int ob = 0; ob < 2; ++ob)
+        for (int s = 0; s < S0; ++s)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int unit = 32 * ob + (lane & 31), k = 2 * s + (lane >> 5);
+                *o++ = (k < D && deg_hidden(unit, D) >= deg_in(k)) ? W0[(int64_t)k * H + unit] : 0.0f;
+            }
+    for (int ob = 0; ob < 2; ++ob)
+        for (int h = 0; h < 2; ++h)
+            for (int r = 0; r < 16; ++r) *o++ = b0[32 * ob + acc_row(r, h)];
+    // layer 1: step (t, r) contracts hidden unit kk = 32t + acc_row(r, lane>>5)
+    for (int ob = 0; ob < 2; ++ob)
+        for (int t = 0; t < 2; ++t)
+            for (int r4 = 0; r4 < 4; ++r4)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 4; ++e) {
+                        const int unit = 32 * ob + (lane & 31), kk = 32 * t + acc_row(4 * r4 + e, lane >> 5);
+                        *o++ = deg_hidden(unit, D) >= deg_hidden(kk, D) ? W1[(int64_t)kk * H + unit] : 0.0f;
+                    }
+    for (int ob = 0; ob < 2; ++ob)
+        for (int h = 0; h < 2; ++h)
+            for (int r = 0; r < 16; ++r) *o++ = b1[32 * ob + acc_row(r, h)];
+    // output layer, dimensions 1..D-1 (dimension 0 has no inputs): A[i = basis (lane&31)][k = kk]
+    for (int d = 1; d < D; ++d)
+        for (int t = 0; t < 2; ++t)
+            for (int r4 = 0; r4 < 4; ++r4)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 4; ++e) {
+                        const int jb = lane & 31, kk = 32 * t + acc_row(4 * r4 + e, lane >> 5);
+                        float v = 0.0f;
+                        if (jb < nl.n_out && deg_out(d) >= deg_hidden(kk, D)) v = W2[(int64_t)kk * NO + (jb * D + d)];
+                        *o++ = v;
+                    }
+    for (int d = 0; d < D; ++d)
+        for (int h = 0; h < 2; ++h)
+            for (int r = 0; r < 16; ++r) {
+                const int jb = acc_row(r, h);
+                *o++ = jb < nl.n_out ? b2[jb * D + d] : 0.0f;
+            }
+}
+
+// Decides whether the MFMA kernel covers this model and builds its parameter-independent parts.
+// i64 / p64: the fp64 tables already built by model_build (I: [4][nb][n_mesh]; prior: OB or M), o2b: [nb][nb].
+static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::vector<double>& p64, const std::vector<double>& o2b) {
+    const wf_model_desc& d = m->desc;
+    const int D = d.n_dim;
+    m->mfma_ok = false;
+    if (D > 4 || m->i_nb > 32 || m->p_nb > 32) return WF_OK;
+    const bool imade = d.layer_kind == WF_LAYER_IMADE && d.n_flow_layers > 0;
+    if (imade && !bc_only_zeroes(d.i_left, d.i_right, true)) return WF_OK;
+    const bool spline_prior = d.prior_kind == WF_PRIOR_WAVEFLOW || d.prior_kind == WF_PRIOR_MFLOW;
+    if (spline_prior && !bc_only_zeroes(d.p_left, d.p_right, false)) return WF_OK;
+    const int n_nets = (int)m->nets.size();
+    const int consts = 32 + 32 + 1024;
+    const int64_t total = (int64_t)mfma_net_floats(D) * n_nets + consts;
+    if (total * 4 > 160 * 1024) return WF_OK;  // all nets must be LDS-resident
+
+    MfmaDev& md = m->mdev;
+    md = MfmaDev{};
+    md.D = D; md.n_layers = d.n_flow_layers; md.layer_kind = d.layer_kind; md.box_kind = d.box_kind; md.prior_kind = d.prior_kind;
+    md.box_L = d.box_size; md.i_reg = d.i_reg; md.normal_offset = d.normal_offset; md.constrained_mask = m->dev.constrained_mask;
+    md.i_nb = m->i_nb; md.p_nb = m->p_nb; md.n_mesh = d.n_mesh;
+    md.image_floats = (int)total;
+    for (int n = 0; n < n_nets; ++n) md.net_off[n] = mfma_net_floats(D) * n;
+    md.const_off = mfma_net_floats(D) * n_nets;
+
+    m->mfma_consts.assign(consts, 0.0f);
+    if (imade) {
+        row_factors(WF_SPLINE_I, true, d.i_degree, m->i_nb, d.i_left, d.i_right, m->mfma_consts.data());
+        std::vector<float> rows;
+        pack_rows_acc(i64, m->i_nb, d.n_mesh, 2, rows);
+        int rc = upload_table(m, rows, &md.tabI);
+        if (rc) return rc;
+    }
+    if (spline_prior) {
+        const bool mflow = d.prior_kind == WF_PRIOR_MFLOW;
+        row_factors(mflow ? WF_SPLINE_M : WF_SPLINE_B, mflow, d.p_degree, m->p_nb, d.p_left, d.p_right, m->mfma_consts.data() + 32);
+        std::vector<float> rows;
+        pack_rows_acc(p64, m->p_nb, d.n_mesh, 1, rows);
+        int rc = upload_table(m, rows, &md.tabP);
+        if (rc) return rc;
+        if (!mflow) {
+            // c[i] = sum_a w[a] * ob_to_b[a][i]: A[i = lane&31][k = a = acc_row(r, lane>>5)]
+            float* o = m->mfma_consts.data() + 64;
+            const int nb = m->p_nb;
+            for (int r4 = 0; r4 < 4; ++r4)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 4; ++e) {
+                        const int i = lane & 31, a = acc_row(4 * r4 + e, lane >> 5);
+                        *o++ = (i < nb && a < nb) ? (float)o2b[(size_t)a * nb + i] : 0.0f;
+                    }
+        }
+    }
+    int rc = dev_alloc(m, &m->d_mfma, (size_t)total);
+    if (rc) return rc;
+    md.image = m->d_mfma;
+    rc = dev_alloc(m, &m->d_mdev, 1);
+    if (rc) return rc;
+    WF_HIP(hipMemcpy(m->d_mdev, &md, sizeof(MfmaDev), hipMemcpyHostToDevice));
+    m->mfma_floats = total;
+    m->mfma_ok = true;
+    return WF_OK;
 }
 
 }  // namespace wf
@@ -427,6 +609,13 @@ int wf_model_set_params(wf_model* m, const float* flat_host, int64_t n, void* st
     for (size_t i = 0; i < m->nets.size(); ++i) build_plain_image(m, (int)i, flat_host, img.data() + m->plain_off[i]);
     hipStream_t s = (hipStream_t)stream;
     if (!img.empty()) WF_HIP(hipMemcpyAsync(m->d_plain, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice, s));
+    std::vector<float> mimg;
+    if (m->mfma_ok) {
+        mimg.assign((size_t)m->mfma_floats, 0.0f);
+        for (size_t i = 0; i < m->nets.size(); ++i) build_mfma_image(m, (int)i, flat_host, mimg.data() + m->mdev.net_off[i]);
+        std::copy(m->mfma_consts.begin(), m->mfma_consts.end(), mimg.begin() + m->mdev.const_off);
+        WF_HIP(hipMemcpyAsync(m->d_mfma, mimg.data(), mimg.size() * sizeof(float), hipMemcpyHostToDevice, s));
+    }
     WF_HIP(hipStreamSynchronize(s));
     m->params_set = true;
     return WF_OK;
@@ -442,6 +631,8 @@ static int check_fwd(const wf_model* m, const void* x, int64_t B, const void* ou
 static int dispatch(const wf_model* m, int mode, const float* x, int64_t B, float* out, float* u, int32_t* idx, void* stream) {
     DeviceGuard g(m->device);
     if (B == 0) return WF_OK;
+    const bool use_mfma = m->mfma_ok && m->kernel_kind != WF_KERNEL_SCALAR;
+    if (use_mfma) return launch_mfma(m->dev.D, m->d_mdev, (int)(m->mfma_floats * sizeof(float)), mode, x, B, out, u, idx, stream);
     return launch_scalar(m->dev, m->d_dev, mode, x, B, out, u, idx, stream);
 }
 
