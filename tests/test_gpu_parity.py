@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 # with the 1e-7 floor or psi is near a node (d logp = 2 dpsi/psi).  So every comparison below is made against
 # the fp64 yardstick `truth` (oracle f64=True: same tables, parameters and formulas, fp64 arithmetic) and asks
 # that the HIP result is as close to it as the fp32 oracle is:
-#   * at least as many walkers within 1e-5*|truth| + ATOL as for the fp32 oracle (up to 2x + 0.2 %),
+#   * at least as many walkers within 1e-5*|truth| + ATOL as for the fp32 oracle (up to 2x + 0.2 % + 4),
 #   * worst-case deviation within 4x the fp32 oracle's worst case,
 #   * median deviation within 2x the fp32 oracle's median.
 RTOL, ATOL = 1e-5, 2e-5
@@ -38,8 +38,9 @@ def as_accurate_as_fp32_reference(gpu, oracle32, truth, rtol=RTOL, atol=ATOL):
     assert np.isfinite(gpu).all()
     tol = atol + rtol * np.abs(truth)
     e_g, e_o = np.abs(gpu - truth), np.abs(oracle32 - truth)
-    f_g, f_o = (e_g > tol).mean(), (e_o > tol).mean()
-    assert f_g <= 2 * f_o + 0.002, f"fraction outside 1e-5 rel: HIP {f_g:.4f} vs fp32 oracle {f_o:.4f}"
+    n_g, n_o = int((e_g > tol).sum()), int((e_o > tol).sum())
+    # (+4: small-sample slack, the counts are Poisson-like for batches of a few hundred walkers)
+    assert n_g <= 2 * n_o + 4 + 0.002 * e_g.size, f"walkers outside 1e-5 rel: HIP {n_g} vs fp32 oracle {n_o} of {e_g.size}"
     assert e_g.max() <= 4 * e_o.max() + atol, f"max deviation from exact arithmetic: HIP {e_g.max():.3e} vs fp32 oracle {e_o.max():.3e}"
     assert np.median(e_g) <= 2 * np.median(e_o) + 1e-7 * max(1.0, np.abs(truth).max()), (np.median(e_g), np.median(e_o))
 
