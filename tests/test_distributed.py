@@ -1,0 +1,86 @@
+"""N>1 path on CPU: world_size-2 gloo processes exercise the sharding arithmetic and the single all-reduce."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+from waveflow_amd import distributed as wfd
+
+
+def test_shard_bounds_cover_everything_once():
+    for n in (0, 1, 7, 256, 1 << 20, (1 << 23) + 3):
+        for world in (1, 2, 3, 8):
+            rows = [wfd.shard_bounds(n, r, world) for r in range(world)]
+            assert rows[0][0] == 0 and rows[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(rows, rows[1:]))
+            sizes = [hi - lo for lo, hi in rows]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        wfd.shard_bounds(10, 2, 2)
+
+
+def test_moments_to_stats():
+    v = np.random.default_rng(0).normal(3.0, 2.0, size=10000)
+    mean, var, se = wfd.moments_to_stats([v.sum(), (v ** 2).sum(), v.size])
+    assert abs(mean - v.mean()) < 1e-12 and abs(var - v.var()) < 1e-9 and abs(se - v.std() / 100) < 1e-9
+    assert all(np.isnan(wfd.moments_to_stats([0, 0, 0])))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_total, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # every rank generates the same global vector and keeps only its shard (stand-in for its walkers' log_pdf)
+        v = np.random.default_rng(123).normal(-16.0, 5.0, size=n_total).astype(np.float32)
+        lo, hi = wfd.shard_bounds(n_total, rank, world)
+        mine = v[lo:hi].astype(np.float64)
+        sums = torch.tensor([mine.sum(), (mine ** 2).sum(), float(mine.size)], dtype=torch.float64)
+        wfd.all_reduce_moments(sums)
+        q.put((rank, sums.tolist(), (lo, hi)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_two_rank_expectation_matches_single_rank(world):
+    n_total = 100003
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    v = np.random.default_rng(123).normal(-16.0, 5.0, size=n_total).astype(np.float32).astype(np.float64)
+    ref = [v.sum(), (v ** 2).sum(), float(n_total)]
+    for rank, sums, rows in res:
+        assert sums[2] == n_total
+        assert abs(sums[0] - ref[0]) <= 1e-12 * abs(ref[0]) and abs(sums[1] - ref[1]) <= 1e-12 * ref[1]
+    # every rank holds the same reduced triple (bitwise: gloo reduces in a fixed order)
+    assert all(r[1] == res[0][1] for r in res)
+    mean, var, se = wfd.moments_to_stats(res[0][1])
+    assert abs(mean - v.mean()) < 1e-9
+
+
+def test_all_reduce_is_noop_without_group():
+    s = torch.tensor([1.0, 2.0, 3.0], dtype=torch.float64)
+    assert wfd.all_reduce_moments(s).tolist() == [1.0, 2.0, 3.0]

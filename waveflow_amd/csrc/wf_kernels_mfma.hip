@@ -25,6 +25,8 @@
 // whole launch, so waves run free of barriers after the prologue.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "wf_internal.h"
 
 namespace wf {
@@ -34,7 +36,6 @@ namespace {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-constexpr int kWaves = 8;  // waves per workgroup (2 per SIMD)
 
 __device__ __forceinline__ float fast_tanh(float x) {
     // tanh(x) = 1 - 2 / (exp(2x) + 1); v_exp_f32 is 2^x
@@ -192,7 +193,7 @@ __device__ __forceinline__ float lerp_dot(const f32x16& q, const float* __restri
     return xhalf_sum(__builtin_fmaf(Bv - A, t, A));
 }
 
-template <int D>
+template <int D, int kWaves>
 __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev* __restrict__ mp, int mode, const float* __restrict__ xg, int64_t B,
                                                       float* __restrict__ out, float* __restrict__ u_out, int32_t* __restrict__ idx_out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -390,11 +391,11 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev* __restrict_
     }
 }
 
-template <int D>
-int launch_d(const MfmaDev* mdev, int lds_bytes, int mode, const float* x, int64_t B, float* out, float* u, int32_t* idx, hipStream_t s) {
+template <int D, int kWaves>
+int launch_dw(const MfmaDev* mdev, int lds_bytes, int mode, const float* x, int64_t B, float* out, float* u, int32_t* idx, hipStream_t s) {
     static int configured_bytes = -1;
     if (lds_bytes > configured_bytes) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mfma<D>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mfma<D, kWaves>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) {
             set_hip_error((int)e);
             return WF_ERR_HIP;
@@ -404,13 +405,31 @@ int launch_d(const MfmaDev* mdev, int lds_bytes, int mode, const float* x, int64
     const int64_t n_tiles = (B + 31) / 32;
     int64_t grid = (n_tiles + kWaves - 1) / kWaves;
     if (grid > 256) grid = 256;  // one persistent workgroup per CU
-    hipLaunchKernelGGL(k_mfma<D>, dim3((unsigned)grid), dim3(kWaves * 64), lds_bytes, s, mdev, mode, x, B, out, u, idx);
+    hipLaunchKernelGGL((k_mfma<D, kWaves>), dim3((unsigned)grid), dim3(kWaves * 64), lds_bytes, s, mdev, mode, x, B, out, u, idx);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_hip_error((int)e);
         return WF_ERR_HIP;
     }
     return WF_OK;
+}
+
+int waves_per_group() {
+    static int w = [] {
+        const char* e = getenv("WF_MFMA_WAVES");  // tuning knob: 8, 12 or 16 waves per workgroup
+        const int v = e ? atoi(e) : 0;
+        return (v == 8 || v == 12 || v == 16) ? v : 12;
+    }();
+    return w;
+}
+
+template <int D>
+int launch_d(const MfmaDev* mdev, int lds_bytes, int mode, const float* x, int64_t B, float* out, float* u, int32_t* idx, hipStream_t s) {
+    switch (waves_per_group()) {
+        case 8: return launch_dw<D, 8>(mdev, lds_bytes, mode, x, B, out, u, idx, s);
+        case 16: return launch_dw<D, 16>(mdev, lds_bytes, mode, x, B, out, u, idx, s);
+        default: return launch_dw<D, 12>(mdev, lds_bytes, mode, x, B, out, u, idx, s);
+    }
 }
 
 }  // namespace
