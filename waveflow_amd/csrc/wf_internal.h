@@ -71,16 +71,19 @@ struct MfmaDev {
     float box_L, i_reg, normal_offset;
     unsigned constrained_mask;
     int i_nb, p_nb, n_mesh;
+    float F_I, F_P;            // sum of the row factors fk (flow-layer spline / prior spline)
     const float* image;        // LDS image: every net, then the constants block
     int image_floats;
     int net_off[kMaxNets];     // float offset of net n inside the image
     int const_off;             // fkI[2][16], fkP[2][16], ob_to_b image [4][64][4]
-    const float* tabI;         // [n_mesh][nd 0..1][half][16] fp32, I-spline rows in accumulator order
-    const float* tabP;         // [n_mesh][half][16] fp32, prior (orthogonal-B or M) rows, nd 0
+    const float* tabI;         // [n_mesh][nd 0..1][half][16] fp32: fk_row * I_row, accumulator row order
+    const float* rsI;          // [n_mesh][nd 0..1]: sum over rows of tabI
+    const float* tabP;         // [n_mesh][half][16] fp32, prior rows (orthogonal-B as is; M: fk_row * M_row), nd 0
 };
 
 int launch_mfma(int D, const MfmaDev* mdev, int lds_bytes, int mode, const float* x, int64_t B, float* out, float* u,
                 int32_t* idx, void* stream);
+int mfma_extra_lds_floats(int n_nets);
 
 // ---- kernel launchers (wf_kernels_*.hip).  mode: 0 = log_pdf, 1 = psi, 2 = flow only (u, logdet)
 int launch_scalar(const ModelDev& md, const ModelDev* md_dev, int mode, const float* x, int64_t B, float* out, float* u,

@@ -1,28 +1,33 @@
-// wf_kernels_mfma.hip -- throughput kernel: one wave = one tile of 32 walkers, conditioner GEMMs on
-// v_mfma_f32_32x32x2_f32 (exact fp32), everything else fused around them (gfx950 / CDNA4).
+// wf_kernels_mfma.hip -- throughput kernel: one wave = one tile of 32 walkers, conditioner GEMMs on the
+// matrix cores, everything else fused around them (gfx950 / CDNA4).
 //
 // Orientation.  Every dense layer is computed transposed, OUT[unit][walker] = W^T[unit][k] * IN[k][walker]:
-//   * the MFMA's C/D layout puts the walker on the lane (column j = lane & 31) and the 32 output units of a
+//   * the MFMA C/D layout puts the walker on the lane (column j = lane & 31) and the 32 output units of a
 //     block in the 16 accumulator registers of the two lane halves (row = (r&3) + 8*(r>>2) + 4*(lane>>5));
-//   * that is exactly the B-operand layout of the next layer's MFMA (B[k][j]: lane half h supplies k = h of
-//     each K=2 step), so an accumulator register -- after tanh -- IS the next B operand: the whole
-//     2 -> 64 -> 64 -> D*n_bases chain runs with no LDS transposes and no cross-lane traffic;
-//   * the A operand (weights) is pre-permuted on the host into that k order and streamed from LDS with one
-//     ds_read_b128 per four MFMAs (wf_model.cpp: build_mfma_image);
-//   * the per-walker spline-weight post-processing (sigmoid, normalisations, bias removal, boundary
-//     conditions) and the table lerp act on the 16 registers of a lane; the two halves of a walker are
-//     combined with v_permlane32_swap.
+//   * that is also the B-operand layout of the next layer's MFMA (lane half h supplies the k's of its own
+//     registers), so an accumulator tile -- after the activation -- IS the next B operand: the whole
+//     D -> 64 -> 64 -> D*n_bases chain runs with no LDS transposes and no cross-lane traffic;
+//   * the A operand (weights) is pre-permuted on the host into that k order and streamed from LDS
+//     (wf_model.cpp: build_mfma_image).
+// Precision.  On gfx950 the f32-input MFMA runs at the f32 VALU rate and does not overlap with VALU work
+// (measured: profiles/r01_ubench_coexec.txt), so the two K=64 layers use v_mfma_f32_32x32x16_f16 with a
+// two-way fp16 split of both operands: x = hi + lo*2^-11 (hi = rn16(x), lo = rn16((x - hi)*2^11), 22
+// significant bits), three products hi*hi + (hi*lo + lo*hi)*2^-11 accumulated in fp32.  Its error is
+// indistinguishable from an fp32 FMA chain (dominated by the fp32 accumulation; tests/test_gpu_parity.py).
+// The K = D input layer and the 32x32 ob_to_b product of the B-prior stay on v_mfma_f32_32x32x2_f32.
+// Constant folding done on the host: 2*log2(e) into (W0,b0,W1,b1) so tanh(x) = 1 - 2/(2^x' + 1) needs no
+// scaling multiply, -log2(e) into (W2,b2) of sigmoid heads, +1e30 biases on padding rows (sigmoid -> 0), the
+// remove_bias / boundary-condition row factors f_j*keep_j into the spline tables (plus their row sums).
 // Algebra used (exact in real arithmetic, fewer roundings than the reference's sequence):
-//   with q_j = (sigmoid(o_j) + reg * S1) * f_j * keep_j  (S1 = sum sigmoid, f = remove_bias factors, keep = 0 on
-//   rows a {0: 0} / {0: 1} constraint zeroes), the reference's weights are c_j = q_j / sum(q); so
-//   y = (sum_j q_j lerp_j(x)) / sum(q) and only two reductions are needed (made.py:66-79,
-//   isplines_jax.py:158-202).  For the B-spline prior the two L2 normalisations and the division by the signed
-//   sum collapse to psi_d = sign(sum o) * (c . lerp) / |c| with c = (o * keep) @ ob_to_b
-//   (wavefunctions.py:40-46, bsplines_jax.py:127-137, 173-199).
+//   with v_j = sigmoid(o_j), S1 = sum v, the reference's weights are c_j = q_j / sum(q),
+//   q_j = (v_j + reg*S1) * f_j * keep_j (made.py:66-79, isplines_jax.py:158-202), hence
+//   y = [sum_j v_j T'_j(x) + reg*S1*R(x)] / [sum_j v_j fk_j + reg*S1*F] with T' = fk*T, R = sum_j T'_j, F = sum fk.
+//   For the B-spline prior the two L2 normalisations and the division by the signed sum collapse to
+//   psi_d = sign(sum o) * (c . lerp) / |c|, c = (o * keep) @ ob_to_b (wavefunctions.py:40-46,
+//   bsplines_jax.py:127-137, 173-199).
+//   Output dimension 0 of every net depends on no input (output degree -1, model_factory.py:15-18): its
+//   weights are per-net constants, computed once per workgroup in the prologue.
 // The table index arithmetic (floor/ceil of u * (n_mesh-1), isplines_jax.py:46-48) is kept verbatim.
-//
-// Tables stay in global memory (L2-resident, 256 B per mesh row); LDS holds every net's weights for the
-// whole launch, so waves run free of barriers after the prologue.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -35,18 +40,17 @@ namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 
+constexpr float kLoScale = 2048.0f, kLoInv = 1.0f / 2048.0f;
 
-__device__ __forceinline__ float fast_tanh(float x) {
-    // tanh(x) = 1 - 2 / (exp(2x) + 1); v_exp_f32 is 2^x
-    const float t = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
-    return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(t + 1.0f), 1.0f);
+__device__ __forceinline__ float act_tanh(float xs) {  // xs = 2*log2(e)*x (scale folded into the weights)
+    return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(xs) + 1.0f), 1.0f);
 }
-
-__device__ __forceinline__ float fast_sigmoid(float x) {
-    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+__device__ __forceinline__ float act_sigmoid(float xs) {  // xs = -log2(e)*x
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(xs));
 }
-
 __device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
 
 // sum of the two lane halves (lane l and l^32), result in every lane
@@ -56,20 +60,11 @@ __device__ __forceinline__ float xhalf_sum(float v) {
     return __uint_as_float(s[0]) + __uint_as_float(s[1]);
 }
 
-__device__ __forceinline__ f32x16 lds_load16(const float* p) {
+__device__ __forceinline__ f32x16 load16(const float* p) {
     const f32x4* q = reinterpret_cast<const f32x4*>(p);
     const f32x4 a = q[0], b = q[1], c = q[2], d = q[3];
     return f32x16{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3], c[0], c[1], c[2], c[3], d[0], d[1], d[2], d[3]};
 }
-
-__device__ __forceinline__ f32x16 glb_load16(const float* __restrict__ p) {
-    const f32x4* q = reinterpret_cast<const f32x4*>(p);
-    const f32x4 a = q[0], b = q[1], c = q[2], d = q[3];
-    return f32x16{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3], c[0], c[1], c[2], c[3], d[0], d[1], d[2], d[3]};
-}
-
-// row of accumulator register r in lane half h
-__device__ __forceinline__ constexpr int row_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 struct Lerp {
     int il, ir, xl, xr;
@@ -94,111 +89,138 @@ __device__ __forceinline__ Lerp make_lerp(float x, int n_mesh) {
     return L;
 }
 
-// Hidden layers of one conditioner net for the wave's 32 walkers.  in[]: the D inputs of this lane's walker.
-// net: LDS image (see build_mfma_image).  Result: h2[2] (64 units x 32 walkers) in accumulator layout.
-template <int D>
-__device__ __forceinline__ void hidden_layers(const float* net, const float (&in)[D], int lane, f32x16 (&h2)[2]) {
-    constexpr int S0 = (D + 1) / 2;
-    const int h = lane >> 5;
-    const float* W0 = net;
-    const float* b0 = W0 + 2 * S0 * 64;
-    const float* W1 = b0 + 64;
-    const float* b1 = W1 + 4096;
-    f32x16 h1[2];
+// 32 activations of one block (accumulator layout) -> the two K=16 B fragments, split hi / lo
+struct Frag {
+    f16x8 hi[2], lo[2];
+};
+__device__ __forceinline__ void split_block(const f32x16& x, Frag& f) {
 #pragma unroll
-    for (int ob = 0; ob < 2; ++ob) {
-        h1[ob] = lds_load16(b0 + (ob * 2 + h) * 16);
+    for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int s = 0; s < S0; ++s) {
-            const float a = W0[(ob * S0 + s) * 64 + lane];
-            const float lo = in[2 * s];
-            const float hi = (2 * s + 1 < D) ? in[(2 * s + 1 < D) ? 2 * s + 1 : D - 1] : 0.0f;
-            const float b = h ? hi : lo;
-            h1[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, h1[ob], 0, 0, 0);
+        for (int j = 0; j < 8; ++j) {
+            const float v = x[8 * s + j];
+            const _Float16 h = (_Float16)v;
+            f.hi[s][j] = h;
+            f.lo[s][j] = (_Float16)((v - (float)h) * kLoScale);
+        }
+}
+
+// one 32-unit output block of a K=64 layer: acc1 += Ahi*Bhi ; acc2 += Ahi*Blo + Alo*Bhi ; result acc1 + acc2*2^-11
+// Wh / Wl: LDS images [t][s][lane][8 halves] of this block
+__device__ __forceinline__ f32x16 dense64_block(const _Float16* Wh, const _Float16* Wl, const Frag (&in)[2], f32x16 bias, int lane) {
+    f32x16 acc1 = bias;
+    f32x16 acc2 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(Wh + ((t * 2 + s) * 64 + lane) * 8);
+            const f16x8 al = *reinterpret_cast<const f16x8*>(Wl + ((t * 2 + s) * 64 + lane) * 8);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, in[t].hi[s], acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, in[t].lo[s], acc2, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, in[t].hi[s], acc2, 0, 0, 0);
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) h1[ob][r] = fast_tanh(h1[ob][r]);
-    }
+    for (int r = 0; r < 16; ++r) acc1[r] = __builtin_fmaf(acc2[r], kLoInv, acc1[r]);
+    return acc1;
+}
+
+// float offsets inside a net image (wf_model.cpp: build_mfma_image)
+template <int D>
+struct NetOff {
+    static constexpr int S0 = (D + 1) / 2;
+    static constexpr int W0 = 0;
+    static constexpr int b0 = W0 + 2 * S0 * 64;
+    static constexpr int W1h = b0 + 64;
+    static constexpr int W1l = W1h + 2048;
+    static constexpr int b1 = W1l + 2048;
+    static constexpr int W2h = b1 + 64;
+    static constexpr int W2l = W2h + (D - 1) * 1024;
+    static constexpr int b2 = W2l + (D - 1) * 1024;
+    static constexpr int total = b2 + 32 * D;
+};
+
+// Hidden layers of one conditioner net for the wave's 32 walkers; result: second hidden layer as B fragments.
+template <int D>
+__device__ __forceinline__ void hidden_layers(const float* net, const float (&in)[D], int lane, Frag (&h2)[2]) {
+    using O = NetOff<D>;
+    const int h = lane >> 5;
+    Frag h1[2];
 #pragma unroll
     for (int ob = 0; ob < 2; ++ob) {
-        h2[ob] = lds_load16(b1 + (ob * 2 + h) * 16);
+        f32x16 a = load16(net + O::b0 + (ob * 2 + h) * 16);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int s = 0; s < O::S0; ++s) {
+            const float w = net[O::W0 + (ob * O::S0 + s) * 64 + lane];
+            const float lo = in[2 * s];
+            const float hi = (2 * s + 1 < D) ? in[(2 * s + 1 < D) ? 2 * s + 1 : D - 1] : 0.0f;
+            a = __builtin_amdgcn_mfma_f32_32x32x2f32(w, h ? hi : lo, a, 0, 0, 0);
+        }
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const f32x4 a4 = *reinterpret_cast<const f32x4*>(W1 + (((ob * 2 + t) * 4 + r4) * 64 + lane) * 4);
+        for (int r = 0; r < 16; ++r) a[r] = act_tanh(a[r]);
+        split_block(a, h1[ob]);
+    }
+    const _Float16* W1h = reinterpret_cast<const _Float16*>(net + O::W1h);
+    const _Float16* W1l = reinterpret_cast<const _Float16*>(net + O::W1l);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) h2[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], h1[t][4 * r4 + e], h2[ob], 0, 0, 0);
-            }
+    for (int ob = 0; ob < 2; ++ob) {
+        f32x16 a = dense64_block(W1h + ob * 2048, W1l + ob * 2048, h1, load16(net + O::b1 + (ob * 2 + h) * 16), lane);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) h2[ob][r] = fast_tanh(h2[ob][r]);
+        for (int r = 0; r < 16; ++r) a[r] = act_tanh(a[r]);
+        split_block(a, h2[ob]);
     }
 }
 
-// Output block of dimension d: o[basis row][walker] in accumulator layout.  Dimension 0 depends on no hidden
-// unit (output degree -1, model_factory.py:15-18): bias only.
+// Output block of dimension d >= 1: raw (scaled) outputs o[basis row][walker] in accumulator layout.
 template <int D>
-__device__ __forceinline__ f32x16 out_block(const float* net, const f32x16 (&h2)[2], int d, int lane) {
-    constexpr int S0 = (D + 1) / 2;
+__device__ __forceinline__ f32x16 out_block(const float* net, const Frag (&h2)[2], int d, int lane) {
+    using O = NetOff<D>;
     const int h = lane >> 5;
-    const float* W2 = net + 2 * S0 * 64 + 64 + 4096 + 64;
-    const float* b2 = W2 + (D - 1) * 2048;
-    f32x16 o = lds_load16(b2 + (d * 2 + h) * 16);
-    if (d > 0) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const f32x4 a4 = *reinterpret_cast<const f32x4*>(W2 + ((((d - 1) * 2 + t) * 4 + r4) * 64 + lane) * 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], h2[t][4 * r4 + e], o, 0, 0, 0);
-            }
-    }
-    return o;
+    const _Float16* W2h = reinterpret_cast<const _Float16*>(net + O::W2h);
+    const _Float16* W2l = reinterpret_cast<const _Float16*>(net + O::W2l);
+    return dense64_block(W2h + (d - 1) * 2048, W2l + (d - 1) * 2048, h2, load16(net + O::b2 + (d * 2 + h) * 16), lane);
 }
 
-// q_j = (sigmoid(o_j) + reg * S1) * fk_j on this lane's 16 rows; returns sum(q) over the walker's 32 rows.
-__device__ __forceinline__ float spline_weights(f32x16& o, const float* fk_lds, float reg, int nb, int h) {
-    const f32x16 fk = lds_load16(fk_lds + h * 16);
-    float s1 = 0.0f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float v = row_of(r, 0) + 4 * h < nb ? fast_sigmoid(o[r]) : 0.0f;
-        o[r] = v;
-        s1 += v;
-    }
-    s1 = xhalf_sum(s1);
-    const float rs = reg * s1;
-    float sq = 0.0f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        o[r] = (o[r] + rs) * fk[r];
-        sq += o[r];
-    }
-    return xhalf_sum(sq);
-}
-
-// sum_j q_j * lerp_j over the walker's rows for one table order; rows of this half at tl / tr
-__device__ __forceinline__ float lerp_dot(const f32x16& q, const float* __restrict__ tl, const float* __restrict__ tr, float t) {
-    const f32x16 a = glb_load16(tl), b = glb_load16(tr);
+// sum_r v_r * lerp(T'_r) over this lane's 16 rows (both halves summed); tl / tr: this half's 16 table values at x_l / x_r
+__device__ __forceinline__ float lerp_dot(const f32x16& v, const float* __restrict__ tl, const float* __restrict__ tr, float t) {
+    const f32x16 a = load16(tl), b = load16(tr);
     float sa0 = 0.0f, sa1 = 0.0f, sb0 = 0.0f, sb1 = 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
-        sa0 = __builtin_fmaf(q[r], a[r], sa0);
-        sb0 = __builtin_fmaf(q[r], b[r], sb0);
-        sa1 = __builtin_fmaf(q[r + 1], a[r + 1], sa1);
-        sb1 = __builtin_fmaf(q[r + 1], b[r + 1], sb1);
+        sa0 = __builtin_fmaf(v[r], a[r], sa0);
+        sb0 = __builtin_fmaf(v[r], b[r], sb0);
+        sa1 = __builtin_fmaf(v[r + 1], a[r + 1], sa1);
+        sb1 = __builtin_fmaf(v[r + 1], b[r + 1], sb1);
     }
     const float A = sa0 + sa1, Bv = sb0 + sb1;
     return xhalf_sum(__builtin_fmaf(Bv - A, t, A));
 }
 
+// sigmoid weights of one block and their two sums: S1 = sum v, Sf = sum v*fk (over the walker's 32 rows)
+__device__ __forceinline__ void sigmoid_block(f32x16& o, const float* fk_lds, int h, float& S1, float& Sf) {
+    const f32x16 fk = load16(fk_lds + h * 16);
+    float s1 = 0.0f, sf = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float v = act_sigmoid(o[r]);
+        o[r] = v;
+        s1 += v;
+        sf = __builtin_fmaf(v, fk[r], sf);
+    }
+    S1 = xhalf_sum(s1);
+    Sf = xhalf_sum(sf);
+}
+
+// per-net prologue record for output dimension 0 (LDS): v0[2][16], then scalars
+constexpr int kDim0Floats = 48;
+
 template <int D, int kWaves>
 __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev* __restrict__ mp, int mode, const float* __restrict__ xg, int64_t B,
                                                       float* __restrict__ out, float* __restrict__ u_out, int32_t* __restrict__ idx_out) {
+    using O = NetOff<D>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const MfmaDev& mm = *mp;
-    // ---- prologue: stage every net's weight image into LDS (one pass, 16 B per lane)
+    // ---- prologue 1: stage every net's weight image + constants into LDS (one pass, 16 B per lane)
     {
         const f32x4* src = reinterpret_cast<const f32x4*>(mm.image);
         f32x4* dst = reinterpret_cast<f32x4*>(lds);
@@ -209,12 +231,61 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev* __restrict_
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
+    const float* consts = lds + mm.const_off;
+    const float* fkI = consts;        // [2][16] remove_bias * keep factors of the flow-layer I-spline
+    const float* fkP = consts + 32;   // [2][16] prior: keep (B) or remove_bias * keep (M)
+    const float* ob2b = consts + 64;  // [4][64][4] ob_to_b in f32-MFMA A order
+    float* dim0 = lds + mm.image_floats;   // [n_nets][kDim0Floats], written below
+    const int n_nets = mm.n_layers + ((mm.prior_kind == WF_PRIOR_WAVEFLOW || mm.prior_kind == WF_PRIOR_MFLOW) ? 1 : 0);
+
+    // ---- prologue 2: output dimension 0 of every net is input-independent -> once per workgroup
+    for (int n = wave; n < n_nets; n += kWaves) {
+        const float* net = lds + mm.net_off[n];
+        f32x16 o = load16(net + O::b2 + (0 * 2 + h) * 16);
+        float* rec = dim0 + n * kDim0Floats;
+        const bool is_prior = n == mm.n_layers;
+        if (!is_prior && mm.layer_kind == WF_LAYER_MADE) {
+            // rows 0 / 1 = log_weight / bias
+            if (lane == 0) { rec[32] = o[0]; rec[33] = o[1]; }
+        } else if (is_prior && mm.prior_kind == WF_PRIOR_WAVEFLOW) {
+            const f32x16 keep = load16(fkP + h * 16);
+            float s1 = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s1 += o[r]; o[r] = o[r] * keep[r]; }
+            s1 = xhalf_sum(s1);
+            f32x16 c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const f32x4 a4 = *reinterpret_cast<const f32x4*>(ob2b + (r4 * 64 + lane) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], o[4 * r4 + e], c, 0, 0, 0);
+            }
+            float n2 = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) n2 = __builtin_fmaf(c[r], c[r], n2);
+            n2 = xhalf_sum(n2);
+            if (j == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rec[h * 16 + r] = c[r];
+            }
+            if (lane == 0) { rec[32] = __builtin_amdgcn_rsqf(n2); rec[33] = s1 < 0.0f ? -1.0f : 1.0f; }
+        } else {
+            float S1, Sf;
+            sigmoid_block(o, is_prior ? fkP : fkI, h, S1, Sf);
+            const float reg = is_prior ? 0.0f : mm.i_reg;
+            const float F = is_prior ? mm.F_P : mm.F_I;
+            const float rs = reg * S1;
+            if (j == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rec[h * 16 + r] = o[r];
+            }
+            if (lane == 0) { rec[32] = 1.0f / __builtin_fmaf(rs, F, Sf); rec[33] = rs; }
+        }
+    }
+    __syncthreads();
+
     const int64_t n_tiles = (B + 31) >> 5;
     const int idx_stride = (mm.n_layers + 1) * D * 2;
-    const float* consts = lds + mm.const_off;
-    const float* fkI = consts;            // [2][16]
-    const float* fkP = consts + 32;       // [2][16]
-    const float* ob2b = consts + 64;      // [4][64][4]
     const float L = mm.box_L, tol = 1e-7f;
 
     for (int64_t tile = (int64_t)blockIdx.x * kWaves + wave; tile < n_tiles; tile += (int64_t)gridDim.x * kWaves) {
@@ -226,7 +297,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev* __restrict_
         for (int d = 0; d < D; ++d) cur[d] = xg[wl * D + d];
         int32_t* idx = (idx_out && valid && h == 0) ? idx_out + w * idx_stride : nullptr;
 
-        // ---- BoxTransformLayer (made.py:118-137, 156-183)
+        // ---- BoxTransformLayer (made.py:118-137, 156-183); IEEE divisions: layer-0 bin indices must be exact
         float logdet = 0.0f;
         if (mm.box_kind == WF_BOX_MEAN) {
             float s = 0.0f;
@@ -262,31 +333,52 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev* __restrict_
         // ---- flow layers
         for (int l = 0; l < mm.n_layers; ++l) {
             const float* net = lds + mm.net_off[l];
-            f32x16 h2[2];
+            const float* rec = dim0 + l * kDim0Floats;
+            Frag h2[2];
             hidden_layers<D>(net, cur, lane, h2);
             if (mm.layer_kind == WF_LAYER_IMADE) {
-                const int nb = mm.i_nb;
 #pragma unroll
                 for (int d = 0; d < D; ++d) {
-                    f32x16 q = out_block<D>(net, h2, d, lane);
-                    const float S = spline_weights(q, fkI, mm.i_reg, nb, h);
+                    f32x16 v;
+                    float rS, rs;
+                    if (d == 0) {
+                        v = load16(rec + h * 16);
+                        rS = rec[32];
+                        rs = rec[33];
+                    } else {
+                        v = out_block<D>(net, h2, d, lane);
+                        float S1, Sf;
+                        sigmoid_block(v, fkI, h, S1, Sf);
+                        rs = mm.i_reg * S1;
+                        rS = __builtin_amdgcn_rcpf(__builtin_fmaf(rs, mm.F_I, Sf));
+                    }
                     const Lerp Lp = make_lerp(cur[d], mm.n_mesh);
                     if (idx) { idx[(l * D + d) * 2] = Lp.xl; idx[(l * D + d) * 2 + 1] = Lp.xr; }
-                    const float* tl = mm.tabI + ((size_t)Lp.il * 4 + h) * 16;   // [mesh][nd][h][16]
+                    const float* tl = mm.tabI + ((size_t)Lp.il * 4 + h) * 16;   // [mesh][nd][h][16], fk pre-multiplied
                     const float* tr = mm.tabI + ((size_t)Lp.ir * 4 + h) * 16;
-                    const float ynum = lerp_dot(q, tl, tr, Lp.t);
-                    const float dnum = lerp_dot(q, tl + 32, tr + 32, Lp.t);
-                    const float rS = 1.0f / S;
+                    const f32x2 rl = *reinterpret_cast<const f32x2*>(mm.rsI + (size_t)Lp.il * 2);   // row sums [mesh][nd]
+                    const f32x2 rr = *reinterpret_cast<const f32x2*>(mm.rsI + (size_t)Lp.ir * 2);
+                    float ynum = lerp_dot(v, tl, tr, Lp.t);
+                    float dnum = lerp_dot(v, tl + 32, tr + 32, Lp.t);
+                    ynum = __builtin_fmaf(rs, __builtin_fmaf(rr[0] - rl[0], Lp.t, rl[0]), ynum);
+                    dnum = __builtin_fmaf(rs, __builtin_fmaf(rr[1] - rl[1], Lp.t, rl[1]), dnum);
                     nxt[d] = ynum * rS;
-                    logdet = logdet + fast_log(dnum * rS + 1e-7f);
+                    logdet = logdet + fast_log(__builtin_fmaf(dnum, rS, 1e-7f));
                 }
             } else {
                 // MADE (made.py:21-27): rows 0 / 1 of block d = log_weight / bias (lane half 0, registers 0 / 1)
                 float ls = 0.0f;
 #pragma unroll
                 for (int d = 0; d < D; ++d) {
-                    const f32x16 o = out_block<D>(net, h2, d, lane);
-                    const float lw = __shfl(o[0], j), bias = __shfl(o[1], j);
+                    float lw, bias;
+                    if (d == 0) {
+                        lw = rec[32];
+                        bias = rec[33];
+                    } else {
+                        const f32x16 o = out_block<D>(net, h2, d, lane);
+                        lw = __shfl(o[0], j);
+                        bias = __shfl(o[1], j);
+                    }
                     nxt[d] = (cur[d] - bias) * __expf(-lw);
                     ls = ls + lw;
                 }
@@ -301,42 +393,45 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev* __restrict_
         if (mode != 2) {
             if (mm.prior_kind == WF_PRIOR_WAVEFLOW) {
                 const float* net = lds + mm.net_off[mm.n_layers];
-                const int nb = mm.p_nb;
-                f32x16 h2[2];
+                const float* rec = dim0 + mm.n_layers * kDim0Floats;
+                Frag h2[2];
                 hidden_layers<D>(net, cur, lane, h2);
-                const f32x16 keep = lds_load16(fkP + h * 16);
+                const f32x16 keep = load16(fkP + h * 16);
                 float lp = 0.0f, prod = 1.0f;
 #pragma unroll
                 for (int d = 0; d < D; ++d) {
-                    f32x16 o = out_block<D>(net, h2, d, lane);
-                    float s1 = 0.0f;
+                    f32x16 c;
+                    float rnorm, sgn;
+                    if (d == 0) {
+                        c = load16(rec + h * 16);
+                        rnorm = rec[32];
+                        sgn = rec[33];
+                    } else {
+                        f32x16 o = out_block<D>(net, h2, d, lane);
+                        float s1 = 0.0f;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        o[r] = row_of(r, 0) + 4 * h < nb ? o[r] : 0.0f;
-                        s1 += o[r];
-                        o[r] = o[r] * keep[r];
+                        for (int r = 0; r < 16; ++r) { s1 += o[r]; o[r] = o[r] * keep[r]; }
+                        s1 = xhalf_sum(s1);
+                        // c = (o * keep) @ ob_to_b on v_mfma_f32_32x32x2_f32 (K = 32, unnormalised operands)
+                        c = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; ++r4) {
+                            const f32x4 a4 = *reinterpret_cast<const f32x4*>(ob2b + (r4 * 64 + lane) * 4);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], o[4 * r4 + e], c, 0, 0, 0);
+                        }
+                        float n2 = 0.0f;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) n2 = __builtin_fmaf(c[r], c[r], n2);
+                        rnorm = __builtin_amdgcn_rsqf(xhalf_sum(n2));
+                        sgn = s1 < 0.0f ? -1.0f : 1.0f;
                     }
-                    s1 = xhalf_sum(s1);
-                    // c = (o * keep) @ ob_to_b on the matrix pipe (K = 32)
-                    f32x16 c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-                    for (int r4 = 0; r4 < 4; ++r4) {
-                        const f32x4 a4 = *reinterpret_cast<const f32x4*>(ob2b + (r4 * 64 + lane) * 4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], o[4 * r4 + e], c, 0, 0, 0);
-                    }
-                    float n2 = 0.0f;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) n2 = __builtin_fmaf(c[r], c[r], n2);
-                    n2 = xhalf_sum(n2);
                     cur[d] = fminf(fmaxf(cur[d], 0.0f), 1.0f);
                     const Lerp Lp = make_lerp(cur[d], mm.n_mesh);
                     if (idx) { idx[(mm.n_layers * D + d) * 2] = Lp.xl; idx[(mm.n_layers * D + d) * 2 + 1] = Lp.xr; }
                     const float* tl = mm.tabP + ((size_t)Lp.il * 2 + h) * 16;   // [mesh][h][16]
                     const float* tr = mm.tabP + ((size_t)Lp.ir * 2 + h) * 16;
-                    const float num = lerp_dot(c, tl, tr, Lp.t);
-                    float v = num * __builtin_amdgcn_rsqf(n2);
-                    v = s1 < 0.0f ? -v : v;
+                    float v = lerp_dot(c, tl, tr, Lp.t) * rnorm * sgn;
                     const bool constrained = (mm.constrained_mask >> d) & 1u;
                     if (mode == 0) {
                         float pr = v * v;
@@ -350,21 +445,29 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev* __restrict_
                 result = mode == 0 ? lp + logdet : prod * __expf(0.5f * logdet);
             } else if (mm.prior_kind == WF_PRIOR_MFLOW) {
                 const float* net = lds + mm.net_off[mm.n_layers];
-                const int nb = mm.p_nb;
-                f32x16 h2[2];
+                const float* rec = dim0 + mm.n_layers * kDim0Floats;
+                Frag h2[2];
                 hidden_layers<D>(net, cur, lane, h2);
                 float lp = 0.0f;
 #pragma unroll
                 for (int d = 0; d < D; ++d) {
-                    f32x16 q = out_block<D>(net, h2, d, lane);
-                    const float S = spline_weights(q, fkP, 0.0f, nb, h);
+                    f32x16 v;
+                    float rS;
+                    if (d == 0) {
+                        v = load16(rec + h * 16);
+                        rS = rec[32];
+                    } else {
+                        v = out_block<D>(net, h2, d, lane);
+                        float S1, Sf;
+                        sigmoid_block(v, fkP, h, S1, Sf);
+                        rS = __builtin_amdgcn_rcpf(Sf);
+                    }
                     cur[d] = fminf(fmaxf(cur[d], 0.0f), 1.0f);
                     const Lerp Lp = make_lerp(cur[d], mm.n_mesh);
                     if (idx) { idx[(mm.n_layers * D + d) * 2] = Lp.xl; idx[(mm.n_layers * D + d) * 2 + 1] = Lp.xr; }
-                    const float* tl = mm.tabP + ((size_t)Lp.il * 2 + h) * 16;
+                    const float* tl = mm.tabP + ((size_t)Lp.il * 2 + h) * 16;   // fk pre-multiplied
                     const float* tr = mm.tabP + ((size_t)Lp.ir * 2 + h) * 16;
-                    const float v = lerp_dot(q, tl, tr, Lp.t) / S;
-                    lp = lp + fast_log(v + 1e-7f);
+                    lp = lp + fast_log(__builtin_fmaf(lerp_dot(v, tl, tr, Lp.t), rS, 1e-7f));
                 }
                 result = lp + logdet;
             } else if (mm.prior_kind == WF_PRIOR_UNIFORM) {
@@ -433,6 +536,8 @@ int launch_d(const MfmaDev* mdev, int lds_bytes, int mode, const float* x, int64
 }
 
 }  // namespace
+
+int mfma_extra_lds_floats(int n_nets) { return n_nets * kDim0Floats; }
 
 int launch_mfma(int D, const MfmaDev* mdev, int lds_bytes, int mode, const float* x, int64_t B, float* out, float* u, int32_t* idx,
                 void* stream) {

@@ -364,19 +364,40 @@ static void row_factors(int kind, bool with_remove_bias, int k, int nb, const wf
         for (int r = 0; r < 16; ++r) out32[h * 16 + r] = f[acc_row(r, h)];
 }
 
-// [n_mesh][n_orders][half][16]
-static void pack_rows_acc(const std::vector<double>& t64, int nb, int n_mesh, int n_orders, std::vector<float>& out) {
+// [n_mesh][n_orders][half][16], each row scaled by fk[row] (may be null); rowsum (may be null): [n_mesh][n_orders]
+static void pack_rows_acc(const std::vector<double>& t64, int nb, int n_mesh, int n_orders, const float* fk32 /* [2][16] */,
+                          std::vector<float>& out, std::vector<float>* rowsum) {
     out.assign((size_t)n_mesh * n_orders * 32, 0.0f);
+    if (rowsum) rowsum->assign((size_t)n_mesh * n_orders, 0.0f);
     for (int m = 0; m < n_mesh; ++m)
-        for (int nd = 0; nd < n_orders; ++nd)
+        for (int nd = 0; nd < n_orders; ++nd) {
+            double rs = 0.0;
             for (int h = 0; h < 2; ++h)
                 for (int r = 0; r < 16; ++r) {
                     const int row = acc_row(r, h);
-                    if (row < nb) out[(((size_t)m * n_orders + nd) * 2 + h) * 16 + r] = (float)t64[((size_t)nd * nb + row) * n_mesh + m];
+                    if (row >= nb) continue;
+                    const float t = (float)t64[((size_t)nd * nb + row) * n_mesh + m];   // the reference's fp32 table entry
+                    const float v = fk32 ? (float)((double)fk32[h * 16 + r] * (double)t) : t;
+                    out[(((size_t)m * n_orders + nd) * 2 + h) * 16 + r] = v;
+                    rs += (double)v;
                 }
+            if (rowsum) (*rowsum)[(size_t)m * n_orders + nd] = (float)rs;
+        }
 }
 
-// LDS image of net n in MFMA operand order (wf_kernels_mfma.hip)
+// x = hi + lo * 2^-11 with hi, lo in fp16 (round to nearest)
+static inline void split_f16(float x, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)x;
+    lo = (_Float16)((x - (float)hi) * 2048.0f);
+}
+
+static bool net_has_sigmoid_head(const wf_model* m, int n) {
+    const bool is_prior = n == m->desc.n_flow_layers;
+    if (is_prior) return m->desc.prior_kind == WF_PRIOR_MFLOW;
+    return m->desc.layer_kind == WF_LAYER_IMADE;
+}
+
+// LDS image of net n in MFMA operand order (wf_kernels_mfma.hip: NetOff<D>)
 static void build_mfma_image(const wf_model* m, int n, const float* flat, float* img) {
     const int D = m->desc.n_dim, H = kHidden;
     const int S0 = (D + 1) / 2;
@@ -388,45 +409,62 @@ static void build_mfma_image(const wf_model* m, int n, const float* flat, float*
     const float* b1 = W1 + (int64_t)H * H;
     const float* W2 = b1 + H;
     const float* b2 = W2 + (int64_t)H * NO;
+    // folded activation scales: tanh(x) = 1 - 2/(2^(c1 x) + 1), sigmoid(x) = 1/(1 + 2^(c2 x))
+    const double c1 = 2.0 * 1.4426950408889634074;
+    const bool sig = net_has_sigmoid_head(m, n);
+    const double c2 = sig ? -1.4426950408889634074 : 1.0;
     float* o = img;
-    // layer 0: A[i = unit 32*ob + (lane&31)][k = 2s + (lane>>5)]
+    // layer 0 (f32 MFMA): A[i = unit 32*ob + (lane&31)][k = 2s + (lane>>5)]
     for (int ob = 0; ob < 2; ++ob)
         for (int s = 0; s < S0; ++s)
             for (int lane = 0; lane < 64; ++lane) {
                 const int unit = 32 * ob + (lane & 31), k = 2 * s + (lane >> 5);
-                *o++ = (k < D && deg_hidden(unit, D) >= deg_in(k)) ? W0[(int64_t)k * H + unit] : 0.0f;
+                *o++ = (k < D && deg_hidden(unit, D) >= deg_in(k)) ? (float)(c1 * (double)W0[(int64_t)k * H + unit]) : 0.0f;
             }
     for (int ob = 0; ob < 2; ++ob)
         for (int h = 0; h < 2; ++h)
-            for (int r = 0; r < 16; ++r) *o++ = b0[32 * ob + acc_row(r, h)];
-    // layer 1: step (t, r) contracts hidden unit kk = 32t + acc_row(r, lane>>5)
-    for (int ob = 0; ob < 2; ++ob)
-        for (int t = 0; t < 2; ++t)
-            for (int r4 = 0; r4 < 4; ++r4)
-                for (int lane = 0; lane < 64; ++lane)
-                    for (int e = 0; e < 4; ++e) {
-                        const int unit = 32 * ob + (lane & 31), kk = 32 * t + acc_row(4 * r4 + e, lane >> 5);
-                        *o++ = deg_hidden(unit, D) >= deg_hidden(kk, D) ? W1[(int64_t)kk * H + unit] : 0.0f;
-                    }
+            for (int r = 0; r < 16; ++r) *o++ = (float)(c1 * (double)b0[32 * ob + acc_row(r, h)]);
+    // layer 1 (f16 MFMA, K = 16 per step): step (t, s), element j of lane half h contracts hidden unit
+    // kk = 32t + acc_row(8s + j, h);  images [ob][t][s][lane][8] for hi then lo
+    {
+        _Float16* hi = reinterpret_cast<_Float16*>(o);
+        _Float16* lo = hi + 4096;
+        for (int ob = 0; ob < 2; ++ob)
+            for (int t = 0; t < 2; ++t)
+                for (int s = 0; s < 2; ++s)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int unit = 32 * ob + (lane & 31), kk = 32 * t + acc_row(8 * s + j, lane >> 5);
+                            const float v = deg_hidden(unit, D) >= deg_hidden(kk, D) ? (float)(c1 * (double)W1[(int64_t)kk * H + unit]) : 0.0f;
+                            split_f16(v, *hi++, *lo++);
+                        }
+        o += 4096;
+    }
     for (int ob = 0; ob < 2; ++ob)
         for (int h = 0; h < 2; ++h)
-            for (int r = 0; r < 16; ++r) *o++ = b1[32 * ob + acc_row(r, h)];
-    // output layer, dimensions 1..D-1 (dimension 0 has no inputs): A[i = basis (lane&31)][k = kk]
-    for (int d = 1; d < D; ++d)
-        for (int t = 0; t < 2; ++t)
-            for (int r4 = 0; r4 < 4; ++r4)
-                for (int lane = 0; lane < 64; ++lane)
-                    for (int e = 0; e < 4; ++e) {
-                        const int jb = lane & 31, kk = 32 * t + acc_row(4 * r4 + e, lane >> 5);
-                        float v = 0.0f;
-                        if (jb < nl.n_out && deg_out(d) >= deg_hidden(kk, D)) v = W2[(int64_t)kk * NO + (jb * D + d)];
-                        *o++ = v;
-                    }
+            for (int r = 0; r < 16; ++r) *o++ = (float)(c1 * (double)b1[32 * ob + acc_row(r, h)]);
+    // output layer, dimensions 1..D-1: A[i = basis (lane&31)][k = kk]
+    {
+        _Float16* hi = reinterpret_cast<_Float16*>(o);
+        _Float16* lo = hi + (D - 1) * 2048;
+        for (int d = 1; d < D; ++d)
+            for (int t = 0; t < 2; ++t)
+                for (int s = 0; s < 2; ++s)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int jb = lane & 31, kk = 32 * t + acc_row(8 * s + j, lane >> 5);
+                            float v = 0.0f;
+                            if (jb < nl.n_out && deg_out(d) >= deg_hidden(kk, D)) v = (float)(c2 * (double)W2[(int64_t)kk * NO + (jb * D + d)]);
+                            split_f16(v, *hi++, *lo++);
+                        }
+        o += (D - 1) * 2048;
+    }
+    // biases; padding rows of sigmoid heads get +1e30 so that sigmoid(-x) -> 0 exactly
     for (int d = 0; d < D; ++d)
         for (int h = 0; h < 2; ++h)
             for (int r = 0; r < 16; ++r) {
                 const int jb = acc_row(r, h);
-                *o++ = jb < nl.n_out ? b2[jb * D + d] : 0.0f;
+                *o++ = jb < nl.n_out ? (float)(c2 * (double)b2[jb * D + d]) : (sig ? 1e30f : 0.0f);
             }
 }
 
@@ -444,7 +482,7 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
     const int n_nets = (int)m->nets.size();
     const int consts = 32 + 32 + 1024;
     const int64_t total = (int64_t)mfma_net_floats(D) * n_nets + consts;
-    if (total * 4 > 160 * 1024) return WF_OK;  // all nets must be LDS-resident
+    if ((total + mfma_extra_lds_floats(n_nets)) * 4 > 160 * 1024) return WF_OK;  // all nets must be LDS-resident
 
     MfmaDev& md = m->mdev;
     md = MfmaDev{};
@@ -457,17 +495,28 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
 
     m->mfma_consts.assign(consts, 0.0f);
     if (imade) {
-        row_factors(WF_SPLINE_I, true, d.i_degree, m->i_nb, d.i_left, d.i_right, m->mfma_consts.data());
-        std::vector<float> rows;
-        pack_rows_acc(i64, m->i_nb, d.n_mesh, 2, rows);
+        float* fk = m->mfma_consts.data();
+        row_factors(WF_SPLINE_I, true, d.i_degree, m->i_nb, d.i_left, d.i_right, fk);
+        double F = 0;
+        for (int i = 0; i < 32; ++i) F += fk[i];
+        md.F_I = (float)F;
+        std::vector<float> rows, rowsum;
+        pack_rows_acc(i64, m->i_nb, d.n_mesh, 2, fk, rows, &rowsum);
         int rc = upload_table(m, rows, &md.tabI);
+        if (rc) return rc;
+        rc = upload_table(m, rowsum, &md.rsI);
         if (rc) return rc;
     }
     if (spline_prior) {
         const bool mflow = d.prior_kind == WF_PRIOR_MFLOW;
-        row_factors(mflow ? WF_SPLINE_M : WF_SPLINE_B, mflow, d.p_degree, m->p_nb, d.p_left, d.p_right, m->mfma_consts.data() + 32);
+        float* fk = m->mfma_consts.data() + 32;
+        row_factors(mflow ? WF_SPLINE_M : WF_SPLINE_B, mflow, d.p_degree, m->p_nb, d.p_left, d.p_right, fk);
+        double F = 0;
+        for (int i = 0; i < 32; ++i) F += fk[i];
+        md.F_P = (float)F;
         std::vector<float> rows;
-        pack_rows_acc(p64, m->p_nb, d.n_mesh, 1, rows);
+        // M prior: the row factors are folded into the table; B prior: they act on the weights before ob_to_b
+        pack_rows_acc(p64, m->p_nb, d.n_mesh, 1, mflow ? fk : nullptr, rows, nullptr);
         int rc = upload_table(m, rows, &md.tabP);
         if (rc) return rc;
         if (!mflow) {
@@ -632,7 +681,7 @@ static int dispatch(const wf_model* m, int mode, const float* x, int64_t B, floa
     DeviceGuard g(m->device);
     if (B == 0) return WF_OK;
     const bool use_mfma = m->mfma_ok && m->kernel_kind != WF_KERNEL_SCALAR;
-    if (use_mfma) return launch_mfma(m->dev.D, m->d_mdev, (int)(m->mfma_floats * sizeof(float)), mode, x, B, out, u, idx, stream);
+    if (use_mfma) return launch_mfma(m->dev.D, m->d_mdev, (int)((m->mfma_floats + mfma_extra_lds_floats((int)m->nets.size())) * sizeof(float)), mode, x, B, out, u, idx, stream);
     return launch_scalar(m->dev, m->d_dev, mode, x, B, out, u, idx, stream);
 }
 
