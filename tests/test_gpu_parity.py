@@ -290,6 +290,36 @@ def test_full_size_properties(he_flat, kernel):
     assert np.array_equal(sums, log_pdf.model.block_sums(lp).cpu().numpy())
 
 
+def test_mfma_kernel_is_bit_reproducible_and_matches_scalar_at_full_size(he_flat):
+    """Guards against the scheduling-dependent corruption described in DESIGN.md §9: every workgroup shape, repeated
+    launches, 2^20 walkers; results must be identical launch to launch and agree with the scalar kernel."""
+    import os
+    torch = _torch()
+    params, psi, log_pdf, om = he_models(he_flat, "scalar")
+    m = log_pdf.model
+    m.ensure_params(params)
+    B = 1 << 20
+    x = torch.from_numpy(sorted_walkers(B, 2, 10.0, 99)).cuda()
+    ref = m.log_pdf(x)
+    ref_psi = m.psi(x)
+    m.set_kernel("mfma")
+    old = os.environ.get("WF_MFMA_WAVES")
+    try:
+        for waves in ("8", "12", "16"):
+            os.environ["WF_MFMA_WAVES"] = waves
+            first = m.log_pdf(x)
+            # fp32 noise between the two kernels is <~1e-2 absolute (tolerance section above); a corrupted tile is off by >0.05
+            assert ((first - ref).abs() > 0.05).sum().item() == 0, waves
+            assert ((m.psi(x) - ref_psi).abs() > 1e-3 * ref_psi.abs().max()).sum().item() == 0, waves
+            for _ in range(8):
+                assert torch.equal(m.log_pdf(x), first), waves
+    finally:
+        if old is None:
+            os.environ.pop("WF_MFMA_WAVES", None)
+        else:
+            os.environ["WF_MFMA_WAVES"] = old
+
+
 def test_abi_error_paths(he_flat):
     import ctypes
     from waveflow_amd import _lib

@@ -13,6 +13,7 @@ SOURCES = ["wf_tables.cpp", "wf_model.cpp", "wf_kernels_scalar.hip", "wf_kernels
 # -ffp-contract=off: the index arithmetic and the table lerp keep the reference's separate
 # multiply / add roundings; dot products that may fuse say so with explicit fmaf / MFMA.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+FLAGS += os.environ.get("WF_CXXFLAGS", "").split()  # experiment switches (-DWF_...)
 
 
 def _hipcc():

@@ -79,6 +79,7 @@ struct MfmaDev {
     const float* tabI;         // [n_mesh][nd 0..1][half][16] fp32: fk_row * I_row, accumulator row order
     const float* rsI;          // [n_mesh][nd 0..1]: sum over rows of tabI
     const float* tabP;         // [n_mesh][half][16] fp32, prior rows (orthogonal-B as is; M: fk_row * M_row), nd 0
+    float* dbg;                // diagnostics builds only (WF_DEBUG)
 };
 
 int launch_mfma(int D, const MfmaDev* mdev, int lds_bytes, int mode, const float* x, int64_t B, float* out, float* u,

@@ -53,11 +53,14 @@ __device__ __forceinline__ float act_sigmoid(float xs) {  // xs = -log2(e)*x
 }
 __device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
 
-// sum of the two lane halves (lane l and l^32), result in every lane
+// sum of the two lane halves (lane l and l^32), result in every lane.
+// v_permlane32_swap is issued from inline asm with its own wait states: with the builtin, hipcc (ROCm 7.2) pads
+// only the "VALU write -> permlane read" side, and this kernel then produced wrong sums on a few tiles per
+// launch (non-deterministically; gone with ds_bpermute, gone with the padding below).  See DESIGN.md §9.
 __device__ __forceinline__ float xhalf_sum(float v) {
-    const unsigned u = __float_as_uint(v);
-    const auto s = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return __uint_as_float(s[0]) + __uint_as_float(s[1]);
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 3" : "+v"(a), "+v"(b));
+    return a + b;
 }
 
 __device__ __forceinline__ f32x16 load16(const float* p) {
@@ -110,6 +113,10 @@ __device__ __forceinline__ void split_block(const f32x16& x, Frag& f) {
 __device__ __forceinline__ f32x16 dense64_block(const _Float16* Wh, const _Float16* Wl, const Frag (&in)[2], f32x16 bias, int lane) {
     f32x16 acc1 = bias;
     f32x16 acc2 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // Scheduling fences around the f16 MFMA chain: when hipcc (ROCm 7.2) interleaved unrelated VALU / memory
+    // instructions of the neighbouring code into this chain, a few tiles per launch came out wrong,
+    // non-deterministically.  With the chain fenced the kernel is bit-reproducible; cost < 1 %.
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -120,6 +127,7 @@ __device__ __forceinline__ f32x16 dense64_block(const _Float16* Wh, const _Float
             acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, in[t].lo[s], acc2, 0, 0, 0);
             acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, in[t].hi[s], acc2, 0, 0, 0);
         }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc1[r] = __builtin_fmaf(acc2[r], kLoInv, acc1[r]);
     return acc1;
@@ -196,6 +204,29 @@ __device__ __forceinline__ float lerp_dot(const f32x16& v, const float* __restri
     return xhalf_sum(__builtin_fmaf(Bv - A, t, A));
 }
 
+#ifdef WF_DEBUG
+__device__ __forceinline__ float lerp_dot_dbg(const f32x16& v, const float* __restrict__ tl, const float* __restrict__ tr, float t, float* g) {
+    const f32x16 a = load16(tl), b = load16(tr);
+    float sa0 = 0.0f, sa1 = 0.0f, sb0 = 0.0f, sb1 = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        sa0 = __builtin_fmaf(v[r], a[r], sa0);
+        sb0 = __builtin_fmaf(v[r], b[r], sb0);
+        sa1 = __builtin_fmaf(v[r + 1], a[r + 1], sa1);
+        sb1 = __builtin_fmaf(v[r + 1], b[r + 1], sb1);
+    }
+    const float A = sa0 + sa1, Bv = sb0 + sb1;
+    const float part = __builtin_fmaf(Bv - A, t, A);
+    const float res = xhalf_sum(part);
+    if (g) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { g[r] = a[r]; g[16 + r] = b[r]; g[32 + r] = v[r]; }
+        g[48] = A; g[49] = Bv; g[50] = part; g[51] = res; g[52] = t;
+    }
+    return res;
+}
+#endif
+
 // sigmoid weights of one block and their two sums: S1 = sum v, Sf = sum v*fk (over the walker's 32 rows)
 __device__ __forceinline__ void sigmoid_block(f32x16& o, const float* fk_lds, int h, float& S1, float& Sf) {
     const f32x16 fk = load16(fk_lds + h * 16);
@@ -215,11 +246,12 @@ __device__ __forceinline__ void sigmoid_block(f32x16& o, const float* fk_lds, in
 constexpr int kDim0Floats = 48;
 
 template <int D, int kWaves>
-__global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev* __restrict__ mp, int mode, const float* __restrict__ xg, int64_t B,
+__global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode, const float* __restrict__ xg, int64_t B,
                                                       float* __restrict__ out, float* __restrict__ u_out, int32_t* __restrict__ idx_out) {
+    // mm is passed BY VALUE: it lives in the kernarg segment, so its fields are scalar loads and the table pointers
+    // are known to be global (with a pointer-to-struct argument hipcc emitted flat_load for every table access).
     using O = NetOff<D>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const MfmaDev& mm = *mp;
     // ---- prologue 1: stage every net's weight image + constants into LDS (one pass, 16 B per lane)
     {
         const f32x4* src = reinterpret_cast<const f32x4*>(mm.image);
@@ -358,7 +390,12 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev* __restrict_
                     const float* tr = mm.tabI + ((size_t)Lp.ir * 4 + h) * 16;
                     const f32x2 rl = *reinterpret_cast<const f32x2*>(mm.rsI + (size_t)Lp.il * 2);   // row sums [mesh][nd]
                     const f32x2 rr = *reinterpret_cast<const f32x2*>(mm.rsI + (size_t)Lp.ir * 2);
+#ifdef WF_DEBUG
+                    float* gdb = (mm.dbg && l == mm.n_layers - 1 && d == 0 && valid) ? mm.dbg + (w * 2 + h) * 64 : nullptr;
+                    float ynum = lerp_dot_dbg(v, tl, tr, Lp.t, gdb);
+#else
                     float ynum = lerp_dot(v, tl, tr, Lp.t);
+#endif
                     float dnum = lerp_dot(v, tl + 32, tr + 32, Lp.t);
                     ynum = __builtin_fmaf(rs, __builtin_fmaf(rr[0] - rl[0], Lp.t, rl[0]), ynum);
                     dnum = __builtin_fmaf(rs, __builtin_fmaf(rr[1] - rl[1], Lp.t, rl[1]), dnum);
@@ -508,7 +545,7 @@ int launch_dw(const MfmaDev* mdev, int lds_bytes, int mode, const float* x, int6
     const int64_t n_tiles = (B + 31) / 32;
     int64_t grid = (n_tiles + kWaves - 1) / kWaves;
     if (grid > 256) grid = 256;  // one persistent workgroup per CU
-    hipLaunchKernelGGL((k_mfma<D, kWaves>), dim3((unsigned)grid), dim3(kWaves * 64), lds_bytes, s, mdev, mode, x, B, out, u, idx);
+    hipLaunchKernelGGL((k_mfma<D, kWaves>), dim3((unsigned)grid), dim3(kWaves * 64), lds_bytes, s, *mdev, mode, x, B, out, u, idx);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_hip_error((int)e);
@@ -518,12 +555,9 @@ int launch_dw(const MfmaDev* mdev, int lds_bytes, int mode, const float* x, int6
 }
 
 int waves_per_group() {
-    static int w = [] {
-        const char* e = getenv("WF_MFMA_WAVES");  // tuning knob: 8, 12 or 16 waves per workgroup
-        const int v = e ? atoi(e) : 0;
-        return (v == 8 || v == 12 || v == 16) ? v : 12;
-    }();
-    return w;
+    const char* e = getenv("WF_MFMA_WAVES");  // tuning knob (read at every launch): 8, 12 or 16 waves per workgroup
+    const int v = e ? atoi(e) : 0;
+    return (v == 8 || v == 12 || v == 16) ? v : 12;
 }
 
 template <int D>

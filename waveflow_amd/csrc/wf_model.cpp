@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <memory>
@@ -681,7 +682,10 @@ static int dispatch(const wf_model* m, int mode, const float* x, int64_t B, floa
     DeviceGuard g(m->device);
     if (B == 0) return WF_OK;
     const bool use_mfma = m->mfma_ok && m->kernel_kind != WF_KERNEL_SCALAR;
-    if (use_mfma) return launch_mfma(m->dev.D, m->d_mdev, (int)((m->mfma_floats + mfma_extra_lds_floats((int)m->nets.size())) * sizeof(float)), mode, x, B, out, u, idx, stream);
+#ifdef WF_DEBUG
+    if (use_mfma && getenv("WF_DBG_PTR")) const_cast<wf_model*>(m)->mdev.dbg = (float*)strtoull(getenv("WF_DBG_PTR"), nullptr, 0);
+#endif
+    if (use_mfma) return launch_mfma(m->dev.D, &m->mdev, (int)((m->mfma_floats + mfma_extra_lds_floats((int)m->nets.size())) * sizeof(float)), mode, x, B, out, u, idx, stream);
     return launch_scalar(m->dev, m->d_dev, mode, x, B, out, u, idx, stream);
 }
 
