@@ -11,8 +11,8 @@
 //     (wf_model.cpp: build_mfma_image).
 // Precision.  On gfx950 the f32-input MFMA runs at the f32 VALU rate and does not overlap with VALU work
 // (measured: profiles/r01_ubench_coexec.txt), so the two K=64 layers use v_mfma_f32_32x32x16_f16 with a
-// two-way fp16 split of both operands: x = hi + lo*2^-11 (hi = rn16(x), lo = rn16((x - hi)*2^11), 22
-// significant bits), three products hi*hi + (hi*lo + lo*hi)*2^-11 accumulated in fp32.  Its error is
+// two-way fp16 split of both operands: x = hi + lo (hi = rn16(x), lo = rn16(x - hi); fp16 subnormals are not
+// flushed, so lo keeps 2^-25 absolute precision), three products hi*hi + hi*lo + lo*hi accumulated in fp32.  Its error is
 // indistinguishable from an fp32 FMA chain (dominated by the fp32 accumulation; tests/test_gpu_parity.py).
 // The K = D input layer and the 32x32 ob_to_b product of the B-prior stay on v_mfma_f32_32x32x2_f32.
 // Constant folding done on the host: 2*log2(e) into (W0,b0,W1,b1) so tanh(x) = 1 - 2/(2^x' + 1) needs no
@@ -43,7 +43,6 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 
-constexpr float kLoScale = 2048.0f, kLoInv = 1.0f / 2048.0f;
 
 __device__ __forceinline__ float act_tanh(float xs) {  // xs = 2*log2(e)*x (scale folded into the weights)
     return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(xs) + 1.0f), 1.0f);
@@ -104,15 +103,14 @@ __device__ __forceinline__ void split_block(const f32x16& x, Frag& f) {
             const float v = x[8 * s + j];
             const _Float16 h = (_Float16)v;
             f.hi[s][j] = h;
-            f.lo[s][j] = (_Float16)((v - (float)h) * kLoScale);
+            f.lo[s][j] = (_Float16)(v - (float)h);   // fp16 subnormals keep 2^-25 absolute precision (not flushed)
         }
 }
 
-// one 32-unit output block of a K=64 layer: acc1 += Ahi*Bhi ; acc2 += Ahi*Blo + Alo*Bhi ; result acc1 + acc2*2^-11
+// one 32-unit output block of a K=64 layer: acc += Ahi*Bhi + Ahi*Blo + Alo*Bhi (fp32 accumulation)
 // Wh / Wl: LDS images [t][s][lane][8 halves] of this block
 __device__ __forceinline__ f32x16 dense64_block(const _Float16* Wh, const _Float16* Wl, const Frag (&in)[2], f32x16 bias, int lane) {
-    f32x16 acc1 = bias;
-    f32x16 acc2 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    f32x16 acc = bias;
     // Scheduling fences around the f16 MFMA chain: when hipcc (ROCm 7.2) interleaved unrelated VALU / memory
     // instructions of the neighbouring code into this chain, a few tiles per launch came out wrong,
     // non-deterministically.  With the chain fenced the kernel is bit-reproducible; cost < 1 %.
@@ -123,14 +121,12 @@ __device__ __forceinline__ f32x16 dense64_block(const _Float16* Wh, const _Float
         for (int s = 0; s < 2; ++s) {
             const f16x8 ah = *reinterpret_cast<const f16x8*>(Wh + ((t * 2 + s) * 64 + lane) * 8);
             const f16x8 al = *reinterpret_cast<const f16x8*>(Wl + ((t * 2 + s) * 64 + lane) * 8);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, in[t].hi[s], acc1, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, in[t].lo[s], acc2, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, in[t].hi[s], acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, in[t].hi[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, in[t].lo[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, in[t].hi[s], acc, 0, 0, 0);
         }
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc1[r] = __builtin_fmaf(acc2[r], kLoInv, acc1[r]);
-    return acc1;
+    return acc;
 }
 
 // float offsets inside a net image (wf_model.cpp: build_mfma_image)
@@ -189,43 +185,49 @@ __device__ __forceinline__ f32x16 out_block(const float* net, const Frag (&h2)[2
     return dense64_block(W2h + (d - 1) * 2048, W2l + (d - 1) * 2048, h2, load16(net + O::b2 + (d * 2 + h) * 16), lane);
 }
 
-// sum_r v_r * lerp(T'_r) over this lane's 16 rows (both halves summed); tl / tr: this half's 16 table values at x_l / x_r
-__device__ __forceinline__ float lerp_dot(const f32x16& v, const float* __restrict__ tl, const float* __restrict__ tr, float t) {
-    const f32x16 a = load16(tl), b = load16(tr);
+// The 16 table values of this lane half at x_l (a) and x_r (b) for one derivative order.
+// (The rows depend on the layer input only, but requesting them before the conditioner MFMAs costs 64 live VGPRs,
+// i.e. a wave per SIMD, and measured no faster: the kernel is issue-bound, not latency-bound.)
+struct Rows {
+    f32x16 a, b;
+};
+__device__ __forceinline__ Rows load_rows(const float* __restrict__ tl, const float* __restrict__ tr) {
+    Rows r;
+    r.a = load16(tl);
+    r.b = load16(tr);
+    return r;
+}
+
+// sum_r v_r * lerp(T'_r) over the walker's 32 rows (both lane halves summed)
+__device__ __forceinline__ float lerp_dot(const f32x16& v, const Rows& R, float t) {
     float sa0 = 0.0f, sa1 = 0.0f, sb0 = 0.0f, sb1 = 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
-        sa0 = __builtin_fmaf(v[r], a[r], sa0);
-        sb0 = __builtin_fmaf(v[r], b[r], sb0);
-        sa1 = __builtin_fmaf(v[r + 1], a[r + 1], sa1);
-        sb1 = __builtin_fmaf(v[r + 1], b[r + 1], sb1);
+        sa0 = __builtin_fmaf(v[r], R.a[r], sa0);
+        sb0 = __builtin_fmaf(v[r], R.b[r], sb0);
+        sa1 = __builtin_fmaf(v[r + 1], R.a[r + 1], sa1);
+        sb1 = __builtin_fmaf(v[r + 1], R.b[r + 1], sb1);
     }
     const float A = sa0 + sa1, Bv = sb0 + sb1;
     return xhalf_sum(__builtin_fmaf(Bv - A, t, A));
 }
 
-#ifdef WF_DEBUG
-__device__ __forceinline__ float lerp_dot_dbg(const f32x16& v, const float* __restrict__ tl, const float* __restrict__ tr, float t, float* g) {
-    const f32x16 a = load16(tl), b = load16(tr);
-    float sa0 = 0.0f, sa1 = 0.0f, sb0 = 0.0f, sb1 = 0.0f;
-#pragma unroll
-    for (int r = 0; r < 16; r += 2) {
-        sa0 = __builtin_fmaf(v[r], a[r], sa0);
-        sb0 = __builtin_fmaf(v[r], b[r], sb0);
-        sa1 = __builtin_fmaf(v[r + 1], a[r + 1], sa1);
-        sb1 = __builtin_fmaf(v[r + 1], b[r + 1], sb1);
-    }
-    const float A = sa0 + sa1, Bv = sb0 + sb1;
-    const float part = __builtin_fmaf(Bv - A, t, A);
-    const float res = xhalf_sum(part);
-    if (g) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { g[r] = a[r]; g[16 + r] = b[r]; g[32 + r] = v[r]; }
-        g[48] = A; g[49] = Bv; g[50] = part; g[51] = res; g[52] = t;
-    }
-    return res;
+// y and log(dy + 1e-7) of one I-spline block from its weights v (unnormalised), rS = 1/sum(q), rs = reg * S1.
+// Table rows [mesh][nd][h][16] (fk pre-multiplied) and their row sums [mesh][nd] are fetched here, one derivative
+// order at a time (32 live registers instead of 64).
+__device__ __forceinline__ void ispline_eval(const MfmaDev& mm, const f32x16& v, const Lerp& Lp, int h, float rS, float rs, float& y,
+                                             float& logdy) {
+    const float* tl = mm.tabI + ((size_t)Lp.il * 4 + h) * 16;
+    const float* tr = mm.tabI + ((size_t)Lp.ir * 4 + h) * 16;
+    const f32x2 rl = *reinterpret_cast<const f32x2*>(mm.rsI + (size_t)Lp.il * 2);
+    const f32x2 rr = *reinterpret_cast<const f32x2*>(mm.rsI + (size_t)Lp.ir * 2);
+    float ynum = lerp_dot(v, load_rows(tl, tr), Lp.t);
+    float dnum = lerp_dot(v, load_rows(tl + 32, tr + 32), Lp.t);
+    ynum = __builtin_fmaf(rs, __builtin_fmaf(rr[0] - rl[0], Lp.t, rl[0]), ynum);
+    dnum = __builtin_fmaf(rs, __builtin_fmaf(rr[1] - rl[1], Lp.t, rl[1]), dnum);
+    y = ynum * rS;
+    logdy = fast_log(__builtin_fmaf(dnum, rS, 1e-7f));
 }
-#endif
 
 // sigmoid weights of one block and their two sums: S1 = sum v, Sf = sum v*fk (over the walker's 32 rows)
 __device__ __forceinline__ void sigmoid_block(f32x16& o, const float* fk_lds, int h, float& S1, float& Sf) {
@@ -241,6 +243,20 @@ __device__ __forceinline__ void sigmoid_block(f32x16& o, const float* fk_lds, in
     S1 = xhalf_sum(s1);
     Sf = xhalf_sum(sf);
 }
+
+#ifdef WF_STAMP
+#define STAMP(k)                                                                                   \
+    do {                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        unsigned long long t_;                                                                     \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                 \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        stamp_acc[k] += t_ - stamp_last;                                                           \
+        stamp_last = t_;                                                                           \
+    } while (0)
+#else
+#define STAMP(k)
+#endif
 
 // per-net prologue record for output dimension 0 (LDS): v0[2][16], then scalars
 constexpr int kDim0Floats = 48;
@@ -319,6 +335,10 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
     const int64_t n_tiles = (B + 31) >> 5;
     const int idx_stride = (mm.n_layers + 1) * D * 2;
     const float L = mm.box_L, tol = 1e-7f;
+#ifdef WF_STAMP
+    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
+#endif
 
     for (int64_t tile = (int64_t)blockIdx.x * kWaves + wave; tile < n_tiles; tile += (int64_t)gridDim.x * kWaves) {
         const int64_t w = tile * 32 + j;
@@ -367,40 +387,39 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
             const float* net = lds + mm.net_off[l];
             const float* rec = dim0 + l * kDim0Floats;
             Frag h2[2];
-            hidden_layers<D>(net, cur, lane, h2);
+            STAMP(0);
+            Lerp Lp[D];
             if (mm.layer_kind == WF_LAYER_IMADE) {
 #pragma unroll
                 for (int d = 0; d < D; ++d) {
-                    f32x16 v;
-                    float rS, rs;
-                    if (d == 0) {
-                        v = load16(rec + h * 16);
-                        rS = rec[32];
-                        rs = rec[33];
-                    } else {
-                        v = out_block<D>(net, h2, d, lane);
-                        float S1, Sf;
-                        sigmoid_block(v, fkI, h, S1, Sf);
-                        rs = mm.i_reg * S1;
-                        rS = __builtin_amdgcn_rcpf(__builtin_fmaf(rs, mm.F_I, Sf));
-                    }
-                    const Lerp Lp = make_lerp(cur[d], mm.n_mesh);
-                    if (idx) { idx[(l * D + d) * 2] = Lp.xl; idx[(l * D + d) * 2 + 1] = Lp.xr; }
-                    const float* tl = mm.tabI + ((size_t)Lp.il * 4 + h) * 16;   // [mesh][nd][h][16], fk pre-multiplied
-                    const float* tr = mm.tabI + ((size_t)Lp.ir * 4 + h) * 16;
-                    const f32x2 rl = *reinterpret_cast<const f32x2*>(mm.rsI + (size_t)Lp.il * 2);   // row sums [mesh][nd]
-                    const f32x2 rr = *reinterpret_cast<const f32x2*>(mm.rsI + (size_t)Lp.ir * 2);
-#ifdef WF_DEBUG
-                    float* gdb = (mm.dbg && l == mm.n_layers - 1 && d == 0 && valid) ? mm.dbg + (w * 2 + h) * 64 : nullptr;
-                    float ynum = lerp_dot_dbg(v, tl, tr, Lp.t, gdb);
-#else
-                    float ynum = lerp_dot(v, tl, tr, Lp.t);
-#endif
-                    float dnum = lerp_dot(v, tl + 32, tr + 32, Lp.t);
-                    ynum = __builtin_fmaf(rs, __builtin_fmaf(rr[0] - rl[0], Lp.t, rl[0]), ynum);
-                    dnum = __builtin_fmaf(rs, __builtin_fmaf(rr[1] - rl[1], Lp.t, rl[1]), dnum);
-                    nxt[d] = ynum * rS;
-                    logdet = logdet + fast_log(__builtin_fmaf(dnum, rS, 1e-7f));
+                    Lp[d] = make_lerp(cur[d], mm.n_mesh);
+                    if (idx) { idx[(l * D + d) * 2] = Lp[d].xl; idx[(l * D + d) * 2 + 1] = Lp[d].xr; }
+                }
+            }
+            hidden_layers<D>(net, cur, lane, h2);
+            STAMP(1);
+            if (mm.layer_kind == WF_LAYER_IMADE) {
+                // dimension 0: constant weights (prologue record)
+                {
+                    const f32x16 v = load16(rec + h * 16);
+                    float ld;
+                    ispline_eval(mm, v, Lp[0], h, rec[32], rec[33], nxt[0], ld);
+                    logdet = logdet + ld;
+                }
+                STAMP(2);
+#pragma unroll
+                for (int d = 1; d < D; ++d) {
+                    f32x16 v = out_block<D>(net, h2, d, lane);
+                    STAMP(3);
+                    float S1, Sf;
+                    sigmoid_block(v, fkI, h, S1, Sf);
+                    STAMP(4);
+                    const float rs = mm.i_reg * S1;
+                    const float rS = __builtin_amdgcn_rcpf(__builtin_fmaf(rs, mm.F_I, Sf));
+                    float ld;
+                    ispline_eval(mm, v, Lp[d], h, rS, rs, nxt[d], ld);
+                    logdet = logdet + ld;
+                    STAMP(5);
                 }
             } else {
                 // MADE (made.py:21-27): rows 0 / 1 of block d = log_weight / bias (lane half 0, registers 0 / 1)
@@ -428,85 +447,91 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
         // ---- density head
         float result = logdet;
         if (mode != 2) {
-            if (mm.prior_kind == WF_PRIOR_WAVEFLOW) {
+            if (mm.prior_kind == WF_PRIOR_WAVEFLOW || mm.prior_kind == WF_PRIOR_MFLOW) {
+                const bool wavefn = mm.prior_kind == WF_PRIOR_WAVEFLOW;
                 const float* net = lds + mm.net_off[mm.n_layers];
                 const float* rec = dim0 + mm.n_layers * kDim0Floats;
+                // the conditioner sees the unclipped u (wavefunctions.py:40), the spline the clipped one (:45)
+                float uc[D];
+                Lerp Lp[D];
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    uc[d] = fminf(fmaxf(cur[d], 0.0f), 1.0f);
+                    Lp[d] = make_lerp(uc[d], mm.n_mesh);
+                    if (idx) { idx[(mm.n_layers * D + d) * 2] = Lp[d].xl; idx[(mm.n_layers * D + d) * 2 + 1] = Lp[d].xr; }
+                }
+                auto prior_rows = [&](int d) {   // [mesh][h][16], nd 0
+                    return load_rows(mm.tabP + ((size_t)Lp[d].il * 2 + h) * 16, mm.tabP + ((size_t)Lp[d].ir * 2 + h) * 16);
+                };
                 Frag h2[2];
                 hidden_layers<D>(net, cur, lane, h2);
-                const f32x16 keep = load16(fkP + h * 16);
                 float lp = 0.0f, prod = 1.0f;
+                if (wavefn) {
+                    const f32x16 keep = load16(fkP + h * 16);
 #pragma unroll
-                for (int d = 0; d < D; ++d) {
-                    f32x16 c;
-                    float rnorm, sgn;
-                    if (d == 0) {
-                        c = load16(rec + h * 16);
-                        rnorm = rec[32];
-                        sgn = rec[33];
-                    } else {
-                        f32x16 o = out_block<D>(net, h2, d, lane);
-                        float s1 = 0.0f;
+                    for (int d = 0; d < D; ++d) {
+                        f32x16 c;
+                        float rnorm, sgn, num;
+                        if (d == 0) {
+                            c = load16(rec + h * 16);
+                            rnorm = rec[32];
+                            sgn = rec[33];
+                            num = lerp_dot(c, prior_rows(0), Lp[0].t);
+                        } else {
+                            f32x16 o = out_block<D>(net, h2, d, lane);
+                            float s1 = 0.0f;
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) { s1 += o[r]; o[r] = o[r] * keep[r]; }
-                        s1 = xhalf_sum(s1);
-                        // c = (o * keep) @ ob_to_b on v_mfma_f32_32x32x2_f32 (K = 32, unnormalised operands)
-                        c = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                            for (int r = 0; r < 16; ++r) { s1 += o[r]; o[r] = o[r] * keep[r]; }
+                            s1 = xhalf_sum(s1);
+                            // c = (o * keep) @ ob_to_b on v_mfma_f32_32x32x2_f32 (K = 32, unnormalised operands)
+                            c = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-                        for (int r4 = 0; r4 < 4; ++r4) {
-                            const f32x4 a4 = *reinterpret_cast<const f32x4*>(ob2b + (r4 * 64 + lane) * 4);
+                            for (int r4 = 0; r4 < 4; ++r4) {
+                                const f32x4 a4 = *reinterpret_cast<const f32x4*>(ob2b + (r4 * 64 + lane) * 4);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], o[4 * r4 + e], c, 0, 0, 0);
+                                for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], o[4 * r4 + e], c, 0, 0, 0);
+                            }
+                            float n2 = 0.0f;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) n2 = __builtin_fmaf(c[r], c[r], n2);
+                            rnorm = __builtin_amdgcn_rsqf(xhalf_sum(n2));
+                            sgn = s1 < 0.0f ? -1.0f : 1.0f;
+                            num = lerp_dot(c, prior_rows(d), Lp[d].t);
                         }
-                        float n2 = 0.0f;
+                        float v = num * rnorm * sgn;
+                        const bool constrained = (mm.constrained_mask >> d) & 1u;
+                        if (mode == 0) {
+                            float pr = v * v;
+                            if (constrained) pr = pr * 0.5f;
+                            lp = lp + fast_log(pr + 1e-7f);
+                        } else {
+                            if (constrained) v = v * 0.70710678118654752f;
+                            prod = prod * v;
+                        }
+                    }
+                    result = mode == 0 ? lp + logdet : prod * __expf(0.5f * logdet);
+                } else {
+                    // MFlow (distributions.py:139-163): M-spline table with the row factors folded in
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) n2 = __builtin_fmaf(c[r], c[r], n2);
-                        rnorm = __builtin_amdgcn_rsqf(xhalf_sum(n2));
-                        sgn = s1 < 0.0f ? -1.0f : 1.0f;
+                    for (int d = 0; d < D; ++d) {
+                        float num, rS;
+                        if (d == 0) {
+                            const f32x16 v = load16(rec + h * 16);
+                            rS = rec[32];
+                            num = lerp_dot(v, prior_rows(0), Lp[0].t);
+                        } else {
+                            f32x16 v = out_block<D>(net, h2, d, lane);
+                            float S1, Sf;
+                            sigmoid_block(v, fkP, h, S1, Sf);
+                            rS = __builtin_amdgcn_rcpf(Sf);
+                            num = lerp_dot(v, prior_rows(d), Lp[d].t);
+                        }
+                        lp = lp + fast_log(__builtin_fmaf(num, rS, 1e-7f));
                     }
-                    cur[d] = fminf(fmaxf(cur[d], 0.0f), 1.0f);
-                    const Lerp Lp = make_lerp(cur[d], mm.n_mesh);
-                    if (idx) { idx[(mm.n_layers * D + d) * 2] = Lp.xl; idx[(mm.n_layers * D + d) * 2 + 1] = Lp.xr; }
-                    const float* tl = mm.tabP + ((size_t)Lp.il * 2 + h) * 16;   // [mesh][h][16]
-                    const float* tr = mm.tabP + ((size_t)Lp.ir * 2 + h) * 16;
-                    float v = lerp_dot(c, tl, tr, Lp.t) * rnorm * sgn;
-                    const bool constrained = (mm.constrained_mask >> d) & 1u;
-                    if (mode == 0) {
-                        float pr = v * v;
-                        if (constrained) pr = pr * 0.5f;
-                        lp = lp + fast_log(pr + 1e-7f);
-                    } else {
-                        if (constrained) v = v * 0.70710678118654752f;
-                        prod = prod * v;
-                    }
+                    result = lp + logdet;
                 }
-                result = mode == 0 ? lp + logdet : prod * __expf(0.5f * logdet);
-            } else if (mm.prior_kind == WF_PRIOR_MFLOW) {
-                const float* net = lds + mm.net_off[mm.n_layers];
-                const float* rec = dim0 + mm.n_layers * kDim0Floats;
-                Frag h2[2];
-                hidden_layers<D>(net, cur, lane, h2);
-                float lp = 0.0f;
 #pragma unroll
-                for (int d = 0; d < D; ++d) {
-                    f32x16 v;
-                    float rS;
-                    if (d == 0) {
-                        v = load16(rec + h * 16);
-                        rS = rec[32];
-                    } else {
-                        v = out_block<D>(net, h2, d, lane);
-                        float S1, Sf;
-                        sigmoid_block(v, fkP, h, S1, Sf);
-                        rS = __builtin_amdgcn_rcpf(Sf);
-                    }
-                    cur[d] = fminf(fmaxf(cur[d], 0.0f), 1.0f);
-                    const Lerp Lp = make_lerp(cur[d], mm.n_mesh);
-                    if (idx) { idx[(mm.n_layers * D + d) * 2] = Lp.xl; idx[(mm.n_layers * D + d) * 2 + 1] = Lp.xr; }
-                    const float* tl = mm.tabP + ((size_t)Lp.il * 2 + h) * 16;   // fk pre-multiplied
-                    const float* tr = mm.tabP + ((size_t)Lp.ir * 2 + h) * 16;
-                    lp = lp + fast_log(__builtin_fmaf(lerp_dot(v, tl, tr, Lp.t), rS, 1e-7f));
-                }
-                result = lp + logdet;
+                for (int d = 0; d < D; ++d) cur[d] = uc[d];
             } else if (mm.prior_kind == WF_PRIOR_UNIFORM) {
 #pragma unroll
                 for (int d = 0; d < D; ++d) cur[d] = fminf(fmaxf(cur[d], 0.0f), 1.0f);
@@ -528,7 +553,14 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
                 for (int d = 0; d < D; ++d) u_out[w * D + d] = cur[d];
             }
         }
+        STAMP(6);
     }
+#ifdef WF_STAMP
+    if (mm.dbg && lane == 0) {
+        unsigned long long* g = reinterpret_cast<unsigned long long*>(mm.dbg) + ((size_t)blockIdx.x * kWaves + wave) * 8;
+        for (int k = 0; k < 8; ++k) g[k] = stamp_acc[k];
+    }
+#endif
 }
 
 template <int D, int kWaves>
@@ -557,15 +589,15 @@ int launch_dw(const MfmaDev* mdev, int lds_bytes, int mode, const float* x, int6
 int waves_per_group() {
     const char* e = getenv("WF_MFMA_WAVES");  // tuning knob (read at every launch): 8, 12 or 16 waves per workgroup
     const int v = e ? atoi(e) : 0;
-    return (v == 8 || v == 12 || v == 16) ? v : 12;
+    return (v == 8 || v == 12 || v == 16) ? v : 8;
 }
 
 template <int D>
 int launch_d(const MfmaDev* mdev, int lds_bytes, int mode, const float* x, int64_t B, float* out, float* u, int32_t* idx, hipStream_t s) {
     switch (waves_per_group()) {
-        case 8: return launch_dw<D, 8>(mdev, lds_bytes, mode, x, B, out, u, idx, s);
+        case 12: return launch_dw<D, 12>(mdev, lds_bytes, mode, x, B, out, u, idx, s);
         case 16: return launch_dw<D, 16>(mdev, lds_bytes, mode, x, B, out, u, idx, s);
-        default: return launch_dw<D, 12>(mdev, lds_bytes, mode, x, B, out, u, idx, s);
+        default: return launch_dw<D, 8>(mdev, lds_bytes, mode, x, B, out, u, idx, s);
     }
 }
 

@@ -386,10 +386,10 @@ static void pack_rows_acc(const std::vector<double>& t64, int nb, int n_mesh, in
         }
 }
 
-// x = hi + lo * 2^-11 with hi, lo in fp16 (round to nearest)
+// x = hi + lo with hi, lo in fp16 (round to nearest; lo may be subnormal: absolute precision 2^-25)
 static inline void split_f16(float x, _Float16& hi, _Float16& lo) {
     hi = (_Float16)x;
-    lo = (_Float16)((x - (float)hi) * 2048.0f);
+    lo = (_Float16)(x - (float)hi);
 }
 
 static bool net_has_sigmoid_head(const wf_model* m, int n) {
@@ -682,7 +682,7 @@ static int dispatch(const wf_model* m, int mode, const float* x, int64_t B, floa
     DeviceGuard g(m->device);
     if (B == 0) return WF_OK;
     const bool use_mfma = m->mfma_ok && m->kernel_kind != WF_KERNEL_SCALAR;
-#ifdef WF_DEBUG
+#if defined(WF_DEBUG) || defined(WF_STAMP)
     if (use_mfma && getenv("WF_DBG_PTR")) const_cast<wf_model*>(m)->mdev.dbg = (float*)strtoull(getenv("WF_DBG_PTR"), nullptr, 0);
 #endif
     if (use_mfma) return launch_mfma(m->dev.D, &m->mdev, (int)((m->mfma_floats + mfma_extra_lds_floats((int)m->nets.size())) * sizeof(float)), mode, x, B, out, u, idx, stream);
