@@ -152,6 +152,15 @@ int wf_flow_fwd(const wf_model* m, const float* x_dev, int64_t B, float* u_dev, 
 int wf_layer_fwd(const wf_model* m, int layer, const float* u_in_dev, int64_t B, float* y_dev, float* logdet_dev,
                  int32_t* bin_idx_dev, void* stream);
 
+/* Rational-quadratic spline bijector, elementwise (flows/bijections/neural_splines.py:16-184; dead code in the reference,
+ * parity unpinned).  x[N]; uw, uh [N][K] unnormalised widths / heights; ud [N][n_deriv] unnormalised derivatives with
+ * n_deriv == K-1 (unconstrained_RQS: identity outside [left, right], boundary derivatives 1) or K+1 (RQS: explicit).
+ * inverse != 0 applies the inverse map.  y[N], logabsdet[N]; bin_dev[N] (may be NULL) = selected bin, -1 in the tails.
+ * min_bin_width = min_bin_height = min_derivative = 1e-3 as in the reference. */
+int wf_rqs_fwd(const float* x_dev, const float* uw_dev, const float* uh_dev, const float* ud_dev, int64_t N, int32_t K,
+               int32_t n_deriv, int32_t inverse, float left, float right, float bottom, float top, float* y_dev,
+               float* logabsdet_dev, int32_t* bin_dev, void* stream);
+
 /* Local block sums for the VQMC expectation (vqmc.py:196: the batch mean is the only reduction over
  * walkers): out_dev[3] (fp64) = { sum v, sum v^2, count } over v[B]; deterministic (fixed-order) reduction.
  * The caller all-reduces these three doubles across ranks (RCCL) -- see waveflow_amd/distributed.py. */

@@ -317,3 +317,20 @@ def rqs(x, uw, uh, ud, inverse=False, left=0.0, right=1.0, bottom=0.0, top=1.0):
                        top, ctypes.byref(o), ctypes.byref(l), ctypes.byref(b))
     assert rc == 0
     return o.value, l.value, b.value
+
+
+def rqs_batch(x, uw, uh, ud, inverse=False, left=0.0, right=1.0, bottom=0.0, top=1.0, f64=False):
+    """neural_splines.py RQS (ud: [N, K+1]) / unconstrained_RQS (ud: [N, K-1]); parity unpinned.  Part 3 of the C
+    file is fp32 in both builds."""
+    x = np.ascontiguousarray(x, np.float32).reshape(-1)
+    uw, uh, ud = (np.ascontiguousarray(a, np.float32) for a in (uw, uh, ud))
+    N, K = uw.shape
+    L = lib(f64)
+    L.wfo_rqs_batch.restype = ctypes.c_int
+    L.wfo_rqs_batch.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int] + \
+                               [ctypes.c_float] * 4 + [ctypes.c_void_p] * 3
+    y = np.zeros(N, np.float32); ld = np.zeros(N, np.float32); b = np.zeros(N, np.int32)
+    rc = L.wfo_rqs_batch(x.ctypes.data, uw.ctypes.data, uh.ctypes.data, ud.ctypes.data, N, K, ud.shape[1], int(inverse), left, right,
+                         bottom, top, y.ctypes.data, ld.ctypes.data, b.ctypes.data)
+    assert rc == 0, rc
+    return y, ld, b

@@ -650,3 +650,26 @@ int wfo_rqs(float x, const float* uw, const float* uh, const float* ud, int K, i
     }
     return 0;
 }
+
+/* Batched form.  n_deriv == K+1: RQS (neural_splines.py:74-184).  n_deriv == K-1: unconstrained_RQS (:16-71):
+ * derivatives padded with the constant log(exp(1 - 1e-3) - 1) at both ends, identity outside [left, right]. */
+int wfo_rqs_batch(const float* x, const float* uw, const float* uh, const float* ud, int64_t N, int K, int n_deriv, int inverse,
+                  float left, float right, float bottom, float top, float* out, float* logabsdet, int32_t* bin) {
+    if (K > WFO_RQS_MAXK) return -1;
+    const float edge = logf(expf(1 - 1e-3f) - 1);
+    for (int64_t e = 0; e < N; ++e) {
+        float d[WFO_RQS_MAXK + 1];
+        if (n_deriv == K - 1) {
+            d[0] = edge; d[K] = edge;
+            for (int i = 0; i < K - 1; ++i) d[i + 1] = ud[e * n_deriv + i];
+            if (!(x[e] >= left && x[e] <= right)) { out[e] = x[e]; logabsdet[e] = 0.0f; if (bin) bin[e] = -1; continue; }
+        } else {
+            for (int i = 0; i <= K; ++i) d[i] = ud[e * n_deriv + i];
+        }
+        int b;
+        int rc = wfo_rqs(x[e], uw + e * K, uh + e * K, d, K, inverse, left, right, bottom, top, out + e, logabsdet + e, &b);
+        if (rc) return rc;
+        if (bin) bin[e] = b;
+    }
+    return 0;
+}

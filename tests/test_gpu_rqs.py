@@ -1,0 +1,72 @@
+"""RQS bijector: HIP kernel vs the oracle restatement and self-consistency.  Parity unpinned."""
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _params(N, K, n_deriv, seed):
+    g = np.random.default_rng(seed)
+    return (g.normal(size=(N, K)).astype(np.float32), g.normal(size=(N, K)).astype(np.float32),
+            g.normal(size=(N, n_deriv)).astype(np.float32))
+
+
+@pytest.mark.parametrize("K", [4, 8, 32])
+@pytest.mark.parametrize("N", [1, 255, 1000, 4099])
+def test_unconstrained_rqs_vs_oracle(K, N):
+    from waveflow_amd.flows import unconstrained_RQS
+    uw, uh, ud = _params(N, K, K - 1, K * 1000 + N)
+    x = np.random.default_rng(1).uniform(-1.3, 1.3, size=N).astype(np.float32)
+    x[:3] = [-1.0, 1.0, 0.0][:min(3, N)]
+    y, ld, b = unconstrained_RQS(x, uw, uh, ud, tail_bound=1.0, return_bin_idx=True)
+    yo, ldo, bo = oracle.rqs_batch(x, uw, uh, ud, left=-1.0, right=1.0, bottom=-1.0, top=1.0)
+    tails = np.abs(x) > 1.0
+    assert np.array_equal(y[tails], x[tails]) and np.all(ld[tails] == 0) and np.all(b[tails] == -1)
+    # bin index: exact except where x sits within rounding of a knot (expf differs between libm and ocml)
+    assert (b != bo).mean() < 2e-3
+    same = b == bo
+    np.testing.assert_allclose(y[same], yo[same], rtol=0, atol=3e-6)
+    np.testing.assert_allclose(ld[same], ldo[same], rtol=2e-5, atol=2e-5)
+    # a flipped bin at a knot still gives a continuous map
+    np.testing.assert_allclose(y, yo, rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize("K", [8, 32])
+def test_rqs_inverse_roundtrip_and_explicit_derivatives(K):
+    from waveflow_amd.flows import RQS
+    N = 20000
+    uw, uh, ud = _params(N, K, K + 1, 7)
+    x = np.random.default_rng(2).uniform(0.001, 0.999, size=N).astype(np.float32)
+    y, ld = RQS(x, uw, uh, ud)
+    yo, ldo, _ = oracle.rqs_batch(x, uw, uh, ud)
+    np.testing.assert_allclose(y, yo, rtol=0, atol=1e-5)
+    x2, ld2 = RQS(y, uw, uh, ud, inverse=True)
+    ok = np.exp(ld) > 1e-2   # well-conditioned bins
+    assert np.abs(x2 - x)[ok].max() < 2e-4
+    assert np.abs(ld + ld2)[ok].max() < 2e-2
+    assert np.all(y >= 0) and np.all(y <= 1) and np.all(np.diff(np.sort(x)) >= 0)
+    # monotone: a sorted scan through one element's spline
+    t = np.linspace(0, 1, 4001, dtype=np.float32)
+    rep = lambda a: np.repeat(a[:1], t.size, axis=0)
+    ys, lds = RQS(t, rep(uw), rep(uh), rep(ud))
+    assert np.all(np.diff(ys) > -1e-6) and abs(ys[0]) < 1e-6 and abs(ys[-1] - 1) < 1e-5
+    fd = np.diff(ys.astype(np.float64)) / np.diff(t.astype(np.float64))
+    mid = np.exp(0.5 * (lds[1:] + lds[:-1]).astype(np.float64))
+    assert np.median(np.abs(fd / mid - 1)) < 2e-3
+
+
+def test_rqs_torch_tensors_and_errors():
+    import torch
+    from waveflow_amd import _lib
+    from waveflow_amd.flows import unconstrained_RQS
+    uw, uh, ud = (torch.from_numpy(a).cuda() for a in _params(512, 8, 7, 3))
+    x = torch.rand(512, device="cuda") * 2 - 1
+    y, ld = unconstrained_RQS(x, uw, uh, ud)
+    assert y.is_cuda and y.shape == x.shape and torch.isfinite(y).all() and torch.isfinite(ld).all()
+    with pytest.raises(ValueError):
+        unconstrained_RQS(x, uw, uh, torch.zeros(512, 9, device="cuda"))
+    L = _lib.lib()
+    assert L.wf_rqs_fwd(None, None, None, None, 0, 2000, 1999, 0, 0.0, 1.0, 0.0, 1.0, None, None, None, None) == -1   # K too large
+    assert L.wf_rqs_fwd(None, None, None, None, 10, 8, 7, 0, 0.0, 1.0, 0.0, 1.0, None, None, None, None) == -1       # null buffers

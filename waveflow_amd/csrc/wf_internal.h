@@ -91,6 +91,8 @@ int launch_scalar(const ModelDev& md, const ModelDev* md_dev, int mode, const fl
                   int32_t* idx, void* stream);
 int launch_scalar_layer(const ModelDev& md, const ModelDev* md_dev, int layer, const float* u_in, int64_t B, float* y,
                         float* logdet, int32_t* idx, void* stream);
+int launch_rqs(const float* x, const float* uw, const float* uh, const float* ud, int64_t N, int K, int n_deriv, int inverse,
+               float left, float right, float bottom, float top, float* y, float* ld, int32_t* bin, void* stream);
 int launch_block_sums(const float* v, int64_t B, double* out, void* ws, int64_t ws_bytes, void* stream);
 int64_t block_sums_ws_bytes(int64_t B);
 

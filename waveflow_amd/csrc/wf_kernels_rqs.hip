@@ -1,0 +1,208 @@
+// wf_kernels_rqs.hip -- rational-quadratic spline bijector (Durkan et al.), elementwise, HBM-bound (gfx950).
+//
+// Restates flows/bijections/neural_splines.py:11-184 (searchsorted :11-13, unconstrained_RQS :16-71, RQS :74-184).
+// That module is dead code in the reference (it calls jax.ops.index_update, removed from JAX) and has no caller and
+// no fixture: PARITY UNPINNED -- checked against oracle/wf_oracle.c (wfo_rqs) and by self-consistency only.
+//
+// Data movement: each element owns rows uw[K], uh[K], ud[K-1 | K+1].  A workgroup stages a [256][K] tile through LDS
+// with fully coalesced 16-byte loads (rows are contiguous in HBM), then every lane walks its own row in LDS
+// (row stride K+1 dwords: conflict-free).  Only the two derivatives of the selected bin are read (softplus on 2
+// values instead of K+1).  Algorithmic traffic: (2K + 2 + 3) * 4 bytes per element.
+#include <hip/hip_runtime.h>
+
+#include "wf_internal.h"
+
+namespace wf {
+
+namespace {
+
+constexpr int kRqsBlock = 256;
+constexpr float kMinBinWidth = 1e-3f, kMinBinHeight = 1e-3f, kMinDerivative = 1e-3f;
+
+// cooperative, coalesced copy of rows [e0, e0+n) x K floats into LDS with row stride K+1
+__device__ __forceinline__ void stage_tile(const float* __restrict__ g, int64_t e0, int n, int K, float* lds) {
+    const int total = n * K;
+    const float* src = g + e0 * K;
+    if ((((uintptr_t)src) & 15) == 0) {
+        const int n4 = total >> 2;
+        const float4* s4 = reinterpret_cast<const float4*>(src);
+        for (int i = threadIdx.x; i < n4; i += kRqsBlock) {
+            const float4 v = s4[i];
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int f = 4 * i + q;
+                lds[(f / K) * (K + 1) + (f % K)] = vv[q];
+            }
+        }
+        for (int f = (n4 << 2) + threadIdx.x; f < total; f += kRqsBlock) lds[(f / K) * (K + 1) + (f % K)] = src[f];
+    } else {
+        for (int f = threadIdx.x; f < total; f += kRqsBlock) lds[(f / K) * (K + 1) + (f % K)] = src[f];
+    }
+}
+
+// softmax-normalised bin sizes of one row (in place: row[i] <- min + (1 - min*K) * softmax_i)
+__device__ __forceinline__ void normalise_row(float* row, int K, float min_size) {
+    float mx = row[0];
+    for (int i = 1; i < K; ++i) mx = fmaxf(mx, row[i]);
+    float s = 0.0f;
+    for (int i = 0; i < K; ++i) {
+        const float e = expf(row[i] - mx);
+        row[i] = e;
+        s = s + e;
+    }
+    for (int i = 0; i < K; ++i) row[i] = min_size + (1 - min_size * K) * (row[i] / s);
+}
+
+// knot i of the cumulative array: lo + (hi - lo) * cumsum_i, end knots forced (neural_splines.py:100-119)
+struct Bin {
+    int idx;
+    float knot, size;
+};
+
+// search: bin = sum(x >= knots) - 1 with eps on the last knot (neural_splines.py:11-13), clamped to [0, K-1]
+__device__ __forceinline__ Bin search_bin(const float* row, int K, float lo, float hi, float x) {
+    int count = 0;
+    float cum = 0.0f, prev = lo, knot_b = lo, size_b = 0.0f;
+    // knot 0
+    if (x >= lo) ++count;
+    for (int i = 0; i < K; ++i) {
+        cum = cum + row[i];
+        float knot = (hi - lo) * cum + lo;
+        if (i == K - 1) knot = hi;
+        const float cmp = (i == K - 1) ? knot + 1e-6f : knot;
+        const bool ge = x >= cmp;
+        // bin i spans [prev, knot]
+        if (count == i + 1 && !ge) { knot_b = prev; size_b = knot - prev; }
+        if (ge) ++count;
+        prev = knot;
+    }
+    Bin b;
+    b.idx = min(max(count - 1, 0), K - 1);
+    if (count - 1 != b.idx || count == 0 || count == K + 1) {
+        // clamped: recompute the selected bin's knots
+        cum = 0.0f; prev = lo;
+        for (int i = 0; i < K; ++i) {
+            cum = cum + row[i];
+            float knot = (hi - lo) * cum + lo;
+            if (i == K - 1) knot = hi;
+            if (i == b.idx) { knot_b = prev; size_b = knot - prev; }
+            prev = knot;
+        }
+    }
+    b.knot = knot_b;
+    b.size = size_b;
+    return b;
+}
+
+// the given bin of a cumulative array
+__device__ __forceinline__ Bin pick_bin(const float* row, int K, float lo, float hi, int idx) {
+    float cum = 0.0f, prev = lo;
+    Bin b;
+    b.idx = idx; b.knot = lo; b.size = 0.0f;
+    for (int i = 0; i < K; ++i) {
+        cum = cum + row[i];
+        float knot = (hi - lo) * cum + lo;
+        if (i == K - 1) knot = hi;
+        if (i == idx) { b.knot = prev; b.size = knot - prev; }
+        prev = knot;
+    }
+    return b;
+}
+
+__device__ __forceinline__ float softplus(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+
+__global__ __launch_bounds__(kRqsBlock) void k_rqs(const float* __restrict__ xg, const float* __restrict__ uw, const float* __restrict__ uh,
+                                                   const float* __restrict__ ud, int64_t N, int K, int n_deriv, int inverse, float left,
+                                                   float right, float bottom, float top, float* __restrict__ yg,
+                                                   float* __restrict__ ldg, int32_t* __restrict__ bing) {
+    extern __shared__ float tile[];  // [256][K+1]
+    const bool unconstrained = n_deriv == K - 1;
+    // boundary derivative constant of unconstrained_RQS: softplus(c) + min_d == 1 (neural_splines.py:36)
+    const float edge = logf(expf(1 - kMinDerivative) - 1);
+    for (int64_t e0 = (int64_t)blockIdx.x * kRqsBlock; e0 < N; e0 += (int64_t)gridDim.x * kRqsBlock) {
+        const int n = (int)min((int64_t)kRqsBlock, N - e0);
+        const int64_t e = e0 + threadIdx.x;
+        const bool active = threadIdx.x < n;
+        const float x = active ? xg[e] : 0.0f;
+        const bool inside = unconstrained ? (x >= left && x <= right) : true;
+        float* row = tile + threadIdx.x * (K + 1);
+        // pass 1: the array that is searched (widths for the forward map, heights for the inverse)
+        __syncthreads();
+        stage_tile(inverse ? uh : uw, e0, n, K, tile);
+        __syncthreads();
+        Bin s{0, 0.0f, 1.0f};
+        if (active) {
+            normalise_row(row, K, inverse ? kMinBinHeight : kMinBinWidth);
+            s = search_bin(row, K, inverse ? bottom : left, inverse ? top : right, x);
+        }
+        // pass 2: the other array, same bin
+        __syncthreads();
+        stage_tile(inverse ? uw : uh, e0, n, K, tile);
+        __syncthreads();
+        if (!active) continue;
+        normalise_row(row, K, inverse ? kMinBinWidth : kMinBinHeight);
+        const Bin o = pick_bin(row, K, inverse ? left : bottom, inverse ? right : top, s.idx);
+        const float in_cw = inverse ? o.knot : s.knot, in_w = inverse ? o.size : s.size;
+        const float in_ch = inverse ? s.knot : o.knot, in_h = inverse ? s.size : o.size;
+        const int b = s.idx;
+        float u0, u1;
+        if (unconstrained) {
+            u0 = b == 0 ? edge : ud[e * n_deriv + (b - 1)];
+            u1 = b == K - 1 ? edge : ud[e * n_deriv + b];
+        } else {
+            u0 = ud[e * n_deriv + b];
+            u1 = ud[e * n_deriv + b + 1];
+        }
+        const float d0 = kMinDerivative + softplus(u0), d1 = kMinDerivative + softplus(u1);
+        const float delta = in_h / in_w;
+        float y, ld;
+        if (inverse) {
+            const float a = (x - in_ch) * (d0 + d1 - 2 * delta) + in_h * (delta - d0);
+            const float bq = in_h * d0 - (x - in_ch) * (d0 + d1 - 2 * delta);
+            const float cq = -delta * (x - in_ch);
+            const float disc = bq * bq - 4 * a * cq;
+            const float root = (2 * cq) / (-bq - sqrtf(disc));
+            y = root * in_w + in_cw;
+            const float t1 = root * (1 - root);
+            const float den = delta + ((d0 + d1 - 2 * delta) * t1);
+            const float num = delta * delta * (d1 * root * root + 2 * delta * t1 + d0 * (1 - root) * (1 - root));
+            ld = -(logf(num) - 2 * logf(den));
+        } else {
+            const float th = (x - in_cw) / in_w;
+            const float t1 = th * (1 - th);
+            const float num = in_h * (delta * th * th + d0 * t1);
+            const float den = delta + ((d0 + d1 - 2 * delta) * t1);
+            y = in_ch + num / den;
+            const float dnum = delta * delta * (d1 * th * th + 2 * delta * t1 + d0 * (1 - th) * (1 - th));
+            ld = logf(dnum) - 2 * logf(den);
+        }
+        if (!inside) { y = x; ld = 0.0f; }   // identity tails (neural_splines.py:26-50)
+        yg[e] = y;
+        ldg[e] = ld;
+        if (bing) bing[e] = inside ? b : -1;
+    }
+}
+
+}  // namespace
+
+int launch_rqs(const float* x, const float* uw, const float* uh, const float* ud, int64_t N, int K, int n_deriv, int inverse, float left,
+               float right, float bottom, float top, float* y, float* ld, int32_t* bin, void* stream) {
+    if (N == 0) return WF_OK;
+    const int lds_bytes = kRqsBlock * (K + 1) * (int)sizeof(float);
+    int64_t blocks = (N + kRqsBlock - 1) / kRqsBlock;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    static int configured = 0;
+    if (lds_bytes > 64 * 1024 && lds_bytes > configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rqs), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) { set_hip_error((int)e); return WF_ERR_HIP; }
+        configured = lds_bytes;
+    }
+    hipLaunchKernelGGL(k_rqs, dim3((unsigned)blocks), dim3(kRqsBlock), lds_bytes, (hipStream_t)stream, x, uw, uh, ud, N, K, n_deriv, inverse,
+                       left, right, bottom, top, y, ld, bin);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_hip_error((int)e); return WF_ERR_HIP; }
+    return WF_OK;
+}
+
+}  // namespace wf

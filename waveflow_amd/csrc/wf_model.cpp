@@ -721,6 +721,19 @@ int wf_layer_fwd(const wf_model* m, int layer, const float* u_in_dev, int64_t B,
     return launch_scalar_layer(m->dev, m->d_dev, layer, u_in_dev, B, y_dev, logdet_dev, bin_idx_dev, stream);
 }
 
+int wf_rqs_fwd(const float* x_dev, const float* uw_dev, const float* uh_dev, const float* ud_dev, int64_t N, int32_t K, int32_t n_deriv,
+               int32_t inverse, float left, float right, float bottom, float top, float* y_dev, float* logabsdet_dev, int32_t* bin_dev,
+               void* stream) {
+    if (N < 0 || K < 1 || K > 256) return WF_ERR_INVALID;
+    if (n_deriv != K - 1 && n_deriv != K + 1) return WF_ERR_INVALID;
+    if (!(right > left) || !(top > bottom)) return WF_ERR_INVALID;
+    if (1e-3f * K > 1.0f) return WF_ERR_INVALID;   // "Minimal bin width too large for the number of bins" (neural_splines.py:91-94)
+    if (N > 0 && (!x_dev || !uw_dev || !uh_dev || (!ud_dev && n_deriv > 0) || !y_dev || !logabsdet_dev)) return WF_ERR_INVALID;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return WF_ERR_NO_DEVICE;
+    return launch_rqs(x_dev, uw_dev, uh_dev, ud_dev, N, K, n_deriv, inverse, left, right, bottom, top, y_dev, logabsdet_dev, bin_dev, stream);
+}
+
 int64_t wf_block_sums_workspace_bytes(int64_t B) { return block_sums_ws_bytes(B); }
 
 int wf_block_sums(const float* v_dev, int64_t B, double* out_dev, void* workspace_dev, int64_t workspace_bytes, void* stream) {
