@@ -84,7 +84,12 @@ def main():
     ap.add_argument("--batch", type=int, default=1 << 20, help="walkers per GPU")
     ap.add_argument("--kernel", default="auto", choices=["auto", "scalar", "mfma"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="he_logpdf", choices=["he_logpdf", "rqs"],
+                    help="he_logpdf: the BASELINE metric (default).  rqs: the RQS bijector kernel alone (SURVEY row a12), an "
+                         "HBM-bound elementwise op: 2 dims x `--batch` walkers, 32 bins")
     args = ap.parse_args()
+    if args.workload == "rqs":
+        return main_rqs(args)
 
     import torch
     import torch.distributed as dist
@@ -175,6 +180,39 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def main_rqs(args):
+    """Secondary line: unconstrained RQS forward, K = 32 bins, N = 2 * batch elements (single GPU, no collective)."""
+    import torch
+    from waveflow_amd.flows import unconstrained_RQS
+    K, N = 32, 2 * args.batch
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    uw = torch.randn(N, K, device="cuda", generator=g)
+    uh = torch.randn(N, K, device="cuda", generator=g)
+    ud = torch.randn(N, K - 1, device="cuda", generator=g)
+    x = torch.rand(N, device="cuda", generator=g) * 2.4 - 1.2
+    for _ in range(args.warmup + 1):
+        unconstrained_RQS(x, uw, uh, ud)
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()
+        unconstrained_RQS(x, uw, uh, ud)
+        b.record()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    bytes_per = (2 * K + (K - 1) + 1) * 4 + 8       # uw, uh, ud, x in; y, logabsdet out
+    gbs = N * bytes_per / (kern_ms * 1e-3) / 1e9
+    print(json.dumps({
+        "metric": "RQS bijector evals/sec", "value": N * args.steps / dt, "unit": "evals/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"unconstrained RQS forward (neural_splines.py:16-71), K=32 bins, {N} elements (2 dims x {args.batch} walkers)"},
+        "roofline": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
+                     "kernel": "k_rqs_reg<32>", "kernel_ms": kern_ms, "bytes_per_eval": bytes_per}}), flush=True)
 
 
 if __name__ == "__main__":

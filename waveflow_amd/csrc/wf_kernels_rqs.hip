@@ -184,11 +184,145 @@ __global__ __launch_bounds__(kRqsBlock) void k_rqs(const float* __restrict__ xg,
     }
 }
 
+
+// ---- register path: K in {4, 8, 16, 32}; every lane loads its own rows with 16-byte loads (a row is 16..128
+// contiguous bytes, so the wave's loads cover whole cache lines between them) and keeps them in registers.
+template <int K>
+__device__ __forceinline__ void load_row(const float* __restrict__ g, int64_t e, float (&r)[K]) {
+    const float4* p = reinterpret_cast<const float4*>(g + e * K);
+#pragma unroll
+    for (int q = 0; q < K / 4; ++q) {
+        const float4 v = p[q];
+        r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
+    }
+}
+
+// r[i] <- bin size i = min + (1 - min*K) * softmax_i(r)
+template <int K>
+__device__ __forceinline__ void normalise_reg(float (&r)[K], float min_size) {
+    float mx = r[0];
+#pragma unroll
+    for (int i = 1; i < K; ++i) mx = fmaxf(mx, r[i]);
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        r[i] = __builtin_amdgcn_exp2f((r[i] - mx) * 1.4426950408889634f);
+        s = s + r[i];
+    }
+    const float c = (1 - min_size * K) / s;
+#pragma unroll
+    for (int i = 0; i < K; ++i) r[i] = __builtin_fmaf(c, r[i], min_size);
+}
+
+template <int K>
+__global__ __launch_bounds__(kRqsBlock) void k_rqs_reg(const float* __restrict__ xg, const float* __restrict__ uw, const float* __restrict__ uh,
+                                                       const float* __restrict__ ud, int64_t N, int n_deriv, int inverse, float left,
+                                                       float right, float bottom, float top, float* __restrict__ yg,
+                                                       float* __restrict__ ldg, int32_t* __restrict__ bing) {
+    const bool unconstrained = n_deriv == K - 1;
+    const float edge = logf(expf(1 - kMinDerivative) - 1);
+    for (int64_t e = (int64_t)blockIdx.x * kRqsBlock + threadIdx.x; e < N; e += (int64_t)gridDim.x * kRqsBlock) {
+        const float x = xg[e];
+        float sr[K], orow[K];   // searched array (widths fwd / heights inv) and the other one
+        load_row<K>(inverse ? uh : uw, e, sr);
+        load_row<K>(inverse ? uw : uh, e, orow);
+        const bool inside = unconstrained ? (x >= left && x <= right) : true;
+        const float slo = inverse ? bottom : left, shi = inverse ? top : right;
+        const float olo = inverse ? left : bottom, ohi = inverse ? right : top;
+        normalise_reg<K>(sr, inverse ? kMinBinHeight : kMinBinWidth);
+        normalise_reg<K>(orow, inverse ? kMinBinWidth : kMinBinHeight);
+        // knots of both arrays in one sweep; bin = sum(x >= knot) - 1 with eps on the last knot, clamped
+        int count = x >= slo ? 1 : 0;
+        float cs = 0.0f, co = 0.0f, sprev = slo, oprev = olo;
+        float s_knot = slo, s_size = sr[0], o_knot = olo, o_size = orow[0];
+        bool first = true;
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            cs = cs + sr[i];
+            co = co + orow[i];
+            float sk = (shi - slo) * cs + slo, ok = (ohi - olo) * co + olo;
+            if (i == K - 1) { sk = shi; ok = ohi; }
+            const bool ge = x >= ((i == K - 1) ? sk + 1e-6f : sk);
+            // bin i is selected if x >= knot_i and not x >= knot_{i+1}; clamping: i == 0 also takes x < knot_0,
+            // i == K-1 also takes x >= last knot
+            const bool sel = (count == i + 1 && !ge) || (i == 0 && count == 0) || (i == K - 1 && ge && count == K);
+            if (sel || (i == 0 && first)) {
+                if (sel) { s_knot = sprev; s_size = sk - sprev; o_knot = oprev; o_size = ok - oprev; }
+            }
+            first = false;
+            if (ge) ++count;
+            sprev = sk;
+            oprev = ok;
+        }
+        const int b = min(max(count - 1, 0), K - 1);
+        const float in_cw = inverse ? o_knot : s_knot, in_w = inverse ? o_size : s_size;
+        const float in_ch = inverse ? s_knot : o_knot, in_h = inverse ? s_size : o_size;
+        float u0, u1;
+        if (unconstrained) {
+            u0 = b == 0 ? edge : ud[e * n_deriv + (b - 1)];
+            u1 = b == K - 1 ? edge : ud[e * n_deriv + b];
+        } else {
+            u0 = ud[e * n_deriv + b];
+            u1 = ud[e * n_deriv + b + 1];
+        }
+        const float d0 = kMinDerivative + softplus(u0), d1 = kMinDerivative + softplus(u1);
+        const float delta = in_h / in_w;
+        float y, ld;
+        if (inverse) {
+            const float a = (x - in_ch) * (d0 + d1 - 2 * delta) + in_h * (delta - d0);
+            const float bq = in_h * d0 - (x - in_ch) * (d0 + d1 - 2 * delta);
+            const float cq = -delta * (x - in_ch);
+            const float disc = bq * bq - 4 * a * cq;
+            const float root = (2 * cq) / (-bq - sqrtf(disc));
+            y = root * in_w + in_cw;
+            const float t1 = root * (1 - root);
+            const float den = delta + ((d0 + d1 - 2 * delta) * t1);
+            const float num = delta * delta * (d1 * root * root + 2 * delta * t1 + d0 * (1 - root) * (1 - root));
+            ld = -(logf(num) - 2 * logf(den));
+        } else {
+            const float th = (x - in_cw) / in_w;
+            const float t1 = th * (1 - th);
+            const float num = in_h * (delta * th * th + d0 * t1);
+            const float den = delta + ((d0 + d1 - 2 * delta) * t1);
+            y = in_ch + num / den;
+            const float dnum = delta * delta * (d1 * th * th + 2 * delta * t1 + d0 * (1 - th) * (1 - th));
+            ld = logf(dnum) - 2 * logf(den);
+        }
+        if (!inside) { y = x; ld = 0.0f; }
+        yg[e] = y;
+        ldg[e] = ld;
+        if (bing) bing[e] = inside ? b : -1;
+    }
+}
+
+template <int K>
+int launch_reg(const float* x, const float* uw, const float* uh, const float* ud, int64_t N, int n_deriv, int inverse, float left, float right,
+               float bottom, float top, float* y, float* ld, int32_t* bin, hipStream_t s) {
+    int64_t blocks = (N + kRqsBlock - 1) / kRqsBlock;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(k_rqs_reg<K>, dim3((unsigned)blocks), dim3(kRqsBlock), 0, s, x, uw, uh, ud, N, n_deriv, inverse, left, right, bottom,
+                       top, y, ld, bin);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_hip_error((int)e); return WF_ERR_HIP; }
+    return WF_OK;
+}
+
 }  // namespace
 
 int launch_rqs(const float* x, const float* uw, const float* uh, const float* ud, int64_t N, int K, int n_deriv, int inverse, float left,
                float right, float bottom, float top, float* y, float* ld, int32_t* bin, void* stream) {
     if (N == 0) return WF_OK;
+    const bool aligned = ((((uintptr_t)uw) | ((uintptr_t)uh)) & 15) == 0;
+    if (aligned) {
+        hipStream_t st = (hipStream_t)stream;
+        switch (K) {
+            case 4: return launch_reg<4>(x, uw, uh, ud, N, n_deriv, inverse, left, right, bottom, top, y, ld, bin, st);
+            case 8: return launch_reg<8>(x, uw, uh, ud, N, n_deriv, inverse, left, right, bottom, top, y, ld, bin, st);
+            case 16: return launch_reg<16>(x, uw, uh, ud, N, n_deriv, inverse, left, right, bottom, top, y, ld, bin, st);
+            case 32: return launch_reg<32>(x, uw, uh, ud, N, n_deriv, inverse, left, right, bottom, top, y, ld, bin, st);
+            default: break;
+        }
+    }
     const int lds_bytes = kRqsBlock * (K + 1) * (int)sizeof(float);
     int64_t blocks = (N + kRqsBlock - 1) / kRqsBlock;
     if (blocks > 256 * 8) blocks = 256 * 8;
