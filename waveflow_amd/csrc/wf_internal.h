@@ -50,6 +50,7 @@ struct SplineDev {
 
 struct ModelDev {
     int D;
+    int nbp;                      // padded bases per dimension of every table / weight image (32 or 64)
     int n_layers;
     int layer_kind;
     int box_kind;

@@ -26,11 +26,17 @@ namespace wf {
 
 namespace {
 
-constexpr int kBlock = 256;
-constexpr int NBP = 32;
 constexpr int H = kHidden;
 
-#define SCR(j) scr[(j) * kBlock + threadIdx.x]
+// NBP = padded bases per dimension (32 or 64); the workgroup is 256 / (NBP / 32) lanes so that the thread-private
+// LDS columns (max(64 hidden units, 2 * NBP) rows) stay at 64 KB per workgroup.
+template <int NBP>
+struct Cfg {
+    static constexpr int kBlock = NBP == 32 ? 256 : 128;
+    static constexpr int kRows = 2 * NBP > H ? 2 * NBP : H;
+};
+
+#define SCR(j) scr[(j) * (int)blockDim.x + threadIdx.x]
 
 struct Lerp {
     int il, ir;   // wrapped + clamped gather indices
@@ -57,6 +63,7 @@ __device__ __forceinline__ Lerp make_lerp(float x, int n_mesh) {
 }
 
 // sum_j c_j * X_cached(x, j), j ascending; c_j = SCR(row0 + j); tab = one derivative order, [n_mesh][NBP]
+template <int NBP>
 __device__ __forceinline__ float spline_dot(const float* __restrict__ tab, const Lerp& L, const float* scr, int row0, int nb) {
     const float4* rl = reinterpret_cast<const float4*>(tab + (size_t)L.il * NBP);
     const float4* rr = reinterpret_cast<const float4*>(tab + (size_t)L.ir * NBP);
@@ -145,6 +152,7 @@ __device__ __forceinline__ void hidden_layers(const NetPlain& net, const float (
     for (int a = 0; a < H; ++a) h[a] = SCR(a);
 }
 
+template <int NBP>
 __device__ __forceinline__ float out_unit(const NetPlain& net, const float (&h)[H], int d, int j) {
     const float* __restrict__ w = net.W2t + ((size_t)d * NBP + j) * H;
     float acc = 0.0f;
@@ -154,10 +162,11 @@ __device__ __forceinline__ float out_unit(const NetPlain& net, const float (&h)[
 }
 
 // calculate_bijection_params for dimension d into SCR(0..nb)
+template <int NBP>
 __device__ __forceinline__ void bijection_params(const NetPlain& net, const float (&h)[H], int d, int nb, bool sigmoid, float* scr) {
     float ss = 0.0f;
     for (int j = 0; j < nb; ++j) {
-        float v = out_unit(net, h, d, j);
+        float v = out_unit<NBP>(net, h, d, j);
         if (sigmoid) v = 1.0f / (1.0f + expf(-v));
         SCR(j) = v;
         ss = ss + v;
@@ -165,7 +174,7 @@ __device__ __forceinline__ void bijection_params(const NetPlain& net, const floa
     for (int j = 0; j < nb; ++j) SCR(j) = SCR(j) / ss;
 }
 
-template <int D>
+template <int D, int NBP>
 __device__ __forceinline__ float imade_direct(const ModelDev& md, const NetPlain& net, const float (&x)[D], float (&y)[D],
                                               float* scr, int32_t* idx) {
     float h[H];
@@ -177,27 +186,27 @@ __device__ __forceinline__ float imade_direct(const ModelDev& md, const NetPlain
     float ld = 0.0f;
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-        bijection_params(net, h, d, nb, true, scr);
+        bijection_params<NBP>(net, h, d, nb, true, scr);
         for (int j = 0; j < nb; ++j) SCR(j) = SCR(j) + md.i_reg;
         remove_bias(WF_SPLINE_I, sp.degree, nb, scr);
         enforce_bc(sp, WF_SPLINE_I, scr, 0);
         const Lerp L = make_lerp(x[d], sp.n_mesh);
         if (idx) { idx[2 * d] = L.xl; idx[2 * d + 1] = L.xr; }
-        y[d] = spline_dot(tab0, L, scr, 0, nb);
-        const float dy = spline_dot(tab1, L, scr, 0, nb);
+        y[d] = spline_dot<NBP>(tab0, L, scr, 0, nb);
+        const float dy = spline_dot<NBP>(tab1, L, scr, 0, nb);
         ld = ld + logf(dy + 1e-7f);
     }
     return ld;
 }
 
-template <int D>
+template <int D, int NBP>
 __device__ __forceinline__ float made_direct(const NetPlain& net, const float (&x)[D], float (&y)[D], float* scr) {
     float h[H];
     hidden_layers<D>(net, x, scr, h);
     float ls = 0.0f;
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-        const float lw = out_unit(net, h, d, 0), bias = out_unit(net, h, d, 1);
+        const float lw = out_unit<NBP>(net, h, d, 0), bias = out_unit<NBP>(net, h, d, 1);
         y[d] = (x[d] - bias) * expf(-lw);
         ls = ls + lw;
     }
@@ -236,10 +245,11 @@ __device__ __forceinline__ float box_direct(const ModelDev& md, const float (&x)
 
 __device__ __forceinline__ float clip01(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
 
-template <int D>
-__global__ __launch_bounds__(kBlock) void k_eval(const ModelDev* __restrict__ mdp, int mode, const float* __restrict__ xg, int64_t B,
+template <int D, int NBP>
+__global__ __launch_bounds__(Cfg<NBP>::kBlock) void k_eval(const ModelDev* __restrict__ mdp, int mode, const float* __restrict__ xg, int64_t B,
                                                  float* __restrict__ out, float* __restrict__ u_out, int32_t* __restrict__ idx_out) {
-    __shared__ float scr[2 * NBP * kBlock];
+    constexpr int kBlock = Cfg<NBP>::kBlock;
+    __shared__ float scr[Cfg<NBP>::kRows * kBlock];
     const ModelDev& md = *mdp;
     const int idx_stride = (md.n_layers + 1) * D * 2;
     for (int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x; b < B; b += (int64_t)gridDim.x * kBlock) {
@@ -255,8 +265,8 @@ __global__ __launch_bounds__(kBlock) void k_eval(const ModelDev* __restrict__ md
         }
         for (int l = 0; l < md.n_layers; ++l) {
             float ld;
-            if (md.layer_kind == WF_LAYER_IMADE) ld = imade_direct<D>(md, md.nets[l], cur, nxt, scr, idx ? idx + l * D * 2 : nullptr);
-            else ld = made_direct<D>(md.nets[l], cur, nxt, scr);
+            if (md.layer_kind == WF_LAYER_IMADE) ld = imade_direct<D, NBP>(md, md.nets[l], cur, nxt, scr, idx ? idx + l * D * 2 : nullptr);
+            else ld = made_direct<D, NBP>(md.nets[l], cur, nxt, scr);
             logdet = logdet + ld;
 #pragma unroll
             for (int d = 0; d < D; ++d) cur[d] = nxt[D - 1 - d];  // Reverse
@@ -272,7 +282,7 @@ __global__ __launch_bounds__(kBlock) void k_eval(const ModelDev* __restrict__ md
                 float lp = 0.0f, prod = 1.0f;
 #pragma unroll
                 for (int d = 0; d < D; ++d) {
-                    bijection_params(net, h, d, nb, false, scr);
+                    bijection_params<NBP>(net, h, d, nb, false, scr);
                     enforce_bc(sp, WF_SPLINE_B, scr, 0);
                     cur[d] = clip01(cur[d]);
                     // BSpline_fun.apply_fun: c = w @ ob_to_b; c /= |c|  (bsplines_jax.py:134-135)
@@ -287,7 +297,7 @@ __global__ __launch_bounds__(kBlock) void k_eval(const ModelDev* __restrict__ md
                     for (int j = 0; j < nb; ++j) SCR(NBP + j) = SCR(NBP + j) / nrm;
                     const Lerp L = make_lerp(cur[d], sp.n_mesh);
                     if (idx) { idx[(md.n_layers * D + d) * 2] = L.xl; idx[(md.n_layers * D + d) * 2 + 1] = L.xr; }
-                    float v = spline_dot(sp.tab, L, scr, NBP, nb);
+                    float v = spline_dot<NBP>(sp.tab, L, scr, NBP, nb);
                     const bool constrained = (md.constrained_mask >> d) & 1u;
                     if (mode == 0) {
                         float pr = v * v;
@@ -308,13 +318,13 @@ __global__ __launch_bounds__(kBlock) void k_eval(const ModelDev* __restrict__ md
                 float lp = 0.0f;
 #pragma unroll
                 for (int d = 0; d < D; ++d) {
-                    bijection_params(net, h, d, nb, true, scr);
+                    bijection_params<NBP>(net, h, d, nb, true, scr);
                     remove_bias(WF_SPLINE_M, sp.degree, nb, scr);
                     enforce_bc(sp, WF_SPLINE_M, scr, 0);
                     cur[d] = clip01(cur[d]);
                     const Lerp L = make_lerp(cur[d], sp.n_mesh);
                     if (idx) { idx[(md.n_layers * D + d) * 2] = L.xl; idx[(md.n_layers * D + d) * 2 + 1] = L.xr; }
-                    const float v = spline_dot(sp.tab, L, scr, 0, nb);
+                    const float v = spline_dot<NBP>(sp.tab, L, scr, 0, nb);
                     lp = lp + logf(v + 1e-7f);
                 }
                 result = lp + logdet;
@@ -340,18 +350,19 @@ __global__ __launch_bounds__(kBlock) void k_eval(const ModelDev* __restrict__ md
     }
 }
 
-template <int D>
-__global__ __launch_bounds__(kBlock) void k_layer(const ModelDev* __restrict__ mdp, int layer, const float* __restrict__ ug, int64_t B,
+template <int D, int NBP>
+__global__ __launch_bounds__(Cfg<NBP>::kBlock) void k_layer(const ModelDev* __restrict__ mdp, int layer, const float* __restrict__ ug, int64_t B,
                                                   float* __restrict__ yg, float* __restrict__ ldg, int32_t* __restrict__ idx_out) {
-    __shared__ float scr[2 * NBP * kBlock];
+    constexpr int kBlock = Cfg<NBP>::kBlock;
+    __shared__ float scr[Cfg<NBP>::kRows * kBlock];
     const ModelDev& md = *mdp;
     for (int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x; b < B; b += (int64_t)gridDim.x * kBlock) {
         float cur[D], nxt[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) cur[d] = ug[b * D + d];
         float ld;
-        if (md.layer_kind == WF_LAYER_IMADE) ld = imade_direct<D>(md, md.nets[layer], cur, nxt, scr, idx_out ? idx_out + b * D * 2 : nullptr);
-        else ld = made_direct<D>(md.nets[layer], cur, nxt, scr);
+        if (md.layer_kind == WF_LAYER_IMADE) ld = imade_direct<D, NBP>(md, md.nets[layer], cur, nxt, scr, idx_out ? idx_out + b * D * 2 : nullptr);
+        else ld = made_direct<D, NBP>(md.nets[layer], cur, nxt, scr);
         ldg[b] = ld;
 #pragma unroll
         for (int d = 0; d < D; ++d) yg[b * D + d] = nxt[d];
@@ -415,22 +426,24 @@ int sums_blocks(int64_t B) {
     return (int)n;
 }
 
+template <int NBP>
 int grid_for(int64_t B) {
+    constexpr int kBlock = Cfg<NBP>::kBlock;
     int64_t n = (B + kBlock - 1) / kBlock;
     const int64_t cap = 256 * 8;  // 256 CUs, grid-stride beyond that
     if (n > cap) n = cap;
     return (int)n;
 }
 
-template <int D>
+template <int D, int NBP>
 int launch_eval_d(const ModelDev* mdp, int mode, const float* x, int64_t B, float* out, float* u, int32_t* idx, hipStream_t s) {
-    hipLaunchKernelGGL(k_eval<D>, dim3(grid_for(B)), dim3(kBlock), 0, s, mdp, mode, x, B, out, u, idx);
+    hipLaunchKernelGGL((k_eval<D, NBP>), dim3(grid_for<NBP>(B)), dim3(Cfg<NBP>::kBlock), 0, s, mdp, mode, x, B, out, u, idx);
     return 0;
 }
 
-template <int D>
+template <int D, int NBP>
 int launch_layer_d(const ModelDev* mdp, int layer, const float* u_in, int64_t B, float* y, float* ld, int32_t* idx, hipStream_t s) {
-    hipLaunchKernelGGL(k_layer<D>, dim3(grid_for(B)), dim3(kBlock), 0, s, mdp, layer, u_in, B, y, ld, idx);
+    hipLaunchKernelGGL((k_layer<D, NBP>), dim3(grid_for<NBP>(B)), dim3(Cfg<NBP>::kBlock), 0, s, mdp, layer, u_in, B, y, ld, idx);
     return 0;
 }
 
@@ -445,23 +458,34 @@ int finish_launch() {
 
 }  // namespace
 
-#define WF_DISPATCH_D(D_, CALL)                      \
-    switch (D_) {                                    \
-        case 2: CALL(2); break;                      \
-        case 3: CALL(3); break;                      \
-        case 4: CALL(4); break;                      \
-        case 5: CALL(5); break;                      \
-        case 6: CALL(6); break;                      \
-        case 7: CALL(7); break;                      \
-        case 8: CALL(8); break;                      \
-        default: return WF_ERR_UNSUPPORTED;          \
+#define WF_DISPATCH_D(D_, NBP_, CALL)                                         \
+    if ((NBP_) == 32) {                                                          \
+        switch (D_) {                                                            \
+            case 2: CALL(2, 32); break;                                          \
+            case 3: CALL(3, 32); break;                                          \
+            case 4: CALL(4, 32); break;                                          \
+            case 5: CALL(5, 32); break;                                          \
+            case 6: CALL(6, 32); break;                                          \
+            case 7: CALL(7, 32); break;                                          \
+            case 8: CALL(8, 32); break;                                          \
+            default: return WF_ERR_UNSUPPORTED;                                  \
+        }                                                                        \
+    } else if ((NBP_) == 64) {                                                   \
+        switch (D_) {                                                            \
+            case 2: CALL(2, 64); break;                                          \
+            case 3: CALL(3, 64); break;                                          \
+            case 4: CALL(4, 64); break;                                          \
+            default: return WF_ERR_UNSUPPORTED;                                  \
+        }                                                                        \
+    } else {                                                                     \
+        return WF_ERR_UNSUPPORTED;                                               \
     }
 
 int launch_scalar(const ModelDev& md, const ModelDev* md_dev, int mode, const float* x, int64_t B, float* out, float* u, int32_t* idx,
                   void* stream) {
     hipStream_t s = (hipStream_t)stream;
-#define CALL(DD) launch_eval_d<DD>(md_dev, mode, x, B, out, u, idx, s)
-    WF_DISPATCH_D(md.D, CALL)
+#define CALL(DD, NN) launch_eval_d<DD, NN>(md_dev, mode, x, B, out, u, idx, s)
+    WF_DISPATCH_D(md.D, md.nbp, CALL)
 #undef CALL
     return finish_launch();
 }
@@ -469,8 +493,8 @@ int launch_scalar(const ModelDev& md, const ModelDev* md_dev, int mode, const fl
 int launch_scalar_layer(const ModelDev& md, const ModelDev* md_dev, int layer, const float* u_in, int64_t B, float* y, float* logdet,
                         int32_t* idx, void* stream) {
     hipStream_t s = (hipStream_t)stream;
-#define CALL(DD) launch_layer_d<DD>(md_dev, layer, u_in, B, y, logdet, idx, s)
-    WF_DISPATCH_D(md.D, CALL)
+#define CALL(DD, NN) launch_layer_d<DD, NN>(md_dev, layer, u_in, B, y, logdet, idx, s)
+    WF_DISPATCH_D(md.D, md.nbp, CALL)
 #undef CALL
     return finish_launch();
 }

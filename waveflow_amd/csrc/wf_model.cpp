@@ -176,7 +176,17 @@ static int model_build(wf_model* m) {
         md.constrained_mask |= 1u << d.constrained_left[i];
     }
 
-    m->nbp = 32;
+    // padded bases per dimension: 32 covers every shipped configuration; 64 e.g. the 33-knot ("32-bin") variant
+    {
+        int nb_max = 2;
+        if (d.layer_kind == WF_LAYER_IMADE && d.n_flow_layers > 0) nb_max = std::max(nb_max, n_bases_of(WF_SPLINE_I, d.i_degree, d.i_knots));
+        if (d.prior_kind == WF_PRIOR_WAVEFLOW) nb_max = std::max(nb_max, n_bases_of(WF_SPLINE_B, d.p_degree, d.p_knots));
+        if (d.prior_kind == WF_PRIOR_MFLOW) nb_max = std::max(nb_max, n_bases_of(WF_SPLINE_M, d.p_degree, d.p_knots));
+        m->nbp = nb_max <= 32 ? 32 : 64;
+        if (nb_max > 64) return WF_ERR_UNSUPPORTED;
+        if (m->nbp == 64 && D > 4) return WF_ERR_UNSUPPORTED;
+    }
+    md.nbp = m->nbp;
     std::vector<double> keep_i64, keep_p64, keep_o2b;
     // ---- tables
     if (d.layer_kind == WF_LAYER_IMADE && d.n_flow_layers > 0) {
