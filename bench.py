@@ -24,6 +24,11 @@ FLOP_PER_EVAL = 63232          # dense conditioner: 3 x 15872 + 15616
 BYTES_PER_EVAL = 12            # 2 x fp32 in + 1 x fp32 out
 PEAK_F32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak
 PEAK_HBM_GBS = 8000.0
+# HBM bytes per log_pdf launch of 2^20 walkers from the PMC passes of the same command (separate rocprofv3 --pmc runs,
+# profiles/r01b_pmc_summary_mfma_f16split.txt): FETCH_SIZE 7719 KB + WRITE_SIZE 4096 KB.  The walker read is 8 B/lane
+# (not the 16 B/lane stream the guide's x2 FETCH_SIZE correction was calibrated on) and matches the 8.39 MB of
+# coordinates as reported, so no correction is applied.  Algorithmic bytes: 12 B x 2^20 = 12.6 MB.
+PMC_TRAFFIC_BYTES_2POW20 = (7719 + 4096) * 1024
 
 
 def he_model(kernel):
@@ -101,9 +106,12 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("WF_FORCE_DIST") == "1"   # WF_FORCE_DIST: exercise RCCL init with one rank
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     model, flat = he_model(args.kernel)
     B = args.batch
@@ -135,7 +143,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -151,7 +159,7 @@ def main():
     dt = time.perf_counter() - t0
 
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
@@ -170,7 +178,8 @@ def main():
                                    + (" + 1 RCCL all-reduce of 3 doubles" if world > 1 else ""),
                        "walkers_per_gpu": B, "kernel": args.kernel, "mean_logp": mean_logp},
             "roofline": {"bound": "mfma", "achieved": k_evals_s * FLOP_PER_EVAL / 1e12, "peak": PEAK_F32_MATRIX_TFLOPS,
-                         "unit": "TFLOP/s", "frac": k_evals_s * FLOP_PER_EVAL / 1e12 / PEAK_F32_MATRIX_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": k_evals_s * FLOP_PER_EVAL / 1e12 / PEAK_F32_MATRIX_TFLOPS,
+                         "traffic": PMC_TRAFFIC_BYTES_2POW20 if B == (1 << 20) else None,
                          "kernel": "log_pdf", "kernel_ms": kern_ms, "flop_per_eval": FLOP_PER_EVAL},
             "hbm": {"achieved": k_evals_s * BYTES_PER_EVAL / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": k_evals_s * BYTES_PER_EVAL / 1e9 / PEAK_HBM_GBS, "bytes_per_eval": BYTES_PER_EVAL},
@@ -178,7 +187,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(flat, x_host.numpy())
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
