@@ -85,6 +85,7 @@ typedef struct {
     int32_t n_constrained_left; /* constrained_dimension_indices_left, model_factory.py:124-129 */
     int32_t constrained_left[WF_MAX_DIM];
     int32_t n_mesh;             /* n_spline_base_mesh_points (2000) */
+    float i_reverse_tol;        /* IMADE reverse_fun_tol (bisection tolerance of the inverse, isplines_jax.py:153-156) */
 } wf_model_desc;
 
 typedef struct wf_model wf_model;
@@ -151,6 +152,19 @@ int wf_flow_fwd(const wf_model* m, const float* x_dev, int64_t B, float* u_dev, 
  * following Reverse: y[B][D], logdet[B]; bin_idx_dev [B][D][2] or NULL (IMADE only). */
 int wf_layer_fwd(const wf_model* m, int layer, const float* u_in_dev, int64_t B, float* y_dev, float* logdet_dev,
                  int32_t* bin_idx_dev, void* stream);
+
+/* Serial(...).inverse_fun (bijections.py:462-463): x[B][D] from u[B][D] through the reversed layer stack
+ * (Reverse, IMADE.inverse_fun made.py:85-100 by bisection helpers.py:150-166 / MADE.inverse_fun made.py:29-37,
+ * BoxTransformLayer.reverse_fun_* made.py:139-154,186-197).  exact == 0 reproduces the reference's IMADE.inverse_fun, which
+ * evaluates the conditioner on its inputs (made.py:88) and is therefore not the inverse of direct_fun for columns > 0;
+ * exact != 0 conditions on the reconstructed prefix (the true inverse). */
+int wf_inverse_fwd(const wf_model* m, const float* u_dev, int64_t B, float* x_dev, int32_t exact, void* stream);
+
+/* sample(rng, params, num_samples) of Waveflow (wavefunctions.py:74-107), MFlow (distributions.py:165-190) and Flow
+ * (distributions.py:104-108): column-by-column rejection sampling of the prior, then wf_inverse_fwd.  x_dev[B][D];
+ * latent_dev[B][D] or NULL (`return_original_samples`).  Counter-based Philox4x32-10 keyed by (seed, walker index):
+ * results are reproducible for a given seed but do not follow JAX's threefry stream (parity unpinned). */
+int wf_sample(const wf_model* m, uint64_t seed, int64_t B, float* x_dev, float* latent_dev, int32_t exact, void* stream);
 
 /* Rational-quadratic spline bijector, elementwise (flows/bijections/neural_splines.py:16-184; dead code in the reference,
  * parity unpinned).  x[N]; uw, uh [N][K] unnormalised widths / heights; ud [N][n_deriv] unnormalised derivatives with

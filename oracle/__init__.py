@@ -52,7 +52,7 @@ class _Model(ctypes.Structure):
                 ("i_reg", ctypes.c_float), ("isp", _Spline), ("prior_kind", ctypes.c_int),
                 ("normal_offset", ctypes.c_float), ("psp", _Spline), ("psp_plain", ctypes.c_void_p),
                 ("ob_to_b", ctypes.c_void_p), ("n_constr_left", ctypes.c_int),
-                ("constr_left", ctypes.c_int * MAX_D)]
+                ("constr_left", ctypes.c_int * MAX_D), ("reverse_tol", ctypes.c_float), ("b_to_ob", ctypes.c_void_p)]
 
 
 @functools.lru_cache(None)
@@ -71,6 +71,11 @@ def lib(f64=False):
     L.wfo_flow_direct.restype = ctypes.c_int
     L.wfo_flow_direct.argtypes = [ctypes.POINTER(_Model), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                   ctypes.c_void_p, ctypes.c_void_p]
+    L.wfo_inverse.restype = ctypes.c_int
+    L.wfo_inverse.argtypes = [ctypes.POINTER(_Model), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int]
+    L.wfo_prior_column_density.restype = ctypes.c_int
+    L.wfo_prior_column_density.argtypes = [ctypes.POINTER(_Model), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                           ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
     L.wfo_rqs.restype = ctypes.c_int
     L.wfo_rqs.argtypes = [ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                           ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
@@ -171,7 +176,7 @@ class Model:
 
     def __init__(self, D, n_layers, layer_kind="imade", box=None, box_L=1.0, i_k=5, i_knots=16, i_reg=0.0,
                  i_left=None, i_right=None, prior="waveflow", p_k=5, p_knots=16, p_left=None, p_right=None,
-                 constr_left=(), normal_offset=0.0, n_mesh=2000, hidden=64):
+                 constr_left=(), normal_offset=0.0, n_mesh=2000, hidden=64, reverse_tol=1e-6):
         self.D, self.n_layers, self.hidden = D, n_layers, hidden
         self.keep = []
         m = _Model()
@@ -180,6 +185,7 @@ class Model:
         m.box_kind = {None: 0, "mean": 1, "first": 2}[box]
         m.box_L = box_L
         m.i_reg = i_reg
+        m.reverse_tol = reverse_tol
         self.i_nb = self.p_nb = 0
         if layer_kind == "imade":
             tab = np.ascontiguousarray(table(KIND_I, i_k, i_knots, n_mesh), dtype=np.float32)
@@ -194,7 +200,9 @@ class Model:
             ob32 = np.ascontiguousarray(OB, dtype=np.float32)
             b32 = np.ascontiguousarray(Bt, dtype=np.float32)
             o2b32 = np.ascontiguousarray(o2b, dtype=np.float32)
-            self.keep += [ob32, b32, o2b32]
+            b2o32 = np.ascontiguousarray(b2o, dtype=np.float32)
+            self.keep += [ob32, b32, o2b32, b2o32]
+            m.b_to_ob = b2o32.ctypes.data
             self._spline(m.psp, p_k, ob32, {0: 0} if p_left is None else p_left, {0: 0} if p_right is None else p_right, n_mesh)
             m.psp_plain = b32.ctypes.data
             m.ob_to_b = o2b32.ctypes.data
@@ -291,6 +299,28 @@ class Model:
         lib(f64).wfo_imade_direct(ctypes.byref(self.c), layer_params.ctypes.data, u.ctypes.data, B, y.ctypes.data,
                                ld.ctypes.data, idx.ctypes.data)
         return y, ld, idx
+
+    def inverse(self, params, u, f64=False, exact=False):
+        """Serial.inverse_fun (bijections.py:462-463).  exact=False reproduces the reference's IMADE.inverse_fun, which
+        conditions on its inputs (made.py:88); exact=True is the true autoregressive inverse of direct_fun."""
+        params = np.ascontiguousarray(params, dtype=np.float32)
+        u = np.ascontiguousarray(u, dtype=np.float32).reshape(-1, self.D)
+        x = np.zeros_like(u)
+        rc = lib(f64).wfo_inverse(ctypes.byref(self.c), params.ctypes.data, u.ctypes.data, u.shape[0], x.ctypes.data, int(exact))
+        assert rc == 0
+        return x
+
+    def prior_column_density(self, params, outputs, col, xs):
+        """density (and the rejection bound ymax) of column `col` given the already drawn columns in `outputs` [D]."""
+        params = np.ascontiguousarray(params, dtype=np.float32)
+        outputs = np.ascontiguousarray(outputs, dtype=np.float32).reshape(self.D)
+        xs = np.ascontiguousarray(xs, dtype=np.float32).reshape(-1)
+        dens = np.zeros_like(xs)
+        ymax = ctypes.c_float()
+        rc = lib().wfo_prior_column_density(ctypes.byref(self.c), params.ctypes.data, outputs.ctypes.data, int(col), xs.ctypes.data,
+                                            xs.size, dens.ctypes.data, ctypes.byref(ymax))
+        assert rc == 0
+        return dens, ymax.value
 
     def flow_direct(self, params, x):
         params = np.ascontiguousarray(params, dtype=np.float32)

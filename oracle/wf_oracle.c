@@ -235,6 +235,8 @@ typedef struct {
     const float* ob_to_b;       /* kind 0: [nb][nb] fp32, bsplines_jax.py:134 */
     int n_constr_left;          /* constrained_dimension_indices_left, model_factory.py:124-129 */
     int constr_left[WFO_MAX_D];
+    float reverse_tol;          /* IMADE reverse_fun_tol (made.py:44, isplines_jax.py:153-156) */
+    const float* b_to_ob;       /* kind 0 prior: [nb][nb], used by the rejection sampler's bound (bsplines_jax.py:164-166) */
 } wfo_model;
 
 /* X_cached, isplines_jax.py:45-56 / msplines_jax.py:30-41 / bsplines_jax.py:19-30.
@@ -583,6 +585,142 @@ int wfo_flow_direct(const wfo_model* m, const float* params, const float* x, int
         for (int d = 0; d < D; ++d) u[b * D + d] = (float)uo[d];
         logdet[b] = (float)ld;
     }
+    return 0;
+}
+
+
+/* ------------------------------------------------------------------ */
+/* Part 2b: inverse direction                      */
+/* ------------------------------------------------------------------ */
+
+/* helpers.binary_search (utils/helpers.py:150-166) on func(x) = spline(w, x) - y over [0, 1] */
+static real ispline_reverse(const wfo_model* m, const real* w, real y, real tol) {
+    real low = C(0.0), high = C(1.0);
+    for (;;) {
+        real mid = C(0.5) * (low + high);
+        if (!((low + tol / 2 < mid) && (mid < high - tol / 2))) break;
+        real f = spline_apply(&m->isp, 0, w, mid, 0) - y;
+        if (f > 0) high = mid; else low = mid;
+    }
+    return low;
+}
+
+/* IMADE.inverse_fun (made.py:85-100).  NOTE the reference evaluates the conditioner on `inputs` (the values being
+ * inverted), not on the partially reconstructed outputs (contrast MADE.inverse_fun, made.py:29-37): reproduced. */
+static const float* imade_inverse(const wfo_model* m, const float* p, const real* in, real* out, int exact) {
+    int D = m->D, nb = m->isp.nb;
+    real bij[WFO_MAX_D * WFO_MAX_NB];
+    const float* next = p;
+    for (int d = 0; d < D; ++d) out[d] = C(0.0);
+    for (int d = 0; d < D; ++d) {
+        /* exact != 0: the true autoregressive inverse (conditioner on the reconstructed prefix) */
+        if (d == 0 || exact) next = bijection_params(p, D, m->hidden, nb, 0, exact ? out : in, bij);
+        real* w = bij + d * nb;
+        for (int j = 0; j < nb; ++j) w[j] = w[j] + m->i_reg;
+        remove_bias(1, m->isp.k, nb, w);
+        enforce_bc(&m->isp, m->isp.tab, 1, w);
+        out[d] = ispline_reverse(m, w, in[d], (real)m->reverse_tol);
+    }
+    return next;
+}
+
+/* MADE.inverse_fun (made.py:29-37): sequential, conditioner on the partially reconstructed outputs */
+static const float* made_inverse(const wfo_model* m, const float* p, const real* in, real* out) {
+    int D = m->D;
+    const float* next = p;
+    for (int d = 0; d < D; ++d) out[d] = C(0.0);
+    for (int c = 0; c < D; ++c) {
+        real o[2 * WFO_MAX_D];
+        next = conditioner(p, D, m->hidden, 2, out, o);
+        out[c] = in[c] * R_EXP(o[c]) + o[D + c];
+    }
+    return next;
+}
+
+/* BoxTransformLayer.reverse_fun_mean (made.py:186-197) / reverse_fun_first (made.py:139-154) */
+static void box_reverse(const wfo_model* m, const real* u, real* x) {
+    int D = m->D;
+    real L = m->box_L;
+    if (m->box_kind == 1) {
+        real out[WFO_MAX_D];
+        real c = C(0.0), s = C(0.0);
+        out[0] = C(0.0);
+        for (int i = 0; i < D - 1; ++i) { c = c + u[i]; out[i + 1] = c; }
+        for (int i = 0; i < D; ++i) s = s + out[i];
+        real mean = s / (real)D;
+        real w = out[D - 1];
+        real pm = u[D - 1] * (1 - w) - (C(0.5) - mean);
+        for (int i = 0; i < D; ++i) x[i] = (out[i] - mean + pm) * 2 * L;
+    } else {
+        x[0] = (u[0] - C(0.5)) * 2 * L;
+        for (int i = 1; i < D; ++i) x[i] = u[i] * (L - x[i - 1]) + x[i - 1];
+    }
+}
+
+/* Serial.inverse_fun (bijections.py:462-463): layers in reverse order.  layer_off[l] = offset of layer l's params. */
+int wfo_inverse(const wfo_model* m, const float* params, const float* u, int64_t B, float* x_out, int exact) {
+    int D = m->D;
+    /* parameter offset of each flow layer */
+    int64_t per_layer;
+    {
+        int H = m->hidden, n_out = m->layer_kind == 0 ? m->isp.nb : 2;
+        per_layer = (int64_t)D * H + H + (int64_t)H * H + H + (int64_t)H * n_out * D + (int64_t)n_out * D + (m->layer_kind == 0 ? (int64_t)D * n_out : 0);
+    }
+    for (int64_t b = 0; b < B; ++b) {
+        real cur[WFO_MAX_D], nxt[WFO_MAX_D];
+        for (int d = 0; d < D; ++d) cur[d] = (real)u[b * D + d];
+        for (int l = m->n_layers - 1; l >= 0; --l) {
+            for (int d = 0; d < D; ++d) nxt[d] = cur[D - 1 - d];          /* Reverse.inverse_fun */
+            const float* p = params + per_layer * l;
+            if (m->layer_kind == 0) imade_inverse(m, p, nxt, cur, exact); else made_inverse(m, p, nxt, cur);
+        }
+        if (m->box_kind) { box_reverse(m, cur, nxt); for (int d = 0; d < D; ++d) cur[d] = nxt[d]; }
+        for (int d = 0; d < D; ++d) x_out[b * D + d] = (float)cur[d];
+    }
+    return 0;
+}
+
+/* The density the reference's rejection sampler draws column `col` from, given the already drawn columns
+ * (wavefunctions.py:89-104 / distributions.py:170-186): value at x, and the sampler's upper bound ymax.
+ * outputs: [D] with zeros in the columns not drawn yet. */
+int wfo_prior_column_density(const wfo_model* m, const float* params, const float* outputs, int col, const float* xs, int n,
+                             float* dens, float* ymax_out) {
+    int D = m->D, nb = m->psp.nb, H = m->hidden;
+    int n_out_l = m->layer_kind == 0 ? m->isp.nb : 2;
+    int64_t per_layer = (int64_t)D * H + H + (int64_t)H * H + H + (int64_t)H * n_out_l * D + (int64_t)n_out_l * D + (m->layer_kind == 0 ? (int64_t)D * n_out_l : 0);
+    const float* pp = params + per_layer * m->n_layers;
+    real o[WFO_MAX_D], bij[WFO_MAX_D * WFO_MAX_NB];
+    for (int d = 0; d < D; ++d) o[d] = (real)outputs[d];
+    if (m->prior_kind == 0) {
+        bijection_params(pp, D, H, nb, 1, o, bij);
+        real* w = bij + col * nb;
+        enforce_bc(&m->psp, m->psp_plain, 2, w);
+        real c[WFO_MAX_NB], ss = C(0.0);
+        for (int j = 0; j < nb; ++j) {
+            real acc = C(0.0);
+            for (int a = 0; a < nb; ++a) acc = acc + w[a] * m->ob_to_b[a * nb + j];
+            c[j] = acc; ss = ss + acc * acc;
+        }
+        real nrm = R_SQRT(ss);
+        for (int j = 0; j < nb; ++j) c[j] = c[j] / nrm;
+        real ymax = C(0.0);
+        for (int j = 0; j < nb; ++j) {
+            real acc = C(0.0);
+            for (int a = 0; a < nb; ++a) acc = acc + c[a] * m->b_to_ob[a * nb + j];
+            if (acc * acc > ymax) ymax = acc * acc;
+        }
+        *ymax_out = (float)ymax;
+        for (int i = 0; i < n; ++i) { real v = spline_apply(&m->psp, 0, c, (real)xs[i], 0); dens[i] = (float)(v * v); }
+    } else if (m->prior_kind == 1) {
+        bijection_params(pp, D, H, nb, 0, o, bij);
+        real* w = bij + col * nb;
+        remove_bias(0, m->psp.k, nb, w);
+        enforce_bc(&m->psp, m->psp.tab, 0, w);
+        real mx = w[0];
+        for (int j = 1; j < nb; ++j) if (w[j] > mx) mx = w[j];
+        *ymax_out = (float)(mx * (real)(nb + m->psp.k));   /* params.max() * n_knots, msplines_jax.py:147-150 */
+        for (int i = 0; i < n; ++i) dens[i] = (float)spline_apply(&m->psp, 0, w, (real)xs[i], 0);
+    } else return -1;
     return 0;
 }
 

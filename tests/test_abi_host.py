@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
 def test_desc_struct_matches_header_layout():
     # 4-byte fields only; guards against drift between _lib.ModelDesc and wf_model_desc
     assert ctypes.sizeof(_lib.BC) == 4 + 4 * 4 + 4 * 4
-    assert ctypes.sizeof(_lib.ModelDesc) == 4 * 9 + 2 * 36 + 4 * 3 + 2 * 36 + 4 + 4 + 16 * 4 + 4
+    assert ctypes.sizeof(_lib.ModelDesc) == 4 * 9 + 2 * 36 + 4 * 3 + 2 * 36 + 4 + 4 + 16 * 4 + 4 + 4
 
 
 def test_strerror_and_no_device_is_loud():

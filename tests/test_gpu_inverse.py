@@ -1,0 +1,116 @@
+"""Inverse / sampling direction on the HIP path vs the oracle.  PRNG parity is unpinned (the reference
+draws with JAX's threefry); the deterministic inverse is compared value by value, the sampler distributionally."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import sorted_walkers
+
+pytestmark = pytest.mark.gpu
+
+
+def he(he_flat):
+    from waveflow_amd import checkpoint, model_factory
+    init_fun = model_factory.get_waveflow_model(2, base_spline_degree=6, i_spline_degree=6, n_prior_internal_knots=23,
+                                                n_i_internal_knots=23, i_spline_reg=0.05, i_spline_reverse_fun_tol=1e-6,
+                                                n_flow_layers=3, box_size=10, xu_coord_type="mean")
+    params, psi, log_pdf, sample = init_fun(0, 2)
+    params = checkpoint.unflatten_like(params, he_flat)
+    log_pdf.model.ensure_params(params)
+    return params, psi, log_pdf, sample, oracle.he_model(10.0)
+
+
+@pytest.mark.parametrize("exact", [False, True])
+def test_serial_inverse_vs_oracle(he_flat, exact):
+    params, psi, log_pdf, sample, om = he(he_flat)
+    g = np.random.default_rng(0)
+    u = g.uniform(0.02, 0.98, size=(3000, 2)).astype(np.float32)
+    x = log_pdf.model.inverse(u, exact=exact)
+    xo = om.inverse(he_flat, u, exact=exact)
+    d = np.abs(x - xo)
+    # bisection: identical decisions except where spline(mid) - y changes sign within rounding => off by <= tol * slope
+    assert np.median(d) < 1e-5 and (d > 2e-3).mean() < 5e-3, (np.median(d), d.max())
+    if exact:
+        # the true inverse: direct(inverse(u)) == u up to the bisection tolerance (1e-6 per layer, amplified by 1/slope)
+        u2, _ = log_pdf.model.flow(x)
+        assert np.median(np.abs(u2 - u)) < 2e-5 and np.abs(u2 - u).max() < 5e-3
+
+
+def test_reference_inverse_quirk_is_reproduced(he_flat, golden):
+    """made.py:88: with the conditioner evaluated on the inputs, inverse(direct(x)) != x for columns > 0 -- the reference's
+    published MFlow reconstruction distances (2.4e-2 of the unit box) are of that size."""
+    params, psi, log_pdf, sample, om = he(he_flat)
+    sp = np.sort(golden["he_golden"]["sample_points"], -1).astype(np.float32)
+    u, _ = log_pdf.model.flow(sp)
+    x_ref = log_pdf.model.inverse(u, exact=False)
+    x_exact = log_pdf.model.inverse(u, exact=True)
+    assert np.abs(x_exact - sp).max() < 2e-3
+    assert np.median(np.abs(x_ref - sp)) > 0.05     # the quirk: percent-level errors in box units
+    np.testing.assert_allclose(x_ref, om.inverse(he_flat, u), atol=2e-3)
+
+
+def test_sampler_draws_from_the_prior_columns_and_is_reproducible(he_flat):
+    import torch
+    params, psi, log_pdf, sample, om = he(he_flat)
+    m = log_pdf.model
+    n = 200000
+    x, lat = m.sample(1234, n, return_latent=True, exact=True)
+    x2 = m.sample(1234, n, exact=True)
+    assert torch.equal(x, x2)
+    assert not torch.equal(x, m.sample(1235, n, exact=True))
+    lat = lat.cpu().numpy()
+    assert lat.min() >= 0 and lat.max() <= 1
+    # column 0: the conditioner sees zeros, its density is the same for every walker -> compare the histogram
+    grid = np.linspace(0, 1, 2001)
+    dens, ymax = om.prior_column_density(he_flat, [0, 0], 0, grid)
+    assert dens.max() <= ymax * 1.0001
+    cdf = np.concatenate([[0], np.cumsum(0.5 * (dens[1:] + dens[:-1]) * np.diff(grid))])
+    cdf /= cdf[-1]
+    emp = np.searchsorted(np.sort(lat[:, 0]), grid) / n
+    assert np.abs(emp - cdf).max() < 4.0 / np.sqrt(n)       # Kolmogorov-Smirnov, ~1e-6 false-alarm level
+    # column 1 given column 0 in a narrow bin
+    sel = np.abs(lat[:, 0] - 0.7) < 0.004
+    dens1, _ = om.prior_column_density(he_flat, [0.7, 0], 1, grid)
+    cdf1 = np.concatenate([[0], np.cumsum(0.5 * (dens1[1:] + dens1[:-1]) * np.diff(grid))]); cdf1 /= cdf1[-1]
+    emp1 = np.searchsorted(np.sort(lat[sel, 1]), grid) / sel.sum()
+    assert np.abs(emp1 - cdf1).max() < 4.0 / np.sqrt(sel.sum()) + 0.02
+    # exact inverse => x ~ |psi|^2: direct(x) gives back the latent, walkers are sorted and inside the box
+    xn = x.cpu().numpy()
+    assert np.all(xn[:, 0] <= xn[:, 1] + 1e-4) and np.abs(xn).max() <= 10.0 + 1e-3
+    u, _ = m.flow(x)
+    assert np.median(np.abs(u.cpu().numpy() - lat)) < 2e-5
+    # <log psi^2> over |psi|^2 samples is larger than over uniform walkers (sanity of the whole chain)
+    lp = log_pdf(params, x)
+    assert lp.mean().item() > -3.0
+
+
+def test_closure_surface_sample_and_inverse(he_flat):
+    from waveflow_amd import flows, model_factory, flatten_params
+    params, psi, log_pdf, sample, om = he(he_flat)
+    s = sample(3, params, 250)
+    assert tuple(s.shape) == (250, 2)
+    s2, lat = sample(3, params, 250, return_original_samples=True)
+    assert (s - s2).abs().max().item() == 0 and tuple(lat.shape) == (250, 2)
+    # per-layer protocol: IMADE alone
+    mt = model_factory.get_masked_transform
+    p, dfun, ifun = flows.IMADE(mt(), 5, 16, 0.05, 1e-6)(0, 2)
+    u = np.random.default_rng(0).uniform(0.05, 0.95, size=(500, 2)).astype(np.float32)
+    y, ld = dfun(p, u)
+    x_back, zero = ifun(p, y, exact=True)
+    assert zero == 0 and np.abs(x_back - u).max() < 1e-4
+    # Flow (affine MADE + Normal) and MFlow samplers run and invert exactly (MADE.inverse_fun is the true inverse)
+    init = flows.Flow(flows.Serial(*(flows.MADE(mt(return_simple_masked_transform=True)), flows.Reverse()) * 2), flows.Normal(-0.5))
+    fp, flp, fsample = init(3, 2)
+    xs, lat = fsample(0, fp, 20000, return_original_samples=True)
+    uu, _ = flp.model.flow(xs)
+    assert (uu - lat).abs().max().item() < 1e-3
+    assert abs(lat.mean().item()) < 0.03 and abs(lat.std().item() - 1) < 0.03
+    init = model_factory.get_model(n_flow_layers=2, i_spline_reg=0.02)
+    mp, mlp, msample = init(1, 2)
+    xs = msample(0, mp, 1000)
+    assert xs.min().item() >= 0 and xs.max().item() <= 1
+    # BoxTransformLayer alone
+    _, bdir, brev = flows.BoxTransformLayer(3.0, "first")(0, 3)
+    xw = sorted_walkers(100, 3, 3.0, 1)
+    ub, _ = bdir((), xw)
+    np.testing.assert_allclose(brev((), ub)[0], xw, atol=1e-5)

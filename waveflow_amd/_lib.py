@@ -48,13 +48,13 @@ class ModelDesc(ctypes.Structure):
                 ("i_left", BC), ("i_right", BC), ("prior_kind", ctypes.c_int32), ("p_degree", ctypes.c_int32),
                 ("p_knots", ctypes.c_int32), ("p_left", BC), ("p_right", BC), ("normal_offset", ctypes.c_float),
                 ("n_constrained_left", ctypes.c_int32), ("constrained_left", ctypes.c_int32 * WF_MAX_DIM),
-                ("n_mesh", ctypes.c_int32)]
+                ("n_mesh", ctypes.c_int32), ("i_reverse_tol", ctypes.c_float)]
 
 
 EXPORTS = ["wf_abi_version", "wf_strerror", "wf_last_hip_error", "wf_last_hip_error_string", "wf_device_count",
            "wf_tables_build", "wf_model_create", "wf_model_destroy", "wf_model_param_count", "wf_model_n_bases",
            "wf_model_set_params", "wf_model_set_kernel", "wf_logpdf_fwd", "wf_psi_fwd", "wf_flow_fwd", "wf_layer_fwd",
-           "wf_block_sums", "wf_block_sums_workspace_bytes", "wf_rqs_fwd"]
+           "wf_block_sums", "wf_block_sums_workspace_bytes", "wf_rqs_fwd", "wf_inverse_fwd", "wf_sample"]
 
 _lib = None
 
@@ -99,6 +99,10 @@ def lib():
     L.wf_flow_fwd.argtypes = [vp, vp, i64, vp, vp, vp]
     L.wf_layer_fwd.restype = i32
     L.wf_layer_fwd.argtypes = [vp, i32, vp, i64, vp, vp, vp, vp]
+    L.wf_inverse_fwd.restype = i32
+    L.wf_inverse_fwd.argtypes = [vp, vp, i64, vp, i32, vp]
+    L.wf_sample.restype = i32
+    L.wf_sample.argtypes = [vp, ctypes.c_uint64, i64, vp, vp, i32, vp]
     L.wf_rqs_fwd.restype = i32
     L.wf_rqs_fwd.argtypes = [vp, vp, vp, vp, i64, i32, i32, i32, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                              vp, vp, vp, vp]

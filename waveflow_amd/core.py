@@ -160,6 +160,23 @@ class DeviceModel:
             return back(y), back(ld), back(idx)
         return back(y), back(ld)
 
+    def inverse(self, u, exact=False):
+        """Serial.inverse_fun; exact=False reproduces the reference's IMADE.inverse_fun (conditioner on its inputs)."""
+        t, back = self._to_dev(u)
+        B = t.shape[0]
+        x = self._new((B, self.D))
+        _lib.check(_lib.lib().wf_inverse_fwd(self._h, self._p(t), B, self._p(x), int(bool(exact)), self._stream()), "wf_inverse_fwd")
+        return back(x)
+
+    def sample(self, seed, num_samples, return_latent=False, exact=False):
+        """-> x [n, D] on the device (and the prior-space samples when return_latent)."""
+        B = int(num_samples)
+        x = self._new((B, self.D))
+        lat = self._new((B, self.D)) if return_latent else None
+        _lib.check(_lib.lib().wf_sample(self._h, ctypes.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), B, self._p(x), self._p(lat),
+                                        int(bool(exact)), self._stream()), "wf_sample")
+        return (x, lat) if return_latent else x
+
     def block_sums(self, v):
         """fp64 [sum v, sum v^2, count] on the device (deterministic order)."""
         torch = _torch()

@@ -62,6 +62,8 @@ struct ModelDev {
     SplineDev isp;                // flow-layer I-spline (IMADE)
     SplineDev psp;                // prior spline: orthogonal-B (WAVEFLOW) or M (MFLOW)
     const float* ob_to_b;         // [nb][nbp] fp32 (WAVEFLOW): row a = ob_to_b[a][:]
+    const float* b_to_ob;         // [nb][nbp] fp32 (WAVEFLOW): the sampler's bound (bsplines_jax.py:164-166)
+    float reverse_tol;            // IMADE reverse_fun_tol
     NetPlain nets[kMaxNets];      // flow layers 0..n_layers-1, then the prior net
     NetMfma mnets[kMaxNets];
 };
@@ -92,6 +94,9 @@ int launch_scalar(const ModelDev& md, const ModelDev* md_dev, int mode, const fl
                   int32_t* idx, void* stream);
 int launch_scalar_layer(const ModelDev& md, const ModelDev* md_dev, int layer, const float* u_in, int64_t B, float* y,
                         float* logdet, int32_t* idx, void* stream);
+int launch_scalar_inverse(const ModelDev& md, const ModelDev* md_dev, const float* u, int64_t B, float* x, int exact, void* stream);
+int launch_scalar_sample(const ModelDev& md, const ModelDev* md_dev, unsigned long long seed, int64_t B, float* x, float* latent,
+                         int exact, void* stream);
 int launch_rqs(const float* x, const float* uw, const float* uh, const float* ud, int64_t N, int K, int n_deriv, int inverse,
                float left, float right, float bottom, float top, float* y, float* ld, int32_t* bin, void* stream);
 int launch_block_sums(const float* v, int64_t B, double* out, void* ws, int64_t ws_bytes, void* stream);

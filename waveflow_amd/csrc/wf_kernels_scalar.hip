@@ -369,6 +369,222 @@ __global__ __launch_bounds__(Cfg<NBP>::kBlock) void k_layer(const ModelDev* __re
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Inverse direction: Serial.inverse_fun (bijections.py:462-463) and the samplers of
+// Waveflow (wavefunctions.py:74-107), MFlow (distributions.py:165-190) and Flow (distributions.py:104-108).
+// PRNG: the reference draws with JAX's threefry; here Philox4x32-10 keyed by (seed, walker) -- parity unpinned.
+
+struct Philox {
+    unsigned key0, key1, c0, c1, c2, c3;
+    unsigned out[4];
+    int have;
+    __device__ Philox(unsigned long long seed, unsigned long long stream) : key0((unsigned)seed), key1((unsigned)(seed >> 32)), c0(0), c1(0), c2((unsigned)stream), c3((unsigned)(stream >> 32)), have(0) {}
+    __device__ void round(unsigned& a0, unsigned& a1, unsigned& a2, unsigned& a3, unsigned k0, unsigned k1) {
+        const unsigned long long p0 = 0xD2511F53ull * a0, p1 = 0xCD9E8D57ull * a2;
+        const unsigned h0 = (unsigned)(p0 >> 32), l0 = (unsigned)p0, h1 = (unsigned)(p1 >> 32), l1 = (unsigned)p1;
+        a0 = h1 ^ a1 ^ k0; a1 = l1; a2 = h0 ^ a3 ^ k1; a3 = l0;
+    }
+    __device__ void refill() {
+        unsigned a0 = c0, a1 = c1, a2 = c2, a3 = c3, k0 = key0, k1 = key1;
+#pragma unroll
+        for (int r = 0; r < 10; ++r) { round(a0, a1, a2, a3, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+        out[0] = a0; out[1] = a1; out[2] = a2; out[3] = a3;
+        if (++c0 == 0) ++c1;
+        have = 4;
+    }
+    __device__ float uniform() {   // [0, 1) with 24 random bits, like jax.random.uniform's fp32 mantissa fill
+        if (!have) refill();
+        return (float)(out[--have] >> 8) * (1.0f / 16777216.0f);
+    }
+};
+
+// helpers.binary_search (utils/helpers.py:150-166) on spline(w, x) - y over [0, 1]; weights in SCR(0..nb)
+template <int NBP>
+__device__ __forceinline__ float ispline_reverse(const SplineDev& sp, const float* scr, float y, float tol) {
+    float low = 0.0f, high = 1.0f;
+    for (int it = 0; it < 64; ++it) {   // the loop ends after ~log2(1/tol) halvings; 64 bounds it for any tol
+        const float mid = 0.5f * (low + high);
+        if (!((low + tol / 2 < mid) && (mid < high - tol / 2))) break;
+        const Lerp L = make_lerp(mid, sp.n_mesh);
+        const float f = spline_dot<NBP>(sp.tab, L, scr, 0, sp.nb) - y;
+        if (f > 0) high = mid; else low = mid;
+    }
+    return low;
+}
+
+// IMADE.inverse_fun (made.py:85-100).  exact == 0 reproduces the reference: the conditioner sees `in` (the values
+// being inverted) for every column; exact != 0 conditions on the reconstructed prefix (true inverse of direct_fun).
+template <int D, int NBP>
+__device__ __forceinline__ void imade_inverse(const ModelDev& md, const NetPlain& net, const float (&in)[D], float (&out)[D], float* scr,
+                                              int exact) {
+    const SplineDev& sp = md.isp;
+    const int nb = sp.nb;
+    float h[H];
+#pragma unroll
+    for (int d = 0; d < D; ++d) out[d] = 0.0f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        if (d == 0 || exact) {
+            if (exact) hidden_layers<D>(net, out, scr, h); else hidden_layers<D>(net, in, scr, h);
+        }
+        bijection_params<NBP>(net, h, d, nb, true, scr);
+        for (int j = 0; j < nb; ++j) SCR(j) = SCR(j) + md.i_reg;
+        remove_bias(WF_SPLINE_I, sp.degree, nb, scr);
+        enforce_bc(sp, WF_SPLINE_I, scr, 0);
+        out[d] = ispline_reverse<NBP>(sp, scr, in[d], md.reverse_tol);
+    }
+}
+
+// MADE.inverse_fun (made.py:29-37)
+template <int D, int NBP>
+__device__ __forceinline__ void made_inverse(const NetPlain& net, const float (&in)[D], float (&out)[D], float* scr) {
+    float h[H];
+#pragma unroll
+    for (int d = 0; d < D; ++d) out[d] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        hidden_layers<D>(net, out, scr, h);
+        const float lw = out_unit<NBP>(net, h, c, 0), bias = out_unit<NBP>(net, h, c, 1);
+        out[c] = in[c] * expf(lw) + bias;
+    }
+}
+
+// BoxTransformLayer.reverse_fun_mean (made.py:186-197) / reverse_fun_first (made.py:139-154)
+template <int D>
+__device__ __forceinline__ void box_reverse(const ModelDev& md, const float (&u)[D], float (&x)[D]) {
+    const float L = md.box_L;
+    if (md.box_kind == WF_BOX_MEAN) {
+        float o[D];
+        float c = 0.0f, s = 0.0f;
+        o[0] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < D - 1; ++i) { c = c + u[i]; o[i + 1] = c; }
+#pragma unroll
+        for (int i = 0; i < D; ++i) s = s + o[i];
+        const float mean = s / (float)D;
+        const float w = o[D - 1];
+        const float pm = u[D - 1] * (1 - w) - (0.5f - mean);
+#pragma unroll
+        for (int i = 0; i < D; ++i) x[i] = (o[i] - mean + pm) * 2 * L;
+    } else {
+        x[0] = (u[0] - 0.5f) * 2 * L;
+#pragma unroll
+        for (int i = 1; i < D; ++i) x[i] = u[i] * (L - x[i - 1]) + x[i - 1];
+    }
+}
+
+template <int D, int NBP>
+__device__ __forceinline__ void serial_inverse(const ModelDev& md, float (&cur)[D], float* scr, int exact) {
+    float nxt[D];
+    for (int l = md.n_layers - 1; l >= 0; --l) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) nxt[d] = cur[D - 1 - d];   // Reverse.inverse_fun
+        if (md.layer_kind == WF_LAYER_IMADE) imade_inverse<D, NBP>(md, md.nets[l], nxt, cur, scr, exact);
+        else made_inverse<D, NBP>(md.nets[l], nxt, cur, scr);
+    }
+    if (md.box_kind != WF_BOX_NONE) {
+        box_reverse<D>(md, cur, nxt);
+#pragma unroll
+        for (int d = 0; d < D; ++d) cur[d] = nxt[d];
+    }
+}
+
+template <int D, int NBP>
+__global__ __launch_bounds__(Cfg<NBP>::kBlock) void k_inverse(const ModelDev* __restrict__ mdp, const float* __restrict__ ug, int64_t B,
+                                                              float* __restrict__ xg, int exact) {
+    constexpr int kBlock = Cfg<NBP>::kBlock;
+    __shared__ float scr[Cfg<NBP>::kRows * kBlock];
+    const ModelDev& md = *mdp;
+    for (int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x; b < B; b += (int64_t)gridDim.x * kBlock) {
+        float cur[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) cur[d] = ug[b * D + d];
+        serial_inverse<D, NBP>(md, cur, scr, exact);
+#pragma unroll
+        for (int d = 0; d < D; ++d) xg[b * D + d] = cur[d];
+    }
+}
+
+template <int D, int NBP>
+__global__ __launch_bounds__(Cfg<NBP>::kBlock) void k_sample(const ModelDev* __restrict__ mdp, unsigned long long seed, int64_t B,
+                                                             float* __restrict__ xg, float* __restrict__ latent, int exact) {
+    constexpr int kBlock = Cfg<NBP>::kBlock;
+    __shared__ float scr[Cfg<NBP>::kRows * kBlock];
+    const ModelDev& md = *mdp;
+    for (int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x; b < B; b += (int64_t)gridDim.x * kBlock) {
+        Philox rng(seed, (unsigned long long)b);
+        float cur[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) cur[d] = 0.0f;
+        if (md.prior_kind == WF_PRIOR_UNIFORM) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) cur[d] = rng.uniform();
+        } else if (md.prior_kind == WF_PRIOR_NORMAL) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {   // Box-Muller
+                const float u1 = fmaxf(rng.uniform(), 5.9604645e-8f), u2 = rng.uniform();
+                cur[d] = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+            }
+        } else {
+            const NetPlain& net = md.nets[md.n_layers];
+            const SplineDev& sp = md.psp;
+            const int nb = sp.nb;
+            const bool wavefn = md.prior_kind == WF_PRIOR_WAVEFLOW;
+#pragma unroll
+            for (int col = 0; col < D; ++col) {
+                float h[H];
+                hidden_layers<D>(net, cur, scr, h);   // conditioner on the columns drawn so far, zeros elsewhere
+                bijection_params<NBP>(net, h, col, nb, !wavefn, scr);
+                float ymax = 0.0f;
+                int row0 = 0;
+                if (wavefn) {
+                    enforce_bc(sp, WF_SPLINE_B, scr, 0);
+                    // sample_fun (bsplines_jax.py:144-171): obw = normalised(w @ ob_to_b); ymax = max((obw @ b_to_ob)^2)
+                    float ss = 0.0f;
+                    for (int j = 0; j < nb; ++j) {
+                        float acc = 0.0f;
+                        for (int a = 0; a < nb; ++a) acc = acc + SCR(a) * md.ob_to_b[a * NBP + j];
+                        SCR(NBP + j) = acc;
+                        ss = ss + acc * acc;
+                    }
+                    const float nrm = sqrtf(ss);
+                    for (int j = 0; j < nb; ++j) SCR(NBP + j) = SCR(NBP + j) / nrm;
+                    for (int j = 0; j < nb; ++j) {
+                        float acc = 0.0f;
+                        for (int a = 0; a < nb; ++a) acc = acc + SCR(NBP + a) * md.b_to_ob[a * NBP + j];
+                        ymax = fmaxf(ymax, acc * acc);
+                    }
+                    row0 = NBP;
+                } else {
+                    remove_bias(WF_SPLINE_M, sp.degree, nb, scr);
+                    enforce_bc(sp, WF_SPLINE_M, scr, 0);
+                    float mx = SCR(0);
+                    for (int j = 1; j < nb; ++j) mx = fmaxf(mx, SCR(j));
+                    ymax = mx * (float)(nb + sp.degree);   // params.max() * n_knots (msplines_jax.py:147-150)
+                }
+                // rejection sampling (bounded: a pathological density cannot hang the GPU)
+                float xs = 0.5f;
+                for (int it = 0; it < 100000; ++it) {
+                    const float xc = rng.uniform(), yc = rng.uniform() * ymax;
+                    const Lerp L = make_lerp(xc, sp.n_mesh);
+                    float v = spline_dot<NBP>(sp.tab, L, scr, row0, nb);
+                    if (wavefn) v = v * v;
+                    if (yc < v) { xs = xc; break; }
+                }
+                cur[col] = xs;
+            }
+        }
+        if (latent) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) latent[b * D + d] = cur[d];
+        }
+        serial_inverse<D, NBP>(md, cur, scr, exact);
+#pragma unroll
+        for (int d = 0; d < D; ++d) xg[b * D + d] = cur[d];
+    }
+}
+
 // deterministic fp64 block sums: stage 1 one partial pair per block, stage 2 one block
 constexpr int kSumBlock = 256;
 constexpr int kSumMaxBlocks = 1024;
@@ -494,6 +710,23 @@ int launch_scalar_layer(const ModelDev& md, const ModelDev* md_dev, int layer, c
                         int32_t* idx, void* stream) {
     hipStream_t s = (hipStream_t)stream;
 #define CALL(DD, NN) launch_layer_d<DD, NN>(md_dev, layer, u_in, B, y, logdet, idx, s)
+    WF_DISPATCH_D(md.D, md.nbp, CALL)
+#undef CALL
+    return finish_launch();
+}
+
+int launch_scalar_inverse(const ModelDev& md, const ModelDev* md_dev, const float* u, int64_t B, float* x, int exact, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+#define CALL(DD, NN) hipLaunchKernelGGL((k_inverse<DD, NN>), dim3(grid_for<NN>(B)), dim3(Cfg<NN>::kBlock), 0, s, md_dev, u, B, x, exact)
+    WF_DISPATCH_D(md.D, md.nbp, CALL)
+#undef CALL
+    return finish_launch();
+}
+
+int launch_scalar_sample(const ModelDev& md, const ModelDev* md_dev, unsigned long long seed, int64_t B, float* x, float* latent, int exact,
+                         void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+#define CALL(DD, NN) hipLaunchKernelGGL((k_sample<DD, NN>), dim3(grid_for<NN>(B)), dim3(Cfg<NN>::kBlock), 0, s, md_dev, seed, B, x, latent, exact)
     WF_DISPATCH_D(md.D, md.nbp, CALL)
 #undef CALL
     return finish_launch();

@@ -171,6 +171,7 @@ static int model_build(wf_model* m) {
     md.i_reg = d.i_reg;
     md.prior_kind = d.prior_kind;
     md.normal_offset = d.normal_offset;
+    md.reverse_tol = d.i_reverse_tol > 0.0f ? d.i_reverse_tol : 1.0f / (float)d.n_mesh;   // isplines_jax.py:89-90
     for (int i = 0; i < d.n_constrained_left; ++i) {
         if (d.constrained_left[i] < 0 || d.constrained_left[i] >= D) return WF_ERR_INVALID;
         md.constrained_mask |= 1u << d.constrained_left[i];
@@ -220,10 +221,10 @@ static int model_build(wf_model* m) {
         if (rc) return rc;
         rc = check_bc(d.p_right, nb);
         if (rc) return rc;
-        std::vector<double> b64((size_t)4 * nb * d.n_mesh), ob64((size_t)4 * nb * d.n_mesh), o2b((size_t)nb * nb);
+        std::vector<double> b64((size_t)4 * nb * d.n_mesh), ob64((size_t)4 * nb * d.n_mesh), o2b((size_t)nb * nb), b2o((size_t)nb * nb);
         rc = build_raw_table(WF_SPLINE_B, d.p_degree, d.p_knots, d.n_mesh, b64.data());
         if (rc < 0) return rc;
-        rc = build_ortho_b(d.p_degree, d.p_knots, d.n_mesh, b64.data(), ob64.data(), nullptr, o2b.data());
+        rc = build_ortho_b(d.p_degree, d.p_knots, d.n_mesh, b64.data(), ob64.data(), b2o.data(), o2b.data());
         if (rc < 0) return rc;
         std::vector<float> rows;
         pack_rows(ob64, nb, d.n_mesh, 1, m->nbp, rows);
@@ -235,6 +236,11 @@ static int model_build(wf_model* m) {
         for (int a = 0; a < nb; ++a)
             for (int j = 0; j < nb; ++j) o2b32[(size_t)a * m->nbp + j] = (float)o2b[(size_t)a * nb + j];
         rc = upload_table(m, o2b32, &md.ob_to_b);
+        if (rc) return rc;
+        std::vector<float> b2o32((size_t)nb * m->nbp, 0.0f);
+        for (int a = 0; a < nb; ++a)
+            for (int j = 0; j < nb; ++j) b2o32[(size_t)a * m->nbp + j] = (float)b2o[(size_t)a * nb + j];
+        rc = upload_table(m, b2o32, &md.b_to_ob);
         if (rc) return rc;
         m->p_nb = nb;
         keep_p64.swap(ob64);
@@ -729,6 +735,22 @@ int wf_layer_fwd(const wf_model* m, int layer, const float* u_in_dev, int64_t B,
     DeviceGuard g(m->device);
     if (B == 0) return WF_OK;
     return launch_scalar_layer(m->dev, m->d_dev, layer, u_in_dev, B, y_dev, logdet_dev, bin_idx_dev, stream);
+}
+
+int wf_inverse_fwd(const wf_model* m, const float* u_dev, int64_t B, float* x_dev, int32_t exact, void* stream) {
+    int rc = check_fwd(m, u_dev, B, x_dev);
+    if (rc) return rc;
+    DeviceGuard g(m->device);
+    if (B == 0) return WF_OK;
+    return launch_scalar_inverse(m->dev, m->d_dev, u_dev, B, x_dev, exact, stream);
+}
+
+int wf_sample(const wf_model* m, uint64_t seed, int64_t B, float* x_dev, float* latent_dev, int32_t exact, void* stream) {
+    int rc = check_fwd(m, x_dev, B, x_dev);
+    if (rc) return rc;
+    DeviceGuard g(m->device);
+    if (B == 0) return WF_OK;
+    return launch_scalar_sample(m->dev, m->d_dev, (unsigned long long)seed, B, x_dev, latent_dev, exact, stream);
 }
 
 int wf_rqs_fwd(const float* x_dev, const float* uw_dev, const float* uh_dev, const float* ud_dev, int64_t N, int32_t K, int32_t n_deriv,

@@ -33,6 +33,11 @@ def as_generator(rng):
     return np.random.default_rng(int(np.asarray(rng).astype(np.uint64).sum()) & 0x7FFFFFFF)
 
 
+def seed_from(rng):
+    """A 63-bit seed for the device sampler from whatever the caller uses as `rng`."""
+    return int(as_generator(rng).integers(0, 2 ** 63 - 1))
+
+
 # --------------------------------------------------------------------------- conditioner
 @dataclass
 class MaskedTransform:
@@ -105,6 +110,7 @@ def _desc(D, layers=(), box=None, prior=_lib.PRIOR_UNIFORM, p_degree=0, p_knots=
             d.i_degree, d.i_knots, d.i_reg = first.degree, first.knots, first.reg
             d.i_left, d.i_right = _lib.BC.from_dict(first.left), _lib.BC.from_dict(first.right)
             d.n_mesh = first.n_mesh
+            d.i_reverse_tol = float(first.tol) if first.tol is not None else 0.0
         else:
             d.layer_kind = _lib.LAYER_MADE
     if box is not None:
@@ -141,8 +147,7 @@ def parse_serial(spec):
 
 def _not_yet(name):
     def f(*a, **k):
-        raise NotImplementedError(f"{name}: the inverse / sampling direction is not built on the HIP path yet "
-                                  "(SURVEY.md §8f rank 3); there is deliberately no CPU fallback")
+        raise NotImplementedError(f"{name} is not built on the HIP path; there is deliberately no CPU fallback")
     return f
 
 
@@ -183,7 +188,11 @@ class IMADE(_InitFun):
             model.ensure_params(params)
             return model.layer(0, inputs)
 
-        return params, direct_fun, _not_yet("IMADE.inverse_fun")
+        def inverse_fun(params, inputs, exact=False, **kw):
+            model.ensure_params(params)
+            return model.inverse(inputs, exact=exact), 0   # the reference returns 0 as log-det here (made.py:100)
+
+        return params, direct_fun, inverse_fun
 
 
 class MADE(_InitFun):
@@ -206,7 +215,11 @@ class MADE(_InitFun):
             model.ensure_params(params)
             return model.layer(0, inputs)
 
-        return params, direct_fun, _not_yet("MADE.inverse_fun")
+        def inverse_fun(params, inputs, **kw):
+            model.ensure_params(params)
+            return model.inverse(inputs), 0
+
+        return params, direct_fun, inverse_fun
 
 
 class BoxTransformLayer(_InitFun):
@@ -225,7 +238,10 @@ class BoxTransformLayer(_InitFun):
         def direct_fun(params, inputs, **kw):
             return model.flow(inputs)
 
-        return (), direct_fun, _not_yet("BoxTransformLayer.reverse_fun")
+        def reverse_fun(params, inputs, **kw):
+            return model.inverse(inputs), 0
+
+        return (), direct_fun, reverse_fun
 
 
 class Reverse(_InitFun):
@@ -272,7 +288,11 @@ class Serial(_InitFun):
             def direct_fun(params, inputs, **kw):
                 model.ensure_params(params)
                 return model.flow(inputs)
-            return params, direct_fun, _not_yet("Serial.inverse_fun")
+
+            def inverse_fun(params, inputs, exact=False, **kw):
+                model.ensure_params(params)
+                return model.inverse(inputs, exact=exact), 0
+            return params, direct_fun, inverse_fun
         # general composition: one launch per layer (still the HIP path)
         subs = [f(rng, input_dim) for f in self.init_funs]
 
@@ -283,7 +303,12 @@ class Serial(_InitFun):
                 total = ld if total is None else total + ld
             return inputs, total
 
-        return params, direct_fun, _not_yet("Serial.inverse_fun")
+        def inverse_fun(params, inputs, **kw):
+            for (_, _, ifun), p in zip(reversed(subs), reversed(list(params))):
+                inputs, _ = ifun(p, inputs)
+            return inputs, 0
+
+        return params, direct_fun, inverse_fun
 
 
 # --------------------------------------------------------------------------- distributions
@@ -332,8 +357,12 @@ class Flow(_InitFun):
             model.ensure_params(params)
             return model.log_pdf(inputs, return_sample=return_sample)
 
-        log_pdf.model = model
-        return params, log_pdf, _not_yet("Flow.sample")
+        def sample(rng, params, num_samples=1, return_original_samples=False):
+            model.ensure_params(params)
+            return model.sample(seed_from(rng), num_samples, return_latent=return_original_samples)
+
+        log_pdf.model = sample.model = model
+        return params, log_pdf, sample
 
 
 class MFlow(_InitFun):
@@ -365,5 +394,9 @@ class MFlow(_InitFun):
             model.ensure_params(params)
             return model.log_pdf(inputs, return_sample=return_sample)
 
-        log_pdf.model = model
-        return (tparams, sparams), log_pdf, _not_yet("MFlow.sample")
+        def sample(rng, params, num_samples=1, return_original_samples=False, exact_inverse=False):
+            model.ensure_params(params)
+            return model.sample(seed_from(rng), num_samples, return_latent=return_original_samples, exact=exact_inverse)
+
+        log_pdf.model = sample.model = model
+        return (tparams, sparams), log_pdf, sample

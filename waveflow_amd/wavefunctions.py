@@ -2,7 +2,7 @@
 import numpy as np
 
 from . import _lib
-from .flows import _InitFun, _not_yet, as_generator
+from .flows import _InitFun, as_generator, seed_from
 
 
 class Waveflow(_InitFun):
@@ -44,5 +44,11 @@ class Waveflow(_InitFun):
             model.ensure_params(params)
             return model.psi(inputs)
 
-        log_pdf.model = psi.model = model
-        return (tparams, sparams), psi, log_pdf, _not_yet("Waveflow.sample")
+        def sample(rng, params, num_samples=1, return_original_samples=False, exact_inverse=False):
+            """wavefunctions.py:74-107.  exact_inverse=False keeps the reference's IMADE.inverse_fun (made.py:88): the
+            conditioner sees the values being inverted, so the samples follow a distorted density; True draws from |psi|^2."""
+            model.ensure_params(params)
+            return model.sample(seed_from(rng), num_samples, return_latent=return_original_samples, exact=exact_inverse)
+
+        log_pdf.model = psi.model = sample.model = model
+        return (tparams, sparams), psi, log_pdf, sample
