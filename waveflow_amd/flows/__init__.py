@@ -151,6 +151,10 @@ def _not_yet(name):
     return f
 
 
+def _flip(a):
+    return a.flip(-1) if hasattr(a, "flip") else np.ascontiguousarray(np.asarray(a)[..., ::-1])
+
+
 class _InitFun:
     """A callable init_fun carrying `.spec`."""
     spec = None
@@ -190,7 +194,8 @@ class IMADE(_InitFun):
 
         def inverse_fun(params, inputs, exact=False, **kw):
             model.ensure_params(params)
-            return model.inverse(inputs, exact=exact), 0   # the reference returns 0 as log-det here (made.py:100)
+            # the fused model inverts (layer, Reverse); a stand-alone layer has no Reverse, so undo it on the way in
+            return model.inverse(_flip(inputs), exact=exact), 0   # the reference returns 0 as log-det here (made.py:100)
 
         return params, direct_fun, inverse_fun
 
@@ -217,7 +222,7 @@ class MADE(_InitFun):
 
         def inverse_fun(params, inputs, **kw):
             model.ensure_params(params)
-            return model.inverse(inputs), 0
+            return model.inverse(_flip(inputs)), 0
 
         return params, direct_fun, inverse_fun
 
