@@ -166,6 +166,14 @@ int wf_inverse_fwd(const wf_model* m, const float* u_dev, int64_t B, float* x_de
  * results are reproducible for a given seed but do not follow JAX's threefry stream (parity unpinned). */
 int wf_sample(const wf_model* m, uint64_t seed, int64_t B, float* x_dev, float* latent_dev, int32_t exact, void* stream);
 
+/* H psi = -1/2 laplacian(psi) + V psi of the Waveflow wavefunction: physics.construct_hamiltonian_function (utils/physics.py:79-93)
+ * with physics.laplacian (:50-52, trace of jax.hessian -- the table lerp differentiates to the next cached derivative table,
+ * isplines_jax.py:60-66) and the one-dimensional soft-Coulomb physics.get_potential (:60-76) for `n_protons` <= 8 protons at
+ * `protons_host`.  hpsi_dev[B]; psi_dev[B] and laplacian_dev[B] may be NULL.  The local energy of vqmc.loss_fn_efficient
+ * (vqmc.py:193-200) is hpsi / (psi + 1e-8).  WF_PRIOR_WAVEFLOW models with IMADE layers, <= 32 bases, D <= 4. */
+int wf_hamiltonian_fwd(const wf_model* m, const float* x_dev, int64_t B, const float* protons_host, int32_t n_protons,
+                       float* hpsi_dev, float* psi_dev, float* laplacian_dev, void* stream);
+
 /* Rational-quadratic spline bijector, elementwise (flows/bijections/neural_splines.py:16-184; dead code in the reference,
  * parity unpinned).  x[N]; uw, uh [N][K] unnormalised widths / heights; ud [N][n_deriv] unnormalised derivatives with
  * n_deriv == K-1 (unconstrained_RQS: identity outside [left, right], boundary derivatives 1) or K+1 (RQS: explicit).

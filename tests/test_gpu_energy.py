@@ -1,0 +1,58 @@
+"""Local energy H psi = -1/2 laplacian(psi) + V psi on the HIP path vs oracle/energy_torch.py."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import sorted_walkers
+
+pytestmark = pytest.mark.gpu
+
+
+def he(he_flat):
+    from waveflow_amd import checkpoint, model_factory
+    init_fun = model_factory.get_waveflow_model(2, base_spline_degree=6, i_spline_degree=6, n_prior_internal_knots=23,
+                                                n_i_internal_knots=23, i_spline_reg=0.05, n_flow_layers=3, box_size=10)
+    params, psi, log_pdf, sample = init_fun(0, 2)
+    return checkpoint.unflatten_like(params, he_flat), psi, log_pdf, sample
+
+
+def test_hamiltonian_vs_autograd_oracle(golden, he_flat):
+    import torch
+    from oracle import energy_torch as et
+    from waveflow_amd.utils import physics
+    params, psi, log_pdf, sample = he(he_flat)
+    protons, n_el = physics.system_catalogue[1]["He"]
+    assert n_el == 2
+    h_fn = physics.construct_hamiltonian_function(psi, protons=protons, n_space_dimensions=1, eps=0.0)
+    x = np.concatenate([np.sort(golden["he_golden"]["sample_points"], -1), sorted_walkers(250, 2, 10.0, 5)]).astype(np.float32)
+    h = h_fn(params, x)
+    assert h.shape == (500, 1)
+    hp, ps, lap = h_fn.model.hamiltonian(x, protons.reshape(-1), return_psi=True, return_laplacian=True)
+    ho64, po64, lo64 = et.hamiltonian(et.he_model(torch.float64), he_flat, x.astype(np.float64), protons.reshape(-1))
+    ho32, po32, lo32 = et.hamiltonian(et.he_model(torch.float32), he_flat, x, protons.reshape(-1))
+    np.testing.assert_allclose(ps, po64, rtol=0, atol=3e-5)
+    # second derivatives amplify fp32 rounding: compare with the fp64 autograd oracle, using the fp32 autograd
+    # oracle's own deviation as the yardstick (same idea as tests/test_gpu_parity.py)
+    scale = np.abs(lo64).max()
+    e_g, e_o = np.abs(lap - lo64), np.abs(lo32 - lo64)
+    assert np.median(e_g) <= 3 * np.median(e_o) + 1e-6 * scale, (np.median(e_g), np.median(e_o))
+    assert e_g.max() <= 6 * e_o.max() + 1e-4 * scale, (e_g.max(), e_o.max(), scale)
+    np.testing.assert_allclose(hp, ho64, rtol=0, atol=6 * np.abs(ho32 - ho64).max() + 1e-4 * np.abs(ho64).max())
+    # local energy as vqmc.loss_fn_efficient forms it (vqmc.py:193-200)
+    el = hp / (ps + 1e-8)
+    assert np.isfinite(el).all()
+
+
+def test_hamiltonian_errors_and_shapes(he_flat):
+    from waveflow_amd import _lib, model_factory
+    params, psi, log_pdf, sample = he(he_flat)
+    m = psi.model
+    m.ensure_params(params)
+    assert m.hamiltonian(np.zeros((0, 2), np.float32), [0.0]).shape == (0,)
+    L = _lib.lib()
+    assert L.wf_hamiltonian_fwd(m._h, None, 4, None, 9, None, None, None, None) == -1
+    p2, lp2, _ = model_factory.get_model(n_flow_layers=1)(0, 2)
+    lp2.model.ensure_params(p2)
+    x = np.random.default_rng(0).uniform(0.1, 0.9, size=(8, 2)).astype(np.float32)
+    with pytest.raises(_lib.WfError):
+        lp2.model.hamiltonian(x, [0.0])

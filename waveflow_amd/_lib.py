@@ -54,7 +54,7 @@ class ModelDesc(ctypes.Structure):
 EXPORTS = ["wf_abi_version", "wf_strerror", "wf_last_hip_error", "wf_last_hip_error_string", "wf_device_count",
            "wf_tables_build", "wf_model_create", "wf_model_destroy", "wf_model_param_count", "wf_model_n_bases",
            "wf_model_set_params", "wf_model_set_kernel", "wf_logpdf_fwd", "wf_psi_fwd", "wf_flow_fwd", "wf_layer_fwd",
-           "wf_block_sums", "wf_block_sums_workspace_bytes", "wf_rqs_fwd", "wf_inverse_fwd", "wf_sample"]
+           "wf_block_sums", "wf_block_sums_workspace_bytes", "wf_rqs_fwd", "wf_inverse_fwd", "wf_sample", "wf_hamiltonian_fwd"]
 
 _lib = None
 
@@ -103,6 +103,8 @@ def lib():
     L.wf_inverse_fwd.argtypes = [vp, vp, i64, vp, i32, vp]
     L.wf_sample.restype = i32
     L.wf_sample.argtypes = [vp, ctypes.c_uint64, i64, vp, vp, i32, vp]
+    L.wf_hamiltonian_fwd.restype = i32
+    L.wf_hamiltonian_fwd.argtypes = [vp, vp, i64, vp, i32, vp, vp, vp, vp]
     L.wf_rqs_fwd.restype = i32
     L.wf_rqs_fwd.argtypes = [vp, vp, vp, vp, i64, i32, i32, i32, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                              vp, vp, vp, vp]

@@ -177,6 +177,23 @@ class DeviceModel:
                                         int(bool(exact)), self._stream()), "wf_sample")
         return (x, lat) if return_latent else x
 
+    def hamiltonian(self, x, protons, return_psi=False, return_laplacian=False):
+        """H psi = -1/2 laplacian(psi) + V psi (physics.construct_hamiltonian_function); protons: 1-D positions."""
+        t, back = self._to_dev(x)
+        B = t.shape[0]
+        pr = np.ascontiguousarray(np.asarray(protons, dtype=np.float32).reshape(-1))
+        h = self._new((B,))
+        ps = self._new((B,)) if return_psi else None
+        lap = self._new((B,)) if return_laplacian else None
+        _lib.check(_lib.lib().wf_hamiltonian_fwd(self._h, self._p(t), B, pr.ctypes.data if pr.size else None, pr.size, self._p(h),
+                                                 self._p(ps), self._p(lap), self._stream()), "wf_hamiltonian_fwd")
+        res = [back(h)]
+        if return_psi:
+            res.append(back(ps))
+        if return_laplacian:
+            res.append(back(lap))
+        return res[0] if len(res) == 1 else tuple(res)
+
     def block_sums(self, v):
         """fp64 [sum v, sum v^2, count] on the device (deterministic order)."""
         torch = _torch()

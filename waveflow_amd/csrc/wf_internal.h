@@ -97,6 +97,12 @@ int launch_scalar_layer(const ModelDev& md, const ModelDev* md_dev, int layer, c
 int launch_scalar_inverse(const ModelDev& md, const ModelDev* md_dev, const float* u, int64_t B, float* x, int exact, void* stream);
 int launch_scalar_sample(const ModelDev& md, const ModelDev* md_dev, unsigned long long seed, int64_t B, float* x, float* latent,
                          int exact, void* stream);
+struct Protons {
+    float pos[8];
+    int n;
+};
+int launch_energy(const ModelDev& md, const ModelDev* md_dev, const float* tabI4, const float* tabP3, const float* x, int64_t B,
+                  const Protons& pr, float* hpsi, float* psi, float* lap, void* stream);
 int launch_rqs(const float* x, const float* uw, const float* uh, const float* ud, int64_t N, int K, int n_deriv, int inverse,
                float left, float right, float bottom, float top, float* y, float* ld, int32_t* bin, void* stream);
 int launch_block_sums(const float* v, int64_t B, double* out, void* ws, int64_t ws_bytes, void* stream);

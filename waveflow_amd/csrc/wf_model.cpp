@@ -82,6 +82,8 @@ struct wf_model {
     std::vector<int> mfma_net_floats;
     float* d_tabI = nullptr;
     float* d_tabP = nullptr;
+    const float* d_tabI4 = nullptr;  // [4][n_mesh][32]: I-spline derivative orders 0..3 (local energy)
+    const float* d_tabP3 = nullptr;  // [3][n_mesh][32]: orthogonal-B derivative orders 0..2
 };
 
 namespace wf {
@@ -209,6 +211,12 @@ static int model_build(wf_model* m) {
         rc = upload_table(m, rows, &md.isp.tab);
         if (rc) return rc;
         md.isp.nb = nb; md.isp.nbp = m->nbp; md.isp.n_mesh = d.n_mesh; md.isp.degree = d.i_degree;
+        if (m->nbp == 32) {
+            std::vector<float> rows4;
+            pack_rows(t64, nb, d.n_mesh, 4, 32, rows4);
+            rc = upload_table(m, rows4, &m->d_tabI4);
+            if (rc) return rc;
+        }
         fill_bc(md.isp, d.i_left, d.i_right, t64, nb, d.n_mesh);
         m->i_nb = nb;
         keep_i64.swap(t64);
@@ -231,6 +239,12 @@ static int model_build(wf_model* m) {
         rc = upload_table(m, rows, &md.psp.tab);
         if (rc) return rc;
         md.psp.nb = nb; md.psp.nbp = m->nbp; md.psp.n_mesh = d.n_mesh; md.psp.degree = d.p_degree;
+        if (m->nbp == 32) {
+            std::vector<float> rows3;
+            pack_rows(ob64, nb, d.n_mesh, 3, 32, rows3);
+            rc = upload_table(m, rows3, &m->d_tabP3);
+            if (rc) return rc;
+        }
         fill_bc(md.psp, d.p_left, d.p_right, b64, nb, d.n_mesh);  // BCs use the plain-B table, bsplines_jax.py:176-189
         std::vector<float> o2b32((size_t)nb * m->nbp, 0.0f);
         for (int a = 0; a < nb; ++a)
@@ -751,6 +765,21 @@ int wf_sample(const wf_model* m, uint64_t seed, int64_t B, float* x_dev, float* 
     DeviceGuard g(m->device);
     if (B == 0) return WF_OK;
     return launch_scalar_sample(m->dev, m->d_dev, (unsigned long long)seed, B, x_dev, latent_dev, exact, stream);
+}
+
+int wf_hamiltonian_fwd(const wf_model* m, const float* x_dev, int64_t B, const float* protons_host, int32_t n_protons, float* hpsi_dev,
+                       float* psi_dev, float* laplacian_dev, void* stream) {
+    int rc = check_fwd(m, x_dev, B, hpsi_dev);
+    if (rc) return rc;
+    if (n_protons < 0 || n_protons > 8 || (n_protons > 0 && !protons_host)) return WF_ERR_INVALID;
+    if (m->desc.prior_kind != WF_PRIOR_WAVEFLOW) return WF_ERR_INVALID;
+    if (m->desc.layer_kind != WF_LAYER_IMADE || !m->d_tabI4 || !m->d_tabP3 || m->desc.n_dim > 4) return WF_ERR_UNSUPPORTED;
+    Protons pr{};
+    pr.n = n_protons;
+    for (int i = 0; i < n_protons; ++i) pr.pos[i] = protons_host[i];
+    DeviceGuard g(m->device);
+    if (B == 0) return WF_OK;
+    return launch_energy(m->dev, m->d_dev, m->d_tabI4, m->d_tabP3, x_dev, B, pr, hpsi_dev, psi_dev, laplacian_dev, stream);
 }
 
 int wf_rqs_fwd(const float* x_dev, const float* uw_dev, const float* uh_dev, const float* ud_dev, int64_t N, int32_t K, int32_t n_deriv,
