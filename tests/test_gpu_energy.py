@@ -56,3 +56,29 @@ def test_hamiltonian_errors_and_shapes(he_flat):
     x = np.random.default_rng(0).uniform(0.1, 0.9, size=(8, 2)).astype(np.float32)
     with pytest.raises(_lib.WfError):
         lp2.model.hamiltonian(x, [0.0])
+
+
+def test_checkpoint_artefacts_match_the_reference_files(tmp_path, golden, he_flat):
+    """helpers.create_checkpoint_wavefunc on the HIP path reproduces the files the reference wrote for the same checkpoint."""
+    import pickle
+    from waveflow_amd import checkpoint, flatten_params
+    from waveflow_amd.utils import helpers
+    params, psi, log_pdf, sample = he(he_flat)
+    system_dict = {"system_name": "He", "box_length": 10, "n_particle": 2, "n_space_dimension": 1, "window": 100, "n_plotting": 200}
+    helpers.create_checkpoint_wavefunc(3, str(tmp_path), psi, sample, params, 100000, [0.0, -1.5], [[-1.5]], system_dict)
+    g = golden["he_golden"]
+    z = np.load(tmp_path / "outputs/wavefunctions_2d/values_epoch100000.npy")
+    assert z.shape == g["psi_grid"].shape and z.dtype == g["psi_grid"].dtype
+    assert np.abs(z - g["psi_grid"]).max() < 2.5e-5
+    on = np.load(tmp_path / "outputs/density_1e/onproton_values_epoch100000.npy")
+    assert np.abs(on - g["onproton_values"]).max() < 1e-5
+    np.testing.assert_allclose(np.load(tmp_path / "outputs/density_1e/onproton_coord_epoch100000.npy"), g["onproton_coord"], atol=1e-6)
+    sp = np.load(tmp_path / "outputs/sample_points/values_epoch100000.npy")
+    assert sp.shape == g["sample_points"].shape and sp.dtype == g["sample_points"].dtype
+    assert np.load(tmp_path / "loss.npy").shape == (2,)
+    # the checkpoint round-trips through the reference-format loader
+    loaded, epoch = checkpoint.load_reference_checkpoint(str(tmp_path / "checkpoints"))
+    assert epoch == 100000 and np.array_equal(flatten_params(loaded), he_flat)
+    with open(tmp_path / "checkpoints", "rb") as f:
+        plain, _ = pickle.load(f)       # plain pickle.load works too: leaves are NumPy arrays
+    assert np.array_equal(flatten_params(plain), he_flat)
