@@ -68,6 +68,8 @@ struct ModelDev {
     NetMfma mnets[kMaxNets];
 };
 
+using float4_t = __attribute__((ext_vector_type(4))) float;
+
 // MFMA kernel's view of the model (wf_kernels_mfma.hip)
 struct MfmaDev {
     int D, n_layers, layer_kind, box_kind, prior_kind;
@@ -82,12 +84,15 @@ struct MfmaDev {
     const float* tabI;         // [n_mesh][nd 0..1][half][16] fp32: fk_row * I_row, accumulator row order
     const float* rsI;          // [n_mesh][nd 0..1]: sum over rows of tabI
     const float* tabP;         // [n_mesh][half][16] fp32, prior rows (orthogonal-B as is; M: fk_row * M_row), nd 0
+    const float4_t* comp;      // [n_nets][n_mesh] composite tables of output dimension 0 (k_prepare_dim0)
     float* dbg;                // diagnostics builds only (WF_DEBUG)
 };
 
 int launch_mfma(int D, const MfmaDev* mdev, int lds_bytes, int mode, const float* x, int64_t B, float* out, float* u,
                 int32_t* idx, void* stream);
 int mfma_extra_lds_floats(int n_nets);
+int launch_prepare_dim0(const ModelDev* md_dev, int n_nets, int n_mesh, const float* fk_nat_dev, float F_I, float F_P, void* comp_dev,
+                        void* stream);
 
 // ---- kernel launchers (wf_kernels_*.hip).  mode: 0 = log_pdf, 1 = psi, 2 = flow only (u, logdet)
 int launch_scalar(const ModelDev& md, const ModelDev* md_dev, int mode, const float* x, int64_t B, float* out, float* u,

@@ -25,8 +25,9 @@
 //   For the B-spline prior the two L2 normalisations and the division by the signed sum collapse to
 //   psi_d = sign(sum o) * (c . lerp) / |c|, c = (o * keep) @ ob_to_b (wavefunctions.py:40-46,
 //   bsplines_jax.py:127-137, 173-199).
-//   Output dimension 0 of every net depends on no input (output degree -1, model_factory.py:15-18): its
-//   weights are per-net constants, computed once per workgroup in the prologue.
+//   Output dimension 0 of every net depends on no input (output degree -1, model_factory.py:15-18): its spline
+//   weights are per-net constants and, the lerp being linear in the table, sum_j c_j lerp(T_j, x) = lerp(sum_j c_j T_j, x):
+//   a composite table per net (k_prepare_dim0, rebuilt at every parameter upload) turns that block into two lerps.
 // The table index arithmetic (floor/ceil of u * (n_mesh-1), isplines_jax.py:46-48) is kept verbatim.
 #include <hip/hip_runtime.h>
 
@@ -89,6 +90,19 @@ __device__ __forceinline__ Lerp make_lerp(float x, int n_mesh) {
     const float dx = x - (float)L.xl / (float)n_points;
     L.t = dx * (float)n_points;
     return L;
+}
+
+// Output dimension 0 of every net has an empty mask (model_factory.py:15-18): its spline weights do not depend on the
+// walker, and a lerp is linear in the table values, so  sum_j c_j lerp(T_j, x) == lerp(sum_j c_j T_j, x).  The composite
+// tables (value, derivative) of every net are built once per parameter upload by k_prepare_dim0; a dimension-0 block is
+// then two 16-byte loads and two lerps.  comp[net][mesh] = {Y, DY, 0, 0} (flow layers: spline value and derivative,
+// already divided by sum(q); B prior: psi_0 with its sign and norm; M prior: density; MADE: {log_weight, bias}).
+__device__ __forceinline__ f32x4 comp_lerp(const f32x4* __restrict__ comp, const Lerp& Lp) {
+    const f32x4 a = comp[Lp.il], b = comp[Lp.ir];
+    f32x4 r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r[q] = __builtin_fmaf(b[q] - a[q], Lp.t, a[q]);
+    return r;
 }
 
 // 32 activations of one block (accumulator layout) -> the two K=16 B fragments, split hi / lo
@@ -258,9 +272,6 @@ __device__ __forceinline__ void sigmoid_block(f32x16& o, const float* fk_lds, in
 #define STAMP(k)
 #endif
 
-// per-net prologue record for output dimension 0 (LDS): v0[2][16], then scalars
-constexpr int kDim0Floats = 48;
-
 template <int D, int kWaves>
 __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode, const float* __restrict__ xg, int64_t B,
                                                       float* __restrict__ out, float* __restrict__ u_out, int32_t* __restrict__ idx_out) {
@@ -283,55 +294,6 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
     const float* fkI = consts;        // [2][16] remove_bias * keep factors of the flow-layer I-spline
     const float* fkP = consts + 32;   // [2][16] prior: keep (B) or remove_bias * keep (M)
     const float* ob2b = consts + 64;  // [4][64][4] ob_to_b in f32-MFMA A order
-    float* dim0 = lds + mm.image_floats;   // [n_nets][kDim0Floats], written below
-    const int n_nets = mm.n_layers + ((mm.prior_kind == WF_PRIOR_WAVEFLOW || mm.prior_kind == WF_PRIOR_MFLOW) ? 1 : 0);
-
-    // ---- prologue 2: output dimension 0 of every net is input-independent -> once per workgroup
-    for (int n = wave; n < n_nets; n += kWaves) {
-        const float* net = lds + mm.net_off[n];
-        f32x16 o = load16(net + O::b2 + (0 * 2 + h) * 16);
-        float* rec = dim0 + n * kDim0Floats;
-        const bool is_prior = n == mm.n_layers;
-        if (!is_prior && mm.layer_kind == WF_LAYER_MADE) {
-            // rows 0 / 1 = log_weight / bias
-            if (lane == 0) { rec[32] = o[0]; rec[33] = o[1]; }
-        } else if (is_prior && mm.prior_kind == WF_PRIOR_WAVEFLOW) {
-            const f32x16 keep = load16(fkP + h * 16);
-            float s1 = 0.0f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { s1 += o[r]; o[r] = o[r] * keep[r]; }
-            s1 = xhalf_sum(s1);
-            f32x16 c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const f32x4 a4 = *reinterpret_cast<const f32x4*>(ob2b + (r4 * 64 + lane) * 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], o[4 * r4 + e], c, 0, 0, 0);
-            }
-            float n2 = 0.0f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) n2 = __builtin_fmaf(c[r], c[r], n2);
-            n2 = xhalf_sum(n2);
-            if (j == 0) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) rec[h * 16 + r] = c[r];
-            }
-            if (lane == 0) { rec[32] = __builtin_amdgcn_rsqf(n2); rec[33] = s1 < 0.0f ? -1.0f : 1.0f; }
-        } else {
-            float S1, Sf;
-            sigmoid_block(o, is_prior ? fkP : fkI, h, S1, Sf);
-            const float reg = is_prior ? 0.0f : mm.i_reg;
-            const float F = is_prior ? mm.F_P : mm.F_I;
-            const float rs = reg * S1;
-            if (j == 0) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) rec[h * 16 + r] = o[r];
-            }
-            if (lane == 0) { rec[32] = 1.0f / __builtin_fmaf(rs, F, Sf); rec[33] = rs; }
-        }
-    }
-    __syncthreads();
-
     const int64_t n_tiles = (B + 31) >> 5;
     const int idx_stride = (mm.n_layers + 1) * D * 2;
     const float L = mm.box_L, tol = 1e-7f;
@@ -385,7 +347,6 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
         // ---- flow layers
         for (int l = 0; l < mm.n_layers; ++l) {
             const float* net = lds + mm.net_off[l];
-            const float* rec = dim0 + l * kDim0Floats;
             Frag h2[2];
             STAMP(0);
             Lerp Lp[D];
@@ -399,12 +360,11 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
             hidden_layers<D>(net, cur, lane, h2);
             STAMP(1);
             if (mm.layer_kind == WF_LAYER_IMADE) {
-                // dimension 0: constant weights (prologue record)
+                // dimension 0: walker-independent weights -> composite table (k_prepare_dim0)
                 {
-                    const f32x16 v = load16(rec + h * 16);
-                    float ld;
-                    ispline_eval(mm, v, Lp[0], h, rec[32], rec[33], nxt[0], ld);
-                    logdet = logdet + ld;
+                    const f32x4 c0 = comp_lerp(mm.comp + (size_t)l * mm.n_mesh, Lp[0]);
+                    nxt[0] = c0[0];
+                    logdet = logdet + fast_log(c0[1] + 1e-7f);
                 }
                 STAMP(2);
 #pragma unroll
@@ -428,8 +388,9 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
                 for (int d = 0; d < D; ++d) {
                     float lw, bias;
                     if (d == 0) {
-                        lw = rec[32];
-                        bias = rec[33];
+                        const f32x4 c0 = mm.comp[(size_t)l * mm.n_mesh];   // {log_weight, bias}: constants
+                        lw = c0[0];
+                        bias = c0[1];
                     } else {
                         const f32x16 o = out_block<D>(net, h2, d, lane);
                         lw = __shfl(o[0], j);
@@ -450,7 +411,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
             if (mm.prior_kind == WF_PRIOR_WAVEFLOW || mm.prior_kind == WF_PRIOR_MFLOW) {
                 const bool wavefn = mm.prior_kind == WF_PRIOR_WAVEFLOW;
                 const float* net = lds + mm.net_off[mm.n_layers];
-                const float* rec = dim0 + mm.n_layers * kDim0Floats;
+                const f32x4* comp_p = mm.comp + (size_t)mm.n_layers * mm.n_mesh;
                 // the conditioner sees the unclipped u (wavefunctions.py:40), the spline the clipped one (:45)
                 float uc[D];
                 Lerp Lp[D];
@@ -471,12 +432,9 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
 #pragma unroll
                     for (int d = 0; d < D; ++d) {
                         f32x16 c;
-                        float rnorm, sgn, num;
+                        float rnorm = 1.0f, sgn = 1.0f, num;
                         if (d == 0) {
-                            c = load16(rec + h * 16);
-                            rnorm = rec[32];
-                            sgn = rec[33];
-                            num = lerp_dot(c, prior_rows(0), Lp[0].t);
+                            num = comp_lerp(comp_p, Lp[0])[0];   // psi_0 incl. sign and norm
                         } else {
                             f32x16 o = out_block<D>(net, h2, d, lane);
                             float s1 = 0.0f;
@@ -514,11 +472,9 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
                     // MFlow (distributions.py:139-163): M-spline table with the row factors folded in
 #pragma unroll
                     for (int d = 0; d < D; ++d) {
-                        float num, rS;
+                        float num, rS = 1.0f;
                         if (d == 0) {
-                            const f32x16 v = load16(rec + h * 16);
-                            rS = rec[32];
-                            num = lerp_dot(v, prior_rows(0), Lp[0].t);
+                            num = comp_lerp(comp_p, Lp[0])[0];
                         } else {
                             f32x16 v = out_block<D>(net, h2, d, lane);
                             float S1, Sf;
@@ -563,6 +519,59 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
 #endif
 }
 
+
+// ---- composite tables of output dimension 0 (see comp_lerp); one thread per (net, mesh point); plain weight image
+__global__ void k_prepare_dim0(const ModelDev* __restrict__ mdp, int nm, const float* __restrict__ fk_nat /* [2][32]: I, prior */,
+                               float F_I, float F_P, f32x4* __restrict__ comp) {
+    const ModelDev& md = *mdp;
+    const int n_nets = md.n_layers + ((md.prior_kind == WF_PRIOR_WAVEFLOW || md.prior_kind == WF_PRIOR_MFLOW) ? 1 : 0);
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (nm <= 0 || gid >= n_nets * nm) return;
+    const int n = gid / nm, m = gid % nm;
+    const NetPlain& net = md.nets[n];
+    const bool is_prior = n == md.n_layers;
+    f32x4 out = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (!is_prior && md.layer_kind == WF_LAYER_MADE) {
+        out[0] = net.b2[0];   // log_weight, dimension 0 (rows j = 0 / 1 of block d = 0)
+        out[1] = net.b2[1];
+    } else if (is_prior && md.prior_kind == WF_PRIOR_WAVEFLOW) {
+        const SplineDev& sp = md.psp;
+        const int nb = sp.nb, nbp = sp.nbp;
+        const float* keep = fk_nat + 32;
+        float s1 = 0.0f;
+        for (int j = 0; j < nb; ++j) s1 += net.b2[j];
+        float n2 = 0.0f, num = 0.0f;
+        for (int i = 0; i < nb; ++i) {
+            float c = 0.0f;
+            for (int a = 0; a < nb; ++a) c = __builtin_fmaf(net.b2[a] * keep[a], md.ob_to_b[a * nbp + i], c);
+            n2 = __builtin_fmaf(c, c, n2);
+            num = __builtin_fmaf(c, sp.tab[(size_t)m * nbp + i], num);
+        }
+        out[0] = (s1 < 0.0f ? -num : num) * __builtin_amdgcn_rsqf(n2);
+    } else {
+        const SplineDev& sp = is_prior ? md.psp : md.isp;
+        const int nb = sp.nb, nbp = sp.nbp;
+        const float* fk = fk_nat + (is_prior ? 32 : 0);
+        const float reg = is_prior ? 0.0f : md.i_reg, F = is_prior ? F_P : F_I;
+        float s1 = 0.0f, sf = 0.0f;
+        for (int j = 0; j < nb; ++j) {
+            const float v = 1.0f / (1.0f + expf(-net.b2[j]));
+            s1 += v;
+            sf = __builtin_fmaf(v, fk[j], sf);
+        }
+        const float rs = reg * s1, rS = 1.0f / __builtin_fmaf(rs, F, sf);
+        float y = 0.0f, dy = 0.0f;
+        for (int j = 0; j < nb; ++j) {
+            const float q = (1.0f / (1.0f + expf(-net.b2[j])) + rs) * fk[j];
+            y = __builtin_fmaf(q, sp.tab[(size_t)m * nbp + j], y);
+            if (!is_prior) dy = __builtin_fmaf(q, sp.tab[((size_t)sp.n_mesh + m) * nbp + j], dy);
+        }
+        out[0] = y * rS;
+        out[1] = dy * rS;
+    }
+    comp[gid] = out;
+}
+
 template <int D, int kWaves>
 int launch_dw(const MfmaDev* mdev, int lds_bytes, int mode, const float* x, int64_t B, float* out, float* u, int32_t* idx, hipStream_t s) {
     static int configured_bytes = -1;
@@ -589,21 +598,35 @@ int launch_dw(const MfmaDev* mdev, int lds_bytes, int mode, const float* x, int6
 int waves_per_group() {
     const char* e = getenv("WF_MFMA_WAVES");  // tuning knob (read at every launch): 8, 12 or 16 waves per workgroup
     const int v = e ? atoi(e) : 0;
-    return (v == 8 || v == 12 || v == 16) ? v : 8;
+    return (v == 8 || v == 12 || v == 16) ? v : 16;
 }
 
 template <int D>
 int launch_d(const MfmaDev* mdev, int lds_bytes, int mode, const float* x, int64_t B, float* out, float* u, int32_t* idx, hipStream_t s) {
     switch (waves_per_group()) {
+        case 8: return launch_dw<D, 8>(mdev, lds_bytes, mode, x, B, out, u, idx, s);
         case 12: return launch_dw<D, 12>(mdev, lds_bytes, mode, x, B, out, u, idx, s);
-        case 16: return launch_dw<D, 16>(mdev, lds_bytes, mode, x, B, out, u, idx, s);
-        default: return launch_dw<D, 8>(mdev, lds_bytes, mode, x, B, out, u, idx, s);
+        default: return launch_dw<D, 16>(mdev, lds_bytes, mode, x, B, out, u, idx, s);
     }
 }
 
 }  // namespace
 
-int mfma_extra_lds_floats(int n_nets) { return n_nets * kDim0Floats; }
+int mfma_extra_lds_floats(int) { return 0; }
+
+int launch_prepare_dim0(const ModelDev* md_dev, int n_nets, int n_mesh, const float* fk_nat_dev, float F_I, float F_P, void* comp_dev,
+                        void* stream) {
+    const int total = n_nets * n_mesh;
+    if (total <= 0) return WF_OK;
+    hipLaunchKernelGGL(k_prepare_dim0, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, md_dev, n_mesh, fk_nat_dev, F_I, F_P,
+                       reinterpret_cast<f32x4*>(comp_dev));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_hip_error((int)e);
+        return WF_ERR_HIP;
+    }
+    return WF_OK;
+}
 
 int launch_mfma(int D, const MfmaDev* mdev, int lds_bytes, int mode, const float* x, int64_t B, float* out, float* u, int32_t* idx,
                 void* stream) {

@@ -82,6 +82,8 @@ struct wf_model {
     std::vector<int> mfma_net_floats;
     float* d_tabI = nullptr;
     float* d_tabP = nullptr;
+    float* d_fk_nat = nullptr;       // [2][32] natural-order row factors (I layers, prior) for k_prepare_dim0
+    void* d_comp = nullptr;          // composite tables [n_nets][n_mesh] float4
     const float* d_tabI4 = nullptr;  // [4][n_mesh][32]: I-spline derivative orders 0..3 (local energy)
     const float* d_tabP3 = nullptr;  // [3][n_mesh][32]: orthogonal-B derivative orders 0..2
 };
@@ -378,7 +380,8 @@ static bool bc_only_zeroes(const wf_bc& left, const wf_bc& right, bool is_I) {
 
 // per-row factor: remove_bias scaling (isplines_jax.py:196-202 / msplines_jax.py:186-192) times the
 // 0/1 "kept by the boundary conditions" mask; 0 beyond the real bases.  Layout [half][16] in accumulator order.
-static void row_factors(int kind, bool with_remove_bias, int k, int nb, const wf_bc& left, const wf_bc& right, float* out32) {
+static void row_factors(int kind, bool with_remove_bias, int k, int nb, const wf_bc& left, const wf_bc& right, float* out32,
+                        float* natural32 = nullptr) {
     std::vector<float> f(32, 0.0f);
     for (int j = 0; j < nb; ++j) f[j] = 1.0f;
     if (with_remove_bias)
@@ -393,6 +396,8 @@ static void row_factors(int kind, bool with_remove_bias, int k, int nb, const wf
     if (right.n > 0) f[nb - 1] = 0.0f;
     for (int h = 0; h < 2; ++h)
         for (int r = 0; r < 16; ++r) out32[h * 16 + r] = f[acc_row(r, h)];
+    if (natural32)
+        for (int j = 0; j < 32; ++j) natural32[j] = f[j];
 }
 
 // [n_mesh][n_orders][half][16], each row scaled by fk[row] (may be null); rowsum (may be null): [n_mesh][n_orders]
@@ -525,9 +530,10 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
     md.const_off = mfma_net_floats(D) * n_nets;
 
     m->mfma_consts.assign(consts, 0.0f);
+    std::vector<float> fk_nat(64, 0.0f);
     if (imade) {
         float* fk = m->mfma_consts.data();
-        row_factors(WF_SPLINE_I, true, d.i_degree, m->i_nb, d.i_left, d.i_right, fk);
+        row_factors(WF_SPLINE_I, true, d.i_degree, m->i_nb, d.i_left, d.i_right, fk, fk_nat.data());
         double F = 0;
         for (int i = 0; i < 32; ++i) F += fk[i];
         md.F_I = (float)F;
@@ -541,7 +547,7 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
     if (spline_prior) {
         const bool mflow = d.prior_kind == WF_PRIOR_MFLOW;
         float* fk = m->mfma_consts.data() + 32;
-        row_factors(mflow ? WF_SPLINE_M : WF_SPLINE_B, mflow, d.p_degree, m->p_nb, d.p_left, d.p_right, fk);
+        row_factors(mflow ? WF_SPLINE_M : WF_SPLINE_B, mflow, d.p_degree, m->p_nb, d.p_left, d.p_right, fk, fk_nat.data() + 32);
         double F = 0;
         for (int i = 0; i < 32; ++i) F += fk[i];
         md.F_P = (float)F;
@@ -565,6 +571,16 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
     int rc = dev_alloc(m, &m->d_mfma, (size_t)total);
     if (rc) return rc;
     md.image = m->d_mfma;
+    rc = dev_alloc(m, &m->d_fk_nat, 64);
+    if (rc) return rc;
+    WF_HIP(hipMemcpy(m->d_fk_nat, fk_nat.data(), 64 * sizeof(float), hipMemcpyHostToDevice));
+    {
+        float* comp = nullptr;
+        rc = dev_alloc(m, &comp, (size_t)std::max(n_nets, 1) * d.n_mesh * 4);
+        if (rc) return rc;
+        m->d_comp = comp;
+        md.comp = reinterpret_cast<const float4_t*>(comp);
+    }
     rc = dev_alloc(m, &m->d_mdev, 1);
     if (rc) return rc;
     WF_HIP(hipMemcpy(m->d_mdev, &md, sizeof(MfmaDev), hipMemcpyHostToDevice));
@@ -695,6 +711,9 @@ int wf_model_set_params(wf_model* m, const float* flat_host, int64_t n, void* st
         for (size_t i = 0; i < m->nets.size(); ++i) build_mfma_image(m, (int)i, flat_host, mimg.data() + m->mdev.net_off[i]);
         std::copy(m->mfma_consts.begin(), m->mfma_consts.end(), mimg.begin() + m->mdev.const_off);
         WF_HIP(hipMemcpyAsync(m->d_mfma, mimg.data(), mimg.size() * sizeof(float), hipMemcpyHostToDevice, s));
+        // composite tables of output dimension 0 (needs the plain image uploaded above)
+        int rc = launch_prepare_dim0(m->d_dev, (int)m->nets.size(), m->desc.n_mesh, m->d_fk_nat, m->mdev.F_I, m->mdev.F_P, m->d_comp, stream);
+        if (rc) return rc;
     }
     WF_HIP(hipStreamSynchronize(s));
     m->params_set = true;
