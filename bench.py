@@ -25,10 +25,14 @@ BYTES_PER_EVAL = 12            # 2 x fp32 in + 1 x fp32 out
 PEAK_F32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak
 PEAK_HBM_GBS = 8000.0
 # HBM bytes per log_pdf launch of 2^20 walkers from the PMC passes of the same command (separate rocprofv3 --pmc runs,
-# profiles/r01b_pmc_summary_mfma_f16split.txt): FETCH_SIZE 7719 KB + WRITE_SIZE 4096 KB.  The walker read is 8 B/lane
-# (not the 16 B/lane stream the guide's x2 FETCH_SIZE correction was calibrated on) and matches the 8.39 MB of
-# coordinates as reported, so no correction is applied.  Algorithmic bytes: 12 B x 2^20 = 12.6 MB.
-PMC_TRAFFIC_BYTES_2POW20 = (7719 + 4096) * 1024
+# profiles/r01c_pmc_summary.txt): FETCH_SIZE 10233 KB + WRITE_SIZE 13312 KB.  The walker read is 8 B/lane (not the
+# 16 B/lane stream the guide's x2 FETCH_SIZE correction was calibrated on; an earlier build without table gathers from
+# HBM reported exactly the 8.39 MB of coordinates), so no correction is applied.  Algorithmic bytes: 12 B x 2^20 =
+# 12.6 MB; the excess is register-spill scratch (13 VGPRs at 16 waves per workgroup) and first-touch table rows.
+PMC_TRAFFIC_BYTES_2POW20 = (10233 + 13312) * 1024
+# executed matrix-core work per eval (He): per 32-walker tile 156 v_mfma_f32_32x32x16_f16 + 12 v_mfma_f32_32x32x2_f32
+MFMA_FLOP_PER_EVAL = (156 * 32768 + 12 * 4096) / 32
+PEAK_F16_MATRIX_TFLOPS = 2500.0
 
 
 def he_model(kernel):
@@ -180,7 +184,12 @@ def main():
             "roofline": {"bound": "mfma", "achieved": k_evals_s * FLOP_PER_EVAL / 1e12, "peak": PEAK_F32_MATRIX_TFLOPS,
                          "unit": "TFLOP/s", "frac": k_evals_s * FLOP_PER_EVAL / 1e12 / PEAK_F32_MATRIX_TFLOPS,
                          "traffic": PMC_TRAFFIC_BYTES_2POW20 if B == (1 << 20) else None,
-                         "kernel": "log_pdf", "kernel_ms": kern_ms, "flop_per_eval": FLOP_PER_EVAL},
+                         "kernel": "k_mfma<2,16>", "kernel_ms": kern_ms, "flop_per_eval": FLOP_PER_EVAL,
+                         "note": "achieved = algorithmic fp32 conditioner FLOP (SURVEY 8d) / kernel time; peak = dense f32 MFMA. The K=64 "
+                                 "layers execute as 3 x f16 MFMA products of 2-way split operands (fp32 accumulate, fp32-level error, "
+                                 "see DESIGN.md 4.1), so the fraction can exceed 1; executed matrix work is in `mfma_f16`."},
+            "mfma_f16": {"achieved": k_evals_s * MFMA_FLOP_PER_EVAL / 1e12, "peak": PEAK_F16_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                         "frac": k_evals_s * MFMA_FLOP_PER_EVAL / 1e12 / PEAK_F16_MATRIX_TFLOPS, "flop_per_eval": MFMA_FLOP_PER_EVAL},
             "hbm": {"achieved": k_evals_s * BYTES_PER_EVAL / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": k_evals_s * BYTES_PER_EVAL / 1e9 / PEAK_HBM_GBS, "bytes_per_eval": BYTES_PER_EVAL},
         }

@@ -117,7 +117,7 @@ __device__ __forceinline__ void split_block(const f32x16& x, Frag& f) {
             const float v = x[8 * s + j];
             const _Float16 h = (_Float16)v;
             f.hi[s][j] = h;
-            f.lo[s][j] = (_Float16)(v - (float)h);   // fp16 subnormals keep 2^-25 absolute precision (not flushed)
+            f.lo[s][j] = (_Float16)(v - (float)h);   // exact difference; fp16 subnormals keep 2^-25 absolute precision
         }
 }
 
