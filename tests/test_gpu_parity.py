@@ -186,16 +186,16 @@ def test_waveflow_other_shapes_vs_oracle(kernel, D, box, layers, k, kn):
     as_accurate_as_fp32_reference(ps, pso, pst, atol=1e-6 * np.abs(pst).max())
 
 
-def test_he_33_knot_variant_32_bins(golden):
-    """BASELINE configs[2] "32-bin": 33 internal knots = 32 knot intervals, k = 6 => 39 I-bases / 38 B-bases (> 32: the
-    padded-to-64 scalar kernel; the MFMA kernel reports WF_ERR_UNSUPPORTED for it).  Seeded init, oracle parity only."""
-    from waveflow_amd import model_factory, flatten_params, _lib
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_he_33_knot_variant_32_bins(golden, kernel):
+    """BASELINE configs[2] "32-bin": 33 internal knots = 32 knot intervals, k = 6 => 39 I-bases / 38 B-bases (> 32: two
+    32-row blocks per dimension in the MFMA kernel, 64 padded bases in the scalar kernel).  Seeded init, oracle parity only."""
+    from waveflow_amd import model_factory, flatten_params
     init_fun = model_factory.get_waveflow_model(2, base_spline_degree=6, i_spline_degree=6, n_prior_internal_knots=33,
                                                 n_i_internal_knots=33, i_spline_reg=0.05, n_flow_layers=3, box_size=10.0)
     params, psi, log_pdf, _ = init_fun(7, 2)
     assert (log_pdf.model.i_nb, log_pdf.model.p_nb) == (39, 38)
-    with pytest.raises(_lib.WfError):
-        log_pdf.model.set_kernel("mfma")
+    log_pdf.model.set_kernel(kernel)
     flat = flatten_params(params)
     om = oracle.Model(D=2, n_layers=3, box="mean", box_L=10.0, i_k=6, i_knots=33, i_reg=0.05, i_left={0: 0}, i_right={0: 1},
                       prior="waveflow", p_k=6, p_knots=33, p_left={0: 0}, p_right={0: 0}, constr_left=(0,))

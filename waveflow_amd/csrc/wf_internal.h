@@ -76,20 +76,23 @@ struct MfmaDev {
     float box_L, i_reg, normal_offset;
     unsigned constrained_mask;
     int i_nb, p_nb, n_mesh;
+    int nbk;                   // 32-row blocks per dimension (1: <= 32 bases, 2: <= 64)
     float F_I, F_P;            // sum of the row factors fk (flow-layer spline / prior spline)
-    const float* image;        // LDS image: every net, then the constants block
-    int image_floats;
-    int net_off[kMaxNets];     // float offset of net n inside the image
-    int const_off;             // fkI[2][16], fkP[2][16], ob_to_b image [4][64][4]
-    const float* tabI;         // [n_mesh][nd 0..1][half][16] fp32: fk_row * I_row, accumulator row order
+    const float* image;        // global image: n_nets net images (net_floats each), then the constants block
+    int n_nets, net_floats;
+    int const_img_off;         // float offset of the constants block inside the image
+    int const_floats;          // fkI[nbk][2][16], fkP[nbk][2][16], ob_to_b image [nbk][nbk][4][64][4]
+    int staged;                // 0: every net resident in LDS; 1: one LDS slot, nets re-staged per chunk of tiles
+    const float* tabI;         // [n_mesh][nd 0..1][nbk][half][16] fp32: fk_row * I_row, accumulator row order
     const float* rsI;          // [n_mesh][nd 0..1]: sum over rows of tabI
-    const float* tabP;         // [n_mesh][half][16] fp32, prior rows (orthogonal-B as is; M: fk_row * M_row), nd 0
+    const float* tabP;         // [n_mesh][nbk][half][16] fp32, prior rows (orthogonal-B as is; M: fk_row * M_row), nd 0
     const float4_t* comp;      // [n_nets][n_mesh] composite tables of output dimension 0 (k_prepare_dim0)
-    float* dbg;                // diagnostics builds only (WF_DEBUG)
+    float* dbg;                // diagnostics builds only (WF_DEBUG / WF_STAMP)
 };
 
-int launch_mfma(int D, const MfmaDev* mdev, int lds_bytes, int mode, const float* x, int64_t B, float* out, float* u,
+int launch_mfma(int D, int nbk, const MfmaDev* mdev, int lds_bytes, int mode, const float* x, int64_t B, float* out, float* u,
                 int32_t* idx, void* stream);
+bool mfma_shape_built(int D, int nbk);
 int mfma_extra_lds_floats(int n_nets);
 int launch_prepare_dim0(const ModelDev* md_dev, int n_nets, int n_mesh, const float* fk_nat_dev, float F_I, float F_P, void* comp_dev,
                         void* stream);

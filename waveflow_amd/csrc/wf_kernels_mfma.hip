@@ -143,8 +143,8 @@ __device__ __forceinline__ f32x16 dense64_block(const _Float16* Wh, const _Float
     return acc;
 }
 
-// float offsets inside a net image (wf_model.cpp: build_mfma_image)
-template <int D>
+// float offsets inside a net image (wf_model.cpp: build_mfma_image); NBK = 32-row blocks per dimension (1 or 2)
+template <int D, int NBK>
 struct NetOff {
     static constexpr int S0 = (D + 1) / 2;
     static constexpr int W0 = 0;
@@ -153,15 +153,15 @@ struct NetOff {
     static constexpr int W1l = W1h + 2048;
     static constexpr int b1 = W1l + 2048;
     static constexpr int W2h = b1 + 64;
-    static constexpr int W2l = W2h + (D - 1) * 1024;
-    static constexpr int b2 = W2l + (D - 1) * 1024;
-    static constexpr int total = b2 + 32 * D;
+    static constexpr int W2l = W2h + (D - 1) * NBK * 1024;
+    static constexpr int b2 = W2l + (D - 1) * NBK * 1024;
+    static constexpr int total = b2 + 32 * D * NBK;
 };
 
 // Hidden layers of one conditioner net for the wave's 32 walkers; result: second hidden layer as B fragments.
-template <int D>
+template <int D, int NBK>
 __device__ __forceinline__ void hidden_layers(const float* net, const float (&in)[D], int lane, Frag (&h2)[2]) {
-    using O = NetOff<D>;
+    using O = NetOff<D, NBK>;
     const int h = lane >> 5;
     Frag h1[2];
 #pragma unroll
@@ -189,14 +189,15 @@ __device__ __forceinline__ void hidden_layers(const float* net, const float (&in
     }
 }
 
-// Output block of dimension d >= 1: raw (scaled) outputs o[basis row][walker] in accumulator layout.
-template <int D>
-__device__ __forceinline__ f32x16 out_block(const float* net, const Frag (&h2)[2], int d, int lane) {
-    using O = NetOff<D>;
+// Output block (dimension d >= 1, row block kb): raw (scaled) outputs o[basis row][walker] in accumulator layout.
+template <int D, int NBK>
+__device__ __forceinline__ f32x16 out_block(const float* net, const Frag (&h2)[2], int d, int kb, int lane) {
+    using O = NetOff<D, NBK>;
     const int h = lane >> 5;
     const _Float16* W2h = reinterpret_cast<const _Float16*>(net + O::W2h);
     const _Float16* W2l = reinterpret_cast<const _Float16*>(net + O::W2l);
-    return dense64_block(W2h + (d - 1) * 2048, W2l + (d - 1) * 2048, h2, load16(net + O::b2 + (d * 2 + h) * 16), lane);
+    const int blk = (d - 1) * NBK + kb;
+    return dense64_block(W2h + blk * 2048, W2l + blk * 2048, h2, load16(net + O::b2 + ((d * NBK + kb) * 2 + h) * 16), lane);
 }
 
 // The 16 table values of this lane half at x_l (a) and x_r (b) for one derivative order.
@@ -212,8 +213,8 @@ __device__ __forceinline__ Rows load_rows(const float* __restrict__ tl, const fl
     return r;
 }
 
-// sum_r v_r * lerp(T'_r) over the walker's 32 rows (both lane halves summed)
-__device__ __forceinline__ float lerp_dot(const f32x16& v, const Rows& R, float t) {
+// sum_r v_r * lerp(T'_r): this lane's 16 rows of one block, NOT yet summed over the lane halves
+__device__ __forceinline__ float lerp_dot_part(const f32x16& v, const Rows& R, float t) {
     float sa0 = 0.0f, sa1 = 0.0f, sb0 = 0.0f, sb1 = 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
@@ -223,36 +224,50 @@ __device__ __forceinline__ float lerp_dot(const f32x16& v, const Rows& R, float 
         sb1 = __builtin_fmaf(v[r + 1], R.b[r + 1], sb1);
     }
     const float A = sa0 + sa1, Bv = sb0 + sb1;
-    return xhalf_sum(__builtin_fmaf(Bv - A, t, A));
+    return __builtin_fmaf(Bv - A, t, A);
+}
+
+// sum over the walker's 32 * NBK rows; base_l / base_r: row (mesh point, order) of this lane half, blocks 32 floats apart
+template <int NBK>
+__device__ __forceinline__ float lerp_dot(const f32x16 (&v)[NBK], const float* __restrict__ base_l, const float* __restrict__ base_r, float t) {
+    float part = 0.0f;
+#pragma unroll
+    for (int kb = 0; kb < NBK; ++kb) part += lerp_dot_part(v[kb], load_rows(base_l + kb * 32, base_r + kb * 32), t);
+    return xhalf_sum(part);
 }
 
 // y and log(dy + 1e-7) of one I-spline block from its weights v (unnormalised), rS = 1/sum(q), rs = reg * S1.
-// Table rows [mesh][nd][h][16] (fk pre-multiplied) and their row sums [mesh][nd] are fetched here, one derivative
-// order at a time (32 live registers instead of 64).
-__device__ __forceinline__ void ispline_eval(const MfmaDev& mm, const f32x16& v, const Lerp& Lp, int h, float rS, float rs, float& y,
+// Table rows [mesh][nd][kb][h][16] (fk pre-multiplied) and their row sums [mesh][nd] are fetched here, one derivative
+// order at a time.
+template <int NBK>
+__device__ __forceinline__ void ispline_eval(const MfmaDev& mm, const f32x16 (&v)[NBK], const Lerp& Lp, int h, float rS, float rs, float& y,
                                              float& logdy) {
-    const float* tl = mm.tabI + ((size_t)Lp.il * 4 + h) * 16;
-    const float* tr = mm.tabI + ((size_t)Lp.ir * 4 + h) * 16;
+    const float* tl = mm.tabI + (size_t)Lp.il * (64 * NBK) + h * 16;
+    const float* tr = mm.tabI + (size_t)Lp.ir * (64 * NBK) + h * 16;
     const f32x2 rl = *reinterpret_cast<const f32x2*>(mm.rsI + (size_t)Lp.il * 2);
     const f32x2 rr = *reinterpret_cast<const f32x2*>(mm.rsI + (size_t)Lp.ir * 2);
-    float ynum = lerp_dot(v, load_rows(tl, tr), Lp.t);
-    float dnum = lerp_dot(v, load_rows(tl + 32, tr + 32), Lp.t);
+    float ynum = lerp_dot<NBK>(v, tl, tr, Lp.t);
+    float dnum = lerp_dot<NBK>(v, tl + 32 * NBK, tr + 32 * NBK, Lp.t);
     ynum = __builtin_fmaf(rs, __builtin_fmaf(rr[0] - rl[0], Lp.t, rl[0]), ynum);
     dnum = __builtin_fmaf(rs, __builtin_fmaf(rr[1] - rl[1], Lp.t, rl[1]), dnum);
     y = ynum * rS;
     logdy = fast_log(__builtin_fmaf(dnum, rS, 1e-7f));
 }
 
-// sigmoid weights of one block and their two sums: S1 = sum v, Sf = sum v*fk (over the walker's 32 rows)
-__device__ __forceinline__ void sigmoid_block(f32x16& o, const float* fk_lds, int h, float& S1, float& Sf) {
-    const f32x16 fk = load16(fk_lds + h * 16);
+// sigmoid weights of one dimension (NBK blocks) and their two sums: S1 = sum v, Sf = sum v*fk
+template <int NBK>
+__device__ __forceinline__ void sigmoid_block(f32x16 (&o)[NBK], const float* fk_lds /* [NBK][2][16] */, int h, float& S1, float& Sf) {
     float s1 = 0.0f, sf = 0.0f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float v = act_sigmoid(o[r]);
-        o[r] = v;
-        s1 += v;
-        sf = __builtin_fmaf(v, fk[r], sf);
+    for (int kb = 0; kb < NBK; ++kb) {
+        const f32x16 fk = load16(fk_lds + (kb * 2 + h) * 16);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = act_sigmoid(o[kb][r]);
+            o[kb][r] = v;
+            s1 += v;
+            sf = __builtin_fmaf(v, fk[r], sf);
+        }
     }
     S1 = xhalf_sum(s1);
     Sf = xhalf_sum(sf);
@@ -272,29 +287,37 @@ __device__ __forceinline__ void sigmoid_block(f32x16& o, const float* fk_lds, in
 #define STAMP(k)
 #endif
 
-template <int D, int kWaves>
+// cooperative copy of n_floats (multiple of 4) global -> LDS, 16 B per lane
+template <int kThreads>
+__device__ __forceinline__ void stage_floats(const float* __restrict__ src, float* dst, int n_floats) {
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
+    f32x4* d4 = reinterpret_cast<f32x4*>(dst);
+    const int n4 = n_floats >> 2;
+    for (int i = threadIdx.x; i < n4; i += kThreads) d4[i] = s4[i];
+}
+
+template <int D, int NBK, int kWaves>
 __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode, const float* __restrict__ xg, int64_t B,
                                                       float* __restrict__ out, float* __restrict__ u_out, int32_t* __restrict__ idx_out) {
     // mm is passed BY VALUE: it lives in the kernarg segment, so its fields are scalar loads and the table pointers
     // are known to be global (with a pointer-to-struct argument hipcc emitted flat_load for every table access).
-    using O = NetOff<D>;
+    // LDS: [constants][net slot(s)].  Resident mode: every net has its own slot, staged once.  Staged mode (the nets do
+    // not fit together, e.g. D >= 4 with 3 layers): ONE slot; every workgroup walks its chunk of kWaves tiles through the
+    // nets, re-staging the slot between two barriers per net (the per-tile state is D + 1 registers).
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    // ---- prologue 1: stage every net's weight image + constants into LDS (one pass, 16 B per lane)
-    {
-        const f32x4* src = reinterpret_cast<const f32x4*>(mm.image);
-        f32x4* dst = reinterpret_cast<f32x4*>(lds);
-        const int n4 = mm.image_floats >> 2;
-        for (int i = threadIdx.x; i < n4; i += kWaves * 64) dst[i] = src[i];
-    }
+    constexpr int kThreads = kWaves * 64;
+    stage_floats<kThreads>(mm.image + mm.const_img_off, lds, mm.const_floats);
+    if (!mm.staged) stage_floats<kThreads>(mm.image, lds + mm.const_floats, mm.net_floats * mm.n_nets);
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
-    const float* consts = lds + mm.const_off;
-    const float* fkI = consts;        // [2][16] remove_bias * keep factors of the flow-layer I-spline
-    const float* fkP = consts + 32;   // [2][16] prior: keep (B) or remove_bias * keep (M)
-    const float* ob2b = consts + 64;  // [4][64][4] ob_to_b in f32-MFMA A order
+    const float* fkI = lds;                        // [NBK][2][16] remove_bias * keep factors of the flow-layer I-spline
+    const float* fkP = lds + 32 * NBK;             // [NBK][2][16] prior: keep (B) or remove_bias * keep (M)
+    const float* ob2b = lds + 64 * NBK;            // [NBK out][NBK in][4][64][4] ob_to_b in f32-MFMA A order
+    float* slots = lds + mm.const_floats;
     const int64_t n_tiles = (B + 31) >> 5;
+    const int64_t n_chunks = (n_tiles + kWaves - 1) / kWaves;
     const int idx_stride = (mm.n_layers + 1) * D * 2;
     const float L = mm.box_L, tol = 1e-7f;
 #ifdef WF_STAMP
@@ -302,7 +325,8 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
 #endif
 
-    for (int64_t tile = (int64_t)blockIdx.x * kWaves + wave; tile < n_tiles; tile += (int64_t)gridDim.x * kWaves) {
+    for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        const int64_t tile = chunk * kWaves + wave;    // may be >= n_tiles in the last chunk: computed, never stored
         const int64_t w = tile * 32 + j;
         const bool valid = w < B;
         const int64_t wl = valid ? w : B - 1;
@@ -346,38 +370,41 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
 
         // ---- flow layers
         for (int l = 0; l < mm.n_layers; ++l) {
-            const float* net = lds + mm.net_off[l];
+            const float* net = slots + (mm.staged ? 0 : l * mm.net_floats);
+            if (mm.staged) {
+                __syncthreads();   // every wave is done with the previous occupant of the slot
+                stage_floats<kThreads>(mm.image + (size_t)l * mm.net_floats, slots, mm.net_floats);
+                __syncthreads();
+            }
             Frag h2[2];
             STAMP(0);
-            Lerp Lp[D];
-            if (mm.layer_kind == WF_LAYER_IMADE) {
-#pragma unroll
-                for (int d = 0; d < D; ++d) {
-                    Lp[d] = make_lerp(cur[d], mm.n_mesh);
-                    if (idx) { idx[(l * D + d) * 2] = Lp[d].xl; idx[(l * D + d) * 2 + 1] = Lp[d].xr; }
-                }
-            }
-            hidden_layers<D>(net, cur, lane, h2);
+            hidden_layers<D, NBK>(net, cur, lane, h2);
             STAMP(1);
             if (mm.layer_kind == WF_LAYER_IMADE) {
                 // dimension 0: walker-independent weights -> composite table (k_prepare_dim0)
                 {
-                    const f32x4 c0 = comp_lerp(mm.comp + (size_t)l * mm.n_mesh, Lp[0]);
+                    const Lerp Lp = make_lerp(cur[0], mm.n_mesh);
+                    if (idx) { idx[(l * D) * 2] = Lp.xl; idx[(l * D) * 2 + 1] = Lp.xr; }
+                    const f32x4 c0 = comp_lerp(mm.comp + (size_t)l * mm.n_mesh, Lp);
                     nxt[0] = c0[0];
                     logdet = logdet + fast_log(c0[1] + 1e-7f);
                 }
                 STAMP(2);
 #pragma unroll
                 for (int d = 1; d < D; ++d) {
-                    f32x16 v = out_block<D>(net, h2, d, lane);
+                    f32x16 v[NBK];
+#pragma unroll
+                    for (int kb = 0; kb < NBK; ++kb) v[kb] = out_block<D, NBK>(net, h2, d, kb, lane);
                     STAMP(3);
                     float S1, Sf;
-                    sigmoid_block(v, fkI, h, S1, Sf);
+                    sigmoid_block<NBK>(v, fkI, h, S1, Sf);
                     STAMP(4);
                     const float rs = mm.i_reg * S1;
                     const float rS = __builtin_amdgcn_rcpf(__builtin_fmaf(rs, mm.F_I, Sf));
+                    const Lerp Lp = make_lerp(cur[d], mm.n_mesh);
+                    if (idx) { idx[(l * D + d) * 2] = Lp.xl; idx[(l * D + d) * 2 + 1] = Lp.xr; }
                     float ld;
-                    ispline_eval(mm, v, Lp[d], h, rS, rs, nxt[d], ld);
+                    ispline_eval<NBK>(mm, v, Lp, h, rS, rs, nxt[d], ld);
                     logdet = logdet + ld;
                     STAMP(5);
                 }
@@ -392,7 +419,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
                         lw = c0[0];
                         bias = c0[1];
                     } else {
-                        const f32x16 o = out_block<D>(net, h2, d, lane);
+                        const f32x16 o = out_block<D, NBK>(net, h2, d, 0, lane);
                         lw = __shfl(o[0], j);
                         bias = __shfl(o[1], j);
                     }
@@ -410,84 +437,84 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
         if (mode != 2) {
             if (mm.prior_kind == WF_PRIOR_WAVEFLOW || mm.prior_kind == WF_PRIOR_MFLOW) {
                 const bool wavefn = mm.prior_kind == WF_PRIOR_WAVEFLOW;
-                const float* net = lds + mm.net_off[mm.n_layers];
+                const float* net = slots + (mm.staged ? 0 : mm.n_layers * mm.net_floats);
+                if (mm.staged) {
+                    __syncthreads();
+                    stage_floats<kThreads>(mm.image + (size_t)mm.n_layers * mm.net_floats, slots, mm.net_floats);
+                    __syncthreads();
+                }
                 const f32x4* comp_p = mm.comp + (size_t)mm.n_layers * mm.n_mesh;
-                // the conditioner sees the unclipped u (wavefunctions.py:40), the spline the clipped one (:45)
-                float uc[D];
-                Lerp Lp[D];
+                Frag h2[2];
+                hidden_layers<D, NBK>(net, cur, lane, h2);   // the conditioner sees the unclipped u (wavefunctions.py:40)
+                float lp = 0.0f, prod = 1.0f;
 #pragma unroll
                 for (int d = 0; d < D; ++d) {
-                    uc[d] = fminf(fmaxf(cur[d], 0.0f), 1.0f);
-                    Lp[d] = make_lerp(uc[d], mm.n_mesh);
-                    if (idx) { idx[(mm.n_layers * D + d) * 2] = Lp[d].xl; idx[(mm.n_layers * D + d) * 2 + 1] = Lp[d].xr; }
-                }
-                auto prior_rows = [&](int d) {   // [mesh][h][16], nd 0
-                    return load_rows(mm.tabP + ((size_t)Lp[d].il * 2 + h) * 16, mm.tabP + ((size_t)Lp[d].ir * 2 + h) * 16);
-                };
-                Frag h2[2];
-                hidden_layers<D>(net, cur, lane, h2);
-                float lp = 0.0f, prod = 1.0f;
-                if (wavefn) {
-                    const f32x16 keep = load16(fkP + h * 16);
+                    const float uc = fminf(fmaxf(cur[d], 0.0f), 1.0f);   // the spline sees the clipped one (:45)
+                    const Lerp Lp = make_lerp(uc, mm.n_mesh);
+                    if (idx) { idx[(mm.n_layers * D + d) * 2] = Lp.xl; idx[(mm.n_layers * D + d) * 2 + 1] = Lp.xr; }
+                    const float* tl = mm.tabP + (size_t)Lp.il * (32 * NBK) + h * 16;   // [mesh][kb][h][16], nd 0
+                    const float* tr = mm.tabP + (size_t)Lp.ir * (32 * NBK) + h * 16;
+                    float val;   // psi_d (B prior) or the density factor (M prior)
+                    if (d == 0) {
+                        val = comp_lerp(comp_p, Lp)[0];
+                    } else if (wavefn) {
+                        f32x16 o[NBK];
+                        float s1 = 0.0f;
 #pragma unroll
-                    for (int d = 0; d < D; ++d) {
-                        f32x16 c;
-                        float rnorm = 1.0f, sgn = 1.0f, num;
-                        if (d == 0) {
-                            num = comp_lerp(comp_p, Lp[0])[0];   // psi_0 incl. sign and norm
-                        } else {
-                            f32x16 o = out_block<D>(net, h2, d, lane);
-                            float s1 = 0.0f;
+                        for (int kb = 0; kb < NBK; ++kb) {
+                            o[kb] = out_block<D, NBK>(net, h2, d, kb, lane);
+                            const f32x16 keep = load16(fkP + (kb * 2 + h) * 16);
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) { s1 += o[r]; o[r] = o[r] * keep[r]; }
-                            s1 = xhalf_sum(s1);
-                            // c = (o * keep) @ ob_to_b on v_mfma_f32_32x32x2_f32 (K = 32, unnormalised operands)
-                            c = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-                            for (int r4 = 0; r4 < 4; ++r4) {
-                                const f32x4 a4 = *reinterpret_cast<const f32x4*>(ob2b + (r4 * 64 + lane) * 4);
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], o[4 * r4 + e], c, 0, 0, 0);
-                            }
-                            float n2 = 0.0f;
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) n2 = __builtin_fmaf(c[r], c[r], n2);
-                            rnorm = __builtin_amdgcn_rsqf(xhalf_sum(n2));
-                            sgn = s1 < 0.0f ? -1.0f : 1.0f;
-                            num = lerp_dot(c, prior_rows(d), Lp[d].t);
+                            for (int r = 0; r < 16; ++r) { s1 += o[kb][r]; o[kb][r] = o[kb][r] * keep[r]; }
                         }
-                        float v = num * rnorm * sgn;
+                        s1 = xhalf_sum(s1);
+                        // c = (o * keep) @ ob_to_b on v_mfma_f32_32x32x2_f32 (unnormalised operands: no fp16 split)
+                        f32x16 c[NBK];
+                        float n2 = 0.0f;
+#pragma unroll
+                        for (int ko = 0; ko < NBK; ++ko) {
+                            c[ko] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                            for (int ki = 0; ki < NBK; ++ki)
+#pragma unroll
+                                for (int r4 = 0; r4 < 4; ++r4) {
+                                    const f32x4 a4 = *reinterpret_cast<const f32x4*>(ob2b + (((ko * NBK + ki) * 4 + r4) * 64 + lane) * 4);
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) c[ko] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], o[ki][4 * r4 + e], c[ko], 0, 0, 0);
+                                }
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) n2 = __builtin_fmaf(c[ko][r], c[ko][r], n2);
+                        }
+                        const float rnorm = __builtin_amdgcn_rsqf(xhalf_sum(n2));
+                        val = lerp_dot<NBK>(c, tl, tr, Lp.t) * rnorm;
+                        val = s1 < 0.0f ? -val : val;
+                    } else {
+                        // MFlow (distributions.py:139-163): M-spline table with the row factors folded in
+                        f32x16 v[NBK];
+#pragma unroll
+                        for (int kb = 0; kb < NBK; ++kb) v[kb] = out_block<D, NBK>(net, h2, d, kb, lane);
+                        float S1, Sf;
+                        sigmoid_block<NBK>(v, fkP, h, S1, Sf);
+                        val = lerp_dot<NBK>(v, tl, tr, Lp.t) * __builtin_amdgcn_rcpf(Sf);
+                    }
+                    if (wavefn) {
                         const bool constrained = (mm.constrained_mask >> d) & 1u;
                         if (mode == 0) {
-                            float pr = v * v;
+                            float pr = val * val;
                             if (constrained) pr = pr * 0.5f;
                             lp = lp + fast_log(pr + 1e-7f);
                         } else {
-                            if (constrained) v = v * 0.70710678118654752f;
-                            prod = prod * v;
+                            if (constrained) val = val * 0.70710678118654752f;
+                            prod = prod * val;
                         }
+                    } else {
+                        lp = lp + fast_log(val + 1e-7f);
                     }
-                    result = mode == 0 ? lp + logdet : prod * __expf(0.5f * logdet);
-                } else {
-                    // MFlow (distributions.py:139-163): M-spline table with the row factors folded in
-#pragma unroll
-                    for (int d = 0; d < D; ++d) {
-                        float num, rS = 1.0f;
-                        if (d == 0) {
-                            num = comp_lerp(comp_p, Lp[0])[0];
-                        } else {
-                            f32x16 v = out_block<D>(net, h2, d, lane);
-                            float S1, Sf;
-                            sigmoid_block(v, fkP, h, S1, Sf);
-                            rS = __builtin_amdgcn_rcpf(Sf);
-                            num = lerp_dot(v, prior_rows(d), Lp[d].t);
-                        }
-                        lp = lp + fast_log(__builtin_fmaf(num, rS, 1e-7f));
-                    }
-                    result = lp + logdet;
+                    nxt[d] = uc;
                 }
+                result = (wavefn && mode != 0) ? prod * __expf(0.5f * logdet) : lp + logdet;
 #pragma unroll
-                for (int d = 0; d < D; ++d) cur[d] = uc[d];
+                for (int d = 0; d < D; ++d) cur[d] = nxt[d];
             } else if (mm.prior_kind == WF_PRIOR_UNIFORM) {
 #pragma unroll
                 for (int d = 0; d < D; ++d) cur[d] = fminf(fmaxf(cur[d], 0.0f), 1.0f);
@@ -519,9 +546,8 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
 #endif
 }
 
-
 // ---- composite tables of output dimension 0 (see comp_lerp); one thread per (net, mesh point); plain weight image
-__global__ void k_prepare_dim0(const ModelDev* __restrict__ mdp, int nm, const float* __restrict__ fk_nat /* [2][32]: I, prior */,
+__global__ void k_prepare_dim0(const ModelDev* __restrict__ mdp, int nm, const float* __restrict__ fk_nat /* [2][64]: I, prior */,
                                float F_I, float F_P, f32x4* __restrict__ comp) {
     const ModelDev& md = *mdp;
     const int n_nets = md.n_layers + ((md.prior_kind == WF_PRIOR_WAVEFLOW || md.prior_kind == WF_PRIOR_MFLOW) ? 1 : 0);
@@ -537,7 +563,7 @@ __global__ void k_prepare_dim0(const ModelDev* __restrict__ mdp, int nm, const f
     } else if (is_prior && md.prior_kind == WF_PRIOR_WAVEFLOW) {
         const SplineDev& sp = md.psp;
         const int nb = sp.nb, nbp = sp.nbp;
-        const float* keep = fk_nat + 32;
+        const float* keep = fk_nat + 64;
         float s1 = 0.0f;
         for (int j = 0; j < nb; ++j) s1 += net.b2[j];
         float n2 = 0.0f, num = 0.0f;
@@ -551,7 +577,7 @@ __global__ void k_prepare_dim0(const ModelDev* __restrict__ mdp, int nm, const f
     } else {
         const SplineDev& sp = is_prior ? md.psp : md.isp;
         const int nb = sp.nb, nbp = sp.nbp;
-        const float* fk = fk_nat + (is_prior ? 32 : 0);
+        const float* fk = fk_nat + (is_prior ? 64 : 0);
         const float reg = is_prior ? 0.0f : md.i_reg, F = is_prior ? F_P : F_I;
         float s1 = 0.0f, sf = 0.0f;
         for (int j = 0; j < nb; ++j) {
@@ -572,11 +598,12 @@ __global__ void k_prepare_dim0(const ModelDev* __restrict__ mdp, int nm, const f
     comp[gid] = out;
 }
 
-template <int D, int kWaves>
+template <int D, int NBK, int kWaves>
 int launch_dw(const MfmaDev* mdev, int lds_bytes, int mode, const float* x, int64_t B, float* out, float* u, int32_t* idx, hipStream_t s) {
     static int configured_bytes = -1;
     if (lds_bytes > configured_bytes) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mfma<D, kWaves>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mfma<D, NBK, kWaves>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           lds_bytes);
         if (e != hipSuccess) {
             set_hip_error((int)e);
             return WF_ERR_HIP;
@@ -586,7 +613,7 @@ int launch_dw(const MfmaDev* mdev, int lds_bytes, int mode, const float* x, int6
     const int64_t n_tiles = (B + 31) / 32;
     int64_t grid = (n_tiles + kWaves - 1) / kWaves;
     if (grid > 256) grid = 256;  // one persistent workgroup per CU
-    hipLaunchKernelGGL((k_mfma<D, kWaves>), dim3((unsigned)grid), dim3(kWaves * 64), lds_bytes, s, *mdev, mode, x, B, out, u, idx);
+    hipLaunchKernelGGL((k_mfma<D, NBK, kWaves>), dim3((unsigned)grid), dim3(kWaves * 64), lds_bytes, s, *mdev, mode, x, B, out, u, idx);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_hip_error((int)e);
@@ -599,15 +626,6 @@ int waves_per_group() {
     const char* e = getenv("WF_MFMA_WAVES");  // tuning knob (read at every launch): 8, 12 or 16 waves per workgroup
     const int v = e ? atoi(e) : 0;
     return (v == 8 || v == 12 || v == 16) ? v : 16;
-}
-
-template <int D>
-int launch_d(const MfmaDev* mdev, int lds_bytes, int mode, const float* x, int64_t B, float* out, float* u, int32_t* idx, hipStream_t s) {
-    switch (waves_per_group()) {
-        case 8: return launch_dw<D, 8>(mdev, lds_bytes, mode, x, B, out, u, idx, s);
-        case 12: return launch_dw<D, 12>(mdev, lds_bytes, mode, x, B, out, u, idx, s);
-        default: return launch_dw<D, 16>(mdev, lds_bytes, mode, x, B, out, u, idx, s);
-    }
 }
 
 }  // namespace
@@ -628,15 +646,39 @@ int launch_prepare_dim0(const ModelDev* md_dev, int n_nets, int n_mesh, const fl
     return WF_OK;
 }
 
-int launch_mfma(int D, const MfmaDev* mdev, int lds_bytes, int mode, const float* x, int64_t B, float* out, float* u, int32_t* idx,
+int launch_mfma(int D, int nbk, const MfmaDev* mdev, int lds_bytes, int mode, const float* x, int64_t B, float* out, float* u, int32_t* idx,
                 void* stream) {
     hipStream_t s = (hipStream_t)stream;
-    switch (D) {
-        case 2: return launch_d<2>(mdev, lds_bytes, mode, x, B, out, u, idx, s);
-        case 3: return launch_d<3>(mdev, lds_bytes, mode, x, B, out, u, idx, s);
-        case 4: return launch_d<4>(mdev, lds_bytes, mode, x, B, out, u, idx, s);
-        default: return WF_ERR_UNSUPPORTED;
+#define GO(DD, KK, WW) return launch_dw<DD, KK, WW>(mdev, lds_bytes, mode, x, B, out, u, idx, s)
+    if (D == 2 && nbk == 1) {   // the headline shape: all three workgroup sizes are built (tuning / reproducibility test)
+        switch (waves_per_group()) {
+            case 8: GO(2, 1, 8);
+            case 12: GO(2, 1, 12);
+            default: GO(2, 1, 16);
+        }
     }
+    if (nbk == 1) {
+        switch (D) {
+            case 3: GO(3, 1, 8);
+            case 4: GO(4, 1, 8);
+            case 8: GO(8, 1, 8);
+            default: return WF_ERR_UNSUPPORTED;
+        }
+    }
+    if (nbk == 2) {
+        switch (D) {
+            case 2: GO(2, 2, 8);
+            case 3: GO(3, 2, 8);
+            case 4: GO(4, 2, 8);
+            default: return WF_ERR_UNSUPPORTED;
+        }
+    }
+#undef GO
+    return WF_ERR_UNSUPPORTED;
+}
+
+bool mfma_shape_built(int D, int nbk) {
+    return (nbk == 1 && (D == 2 || D == 3 || D == 4 || D == 8)) || (nbk == 2 && (D == 2 || D == 3 || D == 4));
 }
 
 }  // namespace wf

@@ -79,7 +79,7 @@ struct wf_model {
     wf::MfmaDev mdev{};
     wf::MfmaDev* d_mdev = nullptr;
     std::vector<float> mfma_consts;  // constants block of the LDS image (host copy)
-    std::vector<int> mfma_net_floats;
+    int64_t mfma_lds_floats = 0;
     float* d_tabI = nullptr;
     float* d_tabP = nullptr;
     float* d_fk_nat = nullptr;       // [2][32] natural-order row factors (I layers, prior) for k_prepare_dim0
@@ -362,9 +362,9 @@ static void build_plain_image(const wf_model* m, int n, const float* flat, float
 // ---------------------------------------------------------------------------- MFMA kernel images
 static inline int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-static int mfma_net_floats(int D) {
+static int mfma_net_floats(int D, int nbk) {
     const int S0 = (D + 1) / 2;
-    return 128 * S0 + 64 + 4096 + 64 + (D - 1) * 2048 + 32 * D;
+    return 128 * S0 + 64 + 4096 + 64 + (D - 1) * nbk * 2048 + 32 * D * nbk;
 }
 
 // all constraints are {0: 0} (or the I-spline's right {0: 1}): they only zero the first / last weight
@@ -380,9 +380,9 @@ static bool bc_only_zeroes(const wf_bc& left, const wf_bc& right, bool is_I) {
 
 // per-row factor: remove_bias scaling (isplines_jax.py:196-202 / msplines_jax.py:186-192) times the
 // 0/1 "kept by the boundary conditions" mask; 0 beyond the real bases.  Layout [half][16] in accumulator order.
-static void row_factors(int kind, bool with_remove_bias, int k, int nb, const wf_bc& left, const wf_bc& right, float* out32,
-                        float* natural32 = nullptr) {
-    std::vector<float> f(32, 0.0f);
+static void row_factors(int kind, bool with_remove_bias, int k, int nb, int nbk, const wf_bc& left, const wf_bc& right, float* out_acc,
+                        float* natural64 = nullptr) {
+    std::vector<float> f(64, 0.0f);
     for (int j = 0; j < nb; ++j) f[j] = 1.0f;
     if (with_remove_bias)
         for (int i = 0; i < k; ++i) {
@@ -394,29 +394,31 @@ static void row_factors(int kind, bool with_remove_bias, int k, int nb, const wf
         }
     if (left.n > 0) f[0] = 0.0f;
     if (right.n > 0) f[nb - 1] = 0.0f;
-    for (int h = 0; h < 2; ++h)
-        for (int r = 0; r < 16; ++r) out32[h * 16 + r] = f[acc_row(r, h)];
-    if (natural32)
-        for (int j = 0; j < 32; ++j) natural32[j] = f[j];
+    for (int kb = 0; kb < nbk; ++kb)
+        for (int h = 0; h < 2; ++h)
+            for (int r = 0; r < 16; ++r) out_acc[(kb * 2 + h) * 16 + r] = f[32 * kb + acc_row(r, h)];
+    if (natural64)
+        for (int j = 0; j < 64; ++j) natural64[j] = f[j];
 }
 
-// [n_mesh][n_orders][half][16], each row scaled by fk[row] (may be null); rowsum (may be null): [n_mesh][n_orders]
-static void pack_rows_acc(const std::vector<double>& t64, int nb, int n_mesh, int n_orders, const float* fk32 /* [2][16] */,
+// [n_mesh][n_orders][nbk][half][16], each row scaled by fk (acc layout [kb][h][16], may be null); rowsum (may be null): [n_mesh][n_orders]
+static void pack_rows_acc(const std::vector<double>& t64, int nb, int n_mesh, int n_orders, int nbk, const float* fk_acc,
                           std::vector<float>& out, std::vector<float>* rowsum) {
-    out.assign((size_t)n_mesh * n_orders * 32, 0.0f);
+    out.assign((size_t)n_mesh * n_orders * nbk * 32, 0.0f);
     if (rowsum) rowsum->assign((size_t)n_mesh * n_orders, 0.0f);
     for (int m = 0; m < n_mesh; ++m)
         for (int nd = 0; nd < n_orders; ++nd) {
             double rs = 0.0;
-            for (int h = 0; h < 2; ++h)
-                for (int r = 0; r < 16; ++r) {
-                    const int row = acc_row(r, h);
-                    if (row >= nb) continue;
-                    const float t = (float)t64[((size_t)nd * nb + row) * n_mesh + m];   // the reference's fp32 table entry
-                    const float v = fk32 ? (float)((double)fk32[h * 16 + r] * (double)t) : t;
-                    out[(((size_t)m * n_orders + nd) * 2 + h) * 16 + r] = v;
-                    rs += (double)v;
-                }
+            for (int kb = 0; kb < nbk; ++kb)
+                for (int h = 0; h < 2; ++h)
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = 32 * kb + acc_row(r, h);
+                        if (row >= nb) continue;
+                        const float t = (float)t64[((size_t)nd * nb + row) * n_mesh + m];   // the reference's fp32 table entry
+                        const float v = fk_acc ? (float)((double)fk_acc[(kb * 2 + h) * 16 + r] * (double)t) : t;
+                        out[((((size_t)m * n_orders + nd) * nbk + kb) * 2 + h) * 16 + r] = v;
+                        rs += (double)v;
+                    }
             if (rowsum) (*rowsum)[(size_t)m * n_orders + nd] = (float)rs;
         }
 }
@@ -435,7 +437,7 @@ static bool net_has_sigmoid_head(const wf_model* m, int n) {
 
 // LDS image of net n in MFMA operand order (wf_kernels_mfma.hip: NetOff<D>)
 static void build_mfma_image(const wf_model* m, int n, const float* flat, float* img) {
-    const int D = m->desc.n_dim, H = kHidden;
+    const int D = m->desc.n_dim, H = kHidden, nbk = m->mdev.nbk;
     const int S0 = (D + 1) / 2;
     const NetLayout& nl = m->nets[n];
     const int NO = nl.n_out * D;
@@ -479,29 +481,31 @@ static void build_mfma_image(const wf_model* m, int n, const float* flat, float*
     for (int ob = 0; ob < 2; ++ob)
         for (int h = 0; h < 2; ++h)
             for (int r = 0; r < 16; ++r) *o++ = (float)(c1 * (double)b1[32 * ob + acc_row(r, h)]);
-    // output layer, dimensions 1..D-1: A[i = basis (lane&31)][k = kk]
+    // output layer, dimensions 1..D-1, row blocks kb: A[i = basis 32*kb + (lane&31)][k = kk]
     {
         _Float16* hi = reinterpret_cast<_Float16*>(o);
-        _Float16* lo = hi + (D - 1) * 2048;
+        _Float16* lo = hi + (D - 1) * nbk * 2048;
         for (int d = 1; d < D; ++d)
-            for (int t = 0; t < 2; ++t)
-                for (int s = 0; s < 2; ++s)
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int j = 0; j < 8; ++j) {
-                            const int jb = lane & 31, kk = 32 * t + acc_row(8 * s + j, lane >> 5);
-                            float v = 0.0f;
-                            if (jb < nl.n_out && deg_out(d) >= deg_hidden(kk, D)) v = (float)(c2 * (double)W2[(int64_t)kk * NO + (jb * D + d)]);
-                            split_f16(v, *hi++, *lo++);
-                        }
-        o += (D - 1) * 2048;
+            for (int kb = 0; kb < nbk; ++kb)
+                for (int t = 0; t < 2; ++t)
+                    for (int s = 0; s < 2; ++s)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 8; ++j) {
+                                const int jb = 32 * kb + (lane & 31), kk = 32 * t + acc_row(8 * s + j, lane >> 5);
+                                float v = 0.0f;
+                                if (jb < nl.n_out && deg_out(d) >= deg_hidden(kk, D)) v = (float)(c2 * (double)W2[(int64_t)kk * NO + (jb * D + d)]);
+                                split_f16(v, *hi++, *lo++);
+                            }
+        o += (D - 1) * nbk * 2048;
     }
     // biases; padding rows of sigmoid heads get +1e30 so that sigmoid(-x) -> 0 exactly
     for (int d = 0; d < D; ++d)
-        for (int h = 0; h < 2; ++h)
-            for (int r = 0; r < 16; ++r) {
-                const int jb = acc_row(r, h);
-                *o++ = jb < nl.n_out ? (float)(c2 * (double)b2[jb * D + d]) : (sig ? 1e30f : 0.0f);
-            }
+        for (int kb = 0; kb < nbk; ++kb)
+            for (int h = 0; h < 2; ++h)
+                for (int r = 0; r < 16; ++r) {
+                    const int jb = 32 * kb + acc_row(r, h);
+                    *o++ = jb < nl.n_out ? (float)(c2 * (double)b2[jb * D + d]) : (sig ? 1e30f : 0.0f);
+                }
 }
 
 // Decides whether the MFMA kernel covers this model and builds its parameter-independent parts.
@@ -510,35 +514,40 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
     const wf_model_desc& d = m->desc;
     const int D = d.n_dim;
     m->mfma_ok = false;
-    if (D > 4 || m->i_nb > 32 || m->p_nb > 32) return WF_OK;
+    const int nbk = m->nbp / 32;
+    if (!mfma_shape_built(D, nbk)) return WF_OK;
     const bool imade = d.layer_kind == WF_LAYER_IMADE && d.n_flow_layers > 0;
     if (imade && !bc_only_zeroes(d.i_left, d.i_right, true)) return WF_OK;
     const bool spline_prior = d.prior_kind == WF_PRIOR_WAVEFLOW || d.prior_kind == WF_PRIOR_MFLOW;
     if (spline_prior && !bc_only_zeroes(d.p_left, d.p_right, false)) return WF_OK;
     const int n_nets = (int)m->nets.size();
-    const int consts = 32 + 32 + 1024;
-    const int64_t total = (int64_t)mfma_net_floats(D) * n_nets + consts;
-    if ((total + mfma_extra_lds_floats(n_nets)) * 4 > 160 * 1024) return WF_OK;  // all nets must be LDS-resident
+    const int consts = 64 * nbk + nbk * nbk * 1024;
+    const int net_floats = mfma_net_floats(D, nbk);
+    const int64_t lds_cap = 160 * 1024 / 4;   // floats
+    int staged;
+    if ((int64_t)consts + (int64_t)net_floats * n_nets <= lds_cap) staged = 0;        // every net resident
+    else if ((int64_t)consts + net_floats <= lds_cap) staged = 1;                     // one slot, re-staged per chunk
+    else return WF_OK;
+    const int64_t total = (int64_t)net_floats * n_nets + consts;
 
     MfmaDev& md = m->mdev;
     md = MfmaDev{};
     md.D = D; md.n_layers = d.n_flow_layers; md.layer_kind = d.layer_kind; md.box_kind = d.box_kind; md.prior_kind = d.prior_kind;
     md.box_L = d.box_size; md.i_reg = d.i_reg; md.normal_offset = d.normal_offset; md.constrained_mask = m->dev.constrained_mask;
-    md.i_nb = m->i_nb; md.p_nb = m->p_nb; md.n_mesh = d.n_mesh;
-    md.image_floats = (int)total;
-    for (int n = 0; n < n_nets; ++n) md.net_off[n] = mfma_net_floats(D) * n;
-    md.const_off = mfma_net_floats(D) * n_nets;
+    md.i_nb = m->i_nb; md.p_nb = m->p_nb; md.n_mesh = d.n_mesh; md.nbk = nbk;
+    md.n_nets = n_nets; md.net_floats = net_floats; md.const_img_off = net_floats * n_nets; md.const_floats = consts; md.staged = staged;
+    m->mfma_lds_floats = consts + (staged ? net_floats : net_floats * n_nets);
 
     m->mfma_consts.assign(consts, 0.0f);
-    std::vector<float> fk_nat(64, 0.0f);
+    std::vector<float> fk_nat(128, 0.0f);
     if (imade) {
         float* fk = m->mfma_consts.data();
-        row_factors(WF_SPLINE_I, true, d.i_degree, m->i_nb, d.i_left, d.i_right, fk, fk_nat.data());
+        row_factors(WF_SPLINE_I, true, d.i_degree, m->i_nb, nbk, d.i_left, d.i_right, fk, fk_nat.data());
         double F = 0;
-        for (int i = 0; i < 32; ++i) F += fk[i];
+        for (int i = 0; i < 32 * nbk; ++i) F += fk[i];
         md.F_I = (float)F;
         std::vector<float> rows, rowsum;
-        pack_rows_acc(i64, m->i_nb, d.n_mesh, 2, fk, rows, &rowsum);
+        pack_rows_acc(i64, m->i_nb, d.n_mesh, 2, nbk, fk, rows, &rowsum);
         int rc = upload_table(m, rows, &md.tabI);
         if (rc) return rc;
         rc = upload_table(m, rowsum, &md.rsI);
@@ -546,34 +555,36 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
     }
     if (spline_prior) {
         const bool mflow = d.prior_kind == WF_PRIOR_MFLOW;
-        float* fk = m->mfma_consts.data() + 32;
-        row_factors(mflow ? WF_SPLINE_M : WF_SPLINE_B, mflow, d.p_degree, m->p_nb, d.p_left, d.p_right, fk, fk_nat.data() + 32);
+        float* fk = m->mfma_consts.data() + 32 * nbk;
+        row_factors(mflow ? WF_SPLINE_M : WF_SPLINE_B, mflow, d.p_degree, m->p_nb, nbk, d.p_left, d.p_right, fk, fk_nat.data() + 64);
         double F = 0;
-        for (int i = 0; i < 32; ++i) F += fk[i];
+        for (int i = 0; i < 32 * nbk; ++i) F += fk[i];
         md.F_P = (float)F;
         std::vector<float> rows;
         // M prior: the row factors are folded into the table; B prior: they act on the weights before ob_to_b
-        pack_rows_acc(p64, m->p_nb, d.n_mesh, 1, mflow ? fk : nullptr, rows, nullptr);
+        pack_rows_acc(p64, m->p_nb, d.n_mesh, 1, nbk, mflow ? fk : nullptr, rows, nullptr);
         int rc = upload_table(m, rows, &md.tabP);
         if (rc) return rc;
         if (!mflow) {
-            // c[i] = sum_a w[a] * ob_to_b[a][i]: A[i = lane&31][k = a = acc_row(r, lane>>5)]
-            float* o = m->mfma_consts.data() + 64;
+            // c[i] = sum_a w[a] * ob_to_b[a][i]: block (ko, ki): A[i = 32*ko + (lane&31)][k = a = 32*ki + acc_row(r, lane>>5)]
+            float* o = m->mfma_consts.data() + 64 * nbk;
             const int nb = m->p_nb;
-            for (int r4 = 0; r4 < 4; ++r4)
-                for (int lane = 0; lane < 64; ++lane)
-                    for (int e = 0; e < 4; ++e) {
-                        const int i = lane & 31, a = acc_row(4 * r4 + e, lane >> 5);
-                        *o++ = (i < nb && a < nb) ? (float)o2b[(size_t)a * nb + i] : 0.0f;
-                    }
+            for (int ko = 0; ko < nbk; ++ko)
+                for (int ki = 0; ki < nbk; ++ki)
+                    for (int r4 = 0; r4 < 4; ++r4)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int e = 0; e < 4; ++e) {
+                                const int i = 32 * ko + (lane & 31), a = 32 * ki + acc_row(4 * r4 + e, lane >> 5);
+                                *o++ = (i < nb && a < nb) ? (float)o2b[(size_t)a * nb + i] : 0.0f;
+                            }
         }
     }
     int rc = dev_alloc(m, &m->d_mfma, (size_t)total);
     if (rc) return rc;
     md.image = m->d_mfma;
-    rc = dev_alloc(m, &m->d_fk_nat, 64);
+    rc = dev_alloc(m, &m->d_fk_nat, 128);
     if (rc) return rc;
-    WF_HIP(hipMemcpy(m->d_fk_nat, fk_nat.data(), 64 * sizeof(float), hipMemcpyHostToDevice));
+    WF_HIP(hipMemcpy(m->d_fk_nat, fk_nat.data(), 128 * sizeof(float), hipMemcpyHostToDevice));
     {
         float* comp = nullptr;
         rc = dev_alloc(m, &comp, (size_t)std::max(n_nets, 1) * d.n_mesh * 4);
@@ -581,9 +592,6 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
         m->d_comp = comp;
         md.comp = reinterpret_cast<const float4_t*>(comp);
     }
-    rc = dev_alloc(m, &m->d_mdev, 1);
-    if (rc) return rc;
-    WF_HIP(hipMemcpy(m->d_mdev, &md, sizeof(MfmaDev), hipMemcpyHostToDevice));
     m->mfma_floats = total;
     m->mfma_ok = true;
     return WF_OK;
@@ -708,8 +716,8 @@ int wf_model_set_params(wf_model* m, const float* flat_host, int64_t n, void* st
     std::vector<float> mimg;
     if (m->mfma_ok) {
         mimg.assign((size_t)m->mfma_floats, 0.0f);
-        for (size_t i = 0; i < m->nets.size(); ++i) build_mfma_image(m, (int)i, flat_host, mimg.data() + m->mdev.net_off[i]);
-        std::copy(m->mfma_consts.begin(), m->mfma_consts.end(), mimg.begin() + m->mdev.const_off);
+        for (size_t i = 0; i < m->nets.size(); ++i) build_mfma_image(m, (int)i, flat_host, mimg.data() + (size_t)m->mdev.net_floats * i);
+        std::copy(m->mfma_consts.begin(), m->mfma_consts.end(), mimg.begin() + m->mdev.const_img_off);
         WF_HIP(hipMemcpyAsync(m->d_mfma, mimg.data(), mimg.size() * sizeof(float), hipMemcpyHostToDevice, s));
         // composite tables of output dimension 0 (needs the plain image uploaded above)
         int rc = launch_prepare_dim0(m->d_dev, (int)m->nets.size(), m->desc.n_mesh, m->d_fk_nat, m->mdev.F_I, m->mdev.F_P, m->d_comp, stream);
@@ -734,7 +742,7 @@ static int dispatch(const wf_model* m, int mode, const float* x, int64_t B, floa
 #if defined(WF_DEBUG) || defined(WF_STAMP)
     if (use_mfma && getenv("WF_DBG_PTR")) const_cast<wf_model*>(m)->mdev.dbg = (float*)strtoull(getenv("WF_DBG_PTR"), nullptr, 0);
 #endif
-    if (use_mfma) return launch_mfma(m->dev.D, &m->mdev, (int)((m->mfma_floats + mfma_extra_lds_floats((int)m->nets.size())) * sizeof(float)), mode, x, B, out, u, idx, stream);
+    if (use_mfma) return launch_mfma(m->dev.D, m->mdev.nbk, &m->mdev, (int)(m->mfma_lds_floats * sizeof(float)), mode, x, B, out, u, idx, stream);
     return launch_scalar(m->dev, m->d_dev, mode, x, B, out, u, idx, stream);
 }
 
