@@ -9,7 +9,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libwaveflow_hip.so")
 OBJ = os.path.join(CSRC, "_obj")
 
-SOURCES = ["wf_tables.cpp", "wf_model.cpp", "wf_kernels_scalar.hip", "wf_kernels_mfma.hip", "wf_kernels_rqs.hip", "wf_kernels_energy.hip"]
+SOURCES = ["wf_tables.cpp", "wf_model.cpp", "wf_kernels_scalar.hip", "wf_scalar_inst_d2.hip", "wf_scalar_inst_d3.hip", "wf_scalar_inst_d4.hip", "wf_scalar_inst_d56.hip",
+           "wf_scalar_inst_d78.hip", "wf_scalar_inst_n64.hip", "wf_kernels_mfma.hip", "wf_mfma_inst_d2.hip", "wf_mfma_inst_d34.hip",
+           "wf_mfma_inst_d8.hip", "wf_mfma_inst_k2.hip", "wf_kernels_rqs.hip", "wf_kernels_energy.hip"]
 # -ffp-contract=off: the index arithmetic and the table lerp keep the reference's separate
 # multiply / add roundings; dot products that may fuse say so with explicit fmaf / MFMA.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
@@ -25,6 +27,10 @@ def _hipcc():
 
 def _deps(src):
     d = [os.path.join(CSRC, src), os.path.join(CSRC, "wf_internal.h"), os.path.join(HERE, "..", "include", "waveflow_hip.h")]
+    if "mfma" in src:
+        d.append(os.path.join(CSRC, "wf_mfma_impl.h"))
+    if "scalar" in src:
+        d.append(os.path.join(CSRC, "wf_scalar_impl.h"))
     return [p for p in d if os.path.exists(p)]
 
 
@@ -47,7 +53,7 @@ def build(force=False, verbose=False):
         return r
 
     if jobs:
-        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+        with ThreadPoolExecutor(max_workers=min(os.cpu_count() or 4, len(jobs))) as ex:
             list(ex.map(run, jobs))
     objs = [os.path.join(OBJ, s + ".o") for s in srcs]
     if jobs or force or not os.path.exists(LIB) or any(os.path.getmtime(LIB) < os.path.getmtime(o) for o in objs):
