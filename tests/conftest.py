@@ -14,6 +14,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _native_library():
+    """A fresh checkout has no libwaveflow_hip.so (built files are git-ignored): cross-compile it once (hipcc needs no GPU)."""
+    from waveflow_amd import build as wf_build
+    if not os.path.exists(wf_build.LIB):
+        wf_build.build()
+
+
 @pytest.fixture(scope="session")
 def golden():
     return {n[:-4]: np.load(os.path.join(GOLDEN, n)) for n in os.listdir(GOLDEN) if n.endswith(".npz")}

@@ -358,3 +358,44 @@ def test_abi_error_paths(he_flat):
     d.n_dim, d.hidden, d.n_flow_layers, d.n_mesh, d.i_degree, d.i_knots, d.prior_kind = 2, 64, 1, 2000, 6, 80, _lib.PRIOR_UNIFORM
     h = ctypes.c_void_p()
     assert L.wf_model_create(ctypes.byref(d), 0, ctypes.byref(h)) == -2
+
+
+def test_hip_graph_capture_of_the_step(he_flat):
+    """The launch functions do no allocation / synchronisation, so a step (log_pdf + block sums) can be captured into a
+    hipGraph on the caller's stream and replayed (the batch-256 configuration is launch-bound)."""
+    import ctypes
+    torch = _torch()
+    from waveflow_amd import _lib
+    params, psi, log_pdf, om = he_models(he_flat, "mfma")
+    m = log_pdf.model
+    m.ensure_params(params)
+    L = _lib.lib()
+    B = 256
+    x = torch.from_numpy(sorted_walkers(B, 2, 10.0, 21)).cuda()
+    lp = torch.empty(B, device="cuda")
+    sums = torch.zeros(3, device="cuda", dtype=torch.float64)
+    ws = torch.empty(int(L.wf_block_sums_workspace_bytes(B)), device="cuda", dtype=torch.uint8)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+
+    def step():
+        sp = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        assert L.wf_logpdf_fwd(m._h, P(x), B, P(lp), None, None, sp) == 0
+        assert L.wf_block_sums(P(lp), B, P(sums), P(ws), ws.numel(), sp) == 0
+
+    step()                                   # warm-up outside capture (first launch configures the kernel's LDS size)
+    torch.cuda.synchronize()
+    ref_lp, ref_sums = lp.clone(), sums.clone()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            step()
+    lp.zero_(); sums.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(lp, ref_lp) and torch.equal(sums, ref_sums)
+    # new inputs in the same buffers are picked up by a replay
+    x.copy_(torch.from_numpy(sorted_walkers(B, 2, 10.0, 22)).cuda())
+    g.replay()
+    torch.cuda.synchronize()
+    close(lp.cpu().numpy(), om.log_pdf(he_flat, x.cpu().numpy(), f64=True), rtol=1e-4, atol=2e-2)
