@@ -174,6 +174,26 @@ int wf_sample(const wf_model* m, uint64_t seed, int64_t B, float* x_dev, float* 
 int wf_hamiltonian_fwd(const wf_model* m, const float* x_dev, int64_t B, const float* protons_host, int32_t n_protons,
                        float* hpsi_dev, float* psi_dev, float* laplacian_dev, void* stream);
 
+/* Parameter gradient of psi and of its Laplacian -- the vector-Jacobian product behind vqmc.train_step_efficient
+ * (vqmc.py:193-221: value_and_grad of loss_fn_efficient through physics.laplacian, utils/physics.py:50-52):
+ *     grad_dev[p] = sum_b ( w_psi_dev[b] * d psi_b / d theta_p + w_lap_dev[b] * d laplacian(psi)_b / d theta_p )
+ * in the flat leaf order of wf_model_set_params (masked-out weight entries and the zero_params leaves get 0, as in the
+ * reference where they only enter multiplied by their mask).  The table lerp differentiates to the next cached table and
+ * the order beyond the last cached one clamps to it (JAX's out-of-range index semantics at isplines_jax.py:65).
+ * workspace: wf_psi_vjp_workspace_bytes(m, B) bytes suffice for any B (larger batches are processed in chunks of what the
+ * workspace holds).  Same model coverage as wf_hamiltonian_fwd, zero-only boundary constraints. */
+int64_t wf_psi_vjp_workspace_bytes(const wf_model* m, int64_t B);
+int wf_psi_vjp(const wf_model* m, const float* x_dev, int64_t B, const float* w_psi_dev, const float* w_lap_dev, float* grad_dev,
+               void* workspace_dev, int64_t workspace_bytes, void* stream);
+
+/* Per-walker weights of loss_fn_efficient's tangent rule (vqmc.py:198-212) for wf_psi_vjp, from wf_hamiltonian_fwd's outputs:
+ *     e_loc = hpsi / (psi + 1e-8);   d loss = [2 (e_loc - running_average)/psi - hpsi/psi^2] d psi + (1/psi) d hpsi,
+ *     d hpsi = -1/2 d laplacian + V d psi   =>   w_psi = (... + V/psi) * inv_count,  w_lap = -1/(2 psi) * inv_count
+ * with V the soft-Coulomb potential of wf_hamiltonian_fwd and inv_count = 1 / (global batch size). */
+int wf_vqmc_seeds(const float* x_dev, int64_t B, int32_t n_dim, const float* protons_host, int32_t n_protons, const float* hpsi_dev,
+                  const float* psi_dev, float running_average, float inv_count, float* e_loc_dev, float* w_psi_dev, float* w_lap_dev,
+                  void* stream);
+
 /* Rational-quadratic spline bijector, elementwise (flows/bijections/neural_splines.py:16-184; dead code in the reference,
  * parity unpinned).  x[N]; uw, uh [N][K] unnormalised widths / heights; ud [N][n_deriv] unnormalised derivatives with
  * n_deriv == K-1 (unconstrained_RQS: identity outside [left, right], boundary derivatives 1) or K+1 (RQS: explicit).

@@ -38,9 +38,9 @@ class _Basis(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, tab = ctx.saved_tensors
-        if ctx.nd + 1 >= tab.shape[0]:
-            raise RuntimeError("derivative order beyond the cached tables (the reference caches nd = 0..3)")
-        return (g * _Basis.apply(x, tab, ctx.nd + 1)).sum(-1), None, None
+        # the reference indexes cached_bases_dict[n_derivative + 1] with a traced integer (isplines_jax.py:65): JAX clamps an
+        # out-of-range dynamic index, so the derivative of the highest cached order (nd = 3) is that same order again
+        return (g * _Basis.apply(x, tab, min(ctx.nd + 1, tab.shape[0] - 1))).sum(-1), None, None
 
 
 def table_spline(x, c, tab, nd=0):
@@ -87,7 +87,7 @@ class TorchWaveflow:
 
     def psi(self, flat, x):
         dt = self.dtype
-        p = torch.as_tensor(np.asarray(flat, dtype=np.float32)).to(dt)
+        p = flat.to(dt) if torch.is_tensor(flat) else torch.as_tensor(np.asarray(flat, dtype=np.float32)).to(dt)
         D, L, tol, k = self.D, self.L, 1e-7, self.k
         # BoxTransformLayer
         if self.box == "mean":
@@ -168,6 +168,43 @@ def hamiltonian(model, flat, x, protons):
     V = potential(x.detach(), torch.as_tensor(np.asarray(protons, dtype=np.float64).reshape(-1), dtype=model.dtype))
     hpsi = -0.5 * lap + V * ps.detach()
     return hpsi.detach().numpy(), ps.detach().numpy(), lap.detach().numpy()
+
+
+def _psi_lap(model, p, x):
+    ps = model.psi(p, x)
+    (g,) = torch.autograd.grad(ps.sum(), x, create_graph=True)
+    lap = torch.zeros_like(ps)
+    for i in range(x.shape[1]):
+        (gi,) = torch.autograd.grad(g[:, i].sum(), x, create_graph=True)
+        lap = lap + gi[:, i]
+    return ps, lap
+
+
+def psi_vjp(model, flat, x, w_psi, w_lap):
+    """d/dparams sum_b (w_psi[b] * psi_b + w_lap[b] * laplacian_b): what reverse mode through the Hessian trace gives the
+    reference (value_and_grad over physics.laplacian, vqmc.py:215-221).  -> flat gradient [n_params] (fp64)."""
+    p = torch.as_tensor(np.asarray(flat, dtype=np.float32)).to(model.dtype).clone().requires_grad_(True)
+    x = torch.as_tensor(np.asarray(x), dtype=model.dtype).clone().requires_grad_(True)
+    ps, lap = _psi_lap(model, p, x)
+    F = (torch.as_tensor(np.asarray(w_psi), dtype=model.dtype) * ps).sum() + (torch.as_tensor(np.asarray(w_lap), dtype=model.dtype) * lap).sum()
+    (g,) = torch.autograd.grad(F, p)
+    return g.detach().numpy()
+
+
+def vqmc_loss_grad(model, flat, x, protons, running_average):
+    """loss_fn_efficient + its custom JVP (vqmc.py:193-212) -> (loss, gradient [n_params], local energies [B])."""
+    p = torch.as_tensor(np.asarray(flat, dtype=np.float32)).to(model.dtype).clone().requires_grad_(True)
+    xt = torch.as_tensor(np.asarray(x), dtype=model.dtype).clone().requires_grad_(True)
+    ps, lap = _psi_lap(model, p, xt)
+    V = potential(xt.detach(), torch.as_tensor(np.asarray(protons, dtype=np.float64).reshape(-1), dtype=model.dtype))
+    hpsi = -0.5 * lap + V * ps
+    e_loc = (hpsi / (ps + 1e-8)).detach()
+    psd, hd = ps.detach(), hpsi.detach()
+    # tangent rule: 2 t_psi (E - avg) / psi + (t_E psi - E t_psi) / psi^2, averaged over the batch
+    a = (2.0 * (e_loc - running_average) / psd - hd / psd ** 2) / x.shape[0]
+    c = (1.0 / psd) / x.shape[0]
+    (g,) = torch.autograd.grad((a * ps).sum() + (c * hpsi).sum(), p)
+    return float(e_loc.mean()), g.detach().numpy(), e_loc.numpy()
 
 
 def he_model(dtype=torch.float64):

@@ -54,7 +54,8 @@ class ModelDesc(ctypes.Structure):
 EXPORTS = ["wf_abi_version", "wf_strerror", "wf_last_hip_error", "wf_last_hip_error_string", "wf_device_count",
            "wf_tables_build", "wf_model_create", "wf_model_destroy", "wf_model_param_count", "wf_model_n_bases",
            "wf_model_set_params", "wf_model_set_kernel", "wf_logpdf_fwd", "wf_psi_fwd", "wf_flow_fwd", "wf_layer_fwd",
-           "wf_block_sums", "wf_block_sums_workspace_bytes", "wf_rqs_fwd", "wf_inverse_fwd", "wf_sample", "wf_hamiltonian_fwd"]
+           "wf_block_sums", "wf_block_sums_workspace_bytes", "wf_rqs_fwd", "wf_inverse_fwd", "wf_sample", "wf_hamiltonian_fwd",
+           "wf_psi_vjp", "wf_psi_vjp_workspace_bytes", "wf_vqmc_seeds"]
 
 _lib = None
 
@@ -105,6 +106,12 @@ def lib():
     L.wf_sample.argtypes = [vp, ctypes.c_uint64, i64, vp, vp, i32, vp]
     L.wf_hamiltonian_fwd.restype = i32
     L.wf_hamiltonian_fwd.argtypes = [vp, vp, i64, vp, i32, vp, vp, vp, vp]
+    L.wf_psi_vjp_workspace_bytes.restype = i64
+    L.wf_psi_vjp_workspace_bytes.argtypes = [vp, i64]
+    L.wf_psi_vjp.restype = i32
+    L.wf_psi_vjp.argtypes = [vp, vp, i64, vp, vp, vp, vp, i64, vp]
+    L.wf_vqmc_seeds.restype = i32
+    L.wf_vqmc_seeds.argtypes = [vp, i64, i32, vp, i32, vp, vp, ctypes.c_float, ctypes.c_float, vp, vp, vp, vp]
     L.wf_rqs_fwd.restype = i32
     L.wf_rqs_fwd.argtypes = [vp, vp, vp, vp, i64, i32, i32, i32, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                              vp, vp, vp, vp]

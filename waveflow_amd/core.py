@@ -58,6 +58,7 @@ class DeviceModel:
         self.i_nb = int(L.wf_model_n_bases(h, 0))
         self.p_nb = int(L.wf_model_n_bases(h, 1))
         self._flat = None
+        self._vjp_ws = None
         self.D = int(desc.n_dim)
         self.n_layers = int(desc.n_flow_layers)
 
@@ -193,6 +194,39 @@ class DeviceModel:
         if return_laplacian:
             res.append(back(lap))
         return res[0] if len(res) == 1 else tuple(res)
+
+    def psi_vjp(self, x, w_psi, w_lap):
+        """grad[p] = sum_b (w_psi[b] d psi_b/d theta_p + w_lap[b] d laplacian_b/d theta_p) -> torch.cuda float32 [n_params]."""
+        torch = _torch()
+        L = _lib.lib()
+        t, _ = self._to_dev(x)
+        B = t.shape[0]
+        wp = torch.as_tensor(w_psi, dtype=torch.float32).to(t.device).contiguous()
+        wl = torch.as_tensor(w_lap, dtype=torch.float32).to(t.device).contiguous()
+        if wp.numel() != B or wl.numel() != B:
+            raise ValueError("w_psi / w_lap must have one entry per walker")
+        nbytes = _lib.check(L.wf_psi_vjp_workspace_bytes(self._h, B), "wf_psi_vjp_workspace_bytes")
+        if self._vjp_ws is None or self._vjp_ws.numel() < nbytes:
+            self._vjp_ws = torch.empty(int(nbytes), device=t.device, dtype=torch.uint8)
+        grad = self._new((self.n_params,))
+        _lib.check(L.wf_psi_vjp(self._h, self._p(t), B, self._p(wp), self._p(wl), self._p(grad), self._p(self._vjp_ws),
+                                self._vjp_ws.numel(), self._stream()), "wf_psi_vjp")
+        return grad
+
+    def vqmc_loss_grad(self, x, protons, running_average, global_count=None):
+        """loss_fn_efficient and its gradient (vqmc.py:193-221) for the walkers x on this device.
+        -> (sums fp64 [sum E_L, sum E_L^2, count] (torch.cuda), grad float32 [n_params] scaled by 1/global_count)."""
+        torch = _torch()
+        L = _lib.lib()
+        t, _ = self._to_dev(x)
+        B = t.shape[0]
+        h, ps = self.hamiltonian(t, protons, return_psi=True)
+        pr = np.ascontiguousarray(np.asarray(protons, dtype=np.float32).reshape(-1))
+        el, wp, wl = self._new((B,)), self._new((B,)), self._new((B,))
+        inv = 1.0 / float(global_count if global_count else B)
+        _lib.check(L.wf_vqmc_seeds(self._p(t), B, self.D, pr.ctypes.data if pr.size else None, pr.size, self._p(h), self._p(ps),
+                                   float(running_average), inv, self._p(el), self._p(wp), self._p(wl), self._stream()), "wf_vqmc_seeds")
+        return self.block_sums(el), self.psi_vjp(t, wp, wl)
 
     def block_sums(self, v):
         """fp64 [sum v, sum v^2, count] on the device (deterministic order)."""

@@ -26,6 +26,9 @@ struct NetPlain {
     const float* b1;  // [64]
     const float* W2t; // [D][NBP][64]  (W2 * mask2) transposed and regrouped: row (d, j) = weights of output column j*D+d
     const float* b2;  // [D][NBP]
+    // the same masked weights in the orientation the reverse pass contracts over (wf_kernels_grad.hip)
+    const float* W1n; // [64 in][64 out]   row a = weights out of hidden unit a
+    const float* W2n; // [64 in][D][NBP]   row a = weights out of hidden unit a
 };
 
 // One conditioner net in MFMA operand order (see wf_kernels_mfma.hip)
@@ -111,6 +114,14 @@ struct Protons {
 };
 int launch_energy(const ModelDev& md, const ModelDev* md_dev, const float* tabI4, const float* tabP3, const float* x, int64_t B,
                   const Protons& pr, float* hpsi, float* psi, float* lap, void* stream);
+// reverse pass (wf_kernels_grad.hip)
+int grad_ws_rows(int D);
+int launch_psi_vjp(const ModelDev& md, const ModelDev* md_dev, const float* tabI4, const float* tabP4, const float* fk_nat, const float* x,
+                   int64_t B, const float* w_psi, const float* w_lap, float* ws, int64_t S, float* grad_img, int64_t net_img_floats,
+                   void* stream);
+int launch_grad_scatter(const float* grad_img, const int32_t* map, int64_t n_img, float* grad_flat, void* stream);
+int launch_vqmc_seeds(const float* x, int64_t B, int D, const Protons& pr, const float* hpsi, const float* psi, float running_avg,
+                      float inv_count, float* e_loc, float* w_psi, float* w_lap, void* stream);
 int launch_rqs(const float* x, const float* uw, const float* uh, const float* ud, int64_t N, int K, int n_deriv, int inverse,
                float left, float right, float bottom, float top, float* y, float* ld, int32_t* bin, void* stream);
 int launch_block_sums(const float* v, int64_t B, double* out, void* ws, int64_t ws_bytes, void* stream);

@@ -85,14 +85,19 @@ struct wf_model {
     float* d_fk_nat = nullptr;       // [2][32] natural-order row factors (I layers, prior) for k_prepare_dim0
     void* d_comp = nullptr;          // composite tables [n_nets][n_mesh] float4
     const float* d_tabI4 = nullptr;  // [4][n_mesh][32]: I-spline derivative orders 0..3 (local energy)
-    const float* d_tabP3 = nullptr;  // [3][n_mesh][32]: orthogonal-B derivative orders 0..2
+    const float* d_tabP3 = nullptr;  // [4][n_mesh][32]: orthogonal-B derivative orders 0..3 (the energy uses 0..2)
+    int32_t* d_grad_map = nullptr;   // [n_nets * fwd image floats]: flat parameter index of each forward-image entry, -1 = none
+    float* d_grad_img = nullptr;     // [n_nets * fwd image floats]: gradient accumulator in forward-image layout
 };
 
 namespace wf {
 
-static int64_t plain_net_floats(int D, int nbp) {
+// forward-orientation part of a net's image (W0, b0, W1t, b1, W2t, b2): also the layout of the gradient accumulator
+static int64_t plain_fwd_floats(int D, int nbp) {
     return (int64_t)D * kHidden + kHidden + (int64_t)kHidden * kHidden + kHidden + (int64_t)D * nbp * kHidden + (int64_t)D * nbp;
 }
+// ... followed by W1n, W2n
+static int64_t plain_net_floats(int D, int nbp) { return plain_fwd_floats(D, nbp) + (int64_t)kHidden * kHidden + (int64_t)kHidden * D * nbp; }
 
 static int check_bc(const wf_bc& bc, int nb) {
     if (bc.n < 0 || bc.n > WF_MAX_BC) return WF_ERR_INVALID;
@@ -152,6 +157,7 @@ static int upload_table(wf_model* m, const std::vector<float>& h, const float** 
 }
 
 static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::vector<double>& p64, const std::vector<double>& o2b);
+static int grad_prepare(wf_model* m);
 
 static int model_build(wf_model* m) {
     const wf_model_desc& d = m->desc;
@@ -243,7 +249,7 @@ static int model_build(wf_model* m) {
         md.psp.nb = nb; md.psp.nbp = m->nbp; md.psp.n_mesh = d.n_mesh; md.psp.degree = d.p_degree;
         if (m->nbp == 32) {
             std::vector<float> rows3;
-            pack_rows(ob64, nb, d.n_mesh, 3, 32, rows3);
+            pack_rows(ob64, nb, d.n_mesh, 4, 32, rows3);
             rc = upload_table(m, rows3, &m->d_tabP3);
             if (rc) return rc;
         }
@@ -318,12 +324,16 @@ static int model_build(wf_model* m) {
         np.W1t = p; p += (int64_t)kHidden * kHidden;
         np.b1 = p; p += kHidden;
         np.W2t = p; p += (int64_t)D * m->nbp * kHidden;
-        np.b2 = p;
+        np.b2 = p; p += (int64_t)D * m->nbp;
+        np.W1n = p; p += (int64_t)kHidden * kHidden;
+        np.W2n = p;
     }
     rc = dev_alloc(m, &m->d_dev, 1);
     if (rc) return rc;
     WF_HIP(hipMemcpy(m->d_dev, &md, sizeof(ModelDev), hipMemcpyHostToDevice));
-    return mfma_prepare(m, keep_i64, keep_p64, keep_o2b);
+    rc = mfma_prepare(m, keep_i64, keep_p64, keep_o2b);
+    if (rc) return rc;
+    return grad_prepare(m);
 }
 
 // Re-derives the masked, transposed weight image of net n from the flat parameter vector.
@@ -356,6 +366,16 @@ static void build_plain_image(const wf_model* m, int n, const float* flat, float
             }
     for (int dd = 0; dd < D; ++dd)
         for (int jb = 0; jb < nbp; ++jb) *o++ = jb < nl.n_out ? b2[jb * D + dd] : 0.0f;
+    // reverse-pass orientation: W1 * mask1 [a in][j out], W2 * mask2 [a in][d][jb]
+    for (int a = 0; a < H; ++a)
+        for (int j = 0; j < H; ++j) *o++ = deg_hidden(j, D) >= deg_hidden(a, D) ? W1[(int64_t)a * H + j] : 0.0f;
+    for (int a = 0; a < H; ++a)
+        for (int dd = 0; dd < D; ++dd)
+            for (int jb = 0; jb < nbp; ++jb) {
+                float v = 0.0f;
+                if (jb < nl.n_out && deg_out(dd) >= deg_hidden(a, D)) v = W2[(int64_t)a * NO + (jb * D + dd)];
+                *o++ = v;
+            }
 }
 
 
@@ -597,6 +617,33 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
     return WF_OK;
 }
 
+// The reverse pass (wf_kernels_grad.hip) covers what the local-energy kernel covers, restricted to zero-only constraints.
+static bool grad_capable(const wf_model* m) {
+    const wf_model_desc& d = m->desc;
+    return d.prior_kind == WF_PRIOR_WAVEFLOW && d.layer_kind == WF_LAYER_IMADE && d.n_flow_layers > 0 && m->nbp == 32 && d.n_dim <= 4 &&
+           m->d_tabI4 && m->d_tabP3 && m->d_fk_nat && bc_only_zeroes(d.i_left, d.i_right, true) && bc_only_zeroes(d.p_left, d.p_right, false);
+}
+
+// Index map forward-image entry -> flat parameter: push the code "index + 1" through the image builder; masked and
+// padding entries come out as 0 (no parameter).
+static int grad_prepare(wf_model* m) {
+    if (!grad_capable(m) || m->n_params >= (1 << 24)) return WF_OK;
+    const int D = m->desc.n_dim;
+    const int n_nets = (int)m->nets.size();
+    const int64_t fwd = plain_fwd_floats(D, m->nbp);
+    std::vector<float> code((size_t)m->n_params), img((size_t)plain_net_floats(D, m->nbp));
+    for (int64_t i = 0; i < m->n_params; ++i) code[(size_t)i] = (float)(i + 1);
+    std::vector<int32_t> map((size_t)(fwd * n_nets));
+    for (int n = 0; n < n_nets; ++n) {
+        build_plain_image(m, n, code.data(), img.data());
+        for (int64_t i = 0; i < fwd; ++i) map[(size_t)(fwd * n + i)] = (int32_t)img[(size_t)i] - 1;
+    }
+    int rc = dev_alloc(m, &m->d_grad_map, map.size());
+    if (rc) return rc;
+    WF_HIP(hipMemcpy(m->d_grad_map, map.data(), map.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    return dev_alloc(m, &m->d_grad_img, map.size());
+}
+
 }  // namespace wf
 
 // ------------------------------------------------------------------------------------------ C ABI
@@ -807,6 +854,54 @@ int wf_hamiltonian_fwd(const wf_model* m, const float* x_dev, int64_t B, const f
     DeviceGuard g(m->device);
     if (B == 0) return WF_OK;
     return launch_energy(m->dev, m->d_dev, m->d_tabI4, m->d_tabP3, x_dev, B, pr, hpsi_dev, psi_dev, laplacian_dev, stream);
+}
+
+static int64_t vjp_bytes_per_sample(const wf_model* m) { return (int64_t)m->nets.size() * grad_ws_rows(m->desc.n_dim) * 3 * (int64_t)sizeof(float); }
+
+int64_t wf_psi_vjp_workspace_bytes(const wf_model* m, int64_t B) {
+    if (!m || B < 0) return WF_ERR_INVALID;
+    if (!m->d_grad_map) return WF_ERR_UNSUPPORTED;
+    const int64_t chunk = std::min<int64_t>(std::max<int64_t>(B, 1), 32768);
+    const int64_t S = (chunk * m->desc.n_dim + 63) / 64 * 64;
+    return S * vjp_bytes_per_sample(m);
+}
+
+int wf_psi_vjp(const wf_model* m, const float* x_dev, int64_t B, const float* w_psi_dev, const float* w_lap_dev, float* grad_dev,
+               void* workspace_dev, int64_t workspace_bytes, void* stream) {
+    int rc = check_fwd(m, x_dev, B, grad_dev);
+    if (rc) return rc;
+    if (!grad_dev) return WF_ERR_INVALID;
+    if (!m->d_grad_map) return WF_ERR_UNSUPPORTED;
+    if (B > 0 && (!w_psi_dev || !w_lap_dev || !workspace_dev)) return WF_ERR_INVALID;
+    const int D = m->desc.n_dim;
+    const int64_t S = workspace_bytes / vjp_bytes_per_sample(m) / 64 * 64;   // samples per chunk
+    const int64_t chunk = S / D;
+    if (B > 0 && chunk < 1) return WF_ERR_INVALID;
+    DeviceGuard g(m->device);
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t fwd = plain_fwd_floats(D, m->nbp);
+    const int64_t n_img = fwd * (int64_t)m->nets.size();
+    WF_HIP(hipMemsetAsync(m->d_grad_img, 0, (size_t)n_img * sizeof(float), s));
+    WF_HIP(hipMemsetAsync(grad_dev, 0, (size_t)m->n_params * sizeof(float), s));
+    for (int64_t c0 = 0; c0 < B; c0 += chunk) {
+        const int64_t bc = std::min(chunk, B - c0);
+        rc = launch_psi_vjp(m->dev, m->d_dev, m->d_tabI4, m->d_tabP3, m->d_fk_nat, x_dev + c0 * D, bc, w_psi_dev + c0, w_lap_dev + c0,
+                            (float*)workspace_dev, S, m->d_grad_img, fwd, stream);
+        if (rc) return rc;
+    }
+    return launch_grad_scatter(m->d_grad_img, m->d_grad_map, n_img, grad_dev, stream);
+}
+
+int wf_vqmc_seeds(const float* x_dev, int64_t B, int32_t n_dim, const float* protons_host, int32_t n_protons, const float* hpsi_dev,
+                  const float* psi_dev, float running_average, float inv_count, float* e_loc_dev, float* w_psi_dev, float* w_lap_dev,
+                  void* stream) {
+    if (B < 0 || n_dim < 1 || n_dim > WF_MAX_DIM || n_protons < 0 || n_protons > 8 || (n_protons > 0 && !protons_host)) return WF_ERR_INVALID;
+    if (B > 0 && (!x_dev || !hpsi_dev || !psi_dev || !e_loc_dev || !w_psi_dev || !w_lap_dev)) return WF_ERR_INVALID;
+    if (B == 0) return WF_OK;
+    Protons pr{};
+    pr.n = n_protons;
+    for (int i = 0; i < n_protons; ++i) pr.pos[i] = protons_host[i];
+    return launch_vqmc_seeds(x_dev, B, n_dim, pr, hpsi_dev, psi_dev, running_average, inv_count, e_loc_dev, w_psi_dev, w_lap_dev, stream);
 }
 
 int wf_rqs_fwd(const float* x_dev, const float* uw_dev, const float* uh_dev, const float* ud_dev, int64_t N, int32_t K, int32_t n_deriv,
