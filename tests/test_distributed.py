@@ -84,3 +84,56 @@ def test_two_rank_expectation_matches_single_rank(world):
 def test_all_reduce_is_noop_without_group():
     s = torch.tensor([1.0, 2.0, 3.0], dtype=torch.float64)
     assert wfd.all_reduce_moments(s).tolist() == [1.0, 2.0, 3.0]
+
+
+def _grad_worker(rank, world, port, n_params, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # ragged shards: rank r holds 100 + 7 r walkers; its gradient is already scaled by 1 / global count
+        n_local = 100 + 7 * rank
+        n_global = wfd.global_count(n_local, "cpu")
+        g = np.random.default_rng(50 + rank)
+        grad = torch.tensor(g.normal(size=n_params).astype(np.float32) / n_global)
+        e = g.normal(-2.0, 1.0, size=n_local)
+        sums = torch.tensor([e.sum(), (e ** 2).sum(), float(n_local)], dtype=torch.float64)
+        grad2, sums2 = wfd.all_reduce_gradient_and_moments(grad, sums)
+        q.put((rank, n_global, grad2.numpy(), sums2.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_training_step_collective_packs_gradient_and_moments():
+    """the training step's one all-reduce carries [gradient, sum E, sum E^2, n]."""
+    world, n_params = 2, 32588
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, n_params, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n_global = sum(100 + 7 * r for r in range(world))
+    want_g = np.zeros(n_params)
+    want_s = np.zeros(3)
+    for r in range(world):
+        g = np.random.default_rng(50 + r)
+        want_g += (g.normal(size=n_params).astype(np.float32) / n_global).astype(np.float64)
+        e = g.normal(-2.0, 1.0, size=100 + 7 * r)
+        want_s += [e.sum(), (e ** 2).sum(), e.size]
+    for rank, ng, grad, sums in res:
+        assert ng == n_global and grad.dtype == np.float32 and grad.shape == (n_params,)
+        np.testing.assert_allclose(grad, want_g, rtol=0, atol=1e-7)
+        np.testing.assert_allclose(sums, want_s, rtol=1e-12)
+    assert np.array_equal(res[0][2], res[1][2])
+
+
+def test_gradient_collective_is_noop_without_group():
+    g, s = torch.ones(5), torch.tensor([1.0, 2.0, 3.0], dtype=torch.float64)
+    g2, s2 = wfd.all_reduce_gradient_and_moments(g, s)
+    assert g2 is g and s2 is s and wfd.global_count(17, "cpu") == 17

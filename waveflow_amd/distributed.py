@@ -3,7 +3,8 @@
 The hot path is embarrassingly parallel over walkers: each rank evaluates a contiguous block of rows with its own
 replica of the (tiny) model, and the only cross-rank step is the batch expectation of vqmc.py:196 -- one all-reduce
 of three fp64 numbers [sum v, sum v^2, n] per step (24 B: latency-bound on xGMI, so a single in-place all-reduce
-on the compute stream, no bucketing).  Walker coordinates never move between GPUs.
+on the compute stream, no bucketing); a training step appends the flat gradient to that same buffer (~260 KB as fp64).
+Walker coordinates never move between GPUs.
 """
 import math
 
@@ -24,6 +25,29 @@ def all_reduce_moments(sums, group=None):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
     return sums
+
+
+def all_reduce_gradient_and_moments(grad, sums, group=None):
+    """The training step's single collective: the flat gradient (already scaled by 1 / global batch) and the fp64
+    triple travel in ONE packed fp64 buffer [gradient, sum, sum of squares, n].  -> (gradient float32, sums fp64)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return grad, sums
+    packed = torch.cat([grad.double().reshape(-1), sums.double().reshape(-1)])
+    dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+    return packed[:-3].float(), packed[-3:]
+
+
+def global_count(n_local, device, group=None):
+    """Total walkers over the ranks of `group` (shards may be ragged)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return int(n_local)
+    cnt = torch.tensor([int(n_local)], dtype=torch.int64, device=device)
+    dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
+    return int(cnt.item())
 
 
 def moments_to_stats(sums):

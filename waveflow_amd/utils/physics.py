@@ -35,4 +35,5 @@ def construct_hamiltonian_function(fn, protons=np.array([[0, 0]]), n_space_dimen
         return h[:, None]
 
     h_fn.model = model
+    h_fn.protons = pos
     return h_fn
