@@ -186,6 +186,14 @@ int64_t wf_psi_vjp_workspace_bytes(const wf_model* m, int64_t B);
 int wf_psi_vjp(const wf_model* m, const float* x_dev, int64_t B, const float* w_psi_dev, const float* w_lap_dev, float* grad_dev,
                void* workspace_dev, int64_t workspace_bytes, void* stream);
 
+/* Parameter gradient of the log-density: grad_dev[p] = sum_b w_dev[b] * d log_pdf_b / d theta_p for every model wf_logpdf_fwd
+ * evaluates with <= 32 bases, D <= 4 and zero-only constraints (IMADE or MADE layers; Waveflow, M-spline, Normal or Uniform
+ * prior).  With w = -1/B this is the gradient of benchmark_tests.loss (benchmark_tests.py:84-87, 98-101); with per-walker
+ * weights it is the jacrev(log_pdf) contraction of vqmc.train_step (vqmc.py:175-180). */
+int64_t wf_logpdf_vjp_workspace_bytes(const wf_model* m, int64_t B);
+int wf_logpdf_vjp(const wf_model* m, const float* x_dev, int64_t B, const float* w_dev, float* grad_dev, void* workspace_dev,
+                  int64_t workspace_bytes, void* stream);
+
 /* Per-walker weights of loss_fn_efficient's tangent rule (vqmc.py:198-212) for wf_psi_vjp, from wf_hamiltonian_fwd's outputs:
  *     e_loc = hpsi / (psi + 1e-8);   d loss = [2 (e_loc - running_average)/psi - hpsi/psi^2] d psi + (1/psi) d hpsi,
  *     d hpsi = -1/2 d laplacian + V d psi   =>   w_psi = (... + V/psi) * inv_count,  w_lap = -1/(2 psi) * inv_count

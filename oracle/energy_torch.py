@@ -86,6 +86,13 @@ class TorchWaveflow:
         return p / p.sum(-1, keepdim=True)
 
     def psi(self, flat, x):
+        return self._eval(flat, x, False)
+
+    def log_pdf(self, flat, x):
+        """wavefunctions.py:33-52: sum_d log(psi_d^2 [/ 2 on constrained dimensions] + 1e-7) + log det"""
+        return self._eval(flat, x, True)
+
+    def _eval(self, flat, x, want_log_pdf):
         dt = self.dtype
         p = flat.to(dt) if torch.is_tensor(flat) else torch.as_tensor(np.asarray(flat, dtype=np.float32)).to(dt)
         D, L, tol, k = self.D, self.L, 1e-7, self.k
@@ -142,6 +149,8 @@ class TorchWaveflow:
         scale = torch.ones(D, dtype=dt)
         for d in self.constr_left:
             scale[d] = 1 / np.sqrt(2.0)
+        if want_log_pdf:
+            return torch.log(ps ** 2 * scale ** 2 + 1e-7).sum(-1) + ld
         return (ps * scale).prod(-1) * torch.exp(0.5 * ld)
 
 
@@ -188,6 +197,14 @@ def psi_vjp(model, flat, x, w_psi, w_lap):
     ps, lap = _psi_lap(model, p, x)
     F = (torch.as_tensor(np.asarray(w_psi), dtype=model.dtype) * ps).sum() + (torch.as_tensor(np.asarray(w_lap), dtype=model.dtype) * lap).sum()
     (g,) = torch.autograd.grad(F, p)
+    return g.detach().numpy()
+
+
+def logpdf_vjp(model, flat, x, w):
+    """d/dparams sum_b w[b] log_pdf_b -> flat gradient [n_params] (fp64)."""
+    p = torch.as_tensor(np.asarray(flat, dtype=np.float32)).to(model.dtype).clone().requires_grad_(True)
+    xt = torch.as_tensor(np.asarray(x), dtype=model.dtype)
+    (g,) = torch.autograd.grad((torch.as_tensor(np.asarray(w), dtype=model.dtype) * model.log_pdf(p, xt)).sum(), p)
     return g.detach().numpy()
 
 

@@ -123,3 +123,71 @@ def test_loss_fn_efficient_value_matches_sums(he_flat):
     assert abs(lv - loss) < 1e-2 * max(1.0, abs(lv)), (lv, loss)
     assert abs(mean - loss) < 1e-12
     assert grad.shape == (he_flat.size,) and np.isfinite(grad).all()
+
+
+def test_logpdf_vjp_waveflow_vs_autograd_oracle(golden, he_flat):
+    import torch
+    from oracle import energy_torch as et
+    params, psi, log_pdf, sample = he(he_flat)
+    m = log_pdf.model
+    m.ensure_params(params)
+    x = np.concatenate([np.sort(golden["he_golden"]["sample_points"], -1)[:96], sorted_walkers(32, 2, 8.0, 6)]).astype(np.float32)
+    w = np.random.default_rng(4).normal(size=128).astype(np.float32)
+    got = m.logpdf_vjp(x, w).cpu().numpy().astype(np.float64)
+    want = et.logpdf_vjp(et.he_model(torch.float64), he_flat, x.astype(np.float64), w)
+    assert ((want == 0) <= (np.abs(got) <= 1e-12)).all()
+    assert rel_l2(got, want) < 1e-3, rel_l2(got, want)
+
+
+def _directional_check(log_pdf, params, om, X, seed, n_dirs=6, tol=2e-3):
+    """sum_b w_b log_pdf_b along random parameter directions: HIP gradient . d vs central differences of the fp64 C oracle."""
+    from waveflow_amd import flatten_params
+    m = log_pdf.model
+    m.ensure_params(params)
+    flat = flatten_params(params)
+    g = np.random.default_rng(seed)
+    w = g.normal(size=X.shape[0]).astype(np.float32)
+    grad = m.logpdf_vjp(X, w).cpu().numpy().astype(np.float64)
+    assert grad.shape == flat.shape and np.isfinite(grad).all() and np.abs(grad).max() > 0
+    F = lambda f: float((w.astype(np.float64) * om.log_pdf(f.astype(np.float32), X, f64=True)).sum())
+    worst = 0.0
+    for i in range(n_dirs):
+        # random directions, and directions confined to one leaf block so that every weight group is probed
+        d = g.normal(size=flat.size)
+        if i >= 2:
+            lo = g.integers(0, flat.size - 64)
+            mask = np.zeros(flat.size)
+            mask[lo:lo + g.integers(16, 4096)] = 1
+            d = d * mask
+        d = (d / np.linalg.norm(d)).astype(np.float32)
+        eps = 2e-3
+        fd = (F(flat + eps * d) - F(flat - eps * d)) / (2 * eps)
+        an = float(grad @ d.astype(np.float64))
+        scale = max(abs(fd), 1e-2 * np.linalg.norm(grad) / np.sqrt(flat.size) * 10, 1e-6)
+        worst = max(worst, abs(fd - an) / scale)
+        assert abs(fd - an) <= tol * scale + 1e-4 * np.linalg.norm(grad), (i, fd, an)
+    return worst
+
+
+def test_logpdf_vjp_benchmark_models_vs_fp64_finite_differences():
+    """benchmark_tests.get_model's three families (benchmark_tests.py:50-79): MFlow, IFlow, Flow."""
+    import os
+    import oracle
+    from conftest import GOLDEN
+    from waveflow_amd import flows, model_factory
+    X = np.load(os.path.join(GOLDEN, "circles_x256.npy")).astype(np.float32)[:128]
+    mt = model_factory.get_masked_transform
+    init = flows.MFlow(flows.Serial(*(flows.IMADE(mt(), spline_degree=5, n_internal_knots=15, spline_regularization=0.01,
+                                                  reverse_fun_tol=1e-6), flows.Reverse()) * 3), mt(), spline_degree=3, n_internal_knots=15)
+    params, log_pdf, _ = init(0, 2)
+    om = oracle.Model(D=2, n_layers=3, i_k=5, i_knots=15, i_reg=0.01, prior="mflow", p_k=3, p_knots=15)
+    _directional_check(log_pdf, params, om, X, 1)
+    init = flows.Flow(flows.Serial(*(flows.IMADE(mt(), spline_degree=5, n_internal_knots=15, spline_regularization=0.1,
+                                                 reverse_fun_tol=1e-6), flows.Reverse()) * 2), flows.Uniform(), prior_support=(0.0, 1.0))
+    params, log_pdf, _ = init(2, 2)
+    om = oracle.Model(D=2, n_layers=2, i_k=5, i_knots=15, i_reg=0.1, prior="uniform")
+    _directional_check(log_pdf, params, om, X, 2)
+    init = flows.Flow(flows.Serial(*(flows.MADE(mt(return_simple_masked_transform=True)), flows.Reverse()) * 3), flows.Normal(-0.5))
+    params, log_pdf, _ = init(3, 2)
+    om = oracle.Model(D=2, n_layers=3, layer_kind="made", prior="normal", normal_offset=-0.5)
+    _directional_check(log_pdf, params, om, X, 3)

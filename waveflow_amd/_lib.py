@@ -55,7 +55,8 @@ EXPORTS = ["wf_abi_version", "wf_strerror", "wf_last_hip_error", "wf_last_hip_er
            "wf_tables_build", "wf_model_create", "wf_model_destroy", "wf_model_param_count", "wf_model_n_bases",
            "wf_model_set_params", "wf_model_set_kernel", "wf_logpdf_fwd", "wf_psi_fwd", "wf_flow_fwd", "wf_layer_fwd",
            "wf_block_sums", "wf_block_sums_workspace_bytes", "wf_rqs_fwd", "wf_inverse_fwd", "wf_sample", "wf_hamiltonian_fwd",
-           "wf_psi_vjp", "wf_psi_vjp_workspace_bytes", "wf_vqmc_seeds"]
+           "wf_psi_vjp", "wf_psi_vjp_workspace_bytes", "wf_vqmc_seeds",
+           "wf_logpdf_vjp", "wf_logpdf_vjp_workspace_bytes"]
 
 _lib = None
 
@@ -110,6 +111,10 @@ def lib():
     L.wf_psi_vjp_workspace_bytes.argtypes = [vp, i64]
     L.wf_psi_vjp.restype = i32
     L.wf_psi_vjp.argtypes = [vp, vp, i64, vp, vp, vp, vp, i64, vp]
+    L.wf_logpdf_vjp_workspace_bytes.restype = i64
+    L.wf_logpdf_vjp_workspace_bytes.argtypes = [vp, i64]
+    L.wf_logpdf_vjp.restype = i32
+    L.wf_logpdf_vjp.argtypes = [vp, vp, i64, vp, vp, vp, i64, vp]
     L.wf_vqmc_seeds.restype = i32
     L.wf_vqmc_seeds.argtypes = [vp, i64, i32, vp, i32, vp, vp, ctypes.c_float, ctypes.c_float, vp, vp, vp, vp]
     L.wf_rqs_fwd.restype = i32

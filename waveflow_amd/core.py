@@ -213,6 +213,23 @@ class DeviceModel:
                                 self._vjp_ws.numel(), self._stream()), "wf_psi_vjp")
         return grad
 
+    def logpdf_vjp(self, x, w):
+        """grad[p] = sum_b w[b] d log_pdf_b / d theta_p -> torch.cuda float32 [n_params]."""
+        torch = _torch()
+        L = _lib.lib()
+        t, _ = self._to_dev(x)
+        B = t.shape[0]
+        wt = torch.as_tensor(w, dtype=torch.float32).to(t.device).contiguous()
+        if wt.numel() != B:
+            raise ValueError("w must have one entry per row of x")
+        nbytes = _lib.check(L.wf_logpdf_vjp_workspace_bytes(self._h, B), "wf_logpdf_vjp_workspace_bytes")
+        if self._vjp_ws is None or self._vjp_ws.numel() < nbytes:
+            self._vjp_ws = torch.empty(int(nbytes), device=t.device, dtype=torch.uint8)
+        grad = self._new((self.n_params,))
+        _lib.check(L.wf_logpdf_vjp(self._h, self._p(t), B, self._p(wt), self._p(grad), self._p(self._vjp_ws), self._vjp_ws.numel(),
+                                   self._stream()), "wf_logpdf_vjp")
+        return grad
+
     def vqmc_loss_grad(self, x, protons, running_average, global_count=None):
         """loss_fn_efficient and its gradient (vqmc.py:193-221) for the walkers x on this device.
         -> (sums fp64 [sum E_L, sum E_L^2, count] (torch.cuda), grad float32 [n_params] scaled by 1/global_count)."""

@@ -116,9 +116,9 @@ int launch_energy(const ModelDev& md, const ModelDev* md_dev, const float* tabI4
                   const Protons& pr, float* hpsi, float* psi, float* lap, void* stream);
 // reverse pass (wf_kernels_grad.hip)
 int grad_ws_rows(int D);
-int launch_psi_vjp(const ModelDev& md, const ModelDev* md_dev, const float* tabI4, const float* tabP4, const float* fk_nat, const float* x,
-                   int64_t B, const float* w_psi, const float* w_lap, float* ws, int64_t S, float* grad_img, int64_t net_img_floats,
-                   void* stream);
+int launch_vjp(const ModelDev& md, const ModelDev* md_dev, int mode, int second_order, const float* tabI4, const float* tabP4, const float* fk_nat,
+               const float* x, int64_t B, const float* w1, const float* w2, float* ws, int64_t S, float* grad_img, int64_t net_img_floats,
+               void* stream);
 int launch_grad_scatter(const float* grad_img, const int32_t* map, int64_t n_img, float* grad_flat, void* stream);
 int launch_vqmc_seeds(const float* x, int64_t B, int D, const Protons& pr, const float* hpsi, const float* psi, float running_avg,
                       float inv_count, float* e_loc, float* w_psi, float* w_lap, void* stream);

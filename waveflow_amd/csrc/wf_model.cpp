@@ -86,6 +86,8 @@ struct wf_model {
     void* d_comp = nullptr;          // composite tables [n_nets][n_mesh] float4
     const float* d_tabI4 = nullptr;  // [4][n_mesh][32]: I-spline derivative orders 0..3 (local energy)
     const float* d_tabP3 = nullptr;  // [4][n_mesh][32]: orthogonal-B derivative orders 0..3 (the energy uses 0..2)
+    float* d_grad_fk = nullptr;      // [2][64] natural-order row factors for the reverse pass (flow rows, prior rows)
+    bool grad_psi_ok = false;        // wf_psi_vjp (Waveflow prior, IMADE layers)
     int32_t* d_grad_map = nullptr;   // [n_nets * fwd image floats]: flat parameter index of each forward-image entry, -1 = none
     float* d_grad_img = nullptr;     // [n_nets * fwd image floats]: gradient accumulator in forward-image layout
 };
@@ -283,6 +285,12 @@ static int model_build(wf_model* m) {
         rc = upload_table(m, rows, &md.psp.tab);
         if (rc) return rc;
         md.psp.nb = nb; md.psp.nbp = m->nbp; md.psp.n_mesh = d.n_mesh; md.psp.degree = d.p_degree;
+        if (m->nbp == 32) {
+            std::vector<float> rows4;
+            pack_rows(t64, nb, d.n_mesh, 4, 32, rows4);
+            rc = upload_table(m, rows4, &m->d_tabP3);
+            if (rc) return rc;
+        }
         fill_bc(md.psp, d.p_left, d.p_right, t64, nb, d.n_mesh);
         m->p_nb = nb;
         keep_p64.swap(t64);
@@ -617,18 +625,34 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
     return WF_OK;
 }
 
-// The reverse pass (wf_kernels_grad.hip) covers what the local-energy kernel covers, restricted to zero-only constraints.
+// The reverse pass (wf_kernels_grad.hip): <= 32 bases, D <= 4, constraints that only zero the end weights.
 static bool grad_capable(const wf_model* m) {
     const wf_model_desc& d = m->desc;
-    return d.prior_kind == WF_PRIOR_WAVEFLOW && d.layer_kind == WF_LAYER_IMADE && d.n_flow_layers > 0 && m->nbp == 32 && d.n_dim <= 4 &&
-           m->d_tabI4 && m->d_tabP3 && m->d_fk_nat && bc_only_zeroes(d.i_left, d.i_right, true) && bc_only_zeroes(d.p_left, d.p_right, false);
+    if (m->nbp != 32 || d.n_dim > 4 || m->nets.empty()) return false;
+    const bool imade = d.layer_kind == WF_LAYER_IMADE && d.n_flow_layers > 0;
+    if (imade && (!m->d_tabI4 || !bc_only_zeroes(d.i_left, d.i_right, true))) return false;
+    const bool spline_prior = d.prior_kind == WF_PRIOR_WAVEFLOW || d.prior_kind == WF_PRIOR_MFLOW;
+    if (spline_prior && (!m->d_tabP3 || !bc_only_zeroes(d.p_left, d.p_right, false))) return false;
+    return true;
 }
 
 // Index map forward-image entry -> flat parameter: push the code "index + 1" through the image builder; masked and
 // padding entries come out as 0 (no parameter).
 static int grad_prepare(wf_model* m) {
     if (!grad_capable(m) || m->n_params >= (1 << 24)) return WF_OK;
-    const int D = m->desc.n_dim;
+    const wf_model_desc& d = m->desc;
+    const int D = d.n_dim;
+    {
+        std::vector<float> fk(128, 0.0f), acc(64);
+        if (d.layer_kind == WF_LAYER_IMADE && d.n_flow_layers > 0)
+            row_factors(WF_SPLINE_I, true, d.i_degree, m->i_nb, 1, d.i_left, d.i_right, acc.data(), fk.data());
+        if (d.prior_kind == WF_PRIOR_WAVEFLOW) row_factors(WF_SPLINE_B, false, d.p_degree, m->p_nb, 1, d.p_left, d.p_right, acc.data(), fk.data() + 64);
+        if (d.prior_kind == WF_PRIOR_MFLOW) row_factors(WF_SPLINE_M, true, d.p_degree, m->p_nb, 1, d.p_left, d.p_right, acc.data(), fk.data() + 64);
+        int rc = dev_alloc(m, &m->d_grad_fk, fk.size());
+        if (rc) return rc;
+        WF_HIP(hipMemcpy(m->d_grad_fk, fk.data(), fk.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    m->grad_psi_ok = d.prior_kind == WF_PRIOR_WAVEFLOW && d.layer_kind == WF_LAYER_IMADE && d.n_flow_layers > 0;
     const int n_nets = (int)m->nets.size();
     const int64_t fwd = plain_fwd_floats(D, m->nbp);
     std::vector<float> code((size_t)m->n_params), img((size_t)plain_net_floats(D, m->nbp));
@@ -856,26 +880,24 @@ int wf_hamiltonian_fwd(const wf_model* m, const float* x_dev, int64_t B, const f
     return launch_energy(m->dev, m->d_dev, m->d_tabI4, m->d_tabP3, x_dev, B, pr, hpsi_dev, psi_dev, laplacian_dev, stream);
 }
 
-static int64_t vjp_bytes_per_sample(const wf_model* m) { return (int64_t)m->nets.size() * grad_ws_rows(m->desc.n_dim) * 3 * (int64_t)sizeof(float); }
-
-int64_t wf_psi_vjp_workspace_bytes(const wf_model* m, int64_t B) {
-    if (!m || B < 0) return WF_ERR_INVALID;
-    if (!m->d_grad_map) return WF_ERR_UNSUPPORTED;
-    const int64_t chunk = std::min<int64_t>(std::max<int64_t>(B, 1), 32768);
-    const int64_t S = (chunk * m->desc.n_dim + 63) / 64 * 64;
-    return S * vjp_bytes_per_sample(m);
+static int64_t vjp_bytes_per_sample(const wf_model* m, int nc) {
+    return (int64_t)m->nets.size() * grad_ws_rows(m->desc.n_dim) * nc * (int64_t)sizeof(float);
 }
 
-int wf_psi_vjp(const wf_model* m, const float* x_dev, int64_t B, const float* w_psi_dev, const float* w_lap_dev, float* grad_dev,
-               void* workspace_dev, int64_t workspace_bytes, void* stream) {
-    int rc = check_fwd(m, x_dev, B, grad_dev);
-    if (rc) return rc;
-    if (!grad_dev) return WF_ERR_INVALID;
-    if (!m->d_grad_map) return WF_ERR_UNSUPPORTED;
-    if (B > 0 && (!w_psi_dev || !w_lap_dev || !workspace_dev)) return WF_ERR_INVALID;
+static int64_t vjp_ws_bytes(const wf_model* m, int64_t B, bool second_order) {
+    if (!m || B < 0) return WF_ERR_INVALID;
+    if (!m->d_grad_map || (second_order && !m->grad_psi_ok)) return WF_ERR_UNSUPPORTED;
+    const int64_t chunk = std::min<int64_t>(std::max<int64_t>(B, 1), 32768);
+    const int64_t S = (chunk * (second_order ? m->desc.n_dim : 1) + 63) / 64 * 64;
+    return S * vjp_bytes_per_sample(m, second_order ? 3 : 1);
+}
+
+// mode 0: log_pdf, w1 only;  mode 1: psi (w1) and, with second_order, its Laplacian (w2)
+static int run_vjp_chunks(const wf_model* m, int mode, bool second_order, const float* x_dev, int64_t B, const float* w1, const float* w2,
+                          float* grad_dev, void* workspace_dev, int64_t workspace_bytes, void* stream) {
     const int D = m->desc.n_dim;
-    const int64_t S = workspace_bytes / vjp_bytes_per_sample(m) / 64 * 64;   // samples per chunk
-    const int64_t chunk = S / D;
+    const int64_t S = workspace_bytes / vjp_bytes_per_sample(m, second_order ? 3 : 1) / 64 * 64;   // samples per chunk
+    const int64_t chunk = S / (second_order ? D : 1);
     if (B > 0 && chunk < 1) return WF_ERR_INVALID;
     DeviceGuard g(m->device);
     hipStream_t s = (hipStream_t)stream;
@@ -885,11 +907,34 @@ int wf_psi_vjp(const wf_model* m, const float* x_dev, int64_t B, const float* w_
     WF_HIP(hipMemsetAsync(grad_dev, 0, (size_t)m->n_params * sizeof(float), s));
     for (int64_t c0 = 0; c0 < B; c0 += chunk) {
         const int64_t bc = std::min(chunk, B - c0);
-        rc = launch_psi_vjp(m->dev, m->d_dev, m->d_tabI4, m->d_tabP3, m->d_fk_nat, x_dev + c0 * D, bc, w_psi_dev + c0, w_lap_dev + c0,
-                            (float*)workspace_dev, S, m->d_grad_img, fwd, stream);
+        int rc = launch_vjp(m->dev, m->d_dev, mode, second_order ? 1 : 0, m->d_tabI4, m->d_tabP3, m->d_grad_fk, x_dev + c0 * D, bc, w1 + c0,
+                            w2 ? w2 + c0 : nullptr, (float*)workspace_dev, S, m->d_grad_img, fwd, stream);
         if (rc) return rc;
     }
     return launch_grad_scatter(m->d_grad_img, m->d_grad_map, n_img, grad_dev, stream);
+}
+
+int64_t wf_psi_vjp_workspace_bytes(const wf_model* m, int64_t B) { return vjp_ws_bytes(m, B, true); }
+int64_t wf_logpdf_vjp_workspace_bytes(const wf_model* m, int64_t B) { return vjp_ws_bytes(m, B, false); }
+
+int wf_psi_vjp(const wf_model* m, const float* x_dev, int64_t B, const float* w_psi_dev, const float* w_lap_dev, float* grad_dev,
+               void* workspace_dev, int64_t workspace_bytes, void* stream) {
+    int rc = check_fwd(m, x_dev, B, grad_dev);
+    if (rc) return rc;
+    if (!grad_dev) return WF_ERR_INVALID;
+    if (!m->d_grad_map || !m->grad_psi_ok) return WF_ERR_UNSUPPORTED;
+    if (B > 0 && (!w_psi_dev || !w_lap_dev || !workspace_dev)) return WF_ERR_INVALID;
+    return run_vjp_chunks(m, 1, true, x_dev, B, w_psi_dev, w_lap_dev, grad_dev, workspace_dev, workspace_bytes, stream);
+}
+
+int wf_logpdf_vjp(const wf_model* m, const float* x_dev, int64_t B, const float* w_dev, float* grad_dev, void* workspace_dev,
+                  int64_t workspace_bytes, void* stream) {
+    int rc = check_fwd(m, x_dev, B, grad_dev);
+    if (rc) return rc;
+    if (!grad_dev) return WF_ERR_INVALID;
+    if (!m->d_grad_map) return WF_ERR_UNSUPPORTED;
+    if (B > 0 && (!w_dev || !workspace_dev)) return WF_ERR_INVALID;
+    return run_vjp_chunks(m, 0, false, x_dev, B, w_dev, nullptr, grad_dev, workspace_dev, workspace_bytes, stream);
 }
 
 int wf_vqmc_seeds(const float* x_dev, int64_t B, int32_t n_dim, const float* protons_host, int32_t n_protons, const float* hpsi_dev,
