@@ -191,3 +191,22 @@ def test_logpdf_vjp_benchmark_models_vs_fp64_finite_differences():
     params, log_pdf, _ = init(3, 2)
     om = oracle.Model(D=2, n_layers=3, layer_kind="made", prior="normal", normal_offset=-0.5)
     _directional_check(log_pdf, params, om, X, 3)
+
+
+@pytest.mark.parametrize("model_type", ["Flow", "IFlow", "MFlow"])
+def test_benchmark_training_lowers_the_negative_log_likelihood(tmp_path, model_type):
+    """benchmark_tests.train_model on the committed 256 circles points: loss falls, artefacts follow helpers.py:176-214."""
+    import os
+    from conftest import GOLDEN
+    from waveflow_amd import benchmark_tests
+    X = np.load(os.path.join(GOLDEN, "circles_x256.npy")).astype(np.float32)
+    params, losses = benchmark_tests.train_model(X, 120, 500, model_type=model_type, dataset_name="circles", check_step=60,
+                                                 spline_reg=0.01, save_dir=str(tmp_path), ngrid=40, num_flow_layer=2, spline_degree=5,
+                                                 num_knots=15, step_size=2e-3, verbose=False)
+    assert len(losses) == 121 and np.isfinite(losses).all()
+    assert losses[-1] < losses[0] - 0.05, (losses[0], losses[-1])
+    run = [p for p in (tmp_path / "circles").iterdir()][0]
+    assert np.load(run / "outputs" / "pdf_grid_epoch60.npy").shape == (40, 40)
+    assert np.load(run / "outputs" / "samples_epoch120.npy").shape == (500, 2)
+    assert len(np.loadtxt(run / "kl_divergences.txt")) == 3 and len(np.loadtxt(run / "losses.txt")) >= 120
+    assert (run / "system_info.json").exists()

@@ -70,3 +70,37 @@ def create_checkpoint_wavefunc(rng, save_dir, psi, sample, params, epoch, loss, 
     np.save(f"{one}/onproton_coord_epoch{epoch}.npy", xp)
 
     np.save(f"{save_dir}/outputs/sample_points/values_epoch{epoch}.npy", _np(sample(rng, params, nsample)).astype(np.float32))
+
+
+def make_checkpoint_benchmark(split_rng, params, log_pdf, sample, losses, kde_kl_divergences, kde_hellinger_distances,
+                              reconstruction_distances, n_model_sample=5000, save_dir='./results/benchmarks/', epoch=0, ngrid=300):
+    """helpers.py:170-214: pdf on the [0,1]^2 grid, model samples, their Gaussian KDE (bandwidth 0.01), the KL / Hellinger
+    figures between the two grids and the sample -> latent -> sample reconstruction distance; same file names."""
+    from sklearn.neighbors import KernelDensity
+    output_dir = f"{save_dir}/outputs/"
+    Path(output_dir).mkdir(parents=True, exist_ok=True)
+    x = np.linspace(0.0, 1.0, ngrid)
+    xv, yv = np.meshgrid(x, x)
+    grid = np.stack([xv.reshape(-1), yv.reshape(-1)], axis=-1).astype(np.float32)
+    log_pdf_grid = _np(log_pdf(params, grid)).astype(np.float64).reshape(ngrid, ngrid)
+    pdf_grid = np.exp(log_pdf_grid)
+    np.save(f"{output_dir}/pdf_grid_epoch{epoch}.npy", pdf_grid)
+
+    model_samples, original_samples = sample(split_rng, params, num_samples=n_model_sample, return_original_samples=True)
+    model_samples, original_samples = _np(model_samples), _np(original_samples)
+    np.save(f"{output_dir}/samples_epoch{epoch}.npy", model_samples)
+
+    kde = KernelDensity(kernel='gaussian', bandwidth=0.01, rtol=0.1).fit(model_samples)
+    log_pdf_grid_kde = kde.score_samples(grid).reshape(ngrid, ngrid)
+    pdf_grid_kde = np.exp(log_pdf_grid_kde)
+    np.save(f"{output_dir}/kde_pdf_grid_epoch{epoch}.npy", pdf_grid_kde)
+    kde_kl_divergences.append(float((pdf_grid * (log_pdf_grid - log_pdf_grid_kde)).mean()))
+    kde_hellinger_distances.append(float(((np.sqrt(pdf_grid) - np.sqrt(pdf_grid_kde)) ** 2).mean()))
+
+    _, reconstructed = log_pdf(params, model_samples, return_sample=True)
+    reconstruction_distances.append(float(np.linalg.norm(original_samples - _np(reconstructed), axis=-1).mean()))
+
+    np.savetxt(f'{save_dir}/losses.txt', np.asarray(losses, dtype=np.float64))
+    np.savetxt(f'{save_dir}/kl_divergences.txt', kde_kl_divergences)
+    np.savetxt(f'{save_dir}/hellinger_divergences.txt', kde_hellinger_distances)
+    np.savetxt(f'{save_dir}/reconstruction_distances.txt', reconstruction_distances)
