@@ -210,3 +210,28 @@ def test_benchmark_training_lowers_the_negative_log_likelihood(tmp_path, model_t
     assert np.load(run / "outputs" / "samples_epoch120.npy").shape == (500, 2)
     assert len(np.loadtxt(run / "kl_divergences.txt")) == 3 and len(np.loadtxt(run / "losses.txt")) >= 120
     assert (run / "system_info.json").exists()
+
+
+@pytest.mark.parametrize("D,box,layers,k,kn,B", [(3, "first", 2, 4, 13, 37), (4, "mean", 1, 5, 16, 65), (2, "first", 1, 3, 10, 1)])
+def test_gradients_other_shapes_vs_autograd_oracle(D, box, layers, k, kn, B):
+    """D = 3, 4, both box transforms, ragged batches: psi / Laplacian / log_pdf gradients vs torch (fp64)."""
+    import torch
+    from oracle import energy_torch as et
+    from waveflow_amd import flatten_params, model_factory
+    init_fun = model_factory.get_waveflow_model(D, base_spline_degree=k, i_spline_degree=k, n_prior_internal_knots=kn, n_i_internal_knots=kn,
+                                                i_spline_reg=0.05, n_flow_layers=layers, box_size=5.0, xu_coord_type=box)
+    params, psi, log_pdf, sample = init_fun(7, D)
+    m = psi.model
+    m.ensure_params(params)
+    flat = flatten_params(params)
+    constr = tuple(range(0, D - 1)) if box == "mean" else tuple(range(1, D))
+    mo = et.TorchWaveflow(D, layers, box, 5.0, k, kn, 0.05, constr, dtype=torch.float64)
+    x = sorted_walkers(B, D, 4.5, 21)
+    g = np.random.default_rng(8)
+    wp, wl, w = (g.normal(size=B).astype(np.float32) for _ in range(3))
+    got = m.psi_vjp(x, wp, wl).cpu().numpy().astype(np.float64)
+    want = et.psi_vjp(mo, flat, x.astype(np.float64), wp, wl)
+    assert rel_l2(got, want) < 3e-3, rel_l2(got, want)
+    got = m.logpdf_vjp(x, w).cpu().numpy().astype(np.float64)
+    want = et.logpdf_vjp(mo, flat, x.astype(np.float64), w)
+    assert rel_l2(got, want) < 3e-3, rel_l2(got, want)
