@@ -186,6 +186,13 @@ int64_t wf_psi_vjp_workspace_bytes(const wf_model* m, int64_t B);
 int wf_psi_vjp(const wf_model* m, const float* x_dev, int64_t B, const float* w_psi_dev, const float* w_lap_dev, float* grad_dev,
                void* workspace_dev, int64_t workspace_bytes, void* stream);
 
+/* loss_fn_efficient and its gradient in one pass (vqmc.py:193-221): one forward sweep gives H psi and psi of every walker,
+ * the tangent-rule weights of wf_vqmc_seeds follow on the device, the reverse sweep and the contraction give
+ * grad_dev[n_params] (scaled by inv_count = 1 / global batch); e_loc_dev[B] = hpsi / (psi + 1e-8) for the caller's
+ * batch statistics (wf_block_sums).  Workspace: wf_psi_vjp_workspace_bytes. */
+int wf_vqmc_loss_grad(const wf_model* m, const float* x_dev, int64_t B, const float* protons_host, int32_t n_protons, float running_average,
+                      float inv_count, float* e_loc_dev, float* grad_dev, void* workspace_dev, int64_t workspace_bytes, void* stream);
+
 /* Parameter gradient of the log-density: grad_dev[p] = sum_b w_dev[b] * d log_pdf_b / d theta_p for every model wf_logpdf_fwd
  * evaluates with <= 32 bases, D <= 4 and zero-only constraints (IMADE or MADE layers; Waveflow, M-spline, Normal or Uniform
  * prior).  With w = -1/B this is the gradient of benchmark_tests.loss (benchmark_tests.py:84-87, 98-101); with per-walker

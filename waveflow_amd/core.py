@@ -231,19 +231,22 @@ class DeviceModel:
         return grad
 
     def vqmc_loss_grad(self, x, protons, running_average, global_count=None):
-        """loss_fn_efficient and its gradient (vqmc.py:193-221) for the walkers x on this device.
+        """loss_fn_efficient and its gradient (vqmc.py:193-221) for the walkers x on this device, one fused pass.
         -> (sums fp64 [sum E_L, sum E_L^2, count] (torch.cuda), grad float32 [n_params] scaled by 1/global_count)."""
         torch = _torch()
         L = _lib.lib()
         t, _ = self._to_dev(x)
         B = t.shape[0]
-        h, ps = self.hamiltonian(t, protons, return_psi=True)
         pr = np.ascontiguousarray(np.asarray(protons, dtype=np.float32).reshape(-1))
-        el, wp, wl = self._new((B,)), self._new((B,)), self._new((B,))
-        inv = 1.0 / float(global_count if global_count else B)
-        _lib.check(L.wf_vqmc_seeds(self._p(t), B, self.D, pr.ctypes.data if pr.size else None, pr.size, self._p(h), self._p(ps),
-                                   float(running_average), inv, self._p(el), self._p(wp), self._p(wl), self._stream()), "wf_vqmc_seeds")
-        return self.block_sums(el), self.psi_vjp(t, wp, wl)
+        nbytes = _lib.check(L.wf_psi_vjp_workspace_bytes(self._h, B), "wf_psi_vjp_workspace_bytes")
+        if self._vjp_ws is None or self._vjp_ws.numel() < nbytes:
+            self._vjp_ws = torch.empty(int(nbytes), device=t.device, dtype=torch.uint8)
+        el, grad = self._new((B,)), self._new((self.n_params,))
+        inv = 1.0 / float(global_count if global_count else max(B, 1))
+        _lib.check(L.wf_vqmc_loss_grad(self._h, self._p(t), B, pr.ctypes.data if pr.size else None, pr.size, float(running_average), inv,
+                                       self._p(el), self._p(grad), self._p(self._vjp_ws), self._vjp_ws.numel(), self._stream()),
+                   "wf_vqmc_loss_grad")
+        return self.block_sums(el), grad
 
     def block_sums(self, v):
         """fp64 [sum v, sum v^2, count] on the device (deterministic order)."""

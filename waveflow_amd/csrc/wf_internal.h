@@ -37,6 +37,22 @@ struct NetMfma {
     int image_floats;
 };
 
+using float4_t = __attribute__((ext_vector_type(4))) float;
+
+// One conditioner net for the wave-cooperative kernels (wf_kernels_wave.hip): lane = hidden unit / output row, every
+// matrix in "lane-major float4 groups" [16 groups of 4 contracted indices][64 lanes] so that one load instruction of the
+// wave reads 1 KB contiguous.  P = ceil(D / 2) output passes; lane (dl, j) of pass p is basis row j of dimension 2p + dl.
+struct NetWave {
+    const float* W0;        // [D][64]  W0 * mask0
+    const float* b0;        // [64]
+    const float* b1;        // [64]
+    const float* b2;        // [P][64]
+    const float4_t* W1f;    // [16][64]: lane j,  group g: (W1*mask1)[a = 4g..4g+3][j]
+    const float4_t* W1b;    // [16][64]: lane a,  group g: (W1*mask1)[a][j = 4g..4g+3]
+    const float4_t* W2f;    // [P][16][64]: lane (dl, j), group g: (W2*mask2)[a = 4g..][column of (2p+dl, j)]
+    const float4_t* W2b;    // [P][16][64]: lane a, group g: (W2*mask2)[a][columns of lanes c = 4g..4g+3 of pass p]
+};
+
 struct SplineDev {
     const float* tab;    // [2 or 4][n_mesh][NBP] fp32, mesh-major ("dense rows"); order nd, then mesh point, then basis
     int nb;              // real number of bases
@@ -69,9 +85,8 @@ struct ModelDev {
     float reverse_tol;            // IMADE reverse_fun_tol
     NetPlain nets[kMaxNets];      // flow layers 0..n_layers-1, then the prior net
     NetMfma mnets[kMaxNets];
+    NetWave wnets[kMaxNets];
 };
-
-using float4_t = __attribute__((ext_vector_type(4))) float;
 
 // MFMA kernel's view of the model (wf_kernels_mfma.hip)
 struct MfmaDev {
@@ -112,13 +127,18 @@ struct Protons {
     float pos[8];
     int n;
 };
-int launch_energy(const ModelDev& md, const ModelDev* md_dev, const float* tabI4, const float* tabP3, const float* x, int64_t B,
-                  const Protons& pr, float* hpsi, float* psi, float* lap, void* stream);
 // reverse pass (wf_kernels_grad.hip)
 int grad_ws_rows(int D);
-int launch_vjp(const ModelDev& md, const ModelDev* md_dev, int mode, int second_order, const float* tabI4, const float* tabP4, const float* fk_nat,
-               const float* x, int64_t B, const float* w1, const float* w2, float* ws, int64_t S, float* grad_img, int64_t net_img_floats,
-               void* stream);
+int launch_wgrad(int D, int second_order, int n_nets, int64_t n_samples, const float* ws, float* grad_img, int64_t net_img_floats, void* stream);
+int launch_wave_fwd(const ModelDev& md, const ModelDev* md_dev, int second_order, const float* tabI4, const float* tabP4, const float* fk_nat,
+                    const float* x, int64_t B, float* ws, float* tails, int taped, void* stream);
+int launch_wave_bwd(const ModelDev& md, const ModelDev* md_dev, int mode, int second_order, const float* tabI4, const float* tabP4,
+                    const float* fk_nat, int64_t B, const float* w1, const float* w2, float* ws, const float* tails, void* stream);
+int launch_wave_energy(const ModelDev& md, const ModelDev* md_dev, const float* tabI4, const float* tabP4, const float* fk_nat, const float* x,
+                       int64_t B, const Protons& pr, float* hpsi, float* psi, float* lap, float* tail_ws, void* stream);
+int64_t wave_tail_floats(int D, int second_order);
+int launch_energy_out(int D, const float* tails, const float* x, int64_t B, unsigned constrained_mask, const Protons& pr, float* hpsi, float* psi,
+                      float* lap, void* stream);
 int launch_grad_scatter(const float* grad_img, const int32_t* map, int64_t n_img, float* grad_flat, void* stream);
 int launch_vqmc_seeds(const float* x, int64_t B, int D, const Protons& pr, const float* hpsi, const float* psi, float running_avg,
                       float inv_count, float* e_loc, float* w_psi, float* w_lap, void* stream);

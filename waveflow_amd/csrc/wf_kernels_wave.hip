@@ -1,0 +1,711 @@
+// wf_kernels_wave.hip -- wave-cooperative ring kernels: local energy and parameter gradients, gfx950.
+//
+// One WAVE evaluates one sample (a walker, or a (walker, direction) pair in the second-order ring R3 -- wf_ring.h); its 64
+// lanes are the 64 hidden units of the conditioner (model_factory.py:72), and in the output layer the 2 x 32 basis rows of
+// two dimensions.  A dense layer is then 64 fused multiply-adds per lane and coefficient instead of 4096: the input vector
+// is broadcast from LDS (ds_read_b128, same address in every lane), the weights come in lane-major float4 groups (one
+// 1 KB contiguous load per instruction, NetWave in wf_internal.h).  Normalisations and spline sums are 32-lane butterfly
+// reductions.  Compared with the one-lane-per-walker form this cuts the serial chain of a sample by ~60x (what bounds a
+// 128..256-walker training step) and needs no register spills.
+//
+//   k_wave_fwd   forward ring evaluation; writes the tape (layer inputs, hidden activations) and the tail
+//                (per-dimension prior factors, log det, latent point) of each sample
+//   k_energy_out psi, laplacian, H psi per walker from the tails      physics.py:50-52, 60-76, 79-93
+//   k_wave_bwd   reverse sweep from the tape: pre-activation adjoints into the tape for k_wgrad (wf_kernels_grad.hip)
+//
+// Derivative semantics of the table lerp and the adjoint-in-reversed-order ring trick: see wf_kernels_grad.hip / wf_ring.h.
+#include <hip/hip_runtime.h>
+
+#include "wf_internal.h"
+#include "wf_ring.h"
+
+namespace wf {
+
+namespace {
+
+using namespace ring;
+constexpr int H = kHidden;
+constexpr int kWaves = 4;
+#ifndef WF_WAVE_OCC
+#define WF_WAVE_OCC 3   // waves per SIMD the register allocation aims at (measured: DESIGN.md §4.5)
+#endif
+constexpr int kWB = 64 * kWaves;
+
+// ---- coefficient access
+__device__ __forceinline__ float coef(R1 a, int) { return a.c0; }
+__device__ __forceinline__ float coef(R3 a, int k) { return k == 0 ? a.c0 : (k == 1 ? a.c1 : a.c2); }
+__device__ __forceinline__ R1 from_arr(R1*, const float* c) { return R1{c[0]}; }
+__device__ __forceinline__ R3 from_arr(R3*, const float* c) { return R3{c[0], c[1], c[2]}; }
+template <class T> __device__ __forceinline__ T sel(bool first, T a, T b) { return first ? a : b; }
+
+// ---- cross-lane: DPP butterflies inside a row of 16 lanes, the gfx950 permlane swaps across rows / halves
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// rows 0,1 and rows 2,3 exchanged (v_permlane16_swap) / halves exchanged (v_permlane32_swap); the wait states around the
+// swaps are spelled out
+__device__ __forceinline__ float swap16_sum(float v) {
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 3" : "+v"(a), "+v"(b));
+    return a + b;
+}
+__device__ __forceinline__ float swap32_other(float v) {
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 3" : "+v"(a), "+v"(b));
+    // a = [lo, lo], b = [hi, hi]: the value of the other half is whichever differs from mine
+    return (threadIdx.x & 32) ? a : b;
+}
+__device__ __forceinline__ float hsum(float v) {   // sum over the 32 lanes of this lane's half, in every lane
+    v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);   // row_half_mirror
+    v = dpp_add<0x140>(v);   // row_mirror
+    return swap16_sum(v);
+}
+__device__ __forceinline__ R1 half_sum(R1 a) { return R1{hsum(a.c0)}; }
+__device__ __forceinline__ R3 half_sum(R3 a) { return R3{hsum(a.c0), hsum(a.c1), hsum(a.c2)}; }
+__device__ __forceinline__ R1 xhalf(R1 a) { return R1{swap32_other(a.c0)}; }
+__device__ __forceinline__ R3 xhalf(R3 a) { return R3{swap32_other(a.c0), swap32_other(a.c1), swap32_other(a.c2)}; }
+template <class T> __device__ __forceinline__ T wave_sum(T a) {
+    const T h = half_sum(a);
+    return h + xhalf(h);
+}
+__device__ __forceinline__ R1 from_lane(R1 a, int src) { return R1{__shfl(a.c0, src)}; }
+__device__ __forceinline__ R3 from_lane(R3 a, int src) { return R3{__shfl(a.c0, src), __shfl(a.c1, src), __shfl(a.c2, src)}; }
+
+// ---- per-wave LDS vector [NC][64]
+template <class T> __device__ __forceinline__ void put(float (*buf)[64], int lane, T v) {
+#pragma unroll
+    for (int k = 0; k < T::NC; ++k) buf[k][lane] = coef(v, k);
+    __builtin_amdgcn_wave_barrier();
+}
+// out[lane] = sum_a in[a] * W[lane][a], W in lane-major float4 groups
+template <class T>
+__device__ __forceinline__ T gemv(const float4_t* __restrict__ img, const float (*buf)[64], int lane) {
+    float acc[T::NC];
+#pragma unroll
+    for (int k = 0; k < T::NC; ++k) acc[k] = 0.0f;
+#pragma unroll 4
+    for (int g = 0; g < 16; ++g) {
+        const float4_t w = img[g * 64 + lane];
+#pragma unroll
+        for (int k = 0; k < T::NC; ++k) {
+            const float4_t x = *reinterpret_cast<const float4_t*>(&buf[k][4 * g]);
+            acc[k] = __builtin_fmaf(w.x, x.x, acc[k]);
+            acc[k] = __builtin_fmaf(w.y, x.y, acc[k]);
+            acc[k] = __builtin_fmaf(w.z, x.z, acc[k]);
+            acc[k] = __builtin_fmaf(w.w, x.w, acc[k]);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    return from_arr((T*)nullptr, acc);
+}
+// out[lane (half h, j)] = sum_{a < 32} in[h][a] * M[a][j]   (M: [32][32] row-major; in = buf of this lane's half)
+template <class T>
+__device__ __forceinline__ T gemv32_cols(const float* __restrict__ M, const float (*buf)[64], int half, int j) {
+    float acc[T::NC];
+#pragma unroll
+    for (int k = 0; k < T::NC; ++k) acc[k] = 0.0f;
+#pragma unroll 8
+    for (int a = 0; a < 32; ++a) {
+        const float m = M[a * NBP + j];
+#pragma unroll
+        for (int k = 0; k < T::NC; ++k) acc[k] = __builtin_fmaf(buf[k][half * 32 + a], m, acc[k]);
+    }
+    __builtin_amdgcn_wave_barrier();
+    return from_arr((T*)nullptr, acc);
+}
+// out[lane (half h, a)] = sum_{j < 32} in[h][j] * M[a][j]
+template <class T>
+__device__ __forceinline__ T gemv32_rows(const float* __restrict__ M, const float (*buf)[64], int half, int a) {
+    float acc[T::NC];
+#pragma unroll
+    for (int k = 0; k < T::NC; ++k) acc[k] = 0.0f;
+#pragma unroll 8
+    for (int j = 0; j < 32; ++j) {
+        const float m = M[a * NBP + j];
+#pragma unroll
+        for (int k = 0; k < T::NC; ++k) acc[k] = __builtin_fmaf(buf[k][half * 32 + j], m, acc[k]);
+    }
+    __builtin_amdgcn_wave_barrier();
+    return from_arr((T*)nullptr, acc);
+}
+
+// ---- tape: ws[((sample * n_nets + net) * NC + coefficient) * ROWS + row], ring::Rows
+struct Tape {
+    float* base;      // of this sample
+    int rows;
+};
+template <class T> __device__ __forceinline__ void tput(const Tape& t, int net, int row, T v) {
+#pragma unroll
+    for (int k = 0; k < T::NC; ++k) t.base[((int64_t)net * T::NC + k) * t.rows + row] = coef(v, k);
+}
+template <class T> __device__ __forceinline__ T tget(const Tape& t, int net, int row) {
+    float c[T::NC];
+#pragma unroll
+    for (int k = 0; k < T::NC; ++k) c[k] = t.base[((int64_t)net * T::NC + k) * t.rows + row];
+    return from_arr((T*)nullptr, c);
+}
+// uniform ring values in the tail: tail[sample][slot][coefficient]
+template <class T> __device__ __forceinline__ void tail_put(float* tl, int slot, T v) {
+#pragma unroll
+    for (int k = 0; k < T::NC; ++k) tl[slot * T::NC + k] = coef(v, k);
+}
+template <class T> __device__ __forceinline__ T tail_get(const float* tl, int slot) {
+    float c[T::NC];
+#pragma unroll
+    for (int k = 0; k < T::NC; ++k) c[k] = tl[slot * T::NC + k];
+    return from_arr((T*)nullptr, c);
+}
+template <int D> struct Tail {   // slots
+    static constexpr int V = 0, LD = D, U = D + 1, N = 2 * D + 1;
+};
+
+// two masked tanh layers, lane = hidden unit; leaves h2 in `vec` and returns it
+template <int D, class T>
+__device__ __forceinline__ T hidden_fwd(const NetWave& net, const T (&x)[D], float (*vec)[64], int lane, const Tape& tape, int n, bool taped) {
+    T z = cst<T>(net.b0[lane]);
+#pragma unroll
+    for (int a = 0; a < D; ++a) z = z + x[a] * net.W0[a * H + lane];
+    const T h1 = rtanh(z);
+    if (taped) tput(tape, n, Rows<D>::H1 + lane, h1);
+    put(vec, lane, h1);
+    const T h2 = rtanh(gemv<T>(net.W1f, vec, lane) + net.b1[lane]);
+    if (taped) tput(tape, n, Rows<D>::H2 + lane, h2);
+    put(vec, lane, h2);
+    return h2;
+}
+
+// state of one sigmoid head lane (IMADE layer or M-spline prior): c = g (p / S0 + reg) / Q, see wf_kernels_grad.hip
+template <class T> struct SigHead {
+    T p, rS0, rQ, c;
+};
+template <class T>
+__device__ __forceinline__ SigHead<T> sigmoid_head(T o, bool valid, bool valid_d, float g, float reg) {
+    SigHead<T> h;
+    h.p = valid ? rsigmoid(o) : cst<T>(0.0f);
+    T S0 = half_sum(h.p);
+    if (!valid_d) S0 = cst<T>(1.0f);
+    h.rS0 = rrcp(S0);
+    const T q = (h.p * h.rS0 + reg) * (valid ? g : 0.0f);
+    T Q = half_sum(q);
+    if (!valid_d) Q = cst<T>(1.0f);
+    h.rQ = rrcp(Q);
+    h.c = q * h.rQ;
+    return h;
+}
+// reverse of the head: cbar (this lane) -> obar (this lane)
+template <class T>
+__device__ __forceinline__ T sigmoid_head_bwd(const SigHead<T>& h, T gc, bool valid, float g) {
+    const T dotC = half_sum(gc * h.c);
+    const T gw0 = ((gc - dotC) * h.rQ) * (valid ? g : 0.0f);
+    const T dot0 = half_sum(gw0 * (h.p * h.rS0));
+    return valid ? ((gw0 - dot0) * h.rS0) * (h.p * (1.0f - h.p)) : cst<T>(0.0f);
+}
+
+// psi head lane state (wavefunctions.py:54-71, bsplines_jax.py:127-137 with zero-only constraints)
+template <class T> struct PsiHead {
+    T o, rS, rN1, rN2, a, e;
+};
+template <class T>
+__device__ __forceinline__ PsiHead<T> psi_head(T o, bool valid, bool valid_d, float keep, const float* __restrict__ o2b, float (*ov)[64], int lane) {
+    PsiHead<T> h;
+    h.o = valid ? o : cst<T>(0.0f);
+    T S = half_sum(h.o);
+    if (!valid_d) S = cst<T>(1.0f);
+    h.rS = rrcp(S);
+    const T w = (h.o * h.rS) * (valid ? keep : 0.0f);
+    T N1 = half_sum(w * w);
+    if (!valid_d) N1 = cst<T>(1.0f);
+    h.rN1 = rrsqrt(N1);
+    h.a = w * h.rN1;
+    put(ov, lane, h.a);
+    const T c = gemv32_cols<T>(o2b, ov, lane >> 5, lane & 31);   // c_j = sum_a a_a ob_to_b[a][j]
+    T N2 = half_sum(c * c);
+    if (!valid_d) N2 = cst<T>(1.0f);
+    h.rN2 = rrsqrt(N2);
+    h.e = c * h.rN2;
+    return h;
+}
+
+template <class T> __device__ __forceinline__ T clip01(T u, bool& inside) {
+    inside = true;
+    if (u.c0 < 0.0f) { inside = false; return cst<T>(0.0f); }
+    if (u.c0 > 1.0f) { inside = false; return cst<T>(1.0f); }
+    return u;
+}
+
+template <int D, class T>
+__device__ __forceinline__ void box_forward(const ModelDev& md, T (&cur)[D], T& logdet) {
+    const float L = md.box_L, tol = 1e-7f;
+    T nxt[D];
+    if (md.box_kind == WF_BOX_MEAN) {
+        T sm = cst<T>(0.0f);
+#pragma unroll
+        for (int d = 0; d < D; ++d) sm = sm + cur[d];
+        const T mean = sm * (1.0f / (float)D);
+        const T l = mean - cur[0];
+        const T wd = cur[D - 1] - cur[0];
+        T space = cst<T>(2 * L);
+#pragma unroll
+        for (int i = 0; i < D - 1; ++i) {
+            const T diff = cur[i + 1] - cur[i];
+            nxt[i] = diff * rrcp(space + tol);
+            logdet = logdet - rlog(space + tol);
+            space = space - diff;
+        }
+        const T den = (2 * L - wd) + tol;
+        nxt[D - 1] = ((mean + L) - l) * rrcp(den);
+        logdet = logdet - rlog(den);
+    } else if (md.box_kind == WF_BOX_FIRST) {
+        nxt[0] = (cur[0] + L) * (1.0f / (2 * L));
+        T ls = cst<T>(0.0f);
+#pragma unroll
+        for (int i = 1; i < D; ++i) nxt[i] = (cur[i] - cur[i - 1]) * rrcp((L - cur[i - 1]) + tol);
+#pragma unroll
+        for (int i = 0; i < D - 1; ++i) ls = ls + rlog((L - cur[i]) + tol);
+        logdet = cst<T>(-logf(2 * L)) - ls;
+    } else {
+        return;
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) cur[d] = nxt[d];
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+template <int D, class T>
+__global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(WF_WAVE_OCC, WF_WAVE_OCC))) void k_wave_fwd(const ModelDev* __restrict__ mdp, const float* __restrict__ tabI, const float* __restrict__ tabP,
+                                                   const float* __restrict__ fk_nat, const float* __restrict__ xg, int64_t B,
+                                                   float* __restrict__ ws, float* __restrict__ tails, int taped) {
+    __shared__ float lds[kWaves][2][T::NC][64];
+    const ModelDev& md = *mdp;
+    constexpr int DIRS = T::NC == 3 ? D : 1;
+    constexpr int P = (D + 1) / 2;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float (*vec)[64] = lds[wv][0];
+    float (*ov)[64] = lds[wv][1];
+    const int dl = lane >> 5, j = lane & 31;
+    const bool imade = md.layer_kind == WF_LAYER_IMADE;
+    const bool has_pnet = md.prior_kind == WF_PRIOR_WAVEFLOW || md.prior_kind == WF_PRIOR_MFLOW;
+    const int n_nets = md.n_layers + (has_pnet ? 1 : 0);
+    const int n_mesh = imade ? md.isp.n_mesh : md.psp.n_mesh;
+    const size_t plane = (size_t)n_mesh * NBP;
+    const float* __restrict__ gI = fk_nat;
+    const float* __restrict__ kP = fk_nat + 64;
+    T* const tag = nullptr;
+    const int64_t n_samples = B * DIRS;
+    for (int64_t s = (int64_t)blockIdx.x * kWaves + wv; s < n_samples; s += (int64_t)gridDim.x * kWaves) {
+        const int64_t b = s / DIRS;
+        const int dir = (int)(s - b * DIRS);
+        const Tape tape{ws + s * (int64_t)n_nets * T::NC * Rows<D>::N, Rows<D>::N};
+        float* tl = tails + s * (int64_t)Tail<D>::N * T::NC;
+        T cur[D], nxt[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) cur[d] = make_var(tag, xg[b * D + d], d == dir);
+        T logdet = cst<T>(0.0f);
+        box_forward<D, T>(md, cur, logdet);
+        for (int l = 0; l < md.n_layers; ++l) {
+            const NetWave& net = md.wnets[l];
+            if (taped) {
+#pragma unroll
+                for (int d = 0; d < D; ++d)
+                    if (lane == d) tput(tape, l, Rows<D>::U + d, cur[d]);
+            }
+            hidden_fwd<D, T>(net, cur, vec, lane, tape, l, taped);
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const int d = 2 * p + dl;
+                const bool valid_d = d < D;
+                const T o = gemv<T>(net.W2f + p * 1024, vec, lane) + net.b2[p * 64 + lane];
+                const T u = sel(dl == 0, cur[2 * p], cur[2 * p + 1 < D ? 2 * p + 1 : 2 * p]);
+                T y, ld;
+                if (imade) {
+                    const int nb = md.isp.nb;
+                    const bool valid = valid_d && j < nb;
+                    const SigHead<T> hd = sigmoid_head(o, valid, valid_d, gI[j], md.i_reg);
+                    const Lerp lp = make_lerp(u.c0, n_mesh);
+                    float t[4];
+                    lerp4(tabI, plane, lp, j, t);
+                    y = half_sum(hd.c * lift(t, 0, u));
+                    const T dy = half_sum(hd.c * lift(t, 1, u));
+                    ld = valid_d ? rlog(dy + 1e-7f) : cst<T>(0.0f);
+                } else {
+                    // MADE (made.py:21-27): rows 0 / 1 of the dimension are log_weight / bias
+                    const T lw = from_lane(o, dl * 32), bias = from_lane(o, dl * 32 + 1);
+                    y = (u - bias) * rexp(cst<T>(0.0f) - lw);
+                    ld = valid_d ? cst<T>(0.0f) - lw : cst<T>(0.0f);
+                }
+                const T y_o = xhalf(y), ld_o = xhalf(ld);
+                nxt[2 * p] = sel(dl == 0, y, y_o);
+                if (2 * p + 1 < D) nxt[2 * p + 1] = sel(dl == 0, y_o, y);
+                logdet = logdet + ld + ld_o;
+            }
+#pragma unroll
+            for (int d = 0; d < D; ++d) cur[d] = nxt[D - 1 - d];
+        }
+        // ---- prior
+        T v[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) v[d] = cst<T>(1.0f);
+        if (has_pnet) {
+            const int NP = md.n_layers;
+            const NetWave& net = md.wnets[NP];
+            const int nb = md.psp.nb;
+            if (taped) {
+#pragma unroll
+                for (int d = 0; d < D; ++d)
+                    if (lane == d) tput(tape, NP, Rows<D>::U + d, cur[d]);
+            }
+            hidden_fwd<D, T>(net, cur, vec, lane, tape, NP, taped);
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const int d = 2 * p + dl;
+                const bool valid_d = d < D, valid = valid_d && j < nb;
+                const T o = gemv<T>(net.W2f + p * 1024, vec, lane) + net.b2[p * 64 + lane];
+                bool inside;
+                const T uc = clip01(sel(dl == 0, cur[2 * p], cur[2 * p + 1 < D ? 2 * p + 1 : 2 * p]), inside);
+                const Lerp lp = make_lerp(uc.c0, n_mesh);
+                float t[4];
+                lerp4(tabP, plane, lp, j, t);
+                T val;
+                if (md.prior_kind == WF_PRIOR_WAVEFLOW) {
+                    const PsiHead<T> hd = psi_head(o, valid, valid_d, kP[j], md.ob_to_b, ov, lane);
+                    val = half_sum(hd.e * lift(t, 0, uc));
+                } else {
+                    const SigHead<T> hd = sigmoid_head(o, valid, valid_d, kP[j], 0.0f);
+                    val = half_sum(hd.c * lift(t, 0, uc));
+                }
+                const T val_o = xhalf(val);
+                v[2 * p] = sel(dl == 0, val, val_o);
+                if (2 * p + 1 < D) v[2 * p + 1] = sel(dl == 0, val_o, val);
+            }
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                tail_put(tl, Tail<D>::V + d, v[d]);
+                tail_put(tl, Tail<D>::U + d, cur[d]);
+            }
+            tail_put(tl, Tail<D>::LD, logdet);
+        }
+    }
+}
+
+// psi of one sample from its tail: prod_d (v_d scale_d) * exp(logdet / 2)
+template <int D, class T>
+__device__ __forceinline__ T psi_from_tail(const float* tl, unsigned constrained_mask, T (&v)[D], T& E) {
+    T prod = cst<T>(1.0f);
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        v[d] = tail_get<T>(tl, Tail<D>::V + d);
+        prod = prod * (v[d] * (((constrained_mask >> d) & 1u) ? 0.70710678118654752f : 1.0f));
+    }
+    E = rexp(tail_get<T>(tl, Tail<D>::LD) * 0.5f);
+    return prod * E;
+}
+
+// ---- H psi = -1/2 laplacian + V psi per walker from the R3 tails of its D directions
+template <int D>
+__global__ void k_energy_out(const float* __restrict__ tails, const float* __restrict__ xg, int64_t B, unsigned constrained_mask, const Protons pr,
+                             float* __restrict__ hpsi, float* __restrict__ psi_out, float* __restrict__ lap_out) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float lap = 0.0f, psv = 0.0f;
+#pragma unroll
+    for (int dir = 0; dir < D; ++dir) {
+        R3 v[D], E;
+        const R3 ps = psi_from_tail<D, R3>(tails + (b * D + dir) * (int64_t)Tail<D>::N * 3, constrained_mask, v, E);
+        lap += 2.0f * ps.c2;
+        psv = ps.c0;
+    }
+    float V = 0.0f;   // physics.py:60-76
+    for (int p = 0; p < pr.n; ++p)
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const float r = pr.pos[p] - xg[b * D + d];
+            V -= 1.0f / sqrtf(1.0f + r * r);
+        }
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int k = 0; k < i; ++k) {
+            const float r = xg[b * D + i] - xg[b * D + k];
+            V += 1.0f / sqrtf(1.0f + r * r);
+        }
+    hpsi[b] = -0.5f * lap + V * psv;
+    if (psi_out) psi_out[b] = psv;
+    if (lap_out) lap_out[b] = lap;
+}
+
+// ------------------------------------------------------------------------------------------------ reverse
+// pre-activation adjoints of one conditioner from hbar2 (this lane's hidden unit); adds the W0 path to gU
+template <int D, class T>
+__device__ __forceinline__ void hidden_bwd(const NetWave& net, T hb2, float (*vec)[64], int lane, const Tape& tape, int n, T (&gU)[D]) {
+    const T h2 = tget<T>(tape, n, Rows<D>::H2 + lane);
+    const T A2 = hb2 * (1.0f - h2 * h2);
+    tput(tape, n, Rows<D>::A2 + lane, A2);
+    put(vec, lane, A2);
+    const T hb1 = gemv<T>(net.W1b, vec, lane);
+    const T h1 = tget<T>(tape, n, Rows<D>::H1 + lane);
+    const T A1 = hb1 * (1.0f - h1 * h1);
+    tput(tape, n, Rows<D>::A1 + lane, A1);
+#pragma unroll
+    for (int a = 0; a < D; ++a) gU[a] = gU[a] + wave_sum(A1 * net.W0[a * H + lane]);
+}
+
+// mode 0: sum_b w1[b] log_pdf_b;  mode 1: sum_b (w1[b] psi_b + w2[b] laplacian_b)
+template <int D, class T>
+__global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(WF_WAVE_OCC, WF_WAVE_OCC))) void k_wave_bwd(const ModelDev* __restrict__ mdp, int mode, const float* __restrict__ tabI, const float* __restrict__ tabP,
+                                                   const float* __restrict__ fk_nat, int64_t B, const float* __restrict__ w1, const float* __restrict__ w2,
+                                                   float* __restrict__ ws, const float* __restrict__ tails) {
+    __shared__ float lds[kWaves][2][T::NC][64];
+    const ModelDev& md = *mdp;
+    constexpr int DIRS = T::NC == 3 ? D : 1;
+    constexpr int P = (D + 1) / 2;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float (*vec)[64] = lds[wv][0];
+    float (*ov)[64] = lds[wv][1];
+    const int dl = lane >> 5, j = lane & 31;
+    const bool imade = md.layer_kind == WF_LAYER_IMADE;
+    const bool has_pnet = md.prior_kind == WF_PRIOR_WAVEFLOW || md.prior_kind == WF_PRIOR_MFLOW;
+    const int n_nets = md.n_layers + (has_pnet ? 1 : 0);
+    const int n_mesh = imade ? md.isp.n_mesh : md.psp.n_mesh;
+    const size_t plane = (size_t)n_mesh * NBP;
+    const float* __restrict__ gI = fk_nat;
+    const float* __restrict__ kP = fk_nat + 64;
+    T* const tag = nullptr;
+    const int64_t n_samples = B * DIRS;
+    for (int64_t s = (int64_t)blockIdx.x * kWaves + wv; s < n_samples; s += (int64_t)gridDim.x * kWaves) {
+        const int64_t b = s / DIRS;
+        const int dir = (int)(s - b * DIRS);
+        const Tape tape{ws + s * (int64_t)n_nets * T::NC * Rows<D>::N, Rows<D>::N};
+        const float* tl = tails + s * (int64_t)Tail<D>::N * T::NC;
+        T v[D], E;
+        const T psi = psi_from_tail<D, T>(tl, md.constrained_mask, v, E);
+        T gLD, gProd = cst<T>(0.0f), gOut = cst<T>(0.0f);
+        if (mode == 1) {
+            const T gPsi = adj_value(tag, dir == 0 ? w1[b] : 0.0f) + adj_second(tag, w2 ? w2[b] : 0.0f);
+            gLD = (gPsi * psi) * 0.5f;
+            gProd = gPsi * E;
+        } else {
+            gOut = adj_value(tag, w1[b]);
+            gLD = gOut;
+        }
+        T gU[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) gU[d] = cst<T>(0.0f);
+        if (has_pnet) {
+            const int NP = md.n_layers;
+            const NetWave& net = md.wnets[NP];
+            const int nb = md.psp.nb;
+            T cur[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) cur[d] = tail_get<T>(tl, Tail<D>::U + d);
+            put(vec, lane, tget<T>(tape, NP, Rows<D>::H2 + lane));
+            T hb2 = cst<T>(0.0f);
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const int d = 2 * p + dl;
+                const bool valid_d = d < D, valid = valid_d && j < nb;
+                const T o = gemv<T>(net.W2f + p * 1024, vec, lane) + net.b2[p * 64 + lane];
+                bool inside;
+                const T uc = clip01(sel(dl == 0, cur[2 * p], cur[2 * p + 1 < D ? 2 * p + 1 : 2 * p]), inside);
+                const Lerp lp = make_lerp(uc.c0, n_mesh);
+                float t[4];
+                lerp4(tabP, plane, lp, j, t);
+                // adjoint of this half's prior factor v_d
+                T gv_lo, gv_hi;
+                {
+                    T gvs[2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int dd = 2 * p + q < D ? 2 * p + q : 2 * p;
+                        const float sc = ((md.constrained_mask >> dd) & 1u) ? 0.70710678118654752f : 1.0f;
+                        if (mode == 1) {
+                            T others = cst<T>(1.0f);
+#pragma unroll
+                            for (int e = 0; e < D; ++e) {
+                                const float se = ((md.constrained_mask >> e) & 1u) ? 0.70710678118654752f : 1.0f;
+                                others = e == dd ? others * se : others * (v[e] * se);
+                            }
+                            gvs[q] = gProd * others;
+                        } else if (md.prior_kind == WF_PRIOR_WAVEFLOW) {
+                            gvs[q] = (gOut * rrcp((v[dd] * v[dd]) * (sc * sc) + 1e-7f)) * (v[dd] * (2.0f * sc * sc));
+                        } else {
+                            gvs[q] = gOut * rrcp(v[dd] + 1e-7f);
+                        }
+                    }
+                    gv_lo = gvs[0];
+                    gv_hi = gvs[1];
+                }
+                const T gv = sel(dl == 0, gv_lo, gv_hi);
+                T go, d1;
+                if (md.prior_kind == WF_PRIOR_WAVEFLOW) {
+                    const PsiHead<T> hd = psi_head(o, valid, valid_d, kP[j], md.ob_to_b, ov, lane);
+                    const T ge = gv * lift(t, 0, uc);
+                    const T dotE = half_sum(ge * hd.e);
+                    d1 = half_sum(hd.e * lift(t, 1, uc));
+                    const T gc = (ge - hd.e * dotE) * hd.rN2;
+                    put(ov, lane, gc);
+                    const T ga = gemv32_rows<T>(md.ob_to_b, ov, dl, j);          // abar_a = sum_j cbar_j ob_to_b[a][j]
+                    const T dotA = half_sum(ga * hd.a);
+                    const T gw = ((ga - hd.a * dotA) * hd.rN1) * (valid ? kP[j] : 0.0f);
+                    const T dotW = half_sum(gw * (hd.o * hd.rS));
+                    go = valid ? (gw - dotW) * hd.rS : cst<T>(0.0f);
+                } else {
+                    const SigHead<T> hd = sigmoid_head(o, valid, valid_d, kP[j], 0.0f);
+                    d1 = half_sum(hd.c * lift(t, 1, uc));
+                    go = sigmoid_head_bwd(hd, gv * lift(t, 0, uc), valid, kP[j]);
+                }
+                const T gu = (valid_d && inside) ? gv * d1 : cst<T>(0.0f);
+                const T gu_o = xhalf(gu);
+                gU[2 * p] = gU[2 * p] + sel(dl == 0, gu, gu_o);
+                if (2 * p + 1 < D) gU[2 * p + 1] = gU[2 * p + 1] + sel(dl == 0, gu_o, gu);
+                if (valid_d) tput(tape, NP, Rows<D>::O + d * NBP + j, go);
+                put(ov, lane, go);
+                hb2 = hb2 + gemv<T>(net.W2b + p * 1024, ov, lane);
+            }
+            hidden_bwd<D, T>(net, hb2, vec, lane, tape, NP, gU);
+        } else if (md.prior_kind == WF_PRIOR_NORMAL) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) gU[d] = gOut * ((tail_get<T>(tl, Tail<D>::U + d) + md.normal_offset) * -1.0f);
+        }
+        // ---- flow layers, last to first
+        for (int l = md.n_layers - 1; l >= 0; --l) {
+            const NetWave& net = md.wnets[l];
+            T gY[D], U[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                gY[d] = gU[D - 1 - d];   // Reverse (bijections.py:337-340)
+                U[d] = tget<T>(tape, l, Rows<D>::U + d);
+            }
+#pragma unroll
+            for (int d = 0; d < D; ++d) gU[d] = cst<T>(0.0f);
+            put(vec, lane, tget<T>(tape, l, Rows<D>::H2 + lane));
+            T hb2 = cst<T>(0.0f);
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const int d = 2 * p + dl;
+                const bool valid_d = d < D;
+                const T o = gemv<T>(net.W2f + p * 1024, vec, lane) + net.b2[p * 64 + lane];
+                const T u = sel(dl == 0, U[2 * p], U[2 * p + 1 < D ? 2 * p + 1 : 2 * p]);
+                const T gy = sel(dl == 0, gY[2 * p], gY[2 * p + 1 < D ? 2 * p + 1 : 2 * p]);
+                T go, gu;
+                if (imade) {
+                    const int nb = md.isp.nb;
+                    const bool valid = valid_d && j < nb;
+                    const SigHead<T> hd = sigmoid_head(o, valid, valid_d, gI[j], md.i_reg);
+                    const Lerp lp = make_lerp(u.c0, n_mesh);
+                    float t[4];
+                    lerp4(tabI, plane, lp, j, t);
+                    const T b0 = lift(t, 0, u), b1 = lift(t, 1, u);
+                    const T dy = half_sum(hd.c * b1);
+                    const T y2 = half_sum(hd.c * lift(t, 2, u));
+                    const T gdy = gLD * rrcp(dy + 1e-7f);
+                    gu = valid_d ? gy * dy + gdy * y2 : cst<T>(0.0f);
+                    go = sigmoid_head_bwd(hd, gy * b0 + gdy * b1, valid, gI[j]);
+                } else {
+                    const T lw = from_lane(o, dl * 32), bias = from_lane(o, dl * 32 + 1);
+                    const T e = rexp(cst<T>(0.0f) - lw);
+                    const T y = (u - bias) * e;
+                    gu = valid_d ? gy * e : cst<T>(0.0f);
+                    go = cst<T>(0.0f);
+                    if (valid_d && j == 0) go = cst<T>(0.0f) - (gy * y) - gLD;   // d y / d lw = -y,  d logdet / d lw = -1
+                    if (valid_d && j == 1) go = cst<T>(0.0f) - (gy * e);          // d y / d bias = -e
+                }
+                const T gu_o = xhalf(gu);
+                gU[2 * p] = gU[2 * p] + sel(dl == 0, gu, gu_o);
+                if (2 * p + 1 < D) gU[2 * p + 1] = gU[2 * p + 1] + sel(dl == 0, gu_o, gu);
+                if (valid_d) tput(tape, l, Rows<D>::O + d * NBP + j, go);
+                put(ov, lane, go);
+                hb2 = hb2 + gemv<T>(net.W2b + p * 1024, ov, lane);
+            }
+            hidden_bwd<D, T>(net, hb2, vec, lane, tape, l, gU);
+        }
+    }
+}
+
+int finish() {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_hip_error((int)e);
+        return WF_ERR_HIP;
+    }
+    return WF_OK;
+}
+
+unsigned wave_grid(int64_t n_samples) {
+    int64_t blocks = (n_samples + kWaves - 1) / kWaves;
+    const int64_t cap = 256 * 8;   // 8 workgroups of 4 waves per CU
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (unsigned)blocks;
+}
+
+template <int D, class T>
+int run_fwd(const ModelDev* md_dev, const float* tabI4, const float* tabP4, const float* fk_nat, const float* x, int64_t B, float* ws, float* tails,
+            int taped, hipStream_t s) {
+    const int64_t n_samples = B * (T::NC == 3 ? D : 1);
+    hipLaunchKernelGGL((k_wave_fwd<D, T>), dim3(wave_grid(n_samples)), dim3(kWB), 0, s, md_dev, tabI4, tabP4, fk_nat, x, B, ws, tails, taped);
+    return finish();
+}
+template <int D, class T>
+int run_bwd(const ModelDev* md_dev, int mode, const float* tabI4, const float* tabP4, const float* fk_nat, int64_t B, const float* w1, const float* w2,
+            float* ws, const float* tails, hipStream_t s) {
+    const int64_t n_samples = B * (T::NC == 3 ? D : 1);
+    hipLaunchKernelGGL((k_wave_bwd<D, T>), dim3(wave_grid(n_samples)), dim3(kWB), 0, s, md_dev, mode, tabI4, tabP4, fk_nat, B, w1, w2, ws, tails);
+    return finish();
+}
+
+}  // namespace
+
+int64_t wave_tail_floats(int D, int second_order) { return (int64_t)(2 * D + 1) * (second_order ? 3 * D : 1); }   // per walker
+
+#define WF_WAVE_DISPATCH(CALL)                    \
+    switch (md.D) {                               \
+        case 2: return CALL(2);                   \
+        case 3: return CALL(3);                   \
+        case 4: return CALL(4);                   \
+        default: return WF_ERR_UNSUPPORTED;       \
+    }
+
+int launch_wave_fwd(const ModelDev& md, const ModelDev* md_dev, int second_order, const float* tabI4, const float* tabP4, const float* fk_nat,
+                    const float* x, int64_t B, float* ws, float* tails, int taped, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+#define CALL(DD) (second_order ? run_fwd<DD, R3>(md_dev, tabI4, tabP4, fk_nat, x, B, ws, tails, taped, s) \
+                               : run_fwd<DD, R1>(md_dev, tabI4, tabP4, fk_nat, x, B, ws, tails, taped, s))
+    WF_WAVE_DISPATCH(CALL)
+#undef CALL
+}
+
+int launch_wave_bwd(const ModelDev& md, const ModelDev* md_dev, int mode, int second_order, const float* tabI4, const float* tabP4,
+                    const float* fk_nat, int64_t B, const float* w1, const float* w2, float* ws, const float* tails, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+#define CALL(DD) (second_order ? run_bwd<DD, R3>(md_dev, mode, tabI4, tabP4, fk_nat, B, w1, w2, ws, tails, s) \
+                               : run_bwd<DD, R1>(md_dev, mode, tabI4, tabP4, fk_nat, B, w1, w2, ws, tails, s))
+    WF_WAVE_DISPATCH(CALL)
+#undef CALL
+}
+
+int launch_energy_out(int D, const float* tails, const float* x, int64_t B, unsigned constrained_mask, const Protons& pr, float* hpsi, float* psi,
+                      float* lap, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)((B + 255) / 256)), block(256);
+    switch (D) {
+        case 2: hipLaunchKernelGGL(k_energy_out<2>, grid, block, 0, s, tails, x, B, constrained_mask, pr, hpsi, psi, lap); break;
+        case 3: hipLaunchKernelGGL(k_energy_out<3>, grid, block, 0, s, tails, x, B, constrained_mask, pr, hpsi, psi, lap); break;
+        case 4: hipLaunchKernelGGL(k_energy_out<4>, grid, block, 0, s, tails, x, B, constrained_mask, pr, hpsi, psi, lap); break;
+        default: return WF_ERR_UNSUPPORTED;
+    }
+    return finish();
+}
+
+// H psi, psi, laplacian of B walkers: forward in R3 without a tape, then the per-walker combination
+int launch_wave_energy(const ModelDev& md, const ModelDev* md_dev, const float* tabI4, const float* tabP4, const float* fk_nat, const float* x,
+                       int64_t B, const Protons& pr, float* hpsi, float* psi, float* lap, float* tail_ws, void* stream) {
+    int rc = launch_wave_fwd(md, md_dev, 1, tabI4, tabP4, fk_nat, x, B, nullptr, tail_ws, 0, stream);
+    if (rc) return rc;
+    return launch_energy_out(md.D, tail_ws, x, B, md.constrained_mask, pr, hpsi, psi, lap, stream);
+}
+
+}  // namespace wf

@@ -86,6 +86,9 @@ struct wf_model {
     void* d_comp = nullptr;          // composite tables [n_nets][n_mesh] float4
     const float* d_tabI4 = nullptr;  // [4][n_mesh][32]: I-spline derivative orders 0..3 (local energy)
     const float* d_tabP3 = nullptr;  // [4][n_mesh][32]: orthogonal-B derivative orders 0..3 (the energy uses 0..2)
+    float* d_scratch = nullptr;      // private scratch of wf_hamiltonian_fwd (grown on demand)
+    int64_t scratch_floats = 0;
+    float* d_wave = nullptr;         // NetWave images (nbp == 32 only)
     float* d_grad_fk = nullptr;      // [2][64] natural-order row factors for the reverse pass (flow rows, prior rows)
     bool grad_psi_ok = false;        // wf_psi_vjp (Waveflow prior, IMADE layers)
     int32_t* d_grad_map = nullptr;   // [n_nets * fwd image floats]: flat parameter index of each forward-image entry, -1 = none
@@ -160,6 +163,7 @@ static int upload_table(wf_model* m, const std::vector<float>& h, const float** 
 
 static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::vector<double>& p64, const std::vector<double>& o2b);
 static int grad_prepare(wf_model* m);
+static int64_t wave_net_floats(int D);
 
 static int model_build(wf_model* m) {
     const wf_model_desc& d = m->desc;
@@ -336,6 +340,23 @@ static int model_build(wf_model* m) {
         np.W1n = p; p += (int64_t)kHidden * kHidden;
         np.W2n = p;
     }
+    if (m->nbp == 32) {
+        const int P = (D + 1) / 2;
+        rc = dev_alloc(m, &m->d_wave, (size_t)(wave_net_floats(D) * n_nets));
+        if (rc) return rc;
+        for (int n = 0; n < n_nets; ++n) {
+            float* p = m->d_wave + wave_net_floats(D) * n;
+            NetWave& nw = md.wnets[n];
+            nw.W0 = p; p += (int64_t)D * kHidden;
+            nw.b0 = p; p += kHidden;
+            nw.b1 = p; p += kHidden;
+            nw.b2 = p; p += (int64_t)P * 64;
+            nw.W1f = reinterpret_cast<const float4_t*>(p); p += 4096;
+            nw.W1b = reinterpret_cast<const float4_t*>(p); p += 4096;
+            nw.W2f = reinterpret_cast<const float4_t*>(p); p += (int64_t)P * 4096;
+            nw.W2b = reinterpret_cast<const float4_t*>(p);
+        }
+    }
     rc = dev_alloc(m, &m->d_dev, 1);
     if (rc) return rc;
     WF_HIP(hipMemcpy(m->d_dev, &md, sizeof(ModelDev), hipMemcpyHostToDevice));
@@ -386,6 +407,55 @@ static void build_plain_image(const wf_model* m, int n, const float* flat, float
             }
 }
 
+
+// Wave-kernel image of net n (NetWave): W0 [D][64], b0, b1, b2 [P][64], W1f, W1b [16][64][4], W2f, W2b [P][16][64][4]
+static int64_t wave_net_floats(int D) {
+    const int P = (D + 1) / 2;
+    return (int64_t)D * kHidden + 2 * kHidden + (int64_t)P * 64 + 2 * 4096 + (int64_t)P * 2 * 4096;
+}
+
+static void build_wave_image(const wf_model* m, int n, const float* flat, float* img) {
+    const int D = m->desc.n_dim, H = kHidden, P = (D + 1) / 2;
+    const NetLayout& nl = m->nets[n];
+    const int NO = nl.n_out * D;
+    const float* W0 = flat + nl.offset;
+    const float* b0 = W0 + (int64_t)D * H;
+    const float* W1 = b0 + H;
+    const float* b1 = W1 + (int64_t)H * H;
+    const float* W2 = b1 + H;
+    const float* b2 = W2 + (int64_t)H * NO;
+    auto w1m = [&](int a, int j) { return deg_hidden(j, D) >= deg_hidden(a, D) ? W1[(int64_t)a * H + j] : 0.0f; };
+    // column of output lane c of pass p: (d, jb) = (2p + (c >> 5), c & 31)
+    auto w2m = [&](int a, int p, int c) {
+        const int d = 2 * p + (c >> 5), jb = c & 31;
+        if (d >= D || jb >= nl.n_out || deg_out(d) < deg_hidden(a, D)) return 0.0f;
+        return W2[(int64_t)a * NO + (jb * D + d)];
+    };
+    float* o = img;
+    for (int a = 0; a < D; ++a)
+        for (int j = 0; j < H; ++j) *o++ = deg_hidden(j, D) >= deg_in(a) ? W0[(int64_t)a * H + j] : 0.0f;
+    for (int j = 0; j < H; ++j) *o++ = b0[j];
+    for (int j = 0; j < H; ++j) *o++ = b1[j];
+    for (int p = 0; p < P; ++p)
+        for (int c = 0; c < 64; ++c) {
+            const int d = 2 * p + (c >> 5), jb = c & 31;
+            *o++ = (d < D && jb < nl.n_out) ? b2[jb * D + d] : 0.0f;
+        }
+    for (int g = 0; g < 16; ++g)
+        for (int j = 0; j < 64; ++j)
+            for (int e = 0; e < 4; ++e) *o++ = w1m(4 * g + e, j);
+    for (int g = 0; g < 16; ++g)
+        for (int a = 0; a < 64; ++a)
+            for (int e = 0; e < 4; ++e) *o++ = w1m(a, 4 * g + e);
+    for (int p = 0; p < P; ++p)
+        for (int g = 0; g < 16; ++g)
+            for (int c = 0; c < 64; ++c)
+                for (int e = 0; e < 4; ++e) *o++ = w2m(4 * g + e, p, c);
+    for (int p = 0; p < P; ++p)
+        for (int g = 0; g < 16; ++g)
+            for (int a = 0; a < 64; ++a)
+                for (int e = 0; e < 4; ++e) *o++ = w2m(a, p, 4 * g + e);
+}
 
 // ---------------------------------------------------------------------------- MFMA kernel images
 static inline int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -784,6 +854,13 @@ int wf_model_set_params(wf_model* m, const float* flat_host, int64_t n, void* st
     for (size_t i = 0; i < m->nets.size(); ++i) build_plain_image(m, (int)i, flat_host, img.data() + m->plain_off[i]);
     hipStream_t s = (hipStream_t)stream;
     if (!img.empty()) WF_HIP(hipMemcpyAsync(m->d_plain, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice, s));
+    std::vector<float> wimg;
+    if (m->d_wave) {
+        const int64_t wf = wave_net_floats(m->desc.n_dim);
+        wimg.resize((size_t)(wf * (int64_t)m->nets.size()));
+        for (size_t i = 0; i < m->nets.size(); ++i) build_wave_image(m, (int)i, flat_host, wimg.data() + wf * (int64_t)i);
+        if (!wimg.empty()) WF_HIP(hipMemcpyAsync(m->d_wave, wimg.data(), wimg.size() * sizeof(float), hipMemcpyHostToDevice, s));
+    }
     std::vector<float> mimg;
     if (m->mfma_ok) {
         mimg.assign((size_t)m->mfma_floats, 0.0f);
@@ -865,50 +942,100 @@ int wf_sample(const wf_model* m, uint64_t seed, int64_t B, float* x_dev, float* 
     return launch_scalar_sample(m->dev, m->d_dev, (unsigned long long)seed, B, x_dev, latent_dev, exact, stream);
 }
 
+// grows the model's private device scratch (tails of the wave kernels when the caller passes no workspace)
+static int ensure_scratch(const wf_model* cm, int64_t floats) {
+    wf_model* m = const_cast<wf_model*>(cm);
+    if (m->scratch_floats >= floats) return WF_OK;
+    if (m->d_scratch) {
+        WF_HIP(hipDeviceSynchronize());
+        (void)hipFree(m->d_scratch);
+        m->allocs.erase(std::remove(m->allocs.begin(), m->allocs.end(), (void*)m->d_scratch), m->allocs.end());
+        m->d_scratch = nullptr;
+        m->scratch_floats = 0;
+    }
+    int rc = dev_alloc(m, &m->d_scratch, (size_t)floats);
+    if (rc) return rc;
+    m->scratch_floats = floats;
+    return WF_OK;
+}
+
 int wf_hamiltonian_fwd(const wf_model* m, const float* x_dev, int64_t B, const float* protons_host, int32_t n_protons, float* hpsi_dev,
                        float* psi_dev, float* laplacian_dev, void* stream) {
     int rc = check_fwd(m, x_dev, B, hpsi_dev);
     if (rc) return rc;
     if (n_protons < 0 || n_protons > 8 || (n_protons > 0 && !protons_host)) return WF_ERR_INVALID;
     if (m->desc.prior_kind != WF_PRIOR_WAVEFLOW) return WF_ERR_INVALID;
-    if (m->desc.layer_kind != WF_LAYER_IMADE || !m->d_tabI4 || !m->d_tabP3 || m->desc.n_dim > 4) return WF_ERR_UNSUPPORTED;
+    if (m->desc.layer_kind != WF_LAYER_IMADE || !m->d_tabI4 || !m->d_tabP3 || !m->d_grad_fk || m->desc.n_dim > 4) return WF_ERR_UNSUPPORTED;
     Protons pr{};
     pr.n = n_protons;
     for (int i = 0; i < n_protons; ++i) pr.pos[i] = protons_host[i];
     DeviceGuard g(m->device);
     if (B == 0) return WF_OK;
-    return launch_energy(m->dev, m->d_dev, m->d_tabI4, m->d_tabP3, x_dev, B, pr, hpsi_dev, psi_dev, laplacian_dev, stream);
+    const int D = m->desc.n_dim;
+    const int64_t chunk = std::min<int64_t>(B, (int64_t)1 << 20);
+    rc = ensure_scratch(m, chunk * wave_tail_floats(D, 1));
+    if (rc) return rc;
+    for (int64_t c0 = 0; c0 < B; c0 += chunk) {
+        const int64_t bc = std::min(chunk, B - c0);
+        rc = launch_wave_energy(m->dev, m->d_dev, m->d_tabI4, m->d_tabP3, m->d_grad_fk, x_dev + c0 * D, bc, pr, hpsi_dev + c0,
+                                psi_dev ? psi_dev + c0 : nullptr, laplacian_dev ? laplacian_dev + c0 : nullptr, m->d_scratch, stream);
+        if (rc) return rc;
+    }
+    return WF_OK;
 }
 
-static int64_t vjp_bytes_per_sample(const wf_model* m, int nc) {
-    return (int64_t)m->nets.size() * grad_ws_rows(m->desc.n_dim) * nc * (int64_t)sizeof(float);
+// workspace of the reverse pass per walker: tape + tails of its samples, plus 4 floats (H psi, psi, w_psi, w_lap)
+static int64_t vjp_bytes_per_walker(const wf_model* m, bool second_order) {
+    const int D = m->desc.n_dim;
+    const int64_t samples = second_order ? D : 1, nc = second_order ? 3 : 1;
+    return (samples * ((int64_t)m->nets.size() * grad_ws_rows(D) * nc) + wave_tail_floats(D, second_order ? 1 : 0) + 4) * (int64_t)sizeof(float);
 }
 
 static int64_t vjp_ws_bytes(const wf_model* m, int64_t B, bool second_order) {
     if (!m || B < 0) return WF_ERR_INVALID;
     if (!m->d_grad_map || (second_order && !m->grad_psi_ok)) return WF_ERR_UNSUPPORTED;
     const int64_t chunk = std::min<int64_t>(std::max<int64_t>(B, 1), 32768);
-    const int64_t S = (chunk * (second_order ? m->desc.n_dim : 1) + 63) / 64 * 64;
-    return S * vjp_bytes_per_sample(m, second_order ? 3 : 1);
+    return chunk * vjp_bytes_per_walker(m, second_order);
 }
 
-// mode 0: log_pdf, w1 only;  mode 1: psi (w1) and, with second_order, its Laplacian (w2)
+// mode 0: log_pdf, w1 only;  mode 1: psi (w1) and, with second_order, its Laplacian (w2);
+// mode 2: loss_fn_efficient (vqmc.py:193-212): the weights come from H psi of the same forward sweep, e_loc_dev is written
 static int run_vjp_chunks(const wf_model* m, int mode, bool second_order, const float* x_dev, int64_t B, const float* w1, const float* w2,
-                          float* grad_dev, void* workspace_dev, int64_t workspace_bytes, void* stream) {
+                          const Protons* pr, float running_average, float inv_count, float* e_loc_dev, float* grad_dev, void* workspace_dev,
+                          int64_t workspace_bytes, void* stream) {
     const int D = m->desc.n_dim;
-    const int64_t S = workspace_bytes / vjp_bytes_per_sample(m, second_order ? 3 : 1) / 64 * 64;   // samples per chunk
-    const int64_t chunk = S / (second_order ? D : 1);
+    const int64_t chunk = workspace_bytes / vjp_bytes_per_walker(m, second_order);
     if (B > 0 && chunk < 1) return WF_ERR_INVALID;
     DeviceGuard g(m->device);
     hipStream_t s = (hipStream_t)stream;
+    const int n_nets = (int)m->nets.size();
     const int64_t fwd = plain_fwd_floats(D, m->nbp);
-    const int64_t n_img = fwd * (int64_t)m->nets.size();
+    const int64_t n_img = fwd * n_nets;
+    const int64_t samples_per = second_order ? D : 1, nc = second_order ? 3 : 1;
+    float* tape = (float*)workspace_dev;
+    float* tails = tape + chunk * samples_per * n_nets * grad_ws_rows(D) * nc;
+    float* per_walker = tails + chunk * wave_tail_floats(D, second_order ? 1 : 0);   // [4][chunk]
     WF_HIP(hipMemsetAsync(m->d_grad_img, 0, (size_t)n_img * sizeof(float), s));
     WF_HIP(hipMemsetAsync(grad_dev, 0, (size_t)m->n_params * sizeof(float), s));
     for (int64_t c0 = 0; c0 < B; c0 += chunk) {
         const int64_t bc = std::min(chunk, B - c0);
-        int rc = launch_vjp(m->dev, m->d_dev, mode, second_order ? 1 : 0, m->d_tabI4, m->d_tabP3, m->d_grad_fk, x_dev + c0 * D, bc, w1 + c0,
-                            w2 ? w2 + c0 : nullptr, (float*)workspace_dev, S, m->d_grad_img, fwd, stream);
+        const float* x = x_dev + c0 * D;
+        int rc = launch_wave_fwd(m->dev, m->d_dev, second_order ? 1 : 0, m->d_tabI4, m->d_tabP3, m->d_grad_fk, x, bc, tape, tails, 1, stream);
+        if (rc) return rc;
+        const float *cw1 = w1 ? w1 + c0 : nullptr, *cw2 = w2 ? w2 + c0 : nullptr;
+        if (mode == 2) {
+            float *hpsi = per_walker, *psi = per_walker + chunk, *wp = per_walker + 2 * chunk, *wl = per_walker + 3 * chunk;
+            rc = launch_energy_out(D, tails, x, bc, m->dev.constrained_mask, *pr, hpsi, psi, nullptr, stream);
+            if (rc) return rc;
+            rc = launch_vqmc_seeds(x, bc, D, *pr, hpsi, psi, running_average, inv_count, e_loc_dev + c0, wp, wl, stream);
+            if (rc) return rc;
+            cw1 = wp;
+            cw2 = wl;
+        }
+        rc = launch_wave_bwd(m->dev, m->d_dev, mode == 0 ? 0 : 1, second_order ? 1 : 0, m->d_tabI4, m->d_tabP3, m->d_grad_fk, bc, cw1, cw2, tape,
+                             tails, stream);
+        if (rc) return rc;
+        rc = launch_wgrad(D, second_order ? 1 : 0, n_nets, bc * samples_per, tape, m->d_grad_img, fwd, stream);
         if (rc) return rc;
     }
     return launch_grad_scatter(m->d_grad_img, m->d_grad_map, n_img, grad_dev, stream);
@@ -924,7 +1051,7 @@ int wf_psi_vjp(const wf_model* m, const float* x_dev, int64_t B, const float* w_
     if (!grad_dev) return WF_ERR_INVALID;
     if (!m->d_grad_map || !m->grad_psi_ok) return WF_ERR_UNSUPPORTED;
     if (B > 0 && (!w_psi_dev || !w_lap_dev || !workspace_dev)) return WF_ERR_INVALID;
-    return run_vjp_chunks(m, 1, true, x_dev, B, w_psi_dev, w_lap_dev, grad_dev, workspace_dev, workspace_bytes, stream);
+    return run_vjp_chunks(m, 1, true, x_dev, B, w_psi_dev, w_lap_dev, nullptr, 0.0f, 0.0f, nullptr, grad_dev, workspace_dev, workspace_bytes, stream);
 }
 
 int wf_logpdf_vjp(const wf_model* m, const float* x_dev, int64_t B, const float* w_dev, float* grad_dev, void* workspace_dev,
@@ -934,7 +1061,22 @@ int wf_logpdf_vjp(const wf_model* m, const float* x_dev, int64_t B, const float*
     if (!grad_dev) return WF_ERR_INVALID;
     if (!m->d_grad_map) return WF_ERR_UNSUPPORTED;
     if (B > 0 && (!w_dev || !workspace_dev)) return WF_ERR_INVALID;
-    return run_vjp_chunks(m, 0, false, x_dev, B, w_dev, nullptr, grad_dev, workspace_dev, workspace_bytes, stream);
+    return run_vjp_chunks(m, 0, false, x_dev, B, w_dev, nullptr, nullptr, 0.0f, 0.0f, nullptr, grad_dev, workspace_dev, workspace_bytes, stream);
+}
+
+int wf_vqmc_loss_grad(const wf_model* m, const float* x_dev, int64_t B, const float* protons_host, int32_t n_protons, float running_average,
+                      float inv_count, float* e_loc_dev, float* grad_dev, void* workspace_dev, int64_t workspace_bytes, void* stream) {
+    int rc = check_fwd(m, x_dev, B, grad_dev);
+    if (rc) return rc;
+    if (!grad_dev) return WF_ERR_INVALID;
+    if (n_protons < 0 || n_protons > 8 || (n_protons > 0 && !protons_host)) return WF_ERR_INVALID;
+    if (!m->d_grad_map || !m->grad_psi_ok) return WF_ERR_UNSUPPORTED;
+    if (B > 0 && (!e_loc_dev || !workspace_dev)) return WF_ERR_INVALID;
+    Protons pr{};
+    pr.n = n_protons;
+    for (int i = 0; i < n_protons; ++i) pr.pos[i] = protons_host[i];
+    return run_vjp_chunks(m, 2, true, x_dev, B, nullptr, nullptr, &pr, running_average, inv_count, e_loc_dev, grad_dev, workspace_dev, workspace_bytes,
+                          stream);
 }
 
 int wf_vqmc_seeds(const float* x_dev, int64_t B, int32_t n_dim, const float* protons_host, int32_t n_protons, const float* hpsi_dev,

@@ -1,0 +1,118 @@
+// wf_ring.h -- the coefficient rings of the gradient / local-energy kernels and the ring lift of the table lerp.
+//
+// R3 = IR[t]/t^3 holds the Taylor coefficients a0 + a1 t + a2 t^2 of a quantity along one coordinate direction
+// x + t e_i (psi'' along e_i = 2 psi_2); R1 = IR is the first-order case.  Adjoints are kept in REVERSED coefficient order,
+// which makes the adjoint of a ring product a ring product (see wf_kernels_wave.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "wf_internal.h"
+
+namespace wf {
+namespace ring {
+
+constexpr int NBP = 32;
+
+// Rows of one net in the tape of the reverse pass ([sample][net][coefficient][row]): layer input U (D rows in a slot of 4),
+// hidden activations H1, H2, pre-activation adjoints A1, A2, head-output adjoints O (row d * 32 + j).  Every group starts
+// at a multiple of 4 rows so that k_wgrad can stage with 16-byte loads.
+template <int D> struct Rows {
+    static constexpr int U = 0, H1 = 4, H2 = 4 + 64, A1 = 4 + 128, A2 = 4 + 192, O = 4 + 256, N = 4 + 256 + D * NBP;
+};
+
+// ---- the rings: R3 = IR[t]/t^3 (Taylor coefficients) for psi and its Laplacian, R1 = IR for first-order objectives
+struct R1 {
+    float c0;
+    static constexpr int NC = 1;
+};
+struct R3 {
+    float c0, c1, c2;
+    static constexpr int NC = 3;
+};
+template <class T> __device__ __forceinline__ T cst(float c);
+template <> __device__ __forceinline__ R1 cst<R1>(float c) { return R1{c}; }
+template <> __device__ __forceinline__ R3 cst<R3>(float c) { return R3{c, 0.0f, 0.0f}; }
+__device__ __forceinline__ R1 operator+(R1 a, R1 b) { return R1{a.c0 + b.c0}; }
+__device__ __forceinline__ R1 operator-(R1 a, R1 b) { return R1{a.c0 - b.c0}; }
+__device__ __forceinline__ R1 operator+(R1 a, float c) { return R1{a.c0 + c}; }
+__device__ __forceinline__ R1 operator-(R1 a, float c) { return R1{a.c0 - c}; }
+__device__ __forceinline__ R1 operator-(float c, R1 a) { return R1{c - a.c0}; }
+__device__ __forceinline__ R1 operator*(R1 a, float c) { return R1{a.c0 * c}; }
+__device__ __forceinline__ R1 operator*(R1 a, R1 b) { return R1{a.c0 * b.c0}; }
+__device__ __forceinline__ R3 operator+(R3 a, R3 b) { return R3{a.c0 + b.c0, a.c1 + b.c1, a.c2 + b.c2}; }
+__device__ __forceinline__ R3 operator-(R3 a, R3 b) { return R3{a.c0 - b.c0, a.c1 - b.c1, a.c2 - b.c2}; }
+__device__ __forceinline__ R3 operator+(R3 a, float c) { return R3{a.c0 + c, a.c1, a.c2}; }
+__device__ __forceinline__ R3 operator-(R3 a, float c) { return R3{a.c0 - c, a.c1, a.c2}; }
+__device__ __forceinline__ R3 operator-(float c, R3 a) { return R3{c - a.c0, -a.c1, -a.c2}; }
+__device__ __forceinline__ R3 operator*(R3 a, float c) { return R3{a.c0 * c, a.c1 * c, a.c2 * c}; }
+__device__ __forceinline__ R3 operator*(R3 a, R3 b) {
+    return R3{a.c0 * b.c0, a.c1 * b.c0 + a.c0 * b.c1, a.c2 * b.c0 + a.c1 * b.c1 + a.c0 * b.c2};
+}
+// f(a) from f, f', f'' at a.c0
+__device__ __forceinline__ R1 lift_fn(R1, float f, float, float) { return R1{f}; }
+__device__ __forceinline__ R3 lift_fn(R3 a, float f, float f1, float f2) { return R3{f, f1 * a.c1, f1 * a.c2 + 0.5f * f2 * a.c1 * a.c1}; }
+template <class T> __device__ __forceinline__ T rrcp(T a) {
+    const float r = 1.0f / a.c0;
+    return lift_fn(a, r, -r * r, 2.0f * r * r * r);
+}
+template <class T> __device__ __forceinline__ T rexp(T a) {
+    const float e = expf(a.c0);
+    return lift_fn(a, e, e, e);
+}
+template <class T> __device__ __forceinline__ T rlog(T a) {
+    const float r = 1.0f / a.c0;
+    return lift_fn(a, logf(a.c0), r, -r * r);
+}
+template <class T> __device__ __forceinline__ T rrsqrt(T a) {   // a^(-1/2)
+    const float s = 1.0f / sqrtf(a.c0), r = 1.0f / a.c0;
+    return lift_fn(a, s, -0.5f * s * r, 0.75f * s * r * r);
+}
+template <class T> __device__ __forceinline__ T rtanh(T a) {
+    const float t = tanhf(a.c0), g = 1.0f - t * t;
+    return lift_fn(a, t, g, -2.0f * t * g);
+}
+template <class T> __device__ __forceinline__ T rsigmoid(T a) {
+    const float s = 1.0f / (1.0f + expf(-a.c0)), g = s * (1.0f - s);
+    return lift_fn(a, s, g, g * (1.0f - 2.0f * s));
+}
+// the coordinate x_d along direction `dir`; adjoint seed of the value coefficient (reversed order: last slot)
+__device__ __forceinline__ R1 make_var(R1*, float x, bool) { return R1{x}; }
+__device__ __forceinline__ R3 make_var(R3*, float x, bool along) { return R3{x, along ? 1.0f : 0.0f, 0.0f}; }
+__device__ __forceinline__ R1 adj_value(R1*, float w) { return R1{w}; }
+__device__ __forceinline__ R3 adj_value(R3*, float w) { return R3{0.0f, 0.0f, w}; }
+// ... and of the second-derivative along the direction (psi'' = 2 psi_2)
+__device__ __forceinline__ R1 adj_second(R1*, float) { return R1{0.0f}; }
+__device__ __forceinline__ R3 adj_second(R3*, float w) { return R3{2.0f * w, 0.0f, 0.0f}; }
+
+// ---- table lerp (same index arithmetic as the evaluation kernels) and its ring lift
+struct Lerp {
+    int il, ir;
+    float dx, n;
+};
+__device__ __forceinline__ int wrap_clamp(int i, int n) {
+    if (i < 0) i += n;
+    return min(max(i, 0), n - 1);
+}
+__device__ __forceinline__ Lerp make_lerp(float x0, int n_mesh) {
+    const int n_points = n_mesh - 1;
+    const float xs = x0 * (float)n_points;
+    const int xl = (int)floorf(xs), xr = (int)ceilf(xs);
+    return Lerp{wrap_clamp(xl, n_mesh), wrap_clamp(xr, n_mesh), x0 - (float)xl / (float)n_points, (float)n_points};
+}
+// t[o] = order-o lerp of basis j, o = 0..3; tab [4][n_mesh][NBP]
+__device__ __forceinline__ void lerp4(const float* __restrict__ tab, size_t plane, const Lerp& L, int j, float (&t)[4]) {
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        const float yl = tab[o * plane + (size_t)L.il * NBP + j], yr = tab[o * plane + (size_t)L.ir * NBP + j];
+        t[o] = yl + ((yr - yl) * L.n) * L.dx;
+    }
+}
+// ring value of the order-nd basis at the ring point u (orders beyond 3 clamp to 3)
+__device__ __forceinline__ R1 lift(const float (&t)[4], int nd, R1) { return R1{t[min(nd, 3)]}; }
+__device__ __forceinline__ R3 lift(const float (&t)[4], int nd, R3 u) {
+    const float t0 = t[min(nd, 3)], t1 = t[min(nd + 1, 3)], t2 = t[min(nd + 2, 3)];
+    return R3{t0, t1 * u.c1, t1 * u.c2 + 0.5f * t2 * u.c1 * u.c1};
+}
+
+}  // namespace ring
+}  // namespace wf
