@@ -136,6 +136,8 @@ int launch_wave_bwd(const ModelDev& md, const ModelDev* md_dev, int mode, int se
                     const float* fk_nat, int64_t B, const float* w1, const float* w2, float* ws, const float* tails, void* stream);
 int launch_wave_energy(const ModelDev& md, const ModelDev* md_dev, const float* tabI4, const float* tabP4, const float* fk_nat, const float* x,
                        int64_t B, const Protons& pr, float* hpsi, float* psi, float* lap, float* tail_ws, void* stream);
+int launch_wave_sample(const ModelDev& md, const ModelDev* md_dev, const float* tabI4, const float* tabP4, const float* fk_nat, int draw,
+                       unsigned long long seed, const float* u, int64_t B, float* x, float* latent, int exact, void* stream);
 int64_t wave_tail_floats(int D, int second_order);
 int launch_energy_out(int D, const float* tails, const float* x, int64_t B, unsigned constrained_mask, const Protons& pr, float* hpsi, float* psi,
                       float* lap, void* stream);

@@ -18,6 +18,7 @@
 
 #include "wf_internal.h"
 #include "wf_ring.h"
+#include "wf_scalar_impl.h"   // Philox4x32-10 and the box reverse (shared with the one-lane-per-walker sampler)
 
 namespace wf {
 
@@ -625,6 +626,174 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(WF_WAVE_OCC
     }
 }
 
+// ------------------------------------------------------------------------------------------------ inverse / sampler
+// Serial.inverse_fun (bijections.py:462-463), IMADE.inverse_fun (made.py:85-100, helpers.binary_search), MADE.inverse_fun
+// (made.py:29-37), the box reverse (made.py:139-154, 186-197) and the samplers of Waveflow (wavefunctions.py:74-107,
+// bsplines_jax.py:144-171), MFlow (distributions.py:165-190, msplines_jax.py:129-154) and Flow (distributions.py:104-108), one
+// wave per walker.  Every lane runs the same Philox stream (keyed by seed and walker, as in wf_kernels_scalar.hip), so the
+// accept / bisection decisions are wave-uniform.
+__device__ __forceinline__ float hmax(float v) {
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true)));
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 3" : "+v"(a), "+v"(b));
+    return fmaxf(a, b);
+}
+// value held by the lanes of half `h`, in every lane
+__device__ __forceinline__ float of_half(float v, int h, int dl) {
+    const float o = swap32_other(v);
+    return dl == h ? v : o;
+}
+// order-0 lerp of basis row j (tab: [orders][n_mesh][32])
+__device__ __forceinline__ float lerp0(const float* __restrict__ tab, const Lerp& L, int j) {
+    const float yl = tab[(size_t)L.il * NBP + j], yr = tab[(size_t)L.ir * NBP + j];
+    return yl + ((yr - yl) * L.n) * L.dx;
+}
+
+template <int D>
+__device__ __forceinline__ void wave_serial_inverse(const ModelDev& md, const float* __restrict__ tabI, const float* __restrict__ gI, float (&cur)[D],
+                                                    float (*vec)[64], int lane, int exact) {
+    const int dl = lane >> 5, j = lane & 31;
+    const Tape no_tape{nullptr, 0};
+    float nxt[D];
+    for (int l = md.n_layers - 1; l >= 0; --l) {
+        const NetWave& net = md.wnets[l];
+#pragma unroll
+        for (int d = 0; d < D; ++d) nxt[d] = cur[D - 1 - d];   // Reverse.inverse_fun
+#pragma unroll
+        for (int d = 0; d < D; ++d) cur[d] = 0.0f;
+        if (md.layer_kind == WF_LAYER_IMADE) {
+            const int nb = md.isp.nb, n_mesh = md.isp.n_mesh;
+            const float tol = md.reverse_tol;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                if (d == 0 || exact) {
+                    R1 xin[D];
+#pragma unroll
+                    for (int a = 0; a < D; ++a) xin[a] = R1{exact ? cur[a] : nxt[a]};
+                    hidden_fwd<D, R1>(net, xin, vec, lane, no_tape, 0, false);
+                }
+                const int p = d >> 1, hd = d & 1;
+                const R1 o = gemv<R1>(net.W2f + p * 1024, vec, lane) + net.b2[p * 64 + lane];
+                const bool valid_d = 2 * p + dl < D, valid = valid_d && j < nb;
+                const SigHead<R1> hdw = sigmoid_head(o, valid, valid_d, gI[j], md.i_reg);
+                const float y = nxt[d];
+                float low = 0.0f, high = 1.0f;
+                for (int it = 0; it < 64; ++it) {   // helpers.binary_search
+                    const float mid = 0.5f * (low + high);
+                    if (!((low + tol / 2 < mid) && (mid < high - tol / 2))) break;
+                    const Lerp L = make_lerp(mid, n_mesh);
+                    const float f = of_half(hsum(hdw.c.c0 * lerp0(tabI, L, j)), hd, dl) - y;
+                    if (f > 0) high = mid; else low = mid;
+                }
+                cur[d] = low;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < D; ++c) {
+                R1 xin[D];
+#pragma unroll
+                for (int a = 0; a < D; ++a) xin[a] = R1{cur[a]};
+                hidden_fwd<D, R1>(net, xin, vec, lane, no_tape, 0, false);
+                const int p = c >> 1, hd = c & 1;
+                const R1 o = gemv<R1>(net.W2f + p * 1024, vec, lane) + net.b2[p * 64 + lane];
+                const float lw = __shfl(o.c0, hd * 32), bias = __shfl(o.c0, hd * 32 + 1);
+                cur[c] = nxt[c] * expf(lw) + bias;
+            }
+        }
+    }
+    if (md.box_kind != WF_BOX_NONE) {
+        scalar::box_reverse<D>(md, cur, nxt);
+#pragma unroll
+        for (int d = 0; d < D; ++d) cur[d] = nxt[d];
+    }
+}
+
+// seed_mode 0: invert the latent points ug;  1: draw the latent points from the prior first (and report them)
+template <int D>
+__global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(WF_WAVE_OCC, WF_WAVE_OCC))) void k_wave_sample(
+    const ModelDev* __restrict__ mdp, const float* __restrict__ tabI, const float* __restrict__ tabP, const float* __restrict__ fk_nat, int draw,
+    unsigned long long seed, const float* __restrict__ ug, int64_t B, float* __restrict__ xg, float* __restrict__ latent, int exact) {
+    __shared__ float lds[kWaves][2][1][64];
+    const ModelDev& md = *mdp;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float (*vec)[64] = lds[wv][0];
+    float (*ov)[64] = lds[wv][1];
+    const int dl = lane >> 5, j = lane & 31;
+    const float* __restrict__ gI = fk_nat;
+    const float* __restrict__ kP = fk_nat + 64;
+    const Tape no_tape{nullptr, 0};
+    for (int64_t b = (int64_t)blockIdx.x * kWaves + wv; b < B; b += (int64_t)gridDim.x * kWaves) {
+        float cur[D];
+        if (!draw) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) cur[d] = ug[b * D + d];
+        } else {
+            scalar::Philox rng(seed, (unsigned long long)b);
+#pragma unroll
+            for (int d = 0; d < D; ++d) cur[d] = 0.0f;
+            if (md.prior_kind == WF_PRIOR_UNIFORM) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) cur[d] = rng.uniform();
+            } else if (md.prior_kind == WF_PRIOR_NORMAL) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) {   // Box-Muller
+                    const float u1 = fmaxf(rng.uniform(), 5.9604645e-8f), u2 = rng.uniform();
+                    cur[d] = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+                }
+            } else {
+                const NetWave& net = md.wnets[md.n_layers];
+                const int nb = md.psp.nb, n_mesh = md.psp.n_mesh;
+                const bool wavefn = md.prior_kind == WF_PRIOR_WAVEFLOW;
+#pragma unroll
+                for (int col = 0; col < D; ++col) {
+                    R1 xin[D];
+#pragma unroll
+                    for (int a = 0; a < D; ++a) xin[a] = R1{cur[a]};   // conditioner on the columns drawn so far, zeros elsewhere
+                    hidden_fwd<D, R1>(net, xin, vec, lane, no_tape, 0, false);
+                    const int p = col >> 1, hd = col & 1;
+                    const R1 o = gemv<R1>(net.W2f + p * 1024, vec, lane) + net.b2[p * 64 + lane];
+                    const bool valid_d = 2 * p + dl < D, valid = valid_d && j < nb;
+                    float cj, ymax;
+                    if (wavefn) {
+                        // sample_fun (bsplines_jax.py:144-171): obw = normalised(w @ ob_to_b); ymax = max((obw @ b_to_ob)^2)
+                        const PsiHead<R1> hdw = psi_head(o, valid, valid_d, kP[j], md.ob_to_b, ov, lane);
+                        cj = hdw.e.c0;
+                        put(ov, lane, hdw.e);
+                        const float q = gemv32_cols<R1>(md.b_to_ob, ov, dl, j).c0;
+                        ymax = of_half(hmax(valid ? q * q : 0.0f), hd, dl);
+                    } else {
+                        const SigHead<R1> hdw = sigmoid_head(o, valid, valid_d, kP[j], 0.0f);
+                        cj = hdw.c.c0;
+                        ymax = of_half(hmax(valid ? cj : 0.0f), hd, dl) * (float)(nb + md.psp.degree);   // msplines_jax.py:147-150
+                    }
+                    // rejection sampling (bounded: a pathological density cannot hang the GPU)
+                    float xs = 0.5f;
+                    for (int it = 0; it < 100000; ++it) {
+                        const float xc = rng.uniform(), yc = rng.uniform() * ymax;
+                        const Lerp L = make_lerp(xc, n_mesh);
+                        float v = of_half(hsum(cj * lerp0(tabP, L, j)), hd, dl);
+                        if (wavefn) v = v * v;
+                        if (yc < v) { xs = xc; break; }
+                    }
+                    cur[col] = xs;
+                }
+            }
+            if (latent && lane < D) {
+#pragma unroll
+                for (int d = 0; d < D; ++d)
+                    if (lane == d) latent[b * D + d] = cur[d];
+            }
+        }
+        wave_serial_inverse<D>(md, tabI, gI, cur, vec, lane, exact);
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+            if (lane == d) xg[b * D + d] = cur[d];
+    }
+}
+
 int finish() {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -685,6 +854,27 @@ int launch_wave_bwd(const ModelDev& md, const ModelDev* md_dev, int mode, int se
                                : run_bwd<DD, R1>(md_dev, mode, tabI4, tabP4, fk_nat, B, w1, w2, ws, tails, s))
     WF_WAVE_DISPATCH(CALL)
 #undef CALL
+}
+
+// draw == 0: x = inverse(u);  draw == 1: latent ~ prior, x = inverse(latent)
+int launch_wave_sample(const ModelDev& md, const ModelDev* md_dev, const float* tabI4, const float* tabP4, const float* fk_nat, int draw,
+                       unsigned long long seed, const float* u, int64_t B, float* x, float* latent, int exact, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+#define CALL(DD)                                                                                                                          \
+    hipLaunchKernelGGL(k_wave_sample<DD>, dim3(wave_grid(B)), dim3(kWB), 0, s, md_dev, tabI4, tabP4, fk_nat, draw, seed, u, B, x, latent, exact); \
+    break
+    switch (md.D) {
+        case 2: CALL(2);
+        case 3: CALL(3);
+        case 4: CALL(4);
+        case 5: CALL(5);
+        case 6: CALL(6);
+        case 7: CALL(7);
+        case 8: CALL(8);
+        default: return WF_ERR_UNSUPPORTED;
+    }
+#undef CALL
+    return finish();
 }
 
 int launch_energy_out(int D, const float* tails, const float* x, int64_t B, unsigned constrained_mask, const Protons& pr, float* hpsi, float* psi,

@@ -90,6 +90,7 @@ struct wf_model {
     int64_t scratch_floats = 0;
     float* d_wave = nullptr;         // NetWave images (nbp == 32 only)
     float* d_grad_fk = nullptr;      // [2][64] natural-order row factors for the reverse pass (flow rows, prior rows)
+    bool wave_ok = false;            // the wave-cooperative kernels cover this model (<= 32 bases, zero-only constraints)
     bool grad_psi_ok = false;        // wf_psi_vjp (Waveflow prior, IMADE layers)
     int32_t* d_grad_map = nullptr;   // [n_nets * fwd image floats]: flat parameter index of each forward-image entry, -1 = none
     float* d_grad_img = nullptr;     // [n_nets * fwd image floats]: gradient accumulator in forward-image layout
@@ -695,24 +696,26 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
     return WF_OK;
 }
 
-// The reverse pass (wf_kernels_grad.hip): <= 32 bases, D <= 4, constraints that only zero the end weights.
-static bool grad_capable(const wf_model* m) {
+// The wave-cooperative kernels (wf_kernels_wave.hip): <= 32 bases, constraints that only zero the end weights.
+static bool wave_capable(const wf_model* m) {
     const wf_model_desc& d = m->desc;
-    if (m->nbp != 32 || d.n_dim > 4 || m->nets.empty()) return false;
+    if (m->nbp != 32 || !m->d_wave) return false;
     const bool imade = d.layer_kind == WF_LAYER_IMADE && d.n_flow_layers > 0;
     if (imade && (!m->d_tabI4 || !bc_only_zeroes(d.i_left, d.i_right, true))) return false;
     const bool spline_prior = d.prior_kind == WF_PRIOR_WAVEFLOW || d.prior_kind == WF_PRIOR_MFLOW;
     if (spline_prior && (!m->d_tabP3 || !bc_only_zeroes(d.p_left, d.p_right, false))) return false;
     return true;
 }
+// ... of which the reverse pass and the local energy are instantiated for D <= 4
+static bool grad_capable(const wf_model* m) { return m->wave_ok && m->desc.n_dim <= 4 && !m->nets.empty(); }
 
 // Index map forward-image entry -> flat parameter: push the code "index + 1" through the image builder; masked and
 // padding entries come out as 0 (no parameter).
 static int grad_prepare(wf_model* m) {
-    if (!grad_capable(m) || m->n_params >= (1 << 24)) return WF_OK;
     const wf_model_desc& d = m->desc;
     const int D = d.n_dim;
-    {
+    m->wave_ok = wave_capable(m);
+    if (m->wave_ok) {
         std::vector<float> fk(128, 0.0f), acc(64);
         if (d.layer_kind == WF_LAYER_IMADE && d.n_flow_layers > 0)
             row_factors(WF_SPLINE_I, true, d.i_degree, m->i_nb, 1, d.i_left, d.i_right, acc.data(), fk.data());
@@ -722,6 +725,7 @@ static int grad_prepare(wf_model* m) {
         if (rc) return rc;
         WF_HIP(hipMemcpy(m->d_grad_fk, fk.data(), fk.size() * sizeof(float), hipMemcpyHostToDevice));
     }
+    if (!grad_capable(m) || m->n_params >= (1 << 24)) return WF_OK;
     m->grad_psi_ok = d.prior_kind == WF_PRIOR_WAVEFLOW && d.layer_kind == WF_LAYER_IMADE && d.n_flow_layers > 0;
     const int n_nets = (int)m->nets.size();
     const int64_t fwd = plain_fwd_floats(D, m->nbp);
@@ -926,11 +930,18 @@ int wf_layer_fwd(const wf_model* m, int layer, const float* u_in_dev, int64_t B,
     return launch_scalar_layer(m->dev, m->d_dev, layer, u_in_dev, B, y_dev, logdet_dev, bin_idx_dev, stream);
 }
 
+// Inverse / sampler: the bisection and rejection loops are serial per walker.  One wave per walker (wf_kernels_wave.hip)
+// finishes a 256-walker batch in 0.10 ms where one lane per walker (wf_kernels_scalar.hip) needs 1.4 ms, but it issues
+// ~20x more instructions per walker inside those loops: above ~3e4 walkers the one-lane form is faster (2^18: 4.9 vs 9.4 ms).
+static constexpr int64_t kWaveSampleMax = 32768;
+
 int wf_inverse_fwd(const wf_model* m, const float* u_dev, int64_t B, float* x_dev, int32_t exact, void* stream) {
     int rc = check_fwd(m, u_dev, B, x_dev);
     if (rc) return rc;
     DeviceGuard g(m->device);
     if (B == 0) return WF_OK;
+    if (m->wave_ok && B <= kWaveSampleMax)
+        return launch_wave_sample(m->dev, m->d_dev, m->d_tabI4, m->d_tabP3, m->d_grad_fk, 0, 0ull, u_dev, B, x_dev, nullptr, exact, stream);
     return launch_scalar_inverse(m->dev, m->d_dev, u_dev, B, x_dev, exact, stream);
 }
 
@@ -939,6 +950,9 @@ int wf_sample(const wf_model* m, uint64_t seed, int64_t B, float* x_dev, float* 
     if (rc) return rc;
     DeviceGuard g(m->device);
     if (B == 0) return WF_OK;
+    if (m->wave_ok && B <= kWaveSampleMax)
+        return launch_wave_sample(m->dev, m->d_dev, m->d_tabI4, m->d_tabP3, m->d_grad_fk, 1, (unsigned long long)seed, nullptr, B, x_dev, latent_dev,
+                                  exact, stream);
     return launch_scalar_sample(m->dev, m->d_dev, (unsigned long long)seed, B, x_dev, latent_dev, exact, stream);
 }
 
