@@ -126,6 +126,16 @@ int wf_model_n_bases(const wf_model* m, int which /* 0 = flow-layer spline, 1 = 
  * MFMA-permuted weight images.  Synchronous with respect to `stream`. */
 int wf_model_set_params(wf_model* m, const float* flat_host, int64_t n, void* stream);
 
+/* The same from a device-resident flat vector (fp32, same leaf order): asynchronous on `stream`, no host work -- the images
+ * are filled by a device kernel from per-model descriptions, so a training loop can keep parameters, gradient and optimiser
+ * state on the GPU (and the call can be captured in a hipGraph). */
+int wf_model_set_params_device(wf_model* m, const float* flat_dev, int64_t n, void* stream);
+
+/* One Adam step on device vectors, the rule of jax.example_libraries.optimizers.adam (vqmc.py:136; `step` is the index passed
+ * to opt_update): m <- (1-b1) g + b1 m; v <- (1-b2) g^2 + b2 v; x <- x - step_size * m/(1-b1^(step+1)) / (sqrt(v/(1-b2^(step+1))) + eps). */
+int wf_adam_step(float* params_dev, const float* grad_dev, float* m_dev, float* v_dev, int64_t n, int64_t step, float step_size, float b1,
+                 float b2, float eps, void* stream);
+
 /* select the kernel used by the *_fwd entry points (default WF_KERNEL_AUTO) */
 int wf_model_set_kernel(wf_model* m, int kernel_kind);
 

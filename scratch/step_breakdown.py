@@ -13,7 +13,7 @@ def T(f, n=50):
     torch.cuda.synchronize(); t = time.time()
     for _ in range(n): f()
     torch.cuda.synchronize(); return (time.time() - t) / n * 1e3
-flat = st.x.copy()
+flat = st.x.cpu().numpy().copy()
 i = [0]
 def setp():
     i[0] += 1

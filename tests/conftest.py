@@ -4,6 +4,8 @@ import sys
 import numpy as np
 import pytest
 
+os.environ.setdefault("WF_POISON", "1")   # NaN-fill fresh device allocations of the library: unwritten reads cannot pass by luck
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -122,6 +122,7 @@ def test_loss_fn_efficient_value_matches_sums(he_flat):
     # ratio H psi / psi amplifies their fp32 differences
     assert abs(lv - loss) < 1e-2 * max(1.0, abs(lv)), (lv, loss)
     assert abs(mean - loss) < 1e-12
+    grad = grad.cpu().numpy()
     assert grad.shape == (he_flat.size,) and np.isfinite(grad).all()
 
 
@@ -235,3 +236,35 @@ def test_gradients_other_shapes_vs_autograd_oracle(D, box, layers, k, kn, B):
     got = m.logpdf_vjp(x, w).cpu().numpy().astype(np.float64)
     want = et.logpdf_vjp(mo, flat, x.astype(np.float64), w)
     assert rel_l2(got, want) < 3e-3, rel_l2(got, want)
+
+
+def test_device_parameter_path_matches_host_path(he_flat):
+    """wf_model_set_params_device fills the same images as wf_model_set_params; wf_adam_step follows the host Adam."""
+    import torch
+    from waveflow_amd import DeviceParams, vqmc
+    params, psi, log_pdf, sample = he(he_flat)
+    x = sorted_walkers(4096, 2, 9.0, 3)
+    want_lp, want_psi = log_pdf(params, x), psi(params, x)
+    other = he_flat + np.float32(1e-3)
+    log_pdf.model.set_params(other)                       # overwrite, then come back through the device path
+    dp = DeviceParams(params, torch.as_tensor(he_flat).cuda())
+    assert np.array_equal(log_pdf(dp, x), want_lp) and np.array_equal(psi(dp, x), want_psi)
+    # both kernels read images written by k_pack: the scalar kernel too
+    log_pdf.model.set_kernel("scalar")
+    got = log_pdf(dp, x)
+    log_pdf.model.set_params(he_flat)
+    assert np.array_equal(got, log_pdf.model.log_pdf(x))
+    log_pdf.model.set_kernel("auto")
+    tree = dp.tree()
+    assert np.array_equal(np.concatenate([np.ravel(a) for a in vqmc.flatten_params(tree)[None]]), he_flat)
+    # Adam: device state vs host state over a few steps with the same gradients
+    g = np.random.default_rng(0)
+    oi_h, ou_h, gp_h = vqmc.adam(1e-2)
+    oi_d, ou_d, gp_d = vqmc.adam(1e-2, model=log_pdf.model)
+    sh, sd = oi_h(params), oi_d(params)
+    for i in range(12):
+        gr = g.normal(size=he_flat.size).astype(np.float32)
+        sh = ou_h(i, gr, sh)
+        sd = ou_d(i, torch.as_tensor(gr).cuda(), sd)
+    np.testing.assert_allclose(gp_d(sd).flat.cpu().numpy(), sh.x, rtol=0, atol=2e-6)
+    assert isinstance(gp_d(sd), DeviceParams) and gp_d(sd).version == 12

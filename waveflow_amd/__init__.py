@@ -5,6 +5,6 @@ this package re-creates the reference's model_factory / wavefunctions / flows ca
 There is no CPU fallback: without the built library and a gfx950 device the hot path raises.
 """
 from . import flows, model_factory, wavefunctions  # noqa: F401
-from .core import DeviceModel, build_tables, flatten_params, tree_leaves  # noqa: F401
+from .core import DeviceModel, DeviceParams, build_tables, flatten_params, tree_leaves  # noqa: F401
 
-__all__ = ["flows", "model_factory", "wavefunctions", "DeviceModel", "build_tables", "flatten_params", "tree_leaves"]
+__all__ = ["flows", "model_factory", "wavefunctions", "DeviceModel", "DeviceParams", "build_tables", "flatten_params", "tree_leaves"]

@@ -56,7 +56,7 @@ EXPORTS = ["wf_abi_version", "wf_strerror", "wf_last_hip_error", "wf_last_hip_er
            "wf_model_set_params", "wf_model_set_kernel", "wf_logpdf_fwd", "wf_psi_fwd", "wf_flow_fwd", "wf_layer_fwd",
            "wf_block_sums", "wf_block_sums_workspace_bytes", "wf_rqs_fwd", "wf_inverse_fwd", "wf_sample", "wf_hamiltonian_fwd",
            "wf_psi_vjp", "wf_psi_vjp_workspace_bytes", "wf_vqmc_seeds",
-           "wf_logpdf_vjp", "wf_logpdf_vjp_workspace_bytes", "wf_vqmc_loss_grad"]
+           "wf_logpdf_vjp", "wf_logpdf_vjp_workspace_bytes", "wf_vqmc_loss_grad", "wf_model_set_params_device", "wf_adam_step"]
 
 _lib = None
 
@@ -115,6 +115,10 @@ def lib():
     L.wf_logpdf_vjp_workspace_bytes.argtypes = [vp, i64]
     L.wf_logpdf_vjp.restype = i32
     L.wf_logpdf_vjp.argtypes = [vp, vp, i64, vp, vp, vp, i64, vp]
+    L.wf_model_set_params_device.restype = i32
+    L.wf_model_set_params_device.argtypes = [vp, vp, i64, vp]
+    L.wf_adam_step.restype = i32
+    L.wf_adam_step.argtypes = [vp, vp, vp, vp, i64, i64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, vp]
     L.wf_vqmc_loss_grad.restype = i32
     L.wf_vqmc_loss_grad.argtypes = [vp, vp, i64, vp, i32, ctypes.c_float, ctypes.c_float, vp, vp, vp, i64, vp]
     L.wf_vqmc_seeds.restype = i32

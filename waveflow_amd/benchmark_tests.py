@@ -74,7 +74,7 @@ def loss_and_grad(params, target, log_pdf):
     w = torch.full((n,), -1.0 / n, device=t.device, dtype=torch.float32)
     grad = model.logpdf_vjp(t, w)
     s = model.block_sums(lp).cpu().tolist()
-    return -s[0] / s[2], grad.cpu().numpy()
+    return -s[0] / s[2], grad
 
 
 def _run_directory(save_dir, dataset_name, model_type, spline_reg, num_flow_layer, spline_degree, num_knots):
@@ -95,7 +95,7 @@ def train_model(target, num_epochs, n_model_sample, model_type='IFlow', dataset_
     g = np.random.default_rng(seed)
     params, log_pdf, sample = get_model(model_type, spline_reg, spline_degree=spline_degree, num_layers=num_flow_layer, num_knots=num_knots,
                                         prior_spline_degree=prior_spline_degree, prior_num_knots=prior_num_knots)(int(g.integers(1 << 31)), input_dim)
-    opt_init, opt_update, get_params = adam(step_size=step_size)
+    opt_init, opt_update, get_params = adam(step_size=step_size, model=log_pdf.model)   # parameters and Adam state stay on the GPU
     state = opt_init(params)
     x_dev = torch.as_tensor(np.asarray(target, dtype=np.float32)).cuda(log_pdf.model.device)   # the target set stays in HBM
 

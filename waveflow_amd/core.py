@@ -3,6 +3,7 @@
 PyTorch is used only as plumbing: device buffers, the current HIP stream, torch.distributed.
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -21,8 +22,22 @@ def tree_leaves(tree, out=None):
     return out
 
 
+class DeviceParams:
+    """Parameters that live on the GPU: the flat float32 vector (reference leaf order) plus the pytree they unflatten to.
+    Accepted wherever the closures take `params`; `tree()` downloads them as the reference's pytree of numpy arrays."""
+
+    def __init__(self, template, flat, version=0):
+        self.template, self.flat, self.version = template, flat, version
+
+    def tree(self):
+        from .checkpoint import unflatten_like
+        return unflatten_like(self.template, self.flat.detach().cpu().numpy())
+
+
 def flatten_params(tree):
     """-> contiguous float32 host vector in leaf order."""
+    if isinstance(tree, DeviceParams):
+        return np.ascontiguousarray(tree.flat.detach().cpu().numpy(), dtype=np.float32)
     leaves = tree_leaves(tree)
     parts = []
     for a in leaves:
@@ -59,6 +74,7 @@ class DeviceModel:
         self.p_nb = int(L.wf_model_n_bases(h, 1))
         self._flat = None
         self._vjp_ws = None
+        self._dev_key = None
         self.D = int(desc.n_dim)
         self.n_layers = int(desc.n_flow_layers)
 
@@ -79,8 +95,24 @@ class DeviceModel:
         _lib.check(_lib.lib().wf_model_set_params(self._h, flat.ctypes.data, flat.size, self._stream()), "wf_model_set_params")
         self._flat = flat.copy()
 
+    def set_params_device(self, flat_dev):
+        """Parameters from a float32 cuda vector: asynchronous, no host copy (wf_model_set_params_device)."""
+        if flat_dev.numel() != self.n_params or str(flat_dev.dtype) != "torch.float32" or not flat_dev.is_cuda:
+            raise ValueError(f"expected a float32 cuda vector of {self.n_params} parameters")
+        flat_dev = flat_dev.contiguous()
+        _lib.check(_lib.lib().wf_model_set_params_device(self._h, self._p(flat_dev), flat_dev.numel(), self._stream()),
+                   "wf_model_set_params_device")
+        self._flat = None
+
     def ensure_params(self, tree):
         """Upload `tree` unless it equals what the device already holds."""
+        if isinstance(tree, DeviceParams):
+            key = (id(tree.flat), tree.version)
+            if self._dev_key != key:
+                self.set_params_device(tree.flat)
+                self._dev_key = key
+            return
+        self._dev_key = None
         flat = flatten_params(tree)
         if self._flat is None or flat.size != self._flat.size or not np.array_equal(flat, self._flat):
             self.set_params(flat)
@@ -207,7 +239,7 @@ class DeviceModel:
             raise ValueError("w_psi / w_lap must have one entry per walker")
         nbytes = _lib.check(L.wf_psi_vjp_workspace_bytes(self._h, B), "wf_psi_vjp_workspace_bytes")
         if self._vjp_ws is None or self._vjp_ws.numel() < nbytes:
-            self._vjp_ws = torch.empty(int(nbytes), device=t.device, dtype=torch.uint8)
+            self._vjp_ws = self._workspace(nbytes, t.device)
         grad = self._new((self.n_params,))
         _lib.check(L.wf_psi_vjp(self._h, self._p(t), B, self._p(wp), self._p(wl), self._p(grad), self._p(self._vjp_ws),
                                 self._vjp_ws.numel(), self._stream()), "wf_psi_vjp")
@@ -224,7 +256,7 @@ class DeviceModel:
             raise ValueError("w must have one entry per row of x")
         nbytes = _lib.check(L.wf_logpdf_vjp_workspace_bytes(self._h, B), "wf_logpdf_vjp_workspace_bytes")
         if self._vjp_ws is None or self._vjp_ws.numel() < nbytes:
-            self._vjp_ws = torch.empty(int(nbytes), device=t.device, dtype=torch.uint8)
+            self._vjp_ws = self._workspace(nbytes, t.device)
         grad = self._new((self.n_params,))
         _lib.check(L.wf_logpdf_vjp(self._h, self._p(t), B, self._p(wt), self._p(grad), self._p(self._vjp_ws), self._vjp_ws.numel(),
                                    self._stream()), "wf_logpdf_vjp")
@@ -240,13 +272,29 @@ class DeviceModel:
         pr = np.ascontiguousarray(np.asarray(protons, dtype=np.float32).reshape(-1))
         nbytes = _lib.check(L.wf_psi_vjp_workspace_bytes(self._h, B), "wf_psi_vjp_workspace_bytes")
         if self._vjp_ws is None or self._vjp_ws.numel() < nbytes:
-            self._vjp_ws = torch.empty(int(nbytes), device=t.device, dtype=torch.uint8)
+            self._vjp_ws = self._workspace(nbytes, t.device)
         el, grad = self._new((B,)), self._new((self.n_params,))
         inv = 1.0 / float(global_count if global_count else max(B, 1))
         _lib.check(L.wf_vqmc_loss_grad(self._h, self._p(t), B, pr.ctypes.data if pr.size else None, pr.size, float(running_average), inv,
                                        self._p(el), self._p(grad), self._p(self._vjp_ws), self._vjp_ws.numel(), self._stream()),
                    "wf_vqmc_loss_grad")
         return self.block_sums(el), grad
+
+    def adam_step(self, x, g, m, v, step, step_size, b1=0.9, b2=0.999, eps=1e-8):
+        """In-place Adam update of the cuda vectors x, m, v with the gradient g (wf_adam_step)."""
+        for t in (x, g, m, v):
+            if not t.is_cuda or not t.is_contiguous() or t.numel() != x.numel() or str(t.dtype) != "torch.float32":
+                raise ValueError("adam_step needs contiguous float32 cuda vectors of equal length")
+        _lib.check(_lib.lib().wf_adam_step(self._p(x), self._p(g), self._p(m), self._p(v), x.numel(), int(step), float(step_size), float(b1),
+                                           float(b2), float(eps), self._stream()), "wf_adam_step")
+
+    @staticmethod
+    def _workspace(nbytes, device):
+        torch = _torch()
+        ws = torch.empty(int(nbytes), device=device, dtype=torch.uint8)
+        if os.environ.get("WF_POISON"):
+            ws.fill_(0xFF)   # NaN patterns: see dev_alloc in wf_model.cpp
+        return ws
 
     def block_sums(self, v):
         """fp64 [sum v, sum v^2, count] on the device (deterministic order)."""

@@ -80,8 +80,8 @@ struct ModelDev {
     unsigned constrained_mask;    // bit d set: d in constrained_dimension_indices_left
     SplineDev isp;                // flow-layer I-spline (IMADE)
     SplineDev psp;                // prior spline: orthogonal-B (WAVEFLOW) or M (MFLOW)
-    const float* ob_to_b;         // [nb][nbp] fp32 (WAVEFLOW): row a = ob_to_b[a][:]
-    const float* b_to_ob;         // [nb][nbp] fp32 (WAVEFLOW): the sampler's bound (bsplines_jax.py:164-166)
+    const float* ob_to_b;         // [nbp][nbp] fp32, zero beyond nb (WAVEFLOW): row a = ob_to_b[a][:]
+    const float* b_to_ob;         // [nbp][nbp] fp32, zero beyond nb (WAVEFLOW): the sampler's bound (bsplines_jax.py:164-166)
     float reverse_tol;            // IMADE reverse_fun_tol
     NetPlain nets[kMaxNets];      // flow layers 0..n_layers-1, then the prior net
     NetMfma mnets[kMaxNets];
@@ -141,6 +141,17 @@ int launch_wave_sample(const ModelDev& md, const ModelDev* md_dev, const float* 
 int64_t wave_tail_floats(int D, int second_order);
 int launch_energy_out(int D, const float* tails, const float* x, int64_t B, unsigned constrained_mask, const Protons& pr, float* hpsi, float* psi,
                       float* lap, void* stream);
+// One entry of a device weight image as a function of the flat parameter vector:
+//   kind 0: image float [dst]            = src >= 0 ? (float)(scale * flat[src]) : (float)scale
+//   kind 1: image halves [dst], [dst_lo] = fp16 pair (hi, lo) of that value, hi + lo = value to 2^-25
+struct PackRec {
+    int32_t src, kind;
+    uint32_t dst, dst_lo;
+    double scale;
+};
+int launch_pack(const float* flat_dev, const PackRec* recs, int64_t n, void* image_base, void* stream);
+int launch_adam(float* params, const float* grad, float* m, float* v, int64_t n, int64_t step, float step_size, float b1, float b2, float eps,
+                void* stream);
 int launch_grad_scatter(const float* grad_img, const int32_t* map, int64_t n_img, float* grad_flat, void* stream);
 int launch_vqmc_seeds(const float* x, int64_t B, int D, const Protons& pr, const float* hpsi, const float* psi, float running_avg,
                       float inv_count, float* e_loc, float* w_psi, float* w_lap, void* stream);

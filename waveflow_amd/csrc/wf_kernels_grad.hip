@@ -127,6 +127,34 @@ __global__ void k_grad_scatter(const float* __restrict__ gimg, const int32_t* __
     if (t >= 0) flat[t] = gimg[i];
 }
 
+// ---- weight images from the flat parameter vector (PackRec, wf_internal.h)
+__global__ void k_pack(const float* __restrict__ flat, const PackRec* __restrict__ recs, int64_t n, void* __restrict__ image) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const PackRec r = recs[i];
+    const float v = r.src >= 0 ? (float)(r.scale * (double)flat[r.src]) : (float)r.scale;
+    if (r.kind == 0) {
+        reinterpret_cast<float*>(image)[r.dst] = v;
+    } else {
+        const _Float16 hi = (_Float16)v;
+        reinterpret_cast<_Float16*>(image)[r.dst] = hi;
+        reinterpret_cast<_Float16*>(image)[r.dst_lo] = (_Float16)(v - (float)hi);
+    }
+}
+
+// ---- Adam as in jax.example_libraries.optimizers.adam (vqmc.py:136), step index i as passed to opt_update
+__global__ void k_adam(float* __restrict__ x, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n, float c1, float c2,
+                       float step_size, float b1, float b2, float eps) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i];
+    const float mi = (1.0f - b1) * gi + b1 * m[i];
+    const float vi = (1.0f - b2) * gi * gi + b2 * v[i];
+    m[i] = mi;
+    v[i] = vi;
+    x[i] = x[i] - step_size * (mi / c1) / (sqrtf(vi / c2) + eps);
+}
+
 // ---- loss_fn_efficient's tangent rule as per-walker weights (vqmc.py:198-212)
 __global__ void k_vqmc_seeds(const float* __restrict__ xg, int64_t B, int D, const Protons pr, const float* __restrict__ hpsi,
                              const float* __restrict__ psi, float running_avg, float inv_count, float* __restrict__ e_loc,
@@ -199,6 +227,20 @@ int launch_wgrad(int D, int second_order, int n_nets, int64_t n_samples, const f
         default: return WF_ERR_UNSUPPORTED;
     }
 #undef CALL
+}
+
+int launch_pack(const float* flat_dev, const PackRec* recs, int64_t n, void* image_base, void* stream) {
+    hipLaunchKernelGGL(k_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, flat_dev, recs, n, image_base);
+    return finish();
+}
+
+int launch_adam(float* params, const float* grad, float* m, float* v, int64_t n, int64_t step, float step_size, float b1, float b2, float eps,
+                void* stream) {
+    // bias corrections 1 - b^(i+1) in fp32, as the reference's optimiser computes them
+    const float c1 = 1.0f - powf(b1, (float)(step + 1)), c2 = 1.0f - powf(b2, (float)(step + 1));
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, grad, m, v, n, c1, c2, step_size, b1,
+                       b2, eps);
+    return finish();
 }
 
 int launch_grad_scatter(const float* grad_img, const int32_t* map, int64_t n_img, float* grad_flat, void* stream) {

@@ -86,6 +86,9 @@ struct wf_model {
     void* d_comp = nullptr;          // composite tables [n_nets][n_mesh] float4
     const float* d_tabI4 = nullptr;  // [4][n_mesh][32]: I-spline derivative orders 0..3 (local energy)
     const float* d_tabP3 = nullptr;  // [4][n_mesh][32]: orthogonal-B derivative orders 0..3 (the energy uses 0..2)
+    float* d_flat = nullptr;         // device copy of the flat parameter vector (source of every weight image)
+    wf::PackRec* d_pack[3] = {nullptr, nullptr, nullptr};   // image descriptions: plain, wave, mfma
+    int64_t n_pack[3] = {0, 0, 0};
     float* d_scratch = nullptr;      // private scratch of wf_hamiltonian_fwd (grown on demand)
     int64_t scratch_floats = 0;
     float* d_wave = nullptr;         // NetWave images (nbp == 32 only)
@@ -148,6 +151,9 @@ template <class T>
 static int dev_alloc(wf_model* m, T** p, size_t count) {
     void* q = nullptr;
     WF_HIP(hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)));
+    // WF_POISON=1 (the test suite sets it): fresh device memory starts as NaN patterns, so that a kernel reading anything
+    // it or the host has not written shows up as NaN instead of passing by luck on zero-filled pages
+    if (getenv("WF_POISON")) (void)hipMemset(q, 0xFF, std::max<size_t>(count, 1) * sizeof(T));
     m->allocs.push_back(q);
     *p = (T*)q;
     return WF_OK;
@@ -261,12 +267,12 @@ static int model_build(wf_model* m) {
             if (rc) return rc;
         }
         fill_bc(md.psp, d.p_left, d.p_right, b64, nb, d.n_mesh);  // BCs use the plain-B table, bsplines_jax.py:176-189
-        std::vector<float> o2b32((size_t)nb * m->nbp, 0.0f);
+        std::vector<float> o2b32((size_t)m->nbp * m->nbp, 0.0f);   // full [nbp][nbp]: the wave kernels contract over all 32 rows
         for (int a = 0; a < nb; ++a)
             for (int j = 0; j < nb; ++j) o2b32[(size_t)a * m->nbp + j] = (float)o2b[(size_t)a * nb + j];
         rc = upload_table(m, o2b32, &md.ob_to_b);
         if (rc) return rc;
-        std::vector<float> b2o32((size_t)nb * m->nbp, 0.0f);
+        std::vector<float> b2o32((size_t)m->nbp * m->nbp, 0.0f);
         for (int a = 0; a < nb; ++a)
             for (int j = 0; j < nb; ++j) b2o32[(size_t)a * m->nbp + j] = (float)b2o[(size_t)a * nb + j];
         rc = upload_table(m, b2o32, &md.b_to_ob);
@@ -366,46 +372,60 @@ static int model_build(wf_model* m) {
     return grad_prepare(m);
 }
 
-// Re-derives the masked, transposed weight image of net n from the flat parameter vector.
-static void build_plain_image(const wf_model* m, int n, const float* flat, float* img) {
+// Every entry of a device weight image is scale * flat[src] (or a constant): the images are described once per model as
+// PackRec lists and filled on the device by k_pack (wf_kernels_grad.hip) whenever the parameters change.
+struct ImageWriter {
+    std::vector<PackRec>& out;
+    uint32_t o;   // running float offset inside the image
+    void f32(int64_t src, double scale = 1.0) { out.push_back(PackRec{(int32_t)src, 0, o++, 0u, src >= 0 ? scale : 0.0}); }
+    void cst(double value) { out.push_back(PackRec{-1, 0, o++, 0u, value}); }
+};
+struct NetOffsets {   // flat-vector offsets of the leaves of one conditioner (model_factory.py:72-87 leaf order)
+    int64_t W0, b0, W1, b1, W2, b2;
+    int NO;
+};
+static NetOffsets net_offsets(const wf_model* m, int n) {
+    const int D = m->desc.n_dim, H = kHidden;
+    const NetLayout& nl = m->nets[n];
+    NetOffsets q;
+    q.NO = nl.n_out * D;
+    q.W0 = nl.offset;
+    q.b0 = q.W0 + (int64_t)D * H;
+    q.W1 = q.b0 + H;
+    q.b1 = q.W1 + (int64_t)H * H;
+    q.W2 = q.b1 + H;
+    q.b2 = q.W2 + (int64_t)H * q.NO;
+    return q;
+}
+
+// Masked, transposed weight image of net n (NetPlain), float offset `base` inside d_plain.
+static void describe_plain_image(const wf_model* m, int n, uint32_t base, std::vector<PackRec>& out) {
     const int D = m->desc.n_dim, H = kHidden, nbp = m->nbp;
     const NetLayout& nl = m->nets[n];
-    const int NO = nl.n_out * D;
-    const float* W0 = flat + nl.offset;
-    const float* b0 = W0 + (int64_t)D * H;
-    const float* W1 = b0 + H;
-    const float* b1 = W1 + (int64_t)H * H;
-    const float* W2 = b1 + H;
-    const float* b2 = W2 + (int64_t)H * NO;
-    float* o = img;
+    const NetOffsets q = net_offsets(m, n);
+    ImageWriter w{out, base};
     // W0 * mask0: [D][H]
     for (int a = 0; a < D; ++a)
-        for (int j = 0; j < H; ++j) *o++ = deg_hidden(j, D) >= deg_in(a) ? W0[(int64_t)a * H + j] : 0.0f;
-    for (int j = 0; j < H; ++j) *o++ = b0[j];
+        for (int j = 0; j < H; ++j) w.f32(deg_hidden(j, D) >= deg_in(a) ? q.W0 + (int64_t)a * H + j : -1);
+    for (int j = 0; j < H; ++j) w.f32(q.b0 + j);
     // (W1 * mask1)^T: [j out][a in]
     for (int j = 0; j < H; ++j)
-        for (int a = 0; a < H; ++a) *o++ = deg_hidden(j, D) >= deg_hidden(a, D) ? W1[(int64_t)a * H + j] : 0.0f;
-    for (int j = 0; j < H; ++j) *o++ = b1[j];
+        for (int a = 0; a < H; ++a) w.f32(deg_hidden(j, D) >= deg_hidden(a, D) ? q.W1 + (int64_t)a * H + j : -1);
+    for (int j = 0; j < H; ++j) w.f32(q.b1 + j);
     // (W2 * tile(mask2))^T regrouped: [d][jb][a], reference output column c = jb*D + d (model_factory.py:59-60,81)
     for (int dd = 0; dd < D; ++dd)
         for (int jb = 0; jb < nbp; ++jb)
-            for (int a = 0; a < H; ++a) {
-                float v = 0.0f;
-                if (jb < nl.n_out && deg_out(dd) >= deg_hidden(a, D)) v = W2[(int64_t)a * NO + (jb * D + dd)];
-                *o++ = v;
-            }
+            for (int a = 0; a < H; ++a)
+                w.f32((jb < nl.n_out && deg_out(dd) >= deg_hidden(a, D)) ? q.W2 + (int64_t)a * q.NO + (jb * D + dd) : -1);
     for (int dd = 0; dd < D; ++dd)
-        for (int jb = 0; jb < nbp; ++jb) *o++ = jb < nl.n_out ? b2[jb * D + dd] : 0.0f;
+        for (int jb = 0; jb < nbp; ++jb) w.f32(jb < nl.n_out ? q.b2 + jb * D + dd : -1);
     // reverse-pass orientation: W1 * mask1 [a in][j out], W2 * mask2 [a in][d][jb]
     for (int a = 0; a < H; ++a)
-        for (int j = 0; j < H; ++j) *o++ = deg_hidden(j, D) >= deg_hidden(a, D) ? W1[(int64_t)a * H + j] : 0.0f;
+        for (int j = 0; j < H; ++j) w.f32(deg_hidden(j, D) >= deg_hidden(a, D) ? q.W1 + (int64_t)a * H + j : -1);
     for (int a = 0; a < H; ++a)
         for (int dd = 0; dd < D; ++dd)
-            for (int jb = 0; jb < nbp; ++jb) {
-                float v = 0.0f;
-                if (jb < nl.n_out && deg_out(dd) >= deg_hidden(a, D)) v = W2[(int64_t)a * NO + (jb * D + dd)];
-                *o++ = v;
-            }
+            for (int jb = 0; jb < nbp; ++jb)
+                w.f32((jb < nl.n_out && deg_out(dd) >= deg_hidden(a, D)) ? q.W2 + (int64_t)a * q.NO + (jb * D + dd) : -1);
 }
 
 
@@ -415,47 +435,41 @@ static int64_t wave_net_floats(int D) {
     return (int64_t)D * kHidden + 2 * kHidden + (int64_t)P * 64 + 2 * 4096 + (int64_t)P * 2 * 4096;
 }
 
-static void build_wave_image(const wf_model* m, int n, const float* flat, float* img) {
+static void describe_wave_image(const wf_model* m, int n, uint32_t base, std::vector<PackRec>& out) {
     const int D = m->desc.n_dim, H = kHidden, P = (D + 1) / 2;
     const NetLayout& nl = m->nets[n];
-    const int NO = nl.n_out * D;
-    const float* W0 = flat + nl.offset;
-    const float* b0 = W0 + (int64_t)D * H;
-    const float* W1 = b0 + H;
-    const float* b1 = W1 + (int64_t)H * H;
-    const float* W2 = b1 + H;
-    const float* b2 = W2 + (int64_t)H * NO;
-    auto w1m = [&](int a, int j) { return deg_hidden(j, D) >= deg_hidden(a, D) ? W1[(int64_t)a * H + j] : 0.0f; };
+    const NetOffsets q = net_offsets(m, n);
+    auto w1m = [&](int a, int j) -> int64_t { return deg_hidden(j, D) >= deg_hidden(a, D) ? q.W1 + (int64_t)a * H + j : -1; };
     // column of output lane c of pass p: (d, jb) = (2p + (c >> 5), c & 31)
-    auto w2m = [&](int a, int p, int c) {
+    auto w2m = [&](int a, int p, int c) -> int64_t {
         const int d = 2 * p + (c >> 5), jb = c & 31;
-        if (d >= D || jb >= nl.n_out || deg_out(d) < deg_hidden(a, D)) return 0.0f;
-        return W2[(int64_t)a * NO + (jb * D + d)];
+        if (d >= D || jb >= nl.n_out || deg_out(d) < deg_hidden(a, D)) return -1;
+        return q.W2 + (int64_t)a * q.NO + (jb * D + d);
     };
-    float* o = img;
+    ImageWriter w{out, base};
     for (int a = 0; a < D; ++a)
-        for (int j = 0; j < H; ++j) *o++ = deg_hidden(j, D) >= deg_in(a) ? W0[(int64_t)a * H + j] : 0.0f;
-    for (int j = 0; j < H; ++j) *o++ = b0[j];
-    for (int j = 0; j < H; ++j) *o++ = b1[j];
+        for (int j = 0; j < H; ++j) w.f32(deg_hidden(j, D) >= deg_in(a) ? q.W0 + (int64_t)a * H + j : -1);
+    for (int j = 0; j < H; ++j) w.f32(q.b0 + j);
+    for (int j = 0; j < H; ++j) w.f32(q.b1 + j);
     for (int p = 0; p < P; ++p)
         for (int c = 0; c < 64; ++c) {
             const int d = 2 * p + (c >> 5), jb = c & 31;
-            *o++ = (d < D && jb < nl.n_out) ? b2[jb * D + d] : 0.0f;
+            w.f32((d < D && jb < nl.n_out) ? q.b2 + jb * D + d : -1);
         }
     for (int g = 0; g < 16; ++g)
         for (int j = 0; j < 64; ++j)
-            for (int e = 0; e < 4; ++e) *o++ = w1m(4 * g + e, j);
+            for (int e = 0; e < 4; ++e) w.f32(w1m(4 * g + e, j));
     for (int g = 0; g < 16; ++g)
         for (int a = 0; a < 64; ++a)
-            for (int e = 0; e < 4; ++e) *o++ = w1m(a, 4 * g + e);
+            for (int e = 0; e < 4; ++e) w.f32(w1m(a, 4 * g + e));
     for (int p = 0; p < P; ++p)
         for (int g = 0; g < 16; ++g)
             for (int c = 0; c < 64; ++c)
-                for (int e = 0; e < 4; ++e) *o++ = w2m(4 * g + e, p, c);
+                for (int e = 0; e < 4; ++e) w.f32(w2m(4 * g + e, p, c));
     for (int p = 0; p < P; ++p)
         for (int g = 0; g < 16; ++g)
             for (int a = 0; a < 64; ++a)
-                for (int e = 0; e < 4; ++e) *o++ = w2m(a, p, 4 * g + e);
+                for (int e = 0; e < 4; ++e) w.f32(w2m(a, p, 4 * g + e));
 }
 
 // ---------------------------------------------------------------------------- MFMA kernel images
@@ -522,88 +536,68 @@ static void pack_rows_acc(const std::vector<double>& t64, int nb, int n_mesh, in
         }
 }
 
-// x = hi + lo with hi, lo in fp16 (round to nearest; lo may be subnormal: absolute precision 2^-25)
-static inline void split_f16(float x, _Float16& hi, _Float16& lo) {
-    hi = (_Float16)x;
-    lo = (_Float16)(x - (float)hi);
-}
-
 static bool net_has_sigmoid_head(const wf_model* m, int n) {
     const bool is_prior = n == m->desc.n_flow_layers;
     if (is_prior) return m->desc.prior_kind == WF_PRIOR_MFLOW;
     return m->desc.layer_kind == WF_LAYER_IMADE;
 }
 
-// LDS image of net n in MFMA operand order (wf_kernels_mfma.hip: NetOff<D>)
-static void build_mfma_image(const wf_model* m, int n, const float* flat, float* img) {
+// LDS image of net n in MFMA operand order (wf_kernels_mfma.hip: NetOff<D>), float offset `base` inside d_mfma.  fp16 operand
+// pairs: x = hi + lo with hi, lo in fp16 (round to nearest; lo may be subnormal: absolute precision 2^-25), k_pack splits them.
+static void describe_mfma_image(const wf_model* m, int n, uint32_t base, std::vector<PackRec>& out) {
     const int D = m->desc.n_dim, H = kHidden, nbk = m->mdev.nbk;
     const int S0 = (D + 1) / 2;
     const NetLayout& nl = m->nets[n];
-    const int NO = nl.n_out * D;
-    const float* W0 = flat + nl.offset;
-    const float* b0 = W0 + (int64_t)D * H;
-    const float* W1 = b0 + H;
-    const float* b1 = W1 + (int64_t)H * H;
-    const float* W2 = b1 + H;
-    const float* b2 = W2 + (int64_t)H * NO;
+    const NetOffsets q = net_offsets(m, n);
     // folded activation scales: tanh(x) = 1 - 2/(2^(c1 x) + 1), sigmoid(x) = 1/(1 + 2^(c2 x))
     const double c1 = 2.0 * 1.4426950408889634074;
     const bool sig = net_has_sigmoid_head(m, n);
     const double c2 = sig ? -1.4426950408889634074 : 1.0;
-    float* o = img;
+    ImageWriter w{out, base};
+    auto f16_block = [&](uint32_t n_pairs, auto&& src_of) {   // hi halves then lo halves; returns nothing, advances w.o
+        uint32_t hi = 2 * w.o, lo = hi + n_pairs;
+        for (uint32_t e = 0; e < n_pairs; ++e) {
+            const std::pair<int64_t, double> sv = src_of(e);
+            out.push_back(PackRec{(int32_t)sv.first, 1, hi++, lo++, sv.first >= 0 ? sv.second : 0.0});
+        }
+        w.o += n_pairs;
+    };
     // layer 0 (f32 MFMA): A[i = unit 32*ob + (lane&31)][k = 2s + (lane>>5)]
     for (int ob = 0; ob < 2; ++ob)
         for (int s = 0; s < S0; ++s)
             for (int lane = 0; lane < 64; ++lane) {
                 const int unit = 32 * ob + (lane & 31), k = 2 * s + (lane >> 5);
-                *o++ = (k < D && deg_hidden(unit, D) >= deg_in(k)) ? (float)(c1 * (double)W0[(int64_t)k * H + unit]) : 0.0f;
+                w.f32((k < D && deg_hidden(unit, D) >= deg_in(k)) ? q.W0 + (int64_t)k * H + unit : -1, c1);
             }
     for (int ob = 0; ob < 2; ++ob)
         for (int h = 0; h < 2; ++h)
-            for (int r = 0; r < 16; ++r) *o++ = (float)(c1 * (double)b0[32 * ob + acc_row(r, h)]);
+            for (int r = 0; r < 16; ++r) w.f32(q.b0 + 32 * ob + acc_row(r, h), c1);
     // layer 1 (f16 MFMA, K = 16 per step): step (t, s), element j of lane half h contracts hidden unit
     // kk = 32t + acc_row(8s + j, h);  images [ob][t][s][lane][8] for hi then lo
-    {
-        _Float16* hi = reinterpret_cast<_Float16*>(o);
-        _Float16* lo = hi + 4096;
-        for (int ob = 0; ob < 2; ++ob)
-            for (int t = 0; t < 2; ++t)
-                for (int s = 0; s < 2; ++s)
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int j = 0; j < 8; ++j) {
-                            const int unit = 32 * ob + (lane & 31), kk = 32 * t + acc_row(8 * s + j, lane >> 5);
-                            const float v = deg_hidden(unit, D) >= deg_hidden(kk, D) ? (float)(c1 * (double)W1[(int64_t)kk * H + unit]) : 0.0f;
-                            split_f16(v, *hi++, *lo++);
-                        }
-        o += 4096;
-    }
+    f16_block(4096, [&](uint32_t e) {
+        const int j = e & 7, lane = (e >> 3) & 63, s_ = (e >> 9) & 1, t = (e >> 10) & 1, ob = (e >> 11) & 1;
+        const int unit = 32 * ob + (lane & 31), kk = 32 * t + acc_row(8 * s_ + j, lane >> 5);
+        return std::make_pair(deg_hidden(unit, D) >= deg_hidden(kk, D) ? q.W1 + (int64_t)kk * H + unit : (int64_t)-1, c1);
+    });
     for (int ob = 0; ob < 2; ++ob)
         for (int h = 0; h < 2; ++h)
-            for (int r = 0; r < 16; ++r) *o++ = (float)(c1 * (double)b1[32 * ob + acc_row(r, h)]);
+            for (int r = 0; r < 16; ++r) w.f32(q.b1 + 32 * ob + acc_row(r, h), c1);
     // output layer, dimensions 1..D-1, row blocks kb: A[i = basis 32*kb + (lane&31)][k = kk]
-    {
-        _Float16* hi = reinterpret_cast<_Float16*>(o);
-        _Float16* lo = hi + (D - 1) * nbk * 2048;
-        for (int d = 1; d < D; ++d)
-            for (int kb = 0; kb < nbk; ++kb)
-                for (int t = 0; t < 2; ++t)
-                    for (int s = 0; s < 2; ++s)
-                        for (int lane = 0; lane < 64; ++lane)
-                            for (int j = 0; j < 8; ++j) {
-                                const int jb = 32 * kb + (lane & 31), kk = 32 * t + acc_row(8 * s + j, lane >> 5);
-                                float v = 0.0f;
-                                if (jb < nl.n_out && deg_out(d) >= deg_hidden(kk, D)) v = (float)(c2 * (double)W2[(int64_t)kk * NO + (jb * D + d)]);
-                                split_f16(v, *hi++, *lo++);
-                            }
-        o += (D - 1) * nbk * 2048;
-    }
+    f16_block((uint32_t)((D - 1) * nbk * 2048), [&](uint32_t e) {
+        const int j = e & 7, lane = (e >> 3) & 63, s_ = (e >> 9) & 1, t = (e >> 10) & 1;
+        const int blk = e >> 11, kb = blk % nbk, d = 1 + blk / nbk;
+        const int jb = 32 * kb + (lane & 31), kk = 32 * t + acc_row(8 * s_ + j, lane >> 5);
+        const bool live = jb < nl.n_out && deg_out(d) >= deg_hidden(kk, D);
+        return std::make_pair(live ? q.W2 + (int64_t)kk * q.NO + (jb * D + d) : (int64_t)-1, c2);
+    });
     // biases; padding rows of sigmoid heads get +1e30 so that sigmoid(-x) -> 0 exactly
     for (int d = 0; d < D; ++d)
         for (int kb = 0; kb < nbk; ++kb)
             for (int h = 0; h < 2; ++h)
                 for (int r = 0; r < 16; ++r) {
                     const int jb = 32 * kb + acc_row(r, h);
-                    *o++ = jb < nl.n_out ? (float)(c2 * (double)b2[jb * D + d]) : (sig ? 1e30f : 0.0f);
+                    if (jb < nl.n_out) w.f32(q.b2 + jb * D + d, c2);
+                    else w.cst(sig ? 1e30 : 0.0);
                 }
 }
 
@@ -693,6 +687,9 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
     }
     m->mfma_floats = total;
     m->mfma_ok = true;
+    // the constants block does not depend on the parameters: upload it once
+    WF_HIP(hipMemset(m->d_mfma, 0, (size_t)total * sizeof(float)));
+    WF_HIP(hipMemcpy(m->d_mfma + md.const_img_off, m->mfma_consts.data(), m->mfma_consts.size() * sizeof(float), hipMemcpyHostToDevice));
     return WF_OK;
 }
 
@@ -709,11 +706,36 @@ static bool wave_capable(const wf_model* m) {
 // ... of which the reverse pass and the local energy are instantiated for D <= 4
 static bool grad_capable(const wf_model* m) { return m->wave_ok && m->desc.n_dim <= 4 && !m->nets.empty(); }
 
-// Index map forward-image entry -> flat parameter: push the code "index + 1" through the image builder; masked and
-// padding entries come out as 0 (no parameter).
+// Describes every weight image (PackRec lists on the device) and derives the gradient scatter map: forward-image entry ->
+// flat parameter (masked and padding entries have no source: no gradient).
+static int pack_prepare(wf_model* m, std::vector<PackRec>& plain) {
+    const int D = m->desc.n_dim;
+    const int n_nets = (int)m->nets.size();
+    std::vector<PackRec> wave, mfma;
+    for (int n = 0; n < n_nets; ++n) {
+        describe_plain_image(m, n, (uint32_t)m->plain_off[n], plain);
+        if (m->d_wave) describe_wave_image(m, n, (uint32_t)(wave_net_floats(D) * n), wave);
+        if (m->mfma_ok) describe_mfma_image(m, n, (uint32_t)((int64_t)m->mdev.net_floats * n), mfma);
+    }
+    std::vector<PackRec>* lists[3] = {&plain, &wave, &mfma};
+    for (int i = 0; i < 3; ++i) {
+        m->n_pack[i] = (int64_t)lists[i]->size();
+        if (lists[i]->empty()) continue;
+        int rc = dev_alloc(m, &m->d_pack[i], lists[i]->size());
+        if (rc) return rc;
+        WF_HIP(hipMemcpy(m->d_pack[i], lists[i]->data(), lists[i]->size() * sizeof(PackRec), hipMemcpyHostToDevice));
+    }
+    return dev_alloc(m, &m->d_flat, (size_t)std::max<int64_t>(m->n_params, 1));
+}
+
 static int grad_prepare(wf_model* m) {
     const wf_model_desc& d = m->desc;
     const int D = d.n_dim;
+    std::vector<PackRec> plain;
+    {
+        int rc = pack_prepare(m, plain);
+        if (rc) return rc;
+    }
     m->wave_ok = wave_capable(m);
     if (m->wave_ok) {
         std::vector<float> fk(128, 0.0f), acc(64);
@@ -729,13 +751,11 @@ static int grad_prepare(wf_model* m) {
     m->grad_psi_ok = d.prior_kind == WF_PRIOR_WAVEFLOW && d.layer_kind == WF_LAYER_IMADE && d.n_flow_layers > 0;
     const int n_nets = (int)m->nets.size();
     const int64_t fwd = plain_fwd_floats(D, m->nbp);
-    std::vector<float> code((size_t)m->n_params), img((size_t)plain_net_floats(D, m->nbp));
-    for (int64_t i = 0; i < m->n_params; ++i) code[(size_t)i] = (float)(i + 1);
+    // the plain description lists net n's forward-orientation entries first (plain_net_floats per net)
     std::vector<int32_t> map((size_t)(fwd * n_nets));
-    for (int n = 0; n < n_nets; ++n) {
-        build_plain_image(m, n, code.data(), img.data());
-        for (int64_t i = 0; i < fwd; ++i) map[(size_t)(fwd * n + i)] = (int32_t)img[(size_t)i] - 1;
-    }
+    const int64_t per_net = plain_net_floats(D, m->nbp);
+    for (int n = 0; n < n_nets; ++n)
+        for (int64_t i = 0; i < fwd; ++i) map[(size_t)(fwd * n + i)] = plain[(size_t)(per_net * n + i)].src;
     int rc = dev_alloc(m, &m->d_grad_map, map.size());
     if (rc) return rc;
     WF_HIP(hipMemcpy(m->d_grad_map, map.data(), map.size() * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -845,39 +865,49 @@ int wf_model_set_kernel(wf_model* m, int kernel_kind) {
     return WF_OK;
 }
 
+// fills every weight image from the device-resident flat vector m->d_flat (asynchronous on `stream`)
+static int apply_params(wf_model* m, void* stream) {
+    void* bases[3] = {m->d_plain, m->d_wave, m->d_mfma};
+    for (int i = 0; i < 3; ++i) {
+        if (!m->n_pack[i]) continue;
+        int rc = launch_pack(m->d_flat, m->d_pack[i], m->n_pack[i], bases[i], stream);
+        if (rc) return rc;
+    }
+    if (m->mfma_ok) {
+        // composite tables of output dimension 0 (reads the plain image filled above)
+        int rc = launch_prepare_dim0(m->d_dev, (int)m->nets.size(), m->desc.n_mesh, m->d_fk_nat, m->mdev.F_I, m->mdev.F_P, m->d_comp, stream);
+        if (rc) return rc;
+    }
+    m->params_set = true;
+    return WF_OK;
+}
+
 int wf_model_set_params(wf_model* m, const float* flat_host, int64_t n, void* stream) {
     if (!m || !flat_host) return WF_ERR_INVALID;
     if (n != m->n_params) return WF_ERR_INVALID;
     DeviceGuard g(m->device);
-    std::vector<float> img;
-    try {
-        img.resize((size_t)m->plain_floats);
-    } catch (const std::bad_alloc&) {
-        return WF_ERR_NOMEM;
-    }
-    for (size_t i = 0; i < m->nets.size(); ++i) build_plain_image(m, (int)i, flat_host, img.data() + m->plain_off[i]);
     hipStream_t s = (hipStream_t)stream;
-    if (!img.empty()) WF_HIP(hipMemcpyAsync(m->d_plain, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice, s));
-    std::vector<float> wimg;
-    if (m->d_wave) {
-        const int64_t wf = wave_net_floats(m->desc.n_dim);
-        wimg.resize((size_t)(wf * (int64_t)m->nets.size()));
-        for (size_t i = 0; i < m->nets.size(); ++i) build_wave_image(m, (int)i, flat_host, wimg.data() + wf * (int64_t)i);
-        if (!wimg.empty()) WF_HIP(hipMemcpyAsync(m->d_wave, wimg.data(), wimg.size() * sizeof(float), hipMemcpyHostToDevice, s));
-    }
-    std::vector<float> mimg;
-    if (m->mfma_ok) {
-        mimg.assign((size_t)m->mfma_floats, 0.0f);
-        for (size_t i = 0; i < m->nets.size(); ++i) build_mfma_image(m, (int)i, flat_host, mimg.data() + (size_t)m->mdev.net_floats * i);
-        std::copy(m->mfma_consts.begin(), m->mfma_consts.end(), mimg.begin() + m->mdev.const_img_off);
-        WF_HIP(hipMemcpyAsync(m->d_mfma, mimg.data(), mimg.size() * sizeof(float), hipMemcpyHostToDevice, s));
-        // composite tables of output dimension 0 (needs the plain image uploaded above)
-        int rc = launch_prepare_dim0(m->d_dev, (int)m->nets.size(), m->desc.n_mesh, m->d_fk_nat, m->mdev.F_I, m->mdev.F_P, m->d_comp, stream);
-        if (rc) return rc;
-    }
-    WF_HIP(hipStreamSynchronize(s));
-    m->params_set = true;
+    if (n > 0) WF_HIP(hipMemcpyAsync(m->d_flat, flat_host, (size_t)n * sizeof(float), hipMemcpyHostToDevice, s));
+    int rc = apply_params(m, stream);
+    if (rc) return rc;
+    WF_HIP(hipStreamSynchronize(s));   // the caller may reuse flat_host
     return WF_OK;
+}
+
+int wf_model_set_params_device(wf_model* m, const float* flat_dev, int64_t n, void* stream) {
+    if (!m || !flat_dev) return WF_ERR_INVALID;
+    if (n != m->n_params) return WF_ERR_INVALID;
+    DeviceGuard g(m->device);
+    if (n > 0 && flat_dev != m->d_flat)
+        WF_HIP(hipMemcpyAsync(m->d_flat, flat_dev, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return apply_params(m, stream);
+}
+
+int wf_adam_step(float* params_dev, const float* grad_dev, float* m_dev, float* v_dev, int64_t n, int64_t step, float step_size, float b1,
+                 float b2, float eps, void* stream) {
+    if (n < 0 || step < 0 || (n > 0 && (!params_dev || !grad_dev || !m_dev || !v_dev))) return WF_ERR_INVALID;
+    if (n == 0) return WF_OK;
+    return launch_adam(params_dev, grad_dev, m_dev, v_dev, n, step, step_size, b1, b2, eps, stream);
 }
 
 static int check_fwd(const wf_model* m, const void* x, int64_t B, const void* out) {

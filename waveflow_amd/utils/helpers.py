@@ -28,6 +28,8 @@ def _np(a):
 
 
 def _to_numpy_tree(t):
+    if hasattr(t, "tree") and hasattr(t, "flat"):   # core.DeviceParams
+        return _to_numpy_tree(t.tree())
     if isinstance(t, tuple):
         return tuple(_to_numpy_tree(q) for q in t)
     if isinstance(t, list):

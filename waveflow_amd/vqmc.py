@@ -16,25 +16,49 @@ from pathlib import Path
 import numpy as np
 
 from . import checkpoint
-from .core import flatten_params
+from .core import DeviceParams, flatten_params
 from .model_factory import get_waveflow_model
 from .utils import helpers, physics
 
 
 class OptState:
-    """Adam state over the flat parameter vector (reference leaf order); `template` restores the pytree."""
+    """Adam state over the flat parameter vector (reference leaf order); `template` restores the pytree.  x, m, v are numpy
+    vectors (host state) or float32 cuda tensors (device state: parameters and optimiser never leave the GPU)."""
 
-    def __init__(self, template, x, m, v):
-        self.template, self.x, self.m, self.v = template, x, m, v
+    def __init__(self, template, x, m, v, model=None):
+        self.template, self.x, self.m, self.v, self.model = template, x, m, v, model
+        self.version = 0
+
+    @property
+    def on_device(self):
+        return self.model is not None
 
 
-def adam(step_size, b1=0.9, b2=0.999, eps=1e-8):
-    """-> (opt_init, opt_update, get_params), the triple protocol of jax.example_libraries.optimizers."""
+def adam(step_size, b1=0.9, b2=0.999, eps=1e-8, model=None):
+    """-> (opt_init, opt_update, get_params), the triple protocol of jax.example_libraries.optimizers.
+    With `model` (a DeviceModel) the state lives on that model's GPU, opt_update runs wf_adam_step in place and get_params
+    returns core.DeviceParams; otherwise everything is numpy on the host."""
+    def lr_at(i):
+        return float(step_size(i) if callable(step_size) else step_size)
+
     def opt_init(params):
         x = flatten_params(params).astype(np.float32)
-        return OptState(params, x, np.zeros_like(x), np.zeros_like(x))
+        if model is None:
+            return OptState(params, x, np.zeros_like(x), np.zeros_like(x))
+        import torch
+        dev = f"cuda:{model.device}"
+        template = params.template if isinstance(params, DeviceParams) else params
+        xd = torch.as_tensor(x).to(dev)
+        return OptState(template, xd, torch.zeros_like(xd), torch.zeros_like(xd), model=model)
 
     def opt_update(i, grads, state):
+        if state.on_device:
+            import torch
+            g = grads if hasattr(grads, "is_cuda") else torch.as_tensor(flatten_params(grads) if not isinstance(grads, np.ndarray) else grads)
+            g = g.to(state.x.device, dtype=torch.float32).contiguous()
+            state.model.adam_step(state.x, g, state.m, state.v, i, lr_at(i), b1, b2, eps)
+            state.version += 1
+            return state
         g = grads if isinstance(grads, np.ndarray) and grads.ndim == 1 else flatten_params(grads)
         g = np.asarray(g, dtype=np.float32)
         one = np.float32(1.0)
@@ -42,11 +66,12 @@ def adam(step_size, b1=0.9, b2=0.999, eps=1e-8):
         v = (one - np.float32(b2)) * np.square(g) + np.float32(b2) * state.v
         mhat = m / (one - np.float32(b1) ** np.float32(i + 1))
         vhat = v / (one - np.float32(b2) ** np.float32(i + 1))
-        lr = np.float32(step_size(i) if callable(step_size) else step_size)
-        x = state.x - lr * mhat / (np.sqrt(vhat) + np.float32(eps))
+        x = state.x - np.float32(lr_at(i)) * mhat / (np.sqrt(vhat) + np.float32(eps))
         return OptState(state.template, x.astype(np.float32), m, v)
 
     def get_params(state):
+        if state.on_device:
+            return DeviceParams(state.template, state.x, state.version)
         return checkpoint.unflatten_like(state.template, state.x)
 
     return opt_init, opt_update, get_params
@@ -60,7 +85,7 @@ def create_train_state(box_length, learning_rate, n_particle, rng=0, xu_coord_ty
                                   i_spline_reg=0.05, i_spline_reverse_fun_tol=0.000001,
                                   n_flow_layers=n_flow_layers, box_size=box_length, xu_coord_type=xu_coord_type)
     params, psi, log_pdf, sample = init_fun(rng, n_particle)
-    opt_init, opt_update, get_params = adam(step_size=learning_rate)
+    opt_init, opt_update, get_params = adam(step_size=learning_rate, model=psi.model)   # state on the model's GPU
     return psi, log_pdf, sample, opt_init(params), opt_update, get_params
 
 
@@ -73,7 +98,8 @@ def loss_fn_efficient(params, psi, h_fn, batch, running_average):
 
 def loss_and_grad_efficient(params, psi, h_fn, batch, running_average, group=None):
     """value_and_grad(loss_fn_efficient) with the custom tangent rule (vqmc.py:198-212, 215-221) over the walkers of ALL ranks
-    of `group` (each rank passes its own shard).  -> (loss, flat gradient [n_params] float32, (mean, variance, stderr) of E_L)."""
+    of `group` (each rank passes its own shard).  -> (loss, flat gradient [n_params] float32 cuda tensor, (mean, variance,
+    stderr) of E_L)."""
     from .distributed import all_reduce_gradient_and_moments, global_count, moments_to_stats
     model = psi.model
     model.ensure_params(params)
@@ -85,7 +111,7 @@ def loss_and_grad_efficient(params, psi, h_fn, batch, running_average, group=Non
     sums, grad = model.vqmc_loss_grad(batch, pos, float(np.asarray(running_average).reshape(-1)[0]), global_count=n_global)
     grad, sums = all_reduce_gradient_and_moments(grad, sums, group)   # one collective per step
     s = sums.cpu().tolist()
-    return s[0] / s[2], grad.cpu().numpy(), moments_to_stats(s)
+    return s[0] / s[2], grad, moments_to_stats(s)
 
 
 def train_step_efficient(epoch, psi, h_fn, opt_update, opt_state, params, batch, running_average, group=None):
@@ -130,7 +156,9 @@ class ModelTrainer:
             # unlike vqmc.py:68-71, which reloads the parameters but keeps stepping the freshly initialised optimiser state
             # (so the reloaded parameters are dropped after one step), a restart here continues from the checkpoint
             params, start_epoch = checkpoint.load_reference_checkpoint(f'{save_dir}/checkpoints')
-            opt_state.x = flatten_params(params).astype(np.float32)
+            import torch
+            opt_state.x.copy_(torch.as_tensor(flatten_params(params).astype(np.float32)))
+            opt_state.version += 1
             loss = np.load(f'{save_dir}/loss.npy').tolist()
             energies = np.load(f'{save_dir}/energies.npy').tolist()
         params = get_params(opt_state)
