@@ -80,26 +80,30 @@ template <class T> __device__ __forceinline__ void put(float (*buf)[64], int lan
     for (int k = 0; k < T::NC; ++k) buf[k][lane] = coef(v, k);
     __builtin_amdgcn_wave_barrier();
 }
-// out[lane] = sum_a in[a] * W[lane][a], W in lane-major float4 groups
+// out[lane] = sum_a in[a] * W[lane][a], W in lane-major float4 groups.  Even and odd a accumulate in the two halves of a
+// packed pair (v_pk_fma_f32: two FMAs per lane and instruction) and are added at the end.
+using float2_t = __attribute__((ext_vector_type(2))) float;
 template <class T>
 __device__ __forceinline__ T gemv(const float4_t* __restrict__ img, const float (*buf)[64], int lane) {
-    float acc[T::NC];
+    float2_t acc[T::NC];
 #pragma unroll
-    for (int k = 0; k < T::NC; ++k) acc[k] = 0.0f;
+    for (int k = 0; k < T::NC; ++k) acc[k] = float2_t{0.0f, 0.0f};
 #pragma unroll 4
     for (int g = 0; g < 16; ++g) {
         const float4_t w = img[g * 64 + lane];
+        const float2_t wlo = {w.x, w.y}, whi = {w.z, w.w};
 #pragma unroll
         for (int k = 0; k < T::NC; ++k) {
             const float4_t x = *reinterpret_cast<const float4_t*>(&buf[k][4 * g]);
-            acc[k] = __builtin_fmaf(w.x, x.x, acc[k]);
-            acc[k] = __builtin_fmaf(w.y, x.y, acc[k]);
-            acc[k] = __builtin_fmaf(w.z, x.z, acc[k]);
-            acc[k] = __builtin_fmaf(w.w, x.w, acc[k]);
+            acc[k] = __builtin_elementwise_fma(wlo, float2_t{x.x, x.y}, acc[k]);
+            acc[k] = __builtin_elementwise_fma(whi, float2_t{x.z, x.w}, acc[k]);
         }
     }
     __builtin_amdgcn_wave_barrier();
-    return from_arr((T*)nullptr, acc);
+    float out[T::NC];
+#pragma unroll
+    for (int k = 0; k < T::NC; ++k) out[k] = acc[k].x + acc[k].y;
+    return from_arr((T*)nullptr, out);
 }
 // out[lane (half h, j)] = sum_{a < 32} in[h][a] * M[a][j]   (M: [32][32] row-major; in = buf of this lane's half)
 template <class T>
