@@ -2,6 +2,8 @@
 (only the import changes; optional overrides on the command line for a short run):
 
     python examples/run_vqmc.py [--epochs N] [--batch B] [--lr LR] [--exact-sampler] [--save-dir DIR]
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 examples/run_vqmc.py --batch 8192 ...
+        (one process per GPU: the walkers of a step are split over the ranks, one RCCL all-reduce per step)
 """
 import argparse
 import os
@@ -10,6 +12,16 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from waveflow_amd import vqmc  # noqa: E402   (reference: from waveflow import vqmc)
+
+if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("WF_FORCE_DIST") == "1":
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    dist.init_process_group("nccl", rank=int(os.environ.get("RANK", "0")), world_size=int(os.environ.get("WORLD_SIZE", "1")),
+                            device_id=torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))))
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--epochs", type=int, default=80000)

@@ -91,7 +91,7 @@ def test_training_reduces_the_energy_and_writes_the_reference_artefacts(tmp_path
     params, loss = t.start_training(verbose=False)
     l = np.asarray(loss[1:], dtype=np.float64)
     assert np.isfinite(l).all() and len(l) == 300
-    assert l[-50:].mean() < 0.5 * l[:50].mean()           # <E_L> falls (it starts around +10 .. +50 Ha)
+    assert np.median(l[-50:]) < 0.5 * np.median(l[:50])   # <E_L> falls (it starts around +10 .. +50 Ha; batch means are heavy-tailed)
     # artefacts of helpers.create_checkpoint_wavefunc / vqmc.py:79-88
     sd = t.save_dir
     assert json.load(open(f"{sd}/system_info.json"))["n_particle"] == 2
@@ -105,7 +105,7 @@ def test_training_reduces_the_energy_and_writes_the_reference_artefacts(tmp_path
     t2.save_dir, t2.exact_sampler = sd, True
     params2, loss2 = t2.start_training(restart=True, verbose=False)
     assert len(loss2) == len(np.load(f"{sd}/loss.npy")) + 1 or len(loss2) >= 320
-    assert np.mean(loss2[-20:]) < l[:50].mean()
+    assert np.median(loss2[-20:]) < np.median(l[:50])
     assert checkpoint.load_reference_checkpoint(f"{sd}/checkpoints")[1] == 320
 
 
@@ -319,3 +319,21 @@ def test_training_step_is_graph_capturable(he_flat):
     assert np.mean(np.abs(mg_ - me_) > 1e-5) < 0.25
     np.testing.assert_allclose(sg[0].cpu().numpy(), se[0].cpu().numpy(), rtol=1e-6)     # same parameters: same energies
     np.testing.assert_allclose(sg[2].cpu().numpy()[0], se[2].cpu().numpy()[0], rtol=5e-2)   # after two noisy-entry moves
+
+
+def test_run_vqmc_example_under_torchrun_single_rank(tmp_path):
+    """examples/run_vqmc.py through torch.distributed.run with one rank: RCCL initialises, the packed all-reduce path runs."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, WF_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(ROOT, "examples", "run_vqmc.py"), "--epochs", "40", "--batch", "256", "--lr", "1e-3",
+           "--log-every", "20", "--exact-sampler", "--save-dir", str(tmp_path / "run")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert json.load(open(tmp_path / "run" / "system_info.json"))["system_name"] == "He"
+    loss = np.load(tmp_path / "run" / "loss.npy")
+    assert len(loss) >= 39 and np.isfinite(loss).all()

@@ -143,7 +143,16 @@ class ModelTrainer:
         self.seed = 2          # vqmc.py:57: PRNGKey(2)
         self.exact_sampler = False   # False: the reference's sampler (made.py:88 quirk); True: draws from |psi|^2
 
-    def start_training(self, restart=False, verbose=True):
+    def start_training(self, restart=False, verbose=True, group=None):
+        """Under torch.distributed (one process per GPU, `torchrun examples/run_vqmc.py`) the walkers of a step are split over
+        the ranks: every rank builds the same model from the same seed, draws batch_size / world walkers with its own sampler
+        stream, and the step's single all-reduce (gradient + energy moments) keeps the replicas identical; rank 0 writes."""
+        import torch.distributed as dist
+        distributed = dist.is_available() and dist.is_initialized()
+        rank = dist.get_rank(group) if distributed else 0
+        world = dist.get_world_size(group) if distributed else 1
+        local_batch = (self.batch_size * (rank + 1)) // world - (self.batch_size * rank) // world
+        verbose = verbose and rank == 0
         save_dir = self.save_dir
         rng = np.random.default_rng(self.seed)
         psi, log_pdf, sample, opt_state, opt_update, get_params = create_train_state(
@@ -163,19 +172,21 @@ class ModelTrainer:
             energies = np.load(f'{save_dir}/energies.npy').tolist()
         params = get_params(opt_state)
         running_average = np.zeros(1)
-        helpers.make_result_dirs(save_dir)
         system_dict = {"system_name": self.system_name, "box_length": self.box_length, "n_particle": self.n_particle,
                        "n_space_dimension": self.n_space_dimension, "window": self.window, "n_plotting": self.n_plotting}
-        with open(f"{save_dir}/system_info.json", "w") as fout_sys:
-            json.dump(system_dict, fout_sys, indent=4)
+        if rank == 0:
+            helpers.make_result_dirs(save_dir)
+            with open(f"{save_dir}/system_info.json", "w") as fout_sys:
+                json.dump(system_dict, fout_sys, indent=4)
         if verbose:
             print("Start training...")
         for epoch in range(start_epoch + 1, start_epoch + self.num_epochs + 1):
-            if epoch % self.log_every == 0 or epoch == 1:
-                helpers.create_checkpoint_wavefunc(int(rng.integers(1 << 31)), save_dir, psi, sample, params, epoch, loss, energies,
-                                                   system_dict)
-            batch = sample(int(rng.integers(1 << 31)), params, self.batch_size, exact_inverse=self.exact_sampler)
-            opt_state, new_loss = train_step_efficient(epoch, psi, h_fn, opt_update, opt_state, params, batch, running_average)
+            ckpt_seed, step_seed = int(rng.integers(1 << 31)), int(rng.integers(1 << 31))   # same host stream on every rank
+            if (epoch % self.log_every == 0 or epoch == 1) and rank == 0:
+                helpers.create_checkpoint_wavefunc(ckpt_seed, save_dir, psi, sample, params, epoch, loss, energies, system_dict)
+            batch = sample(step_seed + 7919 * rank, params, local_batch, exact_inverse=self.exact_sampler)
+            opt_state, new_loss = train_step_efficient(epoch, psi, h_fn, opt_update, opt_state, params, batch, running_average,
+                                                       group=group)
             if epoch % 100 == 0:
                 running_average = np.asarray(loss[-100:]).mean()
             if epoch % self.log_every == 0 and verbose:
