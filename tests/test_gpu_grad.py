@@ -328,9 +328,14 @@ def test_run_vqmc_example_under_torchrun_single_rank(tmp_path):
     import subprocess
     import sys
     from conftest import ROOT
+    import socket
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
     env = dict(os.environ, WF_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", "29547", os.path.join(ROOT, "examples", "run_vqmc.py"), "--epochs", "40", "--batch", "256", "--lr", "1e-3",
+           "--master-port", str(port), os.path.join(ROOT, "examples", "run_vqmc.py"), "--epochs", "40", "--batch", "256", "--lr", "1e-3",
            "--log-every", "20", "--exact-sampler", "--save-dir", str(tmp_path / "run")]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
