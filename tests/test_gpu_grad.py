@@ -69,7 +69,8 @@ def test_psi_vjp_chunks_and_errors(he_flat):
     x = torch.as_tensor(sorted_walkers(1000, 2, 8.0, 9)).cuda()
     w = torch.ones(1000, device="cuda")
     full = m.psi_vjp(x, w, w * 0.1)
-    # a workspace that only holds 128 samples forces 16 chunks: same gradient up to the order of the atomic sums
+    assert torch.equal(full, m.psi_vjp(x, w, w * 0.1))      # fixed-order reductions: bitwise reproducible
+    # a workspace that only holds 128 samples forces 16 chunks: same gradient up to the grouping of the sums
     per = L.wf_psi_vjp_workspace_bytes(m._h, 1) // 64
     ws = torch.empty(per * 128, device="cuda", dtype=torch.uint8)
     grad = torch.empty(m.n_params, device="cuda")
@@ -309,16 +310,11 @@ def test_training_step_is_graph_capturable(he_flat):
     torch.cuda.current_stream().wait_stream(side)
     graph.replay()
     torch.cuda.synchronize()
-    # atomics in the weight-gradient contraction make the gradient order-dependent in the last bits, and Adam turns an entry
-    # that is pure rounding noise into a full +-step_size move: compare the moves statistically, not entry by entry
-    x0 = he_flat.astype(np.float64)
-    mg_, me_ = xg.cpu().numpy() - x0, xe.cpu().numpy() - x0
-    assert np.abs(mg_).max() <= 3 * 1e-3 * 1.01 and np.abs(mg_).max() > 1e-3
-    live = np.abs(me_) > 0
-    assert np.corrcoef(mg_[live], me_[live])[0, 1] > 0.95
-    assert np.mean(np.abs(mg_ - me_) > 1e-5) < 0.25
-    np.testing.assert_allclose(sg[0].cpu().numpy(), se[0].cpu().numpy(), rtol=1e-6)     # same parameters: same energies
-    np.testing.assert_allclose(sg[2].cpu().numpy()[0], se[2].cpu().numpy()[0], rtol=5e-2)   # after two noisy-entry moves
+    # every reduction runs in a fixed order (no atomics): the replay reproduces the eager run bit for bit
+    assert np.array_equal(xg.cpu().numpy(), xe.cpu().numpy())
+    for a_, b_ in zip(sg, se):
+        assert np.array_equal(a_.cpu().numpy(), b_.cpu().numpy())
+    assert np.abs(xg.cpu().numpy() - he_flat).max() > 1e-3
 
 
 def test_run_vqmc_example_under_torchrun_single_rank(tmp_path):

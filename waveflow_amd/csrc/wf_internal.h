@@ -129,7 +129,9 @@ struct Protons {
 };
 // reverse pass (wf_kernels_grad.hip)
 int grad_ws_rows(int D);
-int launch_wgrad(int D, int second_order, int n_nets, int64_t n_samples, const float* ws, float* grad_img, int64_t net_img_floats, void* stream);
+int wgrad_partial_floats(int n_nets, int64_t net_img_floats);
+int launch_wgrad(int D, int second_order, int n_nets, int64_t n_samples, const float* ws, float* partial, int accumulate, float* grad_img,
+                 int64_t net_img_floats, void* stream);
 int launch_wave_fwd(const ModelDev& md, const ModelDev* md_dev, int second_order, const float* tabI4, const float* tabP4, const float* fk_nat,
                     const float* x, int64_t B, float* ws, float* tails, int taped, void* stream);
 int launch_wave_bwd(const ModelDev& md, const ModelDev* md_dev, int mode, int second_order, const float* tabI4, const float* tabP4,

@@ -23,7 +23,8 @@
 // The forward and reverse sweeps are the wave-cooperative kernels of wf_kernels_wave.hip; they leave, per sample and
 // net, the layer input U, the hidden activations H1, H2 and the pre-activation adjoints A1, A2, O in a tape in HBM
 // ([sample][net][coefficient][row], row-contiguous).  Here: k_wgrad contracts activations with adjoints over all samples
-// (LDS-tiled 64x64x32, split over the sample axis, fp32 atomics) into a gradient image in the forward weight-image
+// (LDS-tiled 64x64x32, split over the sample axis into per-split partial images that are summed in split order: no
+// atomics, bitwise reproducible) into a gradient image in the forward weight-image
 // layout; k_grad_scatter moves that image to the reference's flat leaf order.  Checker: oracle/energy_torch.py (torch
 // reverse mode through the Hessian trace) and central differences of the fp64 C oracle.
 #include <hip/hip_runtime.h>
@@ -51,6 +52,7 @@ struct WJobs {
 };
 constexpr int kWT = 64;   // output tile
 constexpr int kWK = 32;   // samples per staged slab
+constexpr int kWgradSplit = 64;   // workgroups along the sample axis per (net, matrix, tile): 64 x 3..6 x n_nets fills the chip
 template <int NC>
 __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ ws, int n_nets, int64_t n_samples, int rows, const WJobs jobs,
                                                int n_ntiles_max, float* __restrict__ gimg, int64_t net_img_floats) {
@@ -104,20 +106,30 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ ws, int
             }
         }
     }
-    float* __restrict__ g = gimg + (int64_t)net * net_img_floats;
+    // every image entry belongs to exactly one (job, tile, thread): plain stores into this split's partial image
+    float* __restrict__ g = gimg + ((int64_t)blockIdx.x * n_nets + net) * net_img_floats;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int m = tm * 4 + i, n = n0 + tn * 4 + j;
-            if (m < jb.M && n < jb.N) atomicAdd(&g[jb.out + (int64_t)m * jb.sm + (int64_t)n * jb.sn], acc[i][j]);
+            if (m < jb.M && n < jb.N) g[jb.out + (int64_t)m * jb.sm + (int64_t)n * jb.sn] = acc[i][j];
         }
     if (tm == 0)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + tn * 4 + j;
-            if (n < jb.N) atomicAdd(&g[jb.bias + n], bacc[j]);
+            if (n < jb.N) g[jb.bias + n] = bacc[j];
         }
+}
+
+// grad_img[i] (+)= sum over the splits, in split order: the gradient is bitwise reproducible
+__global__ void k_wgrad_reduce(const float* __restrict__ partial, int split, int64_t n_img, int accumulate, float* __restrict__ gimg) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_img) return;
+    float s = accumulate ? gimg[i] : 0.0f;
+    for (int p = 0; p < split; ++p) s += partial[(int64_t)p * n_img + i];
+    gimg[i] = s;
 }
 
 __global__ void k_grad_scatter(const float* __restrict__ gimg, const int32_t* __restrict__ map, int64_t n_img, float* __restrict__ flat) {
@@ -193,7 +205,8 @@ int finish() {
 }
 
 template <int D, int NC>
-int run_wgrad(int n_nets, int64_t n_samples, const float* ws, float* grad_img, int64_t net_img_floats, hipStream_t s) {
+int run_wgrad(int n_nets, int64_t n_samples, const float* ws, float* partial, int accumulate, float* grad_img, int64_t net_img_floats,
+              hipStream_t s) {
     using R = Rows<D>;
     if (n_nets == 0 || n_samples == 0) return WF_OK;
     // forward-image layout of one net: W0 [D][64], b0 [64], W1t [64 out][64 in], b1 [64], W2t [D*NBP][64], b2 [D*NBP]
@@ -204,10 +217,13 @@ int run_wgrad(int n_nets, int64_t n_samples, const float* ws, float* grad_img, i
     jobs.j[2] = WJob{R::H2, H, R::O, D * NBP, oW2, 1, H, ob2};      // dW2t[(d, jb)][a]
     const int n_ntiles = (D * NBP + kWT - 1) / kWT;
     const int64_t n_slabs = (n_samples + kWK - 1) / kWK;
-    int split = (int)(n_slabs < 256 ? n_slabs : 256);
+    int split = (int)(n_slabs < kWgradSplit ? n_slabs : kWgradSplit);
     if (split < 1) split = 1;
     hipLaunchKernelGGL((k_wgrad<NC>), dim3((unsigned)split, (unsigned)(3 * n_ntiles), (unsigned)n_nets), dim3(256), 0, s, ws, n_nets, n_samples,
-                       R::N, jobs, n_ntiles, grad_img, net_img_floats);
+                       R::N, jobs, n_ntiles, partial, net_img_floats);
+    const int64_t n_img = (int64_t)n_nets * net_img_floats;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((n_img + 255) / 256)), dim3(256), 0, s, (const float*)partial, split, n_img, accumulate,
+                       grad_img);
     return finish();
 }
 
@@ -216,10 +232,14 @@ int run_wgrad(int n_nets, int64_t n_samples, const float* ws, float* grad_img, i
 int grad_ws_rows(int D) { return 4 + 4 * H + D * NBP; }
 
 // tape -> gradient image: sum over samples of activation (x) adjoint, top ring coefficient
-int launch_wgrad(int D, int second_order, int n_nets, int64_t n_samples, const float* ws, float* grad_img, int64_t net_img_floats, void* stream) {
+int wgrad_partial_floats(int n_nets, int64_t net_img_floats) { return kWgradSplit * n_nets * (int)net_img_floats; }
+
+// partial: wgrad_partial_floats scratch; accumulate != 0 adds to grad_img (further chunks of a batch) instead of overwriting it
+int launch_wgrad(int D, int second_order, int n_nets, int64_t n_samples, const float* ws, float* partial, int accumulate, float* grad_img,
+                 int64_t net_img_floats, void* stream) {
     hipStream_t s = (hipStream_t)stream;
-#define CALL(DD) return second_order ? run_wgrad<DD, 3>(n_nets, n_samples, ws, grad_img, net_img_floats, s) \
-                                     : run_wgrad<DD, 1>(n_nets, n_samples, ws, grad_img, net_img_floats, s)
+#define CALL(DD) return second_order ? run_wgrad<DD, 3>(n_nets, n_samples, ws, partial, accumulate, grad_img, net_img_floats, s) \
+                                     : run_wgrad<DD, 1>(n_nets, n_samples, ws, partial, accumulate, grad_img, net_img_floats, s)
     switch (D) {
         case 2: CALL(2);
         case 3: CALL(3);

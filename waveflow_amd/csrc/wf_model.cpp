@@ -96,6 +96,7 @@ struct wf_model {
     bool wave_ok = false;            // the wave-cooperative kernels cover this model (<= 32 bases, zero-only constraints)
     bool grad_psi_ok = false;        // wf_psi_vjp (Waveflow prior, IMADE layers)
     int32_t* d_grad_map = nullptr;   // [n_nets * fwd image floats]: flat parameter index of each forward-image entry, -1 = none
+    float* d_grad_partial = nullptr; // per-split partial gradient images of k_wgrad
     float* d_grad_img = nullptr;     // [n_nets * fwd image floats]: gradient accumulator in forward-image layout
 };
 
@@ -759,6 +760,8 @@ static int grad_prepare(wf_model* m) {
     int rc = dev_alloc(m, &m->d_grad_map, map.size());
     if (rc) return rc;
     WF_HIP(hipMemcpy(m->d_grad_map, map.data(), map.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    rc = dev_alloc(m, &m->d_grad_partial, (size_t)wgrad_partial_floats(n_nets, fwd));
+    if (rc) return rc;
     return dev_alloc(m, &m->d_grad_img, map.size());
 }
 
@@ -1059,7 +1062,7 @@ static int run_vjp_chunks(const wf_model* m, int mode, bool second_order, const 
     float* tape = (float*)workspace_dev;
     float* tails = tape + chunk * samples_per * n_nets * grad_ws_rows(D) * nc;
     float* per_walker = tails + chunk * wave_tail_floats(D, second_order ? 1 : 0);   // [4][chunk]
-    WF_HIP(hipMemsetAsync(m->d_grad_img, 0, (size_t)n_img * sizeof(float), s));
+    WF_HIP(hipMemsetAsync(m->d_grad_img, 0, (size_t)n_img * sizeof(float), s));   // (B == 0: the gradient is zero)
     WF_HIP(hipMemsetAsync(grad_dev, 0, (size_t)m->n_params * sizeof(float), s));
     for (int64_t c0 = 0; c0 < B; c0 += chunk) {
         const int64_t bc = std::min(chunk, B - c0);
@@ -1079,7 +1082,7 @@ static int run_vjp_chunks(const wf_model* m, int mode, bool second_order, const 
         rc = launch_wave_bwd(m->dev, m->d_dev, mode == 0 ? 0 : 1, second_order ? 1 : 0, m->d_tabI4, m->d_tabP3, m->d_grad_fk, bc, cw1, cw2, tape,
                              tails, stream);
         if (rc) return rc;
-        rc = launch_wgrad(D, second_order ? 1 : 0, n_nets, bc * samples_per, tape, m->d_grad_img, fwd, stream);
+        rc = launch_wgrad(D, second_order ? 1 : 0, n_nets, bc * samples_per, tape, m->d_grad_partial, c0 > 0, m->d_grad_img, fwd, stream);
         if (rc) return rc;
     }
     return launch_grad_scatter(m->d_grad_img, m->d_grad_map, n_img, grad_dev, stream);
