@@ -55,7 +55,7 @@ typedef enum { WF_BOX_NONE = 0, WF_BOX_MEAN = 1, WF_BOX_FIRST = 2 } wf_box_kind;
  * :67-112 (Flow) with Uniform (:26-41, prior_support=(0,1)) or Normal(offset) (:8-23) priors */
 typedef enum { WF_PRIOR_WAVEFLOW = 0, WF_PRIOR_MFLOW = 1, WF_PRIOR_UNIFORM = 2, WF_PRIOR_NORMAL = 3 } wf_prior_kind;
 /* which device kernel evaluates the model */
-typedef enum { WF_KERNEL_AUTO = 0, WF_KERNEL_SCALAR = 1, WF_KERNEL_MFMA = 2 } wf_kernel_kind;
+typedef enum { WF_KERNEL_AUTO = 0, WF_KERNEL_SCALAR = 1, WF_KERNEL_MFMA = 2, WF_KERNEL_WAVE = 3 } wf_kernel_kind;
 
 /* constraints_dict_{left,right}: {n_derivative: value} in insertion order
  * (isplines_jax.py:158-194, bsplines_jax.py:173-199, msplines_jax.py:156-184) */

@@ -18,6 +18,7 @@ pytestmark = pytest.mark.gpu
 #   * median deviation within 2x the fp32 oracle's median.
 RTOL, ATOL = 1e-5, 2e-5
 KERNELS = ["scalar", "mfma"]
+KERNELS_ALL = KERNELS + ["wave"]   # the wave kernel (small-batch path) does not report bin indices
 
 
 def _torch():
@@ -59,7 +60,7 @@ def he_models(he_flat, kernel):
     return params, psi, log_pdf, oracle.he_model(10.0)
 
 
-@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("kernel", KERNELS_ALL)
 def test_he_checkpoint_vs_reference_golden_grid(golden, he_flat, kernel):
     params, psi, log_pdf, om = he_models(he_flat, kernel)
     g = golden["he_golden"]
@@ -74,7 +75,7 @@ def test_he_checkpoint_vs_reference_golden_grid(golden, he_flat, kernel):
         assert np.abs(psi(params, np.sort(c, -1)) * s - g[nm + "_values"]).max() < 1e-5
 
 
-@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("kernel", KERNELS_ALL)
 def test_he_logpdf_vs_oracle_samples_and_uniform_walkers(golden, he_flat, kernel):
     params, psi, log_pdf, om = he_models(he_flat, kernel)
     # C2: the 250 reference samples + 6 grid rows (batch 256)
@@ -127,7 +128,7 @@ def test_end_to_end_bin_index_mismatch_rate(he_flat, kernel):
     as_accurate_as_fp32_reference(lp, lpo, om.log_pdf(he_flat, x, threads=8, f64=True))
 
 
-@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("kernel", KERNELS_ALL)
 @pytest.mark.parametrize("B", [0, 1, 63, 64, 255, 257, 1000])
 def test_ragged_and_empty_batches(he_flat, kernel, B):
     params, psi, log_pdf, om = he_models(he_flat, kernel)
@@ -140,7 +141,7 @@ def test_ragged_and_empty_batches(he_flat, kernel, B):
         as_accurate_as_fp32_reference(lp, om.log_pdf(he_flat, x), om.log_pdf(he_flat, x, f64=True))
 
 
-@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("kernel", KERNELS_ALL)
 def test_single_walker_promotion(he_flat, kernel):
     """wavefunctions.py:35-36: a 1-D input is one walker."""
     params, psi, log_pdf, om = he_models(he_flat, kernel)
@@ -149,7 +150,7 @@ def test_single_walker_promotion(he_flat, kernel):
     close(psi(params, x), om.psi(he_flat, x[None], f64=True), rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("kernel", KERNELS_ALL)
 def test_torch_device_tensors_and_streams(he_flat, kernel):
     torch = _torch()
     params, psi, log_pdf, om = he_models(he_flat, kernel)
@@ -163,7 +164,7 @@ def test_torch_device_tensors_and_streams(he_flat, kernel):
     as_accurate_as_fp32_reference(lp.cpu().numpy(), om.log_pdf(he_flat, xn, threads=8), om.log_pdf(he_flat, xn, threads=8, f64=True))
 
 
-@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("kernel", KERNELS_ALL)
 @pytest.mark.parametrize("D,box,layers,k,kn", [(2, "first", 2, 5, 16), (3, "mean", 2, 5, 16), (4, "mean", 1, 3, 10), (8, "mean", 3, 6, 23)])
 def test_waveflow_other_shapes_vs_oracle(kernel, D, box, layers, k, kn):
     """C4 (8-electron chain) and smaller shapes: no reference system exists, parity is vs the oracle only."""
@@ -205,7 +206,7 @@ def test_he_33_knot_variant_32_bins(golden, kernel):
     as_accurate_as_fp32_reference(psi(params, x), pso, pst, atol=1e-6 * np.abs(pst).max())
 
 
-@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("kernel", KERNELS_ALL)
 def test_mflow_and_flow_density_heads_vs_oracle(golden, kernel):
     """C1 (double_circles): MFlow / IFlow / Flow log_pdf.  Parity unpinned in the reference (no saved params)."""
     from waveflow_amd import flows, model_factory, flatten_params

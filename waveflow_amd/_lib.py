@@ -11,7 +11,7 @@ SPLINE_M, SPLINE_I, SPLINE_B, SPLINE_OB = 0, 1, 2, 3
 LAYER_IMADE, LAYER_MADE = 0, 1
 BOX_NONE, BOX_MEAN, BOX_FIRST = 0, 1, 2
 PRIOR_WAVEFLOW, PRIOR_MFLOW, PRIOR_UNIFORM, PRIOR_NORMAL = 0, 1, 2, 3
-KERNEL_AUTO, KERNEL_SCALAR, KERNEL_MFMA = 0, 1, 2
+KERNEL_AUTO, KERNEL_SCALAR, KERNEL_MFMA, KERNEL_WAVE = 0, 1, 2, 3
 ERR_NO_DEVICE = -4
 
 

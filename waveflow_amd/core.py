@@ -118,7 +118,7 @@ class DeviceModel:
             self.set_params(flat)
 
     def set_kernel(self, kind):
-        kind = {"auto": _lib.KERNEL_AUTO, "scalar": _lib.KERNEL_SCALAR, "mfma": _lib.KERNEL_MFMA}.get(kind, kind)
+        kind = {"auto": _lib.KERNEL_AUTO, "scalar": _lib.KERNEL_SCALAR, "mfma": _lib.KERNEL_MFMA, "wave": _lib.KERNEL_WAVE}.get(kind, kind)
         _lib.check(_lib.lib().wf_model_set_kernel(self._h, int(kind)), "wf_model_set_kernel")
 
     # ---- plumbing

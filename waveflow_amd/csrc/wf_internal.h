@@ -140,6 +140,8 @@ int launch_wave_energy(const ModelDev& md, const ModelDev* md_dev, const float* 
                        int64_t B, const Protons& pr, float* hpsi, float* psi, float* lap, float* tail_ws, void* stream);
 int launch_wave_sample(const ModelDev& md, const ModelDev* md_dev, const float* tabI4, const float* tabP4, const float* fk_nat, int draw,
                        unsigned long long seed, const float* u, int64_t B, float* x, float* latent, int exact, void* stream);
+int launch_wave_eval(const ModelDev& md, const ModelDev* md_dev, const float* tabI4, const float* tabP4, const float* fk_nat, int mode,
+                     const float* x, int64_t B, float* out, float* u, float* tail_ws, void* stream);
 int64_t wave_tail_floats(int D, int second_order);
 int launch_energy_out(int D, const float* tails, const float* x, int64_t B, unsigned constrained_mask, const Protons& pr, float* hpsi, float* psi,
                       float* lap, void* stream);

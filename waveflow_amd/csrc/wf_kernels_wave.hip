@@ -442,6 +442,54 @@ __global__ void k_energy_out(const float* __restrict__ tails, const float* __res
     if (lap_out) lap_out[b] = lap;
 }
 
+// ---- log_pdf / psi / (u, log det) per walker from the R1 tails (wavefunctions.py:33-71, distributions.py:95-102, 139-163)
+// mode 0: log_pdf, 1: psi, 2: log det only;  u_out (may be null): the latent point (clipped where the reference clips it)
+template <int D>
+__global__ void k_tail_out(const float* __restrict__ tails, int64_t B, int mode, int prior_kind, unsigned constrained_mask, float normal_offset,
+                           float* __restrict__ out, float* __restrict__ u_out) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float* tl = tails + b * (int64_t)Tail<D>::N;
+    const float ld = tl[Tail<D>::LD];
+    float res = ld;
+    if (mode == 0) {
+        float lp = 0.0f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const float v = tl[Tail<D>::V + d];
+            if (prior_kind == WF_PRIOR_WAVEFLOW) {
+                float pr = v * v;
+                if ((constrained_mask >> d) & 1u) pr = pr / 2;
+                lp = lp + logf(pr + 1e-7f);
+            } else if (prior_kind == WF_PRIOR_MFLOW) {
+                lp = lp + logf(v + 1e-7f);
+            } else if (prior_kind == WF_PRIOR_NORMAL) {
+                const float z = tl[Tail<D>::U + d] + normal_offset;
+                lp = lp + (1.8378770664093453f + z * z) / -2.0f;
+            }
+        }
+        res = lp + ld;
+    } else if (mode == 1) {
+        float prod = 1.0f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            float v = tl[Tail<D>::V + d];
+            if ((constrained_mask >> d) & 1u) v = v / sqrtf(2.0f);
+            prod = prod * v;
+        }
+        res = prod * expf(0.5f * ld);
+    }
+    out[b] = res;
+    if (u_out) {
+        const bool clip = mode != 2 && prior_kind != WF_PRIOR_NORMAL;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const float u = tl[Tail<D>::U + d];
+            u_out[b * D + d] = clip ? fminf(fmaxf(u, 0.0f), 1.0f) : u;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ reverse
 // pre-activation adjoints of one conditioner from hbar2 (this lane's hidden unit); adds the W0 path to gU
 template <int D, class T>
@@ -891,6 +939,25 @@ int launch_energy_out(int D, const float* tails, const float* x, int64_t B, unsi
         case 4: hipLaunchKernelGGL(k_energy_out<4>, grid, block, 0, s, tails, x, B, constrained_mask, pr, hpsi, psi, lap); break;
         default: return WF_ERR_UNSUPPORTED;
     }
+    return finish();
+}
+
+// log_pdf / psi / flow of B walkers through the wave kernel (low latency for small batches); tail_ws: wave_tail_floats(D, 0) * B
+int launch_wave_eval(const ModelDev& md, const ModelDev* md_dev, const float* tabI4, const float* tabP4, const float* fk_nat, int mode,
+                     const float* x, int64_t B, float* out, float* u, float* tail_ws, void* stream) {
+    int rc = launch_wave_fwd(md, md_dev, 0, tabI4, tabP4, fk_nat, x, B, nullptr, tail_ws, 0, stream);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)((B + 255) / 256)), block(256);
+#define CALL(DD) hipLaunchKernelGGL(k_tail_out<DD>, grid, block, 0, s, (const float*)tail_ws, B, mode, md.prior_kind, md.constrained_mask, \
+                                    md.normal_offset, out, u); break
+    switch (md.D) {
+        case 2: CALL(2);
+        case 3: CALL(3);
+        case 4: CALL(4);
+        default: return WF_ERR_UNSUPPORTED;
+    }
+#undef CALL
     return finish();
 }
 

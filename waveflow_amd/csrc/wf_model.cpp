@@ -862,8 +862,9 @@ int wf_model_n_bases(const wf_model* m, int which) {
 }
 
 int wf_model_set_kernel(wf_model* m, int kernel_kind) {
-    if (!m || kernel_kind < WF_KERNEL_AUTO || kernel_kind > WF_KERNEL_MFMA) return WF_ERR_INVALID;
+    if (!m || kernel_kind < WF_KERNEL_AUTO || kernel_kind > WF_KERNEL_WAVE) return WF_ERR_INVALID;
     if (kernel_kind == WF_KERNEL_MFMA && !m->mfma_ok) return WF_ERR_UNSUPPORTED;
+    if (kernel_kind == WF_KERNEL_WAVE && !(m->wave_ok && m->desc.n_dim <= 4)) return WF_ERR_UNSUPPORTED;
     m->kernel_kind = kernel_kind;
     return WF_OK;
 }
@@ -920,9 +921,32 @@ static int check_fwd(const wf_model* m, const void* x, int64_t B, const void* ou
     return WF_OK;
 }
 
+static int ensure_scratch(const wf_model* cm, int64_t floats);
+static constexpr int64_t kWaveEvalMax = 6144;   // measured crossover ~7000 walkers (scratch/crossover.py)
+
 static int dispatch(const wf_model* m, int mode, const float* x, int64_t B, float* out, float* u, int32_t* idx, void* stream) {
     DeviceGuard g(m->device);
     if (B == 0) return WF_OK;
+    // Small batches: one wave per walker (wf_kernels_wave.hip) takes 14 us for up to ~1000 walkers where the MFMA kernel,
+    // which first stages its weight images into LDS, takes 38-42 us whatever the batch; from ~7000 walkers on the MFMA
+    // kernel's throughput wins (4096: 30 vs 42 us, 8192: 46 vs 42 us).  The wave kernel does
+    // not report bin indices.
+    const bool wave_fits = m->wave_ok && m->desc.n_dim <= 4 && !idx && m->desc.n_flow_layers > 0;
+    const bool use_wave = wave_fits && (m->kernel_kind == WF_KERNEL_WAVE || (m->kernel_kind == WF_KERNEL_AUTO && B <= kWaveEvalMax));
+    if (m->kernel_kind == WF_KERNEL_WAVE && !use_wave) return WF_ERR_UNSUPPORTED;
+    if (use_wave) {
+        const int D = m->desc.n_dim;
+        const int64_t chunk = std::min<int64_t>(B, (int64_t)1 << 20);
+        int rc = ensure_scratch(m, chunk * wave_tail_floats(D, 0));
+        if (rc) return rc;
+        for (int64_t c0 = 0; c0 < B; c0 += chunk) {
+            const int64_t bc = std::min(chunk, B - c0);
+            rc = launch_wave_eval(m->dev, m->d_dev, m->d_tabI4, m->d_tabP3, m->d_grad_fk, mode, x + c0 * D, bc, out + c0, u ? u + c0 * D : nullptr,
+                                  m->d_scratch, stream);
+            if (rc) return rc;
+        }
+        return WF_OK;
+    }
     const bool use_mfma = m->mfma_ok && m->kernel_kind != WF_KERNEL_SCALAR;
 #if defined(WF_DEBUG) || defined(WF_STAMP)
     if (use_mfma && getenv("WF_DBG_PTR")) const_cast<wf_model*>(m)->mdev.dbg = (float*)strtoull(getenv("WF_DBG_PTR"), nullptr, 0);
