@@ -173,7 +173,8 @@ __device__ __forceinline__ f32x16 out_block(const float* net, const Frag (&h2)[2
 
 // The 16 table values of this lane half at x_l (a) and x_r (b) for one derivative order.
 // (The rows depend on the layer input only, but requesting them before the conditioner MFMAs costs 64 live VGPRs,
-// i.e. a wave per SIMD, and measured no faster: the kernel is issue-bound, not latency-bound.)
+// i.e. a wave per SIMD, and measured slower every time it was tried: 8 / 12 / 16 waves per workgroup 0.385 / 0.404 / 0.509 ms
+// against 0.34 ms without: the kernel is bound by issue and by register-limited occupancy, not by this latency.)
 struct Rows {
     f32x16 a, b;
 };
