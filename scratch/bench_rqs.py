@@ -9,5 +9,5 @@ for K in (8, 32):
     torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(10): unconstrained_RQS(x, uw, uh, ud)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 10
-    byts = N * ((2 * K + 2) * 4 + 4 + 8)
+    byts = N * ((3 * K - 1) * 4 + 4 + 8)   # K widths + K heights + K-1 derivatives + x in, y + logabsdet out
     print(f"K={K} N={N}: {dt*1e3:.3f} ms  {N/dt:.3e} elem/s  {byts/dt/1e9:.0f} GB/s algorithmic ({byts/dt/8e12*100:.1f}% of 8 TB/s)")
