@@ -338,3 +338,26 @@ def test_run_vqmc_example_under_torchrun_single_rank(tmp_path):
     assert json.load(open(tmp_path / "run" / "system_info.json"))["system_name"] == "He"
     loss = np.load(tmp_path / "run" / "loss.npy")
     assert len(loss) >= 39 and np.isfinite(loss).all()
+
+
+def test_two_rank_training_keeps_replicas_identical(tmp_path):
+    """Two ranks (both on cuda:0, gloo) split every step's walkers: after the packed all-reduce both replicas hold the same
+    parameters bit for bit, see the same global loss, and rank 0 alone wrote the artefacts."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "_two_rank_train.py"), str(tmp_path), "25", "300"]
+    r = subprocess.run(cmd, env=dict(os.environ), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    p0, p1 = np.load(tmp_path / "params_rank0.npy"), np.load(tmp_path / "params_rank1.npy")
+    l0, l1 = np.load(tmp_path / "loss_rank0.npy"), np.load(tmp_path / "loss_rank1.npy")
+    assert np.array_equal(p0, p1) and np.array_equal(l0, l1)
+    assert np.isfinite(p0).all() and np.isfinite(l0).all() and len(l0) == 25
+    assert (tmp_path / "run" / "checkpoints").exists()

@@ -9,6 +9,19 @@ Walker coordinates never move between GPUs.
 import math
 
 
+def _all_reduce_sum(t, group=None):
+    """SUM all-reduce in place.  RCCL reduces device tensors directly; under gloo (CPU tests, or several ranks sharing one
+    GPU in the test suite) a device tensor is reduced through a host copy."""
+    import torch.distributed as dist
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        c = t.cpu()
+        dist.all_reduce(c, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(c)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
 def shard_bounds(n_total, rank, world):
     """Rows [lo, hi) of rank `rank` when `n_total` walkers are cut into `world` contiguous blocks."""
     if not (0 <= rank < world):
@@ -23,7 +36,7 @@ def all_reduce_moments(sums, group=None):
     Works on any backend (nccl/RCCL on GPUs, gloo on CPU tensors); a no-op without an initialised group."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+        _all_reduce_sum(sums, group)
     return sums
 
 
@@ -35,7 +48,7 @@ def all_reduce_gradient_and_moments(grad, sums, group=None):
     if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
         return grad, sums
     packed = torch.cat([grad.double().reshape(-1), sums.double().reshape(-1)])
-    dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+    _all_reduce_sum(packed, group)
     return packed[:-3].float(), packed[-3:]
 
 
@@ -46,7 +59,7 @@ def global_count(n_local, device, group=None):
     if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
         return int(n_local)
     cnt = torch.tensor([int(n_local)], dtype=torch.int64, device=device)
-    dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
+    _all_reduce_sum(cnt, group)
     return int(cnt.item())
 
 
