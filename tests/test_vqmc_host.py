@@ -32,3 +32,15 @@ def test_step_size_schedule_and_first_step():
     np.testing.assert_allclose(get_params(st)[0], [-0.5, 0.5, 0.0], atol=1e-6)
     st2 = opt_update(1, np.array([1.0, 1.0, 1.0], np.float32), st)
     np.testing.assert_allclose(get_params(st2)[0], get_params(st)[0])
+
+
+def test_sliding_statistics_and_bisection_helpers():
+    from waveflow_amd.utils import helpers
+    x = np.arange(10.0)
+    a = helpers.uniform_sliding_average(x, 4)
+    assert a.shape == x.shape and abs(a[-1] - np.mean(x[-4:])) < 1e-12 and abs(a[0] - x[0]) < 1e-12
+    s = helpers.uniform_sliding_stdev(x, 4)
+    assert s.shape == x.shape and abs(s[-1] - np.std(x[-4:])) < 1e-12
+    assert abs(helpers.moving_average(1.0, 3.0, 0.25) - 1.5) < 1e-12
+    r = helpers.binary_search(lambda t: t * t - 0.25, 0.0, 1.0, tol=1e-6)
+    assert abs(r - 0.5) < 2e-6 and r <= 0.5

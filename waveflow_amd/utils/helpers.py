@@ -106,3 +106,40 @@ def make_checkpoint_benchmark(split_rng, params, log_pdf, sample, losses, kde_kl
     np.savetxt(f'{save_dir}/kl_divergences.txt', kde_kl_divergences)
     np.savetxt(f'{save_dir}/hellinger_divergences.txt', kde_hellinger_distances)
     np.savetxt(f'{save_dir}/reconstruction_distances.txt', reconstruction_distances)
+
+
+# ---- small host-side statistics helpers of the reference (helpers.py:121-166), numpy only
+def moving_average(running_average, new_data, beta):
+    """Exponential moving average step (helpers.py:121-122)."""
+    return running_average - beta * (running_average - new_data)
+
+
+def uniform_sliding_average(data, window):
+    """Trailing mean over `window` entries along the last axis, the head padded with its first value (helpers.py:126-134)."""
+    data = np.asarray(data, dtype=float)
+    pad = [(0, 0)] * (data.ndim - 1) + [(window - 1, 0)]
+    c = np.cumsum(np.pad(data, pad, mode='edge'), axis=-1)
+    c[..., window:] = c[..., window:] - c[..., :-window]
+    return c[..., window - 1:] / window
+
+
+def uniform_sliding_stdev(data, window):
+    """Trailing standard deviation over `window` entries along the last axis, the head reflect-padded (helpers.py:137-146)."""
+    data = np.asarray(data, dtype=float)
+    pad = [(0, 0)] * (data.ndim - 1) + [(window - 1, 0)]
+    p = np.pad(data, pad, mode='reflect')
+    v = np.lib.stride_tricks.sliding_window_view(p, window, axis=-1)
+    return v.std(axis=-1)
+
+
+def binary_search(func, low=0.0, high=1.0, tol=1e-3):
+    """Bisection with the reference's stopping rule (helpers.py:150-166): returns the lower end of the final bracket.
+    (On the device this loop is wf_inverse_fwd; this host version serves small scripts.)"""
+    while True:
+        mid = 0.5 * (low + high)
+        if not ((low + tol / 2 < mid) and (mid < high - tol / 2)):
+            return low
+        if func(mid) > 0:
+            high = mid
+        else:
+            low = mid
