@@ -25,11 +25,11 @@ BYTES_PER_EVAL = 12            # 2 x fp32 in + 1 x fp32 out
 PEAK_F32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak
 PEAK_HBM_GBS = 8000.0
 # HBM bytes per log_pdf launch of 2^20 walkers from the PMC passes of the same command (separate rocprofv3 --pmc runs,
-# profiles/r01c_pmc_summary.txt): FETCH_SIZE 10233 KB + WRITE_SIZE 13312 KB.  The walker read is 8 B/lane (not the
+# profiles/r01f_pmc_summary.txt, previously r01c: 10233 + 13312): FETCH_SIZE 10791 KB + WRITE_SIZE 14336 KB.  The walker read is 8 B/lane (not the
 # 16 B/lane stream the guide's x2 FETCH_SIZE correction was calibrated on; an earlier build without table gathers from
 # HBM reported exactly the 8.39 MB of coordinates), so no correction is applied.  Algorithmic bytes: 12 B x 2^20 =
 # 12.6 MB; the excess is register-spill scratch (13 VGPRs at 16 waves per workgroup) and first-touch table rows.
-PMC_TRAFFIC_BYTES_2POW20 = (10233 + 13312) * 1024
+PMC_TRAFFIC_BYTES_2POW20 = (10791 + 14336) * 1024
 # executed matrix-core work per eval (He): per 32-walker tile 156 v_mfma_f32_32x32x16_f16 + 12 v_mfma_f32_32x32x2_f32
 MFMA_FLOP_PER_EVAL = (156 * 32768 + 12 * 4096) / 32
 PEAK_F16_MATRIX_TFLOPS = 2500.0
