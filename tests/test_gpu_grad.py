@@ -361,3 +361,40 @@ def test_two_rank_training_keeps_replicas_identical(tmp_path):
     assert np.array_equal(p0, p1) and np.array_equal(l0, l1)
     assert np.isfinite(p0).all() and np.isfinite(l0).all() and len(l0) == 25
     assert (tmp_path / "run" / "checkpoints").exists()
+
+
+def test_abi_error_paths_of_the_gradient_entry_points(he_flat):
+    import torch
+    from waveflow_amd import _lib, flows, model_factory
+    L = _lib.lib()
+    params, psi, log_pdf, sample = he(he_flat)
+    m = psi.model
+    m.ensure_params(params)
+    x = torch.as_tensor(sorted_walkers(8, 2, 5.0, 1)).cuda()
+    w = torch.ones(8, device="cuda")
+    g = torch.empty(m.n_params, device="cuda")
+    ws = torch.empty(int(L.wf_psi_vjp_workspace_bytes(m._h, 8)), device="cuda", dtype=torch.uint8)
+    # null pointers / wrong sizes
+    assert L.wf_psi_vjp(m._h, x.data_ptr(), 8, None, w.data_ptr(), g.data_ptr(), ws.data_ptr(), ws.numel(), None) == -1
+    assert L.wf_logpdf_vjp(m._h, x.data_ptr(), 8, w.data_ptr(), None, ws.data_ptr(), ws.numel(), None) == -1
+    assert L.wf_vqmc_loss_grad(m._h, x.data_ptr(), 8, None, 9, 0.0, 1.0, w.data_ptr(), g.data_ptr(), ws.data_ptr(), ws.numel(), None) == -1
+    assert L.wf_model_set_params_device(m._h, g.data_ptr(), 5, None) == -1
+    assert L.wf_adam_step(None, g.data_ptr(), g.data_ptr(), g.data_ptr(), 4, 0, 1e-3, 0.9, 0.999, 1e-8, None) == -1
+    assert L.wf_psi_vjp_workspace_bytes(None, 8) == -1
+    # empty batches are fine and give a zero gradient
+    assert L.wf_vqmc_loss_grad(m._h, None, 0, None, 0, 0.0, 1.0, None, g.data_ptr(), None, 0, None) == 0
+    torch.cuda.synchronize()
+    assert g.abs().sum().item() == 0.0
+    # psi / Laplacian gradients need the Waveflow prior; log_pdf gradients work for the density models
+    p2, lp2, _ = model_factory.get_model(n_flow_layers=1, prior_constraint_dict_left={0: 0}, prior_constraint_dict_right={0: 0},
+                                         i_constraint_dict_left={0: 0.0}, i_constraint_dict_right={0: 1.0})(0, 2)
+    lp2.model.ensure_params(p2)
+    assert L.wf_psi_vjp_workspace_bytes(lp2.model._h, 8) == -2
+    xs = torch.rand(8, 2, device="cuda") * 0.8 + 0.1
+    assert torch.isfinite(lp2.model.logpdf_vjp(xs, w)).all()
+    # general (non-zeroing) constraint dictionaries: forward works, gradients are not built
+    p3, lp3, _ = model_factory.get_model(n_flow_layers=1, i_constraint_dict_left={0: 0.0, 1: 0.0}, i_constraint_dict_right={0: 1.0})(0, 2)
+    lp3.model.ensure_params(p3)
+    assert np.isfinite(lp3(p3, xs.cpu().numpy())).all()
+    with pytest.raises(_lib.WfError):
+        lp3.model.logpdf_vjp(xs, w)
