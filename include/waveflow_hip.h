@@ -203,6 +203,29 @@ int wf_psi_vjp(const wf_model* m, const float* x_dev, int64_t B, const float* w_
 int wf_vqmc_loss_grad(const wf_model* m, const float* x_dev, int64_t B, const float* protons_host, int32_t n_protons, float running_average,
                       float inv_count, float* e_loc_dev, float* grad_dev, void* workspace_dev, int64_t workspace_bytes, void* stream);
 
+/* One whole VQMC training step without the host (the body of vqmc.ModelTrainer's loop, vqmc.py:102-117: sample -> loss and
+ * gradient -> Adam -> parameters): every per-step scalar lives on the device, so the sequence of launches is identical from
+ * step to step and can be captured once in a hipGraph and replayed.
+ *   counter_dev          step index i of this step (the value passed to opt_update); seeds the sampler together with `seed`,
+ *                        gives Adam's bias corrections, selects slot i mod ring_len of the loss ring; incremented at the end
+ *   running_average_dev  the `running_average` of loss_fn_efficient (the caller refreshes it every 100 steps, vqmc.py:112-113)
+ *   loss_ring_dev        [ring_len][3] doubles: [sum E_L, sum E_L^2, batch] of each step
+ * The model's weight images must hold params_dev on entry (wf_model_set_params_device); they hold the updated parameters on
+ * exit.  Single process; batch <= 32768 (the wave sampler).  Workspace: wf_vqmc_train_step_workspace_bytes. */
+typedef struct wf_train_state {
+    float* params_dev;
+    float* m_dev;
+    float* v_dev;
+    uint64_t* counter_dev;
+    float* running_average_dev;
+    double* loss_ring_dev;
+    int32_t ring_len;
+} wf_train_state;
+int64_t wf_vqmc_train_step_workspace_bytes(const wf_model* m, int64_t batch);
+int wf_vqmc_train_step(wf_model* m, const wf_train_state* st, uint64_t seed, int64_t batch, const float* protons_host, int32_t n_protons,
+                       float step_size, float b1, float b2, float eps, int32_t exact_sampler, void* workspace_dev, int64_t workspace_bytes,
+                       void* stream);
+
 /* Parameter gradient of the log-density: grad_dev[p] = sum_b w_dev[b] * d log_pdf_b / d theta_p for every model wf_logpdf_fwd
  * evaluates with <= 32 bases, D <= 4 and zero-only constraints (IMADE or MADE layers; Waveflow, M-spline, Normal or Uniform
  * prior).  With w = -1/B this is the gradient of benchmark_tests.loss (benchmark_tests.py:84-87, 98-101); with per-walker

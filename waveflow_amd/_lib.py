@@ -51,12 +51,19 @@ class ModelDesc(ctypes.Structure):
                 ("n_mesh", ctypes.c_int32), ("i_reverse_tol", ctypes.c_float)]
 
 
+class TrainState(ctypes.Structure):
+    """wf_train_state (include/waveflow_hip.h)"""
+    _fields_ = [("params_dev", ctypes.c_void_p), ("m_dev", ctypes.c_void_p), ("v_dev", ctypes.c_void_p), ("counter_dev", ctypes.c_void_p),
+                ("running_average_dev", ctypes.c_void_p), ("loss_ring_dev", ctypes.c_void_p), ("ring_len", ctypes.c_int32)]
+
+
 EXPORTS = ["wf_abi_version", "wf_strerror", "wf_last_hip_error", "wf_last_hip_error_string", "wf_device_count",
            "wf_tables_build", "wf_model_create", "wf_model_destroy", "wf_model_param_count", "wf_model_n_bases",
            "wf_model_set_params", "wf_model_set_kernel", "wf_logpdf_fwd", "wf_psi_fwd", "wf_flow_fwd", "wf_layer_fwd",
            "wf_block_sums", "wf_block_sums_workspace_bytes", "wf_rqs_fwd", "wf_inverse_fwd", "wf_sample", "wf_hamiltonian_fwd",
            "wf_psi_vjp", "wf_psi_vjp_workspace_bytes", "wf_vqmc_seeds",
-           "wf_logpdf_vjp", "wf_logpdf_vjp_workspace_bytes", "wf_vqmc_loss_grad", "wf_model_set_params_device", "wf_adam_step"]
+           "wf_logpdf_vjp", "wf_logpdf_vjp_workspace_bytes", "wf_vqmc_loss_grad", "wf_model_set_params_device", "wf_adam_step",
+           "wf_vqmc_train_step", "wf_vqmc_train_step_workspace_bytes"]
 
 _lib = None
 
@@ -119,6 +126,11 @@ def lib():
     L.wf_model_set_params_device.argtypes = [vp, vp, i64, vp]
     L.wf_adam_step.restype = i32
     L.wf_adam_step.argtypes = [vp, vp, vp, vp, i64, i64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, vp]
+    L.wf_vqmc_train_step_workspace_bytes.restype = i64
+    L.wf_vqmc_train_step_workspace_bytes.argtypes = [vp, i64]
+    L.wf_vqmc_train_step.restype = i32
+    L.wf_vqmc_train_step.argtypes = [vp, ctypes.POINTER(TrainState), ctypes.c_uint64, i64, vp, i32, ctypes.c_float, ctypes.c_float,
+                                     ctypes.c_float, ctypes.c_float, i32, vp, i64, vp]
     L.wf_vqmc_loss_grad.restype = i32
     L.wf_vqmc_loss_grad.argtypes = [vp, vp, i64, vp, i32, ctypes.c_float, ctypes.c_float, vp, vp, vp, i64, vp]
     L.wf_vqmc_seeds.restype = i32

@@ -288,6 +288,31 @@ class DeviceModel:
         _lib.check(_lib.lib().wf_adam_step(self._p(x), self._p(g), self._p(m), self._p(v), x.numel(), int(step), float(step_size), float(b1),
                                            float(b2), float(eps), self._stream()), "wf_adam_step")
 
+    def make_train_state(self, x, m, v, first_step, ring_len=128):
+        """Device-side state of wf_vqmc_train_step around the Adam vectors x, m, v (float32 cuda, updated in place)."""
+        torch = _torch()
+        dev = x.device
+        st = {"x": x, "m": m, "v": v, "ring_len": int(ring_len),
+              "counter": torch.tensor([int(first_step)], dtype=torch.int64, device=dev),
+              "running_average": torch.zeros(1, dtype=torch.float32, device=dev),
+              "ring": torch.zeros(int(ring_len), 3, dtype=torch.float64, device=dev)}
+        st["c"] = _lib.TrainState(x.data_ptr(), m.data_ptr(), v.data_ptr(), st["counter"].data_ptr(), st["running_average"].data_ptr(),
+                                  st["ring"].data_ptr(), int(ring_len))
+        return st
+
+    def train_step(self, st, seed, batch, protons, step_size, b1=0.9, b2=0.999, eps=1e-8, exact_sampler=False):
+        """One whole training step on the device (wf_vqmc_train_step): no host work, capturable in a hipGraph."""
+        L = _lib.lib()
+        pr = np.ascontiguousarray(np.asarray(protons, dtype=np.float32).reshape(-1))
+        nbytes = _lib.check(L.wf_vqmc_train_step_workspace_bytes(self._h, int(batch)), "wf_vqmc_train_step_workspace_bytes")
+        if st.get("ws") is None or st["ws"].numel() < nbytes:
+            st["ws"] = self._workspace(nbytes, st["x"].device)
+        _lib.check(L.wf_vqmc_train_step(self._h, ctypes.byref(st["c"]), int(seed), int(batch), pr.ctypes.data if pr.size else None, pr.size,
+                                        float(step_size), float(b1), float(b2), float(eps), int(bool(exact_sampler)), self._p(st["ws"]),
+                                        st["ws"].numel(), self._stream()), "wf_vqmc_train_step")
+        self._flat = None
+        self._dev_key = None
+
     @staticmethod
     def _workspace(nbytes, device):
         torch = _torch()

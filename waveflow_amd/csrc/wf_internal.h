@@ -112,6 +112,7 @@ int launch_mfma(int D, int nbk, const MfmaDev* mdev, int lds_bytes, int mode, co
                 int32_t* idx, void* stream);
 bool mfma_shape_built(int D, int nbk);
 int mfma_extra_lds_floats(int n_nets);
+int dim0_coef_floats(int n_nets);
 int launch_prepare_dim0(const ModelDev* md_dev, int n_nets, int n_mesh, const float* fk_nat_dev, float F_I, float F_P, void* comp_dev,
                         void* stream);
 
@@ -139,7 +140,8 @@ int launch_wave_bwd(const ModelDev& md, const ModelDev* md_dev, int mode, int se
 int launch_wave_energy(const ModelDev& md, const ModelDev* md_dev, const float* tabI4, const float* tabP4, const float* fk_nat, const float* x,
                        int64_t B, const Protons& pr, float* hpsi, float* psi, float* lap, float* tail_ws, void* stream);
 int launch_wave_sample(const ModelDev& md, const ModelDev* md_dev, const float* tabI4, const float* tabP4, const float* fk_nat, int draw,
-                       unsigned long long seed, const float* u, int64_t B, float* x, float* latent, int exact, void* stream);
+                       unsigned long long seed, const float* u, int64_t B, float* x, float* latent, int exact,
+                       const unsigned long long* seed_offset_dev, void* stream);
 int launch_wave_eval(const ModelDev& md, const ModelDev* md_dev, const float* tabI4, const float* tabP4, const float* fk_nat, int mode,
                      const float* x, int64_t B, float* out, float* u, float* tail_ws, void* stream);
 int64_t wave_tail_floats(int D, int second_order);
@@ -155,10 +157,11 @@ struct PackRec {
 };
 int launch_pack(const float* flat_dev, const PackRec* recs, int64_t n, void* image_base, void* stream);
 int launch_adam(float* params, const float* grad, float* m, float* v, int64_t n, int64_t step, float step_size, float b1, float b2, float eps,
-                void* stream);
+                const unsigned long long* step_dev, void* stream);
+int launch_step_end(const double* sums, double* ring, int ring_len, unsigned long long* counter, void* stream);
 int launch_grad_scatter(const float* grad_img, const int32_t* map, int64_t n_img, float* grad_flat, void* stream);
 int launch_vqmc_seeds(const float* x, int64_t B, int D, const Protons& pr, const float* hpsi, const float* psi, float running_avg,
-                      float inv_count, float* e_loc, float* w_psi, float* w_lap, void* stream);
+                      float inv_count, float* e_loc, float* w_psi, float* w_lap, const float* running_avg_dev, void* stream);
 int launch_rqs(const float* x, const float* uw, const float* uh, const float* ud, int64_t N, int K, int n_deriv, int inverse,
                float left, float right, float bottom, float top, float* y, float* ld, int32_t* bin, void* stream);
 int launch_block_sums(const float* v, int64_t B, double* out, void* ws, int64_t ws_bytes, void* stream);

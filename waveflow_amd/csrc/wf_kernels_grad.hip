@@ -156,9 +156,14 @@ __global__ void k_pack(const float* __restrict__ flat, const PackRec* __restrict
 
 // ---- Adam as in jax.example_libraries.optimizers.adam (vqmc.py:136), step index i as passed to opt_update
 __global__ void k_adam(float* __restrict__ x, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n, float c1, float c2,
-                       float step_size, float b1, float b2, float eps) {
+                       float step_size, float b1, float b2, float eps, const unsigned long long* __restrict__ step_dev) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (step_dev) {   // step index from the device counter (captured training step): bias corrections 1 - b^(step + 1)
+        const float e = (float)(*step_dev + 1);
+        c1 = 1.0f - powf(b1, e);
+        c2 = 1.0f - powf(b2, e);
+    }
     const float gi = g[i];
     const float mi = (1.0f - b1) * gi + b1 * m[i];
     const float vi = (1.0f - b2) * gi * gi + b2 * v[i];
@@ -167,12 +172,24 @@ __global__ void k_adam(float* __restrict__ x, const float* __restrict__ g, float
     x[i] = x[i] - step_size * (mi / c1) / (sqrtf(vi / c2) + eps);
 }
 
+// ---- end of a captured training step: the step's [sum, sum^2, n] goes to slot (counter mod ring_len) of the loss ring and
+// the counter advances (it seeds the next step's sampler and gives Adam's step index)
+__global__ void k_step_end(const double* __restrict__ sums, double* __restrict__ ring, int ring_len, unsigned long long* __restrict__ counter) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const unsigned long long c = *counter;
+        double* slot = ring + (c % (unsigned long long)ring_len) * 3;
+        slot[0] = sums[0]; slot[1] = sums[1]; slot[2] = sums[2];
+        *counter = c + 1;
+    }
+}
+
 // ---- loss_fn_efficient's tangent rule as per-walker weights (vqmc.py:198-212)
 __global__ void k_vqmc_seeds(const float* __restrict__ xg, int64_t B, int D, const Protons pr, const float* __restrict__ hpsi,
                              const float* __restrict__ psi, float running_avg, float inv_count, float* __restrict__ e_loc,
-                             float* __restrict__ w_psi, float* __restrict__ w_lap) {
+                             float* __restrict__ w_psi, float* __restrict__ w_lap, const float* __restrict__ running_avg_dev) {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
+    if (running_avg_dev) running_avg = *running_avg_dev;
     // potential (physics.py:60-76)
     float V = 0.0f;
     for (int p = 0; p < pr.n; ++p)
@@ -255,11 +272,16 @@ int launch_pack(const float* flat_dev, const PackRec* recs, int64_t n, void* ima
 }
 
 int launch_adam(float* params, const float* grad, float* m, float* v, int64_t n, int64_t step, float step_size, float b1, float b2, float eps,
-                void* stream) {
+                const unsigned long long* step_dev, void* stream) {
     // bias corrections 1 - b^(i+1) in fp32, as the reference's optimiser computes them
     const float c1 = 1.0f - powf(b1, (float)(step + 1)), c2 = 1.0f - powf(b2, (float)(step + 1));
     hipLaunchKernelGGL(k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, grad, m, v, n, c1, c2, step_size, b1,
-                       b2, eps);
+                       b2, eps, step_dev);
+    return finish();
+}
+
+int launch_step_end(const double* sums, double* ring, int ring_len, unsigned long long* counter, void* stream) {
+    hipLaunchKernelGGL(k_step_end, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, ring, ring_len, counter);
     return finish();
 }
 
@@ -269,9 +291,9 @@ int launch_grad_scatter(const float* grad_img, const int32_t* map, int64_t n_img
 }
 
 int launch_vqmc_seeds(const float* x, int64_t B, int D, const Protons& pr, const float* hpsi, const float* psi, float running_avg,
-                      float inv_count, float* e_loc, float* w_psi, float* w_lap, void* stream) {
+                      float inv_count, float* e_loc, float* w_psi, float* w_lap, const float* running_avg_dev, void* stream) {
     hipLaunchKernelGGL(k_vqmc_seeds, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, B, D, pr, hpsi, psi, running_avg,
-                       inv_count, e_loc, w_psi, w_lap);
+                       inv_count, e_loc, w_psi, w_lap, running_avg_dev);
     return finish();
 }
 

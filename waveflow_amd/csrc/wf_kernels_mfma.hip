@@ -47,54 +47,87 @@ namespace {
 using mfma::f32x4;
 using mfma::launch_dw;
 
-// ---- composite tables of output dimension 0 (see comp_lerp); one thread per (net, mesh point); plain weight image
-__global__ void k_prepare_dim0(const ModelDev* __restrict__ mdp, int nm, const float* __restrict__ fk_nat /* [2][64]: I, prior */,
-                               float F_I, float F_P, f32x4* __restrict__ comp) {
+// ---- composite tables of output dimension 0 (see comp_lerp), from the plain weight image, in two stages with the arithmetic
+// order of the straightforward per-mesh-point evaluation (the tables are bit-identical to it):
+//   k_dim0_coeffs   one workgroup per net: the walker-independent spline coefficients of dimension 0 (<= 64 values + 2 scalars)
+//   k_prepare_dim0  one thread per (net, mesh point): their dot product with that mesh row
+constexpr int kCoefStride = 66;   // [64 coefficients][scale][unused]
+__global__ __launch_bounds__(64) void k_dim0_coeffs(const ModelDev* __restrict__ mdp, const float* __restrict__ fk_nat /* [2][64]: I, prior */,
+                                                    float F_I, float F_P, float* __restrict__ coef) {
+    __shared__ float sh[64];
+    const ModelDev& md = *mdp;
+    const int n = blockIdx.x, t = threadIdx.x;
+    const NetPlain& net = md.nets[n];
+    const bool is_prior = n == md.n_layers;
+    float* out = coef + (size_t)n * kCoefStride;
+    if (!is_prior && md.layer_kind == WF_LAYER_MADE) {
+        if (t < 2) out[t] = net.b2[t];   // log_weight, bias of dimension 0 (rows j = 0 / 1 of block d = 0)
+        return;
+    }
+    if (is_prior && md.prior_kind == WF_PRIOR_WAVEFLOW) {
+        const SplineDev& sp = md.psp;
+        const int nb = sp.nb, nbp = sp.nbp;
+        const float* keep = fk_nat + 64;
+        float c = 0.0f;
+        if (t < nb)
+            for (int a = 0; a < nb; ++a) c = __builtin_fmaf(net.b2[a] * keep[a], md.ob_to_b[a * nbp + t], c);
+        sh[t] = c;
+        out[t] = c;
+        __syncthreads();
+        if (t == 0) {
+            float s1 = 0.0f, n2 = 0.0f;
+            for (int j = 0; j < nb; ++j) s1 += net.b2[j];
+            for (int i = 0; i < nb; ++i) n2 = __builtin_fmaf(sh[i], sh[i], n2);
+            out[64] = (s1 < 0.0f ? -1.0f : 1.0f);
+            out[65] = n2;
+        }
+        return;
+    }
+    const SplineDev& sp = is_prior ? md.psp : md.isp;
+    const int nb = sp.nb;
+    const float* fk = fk_nat + (is_prior ? 64 : 0);
+    const float reg = is_prior ? 0.0f : md.i_reg, F = is_prior ? F_P : F_I;
+    const float v = t < nb ? 1.0f / (1.0f + expf(-net.b2[t])) : 0.0f;
+    sh[t] = v;
+    __syncthreads();
+    float s1 = 0.0f, sf = 0.0f;   // every thread repeats the two ordered sums (64 terms): no second barrier
+    for (int j = 0; j < nb; ++j) {
+        s1 += sh[j];
+        sf = __builtin_fmaf(sh[j], fk[j], sf);
+    }
+    const float rs = reg * s1, rS = 1.0f / __builtin_fmaf(rs, F, sf);
+    out[t] = t < nb ? (v + rs) * fk[t] : 0.0f;
+    if (t == 0) out[64] = rS;
+}
+
+__global__ void k_prepare_dim0(const ModelDev* __restrict__ mdp, int nm, const float* __restrict__ coef, f32x4* __restrict__ comp) {
     const ModelDev& md = *mdp;
     const int n_nets = md.n_layers + ((md.prior_kind == WF_PRIOR_WAVEFLOW || md.prior_kind == WF_PRIOR_MFLOW) ? 1 : 0);
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (nm <= 0 || gid >= n_nets * nm) return;
     const int n = gid / nm, m = gid % nm;
-    const NetPlain& net = md.nets[n];
     const bool is_prior = n == md.n_layers;
+    const float* __restrict__ c = coef + (size_t)n * kCoefStride;
     f32x4 out = {0.0f, 0.0f, 0.0f, 0.0f};
     if (!is_prior && md.layer_kind == WF_LAYER_MADE) {
-        out[0] = net.b2[0];   // log_weight, dimension 0 (rows j = 0 / 1 of block d = 0)
-        out[1] = net.b2[1];
+        out[0] = c[0];
+        out[1] = c[1];
     } else if (is_prior && md.prior_kind == WF_PRIOR_WAVEFLOW) {
         const SplineDev& sp = md.psp;
         const int nb = sp.nb, nbp = sp.nbp;
-        const float* keep = fk_nat + 64;
-        float s1 = 0.0f;
-        for (int j = 0; j < nb; ++j) s1 += net.b2[j];
-        float n2 = 0.0f, num = 0.0f;
-        for (int i = 0; i < nb; ++i) {
-            float c = 0.0f;
-            for (int a = 0; a < nb; ++a) c = __builtin_fmaf(net.b2[a] * keep[a], md.ob_to_b[a * nbp + i], c);
-            n2 = __builtin_fmaf(c, c, n2);
-            num = __builtin_fmaf(c, sp.tab[(size_t)m * nbp + i], num);
-        }
-        out[0] = (s1 < 0.0f ? -num : num) * __builtin_amdgcn_rsqf(n2);
+        float num = 0.0f;
+        for (int i = 0; i < nb; ++i) num = __builtin_fmaf(c[i], sp.tab[(size_t)m * nbp + i], num);
+        out[0] = (c[64] < 0.0f ? -num : num) * __builtin_amdgcn_rsqf(c[65]);
     } else {
         const SplineDev& sp = is_prior ? md.psp : md.isp;
         const int nb = sp.nb, nbp = sp.nbp;
-        const float* fk = fk_nat + (is_prior ? 64 : 0);
-        const float reg = is_prior ? 0.0f : md.i_reg, F = is_prior ? F_P : F_I;
-        float s1 = 0.0f, sf = 0.0f;
-        for (int j = 0; j < nb; ++j) {
-            const float v = 1.0f / (1.0f + expf(-net.b2[j]));
-            s1 += v;
-            sf = __builtin_fmaf(v, fk[j], sf);
-        }
-        const float rs = reg * s1, rS = 1.0f / __builtin_fmaf(rs, F, sf);
         float y = 0.0f, dy = 0.0f;
         for (int j = 0; j < nb; ++j) {
-            const float q = (1.0f / (1.0f + expf(-net.b2[j])) + rs) * fk[j];
-            y = __builtin_fmaf(q, sp.tab[(size_t)m * nbp + j], y);
-            if (!is_prior) dy = __builtin_fmaf(q, sp.tab[((size_t)sp.n_mesh + m) * nbp + j], dy);
+            y = __builtin_fmaf(c[j], sp.tab[(size_t)m * nbp + j], y);
+            if (!is_prior) dy = __builtin_fmaf(c[j], sp.tab[((size_t)sp.n_mesh + m) * nbp + j], dy);
         }
-        out[0] = y * rS;
-        out[1] = dy * rS;
+        out[0] = y * c[64];
+        out[1] = dy * c[64];
     }
     comp[gid] = out;
 }
@@ -108,12 +141,16 @@ int waves_per_group() {
 }  // namespace
 
 int mfma_extra_lds_floats(int) { return 0; }
+int dim0_coef_floats(int n_nets) { return n_nets * kCoefStride; }
 
 int launch_prepare_dim0(const ModelDev* md_dev, int n_nets, int n_mesh, const float* fk_nat_dev, float F_I, float F_P, void* comp_dev,
                         void* stream) {
     const int total = n_nets * n_mesh;
     if (total <= 0) return WF_OK;
-    hipLaunchKernelGGL(k_prepare_dim0, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, md_dev, n_mesh, fk_nat_dev, F_I, F_P,
+    // the coefficient block sits behind the tables in the same allocation (wf_model.cpp reserves dim0_coef_floats)
+    float* coef = reinterpret_cast<float*>(comp_dev) + (size_t)total * 4;
+    hipLaunchKernelGGL(k_dim0_coeffs, dim3(n_nets), dim3(64), 0, (hipStream_t)stream, md_dev, fk_nat_dev, F_I, F_P, coef);
+    hipLaunchKernelGGL(k_prepare_dim0, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, md_dev, n_mesh, (const float*)coef,
                        reinterpret_cast<f32x4*>(comp_dev));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

@@ -767,8 +767,10 @@ __device__ __forceinline__ void wave_serial_inverse(const ModelDev& md, const fl
 template <int D>
 __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(WF_WAVE_OCC, WF_WAVE_OCC))) void k_wave_sample(
     const ModelDev* __restrict__ mdp, const float* __restrict__ tabI, const float* __restrict__ tabP, const float* __restrict__ fk_nat, int draw,
-    unsigned long long seed, const float* __restrict__ ug, int64_t B, float* __restrict__ xg, float* __restrict__ latent, int exact) {
+    unsigned long long seed, const float* __restrict__ ug, int64_t B, float* __restrict__ xg, float* __restrict__ latent, int exact,
+    const unsigned long long* __restrict__ seed_offset_dev) {
     __shared__ float lds[kWaves][2][1][64];
+    if (seed_offset_dev) seed += *seed_offset_dev * 0x9E3779B97F4A7C15ull;   // a device counter advances the stream (captured steps)
     const ModelDev& md = *mdp;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float (*vec)[64] = lds[wv][0];
@@ -910,10 +912,12 @@ int launch_wave_bwd(const ModelDev& md, const ModelDev* md_dev, int mode, int se
 
 // draw == 0: x = inverse(u);  draw == 1: latent ~ prior, x = inverse(latent)
 int launch_wave_sample(const ModelDev& md, const ModelDev* md_dev, const float* tabI4, const float* tabP4, const float* fk_nat, int draw,
-                       unsigned long long seed, const float* u, int64_t B, float* x, float* latent, int exact, void* stream) {
+                       unsigned long long seed, const float* u, int64_t B, float* x, float* latent, int exact,
+                       const unsigned long long* seed_offset_dev, void* stream) {
     hipStream_t s = (hipStream_t)stream;
 #define CALL(DD)                                                                                                                          \
-    hipLaunchKernelGGL(k_wave_sample<DD>, dim3(wave_grid(B)), dim3(kWB), 0, s, md_dev, tabI4, tabP4, fk_nat, draw, seed, u, B, x, latent, exact); \
+    hipLaunchKernelGGL(k_wave_sample<DD>, dim3(wave_grid(B)), dim3(kWB), 0, s, md_dev, tabI4, tabP4, fk_nat, draw, seed, u, B, x, latent, exact, \
+                       seed_offset_dev);                                                                                                 \
     break
     switch (md.D) {
         case 2: CALL(2);

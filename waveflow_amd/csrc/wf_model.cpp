@@ -681,7 +681,7 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
     WF_HIP(hipMemcpy(m->d_fk_nat, fk_nat.data(), 128 * sizeof(float), hipMemcpyHostToDevice));
     {
         float* comp = nullptr;
-        rc = dev_alloc(m, &comp, (size_t)std::max(n_nets, 1) * d.n_mesh * 4);
+        rc = dev_alloc(m, &comp, (size_t)std::max(n_nets, 1) * d.n_mesh * 4 + (size_t)dim0_coef_floats(std::max(n_nets, 1)));
         if (rc) return rc;
         m->d_comp = comp;
         md.comp = reinterpret_cast<const float4_t*>(comp);
@@ -911,7 +911,7 @@ int wf_adam_step(float* params_dev, const float* grad_dev, float* m_dev, float* 
                  float b2, float eps, void* stream) {
     if (n < 0 || step < 0 || (n > 0 && (!params_dev || !grad_dev || !m_dev || !v_dev))) return WF_ERR_INVALID;
     if (n == 0) return WF_OK;
-    return launch_adam(params_dev, grad_dev, m_dev, v_dev, n, step, step_size, b1, b2, eps, stream);
+    return launch_adam(params_dev, grad_dev, m_dev, v_dev, n, step, step_size, b1, b2, eps, nullptr, stream);
 }
 
 static int check_fwd(const wf_model* m, const void* x, int64_t B, const void* out) {
@@ -998,7 +998,7 @@ int wf_inverse_fwd(const wf_model* m, const float* u_dev, int64_t B, float* x_de
     DeviceGuard g(m->device);
     if (B == 0) return WF_OK;
     if (m->wave_ok && B <= kWaveSampleMax)
-        return launch_wave_sample(m->dev, m->d_dev, m->d_tabI4, m->d_tabP3, m->d_grad_fk, 0, 0ull, u_dev, B, x_dev, nullptr, exact, stream);
+        return launch_wave_sample(m->dev, m->d_dev, m->d_tabI4, m->d_tabP3, m->d_grad_fk, 0, 0ull, u_dev, B, x_dev, nullptr, exact, nullptr, stream);
     return launch_scalar_inverse(m->dev, m->d_dev, u_dev, B, x_dev, exact, stream);
 }
 
@@ -1009,7 +1009,7 @@ int wf_sample(const wf_model* m, uint64_t seed, int64_t B, float* x_dev, float* 
     if (B == 0) return WF_OK;
     if (m->wave_ok && B <= kWaveSampleMax)
         return launch_wave_sample(m->dev, m->d_dev, m->d_tabI4, m->d_tabP3, m->d_grad_fk, 1, (unsigned long long)seed, nullptr, B, x_dev, latent_dev,
-                                  exact, stream);
+                                  exact, nullptr, stream);
     return launch_scalar_sample(m->dev, m->d_dev, (unsigned long long)seed, B, x_dev, latent_dev, exact, stream);
 }
 
@@ -1073,7 +1073,7 @@ static int64_t vjp_ws_bytes(const wf_model* m, int64_t B, bool second_order) {
 // mode 2: loss_fn_efficient (vqmc.py:193-212): the weights come from H psi of the same forward sweep, e_loc_dev is written
 static int run_vjp_chunks(const wf_model* m, int mode, bool second_order, const float* x_dev, int64_t B, const float* w1, const float* w2,
                           const Protons* pr, float running_average, float inv_count, float* e_loc_dev, float* grad_dev, void* workspace_dev,
-                          int64_t workspace_bytes, void* stream) {
+                          int64_t workspace_bytes, void* stream, const float* running_average_dev = nullptr) {
     const int D = m->desc.n_dim;
     const int64_t chunk = workspace_bytes / vjp_bytes_per_walker(m, second_order);
     if (B > 0 && chunk < 1) return WF_ERR_INVALID;
@@ -1098,7 +1098,7 @@ static int run_vjp_chunks(const wf_model* m, int mode, bool second_order, const 
             float *hpsi = per_walker, *psi = per_walker + chunk, *wp = per_walker + 2 * chunk, *wl = per_walker + 3 * chunk;
             rc = launch_energy_out(D, tails, x, bc, m->dev.constrained_mask, *pr, hpsi, psi, nullptr, stream);
             if (rc) return rc;
-            rc = launch_vqmc_seeds(x, bc, D, *pr, hpsi, psi, running_average, inv_count, e_loc_dev + c0, wp, wl, stream);
+            rc = launch_vqmc_seeds(x, bc, D, *pr, hpsi, psi, running_average, inv_count, e_loc_dev + c0, wp, wl, running_average_dev, stream);
             if (rc) return rc;
             cw1 = wp;
             cw2 = wl;
@@ -1150,6 +1150,54 @@ int wf_vqmc_loss_grad(const wf_model* m, const float* x_dev, int64_t B, const fl
                           stream);
 }
 
+// ---- one whole training step on the device (see include/waveflow_hip.h)
+static int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
+
+int64_t wf_vqmc_train_step_workspace_bytes(const wf_model* m, int64_t batch) {
+    if (!m || batch < 1) return WF_ERR_INVALID;
+    if (!m->d_grad_map || !m->grad_psi_ok || batch > kWaveSampleMax) return WF_ERR_UNSUPPORTED;
+    return align256(batch * m->desc.n_dim * 4) + align256(batch * 4) + align256(m->n_params * 4) + 256 + align256(block_sums_ws_bytes(batch)) +
+           vjp_ws_bytes(m, batch, true);
+}
+
+int wf_vqmc_train_step(wf_model* m, const wf_train_state* st, uint64_t seed, int64_t batch, const float* protons_host, int32_t n_protons,
+                       float step_size, float b1, float b2, float eps, int32_t exact_sampler, void* workspace_dev, int64_t workspace_bytes,
+                       void* stream) {
+    if (!m || !st || batch < 1 || n_protons < 0 || n_protons > 8 || (n_protons > 0 && !protons_host)) return WF_ERR_INVALID;
+    if (!st->params_dev || !st->m_dev || !st->v_dev || !st->counter_dev || !st->running_average_dev || !st->loss_ring_dev || st->ring_len < 1)
+        return WF_ERR_INVALID;
+    if (!m->d_grad_map || !m->grad_psi_ok || !m->wave_ok || batch > kWaveSampleMax) return WF_ERR_UNSUPPORTED;
+    if (!m->params_set || !workspace_dev || workspace_bytes < wf_vqmc_train_step_workspace_bytes(m, batch)) return WF_ERR_INVALID;
+    DeviceGuard g(m->device);
+    const int D = m->desc.n_dim;
+    char* p = (char*)workspace_dev;
+    float* x = (float*)p; p += align256(batch * D * 4);
+    float* e_loc = (float*)p; p += align256(batch * 4);
+    float* grad = (float*)p; p += align256(m->n_params * 4);
+    double* sums = (double*)p; p += 256;
+    void* sums_ws = p; p += align256(block_sums_ws_bytes(batch));
+    const int64_t vjp_bytes = workspace_bytes - (p - (char*)workspace_dev);
+    Protons pr{};
+    pr.n = n_protons;
+    for (int i = 0; i < n_protons; ++i) pr.pos[i] = protons_host[i];
+    const unsigned long long* counter = (const unsigned long long*)st->counter_dev;
+    // walkers ~ the sampler, stream advanced by the device counter
+    int rc = launch_wave_sample(m->dev, m->d_dev, m->d_tabI4, m->d_tabP3, m->d_grad_fk, 1, (unsigned long long)seed, nullptr, batch, x, nullptr,
+                                exact_sampler, counter, stream);
+    if (rc) return rc;
+    // mean local energy and its gradient under the custom tangent rule, running average from the device scalar
+    rc = run_vjp_chunks(m, 2, true, x, batch, nullptr, nullptr, &pr, 0.0f, 1.0f / (float)batch, e_loc, grad, p, vjp_bytes, stream,
+                        st->running_average_dev);
+    if (rc) return rc;
+    rc = launch_block_sums(e_loc, batch, sums, sums_ws, block_sums_ws_bytes(batch), stream);
+    if (rc) return rc;
+    rc = launch_adam(st->params_dev, grad, st->m_dev, st->v_dev, m->n_params, 0, step_size, b1, b2, eps, counter, stream);
+    if (rc) return rc;
+    rc = wf_model_set_params_device(m, st->params_dev, m->n_params, stream);
+    if (rc) return rc;
+    return launch_step_end(sums, st->loss_ring_dev, st->ring_len, (unsigned long long*)st->counter_dev, stream);
+}
+
 int wf_vqmc_seeds(const float* x_dev, int64_t B, int32_t n_dim, const float* protons_host, int32_t n_protons, const float* hpsi_dev,
                   const float* psi_dev, float running_average, float inv_count, float* e_loc_dev, float* w_psi_dev, float* w_lap_dev,
                   void* stream) {
@@ -1159,7 +1207,7 @@ int wf_vqmc_seeds(const float* x_dev, int64_t B, int32_t n_dim, const float* pro
     Protons pr{};
     pr.n = n_protons;
     for (int i = 0; i < n_protons; ++i) pr.pos[i] = protons_host[i];
-    return launch_vqmc_seeds(x_dev, B, n_dim, pr, hpsi_dev, psi_dev, running_average, inv_count, e_loc_dev, w_psi_dev, w_lap_dev, stream);
+    return launch_vqmc_seeds(x_dev, B, n_dim, pr, hpsi_dev, psi_dev, running_average, inv_count, e_loc_dev, w_psi_dev, w_lap_dev, nullptr, stream);
 }
 
 int wf_rqs_fwd(const float* x_dev, const float* uw_dev, const float* uh_dev, const float* ud_dev, int64_t N, int32_t K, int32_t n_deriv,

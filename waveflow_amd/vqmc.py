@@ -140,6 +140,7 @@ class ModelTrainer:
         self.num_epochs = num_epochs
         self.batch_size = batch_size
         self.save_dir = f'./results/{self.system_name}_{self.n_space_dimension}d_L{self.box_length}box'
+        self.use_graph = True  # single process: capture the whole step (wf_vqmc_train_step) in a hipGraph and replay it
         self.seed = 2          # vqmc.py:57: PRNGKey(2)
         self.exact_sampler = False   # False: the reference's sampler (made.py:88 quirk); True: draws from |psi|^2
 
@@ -180,6 +181,12 @@ class ModelTrainer:
                 json.dump(system_dict, fout_sys, indent=4)
         if verbose:
             print("Start training...")
+        if self.use_graph and not distributed and self.batch_size <= 32768:
+            params, loss, energies = self._train_graphed(psi, sample, h_fn, opt_state, get_params, start_epoch, loss, energies, system_dict,
+                                                         save_dir, rng, verbose)
+            self.params, self.loss, self.energies = params, loss, energies
+            self.psi, self.log_pdf, self.sample, self.h_fn = psi, log_pdf, sample, h_fn
+            return params, loss
         for epoch in range(start_epoch + 1, start_epoch + self.num_epochs + 1):
             ckpt_seed, step_seed = int(rng.integers(1 << 31)), int(rng.integers(1 << 31))   # same host stream on every rank
             if (epoch % self.log_every == 0 or epoch == 1) and rank == 0:
@@ -197,3 +204,58 @@ class ModelTrainer:
         self.params, self.loss, self.energies = params, loss, energies
         self.psi, self.log_pdf, self.sample, self.h_fn = psi, log_pdf, sample, h_fn
         return params, loss
+
+    def _train_graphed(self, psi, sample, h_fn, opt_state, get_params, start_epoch, loss, energies, system_dict, save_dir, rng, verbose):
+        """The training loop with the step captured once in a hipGraph: per epoch one graph launch; the host looks at the
+        losses every 100 epochs (to refresh the running average, vqmc.py:112-113) and at checkpoints."""
+        import torch
+        model = psi.model
+        st = model.make_train_state(opt_state.x, opt_state.m, opt_state.v, start_epoch + 1, ring_len=128)
+        model.set_params_device(opt_state.x)
+        step_args = (st, int(rng.integers(1 << 62)), self.batch_size, h_fn.protons, self.learning_rate)
+        side = torch.cuda.Stream(device=model.device)
+        side.wait_stream(torch.cuda.current_stream(model.device))
+        with torch.cuda.stream(side):
+            # the workspace is allocated here, outside the capture
+            from . import _lib
+            nbytes = _lib.check(_lib.lib().wf_vqmc_train_step_workspace_bytes(model._h, self.batch_size), "wf_vqmc_train_step_workspace_bytes")
+            st["ws"] = model._workspace(nbytes, opt_state.x.device)
+            side.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                model.train_step(*step_args, exact_sampler=self.exact_sampler)
+        torch.cuda.current_stream(model.device).wait_stream(side)
+        fetched = [start_epoch]   # losses of the epochs up to here are on the host
+
+        def fetch(upto, keep_last_back=False):
+            torch.cuda.synchronize(model.device)
+            ring = st["ring"].cpu().numpy()
+            new = [float(ring[e % st["ring_len"], 0] / ring[e % st["ring_len"], 2]) for e in range(fetched[0] + 1, upto + 1)]
+            fetched[0] = upto
+            return new
+
+        params = get_params(opt_state)
+        for epoch in range(start_epoch + 1, start_epoch + self.num_epochs + 1):
+            if epoch % self.log_every == 0 or epoch == 1:
+                new = fetch(epoch - 1)
+                loss.extend(new)
+                energies.extend([[v] for v in new])
+                opt_state.version += 1
+                params = get_params(opt_state)
+                helpers.create_checkpoint_wavefunc(int(rng.integers(1 << 31)), save_dir, psi, sample, params, epoch, loss, energies, system_dict)
+                model.set_params_device(opt_state.x)
+            graph.replay()
+            if epoch % 100 == 0:
+                new = fetch(epoch)
+                loss.extend(new[:-1])
+                energies.extend([[v] for v in new[:-1]])
+                st["running_average"].fill_(float(np.asarray(loss[-100:]).mean()))   # before this epoch's loss joins (vqmc.py:112-118)
+                loss.append(new[-1])
+                energies.append([new[-1]])
+                if epoch % self.log_every == 0 and verbose:
+                    print(f"epoch {epoch} | Loss: {round(float(new[-1]), 3)}")
+        new = fetch(start_epoch + self.num_epochs)
+        loss.extend(new)
+        energies.extend([[v] for v in new])
+        opt_state.version += 1
+        return get_params(opt_state), loss, energies
