@@ -704,9 +704,76 @@ __device__ __forceinline__ float lerp0(const float* __restrict__ tab, const Lerp
     return yl + ((yr - yl) * L.n) * L.dx;
 }
 
+// x with sum_j c_j I_j(x) = y as helpers.binary_search returns it (utils/helpers.py:150-166: K halvings of [0, 1], the lower
+// end of the last bracket), without the K dependent table reads of the halving loop: the spline is monotone and piecewise
+// linear on the mesh, so (1) the mesh interval that contains the root is found by two 64-way searches (every lane evaluates
+// the spline at one mesh point), (2) the root follows from the line through its two mesh values, (3) it is rounded down to the
+// halving grid 2^-K.  (A halving loop in fp32 takes a wrong turn when |f(mid)| is below its rounding noise, so does this; both
+// stay within one grid step of the exact-arithmetic answer.)  c: this lane's weight (lanes of half `hd` hold the dimension).
+__device__ __forceinline__ float ispline_inverse(const float* __restrict__ tab0 /* [n_mesh][32], order 0 */, int n_mesh, int nb, float c,
+                                                 float y, float tol, int hd, float (*ov)[64], int lane) {
+    put(ov, lane, R1{c});
+    const float* __restrict__ cw = &ov[0][hd * 32];
+    auto spline_at = [&](int m) {   // sum_j c_j T[m][j], j ascending
+        const float4_t* __restrict__ row = reinterpret_cast<const float4_t*>(tab0 + (size_t)m * NBP);
+        float acc = 0.0f;
+#pragma unroll
+        for (int q = 0; q < NBP / 4; ++q) {
+            const float4_t t = row[q], w = *reinterpret_cast<const float4_t*>(cw + 4 * q);
+            acc = __builtin_fmaf(w.x, t.x, acc);
+            acc = __builtin_fmaf(w.y, t.y, acc);
+            acc = __builtin_fmaf(w.z, t.z, acc);
+            acc = __builtin_fmaf(w.w, t.w, acc);
+        }
+        return acc;
+    };
+    // round 1: mesh points 0, 32, 64, ... ; round 2: the 32 points inside the interval found (weights beyond nb are zero)
+    const int last = n_mesh - 1;
+    int m1 = min(lane * 32, last);
+    float g1 = spline_at(m1);
+    // (first lane whose mesh value exceeds y: robust against a rounding-level non-monotonicity of the fp32 sums)
+    int cnt = __ffsll((long long)~__ballot(g1 <= y && lane * 32 <= last)) - 1;
+    if (cnt < 0) cnt = 64;
+    const int base = max(cnt - 1, 0) * 32;
+    const int m2 = min(base + (lane & 31), last);
+    const float g2 = spline_at(m2);
+    cnt = __ffsll((long long)~__ballot(g2 <= y && lane < 32 && base + lane <= last)) - 1;
+    if (cnt < 0) cnt = 64;
+    cnt = min(cnt, 32);
+    const int k = max(cnt - 1, 0);                      // lane k holds the largest mesh point with spline <= y
+    const int m = min(base + k, last);
+    const float yl = __shfl(g2, k);
+    const float yr = m < last ? (k < 31 ? __shfl(g2, k + 1) : spline_at(m + 1)) : yl;
+    __builtin_amdgcn_wave_barrier();
+    const float n = (float)last;
+    float xs = (float)m / n;
+    if (yr > yl) xs = xs + (y - yl) / ((yr - yl) * n);
+    // the halving grid
+    int K = 0;
+    float w = 1.0f;
+    while (K < 64 && w * 0.5f > tol * 0.5f) { w *= 0.5f; ++K; }
+    const float scale = ldexpf(1.0f, K);
+    float q = floorf(xs * scale);
+    q = fminf(fmaxf(q, 0.0f), scale - 1.0f);
+    // The halving loop ends at the largest grid point whose spline value, evaluated by the table lerp, does not exceed y.
+    // The line through the mesh values locates it to within a grid step; the lerp itself decides between the neighbours:
+    // lanes 0..31 evaluate it at q, lanes 32..63 at q + 1 (one more table read, both in flight together).
+    {
+        const int side = lane >> 5, jj = lane & 31;
+        const float xq = fminf(q + (float)side, scale - 1.0f) / scale;
+        const Lerp L = make_lerp(xq, n_mesh);
+        const float f = hsum(cw[jj] * lerp0(tab0, L, jj)) - y;
+        const float f_other = swap32_other(f);
+        const float f_lo = side == 0 ? f : f_other, f_hi = side == 0 ? f_other : f;
+        if (f_hi <= 0.0f && q + 1.0f <= scale - 1.0f) q = q + 1.0f;
+        else if (f_lo > 0.0f && q >= 1.0f) q = q - 1.0f;
+    }
+    return q / scale;
+}
+
 template <int D>
 __device__ __forceinline__ void wave_serial_inverse(const ModelDev& md, const float* __restrict__ tabI, const float* __restrict__ gI, float (&cur)[D],
-                                                    float (*vec)[64], int lane, int exact) {
+                                                    float (*vec)[64], float (*ov)[64], int lane, int exact) {
     const int dl = lane >> 5, j = lane & 31;
     const Tape no_tape{nullptr, 0};
     float nxt[D];
@@ -731,16 +798,7 @@ __device__ __forceinline__ void wave_serial_inverse(const ModelDev& md, const fl
                 const R1 o = gemv<R1>(net.W2f + p * 1024, vec, lane) + net.b2[p * 64 + lane];
                 const bool valid_d = 2 * p + dl < D, valid = valid_d && j < nb;
                 const SigHead<R1> hdw = sigmoid_head(o, valid, valid_d, gI[j], md.i_reg);
-                const float y = nxt[d];
-                float low = 0.0f, high = 1.0f;
-                for (int it = 0; it < 64; ++it) {   // helpers.binary_search
-                    const float mid = 0.5f * (low + high);
-                    if (!((low + tol / 2 < mid) && (mid < high - tol / 2))) break;
-                    const Lerp L = make_lerp(mid, n_mesh);
-                    const float f = of_half(hsum(hdw.c.c0 * lerp0(tabI, L, j)), hd, dl) - y;
-                    if (f > 0) high = mid; else low = mid;
-                }
-                cur[d] = low;
+                cur[d] = ispline_inverse(tabI, n_mesh, nb, hdw.c.c0, nxt[d], tol, hd, ov, lane);
             }
         } else {
 #pragma unroll
@@ -841,7 +899,7 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(WF_WAVE_OCC
                     if (lane == d) latent[b * D + d] = cur[d];
             }
         }
-        wave_serial_inverse<D>(md, tabI, gI, cur, vec, lane, exact);
+        wave_serial_inverse<D>(md, tabI, gI, cur, vec, ov, lane, exact);
 #pragma unroll
         for (int d = 0; d < D; ++d)
             if (lane == d) xg[b * D + d] = cur[d];
