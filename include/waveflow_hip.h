@@ -180,7 +180,8 @@ int wf_sample(const wf_model* m, uint64_t seed, int64_t B, float* x_dev, float* 
  * with physics.laplacian (:50-52, trace of jax.hessian -- the table lerp differentiates to the next cached derivative table,
  * isplines_jax.py:60-66) and the one-dimensional soft-Coulomb physics.get_potential (:60-76) for `n_protons` <= 8 protons at
  * `protons_host`.  hpsi_dev[B]; psi_dev[B] and laplacian_dev[B] may be NULL.  The local energy of vqmc.loss_fn_efficient
- * (vqmc.py:193-200) is hpsi / (psi + 1e-8).  WF_PRIOR_WAVEFLOW models with IMADE layers, <= 32 bases, D <= 4. */
+ * (vqmc.py:193-200) is hpsi / (psi + 1e-8).  WF_PRIOR_WAVEFLOW models with IMADE layers, <= 32 bases per dimension,
+ * zero-only boundary constraints (any D the library supports: 2..8). */
 int wf_hamiltonian_fwd(const wf_model* m, const float* x_dev, int64_t B, const float* protons_host, int32_t n_protons,
                        float* hpsi_dev, float* psi_dev, float* laplacian_dev, void* stream);
 
@@ -227,7 +228,7 @@ int wf_vqmc_train_step(wf_model* m, const wf_train_state* st, uint64_t seed, int
                        void* stream);
 
 /* Parameter gradient of the log-density: grad_dev[p] = sum_b w_dev[b] * d log_pdf_b / d theta_p for every model wf_logpdf_fwd
- * evaluates with <= 32 bases, D <= 4 and zero-only constraints (IMADE or MADE layers; Waveflow, M-spline, Normal or Uniform
+ * evaluates with <= 32 bases per dimension and zero-only constraints (IMADE or MADE layers; Waveflow, M-spline, Normal or Uniform
  * prior).  With w = -1/B this is the gradient of benchmark_tests.loss (benchmark_tests.py:84-87, 98-101); with per-walker
  * weights it is the jacrev(log_pdf) contraction of vqmc.train_step (vqmc.py:175-180). */
 int64_t wf_logpdf_vjp_workspace_bytes(const wf_model* m, int64_t B);

@@ -214,9 +214,11 @@ def test_benchmark_training_lowers_the_negative_log_likelihood(tmp_path, model_t
     assert (run / "system_info.json").exists()
 
 
-@pytest.mark.parametrize("D,box,layers,k,kn,B", [(3, "first", 2, 4, 13, 37), (4, "mean", 1, 5, 16, 65), (2, "first", 1, 3, 10, 1)])
+@pytest.mark.parametrize("D,box,layers,k,kn,B", [(3, "first", 2, 4, 13, 37), (4, "mean", 1, 5, 16, 65), (2, "first", 1, 3, 10, 1), (8, "mean", 2, 4, 13, 9),
+                                              (5, "first", 1, 3, 10, 6)])
 def test_gradients_other_shapes_vs_autograd_oracle(D, box, layers, k, kn, B):
-    """D = 3, 4, both box transforms, ragged batches: psi / Laplacian / log_pdf gradients vs torch (fp64)."""
+    """D = 3 .. 8 (C4: the 8-electron chain), both box transforms, ragged batches: psi / Laplacian / log_pdf gradients and the
+    local energy vs torch (fp64)."""
     import torch
     from oracle import energy_torch as et
     from waveflow_amd import flatten_params, model_factory
@@ -237,6 +239,12 @@ def test_gradients_other_shapes_vs_autograd_oracle(D, box, layers, k, kn, B):
     got = m.logpdf_vjp(x, w).cpu().numpy().astype(np.float64)
     want = et.logpdf_vjp(mo, flat, x.astype(np.float64), w)
     assert rel_l2(got, want) < 3e-3, rel_l2(got, want)
+    protons = np.linspace(-3.0, 3.0, 4)
+    hp, ps, lap = m.hamiltonian(x, protons, return_psi=True, return_laplacian=True)
+    ho, po, lo = et.hamiltonian(mo, flat, x.astype(np.float64), protons)
+    np.testing.assert_allclose(ps, po, rtol=2e-4, atol=1e-6 * np.abs(po).max())
+    np.testing.assert_allclose(lap, lo, rtol=0, atol=2e-3 * np.abs(lo).max())
+    np.testing.assert_allclose(hp, ho, rtol=0, atol=2e-3 * np.abs(ho).max())
 
 
 def test_device_parameter_path_matches_host_path(he_flat):

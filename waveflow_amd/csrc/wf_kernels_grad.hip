@@ -246,7 +246,7 @@ int run_wgrad(int n_nets, int64_t n_samples, const float* ws, float* partial, in
 
 }  // namespace
 
-int grad_ws_rows(int D) { return 4 + 4 * H + D * NBP; }
+int grad_ws_rows(int D) { return 8 + 4 * H + D * NBP; }
 
 // tape -> gradient image: sum over samples of activation (x) adjoint, top ring coefficient
 int wgrad_partial_floats(int n_nets, int64_t net_img_floats) { return kWgradSplit * n_nets * (int)net_img_floats; }
@@ -261,6 +261,10 @@ int launch_wgrad(int D, int second_order, int n_nets, int64_t n_samples, const f
         case 2: CALL(2);
         case 3: CALL(3);
         case 4: CALL(4);
+        case 5: CALL(5);
+        case 6: CALL(6);
+        case 7: CALL(7);
+        case 8: CALL(8);
         default: return WF_ERR_UNSUPPORTED;
     }
 #undef CALL

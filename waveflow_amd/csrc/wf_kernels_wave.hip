@@ -947,6 +947,10 @@ int64_t wave_tail_floats(int D, int second_order) { return (int64_t)(2 * D + 1) 
         case 2: return CALL(2);                   \
         case 3: return CALL(3);                   \
         case 4: return CALL(4);                   \
+        case 5: return CALL(5);                   \
+        case 6: return CALL(6);                   \
+        case 7: return CALL(7);                   \
+        case 8: return CALL(8);                   \
         default: return WF_ERR_UNSUPPORTED;       \
     }
 
@@ -999,6 +1003,10 @@ int launch_energy_out(int D, const float* tails, const float* x, int64_t B, unsi
         case 2: hipLaunchKernelGGL(k_energy_out<2>, grid, block, 0, s, tails, x, B, constrained_mask, pr, hpsi, psi, lap); break;
         case 3: hipLaunchKernelGGL(k_energy_out<3>, grid, block, 0, s, tails, x, B, constrained_mask, pr, hpsi, psi, lap); break;
         case 4: hipLaunchKernelGGL(k_energy_out<4>, grid, block, 0, s, tails, x, B, constrained_mask, pr, hpsi, psi, lap); break;
+        case 5: hipLaunchKernelGGL(k_energy_out<5>, grid, block, 0, s, tails, x, B, constrained_mask, pr, hpsi, psi, lap); break;
+        case 6: hipLaunchKernelGGL(k_energy_out<6>, grid, block, 0, s, tails, x, B, constrained_mask, pr, hpsi, psi, lap); break;
+        case 7: hipLaunchKernelGGL(k_energy_out<7>, grid, block, 0, s, tails, x, B, constrained_mask, pr, hpsi, psi, lap); break;
+        case 8: hipLaunchKernelGGL(k_energy_out<8>, grid, block, 0, s, tails, x, B, constrained_mask, pr, hpsi, psi, lap); break;
         default: return WF_ERR_UNSUPPORTED;
     }
     return finish();
@@ -1017,6 +1025,10 @@ int launch_wave_eval(const ModelDev& md, const ModelDev* md_dev, const float* ta
         case 2: CALL(2);
         case 3: CALL(3);
         case 4: CALL(4);
+        case 5: CALL(5);
+        case 6: CALL(6);
+        case 7: CALL(7);
+        case 8: CALL(8);
         default: return WF_ERR_UNSUPPORTED;
     }
 #undef CALL

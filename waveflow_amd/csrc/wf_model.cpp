@@ -704,8 +704,8 @@ static bool wave_capable(const wf_model* m) {
     if (spline_prior && (!m->d_tabP3 || !bc_only_zeroes(d.p_left, d.p_right, false))) return false;
     return true;
 }
-// ... of which the reverse pass and the local energy are instantiated for D <= 4
-static bool grad_capable(const wf_model* m) { return m->wave_ok && m->desc.n_dim <= 4 && !m->nets.empty(); }
+// ... which is also what the reverse pass and the local energy need (every D the library supports, 2..8, is instantiated)
+static bool grad_capable(const wf_model* m) { return m->wave_ok && !m->nets.empty(); }
 
 // Describes every weight image (PackRec lists on the device) and derives the gradient scatter map: forward-image entry ->
 // flat parameter (masked and padding entries have no source: no gradient).
@@ -864,7 +864,7 @@ int wf_model_n_bases(const wf_model* m, int which) {
 int wf_model_set_kernel(wf_model* m, int kernel_kind) {
     if (!m || kernel_kind < WF_KERNEL_AUTO || kernel_kind > WF_KERNEL_WAVE) return WF_ERR_INVALID;
     if (kernel_kind == WF_KERNEL_MFMA && !m->mfma_ok) return WF_ERR_UNSUPPORTED;
-    if (kernel_kind == WF_KERNEL_WAVE && !(m->wave_ok && m->desc.n_dim <= 4)) return WF_ERR_UNSUPPORTED;
+    if (kernel_kind == WF_KERNEL_WAVE && !m->wave_ok) return WF_ERR_UNSUPPORTED;
     m->kernel_kind = kernel_kind;
     return WF_OK;
 }
@@ -931,7 +931,7 @@ static int dispatch(const wf_model* m, int mode, const float* x, int64_t B, floa
     // which first stages its weight images into LDS, takes 38-42 us whatever the batch; from ~7000 walkers on the MFMA
     // kernel's throughput wins (4096: 30 vs 42 us, 8192: 46 vs 42 us).  The wave kernel does
     // not report bin indices.
-    const bool wave_fits = m->wave_ok && m->desc.n_dim <= 4 && !idx && m->desc.n_flow_layers > 0;
+    const bool wave_fits = m->wave_ok && !idx && m->desc.n_flow_layers > 0;
     const bool use_wave = wave_fits && (m->kernel_kind == WF_KERNEL_WAVE || (m->kernel_kind == WF_KERNEL_AUTO && B <= kWaveEvalMax));
     if (m->kernel_kind == WF_KERNEL_WAVE && !use_wave) return WF_ERR_UNSUPPORTED;
     if (use_wave) {
@@ -1036,7 +1036,7 @@ int wf_hamiltonian_fwd(const wf_model* m, const float* x_dev, int64_t B, const f
     if (rc) return rc;
     if (n_protons < 0 || n_protons > 8 || (n_protons > 0 && !protons_host)) return WF_ERR_INVALID;
     if (m->desc.prior_kind != WF_PRIOR_WAVEFLOW) return WF_ERR_INVALID;
-    if (m->desc.layer_kind != WF_LAYER_IMADE || !m->d_tabI4 || !m->d_tabP3 || !m->d_grad_fk || m->desc.n_dim > 4) return WF_ERR_UNSUPPORTED;
+    if (m->desc.layer_kind != WF_LAYER_IMADE || !m->d_tabI4 || !m->d_tabP3 || !m->d_grad_fk) return WF_ERR_UNSUPPORTED;
     Protons pr{};
     pr.n = n_protons;
     for (int i = 0; i < n_protons; ++i) pr.pos[i] = protons_host[i];

@@ -13,11 +13,12 @@ namespace ring {
 
 constexpr int NBP = 32;
 
-// Rows of one net in the tape of the reverse pass ([sample][net][coefficient][row]): layer input U (D rows in a slot of 4),
+// Rows of one net in the tape of the reverse pass ([sample][net][coefficient][row]): layer input U (D <= 8 rows in a slot of 8),
 // hidden activations H1, H2, pre-activation adjoints A1, A2, head-output adjoints O (row d * 32 + j).  Every group starts
 // at a multiple of 4 rows so that k_wgrad can stage with 16-byte loads.
 template <int D> struct Rows {
-    static constexpr int U = 0, H1 = 4, H2 = 4 + 64, A1 = 4 + 128, A2 = 4 + 192, O = 4 + 256, N = 4 + 256 + D * NBP;
+    static constexpr int U = 0, H1 = 8, H2 = 8 + 64, A1 = 8 + 128, A2 = 8 + 192, O = 8 + 256, N = 8 + 256 + D * NBP;
+    static_assert(D <= 8, "the U slot holds 8 rows");
 };
 
 // ---- the rings: R3 = IR[t]/t^3 (Taylor coefficients) for psi and its Laplacian, R1 = IR for first-order objectives
