@@ -33,6 +33,9 @@ PMC_TRAFFIC_BYTES_2POW20 = (10791 + 14336) * 1024
 # executed matrix-core work per eval (He): per 32-walker tile 156 v_mfma_f32_32x32x16_f16 + 12 v_mfma_f32_32x32x2_f32
 MFMA_FLOP_PER_EVAL = (156 * 32768 + 12 * 4096) / 32
 PEAK_F16_MATRIX_TFLOPS = 2500.0
+# reverse sweep of one (walker, direction) sample, He: per net 3 dense 64x64 products x 3 ring coefficients (+ the 32x32
+# change of basis of the prior), FMA = 2 FLOP
+VQMC_BWD_FLOP_PER_SAMPLE = 2 * (4 * 3 * 64 * 64 * 3 + 2 * 32 * 32 * 3 * 2)
 
 
 def he_model(kernel):
@@ -93,12 +96,14 @@ def main():
     ap.add_argument("--batch", type=int, default=1 << 20, help="walkers per GPU")
     ap.add_argument("--kernel", default="auto", choices=["auto", "scalar", "mfma"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="he_logpdf", choices=["he_logpdf", "rqs"],
+    ap.add_argument("--workload", default="he_logpdf", choices=["he_logpdf", "rqs", "vqmc"],
                     help="he_logpdf: the BASELINE metric (default).  rqs: the RQS bijector kernel alone (SURVEY row a12), an "
                          "HBM-bound elementwise op: 2 dims x `--batch` walkers, 32 bins")
     args = ap.parse_args()
     if args.workload == "rqs":
         return main_rqs(args)
+    if args.workload == "vqmc":
+        return main_vqmc(args)
 
     import torch
     import torch.distributed as dist
@@ -241,6 +246,72 @@ def main_rqs(args):
         "config": {"workload": f"unconstrained RQS forward (neural_splines.py:16-71), K=32 bins, {N} elements (2 dims x {args.batch} walkers)"},
         "roofline": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
                      "kernel": "k_rqs_reg<32>", "kernel_ms": kern_ms, "bytes_per_eval": bytes_per}}), flush=True)
+
+
+def main_vqmc(args):
+    """Secondary line: the VQMC inner loop on the shipped He checkpoint, single GPU.
+    value = loss + gradient walkers/s (wf_vqmc_loss_grad, 2^17 walkers); also H psi walkers/s and whole training steps/s
+    (batch 128, hipGraph replay).  cpu_baseline = the torch autograd oracle on the host cores (bounded sample)."""
+    import torch
+    from waveflow_amd import vqmc
+    from waveflow_amd.utils import physics
+    model, flat = he_model("auto")
+    protons = physics.system_catalogue[1]["He"][0].reshape(-1)
+    B = min(args.batch, 1 << 17)
+    x = walkers(B, 1234).cuda()
+
+    def timed(fn, n):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+
+    n = max(args.steps // 5, 5)
+    t_grad = timed(lambda: model.vqmc_loss_grad(x, protons, -1.8), n)
+    t_h = timed(lambda: model.hamiltonian(x, protons), n)
+    # the dominant kernel of the gradient, timed with events
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for a, b in ev:
+        a.record()
+        model.vqmc_loss_grad(x, protons, -1.8)
+        b.record()
+    torch.cuda.synchronize()
+    step_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    # whole training steps (sample -> loss + gradient -> Adam -> image refill), batch 128, one hipGraph replay each
+    tr = vqmc.ModelTrainer(system_name="He", learning_rate=1e-4, box_length=10, num_epochs=4000, batch_size=128, log_every=10 ** 9)
+    tr.save_dir = os.path.join("/tmp", "wf_bench_vqmc")
+    tr.exact_sampler = True
+    t0 = time.perf_counter()
+    tr.start_training(verbose=False)
+    t_train = (time.perf_counter() - t0) / 4000
+    out = {
+        "metric": "VQMC loss+gradient walkers/sec", "value": B / t_grad, "unit": "walkers/s", "n_gpus": 1, "steps": n, "warmup": 3,
+        "ms_per_step": t_grad * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"1D He (shipped checkpoint): loss_fn_efficient + gradient over {B} walkers (vqmc.py:193-221); also H psi and "
+                               "whole training steps at batch 128", "walkers": B},
+        "hpsi_walkers_per_s": B / t_h, "train_steps_per_s_batch128": 1.0 / t_train, "train_ms_per_step_batch128": t_train * 1e3,
+        "roofline": {"bound": "valu", "achieved": B * 2 * VQMC_BWD_FLOP_PER_SAMPLE / (0.5 * step_ms * 1e-3) / 1e12, "peak": PEAK_F32_MATRIX_TFLOPS,
+                     "unit": "TFLOP/s", "frac": B * 2 * VQMC_BWD_FLOP_PER_SAMPLE / (0.5 * step_ms * 1e-3) / 1e12 / PEAK_F32_MATRIX_TFLOPS,
+                     "traffic": None, "kernel": "k_wave_bwd<2, R3>", "kernel_ms": 0.5 * step_ms,
+                     "note": "the sweeps are fp32 vector (VALU) work, which this contract's bound enum does not name: achieved = algorithmic "
+                             "FMA FLOP of the reverse sweep (2 samples per walker) / its share of the step (~50 %, profiles/r01e_*); "
+                             "peak = the fp32 vector peak"},
+    }
+    if not args.no_cpu_baseline:
+        from oracle import energy_torch as et
+        cores = host_cores()
+        torch.set_num_threads(cores)
+        xs = x[:256].cpu().numpy().astype(np.float64)
+        t0 = time.perf_counter()
+        et.vqmc_loss_grad(et.he_model(torch.float64), flat, xs, protons, -1.8)
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": 256 / dt, "unit": "walkers/s", "cores": cores, "kind": "port",
+                               "sample": "torch reverse-mode oracle (oracle/energy_torch.py, fp64) on 256 walkers of the same batch"}
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
