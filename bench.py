@@ -39,7 +39,7 @@ VQMC_BWD_FLOP_PER_SAMPLE = 2 * (4 * 3 * 64 * 64 * 3 + 2 * 32 * 32 * 3 * 2)
 
 
 def he_model(kernel):
-    from waveflow_amd import checkpoint, model_factory
+    from waveflow_amd import model_factory
     flat = np.load(os.path.join(ROOT, "tests", "golden", "he_checkpoint.npz"))["flat"]
     init_fun = model_factory.get_waveflow_model(2, base_spline_degree=6, i_spline_degree=6, n_prior_internal_knots=23,
                                                 n_i_internal_knots=23, i_spline_reg=0.05, i_spline_reverse_fun_tol=1e-6,
@@ -129,7 +129,6 @@ def main():
     lp = torch.empty(B, device=dev, dtype=torch.float32)
 
     from waveflow_amd import _lib
-    from waveflow_amd import distributed as wfd
     import ctypes
     L = _lib.lib()
     ws = torch.empty(int(L.wf_block_sums_workspace_bytes(B)), device=dev, dtype=torch.uint8)

@@ -10,7 +10,6 @@ the step's only collective is one SUM all-reduce of [gradient, sum E_L, sum E_L^
 with m_hat = m / (1 - b1^(i+1)), v_hat = v / (1 - b2^(i+1)) for the step index i passed to opt_update.
 """
 import json
-import pickle
 from pathlib import Path
 
 import numpy as np
