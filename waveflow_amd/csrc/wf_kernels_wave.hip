@@ -83,20 +83,36 @@ template <class T> __device__ __forceinline__ void put(float (*buf)[64], int lan
 // out[lane] = sum_a in[a] * W[lane][a], W in lane-major float4 groups.  Even and odd a accumulate in the two halves of a
 // packed pair (v_pk_fma_f32: two FMAs per lane and instruction) and are added at the end.
 using float2_t = __attribute__((ext_vector_type(2))) float;
-template <class T>
+template <class T, bool PRELOAD = false>
 __device__ __forceinline__ T gemv(const float4_t* __restrict__ img, const float (*buf)[64], int lane) {
     float2_t acc[T::NC];
 #pragma unroll
     for (int k = 0; k < T::NC; ++k) acc[k] = float2_t{0.0f, 0.0f};
-#pragma unroll 4
-    for (int g = 0; g < 16; ++g) {
-        const float4_t w = img[g * 64 + lane];
-        const float2_t wlo = {w.x, w.y}, whi = {w.z, w.w};
+    if constexpr (T::NC == 1 && PRELOAD) {
+        // the sampler: all 16 weight loads of the lane are requested up front (one L2 round trip per product instead of
+        // four -- it runs at low occupancy on small batches, where that latency is the chain: 70 -> 58 us for 128 walkers;
+        // in the sweeps the extra 64 live registers cost more than they save)
+        float4_t w[16];
 #pragma unroll
-        for (int k = 0; k < T::NC; ++k) {
-            const float4_t x = *reinterpret_cast<const float4_t*>(&buf[k][4 * g]);
-            acc[k] = __builtin_elementwise_fma(wlo, float2_t{x.x, x.y}, acc[k]);
-            acc[k] = __builtin_elementwise_fma(whi, float2_t{x.z, x.w}, acc[k]);
+        for (int g = 0; g < 16; ++g) w[g] = img[g * 64 + lane];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const float4_t x = *reinterpret_cast<const float4_t*>(&buf[0][4 * g]);
+            acc[0] = __builtin_elementwise_fma(float2_t{w[g].x, w[g].y}, float2_t{x.x, x.y}, acc[0]);
+            acc[0] = __builtin_elementwise_fma(float2_t{w[g].z, w[g].w}, float2_t{x.z, x.w}, acc[0]);
+        }
+    } else {
+        // groups of 4 (full unrolling made hipcc hold 48 LDS reads live in the second-order kernels: 256 VGPRs)
+#pragma unroll 4
+        for (int g = 0; g < 16; ++g) {
+            const float4_t w = img[g * 64 + lane];
+            const float2_t wlo = {w.x, w.y}, whi = {w.z, w.w};
+#pragma unroll
+            for (int k = 0; k < T::NC; ++k) {
+                const float4_t x = *reinterpret_cast<const float4_t*>(&buf[k][4 * g]);
+                acc[k] = __builtin_elementwise_fma(wlo, float2_t{x.x, x.y}, acc[k]);
+                acc[k] = __builtin_elementwise_fma(whi, float2_t{x.z, x.w}, acc[k]);
+            }
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -167,7 +183,7 @@ template <int D> struct Tail {   // slots
 };
 
 // two masked tanh layers, lane = hidden unit; leaves h2 in `vec` and returns it
-template <int D, class T>
+template <int D, class T, bool PRELOAD = false>
 __device__ __forceinline__ T hidden_fwd(const NetWave& net, const T (&x)[D], float (*vec)[64], int lane, const Tape& tape, int n, bool taped) {
     T z = cst<T>(net.b0[lane]);
 #pragma unroll
@@ -175,7 +191,7 @@ __device__ __forceinline__ T hidden_fwd(const NetWave& net, const T (&x)[D], flo
     const T h1 = rtanh(z);
     if (taped) tput(tape, n, Rows<D>::H1 + lane, h1);
     put(vec, lane, h1);
-    const T h2 = rtanh(gemv<T>(net.W1f, vec, lane) + net.b1[lane]);
+    const T h2 = rtanh(gemv<T, PRELOAD>(net.W1f, vec, lane) + net.b1[lane]);
     if (taped) tput(tape, n, Rows<D>::H2 + lane, h2);
     put(vec, lane, h2);
     return h2;
@@ -792,10 +808,10 @@ __device__ __forceinline__ void wave_serial_inverse(const ModelDev& md, const fl
                     R1 xin[D];
 #pragma unroll
                     for (int a = 0; a < D; ++a) xin[a] = R1{exact ? cur[a] : nxt[a]};
-                    hidden_fwd<D, R1>(net, xin, vec, lane, no_tape, 0, false);
+                    hidden_fwd<D, R1, true>(net, xin, vec, lane, no_tape, 0, false);
                 }
                 const int p = d >> 1, hd = d & 1;
-                const R1 o = gemv<R1>(net.W2f + p * 1024, vec, lane) + net.b2[p * 64 + lane];
+                const R1 o = gemv<R1, true>(net.W2f + p * 1024, vec, lane) + net.b2[p * 64 + lane];
                 const bool valid_d = 2 * p + dl < D, valid = valid_d && j < nb;
                 const SigHead<R1> hdw = sigmoid_head(o, valid, valid_d, gI[j], md.i_reg);
                 cur[d] = ispline_inverse(tabI, n_mesh, nb, hdw.c.c0, nxt[d], tol, hd, ov, lane);
@@ -806,9 +822,9 @@ __device__ __forceinline__ void wave_serial_inverse(const ModelDev& md, const fl
                 R1 xin[D];
 #pragma unroll
                 for (int a = 0; a < D; ++a) xin[a] = R1{cur[a]};
-                hidden_fwd<D, R1>(net, xin, vec, lane, no_tape, 0, false);
+                hidden_fwd<D, R1, true>(net, xin, vec, lane, no_tape, 0, false);
                 const int p = c >> 1, hd = c & 1;
-                const R1 o = gemv<R1>(net.W2f + p * 1024, vec, lane) + net.b2[p * 64 + lane];
+                const R1 o = gemv<R1, true>(net.W2f + p * 1024, vec, lane) + net.b2[p * 64 + lane];
                 const float lw = __shfl(o.c0, hd * 32), bias = __shfl(o.c0, hd * 32 + 1);
                 cur[c] = nxt[c] * expf(lw) + bias;
             }
@@ -864,9 +880,9 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(WF_WAVE_OCC
                     R1 xin[D];
 #pragma unroll
                     for (int a = 0; a < D; ++a) xin[a] = R1{cur[a]};   // conditioner on the columns drawn so far, zeros elsewhere
-                    hidden_fwd<D, R1>(net, xin, vec, lane, no_tape, 0, false);
+                    hidden_fwd<D, R1, true>(net, xin, vec, lane, no_tape, 0, false);
                     const int p = col >> 1, hd = col & 1;
-                    const R1 o = gemv<R1>(net.W2f + p * 1024, vec, lane) + net.b2[p * 64 + lane];
+                    const R1 o = gemv<R1, true>(net.W2f + p * 1024, vec, lane) + net.b2[p * 64 + lane];
                     const bool valid_d = 2 * p + dl < D, valid = valid_d && j < nb;
                     float cj, ymax;
                     if (wavefn) {
