@@ -132,7 +132,7 @@ struct Protons {
 int grad_ws_rows(int D);
 int wgrad_partial_floats(int n_nets, int64_t net_img_floats);
 int launch_wgrad(int D, int second_order, int n_nets, int64_t n_samples, const float* ws, float* partial, int accumulate, float* grad_img,
-                 int64_t net_img_floats, void* stream);
+                 int64_t net_img_floats, int* split_out, void* stream);
 int launch_wave_fwd(const ModelDev& md, const ModelDev* md_dev, int second_order, const float* tabI4, const float* tabP4, const float* fk_nat,
                     const float* x, int64_t B, float* ws, float* tails, int taped, void* stream);
 int launch_wave_bwd(const ModelDev& md, const ModelDev* md_dev, int mode, int second_order, const float* tabI4, const float* tabP4,
@@ -145,21 +145,25 @@ int launch_wave_sample(const ModelDev& md, const ModelDev* md_dev, const float* 
 int launch_wave_eval(const ModelDev& md, const ModelDev* md_dev, const float* tabI4, const float* tabP4, const float* fk_nat, int mode,
                      const float* x, int64_t B, float* out, float* u, float* tail_ws, void* stream);
 int64_t wave_tail_floats(int D, int second_order);
+int launch_energy_seeds(int D, const float* tails, const float* x, int64_t B, unsigned constrained_mask, const Protons& pr, float running_avg,
+                        const float* running_avg_dev, float inv_count, float* e_loc, float* w_psi, float* w_lap, void* stream);
 int launch_energy_out(int D, const float* tails, const float* x, int64_t B, unsigned constrained_mask, const Protons& pr, float* hpsi, float* psi,
                       float* lap, void* stream);
 // One entry of a device weight image as a function of the flat parameter vector:
-//   kind 0: image float [dst]            = src >= 0 ? (float)(scale * flat[src]) : (float)scale
-//   kind 1: image halves [dst], [dst_lo] = fp16 pair (hi, lo) of that value, hi + lo = value to 2^-25
+//   kind & 0xFF == 0: image float [dst]  = src >= 0 ? (float)(scale * flat[src]) : (float)scale
+//   kind & 0xFF == 1: image halves [dst], [dst_lo] = fp16 pair (hi, lo) of that value, hi + lo = value to 2^-25
+//   kind >> 8: which image (0 plain, 1 wave, 2 mfma)
 struct PackRec {
     int32_t src, kind;
     uint32_t dst, dst_lo;
     double scale;
 };
-int launch_pack(const float* flat_dev, const PackRec* recs, int64_t n, void* image_base, void* stream);
+int launch_pack(const float* flat_dev, const PackRec* recs, int64_t n, void* plain, void* wave, void* mfma, void* stream);
 int launch_adam(float* params, const float* grad, float* m, float* v, int64_t n, int64_t step, float step_size, float b1, float b2, float eps,
                 const unsigned long long* step_dev, void* stream);
 int launch_step_end(const double* sums, double* ring, int ring_len, unsigned long long* counter, void* stream);
-int launch_grad_scatter(const float* grad_img, const int32_t* map, int64_t n_img, float* grad_flat, void* stream);
+int launch_grad_gather(const float* grad_img, const int32_t* inv, int64_t n_params, float* grad_flat, void* stream);
+int launch_grad_gather_partials(const float* partial, int split, int64_t n_img, const int32_t* inv, int64_t n_params, float* grad_flat, void* stream);
 int launch_vqmc_seeds(const float* x, int64_t B, int D, const Protons& pr, const float* hpsi, const float* psi, float running_avg,
                       float inv_count, float* e_loc, float* w_psi, float* w_lap, const float* running_avg_dev, void* stream);
 int launch_rqs(const float* x, const float* uw, const float* uh, const float* ud, int64_t N, int K, int n_deriv, int inverse,

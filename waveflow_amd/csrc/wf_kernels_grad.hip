@@ -132,18 +132,36 @@ __global__ void k_wgrad_reduce(const float* __restrict__ partial, int split, int
     gimg[i] = s;
 }
 
-__global__ void k_grad_scatter(const float* __restrict__ gimg, const int32_t* __restrict__ map, int64_t n_img, float* __restrict__ flat) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_img) return;
-    const int32_t t = map[i];
-    if (t >= 0) flat[t] = gimg[i];
+// flat[p] = gradient-image entry of parameter p (inv[p]; -1: the parameter reaches no image entry -- masked weight or
+// zero_params leaf -- and its gradient is 0).  A gather over the flat vector: every entry is written, no memset needed.
+__global__ void k_grad_gather(const float* __restrict__ gimg, const int32_t* __restrict__ inv, int64_t n_params, float* __restrict__ flat) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_params) return;
+    const int32_t t = inv[p];
+    flat[p] = t >= 0 ? gimg[t] : 0.0f;
+}
+// the same reading the per-split partial images directly (single-chunk batches: k_wgrad_reduce + gather in one launch)
+__global__ void k_grad_gather_partials(const float* __restrict__ partial, int split, int64_t n_img, const int32_t* __restrict__ inv,
+                                       int64_t n_params, float* __restrict__ flat) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_params) return;
+    const int32_t t = inv[p];
+    float s = 0.0f;
+    if (t >= 0)
+        for (int q = 0; q < split; ++q) s += partial[(int64_t)q * n_img + t];
+    flat[p] = s;
 }
 
 // ---- weight images from the flat parameter vector (PackRec, wf_internal.h)
-__global__ void k_pack(const float* __restrict__ flat, const PackRec* __restrict__ recs, int64_t n, void* __restrict__ image) {
+struct PackBases {
+    void* img[3];   // plain, wave, mfma image
+};
+__global__ void k_pack(const float* __restrict__ flat, const PackRec* __restrict__ recs, int64_t n, const PackBases bases) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const PackRec r = recs[i];
+    PackRec r = recs[i];
+    void* __restrict__ image = bases.img[r.kind >> 8];
+    r.kind &= 0xFF;
     const float v = r.src >= 0 ? (float)(r.scale * (double)flat[r.src]) : (float)r.scale;
     if (r.kind == 0) {
         reinterpret_cast<float*>(image)[r.dst] = v;
@@ -223,8 +241,9 @@ int finish() {
 
 template <int D, int NC>
 int run_wgrad(int n_nets, int64_t n_samples, const float* ws, float* partial, int accumulate, float* grad_img, int64_t net_img_floats,
-              hipStream_t s) {
+              int* split_out, hipStream_t s) {
     using R = Rows<D>;
+    if (split_out) *split_out = 0;
     if (n_nets == 0 || n_samples == 0) return WF_OK;
     // forward-image layout of one net: W0 [D][64], b0 [64], W1t [64 out][64 in], b1 [64], W2t [D*NBP][64], b2 [D*NBP]
     const int oW0 = 0, ob0 = D * H, oW1 = ob0 + H, ob1 = oW1 + H * H, oW2 = ob1 + H, ob2 = oW2 + D * NBP * H;
@@ -238,6 +257,10 @@ int run_wgrad(int n_nets, int64_t n_samples, const float* ws, float* partial, in
     if (split < 1) split = 1;
     hipLaunchKernelGGL((k_wgrad<NC>), dim3((unsigned)split, (unsigned)(3 * n_ntiles), (unsigned)n_nets), dim3(256), 0, s, ws, n_nets, n_samples,
                        R::N, jobs, n_ntiles, partial, net_img_floats);
+    if (split_out) {   // the caller sums the partial images itself (launch_grad_gather_partials)
+        *split_out = split;
+        return finish();
+    }
     const int64_t n_img = (int64_t)n_nets * net_img_floats;
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((n_img + 255) / 256)), dim3(256), 0, s, (const float*)partial, split, n_img, accumulate,
                        grad_img);
@@ -252,11 +275,12 @@ int grad_ws_rows(int D) { return 8 + 4 * H + D * NBP; }
 int wgrad_partial_floats(int n_nets, int64_t net_img_floats) { return kWgradSplit * n_nets * (int)net_img_floats; }
 
 // partial: wgrad_partial_floats scratch; accumulate != 0 adds to grad_img (further chunks of a batch) instead of overwriting it
+// split_out != NULL: leave the partial images unreduced and report how many there are
 int launch_wgrad(int D, int second_order, int n_nets, int64_t n_samples, const float* ws, float* partial, int accumulate, float* grad_img,
-                 int64_t net_img_floats, void* stream) {
+                 int64_t net_img_floats, int* split_out, void* stream) {
     hipStream_t s = (hipStream_t)stream;
-#define CALL(DD) return second_order ? run_wgrad<DD, 3>(n_nets, n_samples, ws, partial, accumulate, grad_img, net_img_floats, s) \
-                                     : run_wgrad<DD, 1>(n_nets, n_samples, ws, partial, accumulate, grad_img, net_img_floats, s)
+#define CALL(DD) return second_order ? run_wgrad<DD, 3>(n_nets, n_samples, ws, partial, accumulate, grad_img, net_img_floats, split_out, s) \
+                                     : run_wgrad<DD, 1>(n_nets, n_samples, ws, partial, accumulate, grad_img, net_img_floats, split_out, s)
     switch (D) {
         case 2: CALL(2);
         case 3: CALL(3);
@@ -270,8 +294,11 @@ int launch_wgrad(int D, int second_order, int n_nets, int64_t n_samples, const f
 #undef CALL
 }
 
-int launch_pack(const float* flat_dev, const PackRec* recs, int64_t n, void* image_base, void* stream) {
-    hipLaunchKernelGGL(k_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, flat_dev, recs, n, image_base);
+int launch_pack(const float* flat_dev, const PackRec* recs, int64_t n, void* plain, void* wave, void* mfma, void* stream) {
+    if (n <= 0) return WF_OK;
+    PackBases b;
+    b.img[0] = plain; b.img[1] = wave; b.img[2] = mfma;
+    hipLaunchKernelGGL(k_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, flat_dev, recs, n, b);
     return finish();
 }
 
@@ -289,8 +316,15 @@ int launch_step_end(const double* sums, double* ring, int ring_len, unsigned lon
     return finish();
 }
 
-int launch_grad_scatter(const float* grad_img, const int32_t* map, int64_t n_img, float* grad_flat, void* stream) {
-    hipLaunchKernelGGL(k_grad_scatter, dim3((unsigned)((n_img + 255) / 256)), dim3(256), 0, (hipStream_t)stream, grad_img, map, n_img, grad_flat);
+int launch_grad_gather(const float* grad_img, const int32_t* inv, int64_t n_params, float* grad_flat, void* stream) {
+    if (n_params <= 0) return WF_OK;
+    hipLaunchKernelGGL(k_grad_gather, dim3((unsigned)((n_params + 255) / 256)), dim3(256), 0, (hipStream_t)stream, grad_img, inv, n_params, grad_flat);
+    return finish();
+}
+int launch_grad_gather_partials(const float* partial, int split, int64_t n_img, const int32_t* inv, int64_t n_params, float* grad_flat, void* stream) {
+    if (n_params <= 0) return WF_OK;
+    hipLaunchKernelGGL(k_grad_gather_partials, dim3((unsigned)((n_params + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partial, split, n_img,
+                       inv, n_params, grad_flat);
     return finish();
 }
 

@@ -51,7 +51,9 @@ __device__ __forceinline__ void block_reduce2(double& a, double& b, double* sm) 
     b = sm[kSumBlock];
 }
 
-__global__ __launch_bounds__(kSumBlock) void k_sums_stage1(const float* __restrict__ v, int64_t B, double* __restrict__ partial) {
+// final != NULL (single-block launch): the block's sums are the result, stage 2 is skipped
+__global__ __launch_bounds__(kSumBlock) void k_sums_stage1(const float* __restrict__ v, int64_t B, double* __restrict__ partial,
+                                                           double* __restrict__ final) {
     __shared__ double sm[2 * kSumBlock];
     double s = 0.0, q = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * kSumBlock + threadIdx.x; i < B; i += (int64_t)gridDim.x * kSumBlock) {
@@ -61,8 +63,14 @@ __global__ __launch_bounds__(kSumBlock) void k_sums_stage1(const float* __restri
     }
     block_reduce2(s, q, sm);
     if (threadIdx.x == 0) {
-        partial[2 * blockIdx.x] = s;
-        partial[2 * blockIdx.x + 1] = q;
+        if (final) {
+            final[0] = s;
+            final[1] = q;
+            final[2] = (double)B;
+        } else {
+            partial[2 * blockIdx.x] = s;
+            partial[2 * blockIdx.x + 1] = q;
+        }
     }
 }
 
@@ -163,7 +171,11 @@ int launch_block_sums(const float* v, int64_t B, double* out, void* ws, int64_t,
     hipStream_t s = (hipStream_t)stream;
     const int nb = sums_blocks(B);
     double* partial = (double*)ws;
-    hipLaunchKernelGGL(k_sums_stage1, dim3(nb), dim3(kSumBlock), 0, s, v, B, partial);
+    if (nb == 1) {   // small batches (a training step's 128..256 local energies): one launch
+        hipLaunchKernelGGL(k_sums_stage1, dim3(1), dim3(kSumBlock), 0, s, v, B, partial, out);
+        return finish_launch();
+    }
+    hipLaunchKernelGGL(k_sums_stage1, dim3(nb), dim3(kSumBlock), 0, s, v, B, partial, (double*)nullptr);
     hipLaunchKernelGGL(k_sums_stage2, dim3(1), dim3(kSumBlock), 0, s, (const double*)partial, nb, B, out);
     return finish_launch();
 }

@@ -506,6 +506,46 @@ __global__ void k_tail_out(const float* __restrict__ tails, int64_t B, int mode,
     }
 }
 
+// ---- the same, continued to the weights of loss_fn_efficient's tangent rule (k_vqmc_seeds, wf_kernels_grad.hip): the fused
+// training step needs neither H psi nor psi in memory
+template <int D>
+__global__ void k_energy_seeds(const float* __restrict__ tails, const float* __restrict__ xg, int64_t B, unsigned constrained_mask, const Protons pr,
+                               float running_avg, const float* __restrict__ running_avg_dev, float inv_count, float* __restrict__ e_loc,
+                               float* __restrict__ w_psi, float* __restrict__ w_lap) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    if (running_avg_dev) running_avg = *running_avg_dev;
+    float lap = 0.0f, ps = 0.0f;
+#pragma unroll
+    for (int dir = 0; dir < D; ++dir) {
+        R3 v[D], E;
+        const R3 p3 = psi_from_tail<D, R3>(tails + (b * D + dir) * (int64_t)Tail<D>::N * 3, constrained_mask, v, E);
+        lap += 2.0f * p3.c2;
+        ps = p3.c0;
+    }
+    float V = 0.0f;   // physics.py:60-76
+    for (int p = 0; p < pr.n; ++p)
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const float r = pr.pos[p] - xg[b * D + d];
+            V -= 1.0f / sqrtf(1.0f + r * r);
+        }
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int k = 0; k < i; ++k) {
+            const float r = xg[b * D + i] - xg[b * D + k];
+            V += 1.0f / sqrtf(1.0f + r * r);
+        }
+    const float hp = -0.5f * lap + V * ps;
+    const float el = hp / (ps + 1e-8f);
+    const float a = 2.0f * (el - running_avg) / ps - hp / (ps * ps);
+    const float c = 1.0f / ps;
+    e_loc[b] = el;
+    w_psi[b] = (a + c * V) * inv_count;
+    w_lap[b] = -0.5f * c * inv_count;
+}
+
 // ------------------------------------------------------------------------------------------------ reverse
 // pre-activation adjoints of one conditioner from hbar2 (this lane's hidden unit); adds the W0 path to gU
 template <int D, class T>
@@ -1025,6 +1065,26 @@ int launch_energy_out(int D, const float* tails, const float* x, int64_t B, unsi
         case 8: hipLaunchKernelGGL(k_energy_out<8>, grid, block, 0, s, tails, x, B, constrained_mask, pr, hpsi, psi, lap); break;
         default: return WF_ERR_UNSUPPORTED;
     }
+    return finish();
+}
+
+int launch_energy_seeds(int D, const float* tails, const float* x, int64_t B, unsigned constrained_mask, const Protons& pr, float running_avg,
+                        const float* running_avg_dev, float inv_count, float* e_loc, float* w_psi, float* w_lap, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)((B + 255) / 256)), block(256);
+#define CALL(DD) hipLaunchKernelGGL(k_energy_seeds<DD>, grid, block, 0, s, tails, x, B, constrained_mask, pr, running_avg, running_avg_dev, \
+                                    inv_count, e_loc, w_psi, w_lap); break
+    switch (D) {
+        case 2: CALL(2);
+        case 3: CALL(3);
+        case 4: CALL(4);
+        case 5: CALL(5);
+        case 6: CALL(6);
+        case 7: CALL(7);
+        case 8: CALL(8);
+        default: return WF_ERR_UNSUPPORTED;
+    }
+#undef CALL
     return finish();
 }
 

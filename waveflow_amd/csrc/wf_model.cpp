@@ -87,15 +87,15 @@ struct wf_model {
     const float* d_tabI4 = nullptr;  // [4][n_mesh][32]: I-spline derivative orders 0..3 (local energy)
     const float* d_tabP3 = nullptr;  // [4][n_mesh][32]: orthogonal-B derivative orders 0..3 (the energy uses 0..2)
     float* d_flat = nullptr;         // device copy of the flat parameter vector (source of every weight image)
-    wf::PackRec* d_pack[3] = {nullptr, nullptr, nullptr};   // image descriptions: plain, wave, mfma
-    int64_t n_pack[3] = {0, 0, 0};
+    wf::PackRec* d_pack = nullptr;   // descriptions of every entry of the plain, wave and mfma images
+    int64_t n_pack = 0;
     float* d_scratch = nullptr;      // private scratch of wf_hamiltonian_fwd (grown on demand)
     int64_t scratch_floats = 0;
     float* d_wave = nullptr;         // NetWave images (nbp == 32 only)
     float* d_grad_fk = nullptr;      // [2][64] natural-order row factors for the reverse pass (flow rows, prior rows)
     bool wave_ok = false;            // the wave-cooperative kernels cover this model (<= 32 bases, zero-only constraints)
     bool grad_psi_ok = false;        // wf_psi_vjp (Waveflow prior, IMADE layers)
-    int32_t* d_grad_map = nullptr;   // [n_nets * fwd image floats]: flat parameter index of each forward-image entry, -1 = none
+    int32_t* d_grad_map = nullptr;   // [n_params]: forward-image entry (over all nets) that holds each parameter, -1 = none
     float* d_grad_partial = nullptr; // per-split partial gradient images of k_wgrad
     float* d_grad_img = nullptr;     // [n_nets * fwd image floats]: gradient accumulator in forward-image layout
 };
@@ -718,13 +718,19 @@ static int pack_prepare(wf_model* m, std::vector<PackRec>& plain) {
         if (m->d_wave) describe_wave_image(m, n, (uint32_t)(wave_net_floats(D) * n), wave);
         if (m->mfma_ok) describe_mfma_image(m, n, (uint32_t)((int64_t)m->mdev.net_floats * n), mfma);
     }
+    std::vector<PackRec> all;
+    all.reserve(plain.size() + wave.size() + mfma.size());
     std::vector<PackRec>* lists[3] = {&plain, &wave, &mfma};
-    for (int i = 0; i < 3; ++i) {
-        m->n_pack[i] = (int64_t)lists[i]->size();
-        if (lists[i]->empty()) continue;
-        int rc = dev_alloc(m, &m->d_pack[i], lists[i]->size());
+    for (int i = 0; i < 3; ++i)
+        for (PackRec r : *lists[i]) {
+            r.kind |= i << 8;
+            all.push_back(r);
+        }
+    m->n_pack = (int64_t)all.size();
+    if (!all.empty()) {
+        int rc = dev_alloc(m, &m->d_pack, all.size());
         if (rc) return rc;
-        WF_HIP(hipMemcpy(m->d_pack[i], lists[i]->data(), lists[i]->size() * sizeof(PackRec), hipMemcpyHostToDevice));
+        WF_HIP(hipMemcpy(m->d_pack, all.data(), all.size() * sizeof(PackRec), hipMemcpyHostToDevice));
     }
     return dev_alloc(m, &m->d_flat, (size_t)std::max<int64_t>(m->n_params, 1));
 }
@@ -757,9 +763,13 @@ static int grad_prepare(wf_model* m) {
     const int64_t per_net = plain_net_floats(D, m->nbp);
     for (int n = 0; n < n_nets; ++n)
         for (int64_t i = 0; i < fwd; ++i) map[(size_t)(fwd * n + i)] = plain[(size_t)(per_net * n + i)].src;
-    int rc = dev_alloc(m, &m->d_grad_map, map.size());
+    // inverse: parameter -> its (unique) forward-image entry, -1 for parameters that reach none
+    std::vector<int32_t> inv((size_t)std::max<int64_t>(m->n_params, 1), -1);
+    for (size_t i = 0; i < map.size(); ++i)
+        if (map[i] >= 0) inv[(size_t)map[i]] = (int32_t)i;
+    int rc = dev_alloc(m, &m->d_grad_map, inv.size());
     if (rc) return rc;
-    WF_HIP(hipMemcpy(m->d_grad_map, map.data(), map.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    WF_HIP(hipMemcpy(m->d_grad_map, inv.data(), inv.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     rc = dev_alloc(m, &m->d_grad_partial, (size_t)wgrad_partial_floats(n_nets, fwd));
     if (rc) return rc;
     return dev_alloc(m, &m->d_grad_img, map.size());
@@ -871,10 +881,8 @@ int wf_model_set_kernel(wf_model* m, int kernel_kind) {
 
 // fills every weight image from the device-resident flat vector m->d_flat (asynchronous on `stream`)
 static int apply_params(wf_model* m, void* stream) {
-    void* bases[3] = {m->d_plain, m->d_wave, m->d_mfma};
-    for (int i = 0; i < 3; ++i) {
-        if (!m->n_pack[i]) continue;
-        int rc = launch_pack(m->d_flat, m->d_pack[i], m->n_pack[i], bases[i], stream);
+    {
+        int rc = launch_pack(m->d_flat, m->d_pack, m->n_pack, m->d_plain, m->d_wave, m->d_mfma, stream);
         if (rc) return rc;
     }
     if (m->mfma_ok) {
@@ -1086,8 +1094,12 @@ static int run_vjp_chunks(const wf_model* m, int mode, bool second_order, const 
     float* tape = (float*)workspace_dev;
     float* tails = tape + chunk * samples_per * n_nets * grad_ws_rows(D) * nc;
     float* per_walker = tails + chunk * wave_tail_floats(D, second_order ? 1 : 0);   // [4][chunk]
-    WF_HIP(hipMemsetAsync(m->d_grad_img, 0, (size_t)n_img * sizeof(float), s));   // (B == 0: the gradient is zero)
-    WF_HIP(hipMemsetAsync(grad_dev, 0, (size_t)m->n_params * sizeof(float), s));
+    if (B == 0) {   // the gradient of an empty batch is zero
+        WF_HIP(hipMemsetAsync(grad_dev, 0, (size_t)m->n_params * sizeof(float), s));
+        return WF_OK;
+    }
+    const bool single = B <= chunk;   // one chunk: the partial images are summed by the gather itself (one launch less)
+    int split = 0;
     for (int64_t c0 = 0; c0 < B; c0 += chunk) {
         const int64_t bc = std::min(chunk, B - c0);
         const float* x = x_dev + c0 * D;
@@ -1095,10 +1107,9 @@ static int run_vjp_chunks(const wf_model* m, int mode, bool second_order, const 
         if (rc) return rc;
         const float *cw1 = w1 ? w1 + c0 : nullptr, *cw2 = w2 ? w2 + c0 : nullptr;
         if (mode == 2) {
-            float *hpsi = per_walker, *psi = per_walker + chunk, *wp = per_walker + 2 * chunk, *wl = per_walker + 3 * chunk;
-            rc = launch_energy_out(D, tails, x, bc, m->dev.constrained_mask, *pr, hpsi, psi, nullptr, stream);
-            if (rc) return rc;
-            rc = launch_vqmc_seeds(x, bc, D, *pr, hpsi, psi, running_average, inv_count, e_loc_dev + c0, wp, wl, running_average_dev, stream);
+            float *wp = per_walker + 2 * chunk, *wl = per_walker + 3 * chunk;
+            rc = launch_energy_seeds(D, tails, x, bc, m->dev.constrained_mask, *pr, running_average, running_average_dev, inv_count,
+                                     e_loc_dev + c0, wp, wl, stream);
             if (rc) return rc;
             cw1 = wp;
             cw2 = wl;
@@ -1106,10 +1117,12 @@ static int run_vjp_chunks(const wf_model* m, int mode, bool second_order, const 
         rc = launch_wave_bwd(m->dev, m->d_dev, mode == 0 ? 0 : 1, second_order ? 1 : 0, m->d_tabI4, m->d_tabP3, m->d_grad_fk, bc, cw1, cw2, tape,
                              tails, stream);
         if (rc) return rc;
-        rc = launch_wgrad(D, second_order ? 1 : 0, n_nets, bc * samples_per, tape, m->d_grad_partial, c0 > 0, m->d_grad_img, fwd, stream);
+        rc = launch_wgrad(D, second_order ? 1 : 0, n_nets, bc * samples_per, tape, m->d_grad_partial, c0 > 0, m->d_grad_img, fwd,
+                          single ? &split : nullptr, stream);
         if (rc) return rc;
     }
-    return launch_grad_scatter(m->d_grad_img, m->d_grad_map, n_img, grad_dev, stream);
+    if (single) return launch_grad_gather_partials(m->d_grad_partial, split, n_img, m->d_grad_map, m->n_params, grad_dev, stream);
+    return launch_grad_gather(m->d_grad_img, m->d_grad_map, m->n_params, grad_dev, stream);
 }
 
 int64_t wf_psi_vjp_workspace_bytes(const wf_model* m, int64_t B) { return vjp_ws_bytes(m, B, true); }
