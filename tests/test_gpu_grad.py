@@ -406,3 +406,35 @@ def test_abi_error_paths_of_the_gradient_entry_points(he_flat):
     assert np.isfinite(lp3(p3, xs.cpu().numpy())).all()
     with pytest.raises(_lib.WfError):
         lp3.model.logpdf_vjp(xs, w)
+
+
+def test_model_without_flow_layers(he_flat):
+    """get_waveflow_model(input_dim, n_flow_layers=0) -- the configuration of the reference's tests/test_boundary_constraints.py:
+    box transform + prior only.  psi, log_pdf, H psi and the gradients vs the torch oracle; sampler round trip."""
+    import torch
+    from oracle import energy_torch as et
+    from waveflow_amd import flatten_params, model_factory
+    init_fun = model_factory.get_waveflow_model(2, n_flow_layers=0)          # reference defaults: k = 5, 16 knots, box_size 1
+    params, psi, log_pdf, sample = init_fun(3, 2)
+    flat = flatten_params(params)
+    mo = et.TorchWaveflow(2, 0, "mean", 1.0, 5, 16, 0.0, (0,), dtype=torch.float64)
+    g = np.linspace(0.01, 0.99, 20)
+    x = np.sort(np.stack([g * 1.6 - 0.8, g[::-1] * 0.9 - 0.1], -1), -1).astype(np.float32)
+    for kernel in ("scalar", "mfma", "wave"):
+        try:
+            psi.model.set_kernel(kernel)
+        except Exception:
+            continue
+        np.testing.assert_allclose(psi(params, x), mo.psi(flat, torch.as_tensor(x, dtype=torch.float64)).numpy(), rtol=2e-4, atol=2e-6)
+        np.testing.assert_allclose(log_pdf(params, x), mo.log_pdf(flat, torch.as_tensor(x, dtype=torch.float64)).numpy(), rtol=0, atol=2e-3)
+    psi.model.set_kernel("auto")
+    hp, ps, lap = psi.model.hamiltonian(x, [0.0], return_psi=True, return_laplacian=True)
+    ho, po, lo = et.hamiltonian(mo, flat, x.astype(np.float64), [0.0])
+    np.testing.assert_allclose(lap, lo, rtol=0, atol=2e-3 * np.abs(lo).max())
+    w = np.ones(20, np.float32)
+    got = psi.model.psi_vjp(x, w, 0.1 * w).cpu().numpy().astype(np.float64)
+    want = et.psi_vjp(mo, flat, x.astype(np.float64), w, 0.1 * w)
+    assert rel_l2(got, want) < 3e-3
+    s, lat = sample(5, params, 200, return_original_samples=True, exact_inverse=True)
+    lp, u = log_pdf(params, s, return_sample=True)
+    assert (u - lat).abs().max().item() < 1e-4 and bool(torch.isfinite(lp).all())

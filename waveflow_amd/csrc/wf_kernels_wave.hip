@@ -309,7 +309,7 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(WF_WAVE_OCC
     const bool imade = md.layer_kind == WF_LAYER_IMADE;
     const bool has_pnet = md.prior_kind == WF_PRIOR_WAVEFLOW || md.prior_kind == WF_PRIOR_MFLOW;
     const int n_nets = md.n_layers + (has_pnet ? 1 : 0);
-    const int n_mesh = imade ? md.isp.n_mesh : md.psp.n_mesh;
+    const int n_mesh = (imade && md.n_layers > 0) ? md.isp.n_mesh : md.psp.n_mesh;   // (a model may have no flow layer at all)
     const size_t plane = (size_t)n_mesh * NBP;
     const float* __restrict__ gI = fk_nat;
     const float* __restrict__ kP = fk_nat + 64;
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(WF_WAVE_OCC
     const bool imade = md.layer_kind == WF_LAYER_IMADE;
     const bool has_pnet = md.prior_kind == WF_PRIOR_WAVEFLOW || md.prior_kind == WF_PRIOR_MFLOW;
     const int n_nets = md.n_layers + (has_pnet ? 1 : 0);
-    const int n_mesh = imade ? md.isp.n_mesh : md.psp.n_mesh;
+    const int n_mesh = (imade && md.n_layers > 0) ? md.isp.n_mesh : md.psp.n_mesh;   // (a model may have no flow layer at all)
     const size_t plane = (size_t)n_mesh * NBP;
     const float* __restrict__ gI = fk_nat;
     const float* __restrict__ kP = fk_nat + 64;

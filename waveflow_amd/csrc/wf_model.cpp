@@ -755,7 +755,7 @@ static int grad_prepare(wf_model* m) {
         WF_HIP(hipMemcpy(m->d_grad_fk, fk.data(), fk.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     if (!grad_capable(m) || m->n_params >= (1 << 24)) return WF_OK;
-    m->grad_psi_ok = d.prior_kind == WF_PRIOR_WAVEFLOW && d.layer_kind == WF_LAYER_IMADE && d.n_flow_layers > 0;
+    m->grad_psi_ok = d.prior_kind == WF_PRIOR_WAVEFLOW && (d.layer_kind == WF_LAYER_IMADE || d.n_flow_layers == 0);
     const int n_nets = (int)m->nets.size();
     const int64_t fwd = plain_fwd_floats(D, m->nbp);
     // the plain description lists net n's forward-orientation entries first (plain_net_floats per net)
@@ -939,7 +939,7 @@ static int dispatch(const wf_model* m, int mode, const float* x, int64_t B, floa
     // which first stages its weight images into LDS, takes 38-42 us whatever the batch; from ~7000 walkers on the MFMA
     // kernel's throughput wins (4096: 30 vs 42 us, 8192: 46 vs 42 us).  The wave kernel does
     // not report bin indices.
-    const bool wave_fits = m->wave_ok && !idx && m->desc.n_flow_layers > 0;
+    const bool wave_fits = m->wave_ok && !idx;
     const bool use_wave = wave_fits && (m->kernel_kind == WF_KERNEL_WAVE || (m->kernel_kind == WF_KERNEL_AUTO && B <= kWaveEvalMax));
     if (m->kernel_kind == WF_KERNEL_WAVE && !use_wave) return WF_ERR_UNSUPPORTED;
     if (use_wave) {
@@ -1044,7 +1044,8 @@ int wf_hamiltonian_fwd(const wf_model* m, const float* x_dev, int64_t B, const f
     if (rc) return rc;
     if (n_protons < 0 || n_protons > 8 || (n_protons > 0 && !protons_host)) return WF_ERR_INVALID;
     if (m->desc.prior_kind != WF_PRIOR_WAVEFLOW) return WF_ERR_INVALID;
-    if (m->desc.layer_kind != WF_LAYER_IMADE || !m->d_tabI4 || !m->d_tabP3 || !m->d_grad_fk) return WF_ERR_UNSUPPORTED;
+    if (!m->wave_ok || !m->d_tabP3 || !m->d_grad_fk) return WF_ERR_UNSUPPORTED;
+    if (m->desc.n_flow_layers > 0 && m->desc.layer_kind != WF_LAYER_IMADE) return WF_ERR_UNSUPPORTED;
     Protons pr{};
     pr.n = n_protons;
     for (int i = 0; i < n_protons; ++i) pr.pos[i] = protons_host[i];
