@@ -252,6 +252,17 @@ int wf_rqs_fwd(const float* x_dev, const float* uw_dev, const float* uh_dev, con
                int32_t n_deriv, int32_t inverse, float left, float right, float bottom, float top, float* y_dev,
                float* logabsdet_dev, int32_t* bin_dev, void* stream);
 
+/* NeuralSplineCoupling.direct_fun / inverse_fun (flows/bijections/neural_splines.py:244-300): x[B][dim] (dim even) ->
+ * y[B][dim], logdet[B].  Two half-steps, each: FCNN (Dense(hidden) Tanh Dense(hidden) Tanh Dense((3K-1) dim/2), :187-188) on one
+ * half -> per coordinate K widths and K heights (softmax * 2 tail_bound) and K-1 derivatives (softplus) -> unconstrained_RQS of
+ * the other half with those values as its unnormalised parameters (the reference's double normalisation is kept).
+ * params_dev: f1 then f2, each W1 [dim/2][hidden], b1, W2 [hidden][hidden], b2, W3 [hidden][(3K-1) dim/2], b3 (stax.Dense leaf
+ * order).  The layer is dead code in the reference (only its invertibility is exercised, tests/test_bijections.py:138): parity
+ * unpinned.  hidden <= 64, K <= 32. */
+int64_t wf_nsc_workspace_bytes(int64_t B, int32_t dim, int32_t K);
+int wf_nsc_fwd(const float* x_dev, int64_t B, int32_t dim, int32_t K, float tail_bound, int32_t hidden, const float* params_dev, int32_t inverse,
+               float* y_dev, float* logdet_dev, void* workspace_dev, int64_t workspace_bytes, void* stream);
+
 /* Local block sums for the VQMC expectation (vqmc.py:196: the batch mean is the only reduction over
  * walkers): out_dev[3] (fp64) = { sum v, sum v^2, count } over v[B]; deterministic (fixed-order) reduction.
  * The caller all-reduces these three doubles across ranks (RCCL) -- see waveflow_amd/distributed.py. */

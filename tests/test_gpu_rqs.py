@@ -71,3 +71,65 @@ def test_rqs_torch_tensors_and_errors():
     L = _lib.lib()
     assert L.wf_rqs_fwd(None, None, None, None, 0, 2000, 1999, 0, 0.0, 1.0, 0.0, 1.0, None, None, None, None) == -1   # K too large
     assert L.wf_rqs_fwd(None, None, None, None, 10, 8, 7, 0, 0.0, 1.0, 0.0, 1.0, None, None, None, None) == -1       # null buffers
+
+
+def _nsc_oracle(params, x, K, tail, inverse):
+    """NumPy restatement of NeuralSplineCoupling (neural_splines.py:244-300) on top of the C oracle's RQS (oracle.rqs_batch)."""
+    import oracle
+
+    def fcnn(p, v):
+        (W1, b1), _, (W2, b2), _, (W3, b3) = p
+        h = np.tanh(v.astype(np.float64) @ W1 + b1)
+        h = np.tanh(h @ W2 + b2)
+        return h @ W3 + b3
+
+    def half(p, cond, trans):
+        dh = cond.shape[1]
+        out = fcnn(p, cond).reshape(-1, dh, 3 * K - 1)
+        W, H, D = out[..., :K], out[..., K:2 * K], out[..., 2 * K:]
+        sm = lambda a: np.exp(a - a.max(-1, keepdims=True)) / np.exp(a - a.max(-1, keepdims=True)).sum(-1, keepdims=True)
+        W, H = 2 * tail * sm(W), 2 * tail * sm(H)
+        D = np.log1p(np.exp(D))
+        y, ld, _ = oracle.rqs_batch(trans.reshape(-1).astype(np.float32), W.reshape(-1, K).astype(np.float32), H.reshape(-1, K).astype(np.float32),
+                                 D.reshape(-1, K - 1).astype(np.float32), inverse=inverse, left=-tail, right=tail, bottom=-tail, top=tail)
+        return y.reshape(trans.shape), ld.reshape(trans.shape).sum(1)
+
+    dh = x.shape[1] // 2
+    lower, upper = x[:, :dh], x[:, dh:]
+    f1, f2 = params
+    if not inverse:
+        upper, l1 = half(f1, lower, upper)
+        lower, l2 = half(f2, upper, lower)
+    else:
+        lower, l1 = half(f2, upper, lower)
+        upper, l2 = half(f1, lower, upper)
+    return np.concatenate([lower, upper], 1), l1 + l2
+
+
+@pytest.mark.parametrize("dim,K,hidden", [(2, 5, 8), (4, 8, 8), (6, 5, 16)])
+def test_neural_spline_coupling_layer(dim, K, hidden):
+    """flows.NeuralSplineCoupling (the reference's tests/test_bijections.py:138 checks invertibility only): vs the NumPy / C
+    restatement, inverse(direct(x)) = x, log-dets cancel."""
+    from waveflow_amd import flows
+    g = np.random.default_rng(dim)
+    init_fun = flows.NeuralSplineCoupling(K=K, B=3, hidden_dim=hidden)
+    params, direct_fun, inverse_fun = init_fun(11, dim)
+    # the initial Dense weights are tiny: scale them so that the splines are far from the identity
+    params = tuple([tuple(a * (1.5 if a.ndim == 2 else 3e4) for a in l) if l else () for l in net] for net in params)
+    x = g.uniform(-3.5, 3.5, size=(4097, dim)).astype(np.float32)     # some points outside the +-3 tails (identity there)
+    y, ld = direct_fun(params, x)
+    yo, ldo = _nsc_oracle(params, x, K, 3.0, False)
+    # (the restatement runs the conditioner in fp64, the kernel in fp32)
+    assert np.abs(y - yo).max() < 5e-3 and np.quantile(np.abs(y - yo), 0.999) < 5e-4 and np.abs(ld - ldo).max() < 2e-2
+    assert np.median(np.abs(y - yo)) < 2e-6
+    assert np.abs(y - x).max() > 0.1                                   # it does transform
+    xb, ldb = inverse_fun(params, y)
+    # the inverse amplifies fp32 rounding by 1 / (local slope): judge the round trip by quantiles, and per point by the slope
+    err = np.abs(xb - x).max(1)
+    assert np.median(err) < 3e-4 and np.quantile(err, 0.9) < 1e-2
+    assert np.median(np.abs(ld + ldb)) < 1e-3
+    xo, _ = _nsc_oracle(params, y, K, 3.0, True)
+    assert np.median(np.abs(xb - xo)) < 3e-4 and np.quantile(np.abs(xb - xo), 0.9) < 1e-2
+    import torch
+    yt, ldt = direct_fun(params, torch.as_tensor(x).cuda())
+    assert torch.is_tensor(yt) and np.array_equal(yt.cpu().numpy(), y)

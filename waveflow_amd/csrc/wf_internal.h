@@ -168,6 +168,9 @@ int launch_vqmc_seeds(const float* x, int64_t B, int D, const Protons& pr, const
                       float inv_count, float* e_loc, float* w_psi, float* w_lap, const float* running_avg_dev, void* stream);
 int launch_rqs(const float* x, const float* uw, const float* uh, const float* ud, int64_t N, int K, int n_deriv, int inverse,
                float left, float right, float bottom, float top, float* y, float* ld, int32_t* bin, void* stream);
+int64_t nsc_workspace_floats(int64_t B, int dim, int K);
+int launch_nsc(const float* x, int64_t B, int dim, int K, float tail, int hidden, const float* params, int inverse, float* y, float* logdet,
+               float* ws, void* stream);
 int launch_block_sums(const float* v, int64_t B, double* out, void* ws, int64_t ws_bytes, void* stream);
 int64_t block_sums_ws_bytes(int64_t B);
 

@@ -309,6 +309,77 @@ int launch_reg(const float* x, const float* uw, const float* uh, const float* ud
 
 }  // namespace
 
+// ---- NeuralSplineCoupling (neural_splines.py:244-300): conditioner of one half-step.  FCNN (:187-188) = Dense(hidden), Tanh,
+// Dense(hidden), Tanh, Dense((3K-1) * dh) on the conditioning half; its output, per transformed coordinate, is split into
+// K widths, K heights, K-1 derivatives, the first two soft-maxed and scaled by 2B, the last soft-plussed (:255-259) -- and then
+// handed to unconstrained_RQS as *unnormalised* parameters, which soft-maxes / soft-plusses them again (the reference's
+// double application is kept).  One lane per walker; the network is tiny (hidden 8), its weights are scalar loads.
+// params: W1 [din][h], b1 [h], W2 [h][h], b2 [h], W3 [h][(3K-1)*dh], b3 [(3K-1)*dh]  (stax.Dense leaf order)
+constexpr int kNscMaxHidden = 64;
+__global__ __launch_bounds__(256) void k_nsc_cond(const float* __restrict__ xg, int64_t B, int dim, int cond_off, int trans_off, int dh, int K,
+                                                  float tail, int hidden, const float* __restrict__ params, const float* __restrict__ cond_src,
+                                                  float* __restrict__ uw, float* __restrict__ uh, float* __restrict__ ud, float* __restrict__ xt) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int per = 3 * K - 1, dout = per * dh;
+    const float* W1 = params;
+    const float* b1 = W1 + dh * hidden;
+    const float* W2 = b1 + hidden;
+    const float* b2 = W2 + hidden * hidden;
+    const float* W3 = b2 + hidden;
+    const float* b3 = W3 + hidden * dout;
+    float h1[kNscMaxHidden], h2[kNscMaxHidden];
+    // the conditioning half: columns of x, or (second half-step) the half just transformed
+    for (int j = 0; j < hidden; ++j) {
+        float z = b1[j];
+        for (int a = 0; a < dh; ++a) {
+            const float v = cond_src ? cond_src[b * dh + a] : xg[b * dim + cond_off + a];
+            z = __builtin_fmaf(v, W1[a * hidden + j], z);
+        }
+        h1[j] = tanhf(z);
+    }
+    for (int j = 0; j < hidden; ++j) {
+        float z = b2[j];
+        for (int a = 0; a < hidden; ++a) z = __builtin_fmaf(h1[a], W2[a * hidden + j], z);
+        h2[j] = tanhf(z);
+    }
+    for (int d = 0; d < dh; ++d) {
+        const int64_t e = b * dh + d;
+        float o[96];   // per <= 3 * 32 - 1
+        for (int c = 0; c < per; ++c) {
+            float z = b3[d * per + c];
+            for (int a = 0; a < hidden; ++a) z = __builtin_fmaf(h2[a], W3[a * dout + d * per + c], z);
+            o[c] = z;
+        }
+        // onp.array_split(out, 3, axis=2): sizes K, K, K-1
+        for (int part = 0; part < 2; ++part) {
+            float mx = o[part * K];
+            for (int c = 1; c < K; ++c) mx = fmaxf(mx, o[part * K + c]);
+            float sum = 0.0f;
+            for (int c = 0; c < K; ++c) sum += expf(o[part * K + c] - mx);
+            float* dst = (part == 0 ? uw : uh) + e * K;
+            for (int c = 0; c < K; ++c) dst[c] = 2.0f * tail * (expf(o[part * K + c] - mx) / sum);
+        }
+        for (int c = 0; c < K - 1; ++c) ud[e * (K - 1) + c] = softplus(o[2 * K + c]);
+        xt[e] = xg[b * dim + trans_off + d];
+    }
+}
+
+// y = [lower', upper'], logdet = sum of the per-coordinate log-dets of both half-steps
+__global__ void k_nsc_finish(int64_t B, int dim, int dh, const float* __restrict__ lower, const float* __restrict__ upper,
+                             const float* __restrict__ ld_a, const float* __restrict__ ld_b, float* __restrict__ y, float* __restrict__ logdet) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float s = 0.0f;
+    for (int d = 0; d < dh; ++d) {
+        y[b * dim + d] = lower[b * dh + d];
+        y[b * dim + dh + d] = upper[b * dh + d];
+        s += ld_a[b * dh + d];
+    }
+    for (int d = 0; d < dh; ++d) s += ld_b[b * dh + d];
+    logdet[b] = s;
+}
+
 int launch_rqs(const float* x, const float* uw, const float* uh, const float* ud, int64_t N, int K, int n_deriv, int inverse, float left,
                float right, float bottom, float top, float* y, float* ld, int32_t* bin, void* stream) {
     if (N == 0) return WF_OK;
@@ -336,6 +407,52 @@ int launch_rqs(const float* x, const float* uw, const float* uh, const float* ud
                        left, right, bottom, top, y, ld, bin);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_hip_error((int)e); return WF_ERR_HIP; }
+    return WF_OK;
+}
+
+int64_t nsc_workspace_floats(int64_t B, int dim, int K) {
+    const int64_t E = B * (dim / 2);
+    return E * (3 * K - 1) + 5 * E + 64;   // uw, uh, ud rows; the half being transformed; both results; two log-det vectors
+}
+
+// direct (inverse == 0): upper' = RQS(upper | f1(lower)); lower' = RQS(lower | f2(upper'))   (neural_splines.py:254-271)
+// inverse:               lower' = RQS^-1(lower | f2(upper)); upper' = RQS^-1(upper | f1(lower'))   (:273-292)
+int launch_nsc(const float* x, int64_t B, int dim, int K, float tail, int hidden, const float* params, int inverse, float* y, float* logdet,
+               float* ws, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (B == 0) return WF_OK;
+    const int dh = dim / 2;
+    const int64_t E = B * dh;
+    const int64_t net_floats = (int64_t)dh * hidden + hidden + (int64_t)hidden * hidden + hidden + (int64_t)hidden * (3 * K - 1) * dh + (3 * K - 1) * dh;
+    const float *f1 = params, *f2 = params + net_floats;
+    float* uw = ws;
+    float* uh = uw + E * K;
+    float* ud = uh + E * K;
+    float* xt = ud + E * (K - 1);      // the half being transformed, contiguous
+    float* ha = xt + E;                // result of the first half-step
+    float* hb = ha + E;                // result of the second half-step
+    float* lda = hb + E;
+    float* ldb = lda + E;
+    // (uw / uh must be 16-byte aligned for the register kernel: E * K floats apart -- launch_rqs falls back otherwise)
+    const dim3 grid((unsigned)((B + 255) / 256)), block(256);
+    const int first_cond = inverse ? dh : 0, first_trans = inverse ? 0 : dh;
+    hipLaunchKernelGGL(k_nsc_cond, grid, block, 0, s, x, B, dim, first_cond, first_trans, dh, K, tail, hidden, inverse ? f2 : f1,
+                       (const float*)nullptr, uw, uh, ud, xt);
+    int rc = launch_rqs(xt, uw, uh, ud, E, K, K - 1, inverse, -tail, tail, -tail, tail, ha, lda, nullptr, stream);
+    if (rc) return rc;
+    // second half-step: conditioned on the half just transformed, transforms the other original half
+    hipLaunchKernelGGL(k_nsc_cond, grid, block, 0, s, x, B, dim, 0, inverse ? dh : 0, dh, K, tail, hidden, inverse ? f1 : f2, (const float*)ha, uw,
+                       uh, ud, xt);
+    rc = launch_rqs(xt, uw, uh, ud, E, K, K - 1, inverse, -tail, tail, -tail, tail, hb, ldb, nullptr, stream);
+    if (rc) return rc;
+    // direct: ha = upper', hb = lower';  inverse: ha = lower', hb = upper'
+    hipLaunchKernelGGL(k_nsc_finish, grid, block, 0, s, B, dim, dh, inverse ? (const float*)ha : (const float*)hb,
+                       inverse ? (const float*)hb : (const float*)ha, (const float*)lda, (const float*)ldb, y, logdet);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_hip_error((int)e);
+        return WF_ERR_HIP;
+    }
     return WF_OK;
 }
 

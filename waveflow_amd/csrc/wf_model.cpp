@@ -1237,6 +1237,22 @@ int wf_rqs_fwd(const float* x_dev, const float* uw_dev, const float* uh_dev, con
     return launch_rqs(x_dev, uw_dev, uh_dev, ud_dev, N, K, n_deriv, inverse, left, right, bottom, top, y_dev, logabsdet_dev, bin_dev, stream);
 }
 
+int64_t wf_nsc_workspace_bytes(int64_t B, int32_t dim, int32_t K) {
+    if (B < 0 || dim < 2 || dim > WF_MAX_DIM || (dim & 1) || K < 2 || K > 32) return WF_ERR_INVALID;
+    return nsc_workspace_floats(B, dim, K) * (int64_t)sizeof(float);
+}
+
+int wf_nsc_fwd(const float* x_dev, int64_t B, int32_t dim, int32_t K, float tail_bound, int32_t hidden, const float* params_dev, int32_t inverse,
+               float* y_dev, float* logdet_dev, void* workspace_dev, int64_t workspace_bytes, void* stream) {
+    if (B < 0 || dim < 2 || dim > WF_MAX_DIM || (dim & 1) || K < 2 || K > 32 || hidden < 1 || hidden > 64 || !(tail_bound > 0.0f)) return WF_ERR_INVALID;
+    if (1e-3f * K > 1.0f) return WF_ERR_INVALID;
+    if (B > 0 && (!x_dev || !params_dev || !y_dev || !logdet_dev || !workspace_dev)) return WF_ERR_INVALID;
+    if (workspace_bytes < wf_nsc_workspace_bytes(B, dim, K)) return WF_ERR_INVALID;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return WF_ERR_NO_DEVICE;
+    return launch_nsc(x_dev, B, dim, K, tail_bound, hidden, params_dev, inverse, y_dev, logdet_dev, (float*)workspace_dev, stream);
+}
+
 int64_t wf_block_sums_workspace_bytes(int64_t B) { return block_sums_ws_bytes(B); }
 
 int wf_block_sums(const float* v_dev, int64_t B, double* out_dev, void* workspace_dev, int64_t workspace_bytes, void* stream) {

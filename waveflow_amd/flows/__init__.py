@@ -17,7 +17,7 @@ import numpy as np
 
 from .. import _lib
 from ..core import DeviceModel, flatten_params
-from .neural_splines import RQS, unconstrained_RQS  # noqa: F401
+from .neural_splines import FCNN, RQS, NeuralSplineCoupling, unconstrained_RQS  # noqa: F401
 
 HIDDEN = 64  # model_factory.py:72
 

@@ -55,3 +55,62 @@ def unconstrained_RQS(inputs, unnormalized_widths, unnormalized_heights, unnorma
         raise ValueError("unconstrained_RQS needs K-1 derivatives")
     return _call(inputs, unnormalized_widths, unnormalized_heights, unnormalized_derivatives, inverse, -tail_bound, tail_bound,
                  -tail_bound, tail_bound, return_bin_idx)
+
+
+def FCNN(out_dim, hidden_dim):
+    """neural_splines.py:187-188: the conditioner architecture (Dense, Tanh, Dense, Tanh, Dense) as a description."""
+    return ("fcnn", int(out_dim), int(hidden_dim))
+
+
+class NeuralSplineCoupling:
+    """neural_splines.py:244-300.  init_fun(rng, dim) -> (params, direct_fun, inverse_fun); params = (f1_params, f2_params) in
+    stax layout [(W, b), (), (W, b), (), (W, b)].  The reference's closures ignore their `params` argument and always use the
+    initial networks (:254, :261); here the argument is honoured."""
+
+    def __init__(self, K=5, B=3, hidden_dim=8, network=FCNN):
+        if network is not FCNN:
+            raise NotImplementedError("NeuralSplineCoupling is built with the reference's FCNN conditioner")
+        self.K, self.B, self.hidden = int(K), float(B), int(hidden_dim)
+
+    def _init_net(self, g, din, dout):
+        h = self.hidden
+        def dense(a, b):   # stax.Dense: glorot normal weights, normal(1e-6) biases
+            return (g.normal(0.0, np.sqrt(2.0 / (a + b)), size=(a, b)).astype(np.float32), g.normal(0.0, 1e-6, size=(b,)).astype(np.float32))
+        return [dense(din, h), (), dense(h, h), (), dense(h, dout)]
+
+    def __call__(self, rng, dim, **kwargs):
+        from . import as_generator
+        if dim % 2:
+            raise ValueError("NeuralSplineCoupling needs an even number of dimensions")
+        g = as_generator(rng)
+        dh, per = dim // 2, 3 * self.K - 1
+        params = (self._init_net(g, dh, per * dh), self._init_net(g, dh, per * dh))
+        K, tail, hidden = self.K, self.B, self.hidden
+
+        def run(params, x, inverse):
+            import ctypes
+            torch = __import__("torch")
+            from .. import _lib
+            from ..core import flatten_params
+            L = _lib.lib()
+            was_numpy = not hasattr(x, "detach")
+            t = (torch.as_tensor(np.asarray(x, dtype=np.float32)) if was_numpy else x).to("cuda", dtype=torch.float32).contiguous()
+            if t.dim() != 2 or t.shape[1] != dim:
+                raise ValueError(f"expected inputs of shape [B, {dim}]")
+            Bn = t.shape[0]
+            flat = torch.as_tensor(flatten_params(params)).to(t.device)
+            y = torch.empty_like(t)
+            ld = torch.empty(Bn, device=t.device, dtype=torch.float32)
+            ws = torch.empty(int(_lib.check(L.wf_nsc_workspace_bytes(Bn, dim, K), "wf_nsc_workspace_bytes")), device=t.device, dtype=torch.uint8)
+            P = lambda a: ctypes.c_void_p(a.data_ptr())
+            _lib.check(L.wf_nsc_fwd(P(t), Bn, dim, K, tail, hidden, P(flat), int(inverse), P(y), P(ld), P(ws), ws.numel(),
+                                    ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)), "wf_nsc_fwd")
+            return (y.cpu().numpy(), ld.cpu().numpy()) if was_numpy else (y, ld)
+
+        def direct_fun(params, x, **kw):
+            return run(params, x, False)
+
+        def inverse_fun(params, z, **kw):
+            return run(params, z, True)
+
+        return params, direct_fun, inverse_fun
