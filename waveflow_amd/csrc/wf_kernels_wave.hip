@@ -844,14 +844,20 @@ __device__ __forceinline__ void wave_serial_inverse(const ModelDev& md, const fl
             const float tol = md.reverse_tol;
 #pragma unroll
             for (int d = 0; d < D; ++d) {
-                if (d == 0 || exact) {
-                    R1 xin[D];
-#pragma unroll
-                    for (int a = 0; a < D; ++a) xin[a] = R1{exact ? cur[a] : nxt[a]};
-                    hidden_fwd<D, R1, true>(net, xin, vec, lane, no_tape, 0, false);
-                }
                 const int p = d >> 1, hd = d & 1;
-                const R1 o = gemv<R1, true>(net.W2f + p * 1024, vec, lane) + net.b2[p * 64 + lane];
+                R1 o;
+                if (d == 0) {
+                    // output dimension 0 sees no input (MADE mask, model_factory.py:15-18): its head is the bias alone
+                    o = R1{net.b2[lane]};
+                } else {
+                    if (d == 1 || exact) {   // reference mode: one conditioner pass on the values being inverted (made.py:88)
+                        R1 xin[D];
+#pragma unroll
+                        for (int a = 0; a < D; ++a) xin[a] = R1{exact ? cur[a] : nxt[a]};
+                        hidden_fwd<D, R1, true>(net, xin, vec, lane, no_tape, 0, false);
+                    }
+                    o = gemv<R1, true>(net.W2f + p * 1024, vec, lane) + net.b2[p * 64 + lane];
+                }
                 const bool valid_d = 2 * p + dl < D, valid = valid_d && j < nb;
                 const SigHead<R1> hdw = sigmoid_head(o, valid, valid_d, gI[j], md.i_reg);
                 cur[d] = ispline_inverse(tabI, n_mesh, nb, hdw.c.c0, nxt[d], tol, hd, ov, lane);
@@ -859,12 +865,17 @@ __device__ __forceinline__ void wave_serial_inverse(const ModelDev& md, const fl
         } else {
 #pragma unroll
             for (int c = 0; c < D; ++c) {
-                R1 xin[D];
-#pragma unroll
-                for (int a = 0; a < D; ++a) xin[a] = R1{cur[a]};
-                hidden_fwd<D, R1, true>(net, xin, vec, lane, no_tape, 0, false);
                 const int p = c >> 1, hd = c & 1;
-                const R1 o = gemv<R1, true>(net.W2f + p * 1024, vec, lane) + net.b2[p * 64 + lane];
+                R1 o;
+                if (c == 0) {
+                    o = R1{net.b2[lane]};
+                } else {
+                    R1 xin[D];
+#pragma unroll
+                    for (int a = 0; a < D; ++a) xin[a] = R1{cur[a]};
+                    hidden_fwd<D, R1, true>(net, xin, vec, lane, no_tape, 0, false);
+                    o = gemv<R1, true>(net.W2f + p * 1024, vec, lane) + net.b2[p * 64 + lane];
+                }
                 const float lw = __shfl(o.c0, hd * 32), bias = __shfl(o.c0, hd * 32 + 1);
                 cur[c] = nxt[c] * expf(lw) + bias;
             }
@@ -917,12 +928,17 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(WF_WAVE_OCC
                 const bool wavefn = md.prior_kind == WF_PRIOR_WAVEFLOW;
 #pragma unroll
                 for (int col = 0; col < D; ++col) {
-                    R1 xin[D];
-#pragma unroll
-                    for (int a = 0; a < D; ++a) xin[a] = R1{cur[a]};   // conditioner on the columns drawn so far, zeros elsewhere
-                    hidden_fwd<D, R1, true>(net, xin, vec, lane, no_tape, 0, false);
                     const int p = col >> 1, hd = col & 1;
-                    const R1 o = gemv<R1, true>(net.W2f + p * 1024, vec, lane) + net.b2[p * 64 + lane];
+                    R1 o;
+                    if (col == 0) {
+                        o = R1{net.b2[lane]};   // column 0 is conditioned on nothing: bias only
+                    } else {
+                        R1 xin[D];
+#pragma unroll
+                        for (int a = 0; a < D; ++a) xin[a] = R1{cur[a]};   // conditioner on the columns drawn so far, zeros elsewhere
+                        hidden_fwd<D, R1, true>(net, xin, vec, lane, no_tape, 0, false);
+                        o = gemv<R1, true>(net.W2f + p * 1024, vec, lane) + net.b2[p * 64 + lane];
+                    }
                     const bool valid_d = 2 * p + dl < D, valid = valid_d && j < nb;
                     float cj, ymax;
                     if (wavefn) {
