@@ -400,3 +400,47 @@ def test_hip_graph_capture_of_the_step(he_flat):
     g.replay()
     torch.cuda.synchronize()
     close(lp.cpu().numpy(), om.log_pdf(he_flat, x.cpu().numpy(), f64=True), rtol=1e-4, atol=2e-2)
+
+
+def test_kernel_cross_consistency_sweep():
+    """Random model shapes (D, layers, degrees, knots, box type): the three forward kernels agree with each other (the scalar
+    kernel is the reference-order one that the oracle tests pin); catches shape-dependent indexing mistakes in any of them."""
+    from waveflow_amd import model_factory
+    g = np.random.default_rng(2024)
+    tried = 0
+    for trial in range(24):
+        D = int(g.integers(2, 9))
+        layers = int(g.integers(0, 4))
+        k = int(g.integers(3, 7))
+        kn = int(g.integers(8, 24))
+        if (kn + k - 1) % 2:            # the symmetric orthogonalisation needs an even number of B-spline bases
+            kn += 1
+        if kn + k > 32:                 # I-spline bases = knots + degree: keep within one 32-row block for the wave kernel
+            kn = 32 - k - (32 - k + k - 1) % 2
+            if (kn + k - 1) % 2:
+                kn -= 1
+        box = "mean" if g.integers(2) else "first"
+        init_fun = model_factory.get_waveflow_model(D, base_spline_degree=k, i_spline_degree=k, n_prior_internal_knots=kn,
+                                                    n_i_internal_knots=kn, i_spline_reg=0.05, n_flow_layers=layers, box_size=7.0,
+                                                    xu_coord_type=box)
+        params, psi, log_pdf, _ = init_fun(int(g.integers(1 << 30)), D)
+        x = sorted_walkers(777, D, 7.0, trial)
+        res = {}
+        for kernel in ("scalar", "mfma", "wave"):
+            try:
+                log_pdf.model.set_kernel(kernel)
+            except Exception:
+                continue
+            res[kernel] = (log_pdf(params, x), psi(params, x))
+        assert "scalar" in res and len(res) >= 2, (D, layers, k, kn, list(res))
+        lp0, ps0 = res["scalar"]
+        for kernel, (lp, ps) in res.items():
+            if kernel == "scalar":
+                continue
+            # fp32 conditioning (see as_accurate_as_fp32_reference): most walkers agree to 1e-5 relative, none is far off
+            d = np.abs(lp - lp0)
+            assert np.mean(d > 2e-5 + 1e-5 * np.abs(lp0)) < 0.08 and np.median(d) < 5e-6 * max(1.0, np.abs(lp0).max() / 10), \
+                (kernel, D, layers, k, kn, box, np.median(d), d.max())
+            assert np.abs(ps - ps0).max() <= 2e-3 * np.abs(ps0).max() + 1e-30, (kernel, D, layers, k, kn, box)
+        tried += 1
+    assert tried == 24
