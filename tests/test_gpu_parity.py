@@ -444,3 +444,24 @@ def test_kernel_cross_consistency_sweep():
             assert np.abs(ps - ps0).max() <= 2e-3 * np.abs(ps0).max() + 1e-30, (kernel, D, layers, k, kn, box)
         tried += 1
     assert tried == 24
+
+
+def test_small_batch_calls_are_graph_capturable(he_flat):
+    """The wave path of log_pdf / psi and the local energy for <= 6144 walkers allocate nothing: capture + replay = eager."""
+    torch = _torch()
+    params, psi, log_pdf, om = he_models(he_flat, "auto")
+    m = log_pdf.model
+    m.ensure_params(params)
+    x = torch.as_tensor(sorted_walkers(256, 2, 10.0, 3)).cuda()
+    want_lp, want_h = m.log_pdf(x).clone(), m.hamiltonian(x, [0.0, 0.0]).clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            lp = m.log_pdf(x)
+            h = m.hamiltonian(x, [0.0, 0.0])
+    torch.cuda.current_stream().wait_stream(side)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(lp, want_lp) and torch.equal(h, want_h)

@@ -172,6 +172,10 @@ static int upload_table(wf_model* m, const std::vector<float>& h, const float** 
 static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::vector<double>& p64, const std::vector<double>& o2b);
 static int grad_prepare(wf_model* m);
 static int64_t wave_net_floats(int D);
+}  // namespace wf
+static int ensure_scratch(const wf_model* cm, int64_t floats);
+static constexpr int64_t kWaveEvalMax = 6144;   // measured crossover ~7000 walkers (scratch/crossover.py)
+namespace wf {
 
 static int model_build(wf_model* m) {
     const wf_model_desc& d = m->desc;
@@ -754,6 +758,12 @@ static int grad_prepare(wf_model* m) {
         if (rc) return rc;
         WF_HIP(hipMemcpy(m->d_grad_fk, fk.data(), fk.size() * sizeof(float), hipMemcpyHostToDevice));
     }
+    if (m->wave_ok) {
+        // scratch for the small-batch wave path (tails of up to kWaveEvalMax walkers, first or second order) is reserved here
+        // so that those calls never allocate: they can be captured in a hipGraph
+        int rc = ensure_scratch(m, kWaveEvalMax * std::max(wave_tail_floats(D, 0), wave_tail_floats(D, 1)));
+        if (rc) return rc;
+    }
     if (!grad_capable(m) || m->n_params >= (1 << 24)) return WF_OK;
     m->grad_psi_ok = d.prior_kind == WF_PRIOR_WAVEFLOW && (d.layer_kind == WF_LAYER_IMADE || d.n_flow_layers == 0);
     const int n_nets = (int)m->nets.size();
@@ -929,8 +939,6 @@ static int check_fwd(const wf_model* m, const void* x, int64_t B, const void* ou
     return WF_OK;
 }
 
-static int ensure_scratch(const wf_model* cm, int64_t floats);
-static constexpr int64_t kWaveEvalMax = 6144;   // measured crossover ~7000 walkers (scratch/crossover.py)
 
 static int dispatch(const wf_model* m, int mode, const float* x, int64_t B, float* out, float* u, int32_t* idx, void* stream) {
     DeviceGuard g(m->device);
