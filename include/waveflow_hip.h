@@ -15,10 +15,14 @@
  *   - the caller owns every buffer; `*_dev` pointers are device (HBM) pointers,
  *     row-major, fp32 unless stated; `stream` is a hipStream_t passed as void*
  *     (NULL = the default stream); launches are asynchronous on that stream;
- *   - the library owns wf_model (wf_model_create / wf_model_destroy).  A model
- *     is immutable during a launch: concurrent launches on different streams
- *     are safe, wf_model_set_params must not run concurrently with launches
- *     that use the model;
+ *   - the library owns wf_model (wf_model_create / wf_model_destroy).  The
+ *     large-batch forward entry points (wf_logpdf_fwd / wf_psi_fwd / wf_flow_fwd
+ *     / wf_layer_fwd above 6144 rows, wf_inverse_fwd, wf_sample) only read the
+ *     model: concurrent launches on different streams are safe.  The small-batch
+ *     forward path, wf_hamiltonian_fwd and the gradient / training entry points
+ *     use per-model scratch: issue those for one model on one stream at a time
+ *     (or serialise them with events).  wf_model_set_params(_device) must not run
+ *     concurrently with launches that use the model;
  *   - there is no CPU fallback: on a machine without a gfx950 device every
  *     device entry point returns WF_ERR_NO_DEVICE.
  */
