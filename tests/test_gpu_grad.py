@@ -438,3 +438,26 @@ def test_model_without_flow_layers(he_flat):
     s, lat = sample(5, params, 200, return_original_samples=True, exact_inverse=True)
     lp, u = log_pdf(params, s, return_sample=True)
     assert (u - lat).abs().max().item() < 1e-4 and bool(torch.isfinite(lp).all())
+
+
+def test_trained_energy_respects_the_variational_bound(tmp_path):
+    """Known answer for the derivative path (unpinned in the reference): the lowest antisymmetric eigenvalue of the 1-D
+    soft-Coulomb He Hamiltonian in the box [-10, 10]^2 is -1.8161 (finite-difference diagonalisation, scratch/he1d_exact.py).
+    The energy of the trained wavefunction on an independent |psi|^2 sample must lie just above it: a wrong Laplacian, potential
+    or sampler shows up as a violation of the bound or as an energy far from it."""
+    from waveflow_amd import vqmc
+    t = vqmc.ModelTrainer(system_name="He", learning_rate=1e-3, box_length=10, num_epochs=20000, batch_size=512, log_every=10 ** 9)
+    t.save_dir = str(tmp_path / "run")
+    t.exact_sampler = True
+    params, loss = t.start_training(verbose=False)
+    m = t.psi.model
+    m.ensure_params(params)
+    es = []
+    for seed in range(4):
+        x = m.sample(500 + seed, 1 << 15, exact=True)
+        h, ps = m.hamiltonian(x, t.h_fn.protons, return_psi=True)
+        es.append((h / (ps + 1e-8)).double().cpu().numpy())
+    e = np.concatenate(es)
+    mean, sem = e.mean(), e.std() / np.sqrt(e.size)
+    assert mean > -1.8161 - 5 * sem, (mean, sem)
+    assert mean < -1.70, (mean, sem)
