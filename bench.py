@@ -95,7 +95,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=1 << 20, help="walkers per GPU")
-    ap.add_argument("--kernel", default="auto", choices=["auto", "scalar", "mfma"])
+    ap.add_argument("--kernel", default="auto", choices=["auto", "scalar", "mfma", "wave"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="he_logpdf", choices=["he_logpdf", "rqs", "vqmc"],
                     help="he_logpdf: the BASELINE metric (default).  rqs: the RQS bijector kernel alone (SURVEY row a12), an "
