@@ -199,7 +199,8 @@ def main():
             "roofline": {"bound": "mfma", "achieved": k_evals_s * FLOP_PER_EVAL / 1e12, "peak": PEAK_F32_VIA_F16_SPLIT_TFLOPS,
                          "unit": "TFLOP/s", "frac": k_evals_s * FLOP_PER_EVAL / 1e12 / PEAK_F32_VIA_F16_SPLIT_TFLOPS,
                          "traffic": PMC_TRAFFIC_BYTES_2POW20 if B == (1 << 20) else None,
-                         "kernel": "k_mfma<2,16>", "kernel_ms": kern_ms, "flop_per_eval": FLOP_PER_EVAL,
+                         "kernel": {"scalar": "k_eval<2,32>", "wave": "k_wave_fwd<2,R1>"}.get(args.kernel, "k_mfma<2,1,16>"), "kernel_ms": kern_ms,
+                         "flop_per_eval": FLOP_PER_EVAL,
                          "frac_of_native_f32_mfma_peak": k_evals_s * FLOP_PER_EVAL / 1e12 / PEAK_F32_MATRIX_TFLOPS,
                          "note": "achieved = algorithmic fp32 conditioner FLOP (SURVEY 8d) / kernel time.  The path computes fp32-accurate "
                                  "products on the f16 matrix cores as 3 MFMA products of 2-way split operands (fp32 accumulate, "
