@@ -465,3 +465,29 @@ def test_small_batch_calls_are_graph_capturable(he_flat):
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(lp, want_lp) and torch.equal(h, want_h)
+
+
+def test_bench_two_rank_path_on_a_shared_gpu():
+    """bench.py --gpus 2 under torch.distributed.run (test hook: both ranks on cuda:0, gloo): one JSON line from rank 0 with the
+    whole-job aggregate, the per-step all-reduce completed inside the timed region."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ, WF_BENCH_SHARE_GPU0="1", WF_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2", "--batch", "65536"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 8 and d["scaling"] == "weak" and d["metric"] == "flow log-prob evals/sec"
+    assert abs(d["value"] - 2 * 65536 * 8 / (d["ms_per_step"] * 8e-3)) < 1e-6 * d["value"]
+    assert "cpu_baseline" not in d and d["roofline"]["bound"] == "mfma"
