@@ -216,7 +216,7 @@ int wf_vqmc_loss_grad(const wf_model* m, const float* x_dev, int64_t B, const fl
  *   running_average_dev  the `running_average` of loss_fn_efficient (the caller refreshes it every 100 steps, vqmc.py:112-113)
  *   loss_ring_dev        [ring_len][3] doubles: [sum E_L, sum E_L^2, batch] of each step
  * The model's weight images must hold params_dev on entry (wf_model_set_params_device); they hold the updated parameters on
- * exit.  Single process; batch <= 32768 (the wave sampler).  Workspace: wf_vqmc_train_step_workspace_bytes. */
+ * exit.  Single process; batch <= 131072 (the wave sampler).  Workspace: wf_vqmc_train_step_workspace_bytes. */
 typedef struct wf_train_state {
     float* params_dev;
     float* m_dev;

@@ -116,22 +116,25 @@ def test_closure_surface_sample_and_inverse(he_flat):
     np.testing.assert_allclose(brev((), ub)[0], xw, atol=1e-5)
 
 
-def test_wave_and_one_lane_samplers_draw_from_the_same_distribution(he_flat):
-    """wf_sample switches kernels at 32768 walkers: both sides of the switch produce the same marginals (two-sample
-    Kolmogorov-Smirnov on each coordinate and on the latent columns), and inverse() agrees across the switch."""
+def test_wave_and_one_lane_samplers_draw_from_the_same_distribution(he_flat, monkeypatch):
+    """wf_sample / wf_inverse_fwd switch kernels at 2^17 walkers (WF_WAVE_SAMPLE_MAX moves the switch): both kernels produce the
+    same marginals (two-sample Kolmogorov-Smirnov on each coordinate and on the latent columns), and inverse() agrees."""
     from scipy import stats
     params, psi, log_pdf, sample, om = he(he_flat)
     m = psi.model
     m.ensure_params(params)
     for exact in (True, False):
-        xa, la = m.sample(7, 30000, return_latent=True, exact=exact)      # wave kernel
-        xb, lb = m.sample(8, 40000, return_latent=True, exact=exact)      # one lane per walker
+        monkeypatch.setenv("WF_WAVE_SAMPLE_MAX", "100000000")                 # one wave per walker
+        xa, la = m.sample(7, 30000, return_latent=True, exact=exact)
+        monkeypatch.setenv("WF_WAVE_SAMPLE_MAX", "0")                         # one lane per walker
+        xb, lb = m.sample(8, 40000, return_latent=True, exact=exact)
         for c in range(2):
             for a, b in ((xa, xb), (la, lb)):
                 p = stats.ks_2samp(a[:, c].cpu().numpy(), b[:, c].cpu().numpy()).pvalue
                 assert p > 1e-4, (exact, c, p)
     u = np.random.default_rng(0).uniform(0.01, 0.99, size=(40000, 2)).astype(np.float32)
-    big = m.inverse(u, exact=True)                 # 40000 rows: one lane per walker
-    small = m.inverse(u[:30000], exact=True)       # 30000 rows: wave kernel
-    d = np.abs(big[:30000] - small)
+    big = m.inverse(u, exact=True)                                            # one lane per walker
+    monkeypatch.setenv("WF_WAVE_SAMPLE_MAX", "100000000")
+    small = m.inverse(u, exact=True)                                          # one wave per walker
+    d = np.abs(big - small)
     assert np.median(d) < 1e-6 and np.quantile(d, 0.999) < 2e-4 and d.max() < 2e-3

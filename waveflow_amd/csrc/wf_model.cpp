@@ -1003,17 +1003,22 @@ int wf_layer_fwd(const wf_model* m, int layer, const float* u_in_dev, int64_t B,
     return launch_scalar_layer(m->dev, m->d_dev, layer, u_in_dev, B, y_dev, logdet_dev, bin_idx_dev, stream);
 }
 
-// Inverse / sampler: the bisection and rejection loops are serial per walker.  One wave per walker (wf_kernels_wave.hip)
-// finishes a 256-walker batch in 0.10 ms where one lane per walker (wf_kernels_scalar.hip) needs 1.4 ms, but it issues
-// ~20x more instructions per walker inside those loops: above ~3e4 walkers the one-lane form is faster (2^18: 4.9 vs 9.4 ms).
-static constexpr int64_t kWaveSampleMax = 32768;
+// Inverse / sampler.  One wave per walker (wf_kernels_wave.hip: 64-way mesh search instead of the halving loop, 64 rejection
+// proposals per round) finishes 128 walkers in 29 us where one lane per walker (wf_kernels_scalar.hip, the reference-order
+// loops) needs 1.4 ms, and stays ahead up to ~2^18 walkers (65536: 1.1 vs 1.9 ms; 2^18: 4.4 vs 4.2-4.6 ms; 2^20: 17.3 vs
+// 15.9-17.3 ms, scratch/sampler_crossover.py): the switch sits at 2^17.
+static constexpr int64_t kWaveSampleMax = 131072;
+static int64_t wave_sample_max() {   // tuning knob (read at every call): WF_WAVE_SAMPLE_MAX overrides the switch point
+    const char* e = getenv("WF_WAVE_SAMPLE_MAX");
+    return e ? atoll(e) : kWaveSampleMax;
+}
 
 int wf_inverse_fwd(const wf_model* m, const float* u_dev, int64_t B, float* x_dev, int32_t exact, void* stream) {
     int rc = check_fwd(m, u_dev, B, x_dev);
     if (rc) return rc;
     DeviceGuard g(m->device);
     if (B == 0) return WF_OK;
-    if (m->wave_ok && B <= kWaveSampleMax)
+    if (m->wave_ok && B <= wave_sample_max())
         return launch_wave_sample(m->dev, m->d_dev, m->d_tabI4, m->d_tabP3, m->d_grad_fk, 0, 0ull, u_dev, B, x_dev, nullptr, exact, nullptr, stream);
     return launch_scalar_inverse(m->dev, m->d_dev, u_dev, B, x_dev, exact, stream);
 }
@@ -1023,7 +1028,7 @@ int wf_sample(const wf_model* m, uint64_t seed, int64_t B, float* x_dev, float* 
     if (rc) return rc;
     DeviceGuard g(m->device);
     if (B == 0) return WF_OK;
-    if (m->wave_ok && B <= kWaveSampleMax)
+    if (m->wave_ok && B <= wave_sample_max())
         return launch_wave_sample(m->dev, m->d_dev, m->d_tabI4, m->d_tabP3, m->d_grad_fk, 1, (unsigned long long)seed, nullptr, B, x_dev, latent_dev,
                                   exact, nullptr, stream);
     return launch_scalar_sample(m->dev, m->d_dev, (unsigned long long)seed, B, x_dev, latent_dev, exact, stream);

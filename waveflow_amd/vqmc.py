@@ -180,7 +180,7 @@ class ModelTrainer:
                 json.dump(system_dict, fout_sys, indent=4)
         if verbose:
             print("Start training...")
-        if self.use_graph and not distributed and self.batch_size <= 32768:
+        if self.use_graph and not distributed and self.batch_size <= 131072:
             params, loss, energies = self._train_graphed(psi, sample, h_fn, opt_state, get_params, start_epoch, loss, energies, system_dict,
                                                          save_dir, rng, verbose)
             self.params, self.loss, self.energies = params, loss, energies
