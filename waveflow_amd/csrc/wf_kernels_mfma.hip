@@ -100,6 +100,18 @@ __global__ __launch_bounds__(64) void k_dim0_coeffs(const ModelDev* __restrict__
     if (t == 0) out[64] = rS;
 }
 
+// sum_j c_j row[j], j ascending (the order of the per-mesh-point evaluation), the row fetched with 16-byte loads
+__device__ __forceinline__ float row_dot(const float* __restrict__ row, const float* __restrict__ c, int nb) {
+    float acc = 0.0f;
+    for (int q = 0; 4 * q < nb; ++q) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(row + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (4 * q + e < nb) acc = __builtin_fmaf(c[4 * q + e], t[e], acc);
+    }
+    return acc;
+}
+
 __global__ void k_prepare_dim0(const ModelDev* __restrict__ mdp, int nm, const float* __restrict__ coef, f32x4* __restrict__ comp) {
     const ModelDev& md = *mdp;
     const int n_nets = md.n_layers + ((md.prior_kind == WF_PRIOR_WAVEFLOW || md.prior_kind == WF_PRIOR_MFLOW) ? 1 : 0);
@@ -115,19 +127,12 @@ __global__ void k_prepare_dim0(const ModelDev* __restrict__ mdp, int nm, const f
     } else if (is_prior && md.prior_kind == WF_PRIOR_WAVEFLOW) {
         const SplineDev& sp = md.psp;
         const int nb = sp.nb, nbp = sp.nbp;
-        float num = 0.0f;
-        for (int i = 0; i < nb; ++i) num = __builtin_fmaf(c[i], sp.tab[(size_t)m * nbp + i], num);
-        out[0] = (c[64] < 0.0f ? -num : num) * __builtin_amdgcn_rsqf(c[65]);
+        out[0] = (c[64] < 0.0f ? -row_dot(sp.tab + (size_t)m * nbp, c, nb) : row_dot(sp.tab + (size_t)m * nbp, c, nb)) * __builtin_amdgcn_rsqf(c[65]);
     } else {
         const SplineDev& sp = is_prior ? md.psp : md.isp;
         const int nb = sp.nb, nbp = sp.nbp;
-        float y = 0.0f, dy = 0.0f;
-        for (int j = 0; j < nb; ++j) {
-            y = __builtin_fmaf(c[j], sp.tab[(size_t)m * nbp + j], y);
-            if (!is_prior) dy = __builtin_fmaf(c[j], sp.tab[((size_t)sp.n_mesh + m) * nbp + j], dy);
-        }
-        out[0] = y * c[64];
-        out[1] = dy * c[64];
+        out[0] = row_dot(sp.tab + (size_t)m * nbp, c, nb) * c[64];
+        if (!is_prior) out[1] = row_dot(sp.tab + ((size_t)sp.n_mesh + m) * nbp, c, nb) * c[64];
     }
     comp[gid] = out;
 }
