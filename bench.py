@@ -81,12 +81,18 @@ def cpu_baseline(flat, x_host, budget_s=12.0):
     om.log_pdf(flat, x_host[:n0], threads=cores)
     dt = time.perf_counter() - t
     n = int(min(x_host.shape[0], max(n0, n0 * budget_s / max(dt, 1e-6))))
-    t = time.perf_counter()
-    om.log_pdf(flat, x_host[:n], threads=cores)
-    dt = time.perf_counter() - t
+    # whole passes over the sample until the budget (~12 s of CPU work) is used: the batch itself takes only ~4 s on 16 cores
+    passes, t = 0, time.perf_counter()
+    while True:
+        om.log_pdf(flat, x_host[:n], threads=cores)
+        passes += 1
+        dt = time.perf_counter() - t
+        if dt >= budget_s or passes >= 8:
+            break
+    dt /= passes
     return {"value": n / dt, "unit": "evals/s", "cores": cores, "kind": "port",
             "sample": f"first {n} of the benchmark's walkers, oracle/wf_oracle.c (fp32 restatement of the JAX reference), "
-                      f"OpenMP over walkers on {cores} threads, {dt:.1f} s"}
+                      f"OpenMP over walkers on {cores} threads, {passes} passes of {dt:.1f} s"}
 
 
 def main():
