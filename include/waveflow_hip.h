@@ -239,6 +239,12 @@ int64_t wf_logpdf_vjp_workspace_bytes(const wf_model* m, int64_t B);
 int wf_logpdf_vjp(const wf_model* m, const float* x_dev, int64_t B, const float* w_dev, float* grad_dev, void* workspace_dev,
                   int64_t workspace_bytes, void* stream);
 
+/* Maximum-likelihood value and gradient in one pass (benchmark_tests.loss + grad(loss), benchmark_tests.py:84-101): one forward
+ * sweep gives logp_dev[B] = log_pdf of every row and the tape, the reverse sweep gives grad_dev = weight * sum_b d log_pdf_b / d theta
+ * (weight = -1 / N for the mean negative log-likelihood).  Workspace: wf_logpdf_vjp_workspace_bytes. */
+int wf_logpdf_loss_grad(const wf_model* m, const float* x_dev, int64_t B, float weight, float* logp_dev, float* grad_dev, void* workspace_dev,
+                        int64_t workspace_bytes, void* stream);
+
 /* Per-walker weights of loss_fn_efficient's tangent rule (vqmc.py:198-212) for wf_psi_vjp, from wf_hamiltonian_fwd's outputs:
  *     e_loc = hpsi / (psi + 1e-8);   d loss = [2 (e_loc - running_average)/psi - hpsi/psi^2] d psi + (1/psi) d hpsi,
  *     d hpsi = -1/2 d laplacian + V d psi   =>   w_psi = (... + V/psi) * inv_count,  w_lap = -1/(2 psi) * inv_count

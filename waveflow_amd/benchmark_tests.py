@@ -67,12 +67,8 @@ def loss_and_grad(params, target, log_pdf):
     """value and gradient of `loss` (grad(loss) at benchmark_tests.py:100): one forward and one reverse launch."""
     model = log_pdf.model
     model.ensure_params(params)
-    import torch
     t, _ = model._to_dev(target)
-    n = t.shape[0]
-    lp = model.log_pdf(t)
-    w = torch.full((n,), -1.0 / n, device=t.device, dtype=torch.float32)
-    grad = model.logpdf_vjp(t, w)
+    lp, grad = model.logpdf_loss_grad(t, -1.0 / t.shape[0])     # log_pdf of every point and the gradient of their mean, one sweep pair
     s = model.block_sums(lp).cpu().tolist()
     return -s[0] / s[2], grad
 

@@ -262,6 +262,19 @@ class DeviceModel:
                                    self._stream()), "wf_logpdf_vjp")
         return grad
 
+    def logpdf_loss_grad(self, x, weight):
+        """(log_pdf [B], weight * sum_b d log_pdf_b / d theta [n_params]) from one forward and one reverse sweep."""
+        L = _lib.lib()
+        t, _ = self._to_dev(x)
+        B = t.shape[0]
+        nbytes = _lib.check(L.wf_logpdf_vjp_workspace_bytes(self._h, B), "wf_logpdf_vjp_workspace_bytes")
+        if self._vjp_ws is None or self._vjp_ws.numel() < nbytes:
+            self._vjp_ws = self._workspace(nbytes, t.device)
+        lp, grad = self._new((B,)), self._new((self.n_params,))
+        _lib.check(L.wf_logpdf_loss_grad(self._h, self._p(t), B, float(weight), self._p(lp), self._p(grad), self._p(self._vjp_ws),
+                                         self._vjp_ws.numel(), self._stream()), "wf_logpdf_loss_grad")
+        return lp, grad
+
     def vqmc_loss_grad(self, x, protons, running_average, global_count=None):
         """loss_fn_efficient and its gradient (vqmc.py:193-221) for the walkers x on this device, one fused pass.
         -> (sums fp64 [sum E_L, sum E_L^2, count] (torch.cuda), grad float32 [n_params] scaled by 1/global_count)."""

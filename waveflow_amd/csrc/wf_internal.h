@@ -142,6 +142,7 @@ int launch_wave_energy(const ModelDev& md, const ModelDev* md_dev, const float* 
 int launch_wave_sample(const ModelDev& md, const ModelDev* md_dev, const float* tabI4, const float* tabP4, const float* fk_nat, int draw,
                        unsigned long long seed, const float* u, int64_t B, float* x, float* latent, int exact,
                        const unsigned long long* seed_offset_dev, void* stream);
+int launch_tail_out(const ModelDev& md, int mode, const float* tails, int64_t B, float* out, float* u, void* stream);
 int launch_wave_eval(const ModelDev& md, const ModelDev* md_dev, const float* tabI4, const float* tabP4, const float* fk_nat, int mode,
                      const float* x, int64_t B, float* out, float* u, float* tail_ws, void* stream);
 int64_t wave_tail_floats(int D, int second_order);

@@ -1129,14 +1129,11 @@ int launch_energy_seeds(int D, const float* tails, const float* x, int64_t B, un
 }
 
 // log_pdf / psi / flow of B walkers through the wave kernel (low latency for small batches); tail_ws: wave_tail_floats(D, 0) * B
-int launch_wave_eval(const ModelDev& md, const ModelDev* md_dev, const float* tabI4, const float* tabP4, const float* fk_nat, int mode,
-                     const float* x, int64_t B, float* out, float* u, float* tail_ws, void* stream) {
-    int rc = launch_wave_fwd(md, md_dev, 0, tabI4, tabP4, fk_nat, x, B, nullptr, tail_ws, 0, stream);
-    if (rc) return rc;
+// log_pdf / psi / log det (+ latent point) of B walkers from their first-order tails
+int launch_tail_out(const ModelDev& md, int mode, const float* tails, int64_t B, float* out, float* u, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)((B + 255) / 256)), block(256);
-#define CALL(DD) hipLaunchKernelGGL(k_tail_out<DD>, grid, block, 0, s, (const float*)tail_ws, B, mode, md.prior_kind, md.constrained_mask, \
-                                    md.normal_offset, out, u); break
+#define CALL(DD) hipLaunchKernelGGL(k_tail_out<DD>, grid, block, 0, s, tails, B, mode, md.prior_kind, md.constrained_mask, md.normal_offset, out, u); break
     switch (md.D) {
         case 2: CALL(2);
         case 3: CALL(3);
@@ -1149,6 +1146,13 @@ int launch_wave_eval(const ModelDev& md, const ModelDev* md_dev, const float* ta
     }
 #undef CALL
     return finish();
+}
+
+int launch_wave_eval(const ModelDev& md, const ModelDev* md_dev, const float* tabI4, const float* tabP4, const float* fk_nat, int mode,
+                     const float* x, int64_t B, float* out, float* u, float* tail_ws, void* stream) {
+    int rc = launch_wave_fwd(md, md_dev, 0, tabI4, tabP4, fk_nat, x, B, nullptr, tail_ws, 0, stream);
+    if (rc) return rc;
+    return launch_tail_out(md, mode, tail_ws, B, out, u, stream);
 }
 
 // H psi, psi, laplacian of B walkers: forward in R3 without a tape, then the per-walker combination

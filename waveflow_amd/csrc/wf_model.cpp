@@ -1093,6 +1093,7 @@ static int64_t vjp_ws_bytes(const wf_model* m, int64_t B, bool second_order) {
 
 // mode 0: log_pdf, w1 only;  mode 1: psi (w1) and, with second_order, its Laplacian (w2);
 // mode 2: loss_fn_efficient (vqmc.py:193-212): the weights come from H psi of the same forward sweep, e_loc_dev is written
+// mode 3: maximum likelihood: every walker carries the weight inv_count (signed), e_loc_dev receives log_pdf of the same sweep
 static int run_vjp_chunks(const wf_model* m, int mode, bool second_order, const float* x_dev, int64_t B, const float* w1, const float* w2,
                           const Protons* pr, float running_average, float inv_count, float* e_loc_dev, float* grad_dev, void* workspace_dev,
                           int64_t workspace_bytes, void* stream, const float* running_average_dev = nullptr) {
@@ -1128,7 +1129,16 @@ static int run_vjp_chunks(const wf_model* m, int mode, bool second_order, const 
             cw1 = wp;
             cw2 = wl;
         }
-        rc = launch_wave_bwd(m->dev, m->d_dev, mode == 0 ? 0 : 1, second_order ? 1 : 0, m->d_tabI4, m->d_tabP3, m->d_grad_fk, bc, cw1, cw2, tape,
+        if (mode == 3) {
+            float* wp = per_walker + 2 * chunk;
+            rc = launch_tail_out(m->dev, 0, tails, bc, e_loc_dev + c0, nullptr, stream);
+            if (rc) return rc;
+            uint32_t bits;
+            memcpy(&bits, &inv_count, sizeof bits);
+            WF_HIP(hipMemsetD32Async((hipDeviceptr_t)wp, (int)bits, (size_t)bc, s));
+            cw1 = wp;
+        }
+        rc = launch_wave_bwd(m->dev, m->d_dev, (mode == 0 || mode == 3) ? 0 : 1, second_order ? 1 : 0, m->d_tabI4, m->d_tabP3, m->d_grad_fk, bc, cw1, cw2, tape,
                              tails, stream);
         if (rc) return rc;
         rc = launch_wgrad(D, second_order ? 1 : 0, n_nets, bc * samples_per, tape, m->d_grad_partial, c0 > 0, m->d_grad_img, fwd,
@@ -1160,6 +1170,16 @@ int wf_logpdf_vjp(const wf_model* m, const float* x_dev, int64_t B, const float*
     if (!m->d_grad_map) return WF_ERR_UNSUPPORTED;
     if (B > 0 && (!w_dev || !workspace_dev)) return WF_ERR_INVALID;
     return run_vjp_chunks(m, 0, false, x_dev, B, w_dev, nullptr, nullptr, 0.0f, 0.0f, nullptr, grad_dev, workspace_dev, workspace_bytes, stream);
+}
+
+int wf_logpdf_loss_grad(const wf_model* m, const float* x_dev, int64_t B, float weight, float* logp_dev, float* grad_dev, void* workspace_dev,
+                        int64_t workspace_bytes, void* stream) {
+    int rc = check_fwd(m, x_dev, B, grad_dev);
+    if (rc) return rc;
+    if (!grad_dev) return WF_ERR_INVALID;
+    if (!m->d_grad_map) return WF_ERR_UNSUPPORTED;
+    if (B > 0 && (!logp_dev || !workspace_dev)) return WF_ERR_INVALID;
+    return run_vjp_chunks(m, 3, false, x_dev, B, nullptr, nullptr, nullptr, 0.0f, weight, logp_dev, grad_dev, workspace_dev, workspace_bytes, stream);
 }
 
 int wf_vqmc_loss_grad(const wf_model* m, const float* x_dev, int64_t B, const float* protons_host, int32_t n_protons, float running_average,
