@@ -231,6 +231,13 @@ int wf_vqmc_train_step(wf_model* m, const wf_train_state* st, uint64_t seed, int
                        float step_size, float b1, float b2, float eps, int32_t exact_sampler, void* workspace_dev, int64_t workspace_bytes,
                        void* stream);
 
+/* One epoch of benchmark_tests.train_model (benchmark_tests.py:98-101, 138-144) without the host: -mean log_pdf over the N
+ * resident rows x_dev[N][D], its gradient, Adam, image refill; [sum log_pdf, sum log_pdf^2, N] of the epoch goes to the loss ring
+ * (the loss is -sum / N).  Same state conventions as wf_vqmc_train_step (running_average_dev is unused).  hipGraph-capturable. */
+int64_t wf_mle_train_step_workspace_bytes(const wf_model* m, int64_t N);
+int wf_mle_train_step(wf_model* m, const wf_train_state* st, const float* x_dev, int64_t N, float step_size, float b1, float b2, float eps,
+                      void* workspace_dev, int64_t workspace_bytes, void* stream);
+
 /* Parameter gradient of the log-density: grad_dev[p] = sum_b w_dev[b] * d log_pdf_b / d theta_p for every model wf_logpdf_fwd
  * evaluates with <= 32 bases per dimension and zero-only constraints (IMADE or MADE layers; Waveflow, M-spline, Normal or Uniform
  * prior).  With w = -1/B this is the gradient of benchmark_tests.loss (benchmark_tests.py:84-87, 98-101); with per-walker

@@ -490,3 +490,68 @@ def test_logpdf_loss_grad_matches_separate_calls():
     assert L.wf_logpdf_loss_grad(m._h, X.data_ptr(), 256, -1.0 / 256, lp2.data_ptr(), g2.data_ptr(), ws.data_ptr(), ws.numel(), None) == 0
     torch.cuda.synchronize()
     assert torch.equal(lp2, lp) and rel_l2(g2.cpu().numpy(), grad.cpu().numpy()) < 1e-5
+
+
+def test_mle_train_step_matches_separate_calls():
+    """wf_mle_train_step = logpdf_loss_grad + adam_step + set_params_device (up to Adam's bias corrections being powf on the
+    device and pow on the host); replayed from a hipGraph it is bitwise the eager sequence."""
+    import os
+    import torch
+    from conftest import GOLDEN
+    from waveflow_amd import model_factory
+    from waveflow_amd.vqmc import flatten_params
+    X = torch.as_tensor(np.load(os.path.join(GOLDEN, "circles_x256.npy")).astype(np.float32)).cuda()
+    params, log_pdf, _ = model_factory.get_model(n_flow_layers=2, i_spline_reg=0.02, prior_constraint_dict_left={0: 0},
+                                                 prior_constraint_dict_right={0: 0}, i_constraint_dict_left={0: 0.0},
+                                                 i_constraint_dict_right={0: 1.0})(1, 2)
+    m = log_pdf.model
+    flat0 = torch.as_tensor(flatten_params(params).astype(np.float32)).cuda()
+    n_steps, lr = 6, 1e-3
+
+    # separate calls
+    x, mm, vv = flat0.clone(), torch.zeros_like(flat0), torch.zeros_like(flat0)
+    want_loss = []
+    for step in range(1, n_steps + 1):
+        m.set_params_device(x)
+        lp, grad = m.logpdf_loss_grad(X, -1.0 / 256)
+        s = m.block_sums(lp).cpu().tolist()
+        want_loss.append(-s[0] / s[2])
+        m.adam_step(x, grad, mm, vv, step, lr)
+
+    def run(graphed):
+        x2, m2, v2 = flat0.clone(), torch.zeros_like(flat0), torch.zeros_like(flat0)
+        st = m.make_train_state(x2, m2, v2, 1, ring_len=4)
+        m.set_params_device(x2)
+        if graphed:
+            m.mle_train_step(st, X, lr)     # sizes the workspace outside the capture
+            x2.copy_(flat0); m2.zero_(); v2.zero_(); st["counter"].fill_(1)
+            m.set_params_device(x2)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side):
+                    m.mle_train_step(st, X, lr)
+            torch.cuda.current_stream().wait_stream(side)
+        got = []
+        for step in range(1, n_steps + 1):
+            graph.replay() if graphed else m.mle_train_step(st, X, lr)
+            r = st["ring"].cpu().numpy()
+            got.append(-r[step % 4, 0] / r[step % 4, 2])
+        assert int(st["counter"].item()) == n_steps + 1
+        return x2, m2, v2, got
+
+    xe, me, ve, got_e = run(False)
+    xg, mg, vg, got_g = run(True)
+    assert torch.equal(xe, xg) and torch.equal(me, mg) and torch.equal(ve, vg) and got_e == got_g
+    # (Adam turns a rounding difference in a near-zero gradient entry into a step-size difference: compare in bulk)
+    dx = (xe - x).abs()
+    assert float(torch.quantile(dx, 0.99)) < 1e-5 and float(dx.max()) < 2.5 * n_steps * lr, (float(torch.quantile(dx, 0.99)), float(dx.max()))
+    np.testing.assert_allclose(got_e, want_loss, rtol=0, atol=1e-4)
+    assert got_e[0] == want_loss[0] and want_loss[-1] < want_loss[0]
+    x = xe
+    # the images follow the state: the model evaluates with the trained parameters
+    m.set_kernel("wave")
+    lp_now = m.log_pdf(X)
+    m.set_params_device(x)
+    assert torch.equal(lp_now, m.log_pdf(X))

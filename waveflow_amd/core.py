@@ -326,6 +326,17 @@ class DeviceModel:
         self._flat = None
         self._dev_key = None
 
+    def mle_train_step(self, st, x, step_size, b1=0.9, b2=0.999, eps=1e-8):
+        """One maximum-likelihood epoch on the device (wf_mle_train_step): no host work, capturable in a hipGraph."""
+        L = _lib.lib()
+        nbytes = _lib.check(L.wf_mle_train_step_workspace_bytes(self._h, int(x.shape[0])), "wf_mle_train_step_workspace_bytes")
+        if st.get("ws") is None or st["ws"].numel() < nbytes:
+            st["ws"] = self._workspace(nbytes, st["x"].device)
+        _lib.check(L.wf_mle_train_step(self._h, ctypes.byref(st["c"]), self._p(x), int(x.shape[0]), float(step_size), float(b1), float(b2),
+                                       float(eps), self._p(st["ws"]), st["ws"].numel(), self._stream()), "wf_mle_train_step")
+        self._flat = None
+        self._dev_key = None
+
     @staticmethod
     def _workspace(nbytes, device):
         torch = _torch()

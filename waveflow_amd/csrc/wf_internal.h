@@ -162,6 +162,8 @@ struct PackRec {
 int launch_pack(const float* flat_dev, const PackRec* recs, int64_t n, void* plain, void* wave, void* mfma, void* stream);
 int launch_adam(float* params, const float* grad, float* m, float* v, int64_t n, int64_t step, float step_size, float b1, float b2, float eps,
                 const unsigned long long* step_dev, void* stream);
+// out[i] = value (a kernel, not a memset node: it sits in captured training steps between kernels)
+int launch_fill(float* out, float value, int64_t n, void* stream);
 int launch_step_end(const double* sums, double* ring, int ring_len, unsigned long long* counter, void* stream);
 int launch_grad_gather(const float* grad_img, const int32_t* inv, int64_t n_params, float* grad_flat, void* stream);
 int launch_grad_gather_partials(const float* partial, int split, int64_t n_img, const int32_t* inv, int64_t n_params, float* grad_flat, void* stream);

@@ -311,6 +311,17 @@ int launch_adam(float* params, const float* grad, float* m, float* v, int64_t n,
     return finish();
 }
 
+__global__ void k_fill(float* __restrict__ out, float value, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = value;
+}
+
+int launch_fill(float* out, float value, int64_t n, void* stream) {
+    if (n <= 0) return WF_OK;
+    hipLaunchKernelGGL(k_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, value, n);
+    return finish();
+}
+
 int launch_step_end(const double* sums, double* ring, int ring_len, unsigned long long* counter, void* stream) {
     hipLaunchKernelGGL(k_step_end, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, ring, ring_len, counter);
     return finish();

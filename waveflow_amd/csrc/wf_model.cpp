@@ -1133,9 +1133,8 @@ static int run_vjp_chunks(const wf_model* m, int mode, bool second_order, const 
             float* wp = per_walker + 2 * chunk;
             rc = launch_tail_out(m->dev, 0, tails, bc, e_loc_dev + c0, nullptr, stream);
             if (rc) return rc;
-            uint32_t bits;
-            memcpy(&bits, &inv_count, sizeof bits);
-            WF_HIP(hipMemsetD32Async((hipDeviceptr_t)wp, (int)bits, (size_t)bc, s));
+            rc = launch_fill(wp, inv_count, bc, stream);
+            if (rc) return rc;
             cw1 = wp;
         }
         rc = launch_wave_bwd(m->dev, m->d_dev, (mode == 0 || mode == 3) ? 0 : 1, second_order ? 1 : 0, m->d_tabI4, m->d_tabP3, m->d_grad_fk, bc, cw1, cw2, tape,
@@ -1239,6 +1238,38 @@ int wf_vqmc_train_step(wf_model* m, const wf_train_state* st, uint64_t seed, int
     rc = launch_block_sums(e_loc, batch, sums, sums_ws, block_sums_ws_bytes(batch), stream);
     if (rc) return rc;
     rc = launch_adam(st->params_dev, grad, st->m_dev, st->v_dev, m->n_params, 0, step_size, b1, b2, eps, counter, stream);
+    if (rc) return rc;
+    rc = wf_model_set_params_device(m, st->params_dev, m->n_params, stream);
+    if (rc) return rc;
+    return launch_step_end(sums, st->loss_ring_dev, st->ring_len, (unsigned long long*)st->counter_dev, stream);
+}
+
+int64_t wf_mle_train_step_workspace_bytes(const wf_model* m, int64_t N) {
+    if (!m || N < 1) return WF_ERR_INVALID;
+    if (!m->d_grad_map) return WF_ERR_UNSUPPORTED;
+    return align256(N * 4) + align256(m->n_params * 4) + 256 + align256(block_sums_ws_bytes(N)) + vjp_ws_bytes(m, N, false);
+}
+
+int wf_mle_train_step(wf_model* m, const wf_train_state* st, const float* x_dev, int64_t N, float step_size, float b1, float b2, float eps,
+                      void* workspace_dev, int64_t workspace_bytes, void* stream) {
+    if (!m || !st || !x_dev || N < 1) return WF_ERR_INVALID;
+    if (!st->params_dev || !st->m_dev || !st->v_dev || !st->counter_dev || !st->loss_ring_dev || st->ring_len < 1) return WF_ERR_INVALID;
+    if (!m->d_grad_map) return WF_ERR_UNSUPPORTED;
+    if (!m->params_set || !workspace_dev || workspace_bytes < wf_mle_train_step_workspace_bytes(m, N)) return WF_ERR_INVALID;
+    DeviceGuard g(m->device);
+    char* p = (char*)workspace_dev;
+    float* lp = (float*)p; p += align256(N * 4);
+    float* grad = (float*)p; p += align256(m->n_params * 4);
+    double* sums = (double*)p; p += 256;
+    void* sums_ws = p; p += align256(block_sums_ws_bytes(N));
+    const int64_t vjp_bytes = workspace_bytes - (p - (char*)workspace_dev);
+    // loss = -mean log_pdf (benchmark_tests.py:84-87): value from the forward sweep, gradient from the reverse sweep
+    int rc = run_vjp_chunks(m, 3, false, x_dev, N, nullptr, nullptr, nullptr, 0.0f, -1.0f / (float)N, lp, grad, p, vjp_bytes, stream);
+    if (rc) return rc;
+    rc = launch_block_sums(lp, N, sums, sums_ws, block_sums_ws_bytes(N), stream);
+    if (rc) return rc;
+    rc = launch_adam(st->params_dev, grad, st->m_dev, st->v_dev, m->n_params, 0, step_size, b1, b2, eps,
+                     (const unsigned long long*)st->counter_dev, stream);
     if (rc) return rc;
     rc = wf_model_set_params_device(m, st->params_dev, m->n_params, stream);
     if (rc) return rc;
