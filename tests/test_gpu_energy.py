@@ -82,3 +82,26 @@ def test_checkpoint_artefacts_match_the_reference_files(tmp_path, golden, he_fla
     with open(tmp_path / "checkpoints", "rb") as f:
         plain, _ = pickle.load(f)       # plain pickle.load works too: leaves are NumPy arrays
     assert np.array_equal(flatten_params(plain), he_flat)
+
+
+@pytest.mark.parametrize("D", [2, 3, 5, 8])
+def test_forward_laplacian_sweep_matches_directional_sweeps(D, monkeypatch):
+    """wf_hamiltonian_fwd carries (value, gradient, Laplacian) per walker in one pass; WF_ENERGY_R3 switches back to D passes
+    of second-order Taylor coefficients (the sweep the gradient path tapes).  Same psi bit for bit, same Laplacian up to
+    rounding."""
+    from waveflow_amd import model_factory
+    init_fun = model_factory.get_waveflow_model(D, base_spline_degree=6, i_spline_degree=6, n_prior_internal_knots=23,
+                                                n_i_internal_knots=23, i_spline_reg=0.05, n_flow_layers=2, box_size=10.0)
+    params, psi, log_pdf, sample = init_fun(11, D)
+    m = psi.model
+    m.ensure_params(params)
+    x = sorted_walkers(777, D, 10.0, 3).astype(np.float32)
+    protons = np.linspace(-3, 3, D)
+    monkeypatch.setenv("WF_ENERGY_R3", "1")
+    h3, p3, l3 = m.hamiltonian(x, protons, return_psi=True, return_laplacian=True)
+    monkeypatch.delenv("WF_ENERGY_R3")
+    hf, pf, lf = m.hamiltonian(x, protons, return_psi=True, return_laplacian=True)
+    assert np.array_equal(p3, pf)
+    assert np.isfinite(lf).all() and np.abs(lf).max() > 0
+    assert np.linalg.norm(lf - l3) <= 1e-4 * np.linalg.norm(l3), np.linalg.norm(lf - l3) / np.linalg.norm(l3)
+    assert np.linalg.norm(hf - h3) <= 1e-4 * np.linalg.norm(h3)

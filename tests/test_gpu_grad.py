@@ -555,3 +555,32 @@ def test_mle_train_step_matches_separate_calls():
     lp_now = m.log_pdf(X)
     m.set_params_device(x)
     assert torch.equal(lp_now, m.log_pdf(X))
+
+
+@pytest.mark.parametrize("D", [2, 3, 6])
+def test_forward_laplacian_ring_gradient_matches_directional_ring(D, monkeypatch):
+    """The taped sweeps run in RF (value, gradient, Laplacian / 2 per walker: D + 2 channels, one sample); WF_GRAD_R3 at model
+    creation selects D samples of second-order Taylor coefficients instead.  Both are reverse mode over a Frobenius algebra
+    (wf_ring.h): same local energies, same gradient up to rounding."""
+    from waveflow_amd import model_factory
+    x = sorted_walkers(300, D, 10.0, 9).astype(np.float32)
+    protons = np.linspace(-3, 3, D)
+    out = {}
+    for tag in ("R3", "RF"):
+        if tag == "R3":
+            monkeypatch.setenv("WF_GRAD_R3", "1")
+        else:
+            monkeypatch.delenv("WF_GRAD_R3")
+        init_fun = model_factory.get_waveflow_model(D, base_spline_degree=6, i_spline_degree=6, n_prior_internal_knots=23,
+                                                    n_i_internal_knots=23, i_spline_reg=0.05, n_flow_layers=2, box_size=10.0)
+        params, psi, log_pdf, sample = init_fun(5, D)
+        m = psi.model
+        m.ensure_params(params)
+        sums, grad = m.vqmc_loss_grad(x, protons, -1.0)
+        g = np.random.default_rng(2)
+        wp, wl = g.normal(size=300).astype(np.float32), g.normal(size=300).astype(np.float32)
+        out[tag] = (sums.cpu().numpy(), grad.cpu().numpy().astype(np.float64), m.psi_vjp(x, wp, wl).cpu().numpy().astype(np.float64))
+    (s3, g3, v3), (sf, gf, vf) = out["R3"], out["RF"]
+    np.testing.assert_allclose(sf, s3, rtol=2e-5)
+    # (random signed weights cancel in psi_vjp: fp32 rounding of the two sweeps shows at the 1e-5 level)
+    assert rel_l2(gf, g3) < 2e-5 and rel_l2(vf, v3) < 3e-4, (rel_l2(gf, g3), rel_l2(vf, v3))

@@ -128,14 +128,18 @@ struct Protons {
     float pos[8];
     int n;
 };
+// The sweeps run over a coefficient ring (wf_ring.h).  kind 0: R1 (first order); 1: R3 (one sample per walker and direction,
+// 3 coefficients); 2: RF (one sample per walker, D + 2 coefficients)
+inline int ring_coefs(int D, int kind) { return kind == 0 ? 1 : (kind == 1 ? 3 : D + 2); }
+inline int ring_samples(int D, int kind) { return kind == 1 ? D : 1; }
 // reverse pass (wf_kernels_grad.hip)
 int grad_ws_rows(int D);
 int wgrad_partial_floats(int n_nets, int64_t net_img_floats);
-int launch_wgrad(int D, int second_order, int n_nets, int64_t n_samples, const float* ws, float* partial, int accumulate, float* grad_img,
+int launch_wgrad(int D, int ring_kind, int n_nets, int64_t n_samples, const float* ws, float* partial, int accumulate, float* grad_img,
                  int64_t net_img_floats, int* split_out, void* stream);
-int launch_wave_fwd(const ModelDev& md, const ModelDev* md_dev, int second_order, const float* tabI4, const float* tabP4, const float* fk_nat,
+int launch_wave_fwd(const ModelDev& md, const ModelDev* md_dev, int ring_kind, const float* tabI4, const float* tabP4, const float* fk_nat,
                     const float* x, int64_t B, float* ws, float* tails, int taped, void* stream);
-int launch_wave_bwd(const ModelDev& md, const ModelDev* md_dev, int mode, int second_order, const float* tabI4, const float* tabP4,
+int launch_wave_bwd(const ModelDev& md, const ModelDev* md_dev, int mode, int ring_kind, const float* tabI4, const float* tabP4,
                     const float* fk_nat, int64_t B, const float* w1, const float* w2, float* ws, const float* tails, void* stream);
 int launch_wave_energy(const ModelDev& md, const ModelDev* md_dev, const float* tabI4, const float* tabP4, const float* fk_nat, const float* x,
                        int64_t B, const Protons& pr, float* hpsi, float* psi, float* lap, float* tail_ws, void* stream);
@@ -145,10 +149,10 @@ int launch_wave_sample(const ModelDev& md, const ModelDev* md_dev, const float* 
 int launch_tail_out(const ModelDev& md, int mode, const float* tails, int64_t B, float* out, float* u, void* stream);
 int launch_wave_eval(const ModelDev& md, const ModelDev* md_dev, const float* tabI4, const float* tabP4, const float* fk_nat, int mode,
                      const float* x, int64_t B, float* out, float* u, float* tail_ws, void* stream);
-int64_t wave_tail_floats(int D, int second_order);
-int launch_energy_seeds(int D, const float* tails, const float* x, int64_t B, unsigned constrained_mask, const Protons& pr, float running_avg,
+int64_t wave_tail_floats(int D, int ring_kind);   // per walker
+int launch_energy_seeds(int D, int ring_kind, const float* tails, const float* x, int64_t B, unsigned constrained_mask, const Protons& pr, float running_avg,
                         const float* running_avg_dev, float inv_count, float* e_loc, float* w_psi, float* w_lap, void* stream);
-int launch_energy_out(int D, const float* tails, const float* x, int64_t B, unsigned constrained_mask, const Protons& pr, float* hpsi, float* psi,
+int launch_energy_out(int D, int ring_kind, const float* tails, const float* x, int64_t B, unsigned constrained_mask, const Protons& pr, float* hpsi, float* psi,
                       float* lap, void* stream);
 // One entry of a device weight image as a function of the flat parameter vector:
 //   kind & 0xFF == 0: image float [dst]  = src >= 0 ? (float)(scale * flat[src]) : (float)scale

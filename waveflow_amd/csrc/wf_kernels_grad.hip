@@ -42,7 +42,9 @@ constexpr int kGBlock = 64;
 constexpr int kRows = 64;
 
 
-// ---- kernel 2: weight gradients.  C[m][n] = sum_s sum_k X[m][k][s] * Y[n][NC-1-k][s];  bias[n] = sum_s Y[n][NC-1][s]
+// ---- kernel 2: weight gradients.  C[m][n] = sum_s sum_k X[m][k][s] * Y[n][partner(k)][s];  bias[n] = sum_s Y[n][NC-1][s]
+// partner(k): the slot the pairing of the ring couples with slot k -- value and top slot exchanged, the slots between paired with
+// themselves (R1: 0; R3: 2, 1, 0; RF: D+1, 1..D, 0 -- wf_ring.h)
 struct WJob {
     int xrow, M, yrow, N;      // workspace rows (within a net) of the activations (X) and of the adjoints (Y)
     int out, sm, sn, bias;     // gradient-image offsets (within a net): C[m][n] -> out + m*sm + n*sn; bias[n] -> bias + n
@@ -51,11 +53,13 @@ struct WJobs {
     WJob j[3];
 };
 constexpr int kWT = 64;   // output tile
-constexpr int kWK = 32;   // samples per staged slab
+constexpr int wgrad_slab(int NC) { return NC <= 3 ? 32 : (NC <= 6 ? 16 : 8); }   // samples per staged slab: 2 * NC * slab * 256 B of LDS
+__host__ __device__ constexpr int ring_partner(int NC, int k) { return k == 0 ? NC - 1 : (k == NC - 1 ? 0 : k); }
 constexpr int kWgradSplit = 64;   // workgroups along the sample axis per (net, matrix, tile): 64 x 3..6 x n_nets fills the chip
 template <int NC>
 __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ ws, int n_nets, int64_t n_samples, int rows, const WJobs jobs,
                                                int n_ntiles_max, float* __restrict__ gimg, int64_t net_img_floats) {
+    constexpr int kWK = wgrad_slab(NC);
     __shared__ float4_t Xs[NC][kWK][kWT / 4];   // [coefficient][sample of the slab][row], rows contiguous
     __shared__ float4_t Ys[NC][kWK][kWT / 4];
     const int net = blockIdx.z;
@@ -94,7 +98,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ ws, int
         for (int kk = 0; kk < kWK; ++kk) {
 #pragma unroll
             for (int k = 0; k < NC; ++k) {
-                const float4_t x4 = Xs[k][kk][tm], y4 = Ys[NC - 1 - k][kk][tn];
+                const float4_t x4 = Xs[k][kk][tm], y4 = Ys[ring_partner(NC, k)][kk][tn];
                 const float xv[4] = {x4.x, x4.y, x4.z, x4.w}, yv[4] = {y4.x, y4.y, y4.z, y4.w};
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -252,6 +256,7 @@ int run_wgrad(int n_nets, int64_t n_samples, const float* ws, float* partial, in
     jobs.j[1] = WJob{R::H1, H, R::A2, H, oW1, 1, H, ob1};           // dW1t[j][a]
     jobs.j[2] = WJob{R::H2, H, R::O, D * NBP, oW2, 1, H, ob2};      // dW2t[(d, jb)][a]
     const int n_ntiles = (D * NBP + kWT - 1) / kWT;
+    constexpr int kWK = wgrad_slab(NC);
     const int64_t n_slabs = (n_samples + kWK - 1) / kWK;
     int split = (int)(n_slabs < kWgradSplit ? n_slabs : kWgradSplit);
     if (split < 1) split = 1;
@@ -276,11 +281,12 @@ int wgrad_partial_floats(int n_nets, int64_t net_img_floats) { return kWgradSpli
 
 // partial: wgrad_partial_floats scratch; accumulate != 0 adds to grad_img (further chunks of a batch) instead of overwriting it
 // split_out != NULL: leave the partial images unreduced and report how many there are
-int launch_wgrad(int D, int second_order, int n_nets, int64_t n_samples, const float* ws, float* partial, int accumulate, float* grad_img,
+int launch_wgrad(int D, int ring_kind, int n_nets, int64_t n_samples, const float* ws, float* partial, int accumulate, float* grad_img,
                  int64_t net_img_floats, int* split_out, void* stream) {
     hipStream_t s = (hipStream_t)stream;
-#define CALL(DD) return second_order ? run_wgrad<DD, 3>(n_nets, n_samples, ws, partial, accumulate, grad_img, net_img_floats, split_out, s) \
-                                     : run_wgrad<DD, 1>(n_nets, n_samples, ws, partial, accumulate, grad_img, net_img_floats, split_out, s)
+#define CALL(DD) return ring_kind == 2 ? run_wgrad<DD, DD + 2>(n_nets, n_samples, ws, partial, accumulate, grad_img, net_img_floats, split_out, s) \
+                : ring_kind == 1 ? run_wgrad<DD, 3>(n_nets, n_samples, ws, partial, accumulate, grad_img, net_img_floats, split_out, s)       \
+                                 : run_wgrad<DD, 1>(n_nets, n_samples, ws, partial, accumulate, grad_img, net_img_floats, split_out, s)
     switch (D) {
         case 2: CALL(2);
         case 3: CALL(3);

@@ -16,6 +16,8 @@
 // Derivative semantics of the table lerp and the adjoint-in-reversed-order ring trick: see wf_kernels_grad.hip / wf_ring.h.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "wf_internal.h"
 #include "wf_ring.h"
 #include "wf_scalar_impl.h"   // Philox4x32-10 and the box reverse (shared with the one-lane-per-walker sampler)
@@ -37,6 +39,27 @@ __device__ __forceinline__ float coef(R1 a, int) { return a.c0; }
 __device__ __forceinline__ float coef(R3 a, int k) { return k == 0 ? a.c0 : (k == 1 ? a.c1 : a.c2); }
 __device__ __forceinline__ R1 from_arr(R1*, const float* c) { return R1{c[0]}; }
 __device__ __forceinline__ R3 from_arr(R3*, const float* c) { return R3{c[0], c[1], c[2]}; }
+template <int D> __device__ __forceinline__ float coef(RF<D> a, int k) {
+    float r = a.c0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) r = k == i + 1 ? a.g[i] : r;
+    return k == D + 1 ? a.h : r;
+}
+template <int D> __device__ __forceinline__ RF<D> from_arr(RF<D>*, const float* c) {
+    RF<D> r;
+    r.c0 = c[0];
+#pragma unroll
+    for (int i = 0; i < D; ++i) r.g[i] = c[i + 1];
+    r.h = c[D + 1];
+    return r;
+}
+// componentwise map of a ring value
+template <class T, class F> __device__ __forceinline__ T map_coefs(T a, F f) {
+    float c[T::NC];
+#pragma unroll
+    for (int k = 0; k < T::NC; ++k) c[k] = f(coef(a, k));
+    return from_arr((T*)nullptr, c);
+}
 template <class T> __device__ __forceinline__ T sel(bool first, T a, T b) { return first ? a : b; }
 
 // ---- cross-lane: DPP butterflies inside a row of 16 lanes, the gfx950 permlane swaps across rows / halves
@@ -65,14 +88,17 @@ __device__ __forceinline__ float hsum(float v) {   // sum over the 32 lanes of t
 }
 __device__ __forceinline__ R1 half_sum(R1 a) { return R1{hsum(a.c0)}; }
 __device__ __forceinline__ R3 half_sum(R3 a) { return R3{hsum(a.c0), hsum(a.c1), hsum(a.c2)}; }
+template <int D> __device__ __forceinline__ RF<D> half_sum(RF<D> a) { return map_coefs(a, [](float v) { return hsum(v); }); }
 __device__ __forceinline__ R1 xhalf(R1 a) { return R1{swap32_other(a.c0)}; }
 __device__ __forceinline__ R3 xhalf(R3 a) { return R3{swap32_other(a.c0), swap32_other(a.c1), swap32_other(a.c2)}; }
+template <int D> __device__ __forceinline__ RF<D> xhalf(RF<D> a) { return map_coefs(a, [](float v) { return swap32_other(v); }); }
 template <class T> __device__ __forceinline__ T wave_sum(T a) {
     const T h = half_sum(a);
     return h + xhalf(h);
 }
 __device__ __forceinline__ R1 from_lane(R1 a, int src) { return R1{__shfl(a.c0, src)}; }
 __device__ __forceinline__ R3 from_lane(R3 a, int src) { return R3{__shfl(a.c0, src), __shfl(a.c1, src), __shfl(a.c2, src)}; }
+template <int D> __device__ __forceinline__ RF<D> from_lane(RF<D> a, int src) { return map_coefs(a, [src](float v) { return __shfl(v, src); }); }
 
 // ---- per-wave LDS vector [NC][64]
 template <class T> __device__ __forceinline__ void put(float (*buf)[64], int lane, T v) {
@@ -300,7 +326,7 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(WF_WAVE_OCC
                                                    float* __restrict__ ws, float* __restrict__ tails, int taped) {
     __shared__ float lds[kWaves][2][T::NC][64];
     const ModelDev& md = *mdp;
-    constexpr int DIRS = T::NC == 3 ? D : 1;
+    constexpr int DIRS = kDirs<T, D>;
     constexpr int P = (D + 1) / 2;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float (*vec)[64] = lds[wv][0];
@@ -322,7 +348,7 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(WF_WAVE_OCC
         float* tl = tails + s * (int64_t)Tail<D>::N * T::NC;
         T cur[D], nxt[D];
 #pragma unroll
-        for (int d = 0; d < D; ++d) cur[d] = make_var(tag, xg[b * D + d], d == dir);
+        for (int d = 0; d < D; ++d) cur[d] = make_var(tag, xg[b * D + d], d, dir);
         T logdet = cst<T>(0.0f);
         box_forward<D, T>(md, cur, logdet);
         for (int l = 0; l < md.n_layers; ++l) {
@@ -425,18 +451,19 @@ __device__ __forceinline__ T psi_from_tail(const float* tl, unsigned constrained
     return prod * E;
 }
 
-// ---- H psi = -1/2 laplacian + V psi per walker from the R3 tails of its D directions
-template <int D>
+// ---- H psi = -1/2 laplacian + V psi per walker from the R3 tails of its D directions, or from its one RF tail
+template <int D, class T>
 __global__ void k_energy_out(const float* __restrict__ tails, const float* __restrict__ xg, int64_t B, unsigned constrained_mask, const Protons pr,
                              float* __restrict__ hpsi, float* __restrict__ psi_out, float* __restrict__ lap_out) {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     float lap = 0.0f, psv = 0.0f;
+    constexpr int DIRS = kDirs<T, D>;
 #pragma unroll
-    for (int dir = 0; dir < D; ++dir) {
-        R3 v[D], E;
-        const R3 ps = psi_from_tail<D, R3>(tails + (b * D + dir) * (int64_t)Tail<D>::N * 3, constrained_mask, v, E);
-        lap += 2.0f * ps.c2;
+    for (int dir = 0; dir < DIRS; ++dir) {
+        T v[D], E;
+        const T ps = psi_from_tail<D, T>(tails + (b * DIRS + dir) * (int64_t)Tail<D>::N * T::NC, constrained_mask, v, E);
+        lap += lap_of(ps);
         psv = ps.c0;
     }
     float V = 0.0f;   // physics.py:60-76
@@ -508,7 +535,7 @@ __global__ void k_tail_out(const float* __restrict__ tails, int64_t B, int mode,
 
 // ---- the same, continued to the weights of loss_fn_efficient's tangent rule (k_vqmc_seeds, wf_kernels_grad.hip): the fused
 // training step needs neither H psi nor psi in memory
-template <int D>
+template <int D, class T>
 __global__ void k_energy_seeds(const float* __restrict__ tails, const float* __restrict__ xg, int64_t B, unsigned constrained_mask, const Protons pr,
                                float running_avg, const float* __restrict__ running_avg_dev, float inv_count, float* __restrict__ e_loc,
                                float* __restrict__ w_psi, float* __restrict__ w_lap) {
@@ -516,11 +543,12 @@ __global__ void k_energy_seeds(const float* __restrict__ tails, const float* __r
     if (b >= B) return;
     if (running_avg_dev) running_avg = *running_avg_dev;
     float lap = 0.0f, ps = 0.0f;
+    constexpr int DIRS = kDirs<T, D>;
 #pragma unroll
-    for (int dir = 0; dir < D; ++dir) {
-        R3 v[D], E;
-        const R3 p3 = psi_from_tail<D, R3>(tails + (b * D + dir) * (int64_t)Tail<D>::N * 3, constrained_mask, v, E);
-        lap += 2.0f * p3.c2;
+    for (int dir = 0; dir < DIRS; ++dir) {
+        T v[D], E;
+        const T p3 = psi_from_tail<D, T>(tails + (b * DIRS + dir) * (int64_t)Tail<D>::N * T::NC, constrained_mask, v, E);
+        lap += lap_of(p3);
         ps = p3.c0;
     }
     float V = 0.0f;   // physics.py:60-76
@@ -569,7 +597,7 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(WF_WAVE_OCC
                                                    float* __restrict__ ws, const float* __restrict__ tails) {
     __shared__ float lds[kWaves][2][T::NC][64];
     const ModelDev& md = *mdp;
-    constexpr int DIRS = T::NC == 3 ? D : 1;
+    constexpr int DIRS = kDirs<T, D>;
     constexpr int P = (D + 1) / 2;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float (*vec)[64] = lds[wv][0];
@@ -1022,21 +1050,21 @@ unsigned wave_grid(int64_t n_samples) {
 template <int D, class T>
 int run_fwd(const ModelDev* md_dev, const float* tabI4, const float* tabP4, const float* fk_nat, const float* x, int64_t B, float* ws, float* tails,
             int taped, hipStream_t s) {
-    const int64_t n_samples = B * (T::NC == 3 ? D : 1);
+    const int64_t n_samples = B * kDirs<T, D>;
     hipLaunchKernelGGL((k_wave_fwd<D, T>), dim3(wave_grid(n_samples)), dim3(kWB), 0, s, md_dev, tabI4, tabP4, fk_nat, x, B, ws, tails, taped);
     return finish();
 }
 template <int D, class T>
 int run_bwd(const ModelDev* md_dev, int mode, const float* tabI4, const float* tabP4, const float* fk_nat, int64_t B, const float* w1, const float* w2,
             float* ws, const float* tails, hipStream_t s) {
-    const int64_t n_samples = B * (T::NC == 3 ? D : 1);
+    const int64_t n_samples = B * kDirs<T, D>;
     hipLaunchKernelGGL((k_wave_bwd<D, T>), dim3(wave_grid(n_samples)), dim3(kWB), 0, s, md_dev, mode, tabI4, tabP4, fk_nat, B, w1, w2, ws, tails);
     return finish();
 }
 
 }  // namespace
 
-int64_t wave_tail_floats(int D, int second_order) { return (int64_t)(2 * D + 1) * (second_order ? 3 * D : 1); }   // per walker
+int64_t wave_tail_floats(int D, int ring_kind) { return (int64_t)(2 * D + 1) * ring_coefs(D, ring_kind) * ring_samples(D, ring_kind); }   // per walker
 
 #define WF_WAVE_DISPATCH(CALL)                    \
     switch (md.D) {                               \
@@ -1050,20 +1078,22 @@ int64_t wave_tail_floats(int D, int second_order) { return (int64_t)(2 * D + 1) 
         default: return WF_ERR_UNSUPPORTED;       \
     }
 
-int launch_wave_fwd(const ModelDev& md, const ModelDev* md_dev, int second_order, const float* tabI4, const float* tabP4, const float* fk_nat,
+int launch_wave_fwd(const ModelDev& md, const ModelDev* md_dev, int ring_kind, const float* tabI4, const float* tabP4, const float* fk_nat,
                     const float* x, int64_t B, float* ws, float* tails, int taped, void* stream) {
     hipStream_t s = (hipStream_t)stream;
-#define CALL(DD) (second_order ? run_fwd<DD, R3>(md_dev, tabI4, tabP4, fk_nat, x, B, ws, tails, taped, s) \
-                               : run_fwd<DD, R1>(md_dev, tabI4, tabP4, fk_nat, x, B, ws, tails, taped, s))
+#define CALL(DD) (ring_kind == 2 ? run_fwd<DD, RF<DD>>(md_dev, tabI4, tabP4, fk_nat, x, B, ws, tails, taped, s)  \
+                  : ring_kind == 1 ? run_fwd<DD, R3>(md_dev, tabI4, tabP4, fk_nat, x, B, ws, tails, taped, s) \
+                                   : run_fwd<DD, R1>(md_dev, tabI4, tabP4, fk_nat, x, B, ws, tails, taped, s))
     WF_WAVE_DISPATCH(CALL)
 #undef CALL
 }
 
-int launch_wave_bwd(const ModelDev& md, const ModelDev* md_dev, int mode, int second_order, const float* tabI4, const float* tabP4,
+int launch_wave_bwd(const ModelDev& md, const ModelDev* md_dev, int mode, int ring_kind, const float* tabI4, const float* tabP4,
                     const float* fk_nat, int64_t B, const float* w1, const float* w2, float* ws, const float* tails, void* stream) {
     hipStream_t s = (hipStream_t)stream;
-#define CALL(DD) (second_order ? run_bwd<DD, R3>(md_dev, mode, tabI4, tabP4, fk_nat, B, w1, w2, ws, tails, s) \
-                               : run_bwd<DD, R1>(md_dev, mode, tabI4, tabP4, fk_nat, B, w1, w2, ws, tails, s))
+#define CALL(DD) (ring_kind == 2 ? run_bwd<DD, RF<DD>>(md_dev, mode, tabI4, tabP4, fk_nat, B, w1, w2, ws, tails, s)  \
+                  : ring_kind == 1 ? run_bwd<DD, R3>(md_dev, mode, tabI4, tabP4, fk_nat, B, w1, w2, ws, tails, s) \
+                                   : run_bwd<DD, R1>(md_dev, mode, tabI4, tabP4, fk_nat, B, w1, w2, ws, tails, s))
     WF_WAVE_DISPATCH(CALL)
 #undef CALL
 }
@@ -1091,45 +1121,42 @@ int launch_wave_sample(const ModelDev& md, const ModelDev* md_dev, const float* 
     return finish();
 }
 
-int launch_energy_out(int D, const float* tails, const float* x, int64_t B, unsigned constrained_mask, const Protons& pr, float* hpsi, float* psi,
-                      float* lap, void* stream) {
+#define WF_RING2_DISPATCH(KERNEL, ...)                                                             \
+    switch (D) {                                                                                   \
+        case 2: WF_RING2_CASE(KERNEL, 2, __VA_ARGS__);                                             \
+        case 3: WF_RING2_CASE(KERNEL, 3, __VA_ARGS__);                                             \
+        case 4: WF_RING2_CASE(KERNEL, 4, __VA_ARGS__);                                             \
+        case 5: WF_RING2_CASE(KERNEL, 5, __VA_ARGS__);                                             \
+        case 6: WF_RING2_CASE(KERNEL, 6, __VA_ARGS__);                                             \
+        case 7: WF_RING2_CASE(KERNEL, 7, __VA_ARGS__);                                             \
+        case 8: WF_RING2_CASE(KERNEL, 8, __VA_ARGS__);                                             \
+        default: return WF_ERR_UNSUPPORTED;                                                        \
+    }
+#define WF_RING2_CASE(KERNEL, DD, ...)                                                             \
+    if (ring_kind == 2) hipLaunchKernelGGL((KERNEL<DD, RF<DD>>), grid, block, 0, s, __VA_ARGS__);  \
+    else hipLaunchKernelGGL((KERNEL<DD, R3>), grid, block, 0, s, __VA_ARGS__);                     \
+    break
+
+int launch_energy_out(int D, int ring_kind, const float* tails, const float* x, int64_t B, unsigned constrained_mask, const Protons& pr, float* hpsi,
+                      float* psi, float* lap, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)((B + 255) / 256)), block(256);
-    switch (D) {
-        case 2: hipLaunchKernelGGL(k_energy_out<2>, grid, block, 0, s, tails, x, B, constrained_mask, pr, hpsi, psi, lap); break;
-        case 3: hipLaunchKernelGGL(k_energy_out<3>, grid, block, 0, s, tails, x, B, constrained_mask, pr, hpsi, psi, lap); break;
-        case 4: hipLaunchKernelGGL(k_energy_out<4>, grid, block, 0, s, tails, x, B, constrained_mask, pr, hpsi, psi, lap); break;
-        case 5: hipLaunchKernelGGL(k_energy_out<5>, grid, block, 0, s, tails, x, B, constrained_mask, pr, hpsi, psi, lap); break;
-        case 6: hipLaunchKernelGGL(k_energy_out<6>, grid, block, 0, s, tails, x, B, constrained_mask, pr, hpsi, psi, lap); break;
-        case 7: hipLaunchKernelGGL(k_energy_out<7>, grid, block, 0, s, tails, x, B, constrained_mask, pr, hpsi, psi, lap); break;
-        case 8: hipLaunchKernelGGL(k_energy_out<8>, grid, block, 0, s, tails, x, B, constrained_mask, pr, hpsi, psi, lap); break;
-        default: return WF_ERR_UNSUPPORTED;
-    }
+    if (ring_kind != 1 && ring_kind != 2) return WF_ERR_INVALID;
+    WF_RING2_DISPATCH(k_energy_out, tails, x, B, constrained_mask, pr, hpsi, psi, lap)
     return finish();
 }
 
-int launch_energy_seeds(int D, const float* tails, const float* x, int64_t B, unsigned constrained_mask, const Protons& pr, float running_avg,
+int launch_energy_seeds(int D, int ring_kind, const float* tails, const float* x, int64_t B, unsigned constrained_mask, const Protons& pr, float running_avg,
                         const float* running_avg_dev, float inv_count, float* e_loc, float* w_psi, float* w_lap, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)((B + 255) / 256)), block(256);
-#define CALL(DD) hipLaunchKernelGGL(k_energy_seeds<DD>, grid, block, 0, s, tails, x, B, constrained_mask, pr, running_avg, running_avg_dev, \
-                                    inv_count, e_loc, w_psi, w_lap); break
-    switch (D) {
-        case 2: CALL(2);
-        case 3: CALL(3);
-        case 4: CALL(4);
-        case 5: CALL(5);
-        case 6: CALL(6);
-        case 7: CALL(7);
-        case 8: CALL(8);
-        default: return WF_ERR_UNSUPPORTED;
-    }
-#undef CALL
+    if (ring_kind != 1 && ring_kind != 2) return WF_ERR_INVALID;
+    WF_RING2_DISPATCH(k_energy_seeds, tails, x, B, constrained_mask, pr, running_avg, running_avg_dev, inv_count, e_loc, w_psi, w_lap)
     return finish();
 }
+#undef WF_RING2_CASE
+#undef WF_RING2_DISPATCH
 
-// log_pdf / psi / flow of B walkers through the wave kernel (low latency for small batches); tail_ws: wave_tail_floats(D, 0) * B
-// log_pdf / psi / log det (+ latent point) of B walkers from their first-order tails
 int launch_tail_out(const ModelDev& md, int mode, const float* tails, int64_t B, float* out, float* u, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)((B + 255) / 256)), block(256);
@@ -1155,12 +1182,16 @@ int launch_wave_eval(const ModelDev& md, const ModelDev* md_dev, const float* ta
     return launch_tail_out(md, mode, tail_ws, B, out, u, stream);
 }
 
-// H psi, psi, laplacian of B walkers: forward in R3 without a tape, then the per-walker combination
+// H psi, psi, laplacian of B walkers: forward without a tape, then the per-walker combination.  The forward sweep carries
+// (value, gradient, Laplacian / 2) per walker (RF: D + 2 channels, one pass) -- measured 1.6-1.8x faster than D passes in R3
+// (3 channels each) for every D = 2..8 (scratch/energy_ab.py).
 int launch_wave_energy(const ModelDev& md, const ModelDev* md_dev, const float* tabI4, const float* tabP4, const float* fk_nat, const float* x,
                        int64_t B, const Protons& pr, float* hpsi, float* psi, float* lap, float* tail_ws, void* stream) {
-    int rc = launch_wave_fwd(md, md_dev, 1, tabI4, tabP4, fk_nat, x, B, nullptr, tail_ws, 0, stream);
+    const bool force_r3 = getenv("WF_ENERGY_R3") != nullptr;   // A/B switch, read per call (tests compare the two sweeps)
+    const int kind = force_r3 ? 1 : 2;
+    int rc = launch_wave_fwd(md, md_dev, kind, tabI4, tabP4, fk_nat, x, B, nullptr, tail_ws, 0, stream);
     if (rc) return rc;
-    return launch_energy_out(md.D, tail_ws, x, B, md.constrained_mask, pr, hpsi, psi, lap, stream);
+    return launch_energy_out(md.D, kind, tail_ws, x, B, md.constrained_mask, pr, hpsi, psi, lap, stream);
 }
 
 }  // namespace wf

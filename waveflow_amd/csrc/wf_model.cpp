@@ -95,6 +95,7 @@ struct wf_model {
     float* d_grad_fk = nullptr;      // [2][64] natural-order row factors for the reverse pass (flow rows, prior rows)
     bool wave_ok = false;            // the wave-cooperative kernels cover this model (<= 32 bases, zero-only constraints)
     bool grad_psi_ok = false;        // wf_psi_vjp (Waveflow prior, IMADE layers)
+    int ring2 = 2;                   // coefficient ring of the second-order sweeps (ring_coefs, wf_internal.h): 2 = RF, 1 = R3
     int32_t* d_grad_map = nullptr;   // [n_params]: forward-image entry (over all nets) that holds each parameter, -1 = none
     float* d_grad_partial = nullptr; // per-split partial gradient images of k_wgrad
     float* d_grad_img = nullptr;     // [n_nets * fwd image floats]: gradient accumulator in forward-image layout
@@ -174,6 +175,7 @@ static int grad_prepare(wf_model* m);
 static int64_t wave_net_floats(int D);
 }  // namespace wf
 static int ensure_scratch(const wf_model* cm, int64_t floats);
+static constexpr int kTapedLaplacianMaxD = 8;    // largest D whose reverse sweep runs in RF (measured, scratch/grad_ab.py)
 static constexpr int64_t kWaveEvalMax = 6144;   // measured crossover ~7000 walkers (scratch/crossover.py)
 namespace wf {
 
@@ -766,6 +768,9 @@ static int grad_prepare(wf_model* m) {
     }
     if (!grad_capable(m) || m->n_params >= (1 << 24)) return WF_OK;
     m->grad_psi_ok = d.prior_kind == WF_PRIOR_WAVEFLOW && (d.layer_kind == WF_LAYER_IMADE || d.n_flow_layers == 0);
+    // One taped sample per walker in RF (value, gradient, Laplacian / 2: D + 2 channels), or D samples in R3 (3 channels each).
+    // Fixed per model, because workspace sizes depend on it; WF_GRAD_R3 (read here) selects R3 for A/B tests.
+    m->ring2 = (getenv("WF_GRAD_R3") || D > kTapedLaplacianMaxD) ? 1 : 2;
     const int n_nets = (int)m->nets.size();
     const int64_t fwd = plain_fwd_floats(D, m->nbp);
     // the plain description lists net n's forward-orientation entries first (plain_net_floats per net)
@@ -1080,8 +1085,9 @@ int wf_hamiltonian_fwd(const wf_model* m, const float* x_dev, int64_t B, const f
 // workspace of the reverse pass per walker: tape + tails of its samples, plus 4 floats (H psi, psi, w_psi, w_lap)
 static int64_t vjp_bytes_per_walker(const wf_model* m, bool second_order) {
     const int D = m->desc.n_dim;
-    const int64_t samples = second_order ? D : 1, nc = second_order ? 3 : 1;
-    return (samples * ((int64_t)m->nets.size() * grad_ws_rows(D) * nc) + wave_tail_floats(D, second_order ? 1 : 0) + 4) * (int64_t)sizeof(float);
+    const int kind = second_order ? m->ring2 : 0;
+    const int64_t samples = ring_samples(D, kind), nc = ring_coefs(D, kind);
+    return (samples * ((int64_t)m->nets.size() * grad_ws_rows(D) * nc) + wave_tail_floats(D, kind) + 4) * (int64_t)sizeof(float);
 }
 
 static int64_t vjp_ws_bytes(const wf_model* m, int64_t B, bool second_order) {
@@ -1105,10 +1111,11 @@ static int run_vjp_chunks(const wf_model* m, int mode, bool second_order, const 
     const int n_nets = (int)m->nets.size();
     const int64_t fwd = plain_fwd_floats(D, m->nbp);
     const int64_t n_img = fwd * n_nets;
-    const int64_t samples_per = second_order ? D : 1, nc = second_order ? 3 : 1;
+    const int kind = second_order ? m->ring2 : 0;
+    const int64_t samples_per = ring_samples(D, kind), nc = ring_coefs(D, kind);
     float* tape = (float*)workspace_dev;
     float* tails = tape + chunk * samples_per * n_nets * grad_ws_rows(D) * nc;
-    float* per_walker = tails + chunk * wave_tail_floats(D, second_order ? 1 : 0);   // [4][chunk]
+    float* per_walker = tails + chunk * wave_tail_floats(D, kind);   // [4][chunk]
     if (B == 0) {   // the gradient of an empty batch is zero
         WF_HIP(hipMemsetAsync(grad_dev, 0, (size_t)m->n_params * sizeof(float), s));
         return WF_OK;
@@ -1118,12 +1125,12 @@ static int run_vjp_chunks(const wf_model* m, int mode, bool second_order, const 
     for (int64_t c0 = 0; c0 < B; c0 += chunk) {
         const int64_t bc = std::min(chunk, B - c0);
         const float* x = x_dev + c0 * D;
-        int rc = launch_wave_fwd(m->dev, m->d_dev, second_order ? 1 : 0, m->d_tabI4, m->d_tabP3, m->d_grad_fk, x, bc, tape, tails, 1, stream);
+        int rc = launch_wave_fwd(m->dev, m->d_dev, kind, m->d_tabI4, m->d_tabP3, m->d_grad_fk, x, bc, tape, tails, 1, stream);
         if (rc) return rc;
         const float *cw1 = w1 ? w1 + c0 : nullptr, *cw2 = w2 ? w2 + c0 : nullptr;
         if (mode == 2) {
             float *wp = per_walker + 2 * chunk, *wl = per_walker + 3 * chunk;
-            rc = launch_energy_seeds(D, tails, x, bc, m->dev.constrained_mask, *pr, running_average, running_average_dev, inv_count,
+            rc = launch_energy_seeds(D, kind, tails, x, bc, m->dev.constrained_mask, *pr, running_average, running_average_dev, inv_count,
                                      e_loc_dev + c0, wp, wl, stream);
             if (rc) return rc;
             cw1 = wp;
@@ -1137,10 +1144,10 @@ static int run_vjp_chunks(const wf_model* m, int mode, bool second_order, const 
             if (rc) return rc;
             cw1 = wp;
         }
-        rc = launch_wave_bwd(m->dev, m->d_dev, (mode == 0 || mode == 3) ? 0 : 1, second_order ? 1 : 0, m->d_tabI4, m->d_tabP3, m->d_grad_fk, bc, cw1, cw2, tape,
+        rc = launch_wave_bwd(m->dev, m->d_dev, (mode == 0 || mode == 3) ? 0 : 1, kind, m->d_tabI4, m->d_tabP3, m->d_grad_fk, bc, cw1, cw2, tape,
                              tails, stream);
         if (rc) return rc;
-        rc = launch_wgrad(D, second_order ? 1 : 0, n_nets, bc * samples_per, tape, m->d_grad_partial, c0 > 0, m->d_grad_img, fwd,
+        rc = launch_wgrad(D, kind, n_nets, bc * samples_per, tape, m->d_grad_partial, c0 > 0, m->d_grad_img, fwd,
                           single ? &split : nullptr, stream);
         if (rc) return rc;
     }

@@ -3,8 +3,16 @@
 // R3 = IR[t]/t^3 holds the Taylor coefficients a0 + a1 t + a2 t^2 of a quantity along one coordinate direction
 // x + t e_i (psi'' along e_i = 2 psi_2); R1 = IR is the first-order case.  Adjoints are kept in REVERSED coefficient order,
 // which makes the adjoint of a ring product a ring product (see wf_kernels_wave.hip).
+// RF<D> = (value, gradient, half the Laplacian) with respect to the D coordinates of a walker: the commutative algebra
+// IR[t_1..t_D] / (t_i t_j (i != j), t_i^2 - t_1^2, t^3) with basis 1, t_1..t_D, s = t_i^2 -- the second-order jet of a function
+// projected to what the Laplacian needs.  The sum over the D directions of the R3 second-order coefficients is carried as one
+// number, the value channel and the weight loads are shared.  Like R3 it is a Frobenius algebra (the pairing <a, b> = top
+// coefficient of a b is non-degenerate: 1 <-> s, t_i <-> t_i), so the same reverse sweep works with adjoints stored under that
+// pairing: value and top slot exchanged, gradient slots in place.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 
 #include "wf_internal.h"
 
@@ -30,9 +38,21 @@ struct R3 {
     float c0, c1, c2;
     static constexpr int NC = 3;
 };
-template <class T> __device__ __forceinline__ T cst(float c);
-template <> __device__ __forceinline__ R1 cst<R1>(float c) { return R1{c}; }
-template <> __device__ __forceinline__ R3 cst<R3>(float c) { return R3{c, 0.0f, 0.0f}; }
+template <int D> struct RF {
+    float c0, g[D], h;   // h = laplacian / 2, the coefficient of s
+    static constexpr int NC = D + 2;
+};
+__device__ __forceinline__ R1 make_cst(R1*, float c) { return R1{c}; }
+__device__ __forceinline__ R3 make_cst(R3*, float c) { return R3{c, 0.0f, 0.0f}; }
+template <int D> __device__ __forceinline__ RF<D> make_cst(RF<D>*, float c) {
+    RF<D> r;
+    r.c0 = c;
+#pragma unroll
+    for (int i = 0; i < D; ++i) r.g[i] = 0.0f;
+    r.h = 0.0f;
+    return r;
+}
+template <class T> __device__ __forceinline__ T cst(float c) { return make_cst((T*)nullptr, c); }
 __device__ __forceinline__ R1 operator+(R1 a, R1 b) { return R1{a.c0 + b.c0}; }
 __device__ __forceinline__ R1 operator-(R1 a, R1 b) { return R1{a.c0 - b.c0}; }
 __device__ __forceinline__ R1 operator+(R1 a, float c) { return R1{a.c0 + c}; }
@@ -49,7 +69,50 @@ __device__ __forceinline__ R3 operator*(R3 a, float c) { return R3{a.c0 * c, a.c
 __device__ __forceinline__ R3 operator*(R3 a, R3 b) {
     return R3{a.c0 * b.c0, a.c1 * b.c0 + a.c0 * b.c1, a.c2 * b.c0 + a.c1 * b.c1 + a.c0 * b.c2};
 }
+// RF: componentwise linear maps; products and compositions by the Leibniz / chain rules of gradient and Laplacian
+template <int D, class F> __device__ __forceinline__ RF<D> rf_zip(RF<D> a, RF<D> b, F f) {
+    RF<D> r;
+    r.c0 = f(a.c0, b.c0);
+#pragma unroll
+    for (int i = 0; i < D; ++i) r.g[i] = f(a.g[i], b.g[i]);
+    r.h = f(a.h, b.h);
+    return r;
+}
+template <int D> __device__ __forceinline__ RF<D> operator+(RF<D> a, RF<D> b) { return rf_zip(a, b, [](float x, float y) { return x + y; }); }
+template <int D> __device__ __forceinline__ RF<D> operator-(RF<D> a, RF<D> b) { return rf_zip(a, b, [](float x, float y) { return x - y; }); }
+template <int D> __device__ __forceinline__ RF<D> operator*(RF<D> a, float c) { return rf_zip(a, a, [c](float x, float) { return x * c; }); }
+template <int D> __device__ __forceinline__ RF<D> operator+(RF<D> a, float c) { a.c0 = a.c0 + c; return a; }
+template <int D> __device__ __forceinline__ RF<D> operator-(RF<D> a, float c) { a.c0 = a.c0 - c; return a; }
+template <int D> __device__ __forceinline__ RF<D> operator-(float c, RF<D> a) {
+    RF<D> r = rf_zip(a, a, [](float x, float) { return -x; });
+    r.c0 = c - a.c0;
+    return r;
+}
+template <int D> __device__ __forceinline__ RF<D> operator*(RF<D> a, RF<D> b) {
+    RF<D> r;
+    r.c0 = a.c0 * b.c0;
+    float dot = 0.0f;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        r.g[i] = a.g[i] * b.c0 + a.c0 * b.g[i];
+        dot += a.g[i] * b.g[i];
+    }
+    r.h = a.h * b.c0 + a.c0 * b.h + dot;
+    return r;
+}
 // f(a) from f, f', f'' at a.c0
+template <int D> __device__ __forceinline__ RF<D> lift_fn(RF<D> a, float f, float f1, float f2) {
+    RF<D> r;
+    r.c0 = f;
+    float n2 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        r.g[i] = f1 * a.g[i];
+        n2 += a.g[i] * a.g[i];
+    }
+    r.h = f1 * a.h + 0.5f * f2 * n2;
+    return r;
+}
 __device__ __forceinline__ R1 lift_fn(R1, float f, float, float) { return R1{f}; }
 __device__ __forceinline__ R3 lift_fn(R3 a, float f, float f1, float f2) { return R3{f, f1 * a.c1, f1 * a.c2 + 0.5f * f2 * a.c1 * a.c1}; }
 // Elementary functions through the hardware transcendentals (v_rcp / v_rsq / v_exp / v_log, 1 ulp): the derivative sweeps
@@ -83,13 +146,28 @@ template <class T> __device__ __forceinline__ T rsigmoid(T a) {
     return lift_fn(a, s, g, g * (1.0f - 2.0f * s));
 }
 // the coordinate x_d along direction `dir`; adjoint seed of the value coefficient (reversed order: last slot)
-__device__ __forceinline__ R1 make_var(R1*, float x, bool) { return R1{x}; }
-__device__ __forceinline__ R3 make_var(R3*, float x, bool along) { return R3{x, along ? 1.0f : 0.0f, 0.0f}; }
+__device__ __forceinline__ R1 make_var(R1*, float x, int, int) { return R1{x}; }
+__device__ __forceinline__ R3 make_var(R3*, float x, int d, int dir) { return R3{x, d == dir ? 1.0f : 0.0f, 0.0f}; }
+template <int D> __device__ __forceinline__ RF<D> make_var(RF<D>*, float x, int d, int) {
+    RF<D> r = make_cst((RF<D>*)nullptr, x);
+#pragma unroll
+    for (int i = 0; i < D; ++i) r.g[i] = i == d ? 1.0f : 0.0f;
+    return r;
+}
+// Laplacian carried by psi: the sum over the directions of 2 psi_2 (R3), or the last component (RF)
+__device__ __forceinline__ float lap_of(R3 a) { return 2.0f * a.c2; }
+template <int D> __device__ __forceinline__ float lap_of(RF<D> a) { return 2.0f * a.h; }
 __device__ __forceinline__ R1 adj_value(R1*, float w) { return R1{w}; }
 __device__ __forceinline__ R3 adj_value(R3*, float w) { return R3{0.0f, 0.0f, w}; }
 // ... and of the second-derivative along the direction (psi'' = 2 psi_2)
 __device__ __forceinline__ R1 adj_second(R1*, float) { return R1{0.0f}; }
 __device__ __forceinline__ R3 adj_second(R3*, float w) { return R3{2.0f * w, 0.0f, 0.0f}; }
+template <int D> __device__ __forceinline__ RF<D> adj_value(RF<D>*, float w) {
+    RF<D> r = make_cst((RF<D>*)nullptr, 0.0f);
+    r.h = w;
+    return r;
+}
+template <int D> __device__ __forceinline__ RF<D> adj_second(RF<D>*, float w) { return make_cst((RF<D>*)nullptr, 2.0f * w); }   // laplacian = 2 h
 
 // ---- table lerp (same index arithmetic as the evaluation kernels) and its ring lift
 struct Lerp {
@@ -120,6 +198,12 @@ __device__ __forceinline__ R3 lift(const float (&t)[4], int nd, R3 u) {
     const float t0 = t[min(nd, 3)], t1 = t[min(nd + 1, 3)], t2 = t[min(nd + 2, 3)];
     return R3{t0, t1 * u.c1, t1 * u.c2 + 0.5f * t2 * u.c1 * u.c1};
 }
+
+template <int D> __device__ __forceinline__ RF<D> lift(const float (&t)[4], int nd, RF<D> u) {
+    return lift_fn(u, t[min(nd, 3)], t[min(nd + 1, 3)], t[min(nd + 2, 3)]);
+}
+// samples per walker of a ring: D directions in R3, one otherwise
+template <class T, int D> constexpr int kDirs = std::is_same<T, R3>::value ? D : 1;
 
 }  // namespace ring
 }  // namespace wf
