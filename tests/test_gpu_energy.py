@@ -105,3 +105,35 @@ def test_forward_laplacian_sweep_matches_directional_sweeps(D, monkeypatch):
     assert np.isfinite(lf).all() and np.abs(lf).max() > 0
     assert np.linalg.norm(lf - l3) <= 1e-4 * np.linalg.norm(l3), np.linalg.norm(lf - l3) / np.linalg.norm(l3)
     assert np.linalg.norm(hf - h3) <= 1e-4 * np.linalg.norm(h3)
+
+
+def test_laplacian_where_the_prior_output_sum_vanishes():
+    """A walker met in a batch-4096 He run (scratch/nan_hunt3.py wrote the fixture: parameters of step 111, one walker): the raw
+    outputs of the prior conditioner for dimension 1 sum to 2.6e-7.  The reference divides by that sum before it L2-normalises
+    (model_factory.py:69, bsplines_jax.py:130); in fp32 the quotient form gives a Laplacian of -5e2 (torch oracle) to -7e3 or NaN,
+    the true value (fp64 oracle) is 0.088.  The kernels evaluate the equivalent sign form and stay at the fp64 value."""
+    import os
+    import torch
+    from conftest import GOLDEN
+    from oracle import energy_torch as et
+    from waveflow_amd import checkpoint, model_factory
+    z = np.load(os.path.join(GOLDEN, "he_prior_sum_zero.npz"))
+    init_fun = model_factory.get_waveflow_model(2, base_spline_degree=6, i_spline_degree=6, n_prior_internal_knots=23,
+                                                n_i_internal_knots=23, i_spline_reg=0.05, n_flow_layers=3, box_size=10)
+    params, psi, log_pdf, sample = init_fun(0, 2)
+    params = checkpoint.unflatten_like(params, z["flat"])
+    m = psi.model
+    m.ensure_params(params)
+    x = np.repeat(z["x"], 64, 0)
+    protons = np.zeros(2)
+    h64, p64, l64 = et.hamiltonian(et.he_model(torch.float64), z["flat"], z["x"].astype(np.float64), protons)
+    assert abs(l64[0]) < 1.0
+    h, ps, lap = m.hamiltonian(x, protons, return_psi=True, return_laplacian=True)
+    # (the sign of psi is the sign of that sum -- noise at this point, and the local energy does not depend on it)
+    assert np.isfinite(h).all() and np.abs(lap / ps - l64[0] / p64[0]).max() < 5e-2 * abs(l64[0] / p64[0]), (lap[0], ps[0], l64[0], p64[0])
+    np.testing.assert_allclose(np.abs(ps), abs(p64[0]), rtol=1e-4)
+    np.testing.assert_allclose(h / ps, h64[0] / p64[0], rtol=5e-2)
+    sums, grad = m.vqmc_loss_grad(x, protons, -1.0)
+    assert torch.isfinite(grad).all() and np.isfinite(sums.cpu().numpy()).all()
+    el = h / (ps + 1e-8)
+    np.testing.assert_allclose(sums.cpu().numpy()[0] / 64, el.astype(np.float64).mean(), rtol=1e-3)

@@ -250,18 +250,21 @@ __device__ __forceinline__ T sigmoid_head_bwd(const SigHead<T>& h, T gc, bool va
     return valid ? ((gw0 - dot0) * h.rS0) * (h.p * (1.0f - h.p)) : cst<T>(0.0f);
 }
 
-// psi head lane state (wavefunctions.py:54-71, bsplines_jax.py:127-137 with zero-only constraints)
+// psi head lane state (wavefunctions.py:54-71, bsplines_jax.py:127-137 with zero-only constraints).  The reference divides the
+// raw outputs by their sum S (model_factory.py:69) before the boundary rows are zeroed and the vector is L2-normalised; the
+// scale cancels in that normalisation, only sign(S) survives: a = sign(S) (o keep) / |o keep|.  Evaluated in that form: S is a
+// signed sum that passes through zero (a walker of a 4096-batch He run had S = 2.6e-7), where the quotient form turns fp32
+// rounding into Laplacians of 1e3..inf while the function itself is smooth.
 template <class T> struct PsiHead {
-    T o, rS, rN1, rN2, a, e;
+    T o, rN1, rN2, a, e;
+    float sgn;
 };
 template <class T>
 __device__ __forceinline__ PsiHead<T> psi_head(T o, bool valid, bool valid_d, float keep, const float* __restrict__ o2b, float (*ov)[64], int lane) {
     PsiHead<T> h;
     h.o = valid ? o : cst<T>(0.0f);
-    T S = half_sum(h.o);
-    if (!valid_d) S = cst<T>(1.0f);
-    h.rS = rrcp(S);
-    const T w = (h.o * h.rS) * (valid ? keep : 0.0f);
+    h.sgn = hsum(h.o.c0) < 0.0f ? -1.0f : 1.0f;
+    const T w = h.o * (valid ? keep * h.sgn : 0.0f);
     T N1 = half_sum(w * w);
     if (!valid_d) N1 = cst<T>(1.0f);
     h.rN1 = rrsqrt(N1);
@@ -686,9 +689,7 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(WF_WAVE_OCC
                     put(ov, lane, gc);
                     const T ga = gemv32_rows<T>(md.ob_to_b, ov, dl, j);          // abar_a = sum_j cbar_j ob_to_b[a][j]
                     const T dotA = half_sum(ga * hd.a);
-                    const T gw = ((ga - hd.a * dotA) * hd.rN1) * (valid ? kP[j] : 0.0f);
-                    const T dotW = half_sum(gw * (hd.o * hd.rS));
-                    go = valid ? (gw - dotW) * hd.rS : cst<T>(0.0f);
+                    go = ((ga - hd.a * dotA) * hd.rN1) * (valid ? kP[j] * hd.sgn : 0.0f);
                 } else {
                     const SigHead<T> hd = sigmoid_head(o, valid, valid_d, kP[j], 0.0f);
                     d1 = half_sum(hd.c * lift(t, 1, uc));

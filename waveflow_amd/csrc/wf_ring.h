@@ -104,13 +104,13 @@ template <int D> __device__ __forceinline__ RF<D> operator*(RF<D> a, RF<D> b) {
 template <int D> __device__ __forceinline__ RF<D> lift_fn(RF<D> a, float f, float f1, float f2) {
     RF<D> r;
     r.c0 = f;
-    float n2 = 0.0f;
+    float q = 0.0f;   // f2 |g|^2, with f2 inside the squares (as in R3: a vanishing f2 meets a large g without overflow)
 #pragma unroll
     for (int i = 0; i < D; ++i) {
         r.g[i] = f1 * a.g[i];
-        n2 += a.g[i] * a.g[i];
+        q += (f2 * a.g[i]) * a.g[i];
     }
-    r.h = f1 * a.h + 0.5f * f2 * n2;
+    r.h = f1 * a.h + 0.5f * q;
     return r;
 }
 __device__ __forceinline__ R1 lift_fn(R1, float f, float, float) { return R1{f}; }
