@@ -16,6 +16,9 @@
 // top coefficient (ybar~ * a)_2.  The table lerp keeps the reference's derivative rule (the derivative of the order-nd
 // lerp is the order-(nd+1) lerp, isplines_jax.py:60-66, bsplines_jax.py:32-38); the reference reaches order 4 in this
 // sweep and JAX clamps that traced index to the last cached table (order 3) -- so does ring::lift().
+// The sweeps run by default over RF<D> (wf_ring.h): value, gradient and Laplacian / 2 of every intermediate with respect to the D
+// coordinates -- the D directional jets with their common parts shared.  It is a Frobenius algebra like R3 (pairing = top coefficient
+// of the product), so everything above holds with "reversed order" read as "value and top slot exchanged, gradient slots in place".
 // The same sweep over IR itself (ring R1) gives first-order objectives: sum_b w[b] d log_pdf_b / d theta for every model
 // the library evaluates (IMADE / MADE layers; Waveflow, M-spline, Normal, Uniform priors) -- the maximum-likelihood
 // gradient of benchmark_tests.train_model (benchmark_tests.py:84-101).

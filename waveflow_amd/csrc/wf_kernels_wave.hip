@@ -1,6 +1,6 @@
 // wf_kernels_wave.hip -- wave-cooperative ring kernels: local energy and parameter gradients, gfx950.
 //
-// One WAVE evaluates one sample (a walker, or a (walker, direction) pair in the second-order ring R3 -- wf_ring.h); its 64
+// One WAVE evaluates one sample (a walker in R1 / RF, or a (walker, direction) pair in the second-order ring R3 -- wf_ring.h); its 64
 // lanes are the 64 hidden units of the conditioner (model_factory.py:72), and in the output layer the 2 x 32 basis rows of
 // two dimensions.  A dense layer is then 64 fused multiply-adds per lane and coefficient instead of 4096: the input vector
 // is broadcast from LDS (ds_read_b128, same address in every lane), the weights come in lane-major float4 groups (one
@@ -11,6 +11,7 @@
 //   k_wave_fwd   forward ring evaluation; writes the tape (layer inputs, hidden activations) and the tail
 //                (per-dimension prior factors, log det, latent point) of each sample
 //   k_energy_out psi, laplacian, H psi per walker from the tails      physics.py:50-52, 60-76, 79-93
+//                (second order: RF<D> = (value, gradient, Laplacian / 2) jets, one sample per walker; R3 is the A/B form)
 //   k_wave_bwd   reverse sweep from the tape: pre-activation adjoints into the tape for k_wgrad (wf_kernels_grad.hip)
 //
 // Derivative semantics of the table lerp and the adjoint-in-reversed-order ring trick: see wf_kernels_grad.hip / wf_ring.h.
