@@ -30,9 +30,24 @@ namespace {
 using namespace ring;
 constexpr int H = kHidden;
 constexpr int kWaves = 4;
-#ifndef WF_WAVE_OCC
-#define WF_WAVE_OCC 3   // waves per SIMD the register allocation aims at (measured: DESIGN.md §4.5)
+// waves per SIMD the register allocation of each kernel family aims at (measured: DESIGN.md §4.5, scratch/occ_try.sh)
+#ifndef WF_OCC_FWD1
+#define WF_OCC_FWD1 3   // k_wave_fwd<D, R1>
 #endif
+#ifndef WF_OCC_FWD2
+#define WF_OCC_FWD2 3   // k_wave_fwd<D, R3 / RF>
+#endif
+#ifndef WF_OCC_BWD1
+#define WF_OCC_BWD1 3   // k_wave_bwd<D, R1>
+#endif
+#ifndef WF_OCC_BWD2
+#define WF_OCC_BWD2 2   // k_wave_bwd<D, R3 / RF>: 256 registers per lane (RF<2>: 1.92e7 -> 2.31e7 walkers/s, batch 128: 86 -> 60 us)
+#endif
+#ifndef WF_OCC_SAMPLE
+#define WF_OCC_SAMPLE 3
+#endif
+template <class T> constexpr int kOccFwd = T::NC == 1 ? WF_OCC_FWD1 : WF_OCC_FWD2;
+template <class T> constexpr int kOccBwd = T::NC == 1 ? WF_OCC_BWD1 : WF_OCC_BWD2;
 constexpr int kWB = 64 * kWaves;
 
 // ---- coefficient access
@@ -325,7 +340,7 @@ __device__ __forceinline__ void box_forward(const ModelDev& md, T (&cur)[D], T& 
 
 // ------------------------------------------------------------------------------------------------ forward
 template <int D, class T>
-__global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(WF_WAVE_OCC, WF_WAVE_OCC))) void k_wave_fwd(const ModelDev* __restrict__ mdp, const float* __restrict__ tabI, const float* __restrict__ tabP,
+__global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(kOccFwd<T>, kOccFwd<T>))) void k_wave_fwd(const ModelDev* __restrict__ mdp, const float* __restrict__ tabI, const float* __restrict__ tabP,
                                                    const float* __restrict__ fk_nat, const float* __restrict__ xg, int64_t B,
                                                    float* __restrict__ ws, float* __restrict__ tails, int taped) {
     __shared__ float lds[kWaves][2][T::NC][64];
@@ -596,7 +611,7 @@ __device__ __forceinline__ void hidden_bwd(const NetWave& net, T hb2, float (*ve
 
 // mode 0: sum_b w1[b] log_pdf_b;  mode 1: sum_b (w1[b] psi_b + w2[b] laplacian_b)
 template <int D, class T>
-__global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(WF_WAVE_OCC, WF_WAVE_OCC))) void k_wave_bwd(const ModelDev* __restrict__ mdp, int mode, const float* __restrict__ tabI, const float* __restrict__ tabP,
+__global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(kOccBwd<T>, kOccBwd<T>))) void k_wave_bwd(const ModelDev* __restrict__ mdp, int mode, const float* __restrict__ tabI, const float* __restrict__ tabP,
                                                    const float* __restrict__ fk_nat, int64_t B, const float* __restrict__ w1, const float* __restrict__ w2,
                                                    float* __restrict__ ws, const float* __restrict__ tails) {
     __shared__ float lds[kWaves][2][T::NC][64];
@@ -920,7 +935,7 @@ __device__ __forceinline__ void wave_serial_inverse(const ModelDev& md, const fl
 
 // seed_mode 0: invert the latent points ug;  1: draw the latent points from the prior first (and report them)
 template <int D>
-__global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(WF_WAVE_OCC, WF_WAVE_OCC))) void k_wave_sample(
+__global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(WF_OCC_SAMPLE, WF_OCC_SAMPLE))) void k_wave_sample(
     const ModelDev* __restrict__ mdp, const float* __restrict__ tabI, const float* __restrict__ tabP, const float* __restrict__ fk_nat, int draw,
     unsigned long long seed, const float* __restrict__ ug, int64_t B, float* __restrict__ xg, float* __restrict__ latent, int exact,
     const unsigned long long* __restrict__ seed_offset_dev) {
