@@ -34,9 +34,10 @@ PMC_TRAFFIC_BYTES_2POW20 = (10791 + 14336) * 1024
 MFMA_FLOP_PER_EVAL = (156 * 32768 + 12 * 4096) / 32
 PEAK_F16_MATRIX_TFLOPS = 2500.0
 PEAK_F32_VIA_F16_SPLIT_TFLOPS = PEAK_F16_MATRIX_TFLOPS / 3.0   # three f16 MFMA products per fp32-equivalent multiply-add
-# reverse sweep of one (walker, direction) sample, He: per net 3 dense 64x64 products x 3 ring coefficients (+ the 32x32
-# change of basis of the prior), FMA = 2 FLOP
-VQMC_BWD_FLOP_PER_SAMPLE = 2 * (4 * 3 * 64 * 64 * 3 + 2 * 32 * 32 * 3 * 2)
+# reverse sweep of one walker, He, in the (value, gradient, Laplacian) algebra RF<2> = 4 channels: per net 2 dense 64x64 products
+# (+ the 32x32 change of basis of the prior, forward and transposed, for 2 dimensions), FMA = 2 FLOP
+VQMC_BWD_FLOP_PER_WALKER = 2 * (4 * 2 * 64 * 64 * 4 + 2 * 2 * 32 * 32 * 4)
+VQMC_BWD_SHARE = 0.54   # of the loss + gradient time (profiles/r01h_loss_grad_kernel_stats.csv)
 
 
 def he_model(kernel):
@@ -310,11 +311,11 @@ def main_vqmc(args):
         "config": {"workload": f"1D He (shipped checkpoint): loss_fn_efficient + gradient over {B} walkers (vqmc.py:193-221); also H psi and "
                                "whole training steps at batch 128", "walkers": B},
         "hpsi_walkers_per_s": B / t_h, "train_steps_per_s_batch128": 1.0 / t_train, "train_ms_per_step_batch128": t_train * 1e3,
-        "roofline": {"bound": "valu", "achieved": B * 2 * VQMC_BWD_FLOP_PER_SAMPLE / (0.5 * step_ms * 1e-3) / 1e12, "peak": PEAK_F32_MATRIX_TFLOPS,
-                     "unit": "TFLOP/s", "frac": B * 2 * VQMC_BWD_FLOP_PER_SAMPLE / (0.5 * step_ms * 1e-3) / 1e12 / PEAK_F32_MATRIX_TFLOPS,
-                     "traffic": None, "kernel": "k_wave_bwd<2, R3>", "kernel_ms": 0.5 * step_ms,
+        "roofline": {"bound": "valu", "achieved": B * VQMC_BWD_FLOP_PER_WALKER / (VQMC_BWD_SHARE * step_ms * 1e-3) / 1e12, "peak": PEAK_F32_MATRIX_TFLOPS,
+                     "unit": "TFLOP/s", "frac": B * VQMC_BWD_FLOP_PER_WALKER / (VQMC_BWD_SHARE * step_ms * 1e-3) / 1e12 / PEAK_F32_MATRIX_TFLOPS,
+                     "traffic": None, "kernel": "k_wave_bwd<2, RF<2>>", "kernel_ms": VQMC_BWD_SHARE * step_ms,
                      "note": "the sweeps are fp32 vector (VALU) work, which this contract's bound enum does not name: achieved = algorithmic "
-                             "FMA FLOP of the reverse sweep (2 samples per walker) / its share of the step (~50 %, profiles/r01e_*); "
+                             "FMA FLOP of the reverse sweep (one 4-channel sample per walker) / its share of the step (54 %, profiles/r01h_*); "
                              "peak = the fp32 vector peak"},
     }
     if not args.no_cpu_baseline:

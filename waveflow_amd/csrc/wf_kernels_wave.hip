@@ -383,6 +383,7 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(kOccFwd<T>,
                 const int d = 2 * p + dl;
                 const bool valid_d = d < D;
                 const T o = gemv<T>(net.W2f + p * 1024, vec, lane) + net.b2[p * 64 + lane];
+                if (taped && valid_d) tput(tape, l, Rows<D>::O + d * NBP + j, o);   // the reverse sweep reads it back and stores its adjoint here
                 const T u = sel(dl == 0, cur[2 * p], cur[2 * p + 1 < D ? 2 * p + 1 : 2 * p]);
                 T y, ld;
                 if (imade) {
@@ -428,6 +429,7 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(kOccFwd<T>,
                 const int d = 2 * p + dl;
                 const bool valid_d = d < D, valid = valid_d && j < nb;
                 const T o = gemv<T>(net.W2f + p * 1024, vec, lane) + net.b2[p * 64 + lane];
+                if (taped && valid_d) tput(tape, NP, Rows<D>::O + d * NBP + j, o);
                 bool inside;
                 const T uc = clip01(sel(dl == 0, cur[2 * p], cur[2 * p + 1 < D ? 2 * p + 1 : 2 * p]), inside);
                 const Lerp lp = make_lerp(uc.c0, n_mesh);
@@ -657,13 +659,12 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(kOccBwd<T>,
             T cur[D];
 #pragma unroll
             for (int d = 0; d < D; ++d) cur[d] = tail_get<T>(tl, Tail<D>::U + d);
-            put(vec, lane, tget<T>(tape, NP, Rows<D>::H2 + lane));
             T hb2 = cst<T>(0.0f);
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 const int d = 2 * p + dl;
                 const bool valid_d = d < D, valid = valid_d && j < nb;
-                const T o = gemv<T>(net.W2f + p * 1024, vec, lane) + net.b2[p * 64 + lane];
+                const T o = valid_d ? tget<T>(tape, NP, Rows<D>::O + d * NBP + j) : cst<T>(0.0f);   // head pre-activation, left by the forward sweep
                 bool inside;
                 const T uc = clip01(sel(dl == 0, cur[2 * p], cur[2 * p + 1 < D ? 2 * p + 1 : 2 * p]), inside);
                 const Lerp lp = make_lerp(uc.c0, n_mesh);
@@ -735,13 +736,12 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(kOccBwd<T>,
             }
 #pragma unroll
             for (int d = 0; d < D; ++d) gU[d] = cst<T>(0.0f);
-            put(vec, lane, tget<T>(tape, l, Rows<D>::H2 + lane));
             T hb2 = cst<T>(0.0f);
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 const int d = 2 * p + dl;
                 const bool valid_d = d < D;
-                const T o = gemv<T>(net.W2f + p * 1024, vec, lane) + net.b2[p * 64 + lane];
+                const T o = valid_d ? tget<T>(tape, l, Rows<D>::O + d * NBP + j) : cst<T>(0.0f);
                 const T u = sel(dl == 0, U[2 * p], U[2 * p + 1 < D ? 2 * p + 1 : 2 * p]);
                 const T gy = sel(dl == 0, gY[2 * p], gY[2 * p + 1 < D ? 2 * p + 1 : 2 * p]);
                 T go, gu;
