@@ -45,3 +45,6 @@ trainer.exact_sampler = args.exact_sampler
 if args.save_dir:
     trainer.save_dir = args.save_dir
 trainer.start_training()
+
+if "dist" in globals() and dist.is_initialized():
+    dist.destroy_process_group()

@@ -86,7 +86,7 @@ struct wf_model {
     void* d_comp = nullptr;          // composite tables [n_nets][n_mesh] float4
     const float* d_tabI4 = nullptr;  // [4][n_mesh][32]: I-spline derivative orders 0..3 (local energy)
     const float* d_tabP3 = nullptr;  // [4][n_mesh][32]: orthogonal-B derivative orders 0..3 (the energy uses 0..2)
-    float* d_flat = nullptr;         // device copy of the flat parameter vector (source of every weight image)
+    float* d_flat = nullptr;         // staging copy of a host parameter vector (wf_model_set_params)
     wf::PackRec* d_pack = nullptr;   // descriptions of every entry of the plain, wave and mfma images
     int64_t n_pack = 0;
     float* d_scratch = nullptr;      // private scratch of wf_hamiltonian_fwd (grown on demand)
@@ -894,10 +894,10 @@ int wf_model_set_kernel(wf_model* m, int kernel_kind) {
     return WF_OK;
 }
 
-// fills every weight image from the device-resident flat vector m->d_flat (asynchronous on `stream`)
-static int apply_params(wf_model* m, void* stream) {
+// fills every weight image from a device-resident flat vector (asynchronous on `stream`)
+static int apply_params(wf_model* m, const float* flat_dev, void* stream) {
     {
-        int rc = launch_pack(m->d_flat, m->d_pack, m->n_pack, m->d_plain, m->d_wave, m->d_mfma, stream);
+        int rc = launch_pack(flat_dev, m->d_pack, m->n_pack, m->d_plain, m->d_wave, m->d_mfma, stream);
         if (rc) return rc;
     }
     if (m->mfma_ok) {
@@ -915,7 +915,7 @@ int wf_model_set_params(wf_model* m, const float* flat_host, int64_t n, void* st
     DeviceGuard g(m->device);
     hipStream_t s = (hipStream_t)stream;
     if (n > 0) WF_HIP(hipMemcpyAsync(m->d_flat, flat_host, (size_t)n * sizeof(float), hipMemcpyHostToDevice, s));
-    int rc = apply_params(m, stream);
+    int rc = apply_params(m, m->d_flat, stream);
     if (rc) return rc;
     WF_HIP(hipStreamSynchronize(s));   // the caller may reuse flat_host
     return WF_OK;
@@ -925,9 +925,7 @@ int wf_model_set_params_device(wf_model* m, const float* flat_dev, int64_t n, vo
     if (!m || !flat_dev) return WF_ERR_INVALID;
     if (n != m->n_params) return WF_ERR_INVALID;
     DeviceGuard g(m->device);
-    if (n > 0 && flat_dev != m->d_flat)
-        WF_HIP(hipMemcpyAsync(m->d_flat, flat_dev, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
-    return apply_params(m, stream);
+    return apply_params(m, flat_dev, stream);   // the images are packed straight from the caller's vector (m->d_flat only stages host uploads)
 }
 
 int wf_adam_step(float* params_dev, const float* grad_dev, float* m_dev, float* v_dev, int64_t n, int64_t step, float step_size, float b1,
