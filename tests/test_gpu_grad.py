@@ -215,10 +215,11 @@ def test_benchmark_training_lowers_the_negative_log_likelihood(tmp_path, model_t
 
 
 @pytest.mark.parametrize("D,box,layers,k,kn,B", [(3, "first", 2, 4, 13, 37), (4, "mean", 1, 5, 16, 65), (2, "first", 1, 3, 10, 1), (8, "mean", 2, 4, 13, 9),
-                                              (5, "first", 1, 3, 10, 6)])
+                                              (5, "first", 1, 3, 10, 6), (2, "mean", 2, 6, 33, 33), (3, "first", 1, 5, 30, 17), (4, "mean", 1, 4, 41, 5)])
 def test_gradients_other_shapes_vs_autograd_oracle(D, box, layers, k, kn, B):
-    """D = 3 .. 8 (C4: the 8-electron chain), both box transforms, ragged batches: psi / Laplacian / log_pdf gradients and the
-    local energy vs torch (fp64)."""
+    """D = 3 .. 8 (C4: the 8-electron chain), both box transforms, ragged batches, 33..64 bases per dimension (the 33-knot
+    "32-bin" variant of C3: one dimension x 64 rows per output pass): psi / Laplacian / log_pdf gradients and the local energy
+    vs torch (fp64)."""
     import torch
     from oracle import energy_torch as et
     from waveflow_amd import flatten_params, model_factory

@@ -187,10 +187,11 @@ def test_waveflow_other_shapes_vs_oracle(kernel, D, box, layers, k, kn):
     as_accurate_as_fp32_reference(ps, pso, pst, atol=1e-6 * np.abs(pst).max())
 
 
-@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("kernel", KERNELS_ALL)
 def test_he_33_knot_variant_32_bins(golden, kernel):
     """BASELINE configs[2] "32-bin": 33 internal knots = 32 knot intervals, k = 6 => 39 I-bases / 38 B-bases (> 32: two
-    32-row blocks per dimension in the MFMA kernel, 64 padded bases in the scalar kernel).  Seeded init, oracle parity only."""
+    32-row blocks per dimension in the MFMA kernel, 64 padded bases in the scalar kernel, one dimension x 64 rows per output pass
+    in the wave kernel).  Seeded init, oracle parity only."""
     from waveflow_amd import model_factory, flatten_params
     init_fun = model_factory.get_waveflow_model(2, base_spline_degree=6, i_spline_degree=6, n_prior_internal_knots=33,
                                                 n_i_internal_knots=33, i_spline_reg=0.05, n_flow_layers=3, box_size=10.0)

@@ -133,9 +133,9 @@ struct Protons {
 inline int ring_coefs(int D, int kind) { return kind == 0 ? 1 : (kind == 1 ? 3 : D + 2); }
 inline int ring_samples(int D, int kind) { return kind == 1 ? D : 1; }
 // reverse pass (wf_kernels_grad.hip)
-int grad_ws_rows(int D);
+int grad_ws_rows(int D, int nbp);
 int wgrad_partial_floats(int n_nets, int64_t net_img_floats);
-int launch_wgrad(int D, int ring_kind, int n_nets, int64_t n_samples, const float* ws, float* partial, int accumulate, float* grad_img,
+int launch_wgrad(int D, int nbp, int ring_kind, int n_nets, int64_t n_samples, const float* ws, float* partial, int accumulate, float* grad_img,
                  int64_t net_img_floats, int* split_out, void* stream);
 int launch_wave_fwd(const ModelDev& md, const ModelDev* md_dev, int ring_kind, const float* tabI4, const float* tabP4, const float* fk_nat,
                     const float* x, int64_t B, float* ws, float* tails, int taped, void* stream);

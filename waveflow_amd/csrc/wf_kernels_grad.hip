@@ -246,19 +246,20 @@ int finish() {
     return WF_OK;
 }
 
-template <int D, int NC>
+template <int D, int NC, int NBK = 1>
 int run_wgrad(int n_nets, int64_t n_samples, const float* ws, float* partial, int accumulate, float* grad_img, int64_t net_img_floats,
               int* split_out, hipStream_t s) {
-    using R = Rows<D>;
+    using R = Rows<D, NBK>;
+    constexpr int W = NBP * NBK;
     if (split_out) *split_out = 0;
     if (n_nets == 0 || n_samples == 0) return WF_OK;
     // forward-image layout of one net: W0 [D][64], b0 [64], W1t [64 out][64 in], b1 [64], W2t [D*NBP][64], b2 [D*NBP]
-    const int oW0 = 0, ob0 = D * H, oW1 = ob0 + H, ob1 = oW1 + H * H, oW2 = ob1 + H, ob2 = oW2 + D * NBP * H;
+    const int oW0 = 0, ob0 = D * H, oW1 = ob0 + H, ob1 = oW1 + H * H, oW2 = ob1 + H, ob2 = oW2 + D * W * H;
     WJobs jobs;
     jobs.j[0] = WJob{R::U, D, R::A1, H, oW0, H, 1, ob0};            // dW0[a][j]
     jobs.j[1] = WJob{R::H1, H, R::A2, H, oW1, 1, H, ob1};           // dW1t[j][a]
-    jobs.j[2] = WJob{R::H2, H, R::O, D * NBP, oW2, 1, H, ob2};      // dW2t[(d, jb)][a]
-    const int n_ntiles = (D * NBP + kWT - 1) / kWT;
+    jobs.j[2] = WJob{R::H2, H, R::O, D * W, oW2, 1, H, ob2};      // dW2t[(d, jb)][a]
+    const int n_ntiles = (D * W + kWT - 1) / kWT;
     constexpr int kWK = wgrad_slab(NC);
     const int64_t n_slabs = (n_samples + kWK - 1) / kWK;
     int split = (int)(n_slabs < kWgradSplit ? n_slabs : kWgradSplit);
@@ -277,30 +278,38 @@ int run_wgrad(int n_nets, int64_t n_samples, const float* ws, float* partial, in
 
 }  // namespace
 
-int grad_ws_rows(int D) { return 8 + 4 * H + D * NBP; }
+int grad_ws_rows(int D, int nbp) { return 8 + 4 * H + D * nbp; }
 
 // tape -> gradient image: sum over samples of activation (x) adjoint, top ring coefficient
 int wgrad_partial_floats(int n_nets, int64_t net_img_floats) { return kWgradSplit * n_nets * (int)net_img_floats; }
 
 // partial: wgrad_partial_floats scratch; accumulate != 0 adds to grad_img (further chunks of a batch) instead of overwriting it
 // split_out != NULL: leave the partial images unreduced and report how many there are
-int launch_wgrad(int D, int ring_kind, int n_nets, int64_t n_samples, const float* ws, float* partial, int accumulate, float* grad_img,
+int launch_wgrad(int D, int nbp, int ring_kind, int n_nets, int64_t n_samples, const float* ws, float* partial, int accumulate, float* grad_img,
                  int64_t net_img_floats, int* split_out, void* stream) {
     hipStream_t s = (hipStream_t)stream;
-#define CALL(DD) return ring_kind == 2 ? run_wgrad<DD, DD + 2>(n_nets, n_samples, ws, partial, accumulate, grad_img, net_img_floats, split_out, s) \
-                : ring_kind == 1 ? run_wgrad<DD, 3>(n_nets, n_samples, ws, partial, accumulate, grad_img, net_img_floats, split_out, s)       \
-                                 : run_wgrad<DD, 1>(n_nets, n_samples, ws, partial, accumulate, grad_img, net_img_floats, split_out, s)
+#define CALLK(DD, K) return ring_kind == 2 ? run_wgrad<DD, DD + 2, K>(n_nets, n_samples, ws, partial, accumulate, grad_img, net_img_floats, split_out, s) \
+                    : ring_kind == 1 ? run_wgrad<DD, 3, K>(n_nets, n_samples, ws, partial, accumulate, grad_img, net_img_floats, split_out, s)       \
+                                     : run_wgrad<DD, 1, K>(n_nets, n_samples, ws, partial, accumulate, grad_img, net_img_floats, split_out, s)
+    if (nbp == 64) {
+        switch (D) {
+            case 2: CALLK(2, 2);
+            case 3: CALLK(3, 2);
+            case 4: CALLK(4, 2);
+            default: return WF_ERR_UNSUPPORTED;
+        }
+    }
     switch (D) {
-        case 2: CALL(2);
-        case 3: CALL(3);
-        case 4: CALL(4);
-        case 5: CALL(5);
-        case 6: CALL(6);
-        case 7: CALL(7);
-        case 8: CALL(8);
+        case 2: CALLK(2, 1);
+        case 3: CALLK(3, 1);
+        case 4: CALLK(4, 1);
+        case 5: CALLK(5, 1);
+        case 6: CALLK(6, 1);
+        case 7: CALLK(7, 1);
+        case 8: CALLK(8, 1);
         default: return WF_ERR_UNSUPPORTED;
     }
-#undef CALL
+#undef CALLK
 }
 
 int launch_pack(const float* flat_dev, const PackRec* recs, int64_t n, void* plain, void* wave, void* mfma, void* stream) {

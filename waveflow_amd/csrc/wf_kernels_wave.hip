@@ -112,6 +112,16 @@ template <class T> __device__ __forceinline__ T wave_sum(T a) {
     const T h = half_sum(a);
     return h + xhalf(h);
 }
+// sum over the rows of one dimension: the 32 lanes of a half (NBK = 1: a pass holds two dimensions) or the whole wave (NBK = 2)
+template <int NBK, class T> __device__ __forceinline__ T rsum(T a) {
+    if constexpr (NBK == 1) return half_sum(a);
+    else return wave_sum(a);
+}
+template <int NBK> __device__ __forceinline__ float rsumf(float v) {
+    const float h = hsum(v);
+    if constexpr (NBK == 1) return h;
+    else return h + swap32_other(h);
+}
 __device__ __forceinline__ R1 from_lane(R1 a, int src) { return R1{__shfl(a.c0, src)}; }
 __device__ __forceinline__ R3 from_lane(R3 a, int src) { return R3{__shfl(a.c0, src), __shfl(a.c1, src), __shfl(a.c2, src)}; }
 template <int D> __device__ __forceinline__ RF<D> from_lane(RF<D> a, int src) { return map_coefs(a, [src](float v) { return __shfl(v, src); }); }
@@ -163,32 +173,37 @@ __device__ __forceinline__ T gemv(const float4_t* __restrict__ img, const float 
     for (int k = 0; k < T::NC; ++k) out[k] = acc[k].x + acc[k].y;
     return from_arr((T*)nullptr, out);
 }
-// out[lane (half h, j)] = sum_{a < 32} in[h][a] * M[a][j]   (M: [32][32] row-major; in = buf of this lane's half)
-template <class T>
+// out[lane (half h, j)] = sum_{a < 32} in[h][a] * M[a][j]   (M: [32][32] row-major; in = buf of this lane's half);
+// NBK = 2: out[lane j] = sum_{a < 64} in[a] * M[a][j], M [64][64]
+template <class T, int NBK = 1>
 __device__ __forceinline__ T gemv32_cols(const float* __restrict__ M, const float (*buf)[64], int half, int j) {
+    constexpr int W = 32 * NBK;
+    const int base = NBK == 1 ? half * 32 : 0;
     float acc[T::NC];
 #pragma unroll
     for (int k = 0; k < T::NC; ++k) acc[k] = 0.0f;
 #pragma unroll 8
-    for (int a = 0; a < 32; ++a) {
-        const float m = M[a * NBP + j];
+    for (int a = 0; a < W; ++a) {
+        const float m = M[a * W + j];
 #pragma unroll
-        for (int k = 0; k < T::NC; ++k) acc[k] = __builtin_fmaf(buf[k][half * 32 + a], m, acc[k]);
+        for (int k = 0; k < T::NC; ++k) acc[k] = __builtin_fmaf(buf[k][base + a], m, acc[k]);
     }
     __builtin_amdgcn_wave_barrier();
     return from_arr((T*)nullptr, acc);
 }
 // out[lane (half h, a)] = sum_{j < 32} in[h][j] * M[a][j]
-template <class T>
+template <class T, int NBK = 1>
 __device__ __forceinline__ T gemv32_rows(const float* __restrict__ M, const float (*buf)[64], int half, int a) {
+    constexpr int W = 32 * NBK;
+    const int base = NBK == 1 ? half * 32 : 0;
     float acc[T::NC];
 #pragma unroll
     for (int k = 0; k < T::NC; ++k) acc[k] = 0.0f;
 #pragma unroll 8
-    for (int j = 0; j < 32; ++j) {
-        const float m = M[a * NBP + j];
+    for (int j = 0; j < W; ++j) {
+        const float m = M[a * W + j];
 #pragma unroll
-        for (int k = 0; k < T::NC; ++k) acc[k] = __builtin_fmaf(buf[k][half * 32 + j], m, acc[k]);
+        for (int k = 0; k < T::NC; ++k) acc[k] = __builtin_fmaf(buf[k][base + j], m, acc[k]);
     }
     __builtin_amdgcn_wave_barrier();
     return from_arr((T*)nullptr, acc);
@@ -243,26 +258,26 @@ __device__ __forceinline__ T hidden_fwd(const NetWave& net, const T (&x)[D], flo
 template <class T> struct SigHead {
     T p, rS0, rQ, c;
 };
-template <class T>
+template <class T, int NBK = 1>
 __device__ __forceinline__ SigHead<T> sigmoid_head(T o, bool valid, bool valid_d, float g, float reg) {
     SigHead<T> h;
     h.p = valid ? rsigmoid(o) : cst<T>(0.0f);
-    T S0 = half_sum(h.p);
+    T S0 = rsum<NBK>(h.p);
     if (!valid_d) S0 = cst<T>(1.0f);
     h.rS0 = rrcp(S0);
     const T q = (h.p * h.rS0 + reg) * (valid ? g : 0.0f);
-    T Q = half_sum(q);
+    T Q = rsum<NBK>(q);
     if (!valid_d) Q = cst<T>(1.0f);
     h.rQ = rrcp(Q);
     h.c = q * h.rQ;
     return h;
 }
 // reverse of the head: cbar (this lane) -> obar (this lane)
-template <class T>
+template <class T, int NBK = 1>
 __device__ __forceinline__ T sigmoid_head_bwd(const SigHead<T>& h, T gc, bool valid, float g) {
-    const T dotC = half_sum(gc * h.c);
+    const T dotC = rsum<NBK>(gc * h.c);
     const T gw0 = ((gc - dotC) * h.rQ) * (valid ? g : 0.0f);
-    const T dot0 = half_sum(gw0 * (h.p * h.rS0));
+    const T dot0 = rsum<NBK>(gw0 * (h.p * h.rS0));
     return valid ? ((gw0 - dot0) * h.rS0) * (h.p * (1.0f - h.p)) : cst<T>(0.0f);
 }
 
@@ -275,19 +290,19 @@ template <class T> struct PsiHead {
     T o, rN1, rN2, a, e;
     float sgn;
 };
-template <class T>
+template <class T, int NBK = 1>
 __device__ __forceinline__ PsiHead<T> psi_head(T o, bool valid, bool valid_d, float keep, const float* __restrict__ o2b, float (*ov)[64], int lane) {
     PsiHead<T> h;
     h.o = valid ? o : cst<T>(0.0f);
-    h.sgn = hsum(h.o.c0) < 0.0f ? -1.0f : 1.0f;
+    h.sgn = rsumf<NBK>(h.o.c0) < 0.0f ? -1.0f : 1.0f;
     const T w = h.o * (valid ? keep * h.sgn : 0.0f);
-    T N1 = half_sum(w * w);
+    T N1 = rsum<NBK>(w * w);
     if (!valid_d) N1 = cst<T>(1.0f);
     h.rN1 = rrsqrt(N1);
     h.a = w * h.rN1;
     put(ov, lane, h.a);
-    const T c = gemv32_cols<T>(o2b, ov, lane >> 5, lane & 31);   // c_j = sum_a a_a ob_to_b[a][j]
-    T N2 = half_sum(c * c);
+    const T c = gemv32_cols<T, NBK>(o2b, ov, lane >> 5, NBK == 1 ? (lane & 31) : lane);   // c_j = sum_a a_a ob_to_b[a][j]
+    T N2 = rsum<NBK>(c * c);
     if (!valid_d) N2 = cst<T>(1.0f);
     h.rN2 = rrsqrt(N2);
     h.e = c * h.rN2;
@@ -339,23 +354,25 @@ __device__ __forceinline__ void box_forward(const ModelDev& md, T (&cur)[D], T& 
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-template <int D, class T>
+// NBK = 1: an output pass covers two dimensions x 32 basis rows (lane = (dl, j)); NBK = 2 (33..64 bases): one dimension x 64 rows
+template <int D, class T, int NBK = 1>
 __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(kOccFwd<T>, kOccFwd<T>))) void k_wave_fwd(const ModelDev* __restrict__ mdp, const float* __restrict__ tabI, const float* __restrict__ tabP,
                                                    const float* __restrict__ fk_nat, const float* __restrict__ xg, int64_t B,
                                                    float* __restrict__ ws, float* __restrict__ tails, int taped) {
     __shared__ float lds[kWaves][2][T::NC][64];
     const ModelDev& md = *mdp;
     constexpr int DIRS = kDirs<T, D>;
-    constexpr int P = (D + 1) / 2;
+    constexpr int P = NBK == 1 ? (D + 1) / 2 : D, W = 32 * NBK;
+    using RW = Rows<D, NBK>;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float (*vec)[64] = lds[wv][0];
     float (*ov)[64] = lds[wv][1];
-    const int dl = lane >> 5, j = lane & 31;
+    const int dl = NBK == 1 ? lane >> 5 : 0, j = NBK == 1 ? (lane & 31) : lane;
     const bool imade = md.layer_kind == WF_LAYER_IMADE;
     const bool has_pnet = md.prior_kind == WF_PRIOR_WAVEFLOW || md.prior_kind == WF_PRIOR_MFLOW;
     const int n_nets = md.n_layers + (has_pnet ? 1 : 0);
     const int n_mesh = (imade && md.n_layers > 0) ? md.isp.n_mesh : md.psp.n_mesh;   // (a model may have no flow layer at all)
-    const size_t plane = (size_t)n_mesh * NBP;
+    const size_t plane = (size_t)n_mesh * W;
     const float* __restrict__ gI = fk_nat;
     const float* __restrict__ kP = fk_nat + 64;
     T* const tag = nullptr;
@@ -363,7 +380,7 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(kOccFwd<T>,
     for (int64_t s = (int64_t)blockIdx.x * kWaves + wv; s < n_samples; s += (int64_t)gridDim.x * kWaves) {
         const int64_t b = s / DIRS;
         const int dir = (int)(s - b * DIRS);
-        const Tape tape{ws + s * (int64_t)n_nets * T::NC * Rows<D>::N, Rows<D>::N};
+        const Tape tape{ws + s * (int64_t)n_nets * T::NC * RW::N, RW::N};
         float* tl = tails + s * (int64_t)Tail<D>::N * T::NC;
         T cur[D], nxt[D];
 #pragma unroll
@@ -375,26 +392,26 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(kOccFwd<T>,
             if (taped) {
 #pragma unroll
                 for (int d = 0; d < D; ++d)
-                    if (lane == d) tput(tape, l, Rows<D>::U + d, cur[d]);
+                    if (lane == d) tput(tape, l, RW::U + d, cur[d]);
             }
             hidden_fwd<D, T>(net, cur, vec, lane, tape, l, taped);
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-                const int d = 2 * p + dl;
+                const int d = NBK == 1 ? 2 * p + dl : p;
                 const bool valid_d = d < D;
                 const T o = gemv<T>(net.W2f + p * 1024, vec, lane) + net.b2[p * 64 + lane];
-                if (taped && valid_d) tput(tape, l, Rows<D>::O + d * NBP + j, o);   // the reverse sweep reads it back and stores its adjoint here
-                const T u = sel(dl == 0, cur[2 * p], cur[2 * p + 1 < D ? 2 * p + 1 : 2 * p]);
+                if (taped && valid_d) tput(tape, l, RW::O + d * W + j, o);   // the reverse sweep reads it back and stores its adjoint here
+                const T u = NBK == 1 ? sel(dl == 0, cur[2 * p < D ? 2 * p : 0], cur[2 * p + 1 < D ? 2 * p + 1 : 0]) : cur[p];
                 T y, ld;
                 if (imade) {
                     const int nb = md.isp.nb;
                     const bool valid = valid_d && j < nb;
-                    const SigHead<T> hd = sigmoid_head(o, valid, valid_d, gI[j], md.i_reg);
+                    const SigHead<T> hd = sigmoid_head<T, NBK>(o, valid, valid_d, gI[j], md.i_reg);
                     const Lerp lp = make_lerp(u.c0, n_mesh);
                     float t[4];
-                    lerp4(tabI, plane, lp, j, t);
-                    y = half_sum(hd.c * lift(t, 0, u));
-                    const T dy = half_sum(hd.c * lift(t, 1, u));
+                    lerp4<W>(tabI, plane, lp, j, t);
+                    y = rsum<NBK>(hd.c * lift(t, 0, u));
+                    const T dy = rsum<NBK>(hd.c * lift(t, 1, u));
                     ld = valid_d ? rlog(dy + 1e-7f) : cst<T>(0.0f);
                 } else {
                     // MADE (made.py:21-27): rows 0 / 1 of the dimension are log_weight / bias
@@ -402,10 +419,15 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(kOccFwd<T>,
                     y = (u - bias) * rexp(cst<T>(0.0f) - lw);
                     ld = valid_d ? cst<T>(0.0f) - lw : cst<T>(0.0f);
                 }
-                const T y_o = xhalf(y), ld_o = xhalf(ld);
-                nxt[2 * p] = sel(dl == 0, y, y_o);
-                if (2 * p + 1 < D) nxt[2 * p + 1] = sel(dl == 0, y_o, y);
-                logdet = logdet + ld + ld_o;
+                if constexpr (NBK == 1) {
+                    const T y_o = xhalf(y), ld_o = xhalf(ld);
+                    nxt[2 * p] = sel(dl == 0, y, y_o);
+                    if (2 * p + 1 < D) nxt[2 * p + 1] = sel(dl == 0, y_o, y);
+                    logdet = logdet + ld + ld_o;
+                } else {
+                    nxt[p] = y;
+                    logdet = logdet + ld;
+                }
             }
 #pragma unroll
             for (int d = 0; d < D; ++d) cur[d] = nxt[D - 1 - d];
@@ -421,31 +443,35 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(kOccFwd<T>,
             if (taped) {
 #pragma unroll
                 for (int d = 0; d < D; ++d)
-                    if (lane == d) tput(tape, NP, Rows<D>::U + d, cur[d]);
+                    if (lane == d) tput(tape, NP, RW::U + d, cur[d]);
             }
             hidden_fwd<D, T>(net, cur, vec, lane, tape, NP, taped);
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-                const int d = 2 * p + dl;
+                const int d = NBK == 1 ? 2 * p + dl : p;
                 const bool valid_d = d < D, valid = valid_d && j < nb;
                 const T o = gemv<T>(net.W2f + p * 1024, vec, lane) + net.b2[p * 64 + lane];
-                if (taped && valid_d) tput(tape, NP, Rows<D>::O + d * NBP + j, o);
+                if (taped && valid_d) tput(tape, NP, RW::O + d * W + j, o);
                 bool inside;
-                const T uc = clip01(sel(dl == 0, cur[2 * p], cur[2 * p + 1 < D ? 2 * p + 1 : 2 * p]), inside);
+                const T uc = clip01(NBK == 1 ? sel(dl == 0, cur[2 * p < D ? 2 * p : 0], cur[2 * p + 1 < D ? 2 * p + 1 : 0]) : cur[p], inside);
                 const Lerp lp = make_lerp(uc.c0, n_mesh);
                 float t[4];
-                lerp4(tabP, plane, lp, j, t);
+                lerp4<W>(tabP, plane, lp, j, t);
                 T val;
                 if (md.prior_kind == WF_PRIOR_WAVEFLOW) {
-                    const PsiHead<T> hd = psi_head(o, valid, valid_d, kP[j], md.ob_to_b, ov, lane);
-                    val = half_sum(hd.e * lift(t, 0, uc));
+                    const PsiHead<T> hd = psi_head<T, NBK>(o, valid, valid_d, kP[j], md.ob_to_b, ov, lane);
+                    val = rsum<NBK>(hd.e * lift(t, 0, uc));
                 } else {
-                    const SigHead<T> hd = sigmoid_head(o, valid, valid_d, kP[j], 0.0f);
-                    val = half_sum(hd.c * lift(t, 0, uc));
+                    const SigHead<T> hd = sigmoid_head<T, NBK>(o, valid, valid_d, kP[j], 0.0f);
+                    val = rsum<NBK>(hd.c * lift(t, 0, uc));
                 }
-                const T val_o = xhalf(val);
-                v[2 * p] = sel(dl == 0, val, val_o);
-                if (2 * p + 1 < D) v[2 * p + 1] = sel(dl == 0, val_o, val);
+                if constexpr (NBK == 1) {
+                    const T val_o = xhalf(val);
+                    v[2 * p] = sel(dl == 0, val, val_o);
+                    if (2 * p + 1 < D) v[2 * p + 1] = sel(dl == 0, val_o, val);
+                } else {
+                    v[p] = val;
+                }
             }
         }
         if (lane == 0) {
@@ -612,23 +638,24 @@ __device__ __forceinline__ void hidden_bwd(const NetWave& net, T hb2, float (*ve
 }
 
 // mode 0: sum_b w1[b] log_pdf_b;  mode 1: sum_b (w1[b] psi_b + w2[b] laplacian_b)
-template <int D, class T>
+template <int D, class T, int NBK = 1>
 __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(kOccBwd<T>, kOccBwd<T>))) void k_wave_bwd(const ModelDev* __restrict__ mdp, int mode, const float* __restrict__ tabI, const float* __restrict__ tabP,
                                                    const float* __restrict__ fk_nat, int64_t B, const float* __restrict__ w1, const float* __restrict__ w2,
                                                    float* __restrict__ ws, const float* __restrict__ tails) {
     __shared__ float lds[kWaves][2][T::NC][64];
     const ModelDev& md = *mdp;
     constexpr int DIRS = kDirs<T, D>;
-    constexpr int P = (D + 1) / 2;
+    constexpr int P = NBK == 1 ? (D + 1) / 2 : D, W = 32 * NBK;
+    using RW = Rows<D, NBK>;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float (*vec)[64] = lds[wv][0];
     float (*ov)[64] = lds[wv][1];
-    const int dl = lane >> 5, j = lane & 31;
+    const int dl = NBK == 1 ? lane >> 5 : 0, j = NBK == 1 ? (lane & 31) : lane;
     const bool imade = md.layer_kind == WF_LAYER_IMADE;
     const bool has_pnet = md.prior_kind == WF_PRIOR_WAVEFLOW || md.prior_kind == WF_PRIOR_MFLOW;
     const int n_nets = md.n_layers + (has_pnet ? 1 : 0);
     const int n_mesh = (imade && md.n_layers > 0) ? md.isp.n_mesh : md.psp.n_mesh;   // (a model may have no flow layer at all)
-    const size_t plane = (size_t)n_mesh * NBP;
+    const size_t plane = (size_t)n_mesh * W;
     const float* __restrict__ gI = fk_nat;
     const float* __restrict__ kP = fk_nat + 64;
     T* const tag = nullptr;
@@ -636,7 +663,7 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(kOccBwd<T>,
     for (int64_t s = (int64_t)blockIdx.x * kWaves + wv; s < n_samples; s += (int64_t)gridDim.x * kWaves) {
         const int64_t b = s / DIRS;
         const int dir = (int)(s - b * DIRS);
-        const Tape tape{ws + s * (int64_t)n_nets * T::NC * Rows<D>::N, Rows<D>::N};
+        const Tape tape{ws + s * (int64_t)n_nets * T::NC * RW::N, RW::N};
         const float* tl = tails + s * (int64_t)Tail<D>::N * T::NC;
         T v[D], E;
         const T psi = psi_from_tail<D, T>(tl, md.constrained_mask, v, E);
@@ -662,21 +689,21 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(kOccBwd<T>,
             T hb2 = cst<T>(0.0f);
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-                const int d = 2 * p + dl;
+                const int d = NBK == 1 ? 2 * p + dl : p;
                 const bool valid_d = d < D, valid = valid_d && j < nb;
-                const T o = valid_d ? tget<T>(tape, NP, Rows<D>::O + d * NBP + j) : cst<T>(0.0f);   // head pre-activation, left by the forward sweep
+                const T o = valid_d ? tget<T>(tape, NP, RW::O + d * W + j) : cst<T>(0.0f);   // head pre-activation, left by the forward sweep
                 bool inside;
-                const T uc = clip01(sel(dl == 0, cur[2 * p], cur[2 * p + 1 < D ? 2 * p + 1 : 2 * p]), inside);
+                const T uc = clip01(NBK == 1 ? sel(dl == 0, cur[2 * p < D ? 2 * p : 0], cur[2 * p + 1 < D ? 2 * p + 1 : 0]) : cur[p], inside);
                 const Lerp lp = make_lerp(uc.c0, n_mesh);
                 float t[4];
-                lerp4(tabP, plane, lp, j, t);
+                lerp4<W>(tabP, plane, lp, j, t);
                 // adjoint of this half's prior factor v_d
                 T gv_lo, gv_hi;
                 {
                     T gvs[2];
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
-                        const int dd = 2 * p + q < D ? 2 * p + q : 2 * p;
+                        const int dd = NBK == 1 ? (2 * p + q < D ? 2 * p + q : 2 * p) : p;
                         const float sc = ((md.constrained_mask >> dd) & 1u) ? 0.70710678118654752f : 1.0f;
                         if (mode == 1) {
                             T others = cst<T>(1.0f);
@@ -698,25 +725,29 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(kOccBwd<T>,
                 const T gv = sel(dl == 0, gv_lo, gv_hi);
                 T go, d1;
                 if (md.prior_kind == WF_PRIOR_WAVEFLOW) {
-                    const PsiHead<T> hd = psi_head(o, valid, valid_d, kP[j], md.ob_to_b, ov, lane);
+                    const PsiHead<T> hd = psi_head<T, NBK>(o, valid, valid_d, kP[j], md.ob_to_b, ov, lane);
                     const T ge = gv * lift(t, 0, uc);
-                    const T dotE = half_sum(ge * hd.e);
-                    d1 = half_sum(hd.e * lift(t, 1, uc));
+                    const T dotE = rsum<NBK>(ge * hd.e);
+                    d1 = rsum<NBK>(hd.e * lift(t, 1, uc));
                     const T gc = (ge - hd.e * dotE) * hd.rN2;
                     put(ov, lane, gc);
-                    const T ga = gemv32_rows<T>(md.ob_to_b, ov, dl, j);          // abar_a = sum_j cbar_j ob_to_b[a][j]
-                    const T dotA = half_sum(ga * hd.a);
+                    const T ga = gemv32_rows<T, NBK>(md.ob_to_b, ov, dl, j);          // abar_a = sum_j cbar_j ob_to_b[a][j]
+                    const T dotA = rsum<NBK>(ga * hd.a);
                     go = ((ga - hd.a * dotA) * hd.rN1) * (valid ? kP[j] * hd.sgn : 0.0f);
                 } else {
-                    const SigHead<T> hd = sigmoid_head(o, valid, valid_d, kP[j], 0.0f);
-                    d1 = half_sum(hd.c * lift(t, 1, uc));
-                    go = sigmoid_head_bwd(hd, gv * lift(t, 0, uc), valid, kP[j]);
+                    const SigHead<T> hd = sigmoid_head<T, NBK>(o, valid, valid_d, kP[j], 0.0f);
+                    d1 = rsum<NBK>(hd.c * lift(t, 1, uc));
+                    go = sigmoid_head_bwd<T, NBK>(hd, gv * lift(t, 0, uc), valid, kP[j]);
                 }
                 const T gu = (valid_d && inside) ? gv * d1 : cst<T>(0.0f);
-                const T gu_o = xhalf(gu);
-                gU[2 * p] = gU[2 * p] + sel(dl == 0, gu, gu_o);
-                if (2 * p + 1 < D) gU[2 * p + 1] = gU[2 * p + 1] + sel(dl == 0, gu_o, gu);
-                if (valid_d) tput(tape, NP, Rows<D>::O + d * NBP + j, go);
+                if constexpr (NBK == 1) {
+                    const T gu_o = xhalf(gu);
+                    gU[2 * p] = gU[2 * p] + sel(dl == 0, gu, gu_o);
+                    if (2 * p + 1 < D) gU[2 * p + 1] = gU[2 * p + 1] + sel(dl == 0, gu_o, gu);
+                } else {
+                    gU[p] = gU[p] + gu;
+                }
+                if (valid_d) tput(tape, NP, RW::O + d * W + j, go);
                 put(ov, lane, go);
                 hb2 = hb2 + gemv<T>(net.W2b + p * 1024, ov, lane);
             }
@@ -732,32 +763,32 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(kOccBwd<T>,
 #pragma unroll
             for (int d = 0; d < D; ++d) {
                 gY[d] = gU[D - 1 - d];   // Reverse (bijections.py:337-340)
-                U[d] = tget<T>(tape, l, Rows<D>::U + d);
+                U[d] = tget<T>(tape, l, RW::U + d);
             }
 #pragma unroll
             for (int d = 0; d < D; ++d) gU[d] = cst<T>(0.0f);
             T hb2 = cst<T>(0.0f);
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-                const int d = 2 * p + dl;
+                const int d = NBK == 1 ? 2 * p + dl : p;
                 const bool valid_d = d < D;
-                const T o = valid_d ? tget<T>(tape, l, Rows<D>::O + d * NBP + j) : cst<T>(0.0f);
-                const T u = sel(dl == 0, U[2 * p], U[2 * p + 1 < D ? 2 * p + 1 : 2 * p]);
-                const T gy = sel(dl == 0, gY[2 * p], gY[2 * p + 1 < D ? 2 * p + 1 : 2 * p]);
+                const T o = valid_d ? tget<T>(tape, l, RW::O + d * W + j) : cst<T>(0.0f);
+                const T u = NBK == 1 ? sel(dl == 0, U[2 * p < D ? 2 * p : 0], U[2 * p + 1 < D ? 2 * p + 1 : 0]) : U[p];
+                const T gy = NBK == 1 ? sel(dl == 0, gY[2 * p < D ? 2 * p : 0], gY[2 * p + 1 < D ? 2 * p + 1 : 0]) : gY[p];
                 T go, gu;
                 if (imade) {
                     const int nb = md.isp.nb;
                     const bool valid = valid_d && j < nb;
-                    const SigHead<T> hd = sigmoid_head(o, valid, valid_d, gI[j], md.i_reg);
+                    const SigHead<T> hd = sigmoid_head<T, NBK>(o, valid, valid_d, gI[j], md.i_reg);
                     const Lerp lp = make_lerp(u.c0, n_mesh);
                     float t[4];
-                    lerp4(tabI, plane, lp, j, t);
+                    lerp4<W>(tabI, plane, lp, j, t);
                     const T b0 = lift(t, 0, u), b1 = lift(t, 1, u);
-                    const T dy = half_sum(hd.c * b1);
-                    const T y2 = half_sum(hd.c * lift(t, 2, u));
+                    const T dy = rsum<NBK>(hd.c * b1);
+                    const T y2 = rsum<NBK>(hd.c * lift(t, 2, u));
                     const T gdy = gLD * rrcp(dy + 1e-7f);
                     gu = valid_d ? gy * dy + gdy * y2 : cst<T>(0.0f);
-                    go = sigmoid_head_bwd(hd, gy * b0 + gdy * b1, valid, gI[j]);
+                    go = sigmoid_head_bwd<T, NBK>(hd, gy * b0 + gdy * b1, valid, gI[j]);
                 } else {
                     const T lw = from_lane(o, dl * 32), bias = from_lane(o, dl * 32 + 1);
                     const T e = rexp(cst<T>(0.0f) - lw);
@@ -767,10 +798,14 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(kOccBwd<T>,
                     if (valid_d && j == 0) go = cst<T>(0.0f) - (gy * y) - gLD;   // d y / d lw = -y,  d logdet / d lw = -1
                     if (valid_d && j == 1) go = cst<T>(0.0f) - (gy * e);          // d y / d bias = -e
                 }
-                const T gu_o = xhalf(gu);
-                gU[2 * p] = gU[2 * p] + sel(dl == 0, gu, gu_o);
-                if (2 * p + 1 < D) gU[2 * p + 1] = gU[2 * p + 1] + sel(dl == 0, gu_o, gu);
-                if (valid_d) tput(tape, l, Rows<D>::O + d * NBP + j, go);
+                if constexpr (NBK == 1) {
+                    const T gu_o = xhalf(gu);
+                    gU[2 * p] = gU[2 * p] + sel(dl == 0, gu, gu_o);
+                    if (2 * p + 1 < D) gU[2 * p + 1] = gU[2 * p + 1] + sel(dl == 0, gu_o, gu);
+                } else {
+                    gU[p] = gU[p] + gu;
+                }
+                if (valid_d) tput(tape, l, RW::O + d * W + j, go);
                 put(ov, lane, go);
                 hb2 = hb2 + gemv<T>(net.W2b + p * 1024, ov, lane);
             }
@@ -1064,18 +1099,18 @@ unsigned wave_grid(int64_t n_samples) {
     return (unsigned)blocks;
 }
 
-template <int D, class T>
+template <int D, class T, int NBK = 1>
 int run_fwd(const ModelDev* md_dev, const float* tabI4, const float* tabP4, const float* fk_nat, const float* x, int64_t B, float* ws, float* tails,
             int taped, hipStream_t s) {
     const int64_t n_samples = B * kDirs<T, D>;
-    hipLaunchKernelGGL((k_wave_fwd<D, T>), dim3(wave_grid(n_samples)), dim3(kWB), 0, s, md_dev, tabI4, tabP4, fk_nat, x, B, ws, tails, taped);
+    hipLaunchKernelGGL((k_wave_fwd<D, T, NBK>), dim3(wave_grid(n_samples)), dim3(kWB), 0, s, md_dev, tabI4, tabP4, fk_nat, x, B, ws, tails, taped);
     return finish();
 }
-template <int D, class T>
+template <int D, class T, int NBK = 1>
 int run_bwd(const ModelDev* md_dev, int mode, const float* tabI4, const float* tabP4, const float* fk_nat, int64_t B, const float* w1, const float* w2,
             float* ws, const float* tails, hipStream_t s) {
     const int64_t n_samples = B * kDirs<T, D>;
-    hipLaunchKernelGGL((k_wave_bwd<D, T>), dim3(wave_grid(n_samples)), dim3(kWB), 0, s, md_dev, mode, tabI4, tabP4, fk_nat, B, w1, w2, ws, tails);
+    hipLaunchKernelGGL((k_wave_bwd<D, T, NBK>), dim3(wave_grid(n_samples)), dim3(kWB), 0, s, md_dev, mode, tabI4, tabP4, fk_nat, B, w1, w2, ws, tails);
     return finish();
 }
 
@@ -1095,24 +1130,43 @@ int64_t wave_tail_floats(int D, int ring_kind) { return (int64_t)(2 * D + 1) * r
         default: return WF_ERR_UNSUPPORTED;       \
     }
 
+// 33..64 bases per dimension (nbp == 64): the one-dimension-per-pass kernels, built for D <= 4 (as the 64-row MFMA kernel)
+#define WF_WAVE_DISPATCH64(CALL)                  \
+    switch (md.D) {                               \
+        case 2: return CALL(2);                   \
+        case 3: return CALL(3);                   \
+        case 4: return CALL(4);                   \
+        default: return WF_ERR_UNSUPPORTED;       \
+    }
+
 int launch_wave_fwd(const ModelDev& md, const ModelDev* md_dev, int ring_kind, const float* tabI4, const float* tabP4, const float* fk_nat,
                     const float* x, int64_t B, float* ws, float* tails, int taped, void* stream) {
     hipStream_t s = (hipStream_t)stream;
-#define CALL(DD) (ring_kind == 2 ? run_fwd<DD, RF<DD>>(md_dev, tabI4, tabP4, fk_nat, x, B, ws, tails, taped, s)  \
-                  : ring_kind == 1 ? run_fwd<DD, R3>(md_dev, tabI4, tabP4, fk_nat, x, B, ws, tails, taped, s) \
-                                   : run_fwd<DD, R1>(md_dev, tabI4, tabP4, fk_nat, x, B, ws, tails, taped, s))
+#define CALLK(DD, K) (ring_kind == 2 ? run_fwd<DD, RF<DD>, K>(md_dev, tabI4, tabP4, fk_nat, x, B, ws, tails, taped, s)  \
+                      : ring_kind == 1 ? run_fwd<DD, R3, K>(md_dev, tabI4, tabP4, fk_nat, x, B, ws, tails, taped, s) \
+                                       : run_fwd<DD, R1, K>(md_dev, tabI4, tabP4, fk_nat, x, B, ws, tails, taped, s))
+#define CALL(DD) CALLK(DD, 1)
+#define CALL64(DD) CALLK(DD, 2)
+    if (md.nbp == 64) { WF_WAVE_DISPATCH64(CALL64) }
     WF_WAVE_DISPATCH(CALL)
 #undef CALL
+#undef CALL64
+#undef CALLK
 }
 
 int launch_wave_bwd(const ModelDev& md, const ModelDev* md_dev, int mode, int ring_kind, const float* tabI4, const float* tabP4,
                     const float* fk_nat, int64_t B, const float* w1, const float* w2, float* ws, const float* tails, void* stream) {
     hipStream_t s = (hipStream_t)stream;
-#define CALL(DD) (ring_kind == 2 ? run_bwd<DD, RF<DD>>(md_dev, mode, tabI4, tabP4, fk_nat, B, w1, w2, ws, tails, s)  \
-                  : ring_kind == 1 ? run_bwd<DD, R3>(md_dev, mode, tabI4, tabP4, fk_nat, B, w1, w2, ws, tails, s) \
-                                   : run_bwd<DD, R1>(md_dev, mode, tabI4, tabP4, fk_nat, B, w1, w2, ws, tails, s))
+#define CALLK(DD, K) (ring_kind == 2 ? run_bwd<DD, RF<DD>, K>(md_dev, mode, tabI4, tabP4, fk_nat, B, w1, w2, ws, tails, s)  \
+                      : ring_kind == 1 ? run_bwd<DD, R3, K>(md_dev, mode, tabI4, tabP4, fk_nat, B, w1, w2, ws, tails, s) \
+                                       : run_bwd<DD, R1, K>(md_dev, mode, tabI4, tabP4, fk_nat, B, w1, w2, ws, tails, s))
+#define CALL(DD) CALLK(DD, 1)
+#define CALL64(DD) CALLK(DD, 2)
+    if (md.nbp == 64) { WF_WAVE_DISPATCH64(CALL64) }
     WF_WAVE_DISPATCH(CALL)
 #undef CALL
+#undef CALL64
+#undef CALLK
 }
 
 // draw == 0: x = inverse(u);  draw == 1: latent ~ prior, x = inverse(latent)
@@ -1120,6 +1174,7 @@ int launch_wave_sample(const ModelDev& md, const ModelDev* md_dev, const float* 
                        unsigned long long seed, const float* u, int64_t B, float* x, float* latent, int exact,
                        const unsigned long long* seed_offset_dev, void* stream) {
     hipStream_t s = (hipStream_t)stream;
+    if (md.nbp != 32) return WF_ERR_UNSUPPORTED;   // the 64-row layout is built for the sweeps only
 #define CALL(DD)                                                                                                                          \
     hipLaunchKernelGGL(k_wave_sample<DD>, dim3(wave_grid(B)), dim3(kWB), 0, s, md_dev, tabI4, tabP4, fk_nat, draw, seed, u, B, x, latent, exact, \
                        seed_offset_dev);                                                                                                 \

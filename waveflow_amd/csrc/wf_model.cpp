@@ -84,16 +84,16 @@ struct wf_model {
     float* d_tabP = nullptr;
     float* d_fk_nat = nullptr;       // [2][32] natural-order row factors (I layers, prior) for k_prepare_dim0
     void* d_comp = nullptr;          // composite tables [n_nets][n_mesh] float4
-    const float* d_tabI4 = nullptr;  // [4][n_mesh][32]: I-spline derivative orders 0..3 (local energy)
-    const float* d_tabP3 = nullptr;  // [4][n_mesh][32]: orthogonal-B derivative orders 0..3 (the energy uses 0..2)
+    const float* d_tabI4 = nullptr;  // [4][n_mesh][nbp]: I-spline derivative orders 0..3 (local energy)
+    const float* d_tabP3 = nullptr;  // [4][n_mesh][nbp]: orthogonal-B derivative orders 0..3 (the energy uses 0..2)
     float* d_flat = nullptr;         // staging copy of a host parameter vector (wf_model_set_params)
     wf::PackRec* d_pack = nullptr;   // descriptions of every entry of the plain, wave and mfma images
     int64_t n_pack = 0;
     float* d_scratch = nullptr;      // private scratch of wf_hamiltonian_fwd (grown on demand)
     int64_t scratch_floats = 0;
-    float* d_wave = nullptr;         // NetWave images (nbp == 32 only)
+    float* d_wave = nullptr;         // NetWave images
     float* d_grad_fk = nullptr;      // [2][64] natural-order row factors for the reverse pass (flow rows, prior rows)
-    bool wave_ok = false;            // the wave-cooperative kernels cover this model (<= 32 bases, zero-only constraints)
+    bool wave_ok = false;            // the wave-cooperative sweeps cover this model (zero-only constraints; > 32 bases: D <= 4)
     bool grad_psi_ok = false;        // wf_psi_vjp (Waveflow prior, IMADE layers)
     int ring2 = 2;                   // coefficient ring of the second-order sweeps (ring_coefs, wf_internal.h): 2 = RF, 1 = R3
     int32_t* d_grad_map = nullptr;   // [n_params]: forward-image entry (over all nets) that holds each parameter, -1 = none
@@ -172,7 +172,8 @@ static int upload_table(wf_model* m, const std::vector<float>& h, const float** 
 
 static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::vector<double>& p64, const std::vector<double>& o2b);
 static int grad_prepare(wf_model* m);
-static int64_t wave_net_floats(int D);
+static int64_t wave_net_floats(int D, int nbp);
+static int wave_passes(int D, int nbp) { return nbp == 32 ? (D + 1) / 2 : D; }   // output passes: 2 dimensions x 32 rows, or 1 x 64
 }  // namespace wf
 static int ensure_scratch(const wf_model* cm, int64_t floats);
 static constexpr int kTapedLaplacianMaxD = 8;    // largest D whose reverse sweep runs in RF (measured, scratch/grad_ab.py)
@@ -239,9 +240,9 @@ static int model_build(wf_model* m) {
         rc = upload_table(m, rows, &md.isp.tab);
         if (rc) return rc;
         md.isp.nb = nb; md.isp.nbp = m->nbp; md.isp.n_mesh = d.n_mesh; md.isp.degree = d.i_degree;
-        if (m->nbp == 32) {
+        {   // derivative orders 0..3 for the wave kernels
             std::vector<float> rows4;
-            pack_rows(t64, nb, d.n_mesh, 4, 32, rows4);
+            pack_rows(t64, nb, d.n_mesh, 4, m->nbp, rows4);
             rc = upload_table(m, rows4, &m->d_tabI4);
             if (rc) return rc;
         }
@@ -267,9 +268,9 @@ static int model_build(wf_model* m) {
         rc = upload_table(m, rows, &md.psp.tab);
         if (rc) return rc;
         md.psp.nb = nb; md.psp.nbp = m->nbp; md.psp.n_mesh = d.n_mesh; md.psp.degree = d.p_degree;
-        if (m->nbp == 32) {
+        {
             std::vector<float> rows3;
-            pack_rows(ob64, nb, d.n_mesh, 4, 32, rows3);
+            pack_rows(ob64, nb, d.n_mesh, 4, m->nbp, rows3);
             rc = upload_table(m, rows3, &m->d_tabP3);
             if (rc) return rc;
         }
@@ -303,9 +304,9 @@ static int model_build(wf_model* m) {
         rc = upload_table(m, rows, &md.psp.tab);
         if (rc) return rc;
         md.psp.nb = nb; md.psp.nbp = m->nbp; md.psp.n_mesh = d.n_mesh; md.psp.degree = d.p_degree;
-        if (m->nbp == 32) {
+        {
             std::vector<float> rows4;
-            pack_rows(t64, nb, d.n_mesh, 4, 32, rows4);
+            pack_rows(t64, nb, d.n_mesh, 4, m->nbp, rows4);
             rc = upload_table(m, rows4, &m->d_tabP3);
             if (rc) return rc;
         }
@@ -354,12 +355,12 @@ static int model_build(wf_model* m) {
         np.W1n = p; p += (int64_t)kHidden * kHidden;
         np.W2n = p;
     }
-    if (m->nbp == 32) {
-        const int P = (D + 1) / 2;
-        rc = dev_alloc(m, &m->d_wave, (size_t)(wave_net_floats(D) * n_nets));
+    {
+        const int P = wave_passes(D, m->nbp);
+        rc = dev_alloc(m, &m->d_wave, (size_t)(wave_net_floats(D, m->nbp) * n_nets));
         if (rc) return rc;
         for (int n = 0; n < n_nets; ++n) {
-            float* p = m->d_wave + wave_net_floats(D) * n;
+            float* p = m->d_wave + wave_net_floats(D, m->nbp) * n;
             NetWave& nw = md.wnets[n];
             nw.W0 = p; p += (int64_t)D * kHidden;
             nw.b0 = p; p += kHidden;
@@ -437,19 +438,20 @@ static void describe_plain_image(const wf_model* m, int n, uint32_t base, std::v
 
 
 // Wave-kernel image of net n (NetWave): W0 [D][64], b0, b1, b2 [P][64], W1f, W1b [16][64][4], W2f, W2b [P][16][64][4]
-static int64_t wave_net_floats(int D) {
-    const int P = (D + 1) / 2;
+static int64_t wave_net_floats(int D, int nbp) {
+    const int P = wave_passes(D, nbp);
     return (int64_t)D * kHidden + 2 * kHidden + (int64_t)P * 64 + 2 * 4096 + (int64_t)P * 2 * 4096;
 }
 
 static void describe_wave_image(const wf_model* m, int n, uint32_t base, std::vector<PackRec>& out) {
-    const int D = m->desc.n_dim, H = kHidden, P = (D + 1) / 2;
+    const int D = m->desc.n_dim, H = kHidden, P = wave_passes(D, m->nbp);
+    const bool wide = m->nbp == 64;
     const NetLayout& nl = m->nets[n];
     const NetOffsets q = net_offsets(m, n);
     auto w1m = [&](int a, int j) -> int64_t { return deg_hidden(j, D) >= deg_hidden(a, D) ? q.W1 + (int64_t)a * H + j : -1; };
-    // column of output lane c of pass p: (d, jb) = (2p + (c >> 5), c & 31)
+    // column of output lane c of pass p: (d, jb) = (2p + (c >> 5), c & 31), or (p, c) in the 64-row layout
     auto w2m = [&](int a, int p, int c) -> int64_t {
-        const int d = 2 * p + (c >> 5), jb = c & 31;
+        const int d = wide ? p : 2 * p + (c >> 5), jb = wide ? c : (c & 31);
         if (d >= D || jb >= nl.n_out || deg_out(d) < deg_hidden(a, D)) return -1;
         return q.W2 + (int64_t)a * q.NO + (jb * D + d);
     };
@@ -460,7 +462,7 @@ static void describe_wave_image(const wf_model* m, int n, uint32_t base, std::ve
     for (int j = 0; j < H; ++j) w.f32(q.b1 + j);
     for (int p = 0; p < P; ++p)
         for (int c = 0; c < 64; ++c) {
-            const int d = 2 * p + (c >> 5), jb = c & 31;
+            const int d = wide ? p : 2 * p + (c >> 5), jb = wide ? c : (c & 31);
             w.f32((d < D && jb < nl.n_out) ? q.b2 + jb * D + d : -1);
         }
     for (int g = 0; g < 16; ++g)
@@ -703,7 +705,7 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
 // The wave-cooperative kernels (wf_kernels_wave.hip): <= 32 bases, constraints that only zero the end weights.
 static bool wave_capable(const wf_model* m) {
     const wf_model_desc& d = m->desc;
-    if (m->nbp != 32 || !m->d_wave) return false;
+    if (!m->d_wave || (m->nbp == 64 && d.n_dim > 4)) return false;   // (the 64-row sweeps are built for D <= 4)
     const bool imade = d.layer_kind == WF_LAYER_IMADE && d.n_flow_layers > 0;
     if (imade && (!m->d_tabI4 || !bc_only_zeroes(d.i_left, d.i_right, true))) return false;
     const bool spline_prior = d.prior_kind == WF_PRIOR_WAVEFLOW || d.prior_kind == WF_PRIOR_MFLOW;
@@ -721,7 +723,7 @@ static int pack_prepare(wf_model* m, std::vector<PackRec>& plain) {
     std::vector<PackRec> wave, mfma;
     for (int n = 0; n < n_nets; ++n) {
         describe_plain_image(m, n, (uint32_t)m->plain_off[n], plain);
-        if (m->d_wave) describe_wave_image(m, n, (uint32_t)(wave_net_floats(D) * n), wave);
+        if (m->d_wave) describe_wave_image(m, n, (uint32_t)(wave_net_floats(D, m->nbp) * n), wave);
         if (m->mfma_ok) describe_mfma_image(m, n, (uint32_t)((int64_t)m->mdev.net_floats * n), mfma);
     }
     std::vector<PackRec> all;
@@ -753,9 +755,9 @@ static int grad_prepare(wf_model* m) {
     if (m->wave_ok) {
         std::vector<float> fk(128, 0.0f), acc(64);
         if (d.layer_kind == WF_LAYER_IMADE && d.n_flow_layers > 0)
-            row_factors(WF_SPLINE_I, true, d.i_degree, m->i_nb, 1, d.i_left, d.i_right, acc.data(), fk.data());
-        if (d.prior_kind == WF_PRIOR_WAVEFLOW) row_factors(WF_SPLINE_B, false, d.p_degree, m->p_nb, 1, d.p_left, d.p_right, acc.data(), fk.data() + 64);
-        if (d.prior_kind == WF_PRIOR_MFLOW) row_factors(WF_SPLINE_M, true, d.p_degree, m->p_nb, 1, d.p_left, d.p_right, acc.data(), fk.data() + 64);
+            row_factors(WF_SPLINE_I, true, d.i_degree, m->i_nb, m->nbp / 32, d.i_left, d.i_right, acc.data(), fk.data());
+        if (d.prior_kind == WF_PRIOR_WAVEFLOW) row_factors(WF_SPLINE_B, false, d.p_degree, m->p_nb, m->nbp / 32, d.p_left, d.p_right, acc.data(), fk.data() + 64);
+        if (d.prior_kind == WF_PRIOR_MFLOW) row_factors(WF_SPLINE_M, true, d.p_degree, m->p_nb, m->nbp / 32, d.p_left, d.p_right, acc.data(), fk.data() + 64);
         int rc = dev_alloc(m, &m->d_grad_fk, fk.size());
         if (rc) return rc;
         WF_HIP(hipMemcpy(m->d_grad_fk, fk.data(), fk.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -1021,7 +1023,7 @@ int wf_inverse_fwd(const wf_model* m, const float* u_dev, int64_t B, float* x_de
     if (rc) return rc;
     DeviceGuard g(m->device);
     if (B == 0) return WF_OK;
-    if (m->wave_ok && B <= wave_sample_max())
+    if (m->wave_ok && m->nbp == 32 && B <= wave_sample_max())
         return launch_wave_sample(m->dev, m->d_dev, m->d_tabI4, m->d_tabP3, m->d_grad_fk, 0, 0ull, u_dev, B, x_dev, nullptr, exact, nullptr, stream);
     return launch_scalar_inverse(m->dev, m->d_dev, u_dev, B, x_dev, exact, stream);
 }
@@ -1031,7 +1033,7 @@ int wf_sample(const wf_model* m, uint64_t seed, int64_t B, float* x_dev, float* 
     if (rc) return rc;
     DeviceGuard g(m->device);
     if (B == 0) return WF_OK;
-    if (m->wave_ok && B <= wave_sample_max())
+    if (m->wave_ok && m->nbp == 32 && B <= wave_sample_max())
         return launch_wave_sample(m->dev, m->d_dev, m->d_tabI4, m->d_tabP3, m->d_grad_fk, 1, (unsigned long long)seed, nullptr, B, x_dev, latent_dev,
                                   exact, nullptr, stream);
     return launch_scalar_sample(m->dev, m->d_dev, (unsigned long long)seed, B, x_dev, latent_dev, exact, stream);
@@ -1085,7 +1087,7 @@ static int64_t vjp_bytes_per_walker(const wf_model* m, bool second_order) {
     const int D = m->desc.n_dim;
     const int kind = second_order ? m->ring2 : 0;
     const int64_t samples = ring_samples(D, kind), nc = ring_coefs(D, kind);
-    return (samples * ((int64_t)m->nets.size() * grad_ws_rows(D) * nc) + wave_tail_floats(D, kind) + 4) * (int64_t)sizeof(float);
+    return (samples * ((int64_t)m->nets.size() * grad_ws_rows(D, m->nbp) * nc) + wave_tail_floats(D, kind) + 4) * (int64_t)sizeof(float);
 }
 
 static int64_t vjp_ws_bytes(const wf_model* m, int64_t B, bool second_order) {
@@ -1112,7 +1114,7 @@ static int run_vjp_chunks(const wf_model* m, int mode, bool second_order, const 
     const int kind = second_order ? m->ring2 : 0;
     const int64_t samples_per = ring_samples(D, kind), nc = ring_coefs(D, kind);
     float* tape = (float*)workspace_dev;
-    float* tails = tape + chunk * samples_per * n_nets * grad_ws_rows(D) * nc;
+    float* tails = tape + chunk * samples_per * n_nets * grad_ws_rows(D, m->nbp) * nc;
     float* per_walker = tails + chunk * wave_tail_floats(D, kind);   // [4][chunk]
     if (B == 0) {   // the gradient of an empty batch is zero
         WF_HIP(hipMemsetAsync(grad_dev, 0, (size_t)m->n_params * sizeof(float), s));
@@ -1145,7 +1147,7 @@ static int run_vjp_chunks(const wf_model* m, int mode, bool second_order, const 
         rc = launch_wave_bwd(m->dev, m->d_dev, (mode == 0 || mode == 3) ? 0 : 1, kind, m->d_tabI4, m->d_tabP3, m->d_grad_fk, bc, cw1, cw2, tape,
                              tails, stream);
         if (rc) return rc;
-        rc = launch_wgrad(D, kind, n_nets, bc * samples_per, tape, m->d_grad_partial, c0 > 0, m->d_grad_img, fwd,
+        rc = launch_wgrad(D, m->nbp, kind, n_nets, bc * samples_per, tape, m->d_grad_partial, c0 > 0, m->d_grad_img, fwd,
                           single ? &split : nullptr, stream);
         if (rc) return rc;
     }
@@ -1206,7 +1208,7 @@ static int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
 
 int64_t wf_vqmc_train_step_workspace_bytes(const wf_model* m, int64_t batch) {
     if (!m || batch < 1) return WF_ERR_INVALID;
-    if (!m->d_grad_map || !m->grad_psi_ok || batch > kWaveSampleMax) return WF_ERR_UNSUPPORTED;
+    if (!m->d_grad_map || !m->grad_psi_ok || m->nbp != 32 || batch > kWaveSampleMax) return WF_ERR_UNSUPPORTED;
     return align256(batch * m->desc.n_dim * 4) + align256(batch * 4) + align256(m->n_params * 4) + 256 + align256(block_sums_ws_bytes(batch)) +
            vjp_ws_bytes(m, batch, true);
 }
@@ -1217,7 +1219,7 @@ int wf_vqmc_train_step(wf_model* m, const wf_train_state* st, uint64_t seed, int
     if (!m || !st || batch < 1 || n_protons < 0 || n_protons > 8 || (n_protons > 0 && !protons_host)) return WF_ERR_INVALID;
     if (!st->params_dev || !st->m_dev || !st->v_dev || !st->counter_dev || !st->running_average_dev || !st->loss_ring_dev || st->ring_len < 1)
         return WF_ERR_INVALID;
-    if (!m->d_grad_map || !m->grad_psi_ok || !m->wave_ok || batch > kWaveSampleMax) return WF_ERR_UNSUPPORTED;
+    if (!m->d_grad_map || !m->grad_psi_ok || !m->wave_ok || m->nbp != 32 || batch > kWaveSampleMax) return WF_ERR_UNSUPPORTED;   // (wave sampler: <= 32 bases)
     if (!m->params_set || !workspace_dev || workspace_bytes < wf_vqmc_train_step_workspace_bytes(m, batch)) return WF_ERR_INVALID;
     DeviceGuard g(m->device);
     const int D = m->desc.n_dim;

@@ -24,8 +24,8 @@ constexpr int NBP = 32;
 // Rows of one net in the tape of the reverse pass ([sample][net][coefficient][row]): layer input U (D <= 8 rows in a slot of 8),
 // hidden activations H1, H2, pre-activation adjoints A1, A2, head-output adjoints O (row d * 32 + j).  Every group starts
 // at a multiple of 4 rows so that k_wgrad can stage with 16-byte loads.
-template <int D> struct Rows {
-    static constexpr int U = 0, H1 = 8, H2 = 8 + 64, A1 = 8 + 128, A2 = 8 + 192, O = 8 + 256, N = 8 + 256 + D * NBP;
+template <int D, int NBK = 1> struct Rows {   // NBK: 32-row blocks per dimension (1: <= 32 bases, 2: <= 64)
+    static constexpr int U = 0, H1 = 8, H2 = 8 + 64, A1 = 8 + 128, A2 = 8 + 192, O = 8 + 256, N = 8 + 256 + D * NBP * NBK;
     static_assert(D <= 8, "the U slot holds 8 rows");
 };
 
@@ -184,11 +184,12 @@ __device__ __forceinline__ Lerp make_lerp(float x0, int n_mesh) {
     const int xl = (int)floorf(xs), xr = (int)ceilf(xs);
     return Lerp{wrap_clamp(xl, n_mesh), wrap_clamp(xr, n_mesh), x0 - (float)xl / (float)n_points, (float)n_points};
 }
-// t[o] = order-o lerp of basis j, o = 0..3; tab [4][n_mesh][NBP]
+// t[o] = order-o lerp of basis j, o = 0..3; tab [4][n_mesh][W]
+template <int W = NBP>
 __device__ __forceinline__ void lerp4(const float* __restrict__ tab, size_t plane, const Lerp& L, int j, float (&t)[4]) {
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
-        const float yl = tab[o * plane + (size_t)L.il * NBP + j], yr = tab[o * plane + (size_t)L.ir * NBP + j];
+        const float yl = tab[o * plane + (size_t)L.il * W + j], yr = tab[o * plane + (size_t)L.ir * W + j];
         t[o] = yl + ((yr - yl) * L.n) * L.dx;
     }
 }
