@@ -184,8 +184,8 @@ int wf_sample(const wf_model* m, uint64_t seed, int64_t B, float* x_dev, float* 
  * with physics.laplacian (:50-52, trace of jax.hessian -- the table lerp differentiates to the next cached derivative table,
  * isplines_jax.py:60-66) and the one-dimensional soft-Coulomb physics.get_potential (:60-76) for `n_protons` <= 8 protons at
  * `protons_host`.  hpsi_dev[B]; psi_dev[B] and laplacian_dev[B] may be NULL.  The local energy of vqmc.loss_fn_efficient
- * (vqmc.py:193-200) is hpsi / (psi + 1e-8).  WF_PRIOR_WAVEFLOW models with IMADE layers, <= 32 bases per dimension,
- * zero-only boundary constraints (any D the library supports: 2..8). */
+ * (vqmc.py:193-200) is hpsi / (psi + 1e-8).  WF_PRIOR_WAVEFLOW models with IMADE layers, zero-only boundary constraints;
+ * D = 2..8 with <= 32 bases per dimension, D = 2..4 with 33..64. */
 int wf_hamiltonian_fwd(const wf_model* m, const float* x_dev, int64_t B, const float* protons_host, int32_t n_protons,
                        float* hpsi_dev, float* psi_dev, float* laplacian_dev, void* stream);
 
@@ -216,7 +216,8 @@ int wf_vqmc_loss_grad(const wf_model* m, const float* x_dev, int64_t B, const fl
  *   running_average_dev  the `running_average` of loss_fn_efficient (the caller refreshes it every 100 steps, vqmc.py:112-113)
  *   loss_ring_dev        [ring_len][3] doubles: [sum E_L, sum E_L^2, batch] of each step
  * The model's weight images must hold params_dev on entry (wf_model_set_params_device); they hold the updated parameters on
- * exit.  Single process; batch <= 131072 (the wave sampler).  Workspace: wf_vqmc_train_step_workspace_bytes. */
+ * exit.  Single process; batch <= 131072 and <= 32 bases per dimension (the wave sampler; otherwise WF_ERR_UNSUPPORTED: step from the
+ * host with wf_sample, wf_vqmc_loss_grad, wf_adam_step).  Workspace: wf_vqmc_train_step_workspace_bytes. */
 typedef struct wf_train_state {
     float* params_dev;
     float* m_dev;
@@ -239,7 +240,7 @@ int wf_mle_train_step(wf_model* m, const wf_train_state* st, const float* x_dev,
                       void* workspace_dev, int64_t workspace_bytes, void* stream);
 
 /* Parameter gradient of the log-density: grad_dev[p] = sum_b w_dev[b] * d log_pdf_b / d theta_p for every model wf_logpdf_fwd
- * evaluates with <= 32 bases per dimension and zero-only constraints (IMADE or MADE layers; Waveflow, M-spline, Normal or Uniform
+ * evaluates with zero-only constraints and <= 32 bases per dimension (or <= 64 for D <= 4) (IMADE or MADE layers; Waveflow, M-spline, Normal or Uniform
  * prior).  With w = -1/B this is the gradient of benchmark_tests.loss (benchmark_tests.py:84-87, 98-101); with per-walker
  * weights it is the jacrev(log_pdf) contraction of vqmc.train_step (vqmc.py:175-180). */
 int64_t wf_logpdf_vjp_workspace_bytes(const wf_model* m, int64_t B);

@@ -110,6 +110,21 @@ def test_training_reduces_the_energy_and_writes_the_reference_artefacts(tmp_path
     assert checkpoint.load_reference_checkpoint(f"{sd}/checkpoints")[1] == 320
 
 
+def test_training_with_more_than_32_bases(tmp_path):
+    """trainer.num_knots = 33 (examples/run_vqmc.py:10 pokes this attribute): 39 / 38 bases per dimension.  The sweeps run in the
+    64-row layout; the fused step (whose sampler is 32-row only) gives way to the host-stepped loop."""
+    from waveflow_amd import vqmc
+    t = vqmc.ModelTrainer(system_name="He", learning_rate=1e-3, box_length=10, num_epochs=150, batch_size=256, log_every=10 ** 9)
+    t.num_knots = 33
+    t.save_dir = str(tmp_path / "He_33")
+    t.exact_sampler = True
+    params, loss = t.start_training(verbose=False)
+    l = np.asarray(loss[1:], dtype=np.float64)
+    assert (t.psi.model.i_nb, t.psi.model.p_nb) == (39, 38)
+    assert np.isfinite(l).all() and len(l) == 150
+    assert np.median(l[-30:]) < 0.5 * np.median(l[:30])
+
+
 def test_loss_fn_efficient_value_matches_sums(he_flat):
     from waveflow_amd import vqmc
     from waveflow_amd.utils import physics

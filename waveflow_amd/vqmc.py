@@ -180,7 +180,13 @@ class ModelTrainer:
                 json.dump(system_dict, fout_sys, indent=4)
         if verbose:
             print("Start training...")
-        if self.use_graph and not distributed and self.batch_size <= 131072:
+        # the whole step as one captured launch sequence, where the library has it (wave sampler: <= 32 bases per dimension,
+        # <= 131072 walkers); otherwise the host-stepped loop below (sampler, loss + gradient, Adam: three library calls per step)
+        fused = self.use_graph and not distributed
+        if fused:
+            from . import _lib
+            fused = _lib.lib().wf_vqmc_train_step_workspace_bytes(psi.model._h, int(self.batch_size)) > 0
+        if fused:
             params, loss, energies = self._train_graphed(psi, sample, h_fn, opt_state, get_params, start_epoch, loss, energies, system_dict,
                                                          save_dir, rng, verbose)
             self.params, self.loss, self.energies = params, loss, energies
