@@ -216,8 +216,8 @@ int wf_vqmc_loss_grad(const wf_model* m, const float* x_dev, int64_t B, const fl
  *   running_average_dev  the `running_average` of loss_fn_efficient (the caller refreshes it every 100 steps, vqmc.py:112-113)
  *   loss_ring_dev        [ring_len][3] doubles: [sum E_L, sum E_L^2, batch] of each step
  * The model's weight images must hold params_dev on entry (wf_model_set_params_device); they hold the updated parameters on
- * exit.  Single process; batch <= 131072 and <= 32 bases per dimension (the wave sampler; otherwise WF_ERR_UNSUPPORTED: step from the
- * host with wf_sample, wf_vqmc_loss_grad, wf_adam_step).  Workspace: wf_vqmc_train_step_workspace_bytes. */
+ * exit.  Single process; batch <= 131072 (the wave sampler; beyond: WF_ERR_UNSUPPORTED, step from the host with wf_sample,
+ * wf_vqmc_loss_grad, wf_adam_step).  Workspace: wf_vqmc_train_step_workspace_bytes. */
 typedef struct wf_train_state {
     float* params_dev;
     float* m_dev;

@@ -112,7 +112,7 @@ def test_training_reduces_the_energy_and_writes_the_reference_artefacts(tmp_path
 
 def test_training_with_more_than_32_bases(tmp_path):
     """trainer.num_knots = 33 (examples/run_vqmc.py:10 pokes this attribute): 39 / 38 bases per dimension.  The sweeps run in the
-    64-row layout; the fused step (whose sampler is 32-row only) gives way to the host-stepped loop."""
+    64-row layout, in the fused (captured) step like the 32-row ones."""
     from waveflow_amd import vqmc
     t = vqmc.ModelTrainer(system_name="He", learning_rate=1e-3, box_length=10, num_epochs=150, batch_size=256, log_every=10 ** 9)
     t.num_knots = 33

@@ -138,3 +138,34 @@ def test_wave_and_one_lane_samplers_draw_from_the_same_distribution(he_flat, mon
     small = m.inverse(u, exact=True)                                          # one wave per walker
     d = np.abs(big - small)
     assert np.median(d) < 1e-6 and np.quantile(d, 0.999) < 2e-4 and d.max() < 2e-3
+
+
+def test_wave_sampler_with_more_than_32_bases(monkeypatch):
+    """33 knots at k = 6 (39 / 38 bases): the wave sampler in its 64-row layout against the one-lane kernel -- same marginals, same
+    inverse; and direct(inverse(u)) = u."""
+    from scipy import stats
+    from waveflow_amd import model_factory
+    init_fun = model_factory.get_waveflow_model(2, base_spline_degree=6, i_spline_degree=6, n_prior_internal_knots=33,
+                                                n_i_internal_knots=33, i_spline_reg=0.05, i_spline_reverse_fun_tol=1e-6,
+                                                n_flow_layers=2, box_size=10, xu_coord_type="mean")
+    params, psi, log_pdf, sample = init_fun(3, 2)
+    m = psi.model
+    m.ensure_params(params)
+    assert (m.i_nb, m.p_nb) == (39, 38)
+    for exact in (True, False):
+        monkeypatch.setenv("WF_WAVE_SAMPLE_MAX", "100000000")                 # one wave per walker
+        xa, la = m.sample(7, 30000, return_latent=True, exact=exact)
+        monkeypatch.setenv("WF_WAVE_SAMPLE_MAX", "0")                         # one lane per walker
+        xb, lb = m.sample(8, 40000, return_latent=True, exact=exact)
+        for c in range(2):
+            for a, b in ((xa, xb), (la, lb)):
+                p = stats.ks_2samp(a[:, c].cpu().numpy(), b[:, c].cpu().numpy()).pvalue
+                assert p > 1e-4, (exact, c, p)
+    u = np.random.default_rng(0).uniform(0.01, 0.99, size=(20000, 2)).astype(np.float32)
+    big = m.inverse(u, exact=True)
+    monkeypatch.setenv("WF_WAVE_SAMPLE_MAX", "100000000")
+    small = m.inverse(u, exact=True)
+    d = np.abs(big - small)
+    assert np.median(d) < 1e-6 and np.quantile(d, 0.999) < 2e-4 and d.max() < 2e-3
+    u2, _ = m.flow(small)
+    assert np.median(np.abs(u2 - u)) < 2e-5 and np.abs(u2 - u).max() < 5e-3

@@ -834,9 +834,10 @@ __device__ __forceinline__ float of_half(float v, int h, int dl) {
     const float o = swap32_other(v);
     return dl == h ? v : o;
 }
-// order-0 lerp of basis row j (tab: [orders][n_mesh][32])
+// order-0 lerp of basis row j (tab: [orders][n_mesh][W])
+template <int W = NBP>
 __device__ __forceinline__ float lerp0(const float* __restrict__ tab, const Lerp& L, int j) {
-    const float yl = tab[(size_t)L.il * NBP + j], yr = tab[(size_t)L.ir * NBP + j];
+    const float yl = tab[(size_t)L.il * W + j], yr = tab[(size_t)L.ir * W + j];
     return yl + ((yr - yl) * L.n) * L.dx;
 }
 
@@ -846,15 +847,17 @@ __device__ __forceinline__ float lerp0(const float* __restrict__ tab, const Lerp
 // the spline at one mesh point), (2) the root follows from the line through its two mesh values, (3) it is rounded down to the
 // halving grid 2^-K.  (A halving loop in fp32 takes a wrong turn when |f(mid)| is below its rounding noise, so does this; both
 // stay within one grid step of the exact-arithmetic answer.)  c: this lane's weight (lanes of half `hd` hold the dimension).
-__device__ __forceinline__ float ispline_inverse(const float* __restrict__ tab0 /* [n_mesh][32], order 0 */, int n_mesh, int nb, float c,
+template <int NBK = 1>
+__device__ __forceinline__ float ispline_inverse(const float* __restrict__ tab0 /* [n_mesh][32 NBK], order 0 */, int n_mesh, int nb, float c,
                                                  float y, float tol, int hd, float (*ov)[64], int lane) {
+    constexpr int W = 32 * NBK;
     put(ov, lane, R1{c});
-    const float* __restrict__ cw = &ov[0][hd * 32];
+    const float* __restrict__ cw = &ov[0][NBK == 1 ? hd * 32 : 0];
     auto spline_at = [&](int m) {   // sum_j c_j T[m][j], j ascending
-        const float4_t* __restrict__ row = reinterpret_cast<const float4_t*>(tab0 + (size_t)m * NBP);
+        const float4_t* __restrict__ row = reinterpret_cast<const float4_t*>(tab0 + (size_t)m * W);
         float acc = 0.0f;
 #pragma unroll
-        for (int q = 0; q < NBP / 4; ++q) {
+        for (int q = 0; q < W / 4; ++q) {
             const float4_t t = row[q], w = *reinterpret_cast<const float4_t*>(cw + 4 * q);
             acc = __builtin_fmaf(w.x, t.x, acc);
             acc = __builtin_fmaf(w.y, t.y, acc);
@@ -898,7 +901,9 @@ __device__ __forceinline__ float ispline_inverse(const float* __restrict__ tab0 
         const int side = lane >> 5, jj = lane & 31;
         const float xq = fminf(q + (float)side, scale - 1.0f) / scale;
         const Lerp L = make_lerp(xq, n_mesh);
-        const float f = hsum(cw[jj] * lerp0(tab0, L, jj)) - y;
+        float term = cw[jj] * lerp0<W>(tab0, L, jj);
+        if constexpr (NBK == 2) term += cw[jj + 32] * lerp0<W>(tab0, L, jj + 32);
+        const float f = hsum(term) - y;
         const float f_other = swap32_other(f);
         const float f_lo = side == 0 ? f : f_other, f_hi = side == 0 ? f_other : f;
         if (f_hi <= 0.0f && q + 1.0f <= scale - 1.0f) q = q + 1.0f;
@@ -907,10 +912,10 @@ __device__ __forceinline__ float ispline_inverse(const float* __restrict__ tab0 
     return q / scale;
 }
 
-template <int D>
+template <int D, int NBK = 1>
 __device__ __forceinline__ void wave_serial_inverse(const ModelDev& md, const float* __restrict__ tabI, const float* __restrict__ gI, float (&cur)[D],
                                                     float (*vec)[64], float (*ov)[64], int lane, int exact) {
-    const int dl = lane >> 5, j = lane & 31;
+    const int dl = NBK == 1 ? lane >> 5 : 0, j = NBK == 1 ? (lane & 31) : lane;
     const Tape no_tape{nullptr, 0};
     float nxt[D];
     for (int l = md.n_layers - 1; l >= 0; --l) {
@@ -924,7 +929,7 @@ __device__ __forceinline__ void wave_serial_inverse(const ModelDev& md, const fl
             const float tol = md.reverse_tol;
 #pragma unroll
             for (int d = 0; d < D; ++d) {
-                const int p = d >> 1, hd = d & 1;
+                const int p = NBK == 1 ? d >> 1 : d, hd = NBK == 1 ? (d & 1) : 0;
                 R1 o;
                 if (d == 0) {
                     // output dimension 0 sees no input (MADE mask, model_factory.py:15-18): its head is the bias alone
@@ -938,14 +943,14 @@ __device__ __forceinline__ void wave_serial_inverse(const ModelDev& md, const fl
                     }
                     o = gemv<R1, true>(net.W2f + p * 1024, vec, lane) + net.b2[p * 64 + lane];
                 }
-                const bool valid_d = 2 * p + dl < D, valid = valid_d && j < nb;
-                const SigHead<R1> hdw = sigmoid_head(o, valid, valid_d, gI[j], md.i_reg);
-                cur[d] = ispline_inverse(tabI, n_mesh, nb, hdw.c.c0, nxt[d], tol, hd, ov, lane);
+                const bool valid_d = (NBK == 1 ? 2 * p + dl : p) < D, valid = valid_d && j < nb;
+                const SigHead<R1> hdw = sigmoid_head<R1, NBK>(o, valid, valid_d, gI[j], md.i_reg);
+                cur[d] = ispline_inverse<NBK>(tabI, n_mesh, nb, hdw.c.c0, nxt[d], tol, hd, ov, lane);
             }
         } else {
 #pragma unroll
             for (int c = 0; c < D; ++c) {
-                const int p = c >> 1, hd = c & 1;
+                const int p = NBK == 1 ? c >> 1 : c, hd = NBK == 1 ? (c & 1) : 0;
                 R1 o;
                 if (c == 0) {
                     o = R1{net.b2[lane]};
@@ -969,7 +974,7 @@ __device__ __forceinline__ void wave_serial_inverse(const ModelDev& md, const fl
 }
 
 // seed_mode 0: invert the latent points ug;  1: draw the latent points from the prior first (and report them)
-template <int D>
+template <int D, int NBK = 1>
 __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(WF_OCC_SAMPLE, WF_OCC_SAMPLE))) void k_wave_sample(
     const ModelDev* __restrict__ mdp, const float* __restrict__ tabI, const float* __restrict__ tabP, const float* __restrict__ fk_nat, int draw,
     unsigned long long seed, const float* __restrict__ ug, int64_t B, float* __restrict__ xg, float* __restrict__ latent, int exact,
@@ -980,7 +985,8 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(WF_OCC_SAMP
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float (*vec)[64] = lds[wv][0];
     float (*ov)[64] = lds[wv][1];
-    const int dl = lane >> 5, j = lane & 31;
+    constexpr int W = 32 * NBK;
+    const int dl = NBK == 1 ? lane >> 5 : 0, j = NBK == 1 ? (lane & 31) : lane;
     const float* __restrict__ gI = fk_nat;
     const float* __restrict__ kP = fk_nat + 64;
     const Tape no_tape{nullptr, 0};
@@ -1008,7 +1014,7 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(WF_OCC_SAMP
                 const bool wavefn = md.prior_kind == WF_PRIOR_WAVEFLOW;
 #pragma unroll
                 for (int col = 0; col < D; ++col) {
-                    const int p = col >> 1, hd = col & 1;
+                    const int p = NBK == 1 ? col >> 1 : col, hd = NBK == 1 ? (col & 1) : 0;
                     R1 o;
                     if (col == 0) {
                         o = R1{net.b2[lane]};   // column 0 is conditioned on nothing: bias only
@@ -1019,19 +1025,25 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(WF_OCC_SAMP
                         hidden_fwd<D, R1, true>(net, xin, vec, lane, no_tape, 0, false);
                         o = gemv<R1, true>(net.W2f + p * 1024, vec, lane) + net.b2[p * 64 + lane];
                     }
-                    const bool valid_d = 2 * p + dl < D, valid = valid_d && j < nb;
+                    const bool valid_d = (NBK == 1 ? 2 * p + dl : p) < D, valid = valid_d && j < nb;
                     float cj, ymax;
+                    // maximum over the rows of the column, in every lane
+                    auto col_max = [&](float v) {
+                        const float h = hmax(v);
+                        if constexpr (NBK == 1) return of_half(h, hd, dl);
+                        else return fmaxf(h, swap32_other(h));
+                    };
                     if (wavefn) {
                         // sample_fun (bsplines_jax.py:144-171): obw = normalised(w @ ob_to_b); ymax = max((obw @ b_to_ob)^2)
-                        const PsiHead<R1> hdw = psi_head(o, valid, valid_d, kP[j], md.ob_to_b, ov, lane);
+                        const PsiHead<R1> hdw = psi_head<R1, NBK>(o, valid, valid_d, kP[j], md.ob_to_b, ov, lane);
                         cj = hdw.e.c0;
                         put(ov, lane, hdw.e);
-                        const float q = gemv32_cols<R1>(md.b_to_ob, ov, dl, j).c0;
-                        ymax = of_half(hmax(valid ? q * q : 0.0f), hd, dl);
+                        const float q = gemv32_cols<R1, NBK>(md.b_to_ob, ov, dl, j).c0;
+                        ymax = col_max(valid ? q * q : 0.0f);
                     } else {
-                        const SigHead<R1> hdw = sigmoid_head(o, valid, valid_d, kP[j], 0.0f);
+                        const SigHead<R1> hdw = sigmoid_head<R1, NBK>(o, valid, valid_d, kP[j], 0.0f);
                         cj = hdw.c.c0;
-                        ymax = of_half(hmax(valid ? cj : 0.0f), hd, dl) * (float)(nb + md.psp.degree);   // msplines_jax.py:147-150
+                        ymax = col_max(valid ? cj : 0.0f) * (float)(nb + md.psp.degree);   // msplines_jax.py:147-150
                     }
                     // Rejection sampling, 64 proposals per round: lane t holds proposal number 64 * round + t of the sequence, the
                     // first accepted one in sequence order is taken (same distribution as proposing one by one; the acceptance
@@ -1039,7 +1051,7 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(WF_OCC_SAMP
                     // evaluates the whole spline at its own point: the column's coefficients come from LDS, two table rows per lane.
                     // Bounded (1563 rounds ~ 1e5 proposals): a pathological density cannot hang the GPU.
                     put(ov, lane, R1{cj});
-                    const float* __restrict__ cw = &ov[0][hd * 32];
+                    const float* __restrict__ cw = &ov[0][NBK == 1 ? hd * 32 : 0];
                     float xs = 0.5f;
                     for (int round = 0; round < 1563; ++round) {
                         scalar::Philox prop(seed, (unsigned long long)b);
@@ -1047,11 +1059,11 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(WF_OCC_SAMP
                         prop.c1 = (unsigned)(col + 1);          // the shared stream of this walker uses c1 == 0
                         const float xc = prop.uniform(), yc = prop.uniform() * ymax;
                         const Lerp L = make_lerp(xc, n_mesh);
-                        const float4_t* __restrict__ rl = reinterpret_cast<const float4_t*>(tabP + (size_t)L.il * NBP);
-                        const float4_t* __restrict__ rr = reinterpret_cast<const float4_t*>(tabP + (size_t)L.ir * NBP);
+                        const float4_t* __restrict__ rl = reinterpret_cast<const float4_t*>(tabP + (size_t)L.il * W);
+                        const float4_t* __restrict__ rr = reinterpret_cast<const float4_t*>(tabP + (size_t)L.ir * W);
                         float v = 0.0f;
 #pragma unroll
-                        for (int q = 0; q < NBP / 4; ++q) {
+                        for (int q = 0; q < W / 4; ++q) {
                             const float4_t a4 = rl[q], b4 = rr[q], w4 = *reinterpret_cast<const float4_t*>(cw + 4 * q);
                             v = __builtin_fmaf(w4.x, a4.x + ((b4.x - a4.x) * L.n) * L.dx, v);
                             v = __builtin_fmaf(w4.y, a4.y + ((b4.y - a4.y) * L.n) * L.dx, v);
@@ -1075,7 +1087,7 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(WF_OCC_SAMP
                     if (lane == d) latent[b * D + d] = cur[d];
             }
         }
-        wave_serial_inverse<D>(md, tabI, gI, cur, vec, ov, lane, exact);
+        wave_serial_inverse<D, NBK>(md, tabI, gI, cur, vec, ov, lane, exact);
 #pragma unroll
         for (int d = 0; d < D; ++d)
             if (lane == d) xg[b * D + d] = cur[d];
@@ -1174,22 +1186,30 @@ int launch_wave_sample(const ModelDev& md, const ModelDev* md_dev, const float* 
                        unsigned long long seed, const float* u, int64_t B, float* x, float* latent, int exact,
                        const unsigned long long* seed_offset_dev, void* stream) {
     hipStream_t s = (hipStream_t)stream;
-    if (md.nbp != 32) return WF_ERR_UNSUPPORTED;   // the 64-row layout is built for the sweeps only
-#define CALL(DD)                                                                                                                          \
-    hipLaunchKernelGGL(k_wave_sample<DD>, dim3(wave_grid(B)), dim3(kWB), 0, s, md_dev, tabI4, tabP4, fk_nat, draw, seed, u, B, x, latent, exact, \
-                       seed_offset_dev);                                                                                                 \
+#define CALLK(DD, K)                                                                                                                      \
+    hipLaunchKernelGGL((k_wave_sample<DD, K>), dim3(wave_grid(B)), dim3(kWB), 0, s, md_dev, tabI4, tabP4, fk_nat, draw, seed, u, B, x, latent, \
+                       exact, seed_offset_dev);                                                                                          \
     break
+    if (md.nbp == 64) {
+        switch (md.D) {
+            case 2: CALLK(2, 2);
+            case 3: CALLK(3, 2);
+            case 4: CALLK(4, 2);
+            default: return WF_ERR_UNSUPPORTED;
+        }
+        return finish();
+    }
     switch (md.D) {
-        case 2: CALL(2);
-        case 3: CALL(3);
-        case 4: CALL(4);
-        case 5: CALL(5);
-        case 6: CALL(6);
-        case 7: CALL(7);
-        case 8: CALL(8);
+        case 2: CALLK(2, 1);
+        case 3: CALLK(3, 1);
+        case 4: CALLK(4, 1);
+        case 5: CALLK(5, 1);
+        case 6: CALLK(6, 1);
+        case 7: CALLK(7, 1);
+        case 8: CALLK(8, 1);
         default: return WF_ERR_UNSUPPORTED;
     }
-#undef CALL
+#undef CALLK
     return finish();
 }
 

@@ -1023,7 +1023,7 @@ int wf_inverse_fwd(const wf_model* m, const float* u_dev, int64_t B, float* x_de
     if (rc) return rc;
     DeviceGuard g(m->device);
     if (B == 0) return WF_OK;
-    if (m->wave_ok && m->nbp == 32 && B <= wave_sample_max())
+    if (m->wave_ok && B <= wave_sample_max())
         return launch_wave_sample(m->dev, m->d_dev, m->d_tabI4, m->d_tabP3, m->d_grad_fk, 0, 0ull, u_dev, B, x_dev, nullptr, exact, nullptr, stream);
     return launch_scalar_inverse(m->dev, m->d_dev, u_dev, B, x_dev, exact, stream);
 }
@@ -1033,7 +1033,7 @@ int wf_sample(const wf_model* m, uint64_t seed, int64_t B, float* x_dev, float* 
     if (rc) return rc;
     DeviceGuard g(m->device);
     if (B == 0) return WF_OK;
-    if (m->wave_ok && m->nbp == 32 && B <= wave_sample_max())
+    if (m->wave_ok && B <= wave_sample_max())
         return launch_wave_sample(m->dev, m->d_dev, m->d_tabI4, m->d_tabP3, m->d_grad_fk, 1, (unsigned long long)seed, nullptr, B, x_dev, latent_dev,
                                   exact, nullptr, stream);
     return launch_scalar_sample(m->dev, m->d_dev, (unsigned long long)seed, B, x_dev, latent_dev, exact, stream);
@@ -1208,7 +1208,7 @@ static int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
 
 int64_t wf_vqmc_train_step_workspace_bytes(const wf_model* m, int64_t batch) {
     if (!m || batch < 1) return WF_ERR_INVALID;
-    if (!m->d_grad_map || !m->grad_psi_ok || m->nbp != 32 || batch > kWaveSampleMax) return WF_ERR_UNSUPPORTED;
+    if (!m->d_grad_map || !m->grad_psi_ok || batch > kWaveSampleMax) return WF_ERR_UNSUPPORTED;
     return align256(batch * m->desc.n_dim * 4) + align256(batch * 4) + align256(m->n_params * 4) + 256 + align256(block_sums_ws_bytes(batch)) +
            vjp_ws_bytes(m, batch, true);
 }
@@ -1219,7 +1219,7 @@ int wf_vqmc_train_step(wf_model* m, const wf_train_state* st, uint64_t seed, int
     if (!m || !st || batch < 1 || n_protons < 0 || n_protons > 8 || (n_protons > 0 && !protons_host)) return WF_ERR_INVALID;
     if (!st->params_dev || !st->m_dev || !st->v_dev || !st->counter_dev || !st->running_average_dev || !st->loss_ring_dev || st->ring_len < 1)
         return WF_ERR_INVALID;
-    if (!m->d_grad_map || !m->grad_psi_ok || !m->wave_ok || m->nbp != 32 || batch > kWaveSampleMax) return WF_ERR_UNSUPPORTED;   // (wave sampler: <= 32 bases)
+    if (!m->d_grad_map || !m->grad_psi_ok || !m->wave_ok || batch > kWaveSampleMax) return WF_ERR_UNSUPPORTED;
     if (!m->params_set || !workspace_dev || workspace_bytes < wf_vqmc_train_step_workspace_bytes(m, batch)) return WF_ERR_INVALID;
     DeviceGuard g(m->device);
     const int D = m->desc.n_dim;

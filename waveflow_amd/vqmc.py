@@ -180,8 +180,8 @@ class ModelTrainer:
                 json.dump(system_dict, fout_sys, indent=4)
         if verbose:
             print("Start training...")
-        # the whole step as one captured launch sequence, where the library has it (wave sampler: <= 32 bases per dimension,
-        # <= 131072 walkers); otherwise the host-stepped loop below (sampler, loss + gradient, Adam: three library calls per step)
+        # the whole step as one captured launch sequence, where the library has it (the wave sampler: <= 131072 walkers per
+        # step; models the sweeps cover); otherwise the host-stepped loop below (sampler, loss + gradient, Adam: three library calls per step)
         fused = self.use_graph and not distributed
         if fused:
             from . import _lib
