@@ -165,7 +165,8 @@ def test_torch_device_tensors_and_streams(he_flat, kernel):
 
 
 @pytest.mark.parametrize("kernel", KERNELS_ALL)
-@pytest.mark.parametrize("D,box,layers,k,kn", [(2, "first", 2, 5, 16), (3, "mean", 2, 5, 16), (4, "mean", 1, 3, 10), (8, "mean", 3, 6, 23)])
+@pytest.mark.parametrize("D,box,layers,k,kn", [(2, "first", 2, 5, 16), (3, "mean", 2, 5, 16), (4, "mean", 1, 3, 10), (8, "mean", 3, 6, 23),
+                                           (5, "first", 2, 4, 13), (6, "mean", 3, 6, 23), (7, "mean", 2, 5, 16)])
 def test_waveflow_other_shapes_vs_oracle(kernel, D, box, layers, k, kn):
     """C4 (8-electron chain) and smaller shapes: no reference system exists, parity is vs the oracle only."""
     from waveflow_amd import model_factory, flatten_params

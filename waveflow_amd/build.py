@@ -11,7 +11,7 @@ OBJ = os.path.join(CSRC, "_obj")
 
 SOURCES = ["wf_tables.cpp", "wf_model.cpp", "wf_kernels_scalar.hip", "wf_scalar_inst_d2.hip", "wf_scalar_inst_d3.hip", "wf_scalar_inst_d4.hip", "wf_scalar_inst_d56.hip",
            "wf_scalar_inst_d78.hip", "wf_scalar_inst_n64.hip", "wf_kernels_mfma.hip", "wf_mfma_inst_d2.hip", "wf_mfma_inst_d34.hip",
-           "wf_mfma_inst_d8.hip", "wf_mfma_inst_k2.hip", "wf_kernels_rqs.hip", "wf_kernels_grad.hip", "wf_kernels_wave.hip"]
+           "wf_mfma_inst_d567.hip", "wf_mfma_inst_d8.hip", "wf_mfma_inst_k2.hip", "wf_kernels_rqs.hip", "wf_kernels_grad.hip", "wf_kernels_wave.hip"]
 # -ffp-contract=off: the index arithmetic and the table lerp keep the reference's separate
 # multiply / add roundings; dot products that may fuse say so with explicit fmaf / MFMA.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]

@@ -39,6 +39,7 @@ namespace mfma {
     extern template int launch_dw<DD, KK, WW>(const MfmaDev*, int, int, const float*, int64_t, float*, float*, int32_t*, hipStream_t)
 WF_MFMA_EXTERN(2, 1, 8); WF_MFMA_EXTERN(2, 1, 12); WF_MFMA_EXTERN(2, 1, 16);
 WF_MFMA_EXTERN(3, 1, 8); WF_MFMA_EXTERN(4, 1, 8); WF_MFMA_EXTERN(8, 1, 8);
+WF_MFMA_EXTERN(5, 1, 8); WF_MFMA_EXTERN(6, 1, 8); WF_MFMA_EXTERN(7, 1, 8);
 WF_MFMA_EXTERN(2, 2, 8); WF_MFMA_EXTERN(3, 2, 8); WF_MFMA_EXTERN(4, 2, 8);
 #undef WF_MFMA_EXTERN
 }  // namespace mfma
@@ -180,6 +181,9 @@ int launch_mfma(int D, int nbk, const MfmaDev* mdev, int lds_bytes, int mode, co
         switch (D) {
             case 3: GO(3, 1, 8);
             case 4: GO(4, 1, 8);
+            case 5: GO(5, 1, 8);
+            case 6: GO(6, 1, 8);
+            case 7: GO(7, 1, 8);
             case 8: GO(8, 1, 8);
             default: return WF_ERR_UNSUPPORTED;
         }
@@ -197,7 +201,7 @@ int launch_mfma(int D, int nbk, const MfmaDev* mdev, int lds_bytes, int mode, co
 }
 
 bool mfma_shape_built(int D, int nbk) {
-    return (nbk == 1 && (D == 2 || D == 3 || D == 4 || D == 8)) || (nbk == 2 && (D == 2 || D == 3 || D == 4));
+    return (nbk == 1 && D >= 2 && D <= 8) || (nbk == 2 && D >= 2 && D <= 4);
 }
 
 }  // namespace wf
