@@ -135,7 +135,10 @@ template <class T> __device__ __forceinline__ void put(float (*buf)[64], int lan
 // out[lane] = sum_a in[a] * W[lane][a], W in lane-major float4 groups.  Even and odd a accumulate in the two halves of a
 // packed pair (v_pk_fma_f32: two FMAs per lane and instruction) and are added at the end.
 using float2_t = __attribute__((ext_vector_type(2))) float;
-template <class T, bool PRELOAD = false>
+#ifndef WF_GEMV_UNROLL_BWD
+#define WF_GEMV_UNROLL_BWD 4
+#endif
+template <class T, bool PRELOAD = false, int UNROLL = 4>
 __device__ __forceinline__ T gemv(const float4_t* __restrict__ img, const float (*buf)[64], int lane) {
     float2_t acc[T::NC];
 #pragma unroll
@@ -155,7 +158,7 @@ __device__ __forceinline__ T gemv(const float4_t* __restrict__ img, const float 
         }
     } else {
         // groups of 4 (full unrolling made hipcc hold 48 LDS reads live in the second-order kernels: 256 VGPRs)
-#pragma unroll 4
+#pragma unroll UNROLL
         for (int g = 0; g < 16; ++g) {
             const float4_t w = img[g * 64 + lane];
             const float2_t wlo = {w.x, w.y}, whi = {w.z, w.w};
@@ -629,7 +632,7 @@ __device__ __forceinline__ void hidden_bwd(const NetWave& net, T hb2, float (*ve
     const T A2 = hb2 * (1.0f - h2 * h2);
     tput(tape, n, Rows<D>::A2 + lane, A2);
     put(vec, lane, A2);
-    const T hb1 = gemv<T>(net.W1b, vec, lane);
+    const T hb1 = gemv<T, false, WF_GEMV_UNROLL_BWD>(net.W1b, vec, lane);
     const T h1 = tget<T>(tape, n, Rows<D>::H1 + lane);
     const T A1 = hb1 * (1.0f - h1 * h1);
     tput(tape, n, Rows<D>::A1 + lane, A1);
@@ -749,7 +752,7 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(kOccBwd<T>,
                 }
                 if (valid_d) tput(tape, NP, RW::O + d * W + j, go);
                 put(ov, lane, go);
-                hb2 = hb2 + gemv<T>(net.W2b + p * 1024, ov, lane);
+                hb2 = hb2 + gemv<T, false, WF_GEMV_UNROLL_BWD>(net.W2b + p * 1024, ov, lane);
             }
             hidden_bwd<D, T>(net, hb2, vec, lane, tape, NP, gU);
         } else if (md.prior_kind == WF_PRIOR_NORMAL) {
@@ -807,7 +810,7 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(kOccBwd<T>,
                 }
                 if (valid_d) tput(tape, l, RW::O + d * W + j, go);
                 put(ov, lane, go);
-                hb2 = hb2 + gemv<T>(net.W2b + p * 1024, ov, lane);
+                hb2 = hb2 + gemv<T, false, WF_GEMV_UNROLL_BWD>(net.W2b + p * 1024, ov, lane);
             }
             hidden_bwd<D, T>(net, hb2, vec, lane, tape, l, gU);
         }
