@@ -168,7 +168,9 @@ int launch_adam(float* params, const float* grad, float* m, float* v, int64_t n,
                 const unsigned long long* step_dev, void* stream);
 // out[i] = value (a kernel, not a memset node: it sits in captured training steps between kernels)
 int launch_fill(float* out, float value, int64_t n, void* stream);
-int launch_step_end(const double* sums, double* ring, int ring_len, unsigned long long* counter, void* stream);
+// Adam with the gradient read straight from k_wgrad's per-split partial images (the gather of launch_grad_gather_partials inlined)
+int launch_adam_partials(float* params, const float* partial, int split, int64_t n_img, const int32_t* inv, float* m, float* v, int64_t n,
+                         float step_size, float b1, float b2, float eps, const unsigned long long* step_dev, void* stream);
 int launch_grad_gather(const float* grad_img, const int32_t* inv, int64_t n_params, float* grad_flat, void* stream);
 int launch_grad_gather_partials(const float* partial, int split, int64_t n_img, const int32_t* inv, int64_t n_params, float* grad_flat, void* stream);
 int launch_vqmc_seeds(const float* x, int64_t B, int D, const Protons& pr, const float* hpsi, const float* psi, float running_avg,
@@ -178,7 +180,8 @@ int launch_rqs(const float* x, const float* uw, const float* uh, const float* ud
 int64_t nsc_workspace_floats(int64_t B, int dim, int K);
 int launch_nsc(const float* x, int64_t B, int dim, int K, float tail, int hidden, const float* params, int inverse, float* y, float* logdet,
                float* ws, void* stream);
-int launch_block_sums(const float* v, int64_t B, double* out, void* ws, int64_t ws_bytes, void* stream);
+int launch_block_sums(const float* v, int64_t B, double* out, void* ws, int64_t ws_bytes, void* stream, double* ring = nullptr, int ring_len = 0,
+                      unsigned long long* counter = nullptr);
 int64_t block_sums_ws_bytes(int64_t B);
 
 void set_hip_error(int e);

@@ -197,15 +197,23 @@ __global__ void k_adam(float* __restrict__ x, const float* __restrict__ g, float
     x[i] = x[i] - step_size * (mi / c1) / (sqrtf(vi / c2) + eps);
 }
 
-// ---- end of a captured training step: the step's [sum, sum^2, n] goes to slot (counter mod ring_len) of the loss ring and
-// the counter advances (it seeds the next step's sampler and gives Adam's step index)
-__global__ void k_step_end(const double* __restrict__ sums, double* __restrict__ ring, int ring_len, unsigned long long* __restrict__ counter) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        const unsigned long long c = *counter;
-        double* slot = ring + (c % (unsigned long long)ring_len) * 3;
-        slot[0] = sums[0]; slot[1] = sums[1]; slot[2] = sums[2];
-        *counter = c + 1;
-    }
+// the same with g[i] gathered from the per-split partial gradient images (same summation order as k_grad_gather_partials)
+__global__ void k_adam_partials(float* __restrict__ x, const float* __restrict__ partial, int split, int64_t n_img, const int32_t* __restrict__ inv,
+                                float* __restrict__ m, float* __restrict__ v, int64_t n, float step_size, float b1, float b2, float eps,
+                                const unsigned long long* __restrict__ step_dev) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float e = (float)(*step_dev + 1);
+    const float c1 = 1.0f - powf(b1, e), c2 = 1.0f - powf(b2, e);
+    const int32_t t = inv[i];
+    float gi = 0.0f;
+    if (t >= 0)
+        for (int q = 0; q < split; ++q) gi += partial[(int64_t)q * n_img + t];
+    const float mi = (1.0f - b1) * gi + b1 * m[i];
+    const float vi = (1.0f - b2) * gi * gi + b2 * v[i];
+    m[i] = mi;
+    v[i] = vi;
+    x[i] = x[i] - step_size * (mi / c1) / (sqrtf(vi / c2) + eps);
 }
 
 // ---- loss_fn_efficient's tangent rule as per-walker weights (vqmc.py:198-212)
@@ -329,6 +337,14 @@ int launch_adam(float* params, const float* grad, float* m, float* v, int64_t n,
     return finish();
 }
 
+int launch_adam_partials(float* params, const float* partial, int split, int64_t n_img, const int32_t* inv, float* m, float* v, int64_t n,
+                         float step_size, float b1, float b2, float eps, const unsigned long long* step_dev, void* stream) {
+    if (n <= 0) return WF_OK;
+    hipLaunchKernelGGL(k_adam_partials, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, partial, split, n_img, inv,
+                       m, v, n, step_size, b1, b2, eps, step_dev);
+    return finish();
+}
+
 __global__ void k_fill(float* __restrict__ out, float value, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = value;
@@ -337,11 +353,6 @@ __global__ void k_fill(float* __restrict__ out, float value, int64_t n) {
 int launch_fill(float* out, float value, int64_t n, void* stream) {
     if (n <= 0) return WF_OK;
     hipLaunchKernelGGL(k_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, value, n);
-    return finish();
-}
-
-int launch_step_end(const double* sums, double* ring, int ring_len, unsigned long long* counter, void* stream) {
-    hipLaunchKernelGGL(k_step_end, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, ring, ring_len, counter);
     return finish();
 }
 

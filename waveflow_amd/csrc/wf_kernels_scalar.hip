@@ -51,9 +51,19 @@ __device__ __forceinline__ void block_reduce2(double& a, double& b, double* sm) 
     b = sm[kSumBlock];
 }
 
+// end of a captured training step, done by the thread that holds the sums: they go to slot (counter mod ring_len) of the loss ring and
+// the counter advances (it seeds the next step's sampler and is Adam's step index)
+__device__ __forceinline__ void ring_push(double s, double q, double n, double* __restrict__ ring, int ring_len, unsigned long long* __restrict__ counter) {
+    const unsigned long long c = *counter;
+    double* slot = ring + (c % (unsigned long long)ring_len) * 3;
+    slot[0] = s; slot[1] = q; slot[2] = n;
+    *counter = c + 1;
+}
+
 // final != NULL (single-block launch): the block's sums are the result, stage 2 is skipped
 __global__ __launch_bounds__(kSumBlock) void k_sums_stage1(const float* __restrict__ v, int64_t B, double* __restrict__ partial,
-                                                           double* __restrict__ final) {
+                                                           double* __restrict__ final, double* __restrict__ ring, int ring_len,
+                                                           unsigned long long* __restrict__ counter) {
     __shared__ double sm[2 * kSumBlock];
     double s = 0.0, q = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * kSumBlock + threadIdx.x; i < B; i += (int64_t)gridDim.x * kSumBlock) {
@@ -67,6 +77,7 @@ __global__ __launch_bounds__(kSumBlock) void k_sums_stage1(const float* __restri
             final[0] = s;
             final[1] = q;
             final[2] = (double)B;
+            if (ring) ring_push(s, q, (double)B, ring, ring_len, counter);
         } else {
             partial[2 * blockIdx.x] = s;
             partial[2 * blockIdx.x + 1] = q;
@@ -74,7 +85,8 @@ __global__ __launch_bounds__(kSumBlock) void k_sums_stage1(const float* __restri
     }
 }
 
-__global__ __launch_bounds__(kSumBlock) void k_sums_stage2(const double* __restrict__ partial, int n_blocks, int64_t B, double* __restrict__ out) {
+__global__ __launch_bounds__(kSumBlock) void k_sums_stage2(const double* __restrict__ partial, int n_blocks, int64_t B, double* __restrict__ out,
+                                                           double* __restrict__ ring, int ring_len, unsigned long long* __restrict__ counter) {
     __shared__ double sm[2 * kSumBlock];
     double s = 0.0, q = 0.0;
     for (int i = threadIdx.x; i < n_blocks; i += kSumBlock) {
@@ -86,6 +98,7 @@ __global__ __launch_bounds__(kSumBlock) void k_sums_stage2(const double* __restr
         out[0] = s;
         out[1] = q;
         out[2] = (double)B;
+        if (ring) ring_push(s, q, (double)B, ring, ring_len, counter);
     }
 }
 
@@ -167,16 +180,19 @@ int launch_scalar_sample(const ModelDev& md, const ModelDev* md_dev, unsigned lo
 
 int64_t block_sums_ws_bytes(int64_t) { return (int64_t)kSumMaxBlocks * 2 * sizeof(double); }
 
-int launch_block_sums(const float* v, int64_t B, double* out, void* ws, int64_t, void* stream) {
+// ring != NULL: the kernel that ends up with the sums also pushes them to the loss ring and advances the step counter
+int launch_block_sums(const float* v, int64_t B, double* out, void* ws, int64_t, void* stream, double* ring, int ring_len,
+                      unsigned long long* counter) {
     hipStream_t s = (hipStream_t)stream;
     const int nb = sums_blocks(B);
     double* partial = (double*)ws;
     if (nb == 1) {   // small batches (a training step's 128..256 local energies): one launch
-        hipLaunchKernelGGL(k_sums_stage1, dim3(1), dim3(kSumBlock), 0, s, v, B, partial, out);
+        hipLaunchKernelGGL(k_sums_stage1, dim3(1), dim3(kSumBlock), 0, s, v, B, partial, out, ring, ring_len, counter);
         return finish_launch();
     }
-    hipLaunchKernelGGL(k_sums_stage1, dim3(nb), dim3(kSumBlock), 0, s, v, B, partial, (double*)nullptr);
-    hipLaunchKernelGGL(k_sums_stage2, dim3(1), dim3(kSumBlock), 0, s, (const double*)partial, nb, B, out);
+    hipLaunchKernelGGL(k_sums_stage1, dim3(nb), dim3(kSumBlock), 0, s, v, B, partial, (double*)nullptr, (double*)nullptr, 0,
+                       (unsigned long long*)nullptr);
+    hipLaunchKernelGGL(k_sums_stage2, dim3(1), dim3(kSumBlock), 0, s, (const double*)partial, nb, B, out, ring, ring_len, counter);
     return finish_launch();
 }
 

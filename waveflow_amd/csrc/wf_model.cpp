@@ -1102,7 +1102,7 @@ static int64_t vjp_ws_bytes(const wf_model* m, int64_t B, bool second_order) {
 // mode 3: maximum likelihood: every walker carries the weight inv_count (signed), e_loc_dev receives log_pdf of the same sweep
 static int run_vjp_chunks(const wf_model* m, int mode, bool second_order, const float* x_dev, int64_t B, const float* w1, const float* w2,
                           const Protons* pr, float running_average, float inv_count, float* e_loc_dev, float* grad_dev, void* workspace_dev,
-                          int64_t workspace_bytes, void* stream, const float* running_average_dev = nullptr) {
+                          int64_t workspace_bytes, void* stream, const float* running_average_dev = nullptr, int* defer_gather_split = nullptr) {
     const int D = m->desc.n_dim;
     const int64_t chunk = workspace_bytes / vjp_bytes_per_walker(m, second_order);
     if (B > 0 && chunk < 1) return WF_ERR_INVALID;
@@ -1151,6 +1151,8 @@ static int run_vjp_chunks(const wf_model* m, int mode, bool second_order, const 
                           single ? &split : nullptr, stream);
         if (rc) return rc;
     }
+    if (defer_gather_split) *defer_gather_split = single ? split : 0;
+    if (single && defer_gather_split) return WF_OK;   // the caller reads m->d_grad_partial itself (launch_adam_partials)
     if (single) return launch_grad_gather_partials(m->d_grad_partial, split, n_img, m->d_grad_map, m->n_params, grad_dev, stream);
     return launch_grad_gather(m->d_grad_img, m->d_grad_map, m->n_params, grad_dev, stream);
 }
@@ -1206,6 +1208,19 @@ int wf_vqmc_loss_grad(const wf_model* m, const float* x_dev, int64_t B, const fl
 // ---- one whole training step on the device (see include/waveflow_hip.h)
 static int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
 
+// Adam step of a captured training step: the gradient is either in `grad` (several chunks) or still in the per-split partial images
+// of the single chunk (split > 0), in which case the gather is part of the update kernel
+static int adam_from_sweep(wf_model* m, const wf_train_state* st, const float* grad, int split, float step_size, float b1, float b2, float eps,
+                           void* stream) {
+    const unsigned long long* counter = (const unsigned long long*)st->counter_dev;
+    if (split > 0) {
+        const int64_t n_img = plain_fwd_floats(m->desc.n_dim, m->nbp) * (int64_t)m->nets.size();
+        return launch_adam_partials(st->params_dev, m->d_grad_partial, split, n_img, m->d_grad_map, st->m_dev, st->v_dev, m->n_params, step_size, b1,
+                                    b2, eps, counter, stream);
+    }
+    return launch_adam(st->params_dev, grad, st->m_dev, st->v_dev, m->n_params, 0, step_size, b1, b2, eps, counter, stream);
+}
+
 int64_t wf_vqmc_train_step_workspace_bytes(const wf_model* m, int64_t batch) {
     if (!m || batch < 1) return WF_ERR_INVALID;
     if (!m->d_grad_map || !m->grad_psi_ok || batch > kWaveSampleMax) return WF_ERR_UNSUPPORTED;
@@ -1239,16 +1254,17 @@ int wf_vqmc_train_step(wf_model* m, const wf_train_state* st, uint64_t seed, int
                                 exact_sampler, counter, stream);
     if (rc) return rc;
     // mean local energy and its gradient under the custom tangent rule, running average from the device scalar
+    int split = 0;
     rc = run_vjp_chunks(m, 2, true, x, batch, nullptr, nullptr, &pr, 0.0f, 1.0f / (float)batch, e_loc, grad, p, vjp_bytes, stream,
-                        st->running_average_dev);
+                        st->running_average_dev, &split);
     if (rc) return rc;
-    rc = launch_block_sums(e_loc, batch, sums, sums_ws, block_sums_ws_bytes(batch), stream);
-    if (rc) return rc;
-    rc = launch_adam(st->params_dev, grad, st->m_dev, st->v_dev, m->n_params, 0, step_size, b1, b2, eps, counter, stream);
+    rc = adam_from_sweep(m, st, grad, split, step_size, b1, b2, eps, stream);
     if (rc) return rc;
     rc = wf_model_set_params_device(m, st->params_dev, m->n_params, stream);
     if (rc) return rc;
-    return launch_step_end(sums, st->loss_ring_dev, st->ring_len, (unsigned long long*)st->counter_dev, stream);
+    // batch sums of the local energies -> loss ring, step counter + 1 (after Adam, which reads the counter as its step index)
+    return launch_block_sums(e_loc, batch, sums, sums_ws, block_sums_ws_bytes(batch), stream, st->loss_ring_dev, st->ring_len,
+                             (unsigned long long*)st->counter_dev);
 }
 
 int64_t wf_mle_train_step_workspace_bytes(const wf_model* m, int64_t N) {
@@ -1271,16 +1287,15 @@ int wf_mle_train_step(wf_model* m, const wf_train_state* st, const float* x_dev,
     void* sums_ws = p; p += align256(block_sums_ws_bytes(N));
     const int64_t vjp_bytes = workspace_bytes - (p - (char*)workspace_dev);
     // loss = -mean log_pdf (benchmark_tests.py:84-87): value from the forward sweep, gradient from the reverse sweep
-    int rc = run_vjp_chunks(m, 3, false, x_dev, N, nullptr, nullptr, nullptr, 0.0f, -1.0f / (float)N, lp, grad, p, vjp_bytes, stream);
+    int split = 0;
+    int rc = run_vjp_chunks(m, 3, false, x_dev, N, nullptr, nullptr, nullptr, 0.0f, -1.0f / (float)N, lp, grad, p, vjp_bytes, stream, nullptr, &split);
     if (rc) return rc;
-    rc = launch_block_sums(lp, N, sums, sums_ws, block_sums_ws_bytes(N), stream);
-    if (rc) return rc;
-    rc = launch_adam(st->params_dev, grad, st->m_dev, st->v_dev, m->n_params, 0, step_size, b1, b2, eps,
-                     (const unsigned long long*)st->counter_dev, stream);
+    rc = adam_from_sweep(m, st, grad, split, step_size, b1, b2, eps, stream);
     if (rc) return rc;
     rc = wf_model_set_params_device(m, st->params_dev, m->n_params, stream);
     if (rc) return rc;
-    return launch_step_end(sums, st->loss_ring_dev, st->ring_len, (unsigned long long*)st->counter_dev, stream);
+    return launch_block_sums(lp, N, sums, sums_ws, block_sums_ws_bytes(N), stream, st->loss_ring_dev, st->ring_len,
+                             (unsigned long long*)st->counter_dev);
 }
 
 int wf_vqmc_seeds(const float* x_dev, int64_t B, int32_t n_dim, const float* protons_host, int32_t n_protons, const float* hpsi_dev,
