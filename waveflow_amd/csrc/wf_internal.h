@@ -146,7 +146,8 @@ int launch_wave_energy(const ModelDev& md, const ModelDev* md_dev, const float* 
 int launch_wave_sample(const ModelDev& md, const ModelDev* md_dev, const float* tabI4, const float* tabP4, const float* fk_nat, int draw,
                        unsigned long long seed, const float* u, int64_t B, float* x, float* latent, int exact,
                        const unsigned long long* seed_offset_dev, void* stream);
-int launch_tail_out(const ModelDev& md, int mode, const float* tails, int64_t B, float* out, float* u, void* stream);
+int launch_tail_out(const ModelDev& md, int mode, const float* tails, int64_t B, float* out, float* u, void* stream, float* w_out = nullptr,
+                    float w_value = 0.0f);
 int launch_wave_eval(const ModelDev& md, const ModelDev* md_dev, const float* tabI4, const float* tabP4, const float* fk_nat, int mode,
                      const float* x, int64_t B, float* out, float* u, float* tail_ws, void* stream);
 int64_t wave_tail_floats(int D, int ring_kind);   // per walker
@@ -166,8 +167,6 @@ struct PackRec {
 int launch_pack(const float* flat_dev, const PackRec* recs, int64_t n, void* plain, void* wave, void* mfma, void* stream);
 int launch_adam(float* params, const float* grad, float* m, float* v, int64_t n, int64_t step, float step_size, float b1, float b2, float eps,
                 const unsigned long long* step_dev, void* stream);
-// out[i] = value (a kernel, not a memset node: it sits in captured training steps between kernels)
-int launch_fill(float* out, float value, int64_t n, void* stream);
 // Adam with the gradient read straight from k_wgrad's per-split partial images (the gather of launch_grad_gather_partials inlined)
 int launch_adam_partials(float* params, const float* partial, int split, int64_t n_img, const int32_t* inv, float* m, float* v, int64_t n,
                          float step_size, float b1, float b2, float eps, const unsigned long long* step_dev, void* stream);

@@ -345,17 +345,6 @@ int launch_adam_partials(float* params, const float* partial, int split, int64_t
     return finish();
 }
 
-__global__ void k_fill(float* __restrict__ out, float value, int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = value;
-}
-
-int launch_fill(float* out, float value, int64_t n, void* stream) {
-    if (n <= 0) return WF_OK;
-    hipLaunchKernelGGL(k_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, value, n);
-    return finish();
-}
-
 int launch_grad_gather(const float* grad_img, const int32_t* inv, int64_t n_params, float* grad_flat, void* stream) {
     if (n_params <= 0) return WF_OK;
     hipLaunchKernelGGL(k_grad_gather, dim3((unsigned)((n_params + 255) / 256)), dim3(256), 0, (hipStream_t)stream, grad_img, inv, n_params, grad_flat);

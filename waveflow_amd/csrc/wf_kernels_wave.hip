@@ -539,9 +539,10 @@ __global__ void k_energy_out(const float* __restrict__ tails, const float* __res
 // mode 0: log_pdf, 1: psi, 2: log det only;  u_out (may be null): the latent point (clipped where the reference clips it)
 template <int D>
 __global__ void k_tail_out(const float* __restrict__ tails, int64_t B, int mode, int prior_kind, unsigned constrained_mask, float normal_offset,
-                           float* __restrict__ out, float* __restrict__ u_out) {
+                           float* __restrict__ out, float* __restrict__ u_out, float* __restrict__ w_out, float w_value) {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
+    if (w_out) w_out[b] = w_value;   // constant per-walker weight of a mean objective (seed of the reverse sweep)
     const float* tl = tails + b * (int64_t)Tail<D>::N;
     const float ld = tl[Tail<D>::LD];
     float res = ld;
@@ -583,6 +584,33 @@ __global__ void k_tail_out(const float* __restrict__ tails, int64_t B, int mode,
     }
 }
 
+// local energy and the weights of loss_fn_efficient's tangent rule from (psi, laplacian) of one walker at x[0..D)
+template <int D>
+__device__ __forceinline__ void seed_values(float ps, float lap, const float* __restrict__ x, const Protons& pr, float running_avg, float inv_count,
+                                            float& e_loc, float& w_psi, float& w_lap) {
+    float V = 0.0f;   // physics.py:60-76
+    for (int p = 0; p < pr.n; ++p)
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const float r = pr.pos[p] - x[d];
+            V -= 1.0f / sqrtf(1.0f + r * r);
+        }
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int k = 0; k < i; ++k) {
+            const float r = x[i] - x[k];
+            V += 1.0f / sqrtf(1.0f + r * r);
+        }
+    const float hp = -0.5f * lap + V * ps;
+    const float el = hp / (ps + 1e-8f);
+    const float a = 2.0f * (el - running_avg) / ps - hp / (ps * ps);
+    const float c = 1.0f / ps;
+    e_loc = el;
+    w_psi = (a + c * V) * inv_count;
+    w_lap = -0.5f * c * inv_count;
+}
+
 // ---- the same, continued to the weights of loss_fn_efficient's tangent rule (k_vqmc_seeds, wf_kernels_grad.hip): the fused
 // training step needs neither H psi nor psi in memory
 template <int D, class T>
@@ -601,27 +629,7 @@ __global__ void k_energy_seeds(const float* __restrict__ tails, const float* __r
         lap += lap_of(p3);
         ps = p3.c0;
     }
-    float V = 0.0f;   // physics.py:60-76
-    for (int p = 0; p < pr.n; ++p)
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const float r = pr.pos[p] - xg[b * D + d];
-            V -= 1.0f / sqrtf(1.0f + r * r);
-        }
-#pragma unroll
-    for (int i = 0; i < D; ++i)
-#pragma unroll
-        for (int k = 0; k < i; ++k) {
-            const float r = xg[b * D + i] - xg[b * D + k];
-            V += 1.0f / sqrtf(1.0f + r * r);
-        }
-    const float hp = -0.5f * lap + V * ps;
-    const float el = hp / (ps + 1e-8f);
-    const float a = 2.0f * (el - running_avg) / ps - hp / (ps * ps);
-    const float c = 1.0f / ps;
-    e_loc[b] = el;
-    w_psi[b] = (a + c * V) * inv_count;
-    w_lap[b] = -0.5f * c * inv_count;
+    seed_values<D>(ps, lap, xg + b * D, pr, running_avg, inv_count, e_loc[b], w_psi[b], w_lap[b]);
 }
 
 // ------------------------------------------------------------------------------------------------ reverse
@@ -1252,10 +1260,11 @@ int launch_energy_seeds(int D, int ring_kind, const float* tails, const float* x
 #undef WF_RING2_CASE
 #undef WF_RING2_DISPATCH
 
-int launch_tail_out(const ModelDev& md, int mode, const float* tails, int64_t B, float* out, float* u, void* stream) {
+int launch_tail_out(const ModelDev& md, int mode, const float* tails, int64_t B, float* out, float* u, void* stream, float* w_out, float w_value) {
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)((B + 255) / 256)), block(256);
-#define CALL(DD) hipLaunchKernelGGL(k_tail_out<DD>, grid, block, 0, s, tails, B, mode, md.prior_kind, md.constrained_mask, md.normal_offset, out, u); break
+#define CALL(DD) hipLaunchKernelGGL(k_tail_out<DD>, grid, block, 0, s, tails, B, mode, md.prior_kind, md.constrained_mask, md.normal_offset, out, u, \
+                                    w_out, w_value); break
     switch (md.D) {
         case 2: CALL(2);
         case 3: CALL(3);

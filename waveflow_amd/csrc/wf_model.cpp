@@ -1125,11 +1125,13 @@ static int run_vjp_chunks(const wf_model* m, int mode, bool second_order, const 
     for (int64_t c0 = 0; c0 < B; c0 += chunk) {
         const int64_t bc = std::min(chunk, B - c0);
         const float* x = x_dev + c0 * D;
+        float *wp = per_walker + 2 * chunk, *wl = per_walker + 3 * chunk;
         int rc = launch_wave_fwd(m->dev, m->d_dev, kind, m->d_tabI4, m->d_tabP3, m->d_grad_fk, x, bc, tape, tails, 1, stream);
         if (rc) return rc;
         const float *cw1 = w1 ? w1 + c0 : nullptr, *cw2 = w2 ? w2 + c0 : nullptr;
         if (mode == 2) {
-            float *wp = per_walker + 2 * chunk, *wl = per_walker + 3 * chunk;
+            // (writing E_L and the weights from inside the forward kernel -- possible in RF, where a sample is a whole walker -- was
+            // measured slower: the kernel grows by more than the 4.6 us launch it saves)
             rc = launch_energy_seeds(D, kind, tails, x, bc, m->dev.constrained_mask, *pr, running_average, running_average_dev, inv_count,
                                      e_loc_dev + c0, wp, wl, stream);
             if (rc) return rc;
@@ -1137,10 +1139,7 @@ static int run_vjp_chunks(const wf_model* m, int mode, bool second_order, const 
             cw2 = wl;
         }
         if (mode == 3) {
-            float* wp = per_walker + 2 * chunk;
-            rc = launch_tail_out(m->dev, 0, tails, bc, e_loc_dev + c0, nullptr, stream);
-            if (rc) return rc;
-            rc = launch_fill(wp, inv_count, bc, stream);
+            rc = launch_tail_out(m->dev, 0, tails, bc, e_loc_dev + c0, nullptr, stream, wp, inv_count);   // log_pdf values + the constant weights
             if (rc) return rc;
             cw1 = wp;
         }
