@@ -232,6 +232,20 @@ int wf_vqmc_train_step(wf_model* m, const wf_train_state* st, uint64_t seed, int
                        float step_size, float b1, float b2, float eps, int32_t exact_sampler, void* workspace_dev, int64_t workspace_bytes,
                        void* stream);
 
+/* The same step for walkers sharded over several GPUs (one process per GPU), in two halves around the caller's collective:
+ *   wf_vqmc_train_step_local   this rank's walkers (sampler stream `seed`, advanced by the device counter) -> their contribution to
+ *                              the gradient of loss_fn_efficient, the tangent rule scaled by inv_global_batch = 1 / (walkers of ALL
+ *                              ranks) -> reduce_dev[n_params + 3] doubles = [gradient, sum E_L, sum E_L^2, local walkers]
+ *   (caller)                   SUM all-reduce of reduce_dev over the ranks: the step's one collective (RCCL), on `stream`
+ *   wf_vqmc_train_step_apply   Adam with the reduced gradient, image refill, reduced sums to the loss ring, counter + 1
+ * Every rank ends the step with the same parameters.  Same workspace size as wf_vqmc_train_step (with the local batch); both halves
+ * are asynchronous and hipGraph-capturable. */
+int wf_vqmc_train_step_local(wf_model* m, const wf_train_state* st, uint64_t seed, int64_t batch_local, const float* protons_host, int32_t n_protons,
+                             float inv_global_batch, int32_t exact_sampler, double* reduce_dev, void* workspace_dev, int64_t workspace_bytes,
+                             void* stream);
+int wf_vqmc_train_step_apply(wf_model* m, const wf_train_state* st, const double* reduce_dev, float step_size, float b1, float b2, float eps,
+                             void* stream);
+
 /* One epoch of benchmark_tests.train_model (benchmark_tests.py:98-101, 138-144) without the host: -mean log_pdf over the N
  * resident rows x_dev[N][D], its gradient, Adam, image refill; [sum log_pdf, sum log_pdf^2, N] of the epoch goes to the loss ring
  * (the loss is -sum / N).  Same state conventions as wf_vqmc_train_step (running_average_dev is unused).  hipGraph-capturable. */

@@ -63,7 +63,8 @@ EXPORTS = ["wf_abi_version", "wf_strerror", "wf_last_hip_error", "wf_last_hip_er
            "wf_block_sums", "wf_block_sums_workspace_bytes", "wf_rqs_fwd", "wf_inverse_fwd", "wf_sample", "wf_hamiltonian_fwd",
            "wf_psi_vjp", "wf_psi_vjp_workspace_bytes", "wf_vqmc_seeds",
            "wf_logpdf_vjp", "wf_logpdf_vjp_workspace_bytes", "wf_vqmc_loss_grad", "wf_model_set_params_device", "wf_adam_step",
-           "wf_vqmc_train_step", "wf_vqmc_train_step_workspace_bytes", "wf_nsc_fwd", "wf_nsc_workspace_bytes", "wf_logpdf_loss_grad", "wf_mle_train_step", "wf_mle_train_step_workspace_bytes"]
+           "wf_vqmc_train_step", "wf_vqmc_train_step_workspace_bytes", "wf_nsc_fwd", "wf_nsc_workspace_bytes", "wf_logpdf_loss_grad", "wf_mle_train_step", "wf_mle_train_step_workspace_bytes", "wf_vqmc_train_step_local",
+           "wf_vqmc_train_step_apply"]
 
 _lib = None
 
@@ -135,6 +136,10 @@ def lib():
     L.wf_nsc_workspace_bytes.argtypes = [i64, i32, i32]
     L.wf_nsc_fwd.restype = i32
     L.wf_nsc_fwd.argtypes = [vp, i64, i32, i32, ctypes.c_float, i32, vp, i32, vp, vp, vp, i64, vp]
+    L.wf_vqmc_train_step_local.restype = i32
+    L.wf_vqmc_train_step_local.argtypes = [vp, ctypes.POINTER(TrainState), ctypes.c_uint64, i64, vp, i32, ctypes.c_float, i32, vp, vp, i64, vp]
+    L.wf_vqmc_train_step_apply.restype = i32
+    L.wf_vqmc_train_step_apply.argtypes = [vp, ctypes.POINTER(TrainState), vp, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, vp]
     L.wf_mle_train_step_workspace_bytes.restype = i64
     L.wf_mle_train_step_workspace_bytes.argtypes = [vp, i64]
     L.wf_mle_train_step.restype = i32

@@ -326,6 +326,27 @@ class DeviceModel:
         self._flat = None
         self._dev_key = None
 
+    def train_step_local(self, st, seed, batch_local, protons, inv_global_batch, red, exact_sampler=False):
+        """First half of a sharded training step (wf_vqmc_train_step_local): this rank's walkers -> red[n_params + 3] (float64 cuda)
+        = [gradient contribution, sum E_L, sum E_L^2, local walkers]; the caller all-reduces red and calls train_step_apply."""
+        L = _lib.lib()
+        pr = np.ascontiguousarray(np.asarray(protons, dtype=np.float32).reshape(-1))
+        nbytes = _lib.check(L.wf_vqmc_train_step_workspace_bytes(self._h, int(batch_local)), "wf_vqmc_train_step_workspace_bytes")
+        if st.get("ws") is None or st["ws"].numel() < nbytes:
+            st["ws"] = self._workspace(nbytes, st["x"].device)
+        if str(red.dtype) != "torch.float64" or red.numel() != self.n_params + 3 or not red.is_cuda or not red.is_contiguous():
+            raise ValueError("red must be a contiguous float64 cuda vector of n_params + 3 entries")
+        _lib.check(L.wf_vqmc_train_step_local(self._h, ctypes.byref(st["c"]), int(seed), int(batch_local), pr.ctypes.data if pr.size else None,
+                                              pr.size, float(inv_global_batch), int(bool(exact_sampler)), self._p(red), self._p(st["ws"]),
+                                              st["ws"].numel(), self._stream()), "wf_vqmc_train_step_local")
+
+    def train_step_apply(self, st, red, step_size, b1=0.9, b2=0.999, eps=1e-8):
+        """Second half (wf_vqmc_train_step_apply): Adam with the reduced gradient, image refill, loss ring, counter."""
+        _lib.check(_lib.lib().wf_vqmc_train_step_apply(self._h, ctypes.byref(st["c"]), self._p(red), float(step_size), float(b1), float(b2),
+                                                       float(eps), self._stream()), "wf_vqmc_train_step_apply")
+        self._flat = None
+        self._dev_key = None
+
     def mle_train_step(self, st, x, step_size, b1=0.9, b2=0.999, eps=1e-8):
         """One maximum-likelihood epoch on the device (wf_mle_train_step): no host work, capturable in a hipGraph."""
         L = _lib.lib()

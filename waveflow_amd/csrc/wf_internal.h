@@ -167,6 +167,12 @@ struct PackRec {
 int launch_pack(const float* flat_dev, const PackRec* recs, int64_t n, void* plain, void* wave, void* mfma, void* stream);
 int launch_adam(float* params, const float* grad, float* m, float* v, int64_t n, int64_t step, float step_size, float b1, float b2, float eps,
                 const unsigned long long* step_dev, void* stream);
+// distributed training step (wf_vqmc_train_step_local / _apply): packed fp64 all-reduce buffer, Adam from it, loss-ring push
+int launch_pack_reduce_buffer(const float* partial, int split, int64_t n_img, const int32_t* inv, const float* grad, int64_t n_params, double* red,
+                              void* stream);
+int launch_adam_reduced(float* params, const double* red, float* m, float* v, int64_t n, float step_size, float b1, float b2, float eps,
+                        const unsigned long long* step_dev, void* stream);
+int launch_ring_push(const double* sums, double* ring, int ring_len, unsigned long long* counter, void* stream);
 // Adam with the gradient read straight from k_wgrad's per-split partial images (the gather of launch_grad_gather_partials inlined)
 int launch_adam_partials(float* params, const float* partial, int split, int64_t n_img, const int32_t* inv, float* m, float* v, int64_t n,
                          float step_size, float b1, float b2, float eps, const unsigned long long* step_dev, void* stream);

@@ -159,6 +159,46 @@ __global__ void k_grad_gather_partials(const float* __restrict__ partial, int sp
     flat[p] = s;
 }
 
+// ---- distributed training step: the packed fp64 buffer [gradient, sum E_L, sum E_L^2, n] that travels in the step's one all-reduce
+// red[i] = gradient entry i from the per-split partial images (split > 0) or from the flat fp32 gradient (split == 0); the three sums follow
+__global__ void k_pack_reduce_buffer(const float* __restrict__ partial, int split, int64_t n_img, const int32_t* __restrict__ inv,
+                                     const float* __restrict__ grad, int64_t n_params, double* __restrict__ red) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_params) return;
+    float s = 0.0f;
+    if (split > 0) {
+        const int32_t t = inv[p];
+        if (t >= 0)
+            for (int q = 0; q < split; ++q) s += partial[(int64_t)q * n_img + t];
+    } else {
+        s = grad[p];
+    }
+    red[p] = (double)s;
+}
+// Adam from the reduced buffer (gradient rounded back to fp32, as the single-GPU step holds it)
+__global__ void k_adam_reduced(float* __restrict__ x, const double* __restrict__ red, float* __restrict__ m, float* __restrict__ v, int64_t n,
+                               float step_size, float b1, float b2, float eps, const unsigned long long* __restrict__ step_dev) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float e = (float)(*step_dev + 1);
+    const float c1 = 1.0f - powf(b1, e), c2 = 1.0f - powf(b2, e);
+    const float gi = (float)red[i];
+    const float mi = (1.0f - b1) * gi + b1 * m[i];
+    const float vi = (1.0f - b2) * gi * gi + b2 * v[i];
+    m[i] = mi;
+    v[i] = vi;
+    x[i] = x[i] - step_size * (mi / c1) / (sqrtf(vi / c2) + eps);
+}
+// the reduced sums go to slot (counter mod ring_len) of the loss ring; the counter advances
+__global__ void k_ring_push(const double* __restrict__ sums, double* __restrict__ ring, int ring_len, unsigned long long* __restrict__ counter) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const unsigned long long c = *counter;
+        double* slot = ring + (c % (unsigned long long)ring_len) * 3;
+        slot[0] = sums[0]; slot[1] = sums[1]; slot[2] = sums[2];
+        *counter = c + 1;
+    }
+}
+
 // ---- weight images from the flat parameter vector (PackRec, wf_internal.h)
 struct PackBases {
     void* img[3];   // plain, wave, mfma image
@@ -342,6 +382,25 @@ int launch_adam_partials(float* params, const float* partial, int split, int64_t
     if (n <= 0) return WF_OK;
     hipLaunchKernelGGL(k_adam_partials, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, partial, split, n_img, inv,
                        m, v, n, step_size, b1, b2, eps, step_dev);
+    return finish();
+}
+
+int launch_pack_reduce_buffer(const float* partial, int split, int64_t n_img, const int32_t* inv, const float* grad, int64_t n_params, double* red,
+                              void* stream) {
+    if (n_params <= 0) return WF_OK;
+    hipLaunchKernelGGL(k_pack_reduce_buffer, dim3((unsigned)((n_params + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partial, split, n_img, inv,
+                       grad, n_params, red);
+    return finish();
+}
+int launch_adam_reduced(float* params, const double* red, float* m, float* v, int64_t n, float step_size, float b1, float b2, float eps,
+                        const unsigned long long* step_dev, void* stream) {
+    if (n > 0)
+        hipLaunchKernelGGL(k_adam_reduced, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, red, m, v, n, step_size, b1,
+                           b2, eps, step_dev);
+    return finish();
+}
+int launch_ring_push(const double* sums, double* ring, int ring_len, unsigned long long* counter, void* stream) {
+    hipLaunchKernelGGL(k_ring_push, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, ring, ring_len, counter);
     return finish();
 }
 

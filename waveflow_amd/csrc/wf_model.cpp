@@ -1266,6 +1266,52 @@ int wf_vqmc_train_step(wf_model* m, const wf_train_state* st, uint64_t seed, int
                              (unsigned long long*)st->counter_dev);
 }
 
+int wf_vqmc_train_step_local(wf_model* m, const wf_train_state* st, uint64_t seed, int64_t batch_local, const float* protons_host, int32_t n_protons,
+                             float inv_global_batch, int32_t exact_sampler, double* reduce_dev, void* workspace_dev, int64_t workspace_bytes,
+                             void* stream) {
+    if (!m || !st || !reduce_dev || batch_local < 1 || n_protons < 0 || n_protons > 8 || (n_protons > 0 && !protons_host)) return WF_ERR_INVALID;
+    if (!st->counter_dev || !st->running_average_dev) return WF_ERR_INVALID;
+    if (!m->d_grad_map || !m->grad_psi_ok || !m->wave_ok || batch_local > kWaveSampleMax) return WF_ERR_UNSUPPORTED;
+    if (!m->params_set || !workspace_dev || workspace_bytes < wf_vqmc_train_step_workspace_bytes(m, batch_local)) return WF_ERR_INVALID;
+    DeviceGuard g(m->device);
+    const int D = m->desc.n_dim;
+    char* p = (char*)workspace_dev;
+    float* x = (float*)p; p += align256(batch_local * D * 4);
+    float* e_loc = (float*)p; p += align256(batch_local * 4);
+    float* grad = (float*)p; p += align256(m->n_params * 4);
+    p += 256;
+    void* sums_ws = p; p += align256(block_sums_ws_bytes(batch_local));
+    const int64_t vjp_bytes = workspace_bytes - (p - (char*)workspace_dev);
+    Protons pr{};
+    pr.n = n_protons;
+    for (int i = 0; i < n_protons; ++i) pr.pos[i] = protons_host[i];
+    int rc = launch_wave_sample(m->dev, m->d_dev, m->d_tabI4, m->d_tabP3, m->d_grad_fk, 1, (unsigned long long)seed, nullptr, batch_local, x, nullptr,
+                                exact_sampler, (const unsigned long long*)st->counter_dev, stream);
+    if (rc) return rc;
+    int split = 0;
+    rc = run_vjp_chunks(m, 2, true, x, batch_local, nullptr, nullptr, &pr, 0.0f, inv_global_batch, e_loc, grad, p, vjp_bytes, stream,
+                        st->running_average_dev, &split);
+    if (rc) return rc;
+    const int64_t n_img = plain_fwd_floats(D, m->nbp) * (int64_t)m->nets.size();
+    rc = launch_pack_reduce_buffer(m->d_grad_partial, split, n_img, m->d_grad_map, grad, m->n_params, reduce_dev, stream);
+    if (rc) return rc;
+    return launch_block_sums(e_loc, batch_local, reduce_dev + m->n_params, sums_ws, block_sums_ws_bytes(batch_local), stream);
+}
+
+int wf_vqmc_train_step_apply(wf_model* m, const wf_train_state* st, const double* reduce_dev, float step_size, float b1, float b2, float eps,
+                             void* stream) {
+    if (!m || !st || !reduce_dev) return WF_ERR_INVALID;
+    if (!st->params_dev || !st->m_dev || !st->v_dev || !st->counter_dev || !st->loss_ring_dev || st->ring_len < 1) return WF_ERR_INVALID;
+    if (!m->d_grad_map) return WF_ERR_UNSUPPORTED;
+    DeviceGuard g(m->device);
+    int rc = launch_adam_reduced(st->params_dev, reduce_dev, st->m_dev, st->v_dev, m->n_params, step_size, b1, b2, eps,
+                                 (const unsigned long long*)st->counter_dev, stream);
+    if (rc) return rc;
+    rc = wf_model_set_params_device(m, st->params_dev, m->n_params, stream);
+    if (rc) return rc;
+    return launch_ring_push(reduce_dev + m->n_params, st->loss_ring_dev, st->ring_len, (unsigned long long*)st->counter_dev, stream);
+}
+
 int64_t wf_mle_train_step_workspace_bytes(const wf_model* m, int64_t N) {
     if (!m || N < 1) return WF_ERR_INVALID;
     if (!m->d_grad_map) return WF_ERR_UNSUPPORTED;

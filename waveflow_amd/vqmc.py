@@ -10,6 +10,7 @@ the step's only collective is one SUM all-reduce of [gradient, sum E_L, sum E_L^
 with m_hat = m / (1 - b1^(i+1)), v_hat = v / (1 - b2^(i+1)) for the step index i passed to opt_update.
 """
 import json
+import os
 from pathlib import Path
 
 import numpy as np
@@ -182,13 +183,15 @@ class ModelTrainer:
             print("Start training...")
         # the whole step as one captured launch sequence, where the library has it (the wave sampler: <= 131072 walkers per
         # step; models the sweeps cover); otherwise the host-stepped loop below (sampler, loss + gradient, Adam: three library calls per step)
-        fused = self.use_graph and not distributed
+        # Sharded over several processes: the same sequence in two halves around the step's one all-reduce.
+        fused = self.use_graph and local_batch >= 1
         if fused:
             from . import _lib
-            fused = _lib.lib().wf_vqmc_train_step_workspace_bytes(psi.model._h, int(self.batch_size)) > 0
+            fused = _lib.lib().wf_vqmc_train_step_workspace_bytes(psi.model._h, int(local_batch)) > 0
         if fused:
             params, loss, energies = self._train_graphed(psi, sample, h_fn, opt_state, get_params, start_epoch, loss, energies, system_dict,
-                                                         save_dir, rng, verbose)
+                                                         save_dir, rng, verbose, group=group if distributed else None, rank=rank,
+                                                         local_batch=local_batch)
             self.params, self.loss, self.energies = params, loss, energies
             self.psi, self.log_pdf, self.sample, self.h_fn = psi, log_pdf, sample, h_fn
             return params, loss
@@ -210,26 +213,57 @@ class ModelTrainer:
         self.psi, self.log_pdf, self.sample, self.h_fn = psi, log_pdf, sample, h_fn
         return params, loss
 
-    def _train_graphed(self, psi, sample, h_fn, opt_state, get_params, start_epoch, loss, energies, system_dict, save_dir, rng, verbose):
+    def _train_graphed(self, psi, sample, h_fn, opt_state, get_params, start_epoch, loss, energies, system_dict, save_dir, rng, verbose,
+                       group=None, rank=0, local_batch=None):
         """The training loop with the step captured once in a hipGraph: per epoch one graph launch; the host looks at the
-        losses every 100 epochs (to refresh the running average, vqmc.py:112-113) and at checkpoints."""
+        losses every 100 epochs (to refresh the running average, vqmc.py:112-113) and at checkpoints.
+        With `group` (one process per GPU) the step is wf_vqmc_train_step_local -> all-reduce of one packed fp64 buffer ->
+        wf_vqmc_train_step_apply, issued call by call (WF_GRAPH_COLLECTIVE=1 captures it with the RCCL collective inside) -- either
+        way without a host synchronisation per step."""
         import torch
+        from . import _lib
+        from .distributed import _all_reduce_sum
         model = psi.model
         st = model.make_train_state(opt_state.x, opt_state.m, opt_state.v, start_epoch + 1, ring_len=128)
         model.set_params_device(opt_state.x)
-        step_args = (st, int(rng.integers(1 << 62)), self.batch_size, h_fn.protons, self.learning_rate)
-        side = torch.cuda.Stream(device=model.device)
-        side.wait_stream(torch.cuda.current_stream(model.device))
-        with torch.cuda.stream(side):
-            # the workspace is allocated here, outside the capture
-            from . import _lib
+        seed = int(rng.integers(1 << 62))
+        if group is None:
+            def step():
+                model.train_step(st, seed, self.batch_size, h_fn.protons, self.learning_rate, exact_sampler=self.exact_sampler)
             nbytes = _lib.check(_lib.lib().wf_vqmc_train_step_workspace_bytes(model._h, self.batch_size), "wf_vqmc_train_step_workspace_bytes")
-            st["ws"] = model._workspace(nbytes, opt_state.x.device)
-            side.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=side):
-                model.train_step(*step_args, exact_sampler=self.exact_sampler)
-        torch.cuda.current_stream(model.device).wait_stream(side)
+            capture = True
+        else:
+            import torch.distributed as dist
+            red = torch.zeros(model.n_params + 3, dtype=torch.float64, device=opt_state.x.device)
+
+            def step():   # every rank draws its own walkers (stream seed + 7919 rank); the tangent rule carries 1 / global batch
+                model.train_step_local(st, seed + 7919 * rank, local_batch, h_fn.protons, 1.0 / float(self.batch_size), red,
+                                       exact_sampler=self.exact_sampler)
+                _all_reduce_sum(red, group)
+                model.train_step_apply(st, red, self.learning_rate)
+            nbytes = _lib.check(_lib.lib().wf_vqmc_train_step_workspace_bytes(model._h, int(local_batch)), "wf_vqmc_train_step_workspace_bytes")
+            # Capturing the collective in the graph measured no faster than issuing the three calls (4.91 vs 4.94 s per 20 000 steps, one
+            # rank) and could not be tried on several GPUs here: opt-in.
+            capture = dist.get_backend(group) == "nccl" and os.environ.get("WF_GRAPH_COLLECTIVE") == "1"
+        st["ws"] = model._workspace(nbytes, opt_state.x.device)   # allocated here, outside the capture
+        replay = step
+        if capture:
+            side = torch.cuda.Stream(device=model.device)
+            side.wait_stream(torch.cuda.current_stream(model.device))
+            try:
+                with torch.cuda.stream(side):
+                    if group is not None:   # RCCL sets up its communicator at the first collective: outside the capture
+                        _all_reduce_sum(torch.zeros(8, dtype=torch.float64, device=opt_state.x.device), group)
+                    side.synchronize()
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph, stream=side):
+                        step()
+                replay = graph.replay
+            except Exception:
+                if group is None:
+                    raise
+                replay = step   # collective not capturable on this stack: call by call
+            torch.cuda.current_stream(model.device).wait_stream(side)
         fetched = [start_epoch]   # losses of the epochs up to here are on the host
 
         def fetch(upto, keep_last_back=False):
@@ -247,9 +281,11 @@ class ModelTrainer:
                 energies.extend([[v] for v in new])
                 opt_state.version += 1
                 params = get_params(opt_state)
-                helpers.create_checkpoint_wavefunc(int(rng.integers(1 << 31)), save_dir, psi, sample, params, epoch, loss, energies, system_dict)
+                ckpt_seed = int(rng.integers(1 << 31))   # (drawn on every rank: the host streams stay aligned)
+                if rank == 0:
+                    helpers.create_checkpoint_wavefunc(ckpt_seed, save_dir, psi, sample, params, epoch, loss, energies, system_dict)
                 model.set_params_device(opt_state.x)
-            graph.replay()
+            replay()
             if epoch % 100 == 0:
                 new = fetch(epoch)
                 loss.extend(new[:-1])
