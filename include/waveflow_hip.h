@@ -215,6 +215,11 @@ int wf_vqmc_loss_grad(const wf_model* m, const float* x_dev, int64_t B, const fl
  *                        gives Adam's bias corrections, selects slot i mod ring_len of the loss ring; incremented at the end
  *   running_average_dev  the `running_average` of loss_fn_efficient (the caller refreshes it every 100 steps, vqmc.py:112-113)
  *   loss_ring_dev        [ring_len][3] doubles: [sum E_L, sum E_L^2, batch] of each step
+ *   defer_eval_tables    0: every image of the model holds the updated parameters on exit.  1: the step refreshes the weight
+ *                        images only and leaves out the composite tables that just the large-batch evaluation kernel reads
+ *                        (13 % of a 128-walker step); the caller then calls wf_model_set_params_device(m, params_dev, ..)
+ *                        before wf_logpdf_fwd / wf_psi_fwd / wf_flow_fwd / wf_layer_fwd -- further training steps, wf_sample,
+ *                        wf_hamiltonian_fwd and the gradient entry points need nothing
  * The model's weight images must hold params_dev on entry (wf_model_set_params_device); they hold the updated parameters on
  * exit.  Single process; batch <= 131072 (the wave sampler; beyond: WF_ERR_UNSUPPORTED, step from the host with wf_sample,
  * wf_vqmc_loss_grad, wf_adam_step).  Workspace: wf_vqmc_train_step_workspace_bytes. */
@@ -226,6 +231,7 @@ typedef struct wf_train_state {
     float* running_average_dev;
     double* loss_ring_dev;
     int32_t ring_len;
+    int32_t defer_eval_tables;
 } wf_train_state;
 int64_t wf_vqmc_train_step_workspace_bytes(const wf_model* m, int64_t batch);
 int wf_vqmc_train_step(wf_model* m, const wf_train_state* st, uint64_t seed, int64_t batch, const float* protons_host, int32_t n_protons,

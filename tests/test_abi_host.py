@@ -28,7 +28,7 @@ def test_desc_struct_matches_header_layout():
     assert ctypes.sizeof(_lib.BC) == 4 + 4 * 4 + 4 * 4
     assert ctypes.sizeof(_lib.ModelDesc) == 4 * 9 + 2 * 36 + 4 * 3 + 2 * 36 + 4 + 4 + 16 * 4 + 4 + 4
     # wf_train_state: six pointers + int32 (padded to 8)
-    assert ctypes.sizeof(_lib.TrainState) == 6 * 8 + 8 and _lib.TrainState.ring_len.offset == 48
+    assert ctypes.sizeof(_lib.TrainState) == 6 * 8 + 8 and _lib.TrainState.ring_len.offset == 48 and _lib.TrainState.defer_eval_tables.offset == 52
 
 
 def test_strerror_and_no_device_is_loud():

@@ -93,6 +93,15 @@ def test_training_reduces_the_energy_and_writes_the_reference_artefacts(tmp_path
     l = np.asarray(loss[1:], dtype=np.float64)
     assert np.isfinite(l).all() and len(l) == 300
     assert np.median(l[-50:]) < 0.5 * np.median(l[:50])   # <E_L> falls (it starts around +10 .. +50 Ha; batch means are heavy-tailed)
+    # the captured steps defer the evaluation tables of the large-batch kernel; they are current again when training returns
+    xs = sorted_walkers(9000, 2, 9.0, 4)
+    m = t.psi.model
+    m.set_kernel("mfma")
+    a = m.psi(xs)
+    m.set_kernel("scalar")
+    b = m.psi(xs)
+    m.set_kernel("auto")
+    np.testing.assert_allclose(a, b, rtol=0, atol=2e-5 * np.abs(b).max())
     # artefacts of helpers.create_checkpoint_wavefunc / vqmc.py:79-88
     sd = t.save_dir
     assert json.load(open(f"{sd}/system_info.json"))["n_particle"] == 2

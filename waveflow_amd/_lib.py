@@ -54,7 +54,7 @@ class ModelDesc(ctypes.Structure):
 class TrainState(ctypes.Structure):
     """wf_train_state (include/waveflow_hip.h)"""
     _fields_ = [("params_dev", ctypes.c_void_p), ("m_dev", ctypes.c_void_p), ("v_dev", ctypes.c_void_p), ("counter_dev", ctypes.c_void_p),
-                ("running_average_dev", ctypes.c_void_p), ("loss_ring_dev", ctypes.c_void_p), ("ring_len", ctypes.c_int32)]
+                ("running_average_dev", ctypes.c_void_p), ("loss_ring_dev", ctypes.c_void_p), ("ring_len", ctypes.c_int32), ("defer_eval_tables", ctypes.c_int32)]
 
 
 EXPORTS = ["wf_abi_version", "wf_strerror", "wf_last_hip_error", "wf_last_hip_error_string", "wf_device_count",

@@ -106,7 +106,7 @@ def train_model(target, num_epochs, n_model_sample, model_type='IFlow', dataset_
     # every epoch is the same sequence of launches on resident data: capture it once (wf_mle_train_step) and replay it; the
     # host reads the loss ring at checkpoints and every `ring` epochs
     ring = 256
-    st = model.make_train_state(state.x, state.m, state.v, 1, ring_len=ring)
+    st = model.make_train_state(state.x, state.m, state.v, 1, ring_len=ring, defer_eval_tables=True)   # refreshed before every evaluation below
     model.set_params_device(state.x)
     nbytes = _lib.check(_lib.lib().wf_mle_train_step_workspace_bytes(model._h, int(x_dev.shape[0])), "wf_mle_train_step_workspace_bytes")
     st["ws"] = model._workspace(nbytes, x_dev.device)
@@ -141,4 +141,5 @@ def train_model(target, num_epochs, n_model_sample, model_type='IFlow', dataset_
             print(f"Epoch {epoch} | loss: {losses[-1]}")
     fetch(num_epochs)
     state.version += 1
+    model.set_params_device(state.x)   # every image, evaluation tables included, holds the final parameters
     return get_params(state), losses

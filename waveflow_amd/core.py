@@ -301,8 +301,10 @@ class DeviceModel:
         _lib.check(_lib.lib().wf_adam_step(self._p(x), self._p(g), self._p(m), self._p(v), x.numel(), int(step), float(step_size), float(b1),
                                            float(b2), float(eps), self._stream()), "wf_adam_step")
 
-    def make_train_state(self, x, m, v, first_step, ring_len=128):
-        """Device-side state of wf_vqmc_train_step around the Adam vectors x, m, v (float32 cuda, updated in place)."""
+    def make_train_state(self, x, m, v, first_step, ring_len=128, defer_eval_tables=False):
+        """Device-side state of wf_vqmc_train_step around the Adam vectors x, m, v (float32 cuda, updated in place).
+        defer_eval_tables: the steps skip the tables only the large-batch evaluation kernel reads; the caller refreshes them with
+        set_params_device(x) before evaluating (ensure_params does so for a DeviceParams of a new version)."""
         torch = _torch()
         dev = x.device
         st = {"x": x, "m": m, "v": v, "ring_len": int(ring_len),
@@ -310,7 +312,7 @@ class DeviceModel:
               "running_average": torch.zeros(1, dtype=torch.float32, device=dev),
               "ring": torch.zeros(int(ring_len), 3, dtype=torch.float64, device=dev)}
         st["c"] = _lib.TrainState(x.data_ptr(), m.data_ptr(), v.data_ptr(), st["counter"].data_ptr(), st["running_average"].data_ptr(),
-                                  st["ring"].data_ptr(), int(ring_len))
+                                  st["ring"].data_ptr(), int(ring_len), int(bool(defer_eval_tables)))
         return st
 
     def train_step(self, st, seed, batch, protons, step_size, b1=0.9, b2=0.999, eps=1e-8, exact_sampler=False):

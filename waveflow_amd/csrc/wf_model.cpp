@@ -897,12 +897,12 @@ int wf_model_set_kernel(wf_model* m, int kernel_kind) {
 }
 
 // fills every weight image from a device-resident flat vector (asynchronous on `stream`)
-static int apply_params(wf_model* m, const float* flat_dev, void* stream) {
+static int apply_params(wf_model* m, const float* flat_dev, void* stream, bool eval_tables = true) {
     {
         int rc = launch_pack(flat_dev, m->d_pack, m->n_pack, m->d_plain, m->d_wave, m->d_mfma, stream);
         if (rc) return rc;
     }
-    if (m->mfma_ok) {
+    if (m->mfma_ok && eval_tables) {
         // composite tables of output dimension 0 (reads the plain image filled above)
         int rc = launch_prepare_dim0(m->d_dev, (int)m->nets.size(), m->desc.n_mesh, m->d_fk_nat, m->mdev.F_I, m->mdev.F_P, m->d_comp, stream);
         if (rc) return rc;
@@ -1259,7 +1259,7 @@ int wf_vqmc_train_step(wf_model* m, const wf_train_state* st, uint64_t seed, int
     if (rc) return rc;
     rc = adam_from_sweep(m, st, grad, split, step_size, b1, b2, eps, stream);
     if (rc) return rc;
-    rc = wf_model_set_params_device(m, st->params_dev, m->n_params, stream);
+    rc = apply_params(m, st->params_dev, stream, !st->defer_eval_tables);
     if (rc) return rc;
     // batch sums of the local energies -> loss ring, step counter + 1 (after Adam, which reads the counter as its step index)
     return launch_block_sums(e_loc, batch, sums, sums_ws, block_sums_ws_bytes(batch), stream, st->loss_ring_dev, st->ring_len,
@@ -1307,7 +1307,7 @@ int wf_vqmc_train_step_apply(wf_model* m, const wf_train_state* st, const double
     int rc = launch_adam_reduced(st->params_dev, reduce_dev, st->m_dev, st->v_dev, m->n_params, step_size, b1, b2, eps,
                                  (const unsigned long long*)st->counter_dev, stream);
     if (rc) return rc;
-    rc = wf_model_set_params_device(m, st->params_dev, m->n_params, stream);
+    rc = apply_params(m, st->params_dev, stream, !st->defer_eval_tables);
     if (rc) return rc;
     return launch_ring_push(reduce_dev + m->n_params, st->loss_ring_dev, st->ring_len, (unsigned long long*)st->counter_dev, stream);
 }
@@ -1337,7 +1337,7 @@ int wf_mle_train_step(wf_model* m, const wf_train_state* st, const float* x_dev,
     if (rc) return rc;
     rc = adam_from_sweep(m, st, grad, split, step_size, b1, b2, eps, stream);
     if (rc) return rc;
-    rc = wf_model_set_params_device(m, st->params_dev, m->n_params, stream);
+    rc = apply_params(m, st->params_dev, stream, !st->defer_eval_tables);
     if (rc) return rc;
     return launch_block_sums(lp, N, sums, sums_ws, block_sums_ws_bytes(N), stream, st->loss_ring_dev, st->ring_len,
                              (unsigned long long*)st->counter_dev);

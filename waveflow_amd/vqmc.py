@@ -224,7 +224,9 @@ class ModelTrainer:
         from . import _lib
         from .distributed import _all_reduce_sum
         model = psi.model
-        st = model.make_train_state(opt_state.x, opt_state.m, opt_state.v, start_epoch + 1, ring_len=128)
+        # (the steps leave out the tables only the large-batch evaluation kernel reads; every evaluation below goes through
+        # ensure_params / set_params_device first, and the loop ends with a full refresh)
+        st = model.make_train_state(opt_state.x, opt_state.m, opt_state.v, start_epoch + 1, ring_len=128, defer_eval_tables=True)
         model.set_params_device(opt_state.x)
         seed = int(rng.integers(1 << 62))
         if group is None:
@@ -299,4 +301,5 @@ class ModelTrainer:
         loss.extend(new)
         energies.extend([[v] for v in new])
         opt_state.version += 1
+        model.set_params_device(opt_state.x)   # every image of the model, evaluation tables included, holds the final parameters
         return get_params(opt_state), loss, energies
