@@ -129,9 +129,19 @@ struct Protons {
     int n;
 };
 // The sweeps run over a coefficient ring (wf_ring.h).  kind 0: R1 (first order); 1: R3 (one sample per walker and direction,
-// 3 coefficients); 2: RF (one sample per walker, D + 2 coefficients)
-inline int ring_coefs(int D, int kind) { return kind == 0 ? 1 : (kind == 1 ? 3 : D + 2); }
-inline int ring_samples(int D, int kind) { return kind == 1 ? D : 1; }
+// 3 coefficients); 2: RF<K> (one sample per walker and block of K directions, K + 2 coefficients); 3: RF<D> (one sample per walker).
+// The taped sweeps use kind 2 with K = D up to 5 coordinates; beyond, the 8..10 live floats per value of RF<D> spill hundreds of registers
+// in the reverse sweep and two blocks of 3 or 4 directions are ~20 % faster.  The untaped forward sweep of wf_hamiltonian_fwd is fastest
+// with the whole walker in one sample (kind 3) for every D (scratch/energy_ab.py, scratch/grad_ab.py).
+#ifndef WF_RF_BLOCK_6
+#define WF_RF_BLOCK_6 3
+#endif
+#ifndef WF_RF_BLOCK_78
+#define WF_RF_BLOCK_78 4
+#endif
+constexpr int rf_block(int D) { return D <= 5 ? D : (D == 6 ? WF_RF_BLOCK_6 : WF_RF_BLOCK_78); }
+inline int ring_coefs(int D, int kind) { return kind == 0 ? 1 : (kind == 1 ? 3 : (kind == 2 ? rf_block(D) + 2 : D + 2)); }
+inline int ring_samples(int D, int kind) { return (kind == 0 || kind == 3) ? 1 : (kind == 1 ? D : (D + rf_block(D) - 1) / rf_block(D)); }
 // reverse pass (wf_kernels_grad.hip)
 int grad_ws_rows(int D, int nbp);
 int wgrad_partial_floats(int n_nets, int64_t net_img_floats);

@@ -336,7 +336,7 @@ int wgrad_partial_floats(int n_nets, int64_t net_img_floats) { return kWgradSpli
 int launch_wgrad(int D, int nbp, int ring_kind, int n_nets, int64_t n_samples, const float* ws, float* partial, int accumulate, float* grad_img,
                  int64_t net_img_floats, int* split_out, void* stream) {
     hipStream_t s = (hipStream_t)stream;
-#define CALLK(DD, K) return ring_kind == 2 ? run_wgrad<DD, DD + 2, K>(n_nets, n_samples, ws, partial, accumulate, grad_img, net_img_floats, split_out, s) \
+#define CALLK(DD, K) return ring_kind == 2 ? run_wgrad<DD, rf_block(DD) + 2, K>(n_nets, n_samples, ws, partial, accumulate, grad_img, net_img_floats, split_out, s) \
                     : ring_kind == 1 ? run_wgrad<DD, 3, K>(n_nets, n_samples, ws, partial, accumulate, grad_img, net_img_floats, split_out, s)       \
                                      : run_wgrad<DD, 1, K>(n_nets, n_samples, ws, partial, accumulate, grad_img, net_img_floats, split_out, s)
     if (nbp == 64) {

@@ -1165,7 +1165,9 @@ int64_t wave_tail_floats(int D, int ring_kind) { return (int64_t)(2 * D + 1) * r
 int launch_wave_fwd(const ModelDev& md, const ModelDev* md_dev, int ring_kind, const float* tabI4, const float* tabP4, const float* fk_nat,
                     const float* x, int64_t B, float* ws, float* tails, int taped, void* stream) {
     hipStream_t s = (hipStream_t)stream;
-#define CALLK(DD, K) (ring_kind == 2 ? run_fwd<DD, RF<DD>, K>(md_dev, tabI4, tabP4, fk_nat, x, B, ws, tails, taped, s)  \
+    if (ring_kind == 3 && taped) return WF_ERR_INVALID;   // whole-walker samples for every D: the untaped energy sweep only
+#define CALLK(DD, K) (ring_kind == 3 ? run_fwd<DD, RF<DD>, K>(md_dev, tabI4, tabP4, fk_nat, x, B, ws, tails, 0, s)               \
+                      : ring_kind == 2 ? run_fwd<DD, RF<rf_block(DD)>, K>(md_dev, tabI4, tabP4, fk_nat, x, B, ws, tails, taped, s)  \
                       : ring_kind == 1 ? run_fwd<DD, R3, K>(md_dev, tabI4, tabP4, fk_nat, x, B, ws, tails, taped, s) \
                                        : run_fwd<DD, R1, K>(md_dev, tabI4, tabP4, fk_nat, x, B, ws, tails, taped, s))
 #define CALL(DD) CALLK(DD, 1)
@@ -1180,7 +1182,7 @@ int launch_wave_fwd(const ModelDev& md, const ModelDev* md_dev, int ring_kind, c
 int launch_wave_bwd(const ModelDev& md, const ModelDev* md_dev, int mode, int ring_kind, const float* tabI4, const float* tabP4,
                     const float* fk_nat, int64_t B, const float* w1, const float* w2, float* ws, const float* tails, void* stream) {
     hipStream_t s = (hipStream_t)stream;
-#define CALLK(DD, K) (ring_kind == 2 ? run_bwd<DD, RF<DD>, K>(md_dev, mode, tabI4, tabP4, fk_nat, B, w1, w2, ws, tails, s)  \
+#define CALLK(DD, K) (ring_kind == 2 ? run_bwd<DD, RF<rf_block(DD)>, K>(md_dev, mode, tabI4, tabP4, fk_nat, B, w1, w2, ws, tails, s)  \
                       : ring_kind == 1 ? run_bwd<DD, R3, K>(md_dev, mode, tabI4, tabP4, fk_nat, B, w1, w2, ws, tails, s) \
                                        : run_bwd<DD, R1, K>(md_dev, mode, tabI4, tabP4, fk_nat, B, w1, w2, ws, tails, s))
 #define CALL(DD) CALLK(DD, 1)
@@ -1236,15 +1238,16 @@ int launch_wave_sample(const ModelDev& md, const ModelDev* md_dev, const float* 
         default: return WF_ERR_UNSUPPORTED;                                                        \
     }
 #define WF_RING2_CASE(KERNEL, DD, ...)                                                             \
-    if (ring_kind == 2) hipLaunchKernelGGL((KERNEL<DD, RF<DD>>), grid, block, 0, s, __VA_ARGS__);  \
-    else hipLaunchKernelGGL((KERNEL<DD, R3>), grid, block, 0, s, __VA_ARGS__);                     \
+    if (ring_kind == 3) hipLaunchKernelGGL((KERNEL<DD, RF<DD>>), grid, block, 0, s, __VA_ARGS__);                     \
+    else if (ring_kind == 2) hipLaunchKernelGGL((KERNEL<DD, RF<rf_block(DD)>>), grid, block, 0, s, __VA_ARGS__);     \
+    else hipLaunchKernelGGL((KERNEL<DD, R3>), grid, block, 0, s, __VA_ARGS__);                                       \
     break
 
 int launch_energy_out(int D, int ring_kind, const float* tails, const float* x, int64_t B, unsigned constrained_mask, const Protons& pr, float* hpsi,
                       float* psi, float* lap, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)((B + 255) / 256)), block(256);
-    if (ring_kind != 1 && ring_kind != 2) return WF_ERR_INVALID;
+    if (ring_kind < 1 || ring_kind > 3) return WF_ERR_INVALID;
     WF_RING2_DISPATCH(k_energy_out, tails, x, B, constrained_mask, pr, hpsi, psi, lap)
     return finish();
 }
@@ -1253,7 +1256,7 @@ int launch_energy_seeds(int D, int ring_kind, const float* tails, const float* x
                         const float* running_avg_dev, float inv_count, float* e_loc, float* w_psi, float* w_lap, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)((B + 255) / 256)), block(256);
-    if (ring_kind != 1 && ring_kind != 2) return WF_ERR_INVALID;
+    if (ring_kind < 1 || ring_kind > 2) return WF_ERR_INVALID;
     WF_RING2_DISPATCH(k_energy_seeds, tails, x, B, constrained_mask, pr, running_avg, running_avg_dev, inv_count, e_loc, w_psi, w_lap)
     return finish();
 }
@@ -1292,7 +1295,7 @@ int launch_wave_eval(const ModelDev& md, const ModelDev* md_dev, const float* ta
 int launch_wave_energy(const ModelDev& md, const ModelDev* md_dev, const float* tabI4, const float* tabP4, const float* fk_nat, const float* x,
                        int64_t B, const Protons& pr, float* hpsi, float* psi, float* lap, float* tail_ws, void* stream) {
     const bool force_r3 = getenv("WF_ENERGY_R3") != nullptr;   // A/B switch, read per call (tests compare the two sweeps)
-    const int kind = force_r3 ? 1 : 2;
+    const int kind = force_r3 ? 1 : 3;
     int rc = launch_wave_fwd(md, md_dev, kind, tabI4, tabP4, fk_nat, x, B, nullptr, tail_ws, 0, stream);
     if (rc) return rc;
     return launch_energy_out(md.D, kind, tail_ws, x, B, md.constrained_mask, pr, hpsi, psi, lap, stream);

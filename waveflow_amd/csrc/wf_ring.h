@@ -3,7 +3,7 @@
 // R3 = IR[t]/t^3 holds the Taylor coefficients a0 + a1 t + a2 t^2 of a quantity along one coordinate direction
 // x + t e_i (psi'' along e_i = 2 psi_2); R1 = IR is the first-order case.  Adjoints are kept in REVERSED coefficient order,
 // which makes the adjoint of a ring product a ring product (see wf_kernels_wave.hip).
-// RF<D> = (value, gradient, half the Laplacian) with respect to the D coordinates of a walker: the commutative algebra
+// RF<D> = (value, gradient, half the Laplacian) with respect to D coordinates of a walker (all of them, or a block): the commutative algebra
 // IR[t_1..t_D] / (t_i t_j (i != j), t_i^2 - t_1^2, t^3) with basis 1, t_1..t_D, s = t_i^2 -- the second-order jet of a function
 // projected to what the Laplacian needs.  The sum over the D directions of the R3 second-order coefficients is carried as one
 // number, the value channel and the weight loads are shared.  Like R3 it is a Frobenius algebra (the pairing <a, b> = top
@@ -148,10 +148,11 @@ template <class T> __device__ __forceinline__ T rsigmoid(T a) {
 // the coordinate x_d along direction `dir`; adjoint seed of the value coefficient (reversed order: last slot)
 __device__ __forceinline__ R1 make_var(R1*, float x, int, int) { return R1{x}; }
 __device__ __forceinline__ R3 make_var(R3*, float x, int d, int dir) { return R3{x, d == dir ? 1.0f : 0.0f, 0.0f}; }
-template <int D> __device__ __forceinline__ RF<D> make_var(RF<D>*, float x, int d, int) {
-    RF<D> r = make_cst((RF<D>*)nullptr, x);
+// (sample `dir` of a walker carries the block of directions dir * K .. dir * K + K - 1; the other coordinates are constants in it)
+template <int K> __device__ __forceinline__ RF<K> make_var(RF<K>*, float x, int d, int dir) {
+    RF<K> r = make_cst((RF<K>*)nullptr, x);
 #pragma unroll
-    for (int i = 0; i < D; ++i) r.g[i] = i == d ? 1.0f : 0.0f;
+    for (int i = 0; i < K; ++i) r.g[i] = dir * K + i == d ? 1.0f : 0.0f;
     return r;
 }
 // Laplacian carried by psi: the sum over the directions of 2 psi_2 (R3), or the last component (RF)
@@ -203,8 +204,11 @@ __device__ __forceinline__ R3 lift(const float (&t)[4], int nd, R3 u) {
 template <int D> __device__ __forceinline__ RF<D> lift(const float (&t)[4], int nd, RF<D> u) {
     return lift_fn(u, t[min(nd, 3)], t[min(nd + 1, 3)], t[min(nd + 2, 3)]);
 }
-// samples per walker of a ring: D directions in R3, one otherwise
-template <class T, int D> constexpr int kDirs = std::is_same<T, R3>::value ? D : 1;
+// samples per walker of a ring: D directions in R3, ceil(D / K) blocks of directions in RF<K>, one in R1
+template <class T> struct RingBlock { static constexpr int K = 0; };
+template <> struct RingBlock<R3> { static constexpr int K = 1; };
+template <int KK> struct RingBlock<RF<KK>> { static constexpr int K = KK; };
+template <class T, int D> constexpr int kDirs = RingBlock<T>::K == 0 ? 1 : (D + RingBlock<T>::K - 1) / (RingBlock<T>::K == 0 ? 1 : RingBlock<T>::K);
 
 }  // namespace ring
 }  // namespace wf
