@@ -609,3 +609,36 @@ def test_forward_laplacian_ring_gradient_matches_directional_ring(D, monkeypatch
     np.testing.assert_allclose(sf, s3, rtol=2e-5)
     # (random signed weights cancel in psi_vjp: fp32 rounding of the two sweeps shows at the 1e-5 level)
     assert rel_l2(gf, g3) < 2e-5 and rel_l2(vf, v3) < 3e-4, (rel_l2(gf, g3), rel_l2(vf, v3))
+
+
+def test_deferred_evaluation_tables_contract(he_flat):
+    """wf_train_state.defer_eval_tables = 1: the steps keep the weight images current but leave the composite dimension-0 tables of
+    the large-batch kernel to the next wf_model_set_params_device; the small-batch (wave) kernel, the sampler and further steps
+    never see the difference."""
+    import torch
+    from waveflow_amd.utils import physics
+    params, psi, log_pdf, sample = he(he_flat)
+    m = psi.model
+    protons = physics.system_catalogue[1]["He"][0].reshape(-1)
+    x = torch.as_tensor(sorted_walkers(9000, 2, 9.0, 4)).cuda()
+    out = {}
+    for defer in (False, True):
+        flat = torch.as_tensor(he_flat).cuda().clone()
+        st = m.make_train_state(flat, torch.zeros_like(flat), torch.zeros_like(flat), 1, ring_len=8, defer_eval_tables=defer)
+        m.set_params_device(flat)
+        for _ in range(3):
+            m.train_step(st, 99, 256, protons, 1e-3, exact_sampler=True)
+        m.set_kernel("wave")
+        small = m.psi(x[:2000])
+        m.set_kernel("mfma")
+        before = m.psi(x)
+        m.set_params_device(flat)
+        after = m.psi(x)
+        m.set_kernel("auto")
+        out[defer] = (flat.clone(), small, before, after, st["ring"].clone())
+    # same trajectory either way; the wave kernel and the refreshed large-batch kernel agree in both
+    assert torch.equal(out[False][0], out[True][0]) and torch.equal(out[False][4], out[True][4])
+    assert torch.equal(out[False][1], out[True][1]) and torch.equal(out[False][3], out[True][3])
+    assert torch.equal(out[False][2], out[False][3])            # not deferred: current on exit
+    assert not torch.equal(out[True][2], out[True][3])          # deferred: stale until the refresh
+    np.testing.assert_allclose(out[True][3][:2000].cpu().numpy(), out[True][1].cpu().numpy(), rtol=0, atol=2e-5 * float(out[True][1].abs().max()))
