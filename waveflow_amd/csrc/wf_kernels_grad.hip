@@ -278,7 +278,9 @@ __global__ void k_vqmc_seeds(const float* __restrict__ xg, int64_t B, int D, con
     const float ps = psi[b], hp = hpsi[b];
     const float el = hp / (ps + 1e-8f);
     // d loss = [2 (E - avg)/psi - Hpsi/psi^2] dpsi + (1/psi) dHpsi,  dHpsi = -1/2 dlap + V dpsi
-    const float a = 2.0f * (el - running_avg) / ps - hp / (ps * ps);
+    // 2 (E_L - avg) / psi - H psi / psi^2 (vqmc.py:205-210), written without psi^2: the product of D small factors squared
+    // underflows in fp32 for larger D (an 8-electron chain at its initial parameters), and inf - inf would poison the step
+    const float a = (2.0f * (el - running_avg) - hp / ps) / ps;
     const float c = 1.0f / ps;
     e_loc[b] = el;
     w_psi[b] = (a + c * V) * inv_count;

@@ -604,7 +604,9 @@ __device__ __forceinline__ void seed_values(float ps, float lap, const float* __
         }
     const float hp = -0.5f * lap + V * ps;
     const float el = hp / (ps + 1e-8f);
-    const float a = 2.0f * (el - running_avg) / ps - hp / (ps * ps);
+    // 2 (E_L - avg) / psi - H psi / psi^2 (vqmc.py:205-210), written without psi^2: the product of D small factors squared
+    // underflows in fp32 for larger D (an 8-electron chain at its initial parameters), and inf - inf would poison the step
+    const float a = (2.0f * (el - running_avg) - hp / ps) / ps;
     const float c = 1.0f / ps;
     e_loc = el;
     w_psi = (a + c * V) * inv_count;
