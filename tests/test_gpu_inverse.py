@@ -169,3 +169,25 @@ def test_wave_sampler_with_more_than_32_bases(monkeypatch):
     assert np.median(d) < 1e-6 and np.quantile(d, 0.999) < 2e-4 and d.max() < 2e-3
     u2, _ = m.flow(small)
     assert np.median(np.abs(u2 - u)) < 2e-5 and np.abs(u2 - u).max() < 5e-3
+
+
+@pytest.mark.parametrize("D", [3, 5])
+def test_mean_type_box_inverse_beyond_two_particles(D, monkeypatch):
+    """The reference's reverse of the mean-type box transform is two-particle only (made.py:188); for D > 2 the library inverts
+    direct_fun_mean itself: direct(inverse(u)) = u, walkers sorted and inside the box, in both sampler kernels."""
+    from waveflow_amd import model_factory
+    init_fun = model_factory.get_waveflow_model(D, base_spline_degree=5, i_spline_degree=5, n_prior_internal_knots=16,
+                                                n_i_internal_knots=16, i_spline_reg=0.05, i_spline_reverse_fun_tol=1e-6,
+                                                n_flow_layers=2, box_size=7.0, xu_coord_type="mean")
+    params, psi, log_pdf, sample = init_fun(3, D)
+    m = psi.model
+    m.ensure_params(params)
+    u = np.random.default_rng(0).uniform(0.02, 0.98, size=(5000, D)).astype(np.float32)
+    for limit in ("100000000", "0"):                                          # wave kernel, one-lane kernel
+        monkeypatch.setenv("WF_WAVE_SAMPLE_MAX", limit)
+        x = m.inverse(u, exact=True)
+        assert np.all(np.diff(x, axis=1) >= 0) and np.abs(x).max() <= 7.0 + 1e-4
+        u2, _ = m.flow(x)
+        assert np.median(np.abs(u2 - u)) < 3e-5 and np.abs(u2 - u).max() < 1e-2, (limit, np.abs(u2 - u).max())
+    xs = m.sample(3, 4096, exact=True).cpu().numpy()
+    assert np.all(np.diff(xs, axis=1) >= 0) and np.isfinite(psi(params, xs)).all()

@@ -31,7 +31,7 @@ def _deps(src):
         d.append(os.path.join(CSRC, "wf_mfma_impl.h"))
     if "grad" in src or "wave" in src:
         d.append(os.path.join(CSRC, "wf_ring.h"))
-    if "scalar" in src:
+    if "scalar" in src or "wave" in src:   # (the wave sampler shares Philox and the box reverse with the one-lane kernels)
         d.append(os.path.join(CSRC, "wf_scalar_impl.h"))
     return [p for p in d if os.path.exists(p)]
 

@@ -436,7 +436,26 @@ __device__ __forceinline__ void made_inverse(const NetPlain& net, const float (&
 template <int D>
 __device__ __forceinline__ void box_reverse(const ModelDev& md, const float (&u)[D], float (&x)[D]) {
     const float L = md.box_L;
-    if (md.box_kind == WF_BOX_MEAN) {
+    if (md.box_kind == WF_BOX_MEAN && D > 2) {
+        // The reference's reverse_fun_mean is written for two particles (made.py:186-197, "TODO" at :188).  For D > 2 this is the
+        // inverse of direct_fun_mean (made.py:156-183) itself: differences from the shrinking remaining space, then the offset of
+        // the first particle from the last coordinate.
+        const float tol = 1e-7f;
+        float o[D];
+        float space = 2 * L, c = 0.0f;
+        o[0] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < D - 1; ++i) {
+            const float diff = u[i] * (space + tol);
+            space = space - diff;
+            c = c + diff;
+            o[i + 1] = c;
+        }
+        const float w = o[D - 1];                          // x[D-1] - x[0]
+        const float x0 = u[D - 1] * (2 * L - w + tol) - L; // u[D-1] = (mean + L - l) / (2L - w + tol) with mean - l = x[0]
+#pragma unroll
+        for (int i = 0; i < D; ++i) x[i] = x0 + o[i];
+    } else if (md.box_kind == WF_BOX_MEAN) {
         float o[D];
         float c = 0.0f, s = 0.0f;
         o[0] = 0.0f;
