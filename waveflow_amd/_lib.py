@@ -4,7 +4,7 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libwaveflow_hip.so")
+LIB_PATH = os.environ.get("WF_LIB") or os.path.join(HERE, "libwaveflow_hip.so")   # WF_LIB: experiment builds (scratch/)
 
 WF_MAX_DIM, WF_MAX_BC = 16, 4
 SPLINE_M, SPLINE_I, SPLINE_B, SPLINE_OB = 0, 1, 2, 3

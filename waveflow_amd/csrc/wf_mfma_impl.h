@@ -7,6 +7,17 @@
 
 #include "wf_internal.h"
 
+#ifndef WF_XHALF
+#define WF_XHALF 0
+#endif
+#ifdef WF_NO_FENCE
+#define WF_FENCE()
+#elif defined(WF_FENCE_MASK)   // experiment: which instruction classes may cross (see __builtin_amdgcn_sched_barrier)
+#define WF_FENCE() __builtin_amdgcn_sched_barrier(WF_FENCE_MASK)
+#else
+#define WF_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
 namespace wf {
 namespace mfma {
 
@@ -29,9 +40,21 @@ __device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_log
 // only the "VALU write -> permlane read" side, and this kernel then produced wrong sums on a few tiles per
 // launch (non-deterministically; gone with ds_bpermute, gone with the padding below).  See DESIGN.md §9.
 __device__ __forceinline__ float xhalf_sum(float v) {
+#if WF_XHALF == 1   // experiment: the builtin (hipcc pads the VALU-write -> permlane-read side itself)
+    const unsigned u = __float_as_uint(v);
+    const auto s = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(s[0]) + __uint_as_float(s[1]);
+#elif WF_XHALF == 2  // experiment: LDS crossbar
+    return v + __uint_as_float(__builtin_amdgcn_ds_bpermute((int)(((threadIdx.x & 63) ^ 32) << 2), (int)__float_as_uint(v)));
+#elif WF_XHALF == 3  // experiment: asm swap with the documented 2 wait states in front only
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+#else
     float a = v, b = v;
     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 3" : "+v"(a), "+v"(b));
     return a + b;
+#endif
 }
 
 __device__ __forceinline__ f32x16 load16(const float* p) {
@@ -94,12 +117,17 @@ __device__ __forceinline__ void split_block(const f32x16& x, Frag& f) {
 
 // one 32-unit output block of a K=64 layer: acc += Ahi*Bhi + Ahi*Blo + Alo*Bhi (fp32 accumulation)
 // Wh / Wl: LDS images [t][s][lane][8 halves] of this block
+template <int SITE = 0>
 __device__ __forceinline__ f32x16 dense64_block(const _Float16* Wh, const _Float16* Wl, const Frag (&in)[2], f32x16 bias, int lane) {
     f32x16 acc = bias;
+#ifdef WF_OPEN_SITES   // experiment: the sites in this bit mask get the weak fence WF_FENCE_MASK, every other site the full one
+#undef WF_FENCE
+#define WF_FENCE() do { if ((WF_OPEN_SITES >> SITE) & 1) __builtin_amdgcn_sched_barrier(0x402); else __builtin_amdgcn_sched_barrier(0); } while (0)
+#endif
     // Scheduling fences around the f16 MFMA chain: when hipcc (ROCm 7.2) interleaved unrelated VALU / memory
     // instructions of the neighbouring code into this chain, a few tiles per launch came out wrong,
     // non-deterministically.  With the chain fenced the kernel is bit-reproducible; cost < 1 %.
-    __builtin_amdgcn_sched_barrier(0);
+    WF_FENCE();
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -110,7 +138,7 @@ __device__ __forceinline__ f32x16 dense64_block(const _Float16* Wh, const _Float
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, in[t].lo[s], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, in[t].hi[s], acc, 0, 0, 0);
         }
-    __builtin_amdgcn_sched_barrier(0);
+    WF_FENCE();
     return acc;
 }
 
@@ -130,7 +158,7 @@ struct NetOff {
 };
 
 // Hidden layers of one conditioner net for the wave's 32 walkers; result: second hidden layer as B fragments.
-template <int D, int NBK>
+template <int D, int NBK, int PRIOR = 0>
 __device__ __forceinline__ void hidden_layers(const float* net, const float (&in)[D], int lane, Frag (&h2)[2]) {
     using O = NetOff<D, NBK>;
     const int h = lane >> 5;
@@ -151,24 +179,29 @@ __device__ __forceinline__ void hidden_layers(const float* net, const float (&in
     }
     const _Float16* W1h = reinterpret_cast<const _Float16*>(net + O::W1h);
     const _Float16* W1l = reinterpret_cast<const _Float16*>(net + O::W1l);
-#pragma unroll
-    for (int ob = 0; ob < 2; ++ob) {
-        f32x16 a = dense64_block(W1h + ob * 2048, W1l + ob * 2048, h1, load16(net + O::b1 + (ob * 2 + h) * 16), lane);
+    {
+        f32x16 a = dense64_block<PRIOR * 3 + 0>(W1h, W1l, h1, load16(net + O::b1 + h * 16), lane);
 #pragma unroll
         for (int r = 0; r < 16; ++r) a[r] = act_tanh(a[r]);
-        split_block(a, h2[ob]);
+        split_block(a, h2[0]);
+    }
+    {
+        f32x16 a = dense64_block<PRIOR * 3 + 1>(W1h + 2048, W1l + 2048, h1, load16(net + O::b1 + (2 + h) * 16), lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[r] = act_tanh(a[r]);
+        split_block(a, h2[1]);
     }
 }
 
 // Output block (dimension d >= 1, row block kb): raw (scaled) outputs o[basis row][walker] in accumulator layout.
-template <int D, int NBK>
+template <int D, int NBK, int PRIOR = 0>
 __device__ __forceinline__ f32x16 out_block(const float* net, const Frag (&h2)[2], int d, int kb, int lane) {
     using O = NetOff<D, NBK>;
     const int h = lane >> 5;
     const _Float16* W2h = reinterpret_cast<const _Float16*>(net + O::W2h);
     const _Float16* W2l = reinterpret_cast<const _Float16*>(net + O::W2l);
     const int blk = (d - 1) * NBK + kb;
-    return dense64_block(W2h + blk * 2048, W2l + blk * 2048, h2, load16(net + O::b2 + ((d * NBK + kb) * 2 + h) * 16), lane);
+    return dense64_block<PRIOR * 3 + 2>(W2h + blk * 2048, W2l + blk * 2048, h2, load16(net + O::b2 + ((d * NBK + kb) * 2 + h) * 16), lane);
 }
 
 // The 16 table values of this lane half at x_l (a) and x_r (b) for one derivative order.
@@ -431,8 +464,11 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
                 }
                 const f32x4* comp_p = mm.comp + (size_t)mm.n_layers * mm.n_mesh;
                 Frag h2[2];
-                hidden_layers<D, NBK>(net, cur, lane, h2);   // the conditioner sees the unclipped u (wavefunctions.py:40)
+                hidden_layers<D, NBK, 1>(net, cur, lane, h2);   // the conditioner sees the unclipped u (wavefunctions.py:40)
                 float lp = 0.0f, prod = 1.0f;
+#ifdef WF_DBG_PRIOR
+                float dbg_a = 0.0f, dbg_b = 0.0f;
+#endif
 #pragma unroll
                 for (int d = 0; d < D; ++d) {
                     const float uc = fminf(fmaxf(cur[d], 0.0f), 1.0f);   // the spline sees the clipped one (:45)
@@ -448,7 +484,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
                         float s1 = 0.0f;
 #pragma unroll
                         for (int kb = 0; kb < NBK; ++kb) {
-                            o[kb] = out_block<D, NBK>(net, h2, d, kb, lane);
+                            o[kb] = out_block<D, NBK, 1>(net, h2, d, kb, lane);
                             const f32x16 keep = load16(fkP + (kb * 2 + h) * 16);
 #pragma unroll
                             for (int r = 0; r < 16; ++r) { s1 += o[kb][r]; o[kb][r] = o[kb][r] * keep[r]; }
@@ -457,6 +493,9 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
                         // c = (o * keep) @ ob_to_b on v_mfma_f32_32x32x2_f32 (unnormalised operands: no fp16 split)
                         f32x16 c[NBK];
                         float n2 = 0.0f;
+#if defined(WF_FENCE_OB2B) && (WF_FENCE_OB2B & 1)
+                        __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
                         for (int ko = 0; ko < NBK; ++ko) {
                             c[ko] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -468,12 +507,37 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
 #pragma unroll
                                     for (int e = 0; e < 4; ++e) c[ko] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], o[ki][4 * r4 + e], c[ko], 0, 0, 0);
                                 }
+#if defined(WF_FENCE_OB2B) && (WF_FENCE_OB2B & 2)
+                            __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
                             for (int r = 0; r < 16; ++r) n2 = __builtin_fmaf(c[ko][r], c[ko][r], n2);
                         }
-                        const float rnorm = __builtin_amdgcn_rsqf(xhalf_sum(n2));
-                        val = lerp_dot<NBK>(c, tl, tr, Lp.t) * rnorm;
+                        const float n2s = xhalf_sum(n2);
+                        const float rnorm = __builtin_amdgcn_rsqf(n2s);
+#if defined(WF_DBG_PRIOR) && WF_DBG_PRIOR >= 5
+                        // taps inside the numerator (NBK = 1 only)
+                        const Rows Rw = load_rows(tl, tr);
+                        float sa = 0.0f, sb = 0.0f;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) { sa = __builtin_fmaf(c[0][r], Rw.a[r], sa); sb = __builtin_fmaf(c[0][r], Rw.b[r], sb); }
+                        const float part = __builtin_fmaf(sb - sa, Lp.t, sa);
+                        const float numer = xhalf_sum(part);
+                        if (WF_DBG_PRIOR == 5) { dbg_a = part; dbg_b = Lp.t; }
+                        if (WF_DBG_PRIOR == 6) { dbg_a = sa; dbg_b = sb; }
+                        if (WF_DBG_PRIOR == 7) { dbg_a = (float)Lp.il; dbg_b = (float)Lp.ir; }
+                        if (WF_DBG_PRIOR == 8) { dbg_a = numer - part; dbg_b = Rw.a[0] + Rw.b[15]; }
+#else
+                        const float numer = lerp_dot<NBK>(c, tl, tr, Lp.t);
+#endif
+                        val = numer * rnorm;
                         val = s1 < 0.0f ? -val : val;
+#ifdef WF_DBG_PRIOR
+                        if (WF_DBG_PRIOR == 1) { dbg_a = s1; dbg_b = n2s; }
+                        if (WF_DBG_PRIOR == 2) { dbg_a = numer; dbg_b = c[0][0]; }
+                        if (WF_DBG_PRIOR == 3) { dbg_a = o[0][0]; dbg_b = o[0][15]; }
+                        if (WF_DBG_PRIOR == 4) { dbg_a = c[0][15]; dbg_b = c[0][7]; }
+#endif
                     } else {
                         // MFlow (distributions.py:139-163): M-spline table with the row factors folded in
                         f32x16 v[NBK];
@@ -501,6 +565,10 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
                 result = (wavefn && mode != 0) ? prod * __expf(0.5f * logdet) : lp + logdet;
 #pragma unroll
                 for (int d = 0; d < D; ++d) cur[d] = nxt[d];
+#ifdef WF_DBG_PRIOR
+                cur[0] = dbg_a;
+                cur[D - 1] = dbg_b;
+#endif
             } else if (mm.prior_kind == WF_PRIOR_UNIFORM) {
 #pragma unroll
                 for (int d = 0; d < D; ++d) cur[d] = fminf(fmaxf(cur[d], 0.0f), 1.0f);
