@@ -12,7 +12,7 @@ from waveflow_amd import build as B  # noqa: E402
 
 def main():
     name, flags = sys.argv[1], sys.argv[2].split()
-    units = sys.argv[3:] or ["wf_mfma_inst_d2.hip"]
+    units = sys.argv[3:] or ["wf_mfma_inst_d2.hip", "wf_mfma_inst_d2t2.hip"]
     B.build()
     out_dir = os.path.join(ROOT, "scratch", "variants")
     os.makedirs(out_dir, exist_ok=True)
@@ -21,7 +21,7 @@ def main():
         o = os.path.join(B.OBJ, s + ".o")
         if s in units:
             o = os.path.join(out_dir, f"{name}_{s}.o")
-            cmd = [B._hipcc()] + B.FLAGS + flags + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", os.path.join(B.CSRC, s), "-o", o]
+            cmd = [B._hipcc()] + B.FLAGS + (B.MFMA_FLAGS if "mfma" in s else []) + flags + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", os.path.join(B.CSRC, s), "-o", o]
             if "--save-temps" in os.environ.get("WF_VARIANT_OPTS", ""):
                 cmd += ["-save-temps=obj"]
             subprocess.run(cmd, check=True, cwd=out_dir)

@@ -26,8 +26,10 @@ ref, ref_u = m.log_pdf(x, return_sample=True)
 m.set_kernel("mfma")
 reps = int(os.environ.get("REPS", "12"))
 tag = os.path.basename(os.environ.get("WF_LIB", "default"))
-for waves in ("8", "12", "16"):
+for cfg in os.environ.get("CONFIGS", "8x1 12x1 16x1 8x2 4x2").split():
+    waves, tiles = cfg.split("x")
     os.environ["WF_MFMA_WAVES"] = waves
+    os.environ["WF_MFMA_TILES"] = tiles
     bad_total, unstable, first = 0, 0, None
     report = []
     for r in range(reps):
@@ -45,6 +47,6 @@ for waves in ("8", "12", "16"):
             du = (u - ref_u).abs()[bad].max(0).values.cpu().numpy()
             report.append(f"    launch {r}: {n} walkers in {len(tiles)} tiles; lanes-in-tile {sorted(set((w % 32).tolist()))[:40]}; "
                           f"max|du| {du}; tiles {tiles[:6].tolist()}")
-    print(f"{tag:28s} waves {waves:>2s}: bad walker-launches {bad_total:6d}  launch-to-launch differing values {unstable:6d}", flush=True)
+    print(f"{tag:28s} waves x tiles {cfg:>5s}: bad walker-launches {bad_total:6d}  launch-to-launch differing values {unstable:6d}", flush=True)
     for line in report:
         print(line, flush=True)

@@ -9,7 +9,7 @@ x = bench.walkers(B, 1234).cuda()
 for _ in range(3): m.log_pdf(x)
 dbg.zero_(); m.log_pdf(x); torch.cuda.synchronize()
 W = int(os.environ.get("WF_MFMA_WAVES", "12"))
-g = dbg.view(256, 16, 8)[:, :W].cpu().numpy().astype(np.float64)
+g = dbg[:256 * W * 8].view(256, W, 8).cpu().numpy().astype(np.float64)
 tiles_per_wave = (B // 32) / (256 * W)
 names = ["0 pre-layer (box/prev tail)", "1 hidden layers", "2 dim0 block", "3 out_block d=1 (MFMA)", "4 sigmoid block", "5 lerp d=1", "6 prior+store"]
 tot = g.sum(-1).mean()

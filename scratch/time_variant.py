@@ -24,8 +24,10 @@ B = 1 << 20
 x = torch.from_numpy(sorted_walkers(B, 2, 10.0, 99)).cuda()
 m.set_kernel("mfma")
 tag = os.path.basename(os.environ.get("WF_LIB", "default"))
-for waves in os.environ.get("WAVES", "8 12 16").split():
+for cfg in os.environ.get("CONFIGS", "8x1 12x1 16x1 8x2 4x2").split():
+    waves, tiles = cfg.split("x")
     os.environ["WF_MFMA_WAVES"] = waves
+    os.environ["WF_MFMA_TILES"] = tiles
     for _ in range(5):
         m.log_pdf(x)
     ts = []
@@ -36,4 +38,4 @@ for waves in os.environ.get("WAVES", "8 12 16").split():
         e1.record()
         torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1))
-    print(f"{tag:28s} knots {knots} waves {waves:>2s}: median {np.median(ts):.4f} ms  min {np.min(ts):.4f} ms", flush=True)
+    print(f"{tag:28s} knots {knots} waves x tiles {cfg:>5s}: median {np.median(ts):.4f} ms  min {np.min(ts):.4f} ms", flush=True)

@@ -10,12 +10,14 @@ LIB = os.path.join(HERE, "libwaveflow_hip.so")
 OBJ = os.path.join(CSRC, "_obj")
 
 SOURCES = ["wf_tables.cpp", "wf_model.cpp", "wf_kernels_scalar.hip", "wf_scalar_inst_d2.hip", "wf_scalar_inst_d3.hip", "wf_scalar_inst_d4.hip", "wf_scalar_inst_d56.hip",
-           "wf_scalar_inst_d78.hip", "wf_scalar_inst_n64.hip", "wf_kernels_mfma.hip", "wf_mfma_inst_d2.hip", "wf_mfma_inst_d34.hip",
+           "wf_scalar_inst_d78.hip", "wf_scalar_inst_n64.hip", "wf_kernels_mfma.hip", "wf_mfma_inst_d2.hip", "wf_mfma_inst_d2t2.hip", "wf_mfma_inst_d34.hip",
            "wf_mfma_inst_d567.hip", "wf_mfma_inst_d8.hip", "wf_mfma_inst_k2.hip", "wf_kernels_rqs.hip", "wf_kernels_grad.hip", "wf_kernels_wave.hip"]
 # -ffp-contract=off: the index arithmetic and the table lerp keep the reference's separate
 # multiply / add roundings; dot products that may fuse say so with explicit fmaf / MFMA.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 FLAGS += os.environ.get("WF_CXXFLAGS", "").split()  # experiment switches (-DWF_...)
+# No packed-FP32 VALU code (v_pk_fma_f32 ...) in the translation units of the MFMA kernel: wf_mfma_impl.h, DESIGN.md §9.
+MFMA_FLAGS = ["-fno-slp-vectorize"]
 
 
 def _hipcc():
@@ -43,7 +45,8 @@ def build(force=False, verbose=False):
     for s in srcs:
         o = os.path.join(OBJ, s + ".o")
         if force or not os.path.exists(o) or any(os.path.getmtime(o) < os.path.getmtime(d) for d in _deps(s)):
-            cmd = [_hipcc()] + FLAGS + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", os.path.join(CSRC, s), "-o", o]
+            cmd = [_hipcc()] + FLAGS + (MFMA_FLAGS if "mfma" in s else []) + (["-x", "hip"] if s.endswith(".cpp") else [])
+            cmd += ["-c", os.path.join(CSRC, s), "-o", o]
             jobs.append(cmd)
 
     def run(cmd):

@@ -106,13 +106,17 @@ struct MfmaDev {
     const float* tabP;         // [n_mesh][nbk][half][16] fp32, prior rows (orthogonal-B as is; M: fk_row * M_row), nd 0
     const float4_t* comp;      // [n_nets][n_mesh] composite tables of output dimension 0 (k_prepare_dim0)
     float* dbg;                // diagnostics builds only (WF_DEBUG / WF_STAMP)
+    int exact_div;             // 1: x_l / n by IEEE division (set when the multiply-and-correct form is not bit-identical for this n_mesh)
 };
+
+bool mfma_div_ok(int n_mesh);   // host check of div_by_n (wf_mfma_impl.h) against the division for every x_l in [-1, n_mesh]
 
 int launch_mfma(int D, int nbk, const MfmaDev* mdev, int lds_bytes, int mode, const float* x, int64_t B, float* out, float* u,
                 int32_t* idx, void* stream);
 bool mfma_shape_built(int D, int nbk);
 int mfma_extra_lds_floats(int n_nets);
 int dim0_coef_floats(int n_nets);
+int launch_fold_bias(float* image_dev, int n_nets, int net_floats, int D, int nbk, void* stream);
 int launch_prepare_dim0(const ModelDev* md_dev, int n_nets, int n_mesh, const float* fk_nat_dev, float F_I, float F_P, void* comp_dev,
                         void* stream);
 

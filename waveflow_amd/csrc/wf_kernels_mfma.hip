@@ -31,16 +31,19 @@
 // The table index arithmetic (floor/ceil of u * (n_mesh-1), isplines_jax.py:46-48) is kept verbatim.
 #include "wf_mfma_impl.h"
 
+#include <cmath>
+
 namespace wf {
 
 namespace mfma {
 // shapes built in wf_mfma_inst_*.hip
-#define WF_MFMA_EXTERN(DD, KK, WW) \
-    extern template int launch_dw<DD, KK, WW>(const MfmaDev*, int, int, const float*, int64_t, float*, float*, int32_t*, hipStream_t)
-WF_MFMA_EXTERN(2, 1, 8); WF_MFMA_EXTERN(2, 1, 12); WF_MFMA_EXTERN(2, 1, 16);
-WF_MFMA_EXTERN(3, 1, 8); WF_MFMA_EXTERN(4, 1, 8); WF_MFMA_EXTERN(8, 1, 8);
-WF_MFMA_EXTERN(5, 1, 8); WF_MFMA_EXTERN(6, 1, 8); WF_MFMA_EXTERN(7, 1, 8);
-WF_MFMA_EXTERN(2, 2, 8); WF_MFMA_EXTERN(3, 2, 8); WF_MFMA_EXTERN(4, 2, 8);
+#define WF_MFMA_EXTERN(DD, KK, WW, TT) \
+    extern template int launch_dw<DD, KK, WW, TT>(const MfmaDev*, int, int, const float*, int64_t, float*, float*, int32_t*, hipStream_t)
+WF_MFMA_EXTERN(2, 1, 8, 1); WF_MFMA_EXTERN(2, 1, 12, 1); WF_MFMA_EXTERN(2, 1, 16, 1);
+WF_MFMA_EXTERN(2, 1, 8, 2); WF_MFMA_EXTERN(2, 1, 4, 2);
+WF_MFMA_EXTERN(3, 1, 8, 1); WF_MFMA_EXTERN(4, 1, 8, 1); WF_MFMA_EXTERN(8, 1, 8, 1);
+WF_MFMA_EXTERN(5, 1, 8, 1); WF_MFMA_EXTERN(6, 1, 8, 1); WF_MFMA_EXTERN(7, 1, 8, 1);
+WF_MFMA_EXTERN(2, 2, 8, 1); WF_MFMA_EXTERN(3, 2, 8, 1); WF_MFMA_EXTERN(4, 2, 8, 1);
 #undef WF_MFMA_EXTERN
 }  // namespace mfma
 
@@ -138,16 +141,84 @@ __global__ void k_prepare_dim0(const ModelDev* __restrict__ mdp, int nm, const f
     comp[gid] = out;
 }
 
-int waves_per_group() {
-    const char* e = getenv("WF_MFMA_WAVES");  // tuning knob (read at every launch): 8, 12 or 16 waves per workgroup
+// tuning knobs of the headline shape (read at every launch): WF_MFMA_WAVES = 4, 8, 12 or 16 waves per workgroup,
+// WF_MFMA_TILES = 1 or 2 tiles of 32 walkers per wave (built: 8 / 12 / 16 waves x 1 tile, 4 / 8 waves x 2 tiles)
+// b' = b + sum_k W_k for the layers whose input is a tanh (see act_split_block): the packed weights already hold -2 c W as fp16
+// pairs in MFMA A-operand order, so the column sum is -0.5 * sum over the 64 k's of (hi + lo).  One thread per bias entry, fixed
+// summation order (deterministic); runs after k_pack at every parameter upload.  Padding rows have zero weights: unchanged.
+__global__ void k_fold_bias(float* __restrict__ image, int net_floats, int D, int nbk) {
+    const int S0 = (D + 1) / 2;
+    const int W1h = 128 * S0 + 64, b1 = W1h + 4096, W2h = b1 + 64;
+    const int n_out_blocks = (D - 1) * nbk;
+    const int b2 = W2h + n_out_blocks * 2048;
+    float* net = image + (size_t)blockIdx.x * net_floats;
+    const int n_entries = 64 + n_out_blocks * 32;
+    for (int e = threadIdx.x; e < n_entries; e += blockDim.x) {
+        const _Float16* halves;
+        int n_pairs, blk, bias_at;
+        int h, r;
+        if (e < 64) {   // hidden layer 2: bias entry (ob, h, r)
+            const int ob = e >> 5;
+            h = (e >> 4) & 1; r = e & 15;
+            halves = reinterpret_cast<const _Float16*>(net + W1h);
+            n_pairs = 4096; blk = ob; bias_at = b1 + e;
+        } else {        // output layer, dimension d >= 1, row block kb
+            const int q = e - 64, ob = q >> 5;
+            h = (q >> 4) & 1; r = q & 15;
+            const int d = 1 + ob / nbk, kb = ob % nbk;
+            halves = reinterpret_cast<const _Float16*>(net + W2h);
+            n_pairs = n_out_blocks * 2048; blk = ob; bias_at = b2 + ((d * nbk + kb) * 2 + h) * 16 + r;
+        }
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;   // unit / basis row inside the 32-row block (accumulator order)
+        float sum = 0.0f;
+        for (int ts = 0; ts < 4; ++ts)
+            for (int hh = 0; hh < 2; ++hh)
+                for (int j = 0; j < 8; ++j) {
+                    const int idx = ((blk * 4 + ts) * 64 + row + 32 * hh) * 8 + j;
+                    sum += (float)halves[idx] + (float)halves[n_pairs + idx];
+                }
+        net[bias_at] += -0.5f * sum;
+    }
+}
+
+int waves_per_group(int tiles) {
+    const char* e = getenv("WF_MFMA_WAVES");
     const int v = e ? atoi(e) : 0;
+    if (tiles == 2) return (v == 4 || v == 8) ? v : 8;
     return (v == 8 || v == 12 || v == 16) ? v : 16;
+}
+int tiles_per_wave() {
+    const char* e = getenv("WF_MFMA_TILES");
+    const int v = e ? atoi(e) : 0;
+    return (v == 1 || v == 2) ? v : 1;
 }
 
 }  // namespace
 
 int mfma_extra_lds_floats(int) { return 0; }
+
+// div_by_n of wf_mfma_impl.h, restated on the host: is q = fma(fma(-x*rn, n, x), rn, x*rn) the correctly rounded x / n for every
+// integer x the bin-index arithmetic can produce?
+bool mfma_div_ok(int n_mesh) {
+    const float n = (float)(n_mesh - 1), rn = 1.0f / n;
+    for (int x = -1; x <= n_mesh; ++x) {
+        const float xf = (float)x, q = xf * rn;
+        const float r = fmaf(-q, n, xf);
+        if (fmaf(r, rn, q) != xf / n) return false;
+    }
+    return true;
+}
 int dim0_coef_floats(int n_nets) { return n_nets * kCoefStride; }
+
+int launch_fold_bias(float* image_dev, int n_nets, int net_floats, int D, int nbk, void* stream) {
+    hipLaunchKernelGGL(k_fold_bias, dim3(n_nets), dim3(128), 0, (hipStream_t)stream, image_dev, net_floats, D, nbk);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_hip_error((int)e);
+        return WF_ERR_HIP;
+    }
+    return WF_OK;
+}
 
 int launch_prepare_dim0(const ModelDev* md_dev, int n_nets, int n_mesh, const float* fk_nat_dev, float F_I, float F_P, void* comp_dev,
                         void* stream) {
@@ -169,9 +240,13 @@ int launch_prepare_dim0(const ModelDev* md_dev, int n_nets, int n_mesh, const fl
 int launch_mfma(int D, int nbk, const MfmaDev* mdev, int lds_bytes, int mode, const float* x, int64_t B, float* out, float* u, int32_t* idx,
                 void* stream) {
     hipStream_t s = (hipStream_t)stream;
-#define GO(DD, KK, WW) return launch_dw<DD, KK, WW>(mdev, lds_bytes, mode, x, B, out, u, idx, s)
-    if (D == 2 && nbk == 1) {   // the headline shape: all three workgroup sizes are built (tuning / reproducibility test)
-        switch (waves_per_group()) {
+#define GO(DD, KK, WW) return launch_dw<DD, KK, WW, 1>(mdev, lds_bytes, mode, x, B, out, u, idx, s)
+    if (D == 2 && nbk == 1) {   // the headline shape: several workgroup shapes are built (tuning / reproducibility test)
+        if (tiles_per_wave() == 2) {
+            if (waves_per_group(2) == 4) return launch_dw<2, 1, 4, 2>(mdev, lds_bytes, mode, x, B, out, u, idx, s);
+            return launch_dw<2, 1, 8, 2>(mdev, lds_bytes, mode, x, B, out, u, idx, s);
+        }
+        switch (waves_per_group(1)) {
             case 8: GO(2, 1, 8);
             case 12: GO(2, 1, 12);
             default: GO(2, 1, 16);

@@ -3,8 +3,8 @@
 
 namespace wf {
 namespace mfma {
-template int launch_dw<2, 1, 8>(const MfmaDev*, int, int, const float*, int64_t, float*, float*, int32_t*, hipStream_t);
-template int launch_dw<2, 1, 12>(const MfmaDev*, int, int, const float*, int64_t, float*, float*, int32_t*, hipStream_t);
-template int launch_dw<2, 1, 16>(const MfmaDev*, int, int, const float*, int64_t, float*, float*, int32_t*, hipStream_t);
+template int launch_dw<2, 1, 8, 1>(const MfmaDev*, int, int, const float*, int64_t, float*, float*, int32_t*, hipStream_t);
+template int launch_dw<2, 1, 12, 1>(const MfmaDev*, int, int, const float*, int64_t, float*, float*, int32_t*, hipStream_t);
+template int launch_dw<2, 1, 16, 1>(const MfmaDev*, int, int, const float*, int64_t, float*, float*, int32_t*, hipStream_t);
 }  // namespace mfma
 }  // namespace wf

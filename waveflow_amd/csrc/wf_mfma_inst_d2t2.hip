@@ -1,0 +1,10 @@
+// explicit instantiations of the MFMA kernel (wf_mfma_impl.h): compiled as a separate translation unit
+// two tiles per wave
+#include "wf_mfma_impl.h"
+
+namespace wf {
+namespace mfma {
+template int launch_dw<2, 1, 8, 2>(const MfmaDev*, int, int, const float*, int64_t, float*, float*, int32_t*, hipStream_t);
+template int launch_dw<2, 1, 4, 2>(const MfmaDev*, int, int, const float*, int64_t, float*, float*, int32_t*, hipStream_t);
+}  // namespace mfma
+}  // namespace wf

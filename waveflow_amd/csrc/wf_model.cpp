@@ -558,7 +558,9 @@ static void describe_mfma_image(const wf_model* m, int n, uint32_t base, std::ve
     const int S0 = (D + 1) / 2;
     const NetLayout& nl = m->nets[n];
     const NetOffsets q = net_offsets(m, n);
-    // folded activation scales: tanh(x) = 1 - 2/(2^(c1 x) + 1), sigmoid(x) = 1/(1 + 2^(c2 x))
+    // folded activation scales: tanh(x) = 1 - 2/(2^(c1 x) + 1), sigmoid(x) = 1/(1 + 2^(c2 x)).  The kernel feeds the layers behind a
+    // tanh with r = 1/(2^(c1 x) + 1) instead of tanh = 1 - 2r: their weights carry the factor -2 here, their biases get the column
+    // sums of the weights from k_fold_bias (wf_kernels_mfma.hip) after every k_pack.
     const double c1 = 2.0 * 1.4426950408889634074;
     const bool sig = net_has_sigmoid_head(m, n);
     const double c2 = sig ? -1.4426950408889634074 : 1.0;
@@ -586,7 +588,7 @@ static void describe_mfma_image(const wf_model* m, int n, uint32_t base, std::ve
     f16_block(4096, [&](uint32_t e) {
         const int j = e & 7, lane = (e >> 3) & 63, s_ = (e >> 9) & 1, t = (e >> 10) & 1, ob = (e >> 11) & 1;
         const int unit = 32 * ob + (lane & 31), kk = 32 * t + acc_row(8 * s_ + j, lane >> 5);
-        return std::make_pair(deg_hidden(unit, D) >= deg_hidden(kk, D) ? q.W1 + (int64_t)kk * H + unit : (int64_t)-1, c1);
+        return std::make_pair(deg_hidden(unit, D) >= deg_hidden(kk, D) ? q.W1 + (int64_t)kk * H + unit : (int64_t)-1, -2.0 * c1);
     });
     for (int ob = 0; ob < 2; ++ob)
         for (int h = 0; h < 2; ++h)
@@ -597,7 +599,7 @@ static void describe_mfma_image(const wf_model* m, int n, uint32_t base, std::ve
         const int blk = e >> 11, kb = blk % nbk, d = 1 + blk / nbk;
         const int jb = 32 * kb + (lane & 31), kk = 32 * t + acc_row(8 * s_ + j, lane >> 5);
         const bool live = jb < nl.n_out && deg_out(d) >= deg_hidden(kk, D);
-        return std::make_pair(live ? q.W2 + (int64_t)kk * q.NO + (jb * D + d) : (int64_t)-1, c2);
+        return std::make_pair(live ? q.W2 + (int64_t)kk * q.NO + (jb * D + d) : (int64_t)-1, -2.0 * c2);
     });
     // biases; padding rows of sigmoid heads get +1e30 so that sigmoid(-x) -> 0 exactly
     for (int d = 0; d < D; ++d)
@@ -638,6 +640,7 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
     md.box_L = d.box_size; md.i_reg = d.i_reg; md.normal_offset = d.normal_offset; md.constrained_mask = m->dev.constrained_mask;
     md.i_nb = m->i_nb; md.p_nb = m->p_nb; md.n_mesh = d.n_mesh; md.nbk = nbk;
     md.n_nets = n_nets; md.net_floats = net_floats; md.const_img_off = net_floats * n_nets; md.const_floats = consts; md.staged = staged;
+    md.exact_div = mfma_div_ok(md.n_mesh) ? 0 : 1;
     m->mfma_lds_floats = consts + (staged ? net_floats : net_floats * n_nets);
 
     m->mfma_consts.assign(consts, 0.0f);
@@ -903,6 +906,9 @@ static int apply_params(wf_model* m, const float* flat_dev, void* stream, bool e
         if (rc) return rc;
     }
     if (m->mfma_ok && eval_tables) {
+        // biases of the layers behind a tanh: + column sums of their weights (the kernel's activations are r, tanh = 1 - 2r)
+        int rc0 = launch_fold_bias(m->d_mfma, (int)m->nets.size(), m->mdev.net_floats, m->desc.n_dim, m->mdev.nbk, stream);
+        if (rc0) return rc0;
         // composite tables of output dimension 0 (reads the plain image filled above)
         int rc = launch_prepare_dim0(m->d_dev, (int)m->nets.size(), m->desc.n_mesh, m->d_fk_nat, m->mdev.F_I, m->mdev.F_P, m->d_comp, stream);
         if (rc) return rc;
