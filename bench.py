@@ -23,17 +23,17 @@ sys.path.insert(0, ROOT)
 FLOP_PER_EVAL = 63232          # dense conditioner: 3 x 15872 + 15616
 BYTES_PER_EVAL = 12            # 2 x fp32 in + 1 x fp32 out
 PEAK_F32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak
+PEAK_F16_MATRIX_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16 / bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0
-# HBM bytes per log_pdf launch of 2^20 walkers from the PMC passes of the same command (separate rocprofv3 --pmc runs,
-# profiles/r01f_pmc_summary.txt, previously r01c: 10233 + 13312): FETCH_SIZE 10791 KB + WRITE_SIZE 14336 KB.  The walker read is 8 B/lane (not the
-# 16 B/lane stream the guide's x2 FETCH_SIZE correction was calibrated on; an earlier build without table gathers from
-# HBM reported exactly the 8.39 MB of coordinates), so no correction is applied.  Algorithmic bytes: 12 B x 2^20 =
-# 12.6 MB; the excess is register-spill scratch (13 VGPRs at 16 waves per workgroup) and first-touch table rows.
-PMC_TRAFFIC_BYTES_2POW20 = (10791 + 14336) * 1024
-# executed matrix-core work per eval (He): per 32-walker tile 156 v_mfma_f32_32x32x16_f16 + 12 v_mfma_f32_32x32x2_f32
-MFMA_FLOP_PER_EVAL = (156 * 32768 + 12 * 4096) / 32
-PEAK_F16_MATRIX_TFLOPS = 2500.0
-PEAK_F32_VIA_F16_SPLIT_TFLOPS = PEAK_F16_MATRIX_TFLOPS / 3.0   # three f16 MFMA products per fp32-equivalent multiply-add
+# Executed matrix-core work per eval (He, 23 knots): per 32-walker tile and net 36 v_mfma_f32_32x32x16_f16 (two hidden blocks and one
+# output block of 12 each: 3 split products x 4 K steps; dimension 0 is table-driven and issues none), x 4 nets = 144 of 32768 FLOP,
+# plus 24 v_mfma_f32_32x32x2_f32 of 4096 FLOP (input layer 2 per net, ob_to_b product of the prior 16).
+MFMA_F16_PER_TILE, MFMA_F32_PER_TILE = 144, 24
+MFMA_FLOP_PER_EVAL = (MFMA_F16_PER_TILE * 32768 + MFMA_F32_PER_TILE * 4096) / 32
+# HBM bytes of one 2^20-walker log_pdf launch from the PMC passes of this command (separate rocprofv3 --pmc runs, scratch/pmc.sh):
+# FETCH_SIZE 8893 KB + WRITE_SIZE 4096 KB.  The walker read is 8 B per lane, not the 16 B-per-lane stream the guide's x2 FETCH_SIZE
+# correction is calibrated on (the sum already equals the 12.6 MB of algorithmic bytes), so no correction is applied.
+PMC_TRAFFIC = {"bytes": (8893 + 4096) * 1024, "source": "profiles/r02b_pmc_summary.txt"}
 # reverse sweep of one walker, He, in the (value, gradient, Laplacian) algebra RF<2> = 4 channels: per net 2 dense 64x64 products
 # (+ the 32x32 change of basis of the prior, forward and transposed, for 2 dimensions), FMA = 2 FLOP
 VQMC_BWD_FLOP_PER_WALKER = 2 * (4 * 2 * 64 * 64 * 4 + 2 * 2 * 32 * 32 * 4)
@@ -51,6 +51,78 @@ def he_model(kernel):
     model.set_params(flat)
     model.set_kernel(kernel)
     return model, flat
+
+
+def seeded_model(D, knots, kernel="auto"):
+    """Waveflow model with this build's seeded initial parameters (configs without a shipped checkpoint: SURVEY 8d C3 variant, C4)."""
+    from waveflow_amd import model_factory
+    init_fun = model_factory.get_waveflow_model(D, base_spline_degree=6, i_spline_degree=6, n_prior_internal_knots=knots,
+                                                n_i_internal_knots=knots, i_spline_reg=0.05, n_flow_layers=3, box_size=10, xu_coord_type="mean")
+    params, psi, log_pdf, _ = init_fun(0, D)
+    model = log_pdf.model
+    model.ensure_params(params)
+    model.set_kernel(kernel)
+    return model
+
+
+def sorted_uniform(B, D, seed):
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.rand(B, D, generator=g) * 2 - 1) * 10.0
+    return torch.sort(x, dim=-1).values.contiguous()
+
+
+def kernel_ms(model, x, n=20, warm=5):
+    """Mean HIP-event time of wf_logpdf_fwd on the current stream."""
+    import torch
+    for _ in range(warm):
+        model.log_pdf(x)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for a, b in ev:
+        a.record()
+        model.log_pdf(x)
+        b.record()
+    torch.cuda.synchronize()
+    return float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+
+def extra_legs(model, flat):
+    """The other measurement legs of SURVEY 8d, in the same run (rank 0, N = 1): every figure is a HIP-event kernel time."""
+    import torch
+    out = {}
+    # C3 "32-bin" variant: 33 internal knots = 32 intervals (39 / 38 bases: two 32-row blocks per dimension), seeded parameters
+    m33 = seeded_model(2, 33, "mfma")
+    x = sorted_uniform(1 << 20, 2, 1234).cuda()
+    ms = kernel_ms(m33, x)
+    out["variant_33knot"] = {"evals_per_s": (1 << 20) / (ms * 1e-3), "kernel_ms": ms, "kernel": "k_mfma<2,2,8,1>",
+                             "workload": "He, 33 knots (32 intervals), 2^20 walkers, seeded parameters"}
+    del m33
+    # C2: the reference's batch size, one call (shipped checkpoint); AUTO routes it to the wave kernel
+    model.set_kernel("auto")
+    x256 = sorted_uniform(256, 2, 99).cuda()
+    out["c2_batch256_us"] = kernel_ms(model, x256, n=200, warm=20) * 1e3
+    # C4: 8-electron chain, 2^18 walkers, seeded parameters
+    m8 = seeded_model(8, 23, "mfma")
+    x8 = sorted_uniform(1 << 18, 8, 1234).cuda()
+    ms8 = kernel_ms(m8, x8, n=10, warm=3)
+    out["c4_d8_2pow18"] = {"evals_per_s": (1 << 18) / (ms8 * 1e-3), "kernel_ms": ms8, "kernel": "k_mfma<8,1,8,1>"}
+    del m8
+    torch.cuda.synchronize()
+    return out
+
+
+def cpu_baseline_1thread(flat, x_host, budget_s=5.0):
+    import oracle
+    om = oracle.he_model(10.0)
+    n0 = 2048
+    t = time.perf_counter()
+    om.log_pdf(flat, x_host[:n0], threads=1)
+    dt = time.perf_counter() - t
+    n = int(min(x_host.shape[0], max(n0, n0 * budget_s / max(dt, 1e-6))))
+    t = time.perf_counter()
+    om.log_pdf(flat, x_host[:n], threads=1)
+    dt = time.perf_counter() - t
+    return {"value": n / dt, "unit": "evals/s", "cores": 1, "kind": "port", "sample": f"first {n} walkers, one thread, {dt:.1f} s"}
 
 
 def walkers(B, seed):
@@ -72,7 +144,7 @@ def host_cores():
     return max(1, n)
 
 
-def cpu_baseline(flat, x_host, budget_s=12.0):
+def cpu_baseline(flat, x_host, budget_s=10.0):
     """The oracle (port of the reference algorithm) on the host cores, on a bounded sample of the same walkers."""
     import oracle
     cores = host_cores()
@@ -104,6 +176,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1 << 20, help="walkers per GPU")
     ap.add_argument("--kernel", default="auto", choices=["auto", "scalar", "mfma", "wave"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary legs (33-knot variant, batch 256, D = 8, 1-thread CPU)")
     ap.add_argument("--workload", default="he_logpdf", choices=["he_logpdf", "rqs", "vqmc"],
                     help="he_logpdf: the BASELINE metric (default).  rqs: the RQS bijector kernel alone (SURVEY row a12), an "
                          "HBM-bound elementwise op: 2 dims x `--batch` walkers, 32 bins")
@@ -201,6 +274,9 @@ def main():
         evals = B * world * args.steps
         value = evals / dt
         k_evals_s = B / (kern_ms * 1e-3)
+        waves = os.environ.get("WF_MFMA_WAVES", "16")
+        tiles = os.environ.get("WF_MFMA_TILES", "1")
+        mfma_tflops = k_evals_s * MFMA_FLOP_PER_EVAL / 1e12
         out = {
             "metric": "flow log-prob evals/sec", "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -209,24 +285,32 @@ def main():
                                    f"log_pdf over {B} sorted U(-L,L)^2 walkers per GPU, + fp64 block sums"
                                    + (" + 1 RCCL all-reduce of 3 doubles per step (overlapped with the next step's kernel)" if world > 1 else ""),
                        "walkers_per_gpu": B, "kernel": args.kernel, "mean_logp": mean_logp},
-            "roofline": {"bound": "mfma", "achieved": k_evals_s * FLOP_PER_EVAL / 1e12, "peak": PEAK_F32_VIA_F16_SPLIT_TFLOPS,
-                         "unit": "TFLOP/s", "frac": k_evals_s * FLOP_PER_EVAL / 1e12 / PEAK_F32_VIA_F16_SPLIT_TFLOPS,
-                         "traffic": PMC_TRAFFIC_BYTES_2POW20 if B == (1 << 20) else None,
-                         "kernel": {"scalar": "k_eval<2,32>", "wave": "k_wave_fwd<2,R1>"}.get(args.kernel, "k_mfma<2,1,16>"), "kernel_ms": kern_ms,
-                         "flop_per_eval": FLOP_PER_EVAL,
-                         "frac_of_native_f32_mfma_peak": k_evals_s * FLOP_PER_EVAL / 1e12 / PEAK_F32_MATRIX_TFLOPS,
-                         "note": "achieved = algorithmic fp32 conditioner FLOP (SURVEY 8d) / kernel time.  The path computes fp32-accurate "
-                                 "products on the f16 matrix cores as 3 MFMA products of 2-way split operands (fp32 accumulate, "
-                                 "fp32-level error, DESIGN.md 4.1), so peak = dense f16 MFMA peak / 3 = 833 TFLOP/s of fp32-equivalent "
-                                 "work; against the native f32-input MFMA peak (157.3 TFLOP/s = the f32 vector peak) the same figure is "
-                                 "`frac_of_native_f32_mfma_peak` and exceeds 1.  Executed matrix work: `mfma_f16`."},
-            "mfma_f16": {"achieved": k_evals_s * MFMA_FLOP_PER_EVAL / 1e12, "peak": PEAK_F16_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                         "frac": k_evals_s * MFMA_FLOP_PER_EVAL / 1e12 / PEAK_F16_MATRIX_TFLOPS, "flop_per_eval": MFMA_FLOP_PER_EVAL},
+            # bound = the matrix cores: achieved = EXECUTED f16 / f32 MFMA FLOP per second of the dominant kernel, peak = the dense f16
+            # MFMA peak of the guide.  The algorithmic fp32 figures of SURVEY 8d are the labelled extras.
+            "roofline": {"bound": "mfma", "achieved": mfma_tflops, "peak": PEAK_F16_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                         "frac": mfma_tflops / PEAK_F16_MATRIX_TFLOPS,
+                         "traffic": PMC_TRAFFIC["bytes"] if (B == (1 << 20) and args.kernel in ("auto", "mfma")) else None,
+                         "traffic_source": PMC_TRAFFIC["source"] if (B == (1 << 20) and args.kernel in ("auto", "mfma")) else None,
+                         "kernel": {"scalar": "k_eval<2,32>", "wave": "k_wave_fwd<2,R1>"}.get(args.kernel, f"k_mfma<2,1,{waves},{tiles}>"),
+                         "kernel_ms": kern_ms, "executed_mfma_flop_per_eval": MFMA_FLOP_PER_EVAL,
+                         "algorithmic_flop_per_eval": FLOP_PER_EVAL, "algorithmic_tflops": k_evals_s * FLOP_PER_EVAL / 1e12,
+                         "algorithmic_frac_of_f32_matrix_peak": k_evals_s * FLOP_PER_EVAL / 1e12 / PEAK_F32_MATRIX_TFLOPS,
+                         "note": "achieved = executed matrix FLOP (144 v_mfma_f32_32x32x16_f16 + 24 v_mfma_f32_32x32x2_f32 per 32-walker tile; "
+                                 "fp32-accurate products are three f16 MFMA products of 2-way split operands) / mean HIP-event kernel time; "
+                                 "peak = dense f16 MFMA.  The kernel is bound by vector issue (activations, splines), not by the matrix "
+                                 "cores: DESIGN.md 4.1.  algorithmic_* = SURVEY 8d's 63 232 FLOP per eval against the f32 matrix peak."},
             "hbm": {"achieved": k_evals_s * BYTES_PER_EVAL / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": k_evals_s * BYTES_PER_EVAL / 1e9 / PEAK_HBM_GBS, "bytes_per_eval": BYTES_PER_EVAL},
         }
+        if use_dist:
+            out["rccl_ranks"] = dist.get_world_size()
+            out["dist_backend"] = dist.get_backend()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(flat, x_host.numpy())
+            if not args.no_extras:
+                out["cpu_baseline_1thread"] = cpu_baseline_1thread(flat, x_host.numpy())
+        if world == 1 and not args.no_extras and args.kernel in ("auto", "mfma"):
+            out.update(extra_legs(model, flat))
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()

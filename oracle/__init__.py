@@ -65,6 +65,9 @@ def lib(f64=False):
     L.wfo_eval.restype = ctypes.c_int
     L.wfo_eval.argtypes = [ctypes.POINTER(_Model), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    L.wfo_eval_cond.restype = ctypes.c_int
+    L.wfo_eval_cond.argtypes = [ctypes.POINTER(_Model), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
+                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
     L.wfo_imade_direct.restype = ctypes.c_int
     L.wfo_imade_direct.argtypes = [ctypes.POINTER(_Model), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
@@ -281,6 +284,21 @@ class Model:
         if return_idx:
             res.append(idx)
         return res[0] if len(res) == 1 else tuple(res)
+
+    def log_pdf_cond(self, params, x, threads=1, f64=False):
+        """-> (log_pdf, cond, cond2): cond[b] = the smallest spline derivative dy of any layer / dimension and the smallest
+        per-dimension prior factor (psi_d^2, or the M-spline density) of walker b (log_pdf sums log(. + 1e-7) of these);
+        cond2[b] = the smallest |sum o| / sum |o| of the Waveflow prior head (the reference divides its signed outputs by their sum).
+        A relative tolerance on log_pdf is meaningful where both are well away from 0."""
+        params = np.ascontiguousarray(params, dtype=np.float32)
+        x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1, self.D)
+        B = x.shape[0]
+        out, cond, cond2 = np.zeros(B, np.float32), np.zeros(B, np.float32), np.zeros(B, np.float32)
+        rc = lib(f64).wfo_eval_cond(ctypes.byref(self.c), params.ctypes.data, x.ctypes.data, B, 0, out.ctypes.data, cond.ctypes.data,
+                                    cond2.ctypes.data, threads)
+        if rc:
+            raise RuntimeError(f"wfo_eval_cond rc={rc}")
+        return out, cond, cond2
 
     def log_pdf(self, params, x, return_u=False, return_idx=False, threads=1, f64=False):
         """f64=True: same algorithm, tables and parameters, fp64 arithmetic (result rounded to fp32)."""

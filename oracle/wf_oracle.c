@@ -358,6 +358,16 @@ static const float* conditioner(const float* p, int D, int H, int n_out, const r
     return b2 + NO;
 }
 
+/* Conditioning probes (test infrastructure only).  When set, for the walker being evaluated:
+ *   g_cond   the smallest spline derivative dy of any layer / dimension and the smallest per-dimension prior factor (psi_d^2 or the
+ *            M-spline density): log_pdf sums log(. + 1e-7) of these;
+ *   g_cond2  the smallest |sum_j o_j| / sum_j |o_j| of the Waveflow prior head, whose raw (signed) outputs the reference divides by
+ *            their sum (model_factory.py:69): in fp32 that quotient loses all accuracy as the sum passes through zero.
+ * A relative tolerance on log_pdf is meaningful only where both stay away from 0. */
+static __thread real* g_cond = 0;
+static __thread real* g_cond2 = 0;
+static inline void cond_note(real v) { if (g_cond && v < *g_cond) *g_cond = v; }
+
 /* calculate_bijection_params, model_factory.py:56-70 (set_nn_output_grad_to_zero=False):
  * bij[d][j] = o[j*D + d]; optional sigmoid; bij /= bij.sum(-1).  Returns pointer past (net, zero_params). */
 static const float* bijection_params(const float* p, int D, int H, int nb, int allow_negative, const real* x,
@@ -365,13 +375,15 @@ static const float* bijection_params(const float* p, int D, int H, int nb, int a
     real o[WFO_MAX_D * WFO_MAX_NB];
     const float* next = conditioner(p, D, H, nb, x, o);
     for (int d = 0; d < D; ++d) {
-        real ss = C(0.0);
+        real ss = C(0.0), sa = C(0.0);
         for (int j = 0; j < nb; ++j) {
             real v = o[j * D + d];
             if (!allow_negative) v = C(1.0) / (C(1.0) + R_EXP(-v));     /* jax.nn.sigmoid */
             bij[d * nb + j] = v;
             ss = ss + v;
+            sa = sa + (v < 0 ? -v : v);
         }
+        if (g_cond2 && allow_negative) { real q = (ss < 0 ? -ss : ss) / sa; if (q < *g_cond2) *g_cond2 = q; }
         for (int j = 0; j < nb; ++j) bij[d * nb + j] = bij[d * nb + j] / ss;
     }
     return next + D * nb;  /* skip zero_params[D][nb] */
@@ -390,6 +402,7 @@ static const float* imade_direct(const wfo_model* m, const float* p, const real*
         enforce_bc(&m->isp, m->isp.tab, 1, w);
         y[d] = spline_apply(&m->isp, 0, w, x[d], idx ? idx + 2 * d : 0);
         real dy = spline_apply(&m->isp, 1, w, x[d], 0);  /* grad via defjvp -> table nd+1, isplines_jax.py:60-66 */
+        cond_note(dy);
         ld = ld + R_LOG(dy + C(1e-7));
     }
     *logdet = ld;
@@ -494,6 +507,7 @@ static real eval_one(const wfo_model* m, const float* params, const float* xin, 
             real nrm = R_SQRT(ss);
             for (int j = 0; j < nb; ++j) c[j] = c[j] / nrm;
             real v = spline_apply(&m->psp, 0, c, u[d], pidx ? pidx + 2 * d : 0);
+            cond_note(v * v);
             int constrained = 0;
             for (int q = 0; q < m->n_constr_left; ++q) if (m->constr_left[q] == d) constrained = 1;
             if (mode == 0) {
@@ -519,6 +533,7 @@ static real eval_one(const wfo_model* m, const float* params, const float* xin, 
             enforce_bc(&m->psp, m->psp.tab, 0, w);
             u[d] = clip01(u[d]);
             real v = spline_apply(&m->psp, 0, w, u[d], pidx ? pidx + 2 * d : 0);
+            cond_note(v);
             lp = lp + R_LOG(v + C(1e-7));
         }
         result = lp + logdet;
@@ -555,6 +570,27 @@ int wfo_eval(const wfo_model* m, const float* params, const float* x, int64_t B,
         if (idx_out && m->n_layers <= 8) { idx = idx_local; memset(idx, 0, sizeof(idx_local)); }
         out[b] = (float)eval_one(m, params, x + b * D, mode, u_out ? u_out + b * D : 0, idx);
         if (idx) for (size_t q = 0; q < istride; ++q) idx_out[b * istride + q] = idx[q];
+    }
+    return 0;
+}
+
+/* wfo_eval plus cond_out[B]: the conditioning probe of each walker (see g_cond). */
+int wfo_eval_cond(const wfo_model* m, const float* params, const float* x, int64_t B, int mode, float* out, float* cond_out,
+                  float* cond2_out, int threads) {
+    if (m->D > WFO_MAX_D || m->D < 2 || m->hidden > WFO_MAX_H) return -1;
+    if (m->layer_kind == 0 && m->isp.nb > WFO_MAX_NB) return -1;
+    if (mode == 1 && m->prior_kind != 0) return -2;
+    int D = m->D;
+#pragma omp parallel for schedule(static) num_threads(threads > 1 ? threads : 1)
+    for (int64_t b = 0; b < B; ++b) {
+        real c = C(1e30), c2 = C(1.0);
+        g_cond = &c;
+        g_cond2 = &c2;
+        out[b] = (float)eval_one(m, params, x + b * D, mode, 0, 0);
+        g_cond = 0;
+        g_cond2 = 0;
+        cond_out[b] = (float)c;
+        cond2_out[b] = (float)c2;
     }
     return 0;
 }

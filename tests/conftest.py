@@ -18,10 +18,10 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session", autouse=True)
 def _native_library():
-    """A fresh checkout has no libwaveflow_hip.so (built files are git-ignored): cross-compile it once (hipcc needs no GPU)."""
+    """Built files are git-ignored but travel to the GPU box: always run the (incremental, mtime + flag aware) build so that the
+    suite never runs against a library older than the checked-in sources.  hipcc cross-compiles without a GPU."""
     from waveflow_amd import build as wf_build
-    if not os.path.exists(wf_build.LIB):
-        wf_build.build()
+    wf_build.build()
 
 
 @pytest.fixture(scope="session")

@@ -38,8 +38,34 @@ def _deps(src):
     return [p for p in d if os.path.exists(p)]
 
 
+STAMP = os.path.join(HERE, "libwaveflow_hip.flags")   # next to the library (it travels with it; csrc/_obj does not)
+
+
+def _flags_text():
+    return " ".join(FLAGS) + " | " + " ".join(MFMA_FLAGS)
+
+
+def _library_current():
+    """The library is newer than every source / header and was built with the current flags."""
+    try:
+        if open(STAMP).read() != _flags_text():
+            return False
+        t = os.path.getmtime(LIB)
+    except OSError:
+        return False
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".h"))]
+    deps.append(os.path.join(HERE, "..", "include", "waveflow_hip.h"))
+    return all(os.path.getmtime(d) <= t for d in deps if os.path.exists(d))
+
+
 def build(force=False, verbose=False):
+    if not force and _library_current():
+        return LIB
     os.makedirs(OBJ, exist_ok=True)
+    try:
+        force = force or open(STAMP).read() != _flags_text()   # changed flags (FLAGS / WF_CXXFLAGS / MFMA_FLAGS): everything again
+    except OSError:
+        force = True
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     jobs = []
     for s in srcs:
@@ -63,6 +89,8 @@ def build(force=False, verbose=False):
     objs = [os.path.join(OBJ, s + ".o") for s in srcs]
     if jobs or force or not os.path.exists(LIB) or any(os.path.getmtime(LIB) < os.path.getmtime(o) for o in objs):
         run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    with open(STAMP, "w") as f:
+        f.write(_flags_text())
     return LIB
 
 

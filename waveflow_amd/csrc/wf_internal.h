@@ -99,7 +99,7 @@ struct MfmaDev {
     const float* image;        // global image: n_nets net images (net_floats each), then the constants block
     int n_nets, net_floats;
     int const_img_off;         // float offset of the constants block inside the image
-    int const_floats;          // fkI[nbk][2][16], fkP[nbk][2][16], ob_to_b image [nbk][nbk][4][64][4]
+    int const_floats;          // fkI[nbk][2][16], fkP[nbk][2][16], ob_to_b image [nbk][nbk]{hi, lo}[2 K steps][64 lanes][8 halves]
     int staged;                // 0: every net resident in LDS; 1: one LDS slot, nets re-staged per chunk of tiles
     const float* tabI;         // [n_mesh][nd 0..1][nbk][half][16] fp32: fk_row * I_row, accumulator row order
     const float* rsI;          // [n_mesh][nd 0..1]: sum over rows of tabI
@@ -107,6 +107,7 @@ struct MfmaDev {
     const float4_t* comp;      // [n_nets][n_mesh] composite tables of output dimension 0 (k_prepare_dim0)
     float* dbg;                // diagnostics builds only (WF_DEBUG / WF_STAMP)
     int exact_div;             // 1: x_l / n by IEEE division (set when the multiply-and-correct form is not bit-identical for this n_mesh)
+    int prior_quotient;        // debug (env WF_PRIOR_QUOTIENT=1 at model creation): Waveflow prior head in the reference's quotient form
 };
 
 bool mfma_div_ok(int n_mesh);   // host check of div_by_n (wf_mfma_impl.h) against the division for every x_l in [-1, n_mesh]

@@ -211,6 +211,7 @@ bool mfma_div_ok(int n_mesh) {
 int dim0_coef_floats(int n_nets) { return n_nets * kCoefStride; }
 
 int launch_fold_bias(float* image_dev, int n_nets, int net_floats, int D, int nbk, void* stream) {
+    if (n_nets <= 0 || !image_dev) return WF_OK;
     hipLaunchKernelGGL(k_fold_bias, dim3(n_nets), dim3(128), 0, (hipStream_t)stream, image_dev, net_floats, D, nbk);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -242,7 +243,7 @@ int launch_mfma(int D, int nbk, const MfmaDev* mdev, int lds_bytes, int mode, co
     hipStream_t s = (hipStream_t)stream;
 #define GO(DD, KK, WW) return launch_dw<DD, KK, WW, 1>(mdev, lds_bytes, mode, x, B, out, u, idx, s)
     if (D == 2 && nbk == 1) {   // the headline shape: several workgroup shapes are built (tuning / reproducibility test)
-        if (tiles_per_wave() == 2) {
+        if (tiles_per_wave() == 2 && !idx) {   // (bin indices: one-tile kernels only)
             if (waves_per_group(2) == 4) return launch_dw<2, 1, 4, 2>(mdev, lds_bytes, mode, x, B, out, u, idx, s);
             return launch_dw<2, 1, 8, 2>(mdev, lds_bytes, mode, x, B, out, u, idx, s);
         }

@@ -13,6 +13,14 @@
 
 #include "wf_internal.h"
 
+// WF_PIN(): keeps the hand-written order of [MFMA K step | activation of another block] units (hidden_layers, out_block_first): the
+// scheduler is free inside a unit, not across units.
+#ifdef WF_NO_PIN
+#define WF_PIN()
+#else
+#define WF_PIN() __builtin_amdgcn_sched_barrier(0)
+#endif
+
 namespace wf {
 namespace mfma {
 
@@ -44,6 +52,12 @@ __device__ __forceinline__ f32x16 load16g(const float* p) {
 #else
 #define load16g load16
 #endif
+__device__ __forceinline__ float xhalf_max(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto s = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(s[0]), __uint_as_float(s[1]));
+}
+
 __device__ __forceinline__ f32x16 load16(const float* p) {
     const f32x4* q = reinterpret_cast<const f32x4*>(p);
     const f32x4 a = q[0], b = q[1], c = q[2], d = q[3];
@@ -130,48 +144,55 @@ __device__ __forceinline__ void split8(const float (&r)[8], f16x8& hi, f16x8& lo
     hi = __builtin_bit_cast(f16x8, H);
     lo = __builtin_bit_cast(f16x8, L);
 }
-__device__ __forceinline__ void act_split_block(const f32x16& xs, Frag& f) {
-#ifdef WF_ABL_ACT   // ablation build (timing only): no activation / split arithmetic
+// One K = 16 step (kt, s) of a 32-unit output block of a K=64 layer for the wave's T tiles:
+// acc[t] += Ahi*Bhi + Ahi*Blo + Alo*Bhi (fp32 accumulation).  Wh / Wl: LDS images [k-step][lane][8 halves] of this block; every A
+// fragment is read once and used by all T tiles, whose accumulator chains are independent.
+template <int T>
+__device__ __forceinline__ void mfma_step(const _Float16* Wh, const _Float16* Wl, int kt, int s, const Frag (&in)[T][2], f32x16 (&acc)[T], int lane) {
+    const f16x8 ah = *reinterpret_cast<const f16x8*>(Wh + ((kt * 2 + s) * 64 + lane) * 8);
+    const f16x8 al = *reinterpret_cast<const f16x8*>(Wl + ((kt * 2 + s) * 64 + lane) * 8);
+#ifdef WF_ABL_MFMA   // ablation build (timing only): operands stay live, no matrix instructions
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        f32x4 a = {xs[8 * s], xs[8 * s + 1], xs[8 * s + 2], xs[8 * s + 3]}, b = {xs[8 * s + 4], xs[8 * s + 5], xs[8 * s + 6], xs[8 * s + 7]};
-        f.hi[s] = __builtin_bit_cast(f16x8, a);
-        f.lo[s] = __builtin_bit_cast(f16x8, b);
-    }
+    for (int t = 0; t < T; ++t) asm volatile("" : "+v"(acc[t]) : "v"(ah), "v"(al), "v"(in[t][kt].hi[s]), "v"(in[t][kt].lo[s]));
     return;
 #endif
+#ifdef WF_SETPRIO
+    __builtin_amdgcn_s_setprio(WF_SETPRIO);
+#endif
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        float r[8];
+    for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, in[t][kt].hi[s], acc[t], 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) r[j] = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(xs[8 * s + j]) + 1.0f);
-        split8(r, f.hi[s], f.lo[s]);
-    }
+    for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, in[t][kt].lo[s], acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, in[t][kt].hi[s], acc[t], 0, 0, 0);
+#ifdef WF_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
 }
-
-// One 32-unit output block of a K=64 layer for the wave's T tiles: acc[t] += Ahi*Bhi + Ahi*Blo + Alo*Bhi (fp32 accumulation).
-// Wh / Wl: LDS images [k-step][lane][8 halves] of this block; every A fragment is read once and used by all T tiles, whose
-// accumulator chains are independent (back-to-back MFMA issue without waiting for a result).
 template <int T>
 __device__ __forceinline__ void dense64_block(const _Float16* Wh, const _Float16* Wl, const Frag (&in)[T][2], f32x16 (&acc)[T], int lane) {
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const f16x8 ah = *reinterpret_cast<const f16x8*>(Wh + ((kt * 2 + s) * 64 + lane) * 8);
-            const f16x8 al = *reinterpret_cast<const f16x8*>(Wl + ((kt * 2 + s) * 64 + lane) * 8);
-#ifdef WF_ABL_MFMA   // ablation build (timing only): operands stay live, no matrix instructions
+        for (int s = 0; s < 2; ++s) mfma_step<T>(Wh, Wl, kt, s, in, acc, lane);
+}
+// the activation of registers 8s .. 8s+7 of a block (one K = 16 fragment) of every tile: the unit of work that is placed between
+// the K steps of an MFMA chain that does not depend on it (hidden_layers, out_block_first)
+template <int T>
+__device__ __forceinline__ void act8(const f32x16 (&x)[T], int s, Frag (&f)[T][2], int ob) {
 #pragma unroll
-            for (int t = 0; t < T; ++t) asm volatile("" : "+v"(acc[t]) : "v"(ah), "v"(al), "v"(in[t][kt].hi[s]), "v"(in[t][kt].lo[s]));
-            continue;
+    for (int t = 0; t < T; ++t) {
+#ifdef WF_ABL_ACT
+        f32x4 a = {x[t][8 * s], x[t][8 * s + 1], x[t][8 * s + 2], x[t][8 * s + 3]}, b = {x[t][8 * s + 4], x[t][8 * s + 5], x[t][8 * s + 6], x[t][8 * s + 7]};
+        f[t][ob].hi[s] = __builtin_bit_cast(f16x8, a);
+        f[t][ob].lo[s] = __builtin_bit_cast(f16x8, b);
+#else
+        float r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x[t][8 * s + j]) + 1.0f);
+        split8(r, f[t][ob].hi[s], f[t][ob].lo[s]);
 #endif
-#pragma unroll
-            for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, in[t][kt].hi[s], acc[t], 0, 0, 0);
-#pragma unroll
-            for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, in[t][kt].lo[s], acc[t], 0, 0, 0);
-#pragma unroll
-            for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, in[t][kt].hi[s], acc[t], 0, 0, 0);
-        }
+    }
 }
 
 // float offsets inside a net image (wf_model.cpp: build_mfma_image); NBK = 32-row blocks per dimension (1 or 2)
@@ -189,18 +210,23 @@ struct NetOff {
     static constexpr int total = b2 + 32 * D * NBK;
 };
 
-// Hidden layers of one conditioner net for the wave's T tiles of 32 walkers; result: second hidden layer as B fragments.
+// Hidden layers of one conditioner net for the wave's T tiles of 32 walkers.  Written in the order the instructions should issue:
+// the activation of a finished block sits between the K steps of the next MFMA chain that does not need it yet --
+//   chain(layer 2, block 0), K steps of layer-1 block 0  ||  activation of layer-1 block 1
+//   chain(layer 2, block 1)                              ||  activation of layer-2 block 0
+// Result: h2[t][0] complete, pend[t] = pre-activations of layer-2 block 1 (their activation goes under the first K steps of the
+// output chain: out_block_first).
 template <int D, int NBK, int T>
-__device__ __forceinline__ void hidden_layers(const float* net, const float (&in)[T][D], int lane, Frag (&h2)[T][2]) {
+__device__ __forceinline__ void hidden_layers(const float* net, const float (&in)[T][D], int lane, Frag (&h2)[T][2], f32x16 (&pend)[T]) {
     using O = NetOff<D, NBK>;
     const int h = lane >> 5;
     Frag h1[T][2];
+    f32x16 a[2][T];
 #pragma unroll
     for (int ob = 0; ob < 2; ++ob) {
-        f32x16 a[T];
         const f32x16 bias = load16(net + O::b0 + (ob * 2 + h) * 16);
 #pragma unroll
-        for (int t = 0; t < T; ++t) a[t] = bias;
+        for (int t = 0; t < T; ++t) a[ob][t] = bias;
 #pragma unroll
         for (int s = 0; s < O::S0; ++s) {
             const float w = net[O::W0 + (ob * O::S0 + s) * 64 + lane];
@@ -208,24 +234,43 @@ __device__ __forceinline__ void hidden_layers(const float* net, const float (&in
             for (int t = 0; t < T; ++t) {
                 const float lo = in[t][2 * s];
                 const float hi = (2 * s + 1 < D) ? in[t][(2 * s + 1 < D) ? 2 * s + 1 : D - 1] : 0.0f;
-                a[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, h ? hi : lo, a[t], 0, 0, 0);
+                a[ob][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, h ? hi : lo, a[ob][t], 0, 0, 0);
             }
         }
-#pragma unroll
-        for (int t = 0; t < T; ++t) act_split_block(a[t], h1[t][ob]);
     }
+    act8<T>(a[0], 0, h1, 0);
+    act8<T>(a[0], 1, h1, 0);
     const _Float16* W1h = reinterpret_cast<const _Float16*>(net + O::W1h);
     const _Float16* W1l = reinterpret_cast<const _Float16*>(net + O::W1l);
+    f32x16 c0[T];
+    {
+        const f32x16 bias = load16(net + O::b1 + h * 16);
 #pragma unroll
-    for (int ob = 0; ob < 2; ++ob) {
-        f32x16 a[T];
-        const f32x16 bias = load16(net + O::b1 + (ob * 2 + h) * 16);
-#pragma unroll
-        for (int t = 0; t < T; ++t) a[t] = bias;
-        dense64_block<T>(W1h + ob * 2048, W1l + ob * 2048, h1, a, lane);
-#pragma unroll
-        for (int t = 0; t < T; ++t) act_split_block(a[t], h2[t][ob]);
+        for (int t = 0; t < T; ++t) c0[t] = bias;
     }
+    WF_PIN();
+    mfma_step<T>(W1h, W1l, 0, 0, h1, c0, lane);
+    act8<T>(a[1], 0, h1, 1);
+    WF_PIN();
+    mfma_step<T>(W1h, W1l, 0, 1, h1, c0, lane);
+    act8<T>(a[1], 1, h1, 1);
+    WF_PIN();
+    mfma_step<T>(W1h, W1l, 1, 0, h1, c0, lane);
+    mfma_step<T>(W1h, W1l, 1, 1, h1, c0, lane);
+    {
+        const f32x16 bias = load16(net + O::b1 + (2 + h) * 16);
+#pragma unroll
+        for (int t = 0; t < T; ++t) pend[t] = bias;
+    }
+    WF_PIN();
+    mfma_step<T>(W1h + 2048, W1l + 2048, 0, 0, h1, pend, lane);
+    mfma_step<T>(W1h + 2048, W1l + 2048, 0, 1, h1, pend, lane);
+    act8<T>(c0, 0, h2, 0);
+    WF_PIN();
+    mfma_step<T>(W1h + 2048, W1l + 2048, 1, 0, h1, pend, lane);
+    mfma_step<T>(W1h + 2048, W1l + 2048, 1, 1, h1, pend, lane);
+    act8<T>(c0, 1, h2, 0);
+    WF_PIN();
 }
 
 // Output block (dimension d >= 1, row block kb): raw (scaled) outputs o[basis row][walker] in accumulator layout, T tiles.
@@ -241,6 +286,27 @@ __device__ __forceinline__ void out_block(const float* net, const Frag (&h2)[T][
     for (int t = 0; t < T; ++t) o[t] = bias;
     dense64_block<T>(W2h + blk * 2048, W2l + blk * 2048, h2, o, lane);
 }
+// The first output block of a net (d = 1, kb = 0) also finishes the second hidden layer: the activation of its block 1 (pend) runs
+// under the two K steps that only need block 0.
+template <int D, int NBK, int T>
+__device__ __forceinline__ void out_block_first(const float* net, Frag (&h2)[T][2], const f32x16 (&pend)[T], int lane, f32x16 (&o)[T]) {
+    using O = NetOff<D, NBK>;
+    const int h = lane >> 5;
+    const _Float16* W2h = reinterpret_cast<const _Float16*>(net + O::W2h);
+    const _Float16* W2l = reinterpret_cast<const _Float16*>(net + O::W2l);
+    const f32x16 bias = load16(net + O::b2 + (NBK * 2 + h) * 16);   // (d = 1, kb = 0)
+#pragma unroll
+    for (int t = 0; t < T; ++t) o[t] = bias;
+    WF_PIN();
+    mfma_step<T>(W2h, W2l, 0, 0, h2, o, lane);
+    act8<T>(pend, 0, h2, 1);
+    WF_PIN();
+    mfma_step<T>(W2h, W2l, 0, 1, h2, o, lane);
+    act8<T>(pend, 1, h2, 1);
+    WF_PIN();
+    mfma_step<T>(W2h, W2l, 1, 0, h2, o, lane);
+    mfma_step<T>(W2h, W2l, 1, 1, h2, o, lane);
+}
 
 // The table rows of one spline evaluation of one walker half: x_l and x_r rows, NO derivative orders (NO = 2: value and first
 // derivative of the flow-layer I-spline; 1: the prior), NBK blocks of 16 floats each, plus the row sums.  Fetched as a unit so that
@@ -250,8 +316,8 @@ struct SplineRows {
     f32x16 a[NO][NBK], b[NO][NBK];
     float rl[NO], rr[NO];
 };
-// tab: [mesh][NO][NBK][half][16]; rs: [mesh][NO] (may be null)
-template <int NBK, int NO>
+// tab: [mesh][NO][NBK][half][16]; rs: [mesh][NO] (read when RS)
+template <int NBK, int NO, bool RS>
 __device__ __forceinline__ void fetch_rows(SplineRows<NBK, NO>& R, const float* __restrict__ tab, const float* __restrict__ rs, const Lerp& Lp, int h) {
     const float* tl = tab + (size_t)Lp.il * (32 * NBK * NO) + h * 16;
     const float* tr = tab + (size_t)Lp.ir * (32 * NBK * NO) + h * 16;
@@ -264,8 +330,8 @@ __device__ __forceinline__ void fetch_rows(SplineRows<NBK, NO>& R, const float* 
         }
 #pragma unroll
     for (int o = 0; o < NO; ++o) {
-        R.rl[o] = rs ? rs[(size_t)Lp.il * NO + o] : 0.0f;
-        R.rr[o] = rs ? rs[(size_t)Lp.ir * NO + o] : 0.0f;
+        R.rl[o] = RS ? rs[(size_t)Lp.il * NO + o] : 0.0f;
+        R.rr[o] = RS ? rs[(size_t)Lp.ir * NO + o] : 0.0f;
     }
 }
 
@@ -356,7 +422,11 @@ __device__ __forceinline__ void stage_floats(const float* __restrict__ src, floa
 
 // One wave = T tiles of 32 walkers (T = 2: two independent dependency chains per wave, so that one tile's activation / spline
 // VALU work sits in the other tile's MFMA shadow inside the same instruction stream; the A operands are read from LDS once per pair).
-template <int D, int NBK, int kWaves, int T>
+// IDX: the bin-index output (a diagnostic) is compiled into its own instantiation: the per-lane pointer tests would otherwise
+// cut the hot loop into a hundred basic blocks that the instruction scheduler cannot move work across.
+// SPEC: the headline family (mean-type box, IMADE layers, Waveflow prior, every net resident in LDS, division-free x_l / n) with the
+// model switches as compile-time constants: the tile loop becomes one straight-line block per net.
+template <int D, int NBK, int kWaves, int T, bool IDX, bool SPEC>
 __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode, const float* __restrict__ xg, int64_t B,
                                                       float* __restrict__ out, float* __restrict__ u_out, int32_t* __restrict__ idx_out) {
     // mm is passed BY VALUE: it lives in the kernarg segment, so its fields are scalar loads and the table pointers
@@ -366,15 +436,17 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
     // nets, re-staging the slot between two barriers per net (the per-tile state is D + 1 registers).
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int kThreads = kWaves * 64;
+    const int box_kind = SPEC ? (int)WF_BOX_MEAN : mm.box_kind, layer_kind = SPEC ? (int)WF_LAYER_IMADE : mm.layer_kind;
+    const int prior_kind = SPEC ? (int)WF_PRIOR_WAVEFLOW : mm.prior_kind, staged = SPEC ? 0 : mm.staged, exact_div = SPEC ? 0 : mm.exact_div;
     stage_floats<kThreads>(mm.image + mm.const_img_off, lds, mm.const_floats);
-    if (!mm.staged) stage_floats<kThreads>(mm.image, lds + mm.const_floats, mm.net_floats * mm.n_nets);
+    if (!staged) stage_floats<kThreads>(mm.image, lds + mm.const_floats, mm.net_floats * mm.n_nets);
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
     const float* fkI = lds;                        // [NBK][2][16] remove_bias * keep factors of the flow-layer I-spline
     const float* fkP = lds + 32 * NBK;             // [NBK][2][16] prior: keep (B) or remove_bias * keep (M)
-    const float* ob2b = lds + 64 * NBK;            // [NBK out][NBK in][4][64][4] ob_to_b in f32-MFMA A order
+    const float* ob2b = lds + 64 * NBK;            // [NBK out][NBK in]{hi, lo}[2 K steps][64][8 halves] ob_to_b in f16-MFMA A order
     float* slots = lds + mm.const_floats;
     const int64_t n_tiles = (B + 31) >> 5;
     constexpr int kTilesPerChunk = kWaves * T;
@@ -406,14 +478,14 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
             const int64_t wl = valid[t] ? w[t] : B - 1;
 #pragma unroll
             for (int d = 0; d < D; ++d) cur[t][d] = xg[wl * D + d];
-            idx[t] = (idx_out && valid[t] && h == 0) ? idx_out + w[t] * idx_stride : nullptr;
+            idx[t] = (IDX && idx_out && valid[t] && h == 0) ? idx_out + w[t] * idx_stride : nullptr;
         }
 
         // ---- BoxTransformLayer (made.py:118-137, 156-183); IEEE divisions: layer-0 bin indices must be exact
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             float ld = 0.0f;
-            if (mm.box_kind == WF_BOX_MEAN) {
+            if (box_kind == WF_BOX_MEAN) {
                 float s = 0.0f;
 #pragma unroll
                 for (int d = 0; d < D; ++d) s = s + cur[t][d];
@@ -432,7 +504,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
                 ld = ld - fast_log(2 * L - wd + tol);
 #pragma unroll
                 for (int d = 0; d < D; ++d) cur[t][d] = nxt[t][d];
-            } else if (mm.box_kind == WF_BOX_FIRST) {
+            } else if (box_kind == WF_BOX_FIRST) {
                 nxt[t][0] = (cur[t][0] + L) / (2 * L);
                 float ls = 0.0f;
 #pragma unroll
@@ -448,22 +520,23 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
 
         // ---- flow layers
         for (int l = 0; l < mm.n_layers; ++l) {
-            const float* net = slots + (mm.staged ? 0 : l * mm.net_floats);
-            if (mm.staged) {
+            const float* net = slots + (staged ? 0 : l * mm.net_floats);
+            if (staged) {
                 __syncthreads();   // every wave is done with the previous occupant of the slot
                 stage_floats<kThreads>(mm.image + (size_t)l * mm.net_floats, slots, mm.net_floats);
                 __syncthreads();
             }
             Frag h2[T][2];
+            f32x16 pend[T];
             STAMP(0);
-            hidden_layers<D, NBK, T>(net, cur, lane, h2);
+            hidden_layers<D, NBK, T>(net, cur, lane, h2, pend);
             STAMP(1);
-            if (mm.layer_kind == WF_LAYER_IMADE) {
+            if (layer_kind == WF_LAYER_IMADE) {
                 // dimension 0: walker-independent weights -> composite table (k_prepare_dim0)
 #pragma unroll
                 for (int t = 0; t < T; ++t) {
-                    const Lerp Lp = make_lerp(cur[t][0], mm.n_mesh, rn_mesh, mm.exact_div);
-                    if (idx[t]) { idx[t][(l * D) * 2] = Lp.xl; idx[t][(l * D) * 2 + 1] = Lp.xr; }
+                    const Lerp Lp = make_lerp(cur[t][0], mm.n_mesh, rn_mesh, exact_div);
+                    if (IDX && idx[t]) { idx[t][(l * D) * 2] = Lp.xl; idx[t][(l * D) * 2 + 1] = Lp.xr; }
                     const f32x4 c0 = comp_lerp(mm.comp + (size_t)l * mm.n_mesh, Lp);
                     nxt[t][0] = c0[0];
                     logdet[t] = logdet[t] + fast_log(c0[1] + 1e-7f);
@@ -475,7 +548,8 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
 #pragma unroll
                     for (int kb = 0; kb < NBK; ++kb) {
                         f32x16 o[T];
-                        out_block<D, NBK, T>(net, h2, d, kb, lane, o);
+                        if (d == 1 && kb == 0) out_block_first<D, NBK, T>(net, h2, pend, lane, o);
+                        else out_block<D, NBK, T>(net, h2, d, kb, lane, o);
 #pragma unroll
                         for (int t = 0; t < T; ++t) v[t][kb] = o[t];
                     }
@@ -488,10 +562,10 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
                         sigmoid_block<NBK>(v[t], fkI, h, S1, Sf);
                         const float rs = mm.i_reg * S1;
                         const float rS = __builtin_amdgcn_rcpf(__builtin_fmaf(rs, mm.F_I, Sf));
-                        const Lerp Lp = make_lerp(cur[t][d], mm.n_mesh, rn_mesh, mm.exact_div);
-                        if (idx[t]) { idx[t][(l * D + d) * 2] = Lp.xl; idx[t][(l * D + d) * 2 + 1] = Lp.xr; }
+                        const Lerp Lp = make_lerp(cur[t][d], mm.n_mesh, rn_mesh, exact_div);
+                        if (IDX && idx[t]) { idx[t][(l * D + d) * 2] = Lp.xl; idx[t][(l * D + d) * 2 + 1] = Lp.xr; }
                         SplineRows<NBK, 2> R;
-                        fetch_rows<NBK, 2>(R, mm.tabI, mm.rsI, Lp, h);
+                        fetch_rows<NBK, 2, true>(R, mm.tabI, mm.rsI, Lp, h);
                         float ld;
                         ispline_eval<NBK>(v[t], R, Lp.t, rS, rs, nxt[t][d], ld);
                         logdet[t] = logdet[t] + ld;
@@ -514,7 +588,8 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
                         }
                     } else {
                         f32x16 o[T];
-                        out_block<D, NBK, T>(net, h2, d, 0, lane, o);
+                        if (d == 1) out_block_first<D, NBK, T>(net, h2, pend, lane, o);
+                        else out_block<D, NBK, T>(net, h2, d, 0, lane, o);
 #pragma unroll
                         for (int t = 0; t < T; ++t) {
                             const float lw = __shfl(o[t][0], j);
@@ -538,17 +613,18 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
 #pragma unroll
         for (int t = 0; t < T; ++t) result[t] = logdet[t];
         if (mode != 2) {
-            if (mm.prior_kind == WF_PRIOR_WAVEFLOW || mm.prior_kind == WF_PRIOR_MFLOW) {
-                const bool wavefn = mm.prior_kind == WF_PRIOR_WAVEFLOW;
-                const float* net = slots + (mm.staged ? 0 : mm.n_layers * mm.net_floats);
-                if (mm.staged) {
+            if (prior_kind == WF_PRIOR_WAVEFLOW || prior_kind == WF_PRIOR_MFLOW) {
+                const bool wavefn = prior_kind == WF_PRIOR_WAVEFLOW;
+                const float* net = slots + (staged ? 0 : mm.n_layers * mm.net_floats);
+                if (staged) {
                     __syncthreads();
                     stage_floats<kThreads>(mm.image + (size_t)mm.n_layers * mm.net_floats, slots, mm.net_floats);
                     __syncthreads();
                 }
                 const f32x4* comp_p = mm.comp + (size_t)mm.n_layers * mm.n_mesh;
                 Frag h2[T][2];
-                hidden_layers<D, NBK, T>(net, cur, lane, h2);   // the conditioner sees the unclipped u (wavefunctions.py:40)
+                f32x16 pend[T];
+                hidden_layers<D, NBK, T>(net, cur, lane, h2, pend);   // the conditioner sees the unclipped u (wavefunctions.py:40)
                 float lp[T], prod[T];
 #pragma unroll
                 for (int t = 0; t < T; ++t) { lp[t] = 0.0f; prod[t] = 1.0f; }
@@ -560,8 +636,8 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
 #pragma unroll
                     for (int t = 0; t < T; ++t) {
                         uc[t] = fminf(fmaxf(cur[t][d], 0.0f), 1.0f);   // the spline sees the clipped one (:45)
-                        Lp[t] = make_lerp(uc[t], mm.n_mesh, rn_mesh, mm.exact_div);
-                        if (idx[t]) { idx[t][(mm.n_layers * D + d) * 2] = Lp[t].xl; idx[t][(mm.n_layers * D + d) * 2 + 1] = Lp[t].xr; }
+                        Lp[t] = make_lerp(uc[t], mm.n_mesh, rn_mesh, exact_div);
+                        if (IDX && idx[t]) { idx[t][(mm.n_layers * D + d) * 2] = Lp[t].xl; idx[t][(mm.n_layers * D + d) * 2 + 1] = Lp[t].xr; }
                     }
                     if (d == 0) {
 #pragma unroll
@@ -569,39 +645,69 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
                     } else if (wavefn) {
                         f32x16 o[NBK][T];
 #pragma unroll
-                        for (int kb = 0; kb < NBK; ++kb) out_block<D, NBK, T>(net, h2, d, kb, lane, o[kb]);
+                        for (int kb = 0; kb < NBK; ++kb) {
+                            if (d == 1 && kb == 0) out_block_first<D, NBK, T>(net, h2, pend, lane, o[kb]);
+                            else out_block<D, NBK, T>(net, h2, d, kb, lane, o[kb]);
+                        }
 #pragma unroll
                         for (int t = 0; t < T; ++t) {
-                            float s1 = 0.0f;
+                            float s1 = 0.0f, amax = 0.0f;
 #pragma unroll
                             for (int kb = 0; kb < NBK; ++kb) {
                                 const f32x16 keep = load16(fkP + (kb * 2 + h) * 16);
 #pragma unroll
-                                for (int r = 0; r < 16; ++r) { s1 += o[kb][t][r]; o[kb][t][r] = o[kb][t][r] * keep[r]; }
+                                for (int r = 0; r < 16; ++r) {
+                                    s1 += o[kb][t][r];
+                                    o[kb][t][r] = o[kb][t][r] * keep[r];
+                                    amax = fmaxf(amax, fabsf(o[kb][t][r]));
+                                }
                             }
                             s1 = xhalf_sum(s1);
-                            // c = (o * keep) @ ob_to_b on v_mfma_f32_32x32x2_f32 (unnormalised operands: no fp16 split)
+                            // c = (o * keep) @ ob_to_b as split-fp16 MFMA products.  The head's outputs are unbounded, fp16 is not: the
+                            // walker's 32 * NBK values are scaled by a power of two so that the largest lies in [0.5, 1) -- exact, and
+                            // psi_d = sign * (c . lerp) / |c| does not see a common factor.  WF_PRIOR_QUOTIENT=1 (debug): divide by the signed
+                            // sum first, as model_factory.py:69 does (same function in real arithmetic, a different fp32 rounding pattern).
+                            amax = xhalf_max(amax);
+                            const int ex = amax > 0.0f ? __builtin_amdgcn_frexp_expf(amax) : 0;
+                            const float qs = mm.prior_quotient ? 1.0f / s1 : 1.0f;
+                            Frag of[NBK];
+#pragma unroll
+                            for (int kb = 0; kb < NBK; ++kb)
+#pragma unroll
+                                for (int s = 0; s < 2; ++s) {
+                                    float r8[8];
+#pragma unroll
+                                    for (int jj = 0; jj < 8; ++jj) {
+                                        const float vq = mm.prior_quotient ? o[kb][t][8 * s + jj] * qs : o[kb][t][8 * s + jj];
+                                        r8[jj] = __builtin_amdgcn_ldexpf(vq, mm.prior_quotient ? 0 : -ex);
+                                    }
+                                    split8(r8, of[kb].hi[s], of[kb].lo[s]);
+                                }
                             f32x16 c[NBK];
                             float n2 = 0.0f;
+                            const _Float16* obh = reinterpret_cast<const _Float16*>(ob2b);
 #pragma unroll
                             for (int ko = 0; ko < NBK; ++ko) {
                                 c[ko] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
                                 for (int ki = 0; ki < NBK; ++ki)
 #pragma unroll
-                                    for (int r4 = 0; r4 < 4; ++r4) {
-                                        const f32x4 a4 = *reinterpret_cast<const f32x4*>(ob2b + (((ko * NBK + ki) * 4 + r4) * 64 + lane) * 4);
-#pragma unroll
-                                        for (int e = 0; e < 4; ++e) c[ko] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], o[ki][t][4 * r4 + e], c[ko], 0, 0, 0);
+                                    for (int s = 0; s < 2; ++s) {
+                                        const _Float16* blk = obh + (size_t)(ko * NBK + ki) * 2048;
+                                        const f16x8 ah = *reinterpret_cast<const f16x8*>(blk + (s * 64 + lane) * 8);
+                                        const f16x8 al = *reinterpret_cast<const f16x8*>(blk + 1024 + (s * 64 + lane) * 8);
+                                        c[ko] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, of[ki].hi[s], c[ko], 0, 0, 0);
+                                        c[ko] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, of[ki].lo[s], c[ko], 0, 0, 0);
+                                        c[ko] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, of[ki].hi[s], c[ko], 0, 0, 0);
                                     }
 #pragma unroll
                                 for (int r = 0; r < 16; ++r) n2 = __builtin_fmaf(c[ko][r], c[ko][r], n2);
                             }
                             const float rnorm = __builtin_amdgcn_rsqf(xhalf_sum(n2));
                             SplineRows<NBK, 1> RP;   // prior rows [mesh][kb][h][16], nd 0
-                            fetch_rows<NBK, 1>(RP, mm.tabP, nullptr, Lp[t], h);
+                            fetch_rows<NBK, 1, false>(RP, mm.tabP, nullptr, Lp[t], h);
                             const float v0 = lerp_dot<NBK, 1>(c, RP, 0, Lp[t].t) * rnorm;
-                            val[t] = s1 < 0.0f ? -v0 : v0;
+                            val[t] = (s1 < 0.0f && !mm.prior_quotient) ? -v0 : v0;
                         }
                     } else {
                         // MFlow (distributions.py:139-163): M-spline table with the row factors folded in
@@ -609,7 +715,8 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
 #pragma unroll
                         for (int kb = 0; kb < NBK; ++kb) {
                             f32x16 o[T];
-                            out_block<D, NBK, T>(net, h2, d, kb, lane, o);
+                            if (d == 1 && kb == 0) out_block_first<D, NBK, T>(net, h2, pend, lane, o);
+                            else out_block<D, NBK, T>(net, h2, d, kb, lane, o);
 #pragma unroll
                             for (int t = 0; t < T; ++t) v[t][kb] = o[t];
                         }
@@ -618,7 +725,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
                             float S1, Sf;
                             sigmoid_block<NBK>(v[t], fkP, h, S1, Sf);
                             SplineRows<NBK, 1> RP;
-                            fetch_rows<NBK, 1>(RP, mm.tabP, nullptr, Lp[t], h);
+                            fetch_rows<NBK, 1, false>(RP, mm.tabP, nullptr, Lp[t], h);
                             val[t] = lerp_dot<NBK, 1>(v[t], RP, 0, Lp[t].t) * __builtin_amdgcn_rcpf(Sf);
                         }
                     }
@@ -646,7 +753,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
 #pragma unroll
                     for (int d = 0; d < D; ++d) cur[t][d] = nxt[t][d];
                 }
-            } else if (mm.prior_kind == WF_PRIOR_UNIFORM) {
+            } else if (prior_kind == WF_PRIOR_UNIFORM) {
 #pragma unroll
                 for (int t = 0; t < T; ++t) {
 #pragma unroll
@@ -685,11 +792,11 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
 #endif
 }
 
-template <int D, int NBK, int kWaves, int T>
-int launch_dw(const MfmaDev* mdev, int lds_bytes, int mode, const float* x, int64_t B, float* out, float* u, int32_t* idx, hipStream_t s) {
+template <int D, int NBK, int kWaves, int T, bool IDX, bool SPEC>
+int launch_dwi(const MfmaDev* mdev, int lds_bytes, int mode, const float* x, int64_t B, float* out, float* u, int32_t* idx, hipStream_t s) {
     static int configured_bytes = -1;
     if (lds_bytes > configured_bytes) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mfma<D, NBK, kWaves, T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mfma<D, NBK, kWaves, T, IDX, SPEC>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            lds_bytes);
         if (e != hipSuccess) {
             set_hip_error((int)e);
@@ -700,7 +807,7 @@ int launch_dw(const MfmaDev* mdev, int lds_bytes, int mode, const float* x, int6
     const int64_t n_tiles = (B + 31) / 32;
     int64_t grid = (n_tiles + kWaves * T - 1) / (kWaves * T);
     if (grid > 256) grid = 256;  // one persistent workgroup per CU
-    hipLaunchKernelGGL((k_mfma<D, NBK, kWaves, T>), dim3((unsigned)grid), dim3(kWaves * 64), lds_bytes, s, *mdev, mode, x, B, out, u, idx);
+    hipLaunchKernelGGL((k_mfma<D, NBK, kWaves, T, IDX, SPEC>), dim3((unsigned)grid), dim3(kWaves * 64), lds_bytes, s, *mdev, mode, x, B, out, u, idx);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_hip_error((int)e);
@@ -709,6 +816,21 @@ int launch_dw(const MfmaDev* mdev, int lds_bytes, int mode, const float* x, int6
     return WF_OK;
 }
 
+// launch_dw<D, NBK, kWaves, T>: the shape's kernel; with a bin-index buffer the request goes to the IDX instantiation, which is built
+// for T = 1 only (kWaves as given).
+template <int D, int NBK, int kWaves, int T>
+int launch_dw(const MfmaDev* mdev, int lds_bytes, int mode, const float* x, int64_t B, float* out, float* u, int32_t* idx, hipStream_t s) {
+    if (idx) {
+        if constexpr (T == 1) return launch_dwi<D, NBK, kWaves, 1, true, false>(mdev, lds_bytes, mode, x, B, out, u, idx, s);
+        else return WF_ERR_UNSUPPORTED;
+    }
+    if constexpr (D == 2) {   // the specialised build exists for the two-particle shapes
+        if (mdev->box_kind == WF_BOX_MEAN && mdev->layer_kind == WF_LAYER_IMADE && mdev->prior_kind == WF_PRIOR_WAVEFLOW && !mdev->staged &&
+            !mdev->exact_div)
+            return launch_dwi<D, NBK, kWaves, T, false, true>(mdev, lds_bytes, mode, x, B, out, u, nullptr, s);
+    }
+    return launch_dwi<D, NBK, kWaves, T, false, false>(mdev, lds_bytes, mode, x, B, out, u, nullptr, s);
+}
 
 }  // namespace mfma
 }  // namespace wf

@@ -641,6 +641,7 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
     md.i_nb = m->i_nb; md.p_nb = m->p_nb; md.n_mesh = d.n_mesh; md.nbk = nbk;
     md.n_nets = n_nets; md.net_floats = net_floats; md.const_img_off = net_floats * n_nets; md.const_floats = consts; md.staged = staged;
     md.exact_div = mfma_div_ok(md.n_mesh) ? 0 : 1;
+    md.prior_quotient = (getenv("WF_PRIOR_QUOTIENT") && atoi(getenv("WF_PRIOR_QUOTIENT")) != 0) ? 1 : 0;
     m->mfma_lds_floats = consts + (staged ? net_floats : net_floats * n_nets);
 
     m->mfma_consts.assign(consts, 0.0f);
@@ -671,17 +672,23 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
         int rc = upload_table(m, rows, &md.tabP);
         if (rc) return rc;
         if (!mflow) {
-            // c[i] = sum_a w[a] * ob_to_b[a][i]: block (ko, ki): A[i = 32*ko + (lane&31)][k = a = 32*ki + acc_row(r, lane>>5)]
-            float* o = m->mfma_consts.data() + 64 * nbk;
+            // c[i] = sum_a w[a] * ob_to_b[a][i] as split-fp16 MFMA products: block (ko, ki), K step s:
+            // A[i = 32*ko + (lane&31)][k = a = 32*ki + acc_row(8*s + j, lane>>5)], hi halves [s][lane][8] then lo halves (1024 each)
+            _Float16* o = reinterpret_cast<_Float16*>(m->mfma_consts.data() + 64 * nbk);
             const int nb = m->p_nb;
             for (int ko = 0; ko < nbk; ++ko)
-                for (int ki = 0; ki < nbk; ++ki)
-                    for (int r4 = 0; r4 < 4; ++r4)
+                for (int ki = 0; ki < nbk; ++ki) {
+                    _Float16* blk = o + (size_t)(ko * nbk + ki) * 2048;
+                    for (int s_ = 0; s_ < 2; ++s_)
                         for (int lane = 0; lane < 64; ++lane)
-                            for (int e = 0; e < 4; ++e) {
-                                const int i = 32 * ko + (lane & 31), a = 32 * ki + acc_row(4 * r4 + e, lane >> 5);
-                                *o++ = (i < nb && a < nb) ? (float)o2b[(size_t)a * nb + i] : 0.0f;
+                            for (int j = 0; j < 8; ++j) {
+                                const int i = 32 * ko + (lane & 31), a = 32 * ki + acc_row(8 * s_ + j, lane >> 5);
+                                const float v = (i < nb && a < nb) ? (float)o2b[(size_t)a * nb + i] : 0.0f;
+                                const _Float16 hi = (_Float16)v;
+                                blk[(s_ * 64 + lane) * 8 + j] = hi;
+                                blk[1024 + (s_ * 64 + lane) * 8 + j] = (_Float16)(v - (float)hi);
                             }
+                }
         }
     }
     int rc = dev_alloc(m, &m->d_mfma, (size_t)total);
