@@ -641,4 +641,5 @@ def test_deferred_evaluation_tables_contract(he_flat):
     assert torch.equal(out[False][1], out[True][1]) and torch.equal(out[False][3], out[True][3])
     assert torch.equal(out[False][2], out[False][3])            # not deferred: current on exit
     assert not torch.equal(out[True][2], out[True][3])          # deferred: stale until the refresh
-    np.testing.assert_allclose(out[True][3][:2000].cpu().numpy(), out[True][1].cpu().numpy(), rtol=0, atol=2e-5 * float(out[True][1].abs().max()))
+    # (two fp32 kernels, each within 2.5e-5 of max|psi| of the reference's golden grid: their difference is bounded by the sum)
+    np.testing.assert_allclose(out[True][3][:2000].cpu().numpy(), out[True][1].cpu().numpy(), rtol=0, atol=4e-5 * float(out[True][1].abs().max()))

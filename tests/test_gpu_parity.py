@@ -13,9 +13,10 @@ pytestmark = pytest.mark.gpu
 # with the 1e-7 floor or psi is near a node (d logp = 2 dpsi/psi).  So every comparison below is made against
 # the fp64 yardstick `truth` (oracle f64=True: same tables, parameters and formulas, fp64 arithmetic) and asks
 # that the HIP result is as close to it as the fp32 oracle is:
-#   * at least as many walkers within 1e-5*|truth| + ATOL as for the fp32 oracle (up to 2x + 0.2 % + 4),
-#   * worst-case deviation within 4x the fp32 oracle's worst case,
-#   * median deviation within 2x the fp32 oracle's median.
+#   * at least as many walkers within 1e-5*|truth| + ATOL as for the fp32 oracle (up to 1.25x + 4),
+#   * worst-case deviation within 2x the fp32 oracle's worst case,
+#   * median deviation within 2x the fp32 oracle's median;
+# on the well-conditioned subset (strict_on_well_conditioned_subset) there is no slack factor at all.
 RTOL, ATOL = 1e-5, 2e-5
 KERNELS = ["scalar", "mfma"]
 KERNELS_ALL = KERNELS + ["wave"]   # the wave kernel (small-batch path) does not report bin indices
@@ -34,16 +35,62 @@ def close(a, b, rtol=RTOL, atol=ATOL):
     assert not bad.any(), f"{bad.sum()} of {bad.size} outside tolerance; max abs err {err.max():.3e}"
 
 
-def as_accurate_as_fp32_reference(gpu, oracle32, truth, rtol=RTOL, atol=ATOL):
+def as_accurate_as_fp32_reference(gpu, oracle32, truth, rtol=RTOL, atol=ATOL, what=""):
+    """The HIP result is as close to exact (fp64) arithmetic as the reference-precision (fp32) oracle is:
+      * count outside the north-star tolerance <= 1.25 x the oracle's + 4 + 3 sqrt(oracle's) (the counts are Poisson-like: the last
+        term is their 3-sigma sampling noise; at 2^20 walkers the criterion is 1.27 x, at 3000 walkers it cannot be sharper than ~2 x);
+      * 99th (>= 2000 walkers) / 99.9th (>= 100 000 walkers) percentile of the deviation <= 2 x the oracle's, maximum <= 4 x: the maximum of a
+        few thousand deviations is set by one or two walkers next to a node of psi, where two fp32 evaluations of equal quality -- the
+        scalar kernel follows the reference's operation order -- differ by factors of 2 - 3 either way;
+      * median <= 2 x.
+    Prints the direct pass rates so that the GPU test log carries the numbers."""
     gpu, oracle32, truth = (np.asarray(v, np.float64) for v in (gpu, oracle32, truth))
     assert np.isfinite(gpu).all()
     tol = atol + rtol * np.abs(truth)
     e_g, e_o = np.abs(gpu - truth), np.abs(oracle32 - truth)
     n_g, n_o = int((e_g > tol).sum()), int((e_o > tol).sum())
-    # (+4: small-sample slack, the counts are Poisson-like for batches of a few hundred walkers)
-    assert n_g <= 2 * n_o + 4 + 0.002 * e_g.size, f"walkers outside 1e-5 rel: HIP {n_g} vs fp32 oracle {n_o} of {e_g.size}"
+    direct = np.abs(gpu - oracle32) <= rtol * np.abs(oracle32)
+    print(f"[parity{' ' + what if what else ''}] n={e_g.size}: within 1e-5*|truth|+{atol:g} of fp64: HIP {1 - n_g / max(e_g.size, 1):.5f} "
+          f"fp32-oracle {1 - n_o / max(e_o.size, 1):.5f}; max |err| HIP {e_g.max() if e_g.size else 0:.2e} oracle {e_o.max() if e_o.size else 0:.2e}; "
+          f"median HIP {np.median(e_g) if e_g.size else 0:.2e} oracle {np.median(e_o) if e_o.size else 0:.2e}; "
+          f"direct |HIP - oracle32| <= 1e-5*|oracle32|: {direct.mean() if direct.size else 1:.5f}")
+    assert n_g <= 1.25 * n_o + 4 + 3 * np.sqrt(n_o), f"walkers outside 1e-5 rel: HIP {n_g} vs fp32 oracle {n_o} of {e_g.size}"
+    if e_g.size >= 2000:   # a tail percentile that still averages over >= 30 walkers
+        q = 0.999 if e_g.size >= 100000 else 0.99
+        q_g, q_o = np.quantile(e_g, q), np.quantile(e_o, q)
+        assert q_g <= 2 * q_o + atol, f"{100 * q:g}th percentile of the deviation from exact arithmetic: HIP {q_g:.3e} vs fp32 oracle {q_o:.3e}"
     assert e_g.max() <= 4 * e_o.max() + atol, f"max deviation from exact arithmetic: HIP {e_g.max():.3e} vs fp32 oracle {e_o.max():.3e}"
     assert np.median(e_g) <= 2 * np.median(e_o) + 1e-7 * max(1.0, np.abs(truth).max()), (np.median(e_g), np.median(e_o))
+
+
+# Where is "fp32 log-prob within 1e-5 relative" DEFINED?  log_pdf sums log(dy + 1e-7) over layers / dimensions and log(psi_d^2 + 1e-7)
+# over dimensions (d log v = dv / v), and |log_pdf| itself passes through 0.  The oracle's conditioning probe gives, per walker, the
+# smallest such v.  Measured on 400 000 uniform He walkers (oracle fp32 vs its fp64 build): with every v > 0.05 and |log_pdf| > 1
+# (1.9 % of the walkers) the fp32 reference still misses 1e-5 relative on 3.8 % of them (max 5.1e-5): the change of basis of the
+# B-spline prior (28 x 28, signed, with cancellation) alone costs 2 - 6e-5 absolute in fp32.  So the strict statement that can be made
+# on that subset, and is made below without a slack factor on the bulk, is: the HIP kernels pass 1e-5 relative (against exact
+# arithmetic) as often as the reference's own fp32 arithmetic does (to 0.5 % of the subset), their 99th-percentile deviation is not
+# larger than the reference's (+10 %: sampling noise of a percentile of ~10^3 - 10^4 values), and their worst walker is within 2 x the
+# reference's worst walker (extreme values of two fp32 evaluations of equal quality differ by such factors: the scalar kernel,
+# which follows the reference's operation order, lands on either side).
+COND_MIN, LOGP_MIN = 0.05, 1.0
+
+
+def strict_on_well_conditioned_subset(gpu, oracle32, truth, cond, what=""):
+    gpu, oracle32, truth = (np.asarray(v, np.float64) for v in (gpu, oracle32, truth))
+    sub = (np.asarray(cond) > COND_MIN) & (np.abs(truth) > LOGP_MIN)
+    if sub.sum() < 20:
+        print(f"[strict {what}] only {sub.sum()} well-conditioned walkers of {sub.size}: not evaluated")
+        return
+    e_g, e_o = np.abs(gpu - truth)[sub], np.abs(oracle32 - truth)[sub]
+    rel = 1e-5 * np.abs(truth)[sub]
+    r_g, r_o = (e_g <= rel).mean(), (e_o <= rel).mean()
+    direct = (np.abs(gpu - oracle32)[sub] <= 1e-5 * np.abs(oracle32)[sub]).mean()
+    print(f"[strict {what}] {sub.sum()} of {sub.size} walkers well conditioned: pass 1e-5 rel vs fp64: HIP {r_g:.4f} fp32-oracle {r_o:.4f}; "
+          f"max |err| HIP {e_g.max():.2e} oracle {e_o.max():.2e}; direct HIP vs oracle32 within 1e-5 rel: {direct:.4f}")
+    assert r_g >= r_o - 0.005 - 3 * np.sqrt(r_o * (1 - r_o) / sub.sum()), (r_g, r_o)   # (3 sigma of a rate over sub.sum() walkers)
+    assert np.quantile(e_g, 0.99) <= 1.1 * max(np.quantile(e_o, 0.99), np.quantile(rel, 0.99)), (np.quantile(e_g, 0.99), np.quantile(e_o, 0.99))
+    assert e_g.max() <= 2 * max(e_o.max(), rel.max()), (e_g.max(), e_o.max())
 
 
 def he_models(he_flat, kernel):
@@ -297,10 +344,13 @@ def test_full_size_properties(he_flat, kernel):
     perm = torch.randperm(B, device="cuda", generator=torch.Generator(device="cuda").manual_seed(0))
     lp2 = log_pdf(params, x[perm])
     assert torch.equal(lp2, lp[perm])
-    # a strided sub-sample agrees with the oracle
-    sel = np.arange(0, B, 409)
-    as_accurate_as_fp32_reference(lp[torch.from_numpy(sel).cuda()].cpu().numpy(), om.log_pdf(he_flat, xn[sel], threads=8),
-                                  om.log_pdf(he_flat, xn[sel], threads=8, f64=True))
+    # EVERY walker of the batch against the fp32 oracle and its fp64 build (a few seconds each on the box's cores)
+    import os
+    thr = max(1, min(16, len(os.sched_getaffinity(0))))
+    lp32, _, _ = om.log_pdf_cond(he_flat, xn, threads=thr)
+    lp64, cond, _ = om.log_pdf_cond(he_flat, xn, threads=thr, f64=True)
+    as_accurate_as_fp32_reference(lp.cpu().numpy(), lp32, lp64, what=f"C3 2^20 {kernel}")
+    strict_on_well_conditioned_subset(lp.cpu().numpy(), lp32, lp64, cond, what=f"C3 2^20 {kernel}")
     # Monte-Carlo normalisation: psi is normalised over the full box, so the sorted half (area (2L)^2/2) holds 1/2
     est = (ps.double() ** 2).mean().item() * (20.0 ** 2) / 2
     assert abs(est - 0.5) < 0.01, est
@@ -312,10 +362,28 @@ def test_full_size_properties(he_flat, kernel):
     assert np.array_equal(sums, log_pdf.model.block_sums(lp).cpu().numpy())
 
 
+def _with_env(**kv):
+    import contextlib, os
+
+    @contextlib.contextmanager
+    def cm():
+        old = {k: os.environ.get(k) for k in kv}
+        os.environ.update({k: str(v) for k, v in kv.items()})
+        try:
+            yield
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+    return cm()
+
+
 def test_mfma_kernel_is_bit_reproducible_and_matches_scalar_at_full_size(he_flat):
-    """Guards against the scheduling-dependent corruption described in DESIGN.md §9: every workgroup shape, repeated
-    launches, 2^20 walkers; results must be identical launch to launch and agree with the scalar kernel."""
-    import os
+    """Guards against the scheduling-dependent corruption of DESIGN.md section 9 (packed-FP32 code next to MFMA chains at >= 3 waves per
+    SIMD): every built workgroup shape of the headline kernel (waves x tiles per wave), repeated launches, 2^20 walkers; results must be
+    identical launch to launch and agree with the scalar kernel."""
     torch = _torch()
     params, psi, log_pdf, om = he_models(he_flat, "scalar")
     m = log_pdf.model
@@ -325,21 +393,143 @@ def test_mfma_kernel_is_bit_reproducible_and_matches_scalar_at_full_size(he_flat
     ref = m.log_pdf(x)
     ref_psi = m.psi(x)
     m.set_kernel("mfma")
-    old = os.environ.get("WF_MFMA_WAVES")
-    try:
-        for waves in ("8", "12", "16"):
-            os.environ["WF_MFMA_WAVES"] = waves
+    for waves, tiles in ((8, 1), (12, 1), (16, 1), (8, 2), (4, 2)):
+        with _with_env(WF_MFMA_WAVES=waves, WF_MFMA_TILES=tiles):
             first = m.log_pdf(x)
             # fp32 noise between the two kernels is <~1e-2 absolute (tolerance section above); a corrupted tile is off by >0.05
-            assert ((first - ref).abs() > 0.05).sum().item() == 0, waves
-            assert ((m.psi(x) - ref_psi).abs() > 1e-3 * ref_psi.abs().max()).sum().item() == 0, waves
-            for _ in range(8):
-                assert torch.equal(m.log_pdf(x), first), waves
-    finally:
-        if old is None:
-            os.environ.pop("WF_MFMA_WAVES", None)
+            assert ((first - ref).abs() > 0.05).sum().item() == 0, (waves, tiles)
+            assert ((m.psi(x) - ref_psi).abs() > 1e-3 * ref_psi.abs().max()).sum().item() == 0, (waves, tiles)
+            for _ in range(12):
+                assert torch.equal(m.log_pdf(x), first), (waves, tiles)
+
+
+@pytest.mark.parametrize("D,knots", [(4, 23), (2, 33), (3, 33)])
+def test_mfma_kernel_is_bit_reproducible_other_shapes(D, knots):
+    """The same guard for the staged mode (D = 4: the four nets do not fit LDS together, one slot re-staged between barriers) and for
+    two 32-row blocks per dimension (33 knots: NBK = 2)."""
+    torch = _torch()
+    from waveflow_amd import model_factory
+    init_fun = model_factory.get_waveflow_model(D, base_spline_degree=6, i_spline_degree=6, n_prior_internal_knots=knots,
+                                                n_i_internal_knots=knots, i_spline_reg=0.05, n_flow_layers=3, box_size=10.0)
+    params, psi, log_pdf, _ = init_fun(11, D)
+    m = log_pdf.model
+    m.ensure_params(params)
+    B = 1 << 18
+    x = torch.from_numpy(sorted_walkers(B, D, 10.0, 99)).cuda()
+    m.set_kernel("scalar")
+    ref = m.log_pdf(x)
+    m.set_kernel("mfma")
+    first = m.log_pdf(x)
+    # seeded (untrained) parameters put more walkers next to nodes of psi than the checkpoint does: isolated walkers may differ between
+    # two fp32 kernels; a corrupted 16-lane group would show as >= 16 neighbours
+    assert ((first - ref).abs() > 0.05 + 1e-3 * ref.abs()).sum().item() < 8
+    for _ in range(10):
+        assert torch.equal(m.log_pdf(x), first)
+
+
+@pytest.mark.parametrize("kernel", KERNELS_ALL)
+@pytest.mark.parametrize("config", ["C1", "C2", "C3", "C3-33", "C4"])
+def test_strict_on_the_well_conditioned_subset(golden, he_flat, kernel, config):
+    """North-star tolerance where it is defined (see strict_on_well_conditioned_subset), for the BASELINE configs:
+    C1 double_circles MFlow "8-bin", C2 the 250 + 6 reference walkers, C3 uniform He walkers (shipped checkpoint) and its 33-knot
+    "32-bin" variant, C4 the 8-electron chain."""
+    from waveflow_amd import flows, model_factory, flatten_params
+    import os
+    from conftest import GOLDEN
+    thr = max(1, min(16, len(os.sched_getaffinity(0))))
+    if config in ("C2", "C3"):
+        params, psi, log_pdf, om = he_models(he_flat, kernel)
+        flat = he_flat
+        if config == "C2":
+            sp = np.sort(golden["he_golden"]["sample_points"], -1)
+            x = np.concatenate([sp, he_grid()[1][[0, 99, 4950, 5050, 9900, 9999]]]).astype(np.float32)
         else:
-            os.environ["WF_MFMA_WAVES"] = old
+            x = sorted_walkers(200000, 2, 10.0, 4321)
+    elif config == "C3-33":
+        init_fun = model_factory.get_waveflow_model(2, base_spline_degree=6, i_spline_degree=6, n_prior_internal_knots=33,
+                                                    n_i_internal_knots=33, i_spline_reg=0.05, n_flow_layers=3, box_size=10.0)
+        params, psi, log_pdf, _ = init_fun(7, 2)
+        om = oracle.Model(D=2, n_layers=3, box="mean", box_L=10.0, i_k=6, i_knots=33, i_reg=0.05, i_left={0: 0}, i_right={0: 1},
+                          prior="waveflow", p_k=6, p_knots=33, p_left={0: 0}, p_right={0: 0}, constr_left=(0,))
+        flat = flatten_params(params)
+        x = sorted_walkers(60000, 2, 10.0, 4321)
+    elif config == "C4":
+        init_fun = model_factory.get_waveflow_model(8, base_spline_degree=6, i_spline_degree=6, n_prior_internal_knots=23,
+                                                    n_i_internal_knots=23, i_spline_reg=0.05, n_flow_layers=3, box_size=10.0)
+        params, psi, log_pdf, _ = init_fun(42, 8)
+        om = oracle.Model(D=8, n_layers=3, box="mean", box_L=10.0, i_k=6, i_knots=23, i_reg=0.05, i_left={0: 0}, i_right={0: 1},
+                          prior="waveflow", p_k=6, p_knots=23, p_left={0: 0}, p_right={0: 0}, constr_left=tuple(range(7)))
+        flat = flatten_params(params)
+        x = sorted_walkers(4096, 8, 10.0, 4321)
+    else:   # C1
+        mt = model_factory.get_masked_transform
+        init = flows.MFlow(flows.Serial(*(flows.IMADE(mt(), spline_degree=5, n_internal_knots=9, spline_regularization=0.05,
+                                                      reverse_fun_tol=1e-6), flows.Reverse()) * 3),
+                           mt(), spline_degree=3, n_internal_knots=15)
+        params, log_pdf, _ = init(0, 2)
+        om = oracle.Model(D=2, n_layers=3, i_k=5, i_knots=9, i_reg=0.05, prior="mflow", p_k=3, p_knots=15)
+        flat = flatten_params(params)
+        x = np.load(os.path.join(GOLDEN, "circles_x256.npy")).astype(np.float32)
+    try:
+        log_pdf.model.set_kernel(kernel)
+    except Exception as e:
+        pytest.skip(str(e))
+    lp = log_pdf(params, x)
+    lp32, _, _ = om.log_pdf_cond(flat, x, threads=thr)
+    lp64, cond, _ = om.log_pdf_cond(flat, x, threads=thr, f64=True)
+    strict_on_well_conditioned_subset(lp, lp32, lp64, cond, what=f"{config} {kernel}")
+    as_accurate_as_fp32_reference(lp, lp32, lp64, what=f"{config} {kernel}")
+
+
+def test_c4_eight_electron_chain_at_its_real_size():
+    """BASELINE configs[3]: D = 8, 2^18 walkers, through size-independent properties (no reference system exists: SURVEY 8d) and an
+    oracle comparison of a 4096-walker sample of the same batch."""
+    torch = _torch()
+    from waveflow_amd import model_factory, flatten_params
+    init_fun = model_factory.get_waveflow_model(8, base_spline_degree=6, i_spline_degree=6, n_prior_internal_knots=23,
+                                                n_i_internal_knots=23, i_spline_reg=0.05, n_flow_layers=3, box_size=10.0)
+    params, psi, log_pdf, _ = init_fun(42, 8)
+    log_pdf.model.set_kernel("mfma")
+    B = 1 << 18
+    xn = sorted_walkers(B, 8, 10.0, 1234)
+    x = torch.from_numpy(xn).cuda()
+    lp, u = log_pdf(params, x, return_sample=True)
+    ps = psi(params, x)
+    assert torch.isfinite(lp).all() and torch.isfinite(ps).all()
+    assert (u >= 0).all() and (u <= 1).all()                       # the latent point lies in the unit cube
+    mask = ps.abs() > 1e-3 * ps.abs().max()
+    d = (torch.log(ps[mask].double() ** 2) - lp[mask].double()).abs()
+    assert d.median().item() < 1e-3                                 # log_pdf == log psi^2 away from the 1e-7 floors
+    perm = torch.randperm(B, device="cuda", generator=torch.Generator(device="cuda").manual_seed(0))
+    assert torch.equal(log_pdf(params, x[perm]), lp[perm])          # batch-order independence, bit for bit
+    assert torch.equal(log_pdf(params, x), lp)                      # launch-to-launch reproducibility
+    sel = np.arange(0, B, 64)
+    om = oracle.Model(D=8, n_layers=3, box="mean", box_L=10.0, i_k=6, i_knots=23, i_reg=0.05, i_left={0: 0}, i_right={0: 1},
+                      prior="waveflow", p_k=6, p_knots=23, p_left={0: 0}, p_right={0: 0}, constr_left=tuple(range(7)))
+    flat = flatten_params(params)
+    as_accurate_as_fp32_reference(lp[torch.from_numpy(sel).cuda()].cpu().numpy(), om.log_pdf(flat, xn[sel], threads=8),
+                                  om.log_pdf(flat, xn[sel], threads=8, f64=True), what="C4 2^18 sample")
+
+
+def test_prior_quotient_switch_reproduces_the_reference_form(he_flat):
+    """WF_PRIOR_QUOTIENT=1 (read at model creation): the MFMA kernel divides the prior head's raw outputs by their signed sum before
+    the boundary rows are zeroed and the vector is normalised (model_factory.py:69), instead of carrying the sign separately.  Same
+    function in real arithmetic: the two forms agree with each other and with the oracle to fp32 rounding."""
+    import os
+    os.environ["WF_PRIOR_QUOTIENT"] = "1"
+    try:
+        params, psi, log_pdf, om = he_models(he_flat, "mfma")
+    finally:
+        os.environ.pop("WF_PRIOR_QUOTIENT", None)
+    params2, psi2, log_pdf2, _ = he_models(he_flat, "mfma")
+    x = sorted_walkers(50000, 2, 10.0, 77)
+    a, b = psi(params, x), psi2(params2, x)
+    assert not np.array_equal(a, b)                      # a different rounding pattern: the switch is live
+    assert np.abs(a - b).max() < 2e-5 * np.abs(b).max()
+    lp32 = om.log_pdf(he_flat, x, threads=8)
+    lp64 = om.log_pdf(he_flat, x, threads=8, f64=True)
+    as_accurate_as_fp32_reference(log_pdf(params, x), lp32, lp64, what="quotient form")
+    as_accurate_as_fp32_reference(log_pdf2(params2, x), lp32, lp64, what="sign form")
 
 
 def test_abi_error_paths(he_flat):
