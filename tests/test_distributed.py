@@ -137,3 +137,50 @@ def test_gradient_collective_is_noop_without_group():
     g, s = torch.ones(5), torch.tensor([1.0, 2.0, 3.0], dtype=torch.float64)
     g2, s2 = wfd.all_reduce_gradient_and_moments(g, s)
     assert g2 is g and s2 is s and wfd.global_count(17, "cpu") == 17
+
+
+def _c5_worker(rank, world, port, n_total, n_params, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = wfd.shard_bounds(n_total, rank, world)
+        # the walkers' stand-in payload is a function of the global row index: every rank can form its shard without the others
+        idx = np.arange(lo, hi, dtype=np.float64)
+        e = np.sin(idx * 1e-3) - 1.8
+        sums = torch.tensor([e.sum(), (e ** 2).sum(), float(hi - lo)], dtype=torch.float64)
+        n_global = wfd.global_count(hi - lo, "cpu")
+        grad = torch.full((n_params,), float(hi - lo) / n_global, dtype=torch.float32)   # shard weight: sums to 1 over the ranks
+        grad2, sums2 = wfd.all_reduce_gradient_and_moments(grad, sums)
+        q.put((rank, (lo, hi), n_global, float(grad2.min()), float(grad2.max()), sums2.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_config5_eight_ranks_ragged_shards_of_2pow23_rows():
+    """BASELINE configs[4] on CPU (gloo, world 8): 2^23 + 3 rows cut into ragged contiguous shards, one packed all-reduce of
+    [gradient, sum E, sum E^2, n]; every rank ends with the global triple, the shard weights add up to 1."""
+    world, n_total, n_params = 8, (1 << 23) + 3, 32588
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_c5_worker, args=(r, world, port, n_total, n_params, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    rows = [r[1] for r in res]
+    assert rows[0][0] == 0 and rows[-1][1] == n_total and all(a[1] == b[0] for a, b in zip(rows, rows[1:]))
+    sizes = [hi - lo for lo, hi in rows]
+    assert max(sizes) - min(sizes) == 1          # ragged by one row
+    idx = np.arange(n_total, dtype=np.float64)
+    e = np.sin(idx * 1e-3) - 1.8
+    want = [e.sum(), (e ** 2).sum(), float(n_total)]
+    for rank, _, n_global, gmin, gmax, sums in res:
+        assert n_global == n_total and sums[2] == n_total
+        assert abs(sums[0] - want[0]) <= 1e-11 * abs(want[0]) and abs(sums[1] - want[1]) <= 1e-11 * want[1]
+        assert abs(gmin - 1.0) < 1e-6 and abs(gmax - 1.0) < 1e-6
+    assert all(r[5] == res[0][5] for r in res)    # identical on every rank

@@ -394,6 +394,59 @@ def test_two_rank_training_keeps_replicas_identical(tmp_path):
     assert np.array_equal(p0, p1) and np.array_equal(l0, l1)
     assert np.isfinite(p0).all() and np.isfinite(l0).all() and len(l0) == 25
     assert (tmp_path / "run" / "checkpoints").exists()
+    # the walkers really are sharded: a single process with the same settings draws all 300 walkers of a step from ONE sampler
+    # stream, the two ranks draw 150 each from their own streams, so the loss traces differ (round 1 passed the default process
+    # group on as "no group" and every rank silently trained the whole batch: the traces were then identical)
+    single = tmp_path / "single"
+    single.mkdir()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_two_rank_train.py"), str(single), "25", "300"],
+                       env=dict(os.environ, WF_TEST_BACKEND="none"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    ls = np.load(single / "loss_rank0.npy")
+    assert len(ls) == 25 and not np.array_equal(ls, l0)
+    assert abs(np.mean(ls) - np.mean(l0)) < 5 * (np.std(ls) + np.std(l0)) / np.sqrt(25) + 1.0
+
+
+def test_rccl_single_rank_training_and_bench(tmp_path):
+    """RCCL itself (backend "nccl"), with the one rank this box has: the sharded training step wf_vqmc_train_step_local -> all-reduce of
+    the packed [gradient, sum E, sum E^2, n] buffer -> wf_vqmc_train_step_apply, issued call by call and captured in a hipGraph with the
+    collective inside (WF_GRAPH_COLLECTIVE=1), and bench.py's distributed path (WF_FORCE_DIST=1)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+
+    def port():
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        p = sock.getsockname()[1]
+        sock.close()
+        return p
+
+    out = {}
+    for gc in ("0", "1"):
+        d = tmp_path / f"gc{gc}"
+        d.mkdir()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+               "--master-port", str(port()), os.path.join(ROOT, "tests", "_two_rank_train.py"), str(d), "25", "256"]
+        r = subprocess.run(cmd, env=dict(os.environ, WF_TEST_BACKEND="nccl", WF_GRAPH_COLLECTIVE=gc, HSA_ENABLE_IPC_MODE_LEGACY="0"),
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        out[gc] = (np.load(d / "params_rank0.npy"), np.load(d / "loss_rank0.npy"))
+        assert np.isfinite(out[gc][0]).all() and np.isfinite(out[gc][1]).all() and len(out[gc][1]) == 25
+    # the captured sequence (collective included) replays the same arithmetic as the three calls
+    assert np.array_equal(out["0"][0], out["1"][0]) and np.array_equal(out["0"][1], out["1"][1])
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--batch", "65536",
+                        "--no-cpu-baseline", "--no-extras"],
+                       env=dict(os.environ, WF_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port()), HSA_ENABLE_IPC_MODE_LEGACY="0"),
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1
+    d = json.loads(line[0])
+    assert d["rccl_ranks"] == 1 and d["dist_backend"] == "nccl" and d["n_gpus"] == 1
 
 
 def test_abi_error_paths_of_the_gradient_entry_points(he_flat):

@@ -150,6 +150,8 @@ class ModelTrainer:
         stream, and the step's single all-reduce (gradient + energy moments) keeps the replicas identical; rank 0 writes."""
         import torch.distributed as dist
         distributed = dist.is_available() and dist.is_initialized()
+        if distributed and group is None:
+            group = dist.group.WORLD   # (None would read as "not distributed" further down: the default group, explicitly)
         rank = dist.get_rank(group) if distributed else 0
         world = dist.get_world_size(group) if distributed else 1
         local_batch = (self.batch_size * (rank + 1)) // world - (self.batch_size * rank) // world
@@ -261,10 +263,10 @@ class ModelTrainer:
                     with torch.cuda.graph(graph, stream=side):
                         step()
                 replay = graph.replay
-            except Exception:
-                if group is None:
-                    raise
-                replay = step   # collective not capturable on this stack: call by call
+            except Exception as e:
+                # a failed capture leaves the side stream in an undefined capture state: no silent fallback to call-by-call
+                raise RuntimeError("hipGraph capture of the training step failed" + (" (WF_GRAPH_COLLECTIVE=1: the RCCL all-reduce inside "
+                                   "the graph; unset it to issue the three calls per step instead)" if group is not None else "")) from e
             torch.cuda.current_stream(model.device).wait_stream(side)
         fetched = [start_epoch]   # losses of the epochs up to here are on the host
 
