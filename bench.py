@@ -26,9 +26,9 @@ PEAK_F32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA = f32 vect
 PEAK_F16_MATRIX_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16 / bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0
 # Executed matrix-core work per eval (He, 23 knots): per 32-walker tile and net 36 v_mfma_f32_32x32x16_f16 (two hidden blocks and one
-# output block of 12 each: 3 split products x 4 K steps; dimension 0 is table-driven and issues none), x 4 nets = 144 of 32768 FLOP,
-# plus 24 v_mfma_f32_32x32x2_f32 of 4096 FLOP (input layer 2 per net, ob_to_b product of the prior 16).
-MFMA_F16_PER_TILE, MFMA_F32_PER_TILE = 144, 24
+# output block of 12 each: 3 split products x 4 K steps; dimension 0 is table-driven and issues none), x 4 nets = 144, + 6 for the
+# ob_to_b product of the prior = 150 of 32768 FLOP, plus 8 v_mfma_f32_32x32x2_f32 of 4096 FLOP (input layer, 2 per net).
+MFMA_F16_PER_TILE, MFMA_F32_PER_TILE = 150, 8
 MFMA_FLOP_PER_EVAL = (MFMA_F16_PER_TILE * 32768 + MFMA_F32_PER_TILE * 4096) / 32
 # HBM bytes of one 2^20-walker log_pdf launch from the PMC passes of this command (separate rocprofv3 --pmc runs, scratch/pmc.sh):
 # FETCH_SIZE 8893 KB + WRITE_SIZE 4096 KB.  The walker read is 8 B per lane, not the 16 B-per-lane stream the guide's x2 FETCH_SIZE
@@ -94,7 +94,7 @@ def extra_legs(model, flat):
     m33 = seeded_model(2, 33, "mfma")
     x = sorted_uniform(1 << 20, 2, 1234).cuda()
     ms = kernel_ms(m33, x)
-    out["variant_33knot"] = {"evals_per_s": (1 << 20) / (ms * 1e-3), "kernel_ms": ms, "kernel": "k_mfma<2,2,8,1>",
+    out["variant_33knot"] = {"evals_per_s": (1 << 20) / (ms * 1e-3), "kernel_ms": ms, "kernel": "k_mfma<2,2,16,1>",
                              "workload": "He, 33 knots (32 intervals), 2^20 walkers, seeded parameters"}
     del m33
     # C2: the reference's batch size, one call (shipped checkpoint); AUTO routes it to the wave kernel
@@ -295,7 +295,7 @@ def main():
                          "kernel_ms": kern_ms, "executed_mfma_flop_per_eval": MFMA_FLOP_PER_EVAL,
                          "algorithmic_flop_per_eval": FLOP_PER_EVAL, "algorithmic_tflops": k_evals_s * FLOP_PER_EVAL / 1e12,
                          "algorithmic_frac_of_f32_matrix_peak": k_evals_s * FLOP_PER_EVAL / 1e12 / PEAK_F32_MATRIX_TFLOPS,
-                         "note": "achieved = executed matrix FLOP (144 v_mfma_f32_32x32x16_f16 + 24 v_mfma_f32_32x32x2_f32 per 32-walker tile; "
+                         "note": "achieved = executed matrix FLOP (150 v_mfma_f32_32x32x16_f16 + 8 v_mfma_f32_32x32x2_f32 per 32-walker tile; "
                                  "fp32-accurate products are three f16 MFMA products of 2-way split operands) / mean HIP-event kernel time; "
                                  "peak = dense f16 MFMA.  The kernel is bound by vector issue (activations, splines), not by the matrix "
                                  "cores: DESIGN.md 4.1.  algorithmic_* = SURVEY 8d's 63 232 FLOP per eval against the f32 matrix peak."},

@@ -44,6 +44,7 @@ WF_MFMA_EXTERN(2, 1, 8, 2); WF_MFMA_EXTERN(2, 1, 4, 2);
 WF_MFMA_EXTERN(3, 1, 8, 1); WF_MFMA_EXTERN(4, 1, 8, 1); WF_MFMA_EXTERN(8, 1, 8, 1);
 WF_MFMA_EXTERN(5, 1, 8, 1); WF_MFMA_EXTERN(6, 1, 8, 1); WF_MFMA_EXTERN(7, 1, 8, 1);
 WF_MFMA_EXTERN(2, 2, 8, 1); WF_MFMA_EXTERN(3, 2, 8, 1); WF_MFMA_EXTERN(4, 2, 8, 1);
+WF_MFMA_EXTERN(2, 2, 12, 1); WF_MFMA_EXTERN(2, 2, 16, 1);
 #undef WF_MFMA_EXTERN
 }  // namespace mfma
 
@@ -260,13 +261,18 @@ int launch_mfma(int D, int nbk, const MfmaDev* mdev, int lds_bytes, int mode, co
             case 5: GO(5, 1, 8);
             case 6: GO(6, 1, 8);
             case 7: GO(7, 1, 8);
-            case 8: GO(8, 1, 8);
+            case 8: GO(8, 1, 8);   // (16 waves: 0.62 ms against 0.45 ms at 2^18 walkers -- register spills)
             default: return WF_ERR_UNSUPPORTED;
         }
     }
     if (nbk == 2) {
         switch (D) {
-            case 2: GO(2, 2, 8);
+            case 2:
+                switch (waves_per_group(1)) {
+                    case 8: GO(2, 2, 8);
+                    case 12: GO(2, 2, 12);
+                    default: GO(2, 2, 16);
+                }
             case 3: GO(3, 2, 8);
             case 4: GO(4, 2, 8);
             default: return WF_ERR_UNSUPPORTED;

@@ -4,6 +4,8 @@
 namespace wf {
 namespace mfma {
 template int launch_dw<2, 2, 8, 1>(const MfmaDev*, int, int, const float*, int64_t, float*, float*, int32_t*, hipStream_t);
+template int launch_dw<2, 2, 12, 1>(const MfmaDev*, int, int, const float*, int64_t, float*, float*, int32_t*, hipStream_t);
+template int launch_dw<2, 2, 16, 1>(const MfmaDev*, int, int, const float*, int64_t, float*, float*, int32_t*, hipStream_t);
 template int launch_dw<3, 2, 8, 1>(const MfmaDev*, int, int, const float*, int64_t, float*, float*, int32_t*, hipStream_t);
 template int launch_dw<4, 2, 8, 1>(const MfmaDev*, int, int, const float*, int64_t, float*, float*, int32_t*, hipStream_t);
 }  // namespace mfma
