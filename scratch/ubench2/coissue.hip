@@ -16,7 +16,7 @@ using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 #define OPS : "+v"(acc), "+v"(a), "+v"(b), "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(f4), "+v"(f5), "+v"(f6), "+v"(f7) : "v"(c0), "v"(c1)
 
 enum { P_MFMA = 0, P_MFMA_F2, P_MFMA_F4, P_MFMA_F6, P_MFMA_F8, P_MFMA_E1, P_MFMA_E2, P_MFMA_E4, P_MFMA_E1F3, P_MFMA_E2F2, P_VALU8, P_EXP8, P_IDLE,
-       P_CHAIN12_THEN_VALU48, P_MIX48, P_COUNT };
+       P_CHAIN12_THEN_VALU48, P_MIX48, P_TV_GROUPED, P_TV_ALT, P_TV_ALT2, P_COUNT };
 
 template <int P>
 __device__ __forceinline__ void body(f32x16& acc, f16x8& a, f16x8& b, float& f0, float& f1, float& f2, float& f3, float& f4, float& f5,
@@ -39,6 +39,10 @@ __device__ __forceinline__ void body(f32x16& acc, f16x8& a, f16x8& b, float& f0,
     if constexpr (P == P_VALU8) asm volatile(FMA(3) FMA(4) FMA(5) FMA(6) FMA(7) FMA(8) FMA(9) FMA(10) FMA(3) FMA(4) FMA(5) FMA(6) FMA(7) FMA(8) FMA(9) FMA(10) OPS);
     if constexpr (P == P_EXP8) asm volatile(EXP(3) EXP(4) EXP(5) EXP(6) EXP(7) EXP(8) EXP(9) EXP(10) EXP(3) EXP(4) EXP(5) EXP(6) EXP(7) EXP(8) EXP(9) EXP(10) OPS);
     if constexpr (P == P_IDLE) asm volatile("s_nop 0" OPS);
+    // 8 transcendentals + 8 plain VALU, grouped / alternating / two plain per transcendental (16 exp + 32 fma would be the activation mix)
+    if constexpr (P == P_TV_GROUPED) asm volatile(EXP(3) EXP(4) EXP(5) EXP(6) EXP(7) EXP(8) EXP(9) EXP(10) FMA(3) FMA(4) FMA(5) FMA(6) FMA(7) FMA(8) FMA(9) FMA(10) OPS);
+    if constexpr (P == P_TV_ALT) asm volatile(EXP(3) FMA(7) EXP(4) FMA(8) EXP(5) FMA(9) EXP(6) FMA(10) EXP(7) FMA(3) EXP(8) FMA(4) EXP(9) FMA(5) EXP(10) FMA(6) OPS);
+    if constexpr (P == P_TV_ALT2) asm volatile(EXP(3) FMA(7) FMA(8) EXP(4) FMA(9) FMA(10) EXP(5) FMA(7) FMA(8) EXP(6) FMA(9) FMA(10) EXP(3) FMA(7) FMA(8) EXP(4) FMA(9) FMA(10) EXP(5) FMA(7) FMA(8) EXP(6) FMA(9) FMA(10) OPS);
     // what the shipped kernel does: a dependent chain of 12 MFMAs, then 48 VALU (8 of them transcendental), no interleave
     if constexpr (P == P_CHAIN12_THEN_VALU48)
         asm volatile(MF MF MF MF MF MF MF MF MF MF MF MF
@@ -128,6 +132,15 @@ int main() {
     run<P_MFMA_E2F2, P_IDLE>("mfma + 2 exp + 2 fma", 4, it, 4, 1);
     run<P_VALU8, P_IDLE>("16 fma", 4, it, 16, 1);
     run<P_EXP8, P_IDLE>("16 exp", 4, it, 16, 1);
+    run<P_TV_GROUPED, P_IDLE>("8 exp then 8 fma", 4, it, 16, 1);
+    run<P_TV_ALT, P_IDLE>("exp fma alternating x8", 4, it, 16, 1);
+    run<P_TV_ALT2, P_IDLE>("exp fma fma x8", 4, it, 24, 1);
+    run<P_TV_GROUPED, P_TV_GROUPED>("8 exp then 8 fma, 2 waves/SIMD", 8, it, 16, 16);
+    run<P_TV_ALT, P_TV_ALT>("exp fma alternating, 2 waves/SIMD", 8, it, 16, 16);
+    run<P_TV_GROUPED, P_TV_GROUPED>("8 exp then 8 fma, 4 waves/SIMD", 16, it, 16, 16);
+    run<P_TV_ALT, P_TV_ALT>("exp fma alternating, 4 waves/SIMD", 16, it, 16, 16);
+    run<P_EXP8, P_EXP8>("16 exp, 4 waves/SIMD", 16, it, 16, 16);
+    run<P_VALU8, P_VALU8>("16 fma, 4 waves/SIMD", 16, it, 16, 16);
     run<P_CHAIN12_THEN_VALU48, P_IDLE>("12 mfma then 48 valu (1 wave/SIMD)", 4, it, 12, 1);
     run<P_MIX48, P_IDLE>("12 mfma mixed 48 valu (1 wave/SIMD)", 4, it, 12, 1);
     // two waves per SIMD, different roles

@@ -669,7 +669,8 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
                             // sum first, as model_factory.py:69 does (same function in real arithmetic, a different fp32 rounding pattern).
                             amax = xhalf_max(amax);
                             const int ex = amax > 0.0f ? __builtin_amdgcn_frexp_expf(amax) : 0;
-                            const float qs = mm.prior_quotient ? 1.0f / s1 : 1.0f;
+                            // one multiplier per walker: the power of two (exact, same as ldexp) or, in quotient mode, 1 / sum
+                            const float scale = mm.prior_quotient ? 1.0f / s1 : __builtin_amdgcn_ldexpf(1.0f, -ex);
                             Frag of[NBK];
 #pragma unroll
                             for (int kb = 0; kb < NBK; ++kb)
@@ -677,10 +678,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
                                 for (int s = 0; s < 2; ++s) {
                                     float r8[8];
 #pragma unroll
-                                    for (int jj = 0; jj < 8; ++jj) {
-                                        const float vq = mm.prior_quotient ? o[kb][t][8 * s + jj] * qs : o[kb][t][8 * s + jj];
-                                        r8[jj] = __builtin_amdgcn_ldexpf(vq, mm.prior_quotient ? 0 : -ex);
-                                    }
+                                    for (int jj = 0; jj < 8; ++jj) r8[jj] = o[kb][t][8 * s + jj] * scale;
                                     split8(r8, of[kb].hi[s], of[kb].lo[s]);
                                 }
                             f32x16 c[NBK];
