@@ -177,7 +177,8 @@ int wf_inverse_fwd(const wf_model* m, const float* u_dev, int64_t B, float* x_de
 /* sample(rng, params, num_samples) of Waveflow (wavefunctions.py:74-107), MFlow (distributions.py:165-190) and Flow
  * (distributions.py:104-108): column-by-column rejection sampling of the prior, then wf_inverse_fwd.  x_dev[B][D];
  * latent_dev[B][D] or NULL (`return_original_samples`).  Counter-based Philox4x32-10 keyed by (seed, walker index):
- * results are reproducible for a given seed but do not follow JAX's threefry stream (parity unpinned). */
+ * results are reproducible for a given seed but do not follow JAX's threefry stream (parity unpinned).  The rejection loop of a
+ * column is bounded (~1e5 proposals, where the reference's while_loop is not): a walker that exhausts it is written as NaN. */
 int wf_sample(const wf_model* m, uint64_t seed, int64_t B, float* x_dev, float* latent_dev, int32_t exact, void* stream);
 
 /* H psi = -1/2 laplacian(psi) + V psi of the Waveflow wavefunction: physics.construct_hamiltonian_function (utils/physics.py:79-93)

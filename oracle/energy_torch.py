@@ -224,5 +224,36 @@ def vqmc_loss_grad(model, flat, x, protons, running_average):
     return float(e_loc.mean()), g.detach().numpy(), e_loc.numpy()
 
 
+def _hpsi(model, p, x, protons):
+    xt = torch.as_tensor(np.asarray(x), dtype=model.dtype).clone().requires_grad_(True)
+    ps, lap = _psi_lap(model, p, xt)
+    V = potential(xt.detach(), torch.as_tensor(np.asarray(protons, dtype=np.float64).reshape(-1), dtype=model.dtype))
+    return ps, -0.5 * lap + V * ps, xt
+
+
+def uniform_loss_grad(model, flat, x, protons):
+    """value_and_grad of loss_fn_uniform (vqmc.py:143-154): mean(psi * H psi) / stop_gradient(mean(psi^2)), plain autograd."""
+    p = torch.as_tensor(np.asarray(flat, dtype=np.float32)).to(model.dtype).clone().requires_grad_(True)
+    ps, hpsi, _ = _hpsi(model, p, x, protons)
+    loss = (ps * hpsi).mean() / (ps ** 2).mean().detach()
+    (g,) = torch.autograd.grad(loss, p)
+    return float(loss), g.detach().numpy()
+
+
+def train_step_gradients(model, flat, x, protons, running_average, clip=10.0):
+    """The gradient vqmc.train_step hands to the optimiser (vqmc.py:169-187), plain autograd of the reference's expressions:
+    grad of mean(H psi / psi)  +  mean_b[ d log_pdf_b * (E_b / psi_b - running_average) ], clipped to [-10, 10];
+    loss = mean(clip(E / psi, -100, 100)).  -> (gradient [n_params], loss)"""
+    p = torch.as_tensor(np.asarray(flat, dtype=np.float32)).to(model.dtype).clone().requires_grad_(True)
+    ps, hpsi, xt = _hpsi(model, p, x, protons)
+    ne = hpsi / ps
+    (ge,) = torch.autograd.grad(ne.mean(), p)
+    w = ((ne - running_average) / len(ne)).detach()
+    (gp,) = torch.autograd.grad((w * model.log_pdf(p, xt.detach())).sum(), p)
+    loss = float(torch.clamp(ne.detach(), -100, 100).mean())
+    g = ge + gp
+    return (torch.clamp(g, -clip, clip) if clip is not None else g).detach().numpy(), loss
+
+
 def he_model(dtype=torch.float64):
     return TorchWaveflow(2, 3, "mean", 10.0, 6, 23, 0.05, (0,), dtype=dtype)

@@ -110,10 +110,15 @@ def test_training_reduces_the_energy_and_writes_the_reference_artefacts(tmp_path
     assert np.load(f"{sd}/outputs/wavefunctions_2d/values_epoch300.npy").shape == (10000,)
     assert np.load(f"{sd}/outputs/sample_points/values_epoch150.npy").shape == (250, 2)
     assert len(np.load(f"{sd}/loss.npy")) == 300
-    # restart continues from the checkpoint (epoch counter and parameters)
+    # restart continues from the checkpoint (epoch counter, parameters and Adam's moments: optimizer_state.npz of the same epoch)
+    opt = np.load(f"{sd}/optimizer_state.npz")
+    assert int(opt["epoch"]) == 300 and opt["m"].shape == opt["v"].shape and np.abs(opt["m"]).max() > 0 and opt["v"].min() >= 0
     t2 = vqmc.ModelTrainer(system_name="He", learning_rate=1e-3, box_length=10, num_epochs=20, batch_size=512, log_every=10)
     t2.save_dir, t2.exact_sampler = sd, True
-    params2, loss2 = t2.start_training(restart=True, verbose=False)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")          # "moments restart from zero" would be raised here
+        params2, loss2 = t2.start_training(restart=True, verbose=False)
     assert len(loss2) == len(np.load(f"{sd}/loss.npy")) + 1 or len(loss2) >= 320
     assert np.median(loss2[-20:]) < np.median(l[:50])
     assert checkpoint.load_reference_checkpoint(f"{sd}/checkpoints")[1] == 320
@@ -132,6 +137,54 @@ def test_training_with_more_than_32_bases(tmp_path):
     assert (t.psi.model.i_nb, t.psi.model.p_nb) == (39, 38)
     assert np.isfinite(l).all() and len(l) == 150
     assert np.median(l[-30:]) < 0.5 * np.median(l[:30])
+
+
+def test_train_step_and_train_step_uniform_vs_autograd_oracle(golden, he_flat):
+    """vqmc.py:143-187: the two older training steps; the oracle differentiates the reference's loss expressions with autograd."""
+    import torch
+    from oracle import energy_torch as et
+    from waveflow_amd import flatten_params, vqmc
+    from waveflow_amd.utils import physics
+    params, psi, log_pdf, sample = he(he_flat)
+    protons, _ = physics.system_catalogue[1]["He"]
+    h_fn = physics.construct_hamiltonian_function(psi, protons=protons, n_space_dimensions=1, eps=0.0)
+    mo = et.he_model(torch.float64)
+    x = np.sort(golden["he_golden"]["sample_points"], -1)[:160].astype(np.float32)
+    # E / psi and its derivative blow up where psi vanishes (loss_fn has no 1e-8 guard): keep walkers with a sizeable amplitude
+    _, ps0, _ = et.hamiltonian(mo, he_flat, x.astype(np.float64), protons.reshape(-1))
+    x = x[np.abs(ps0) > 0.05 * np.abs(ps0).max()]
+    assert x.shape[0] > 64
+
+    # --- train_step_uniform
+    loss, grad = vqmc.loss_and_grad_uniform(params, psi, h_fn, x)
+    lo, go = et.uniform_loss_grad(mo, he_flat, x.astype(np.float64), protons.reshape(-1))
+    assert abs(loss - lo) < 1e-4 * max(1.0, abs(lo)), (loss, lo)
+    assert abs(vqmc.loss_fn_uniform(params, psi, h_fn, x) - lo) < 1e-4 * max(1.0, abs(lo))
+    assert rel_l2(grad.cpu().numpy().astype(np.float64), go) < 5e-3
+
+    # --- train_step
+    g, loss = vqmc.train_step_gradients(params, psi, h_fn, log_pdf, x, running_average=-2.0)
+    go, lo = et.train_step_gradients(mo, he_flat, x.astype(np.float64), protons.reshape(-1), -2.0)
+    assert abs(loss - lo) < 2e-3 * max(1.0, abs(lo)), (loss, lo)
+    g = g.cpu().numpy().astype(np.float64)
+    assert np.abs(g).max() <= 10.0
+    assert rel_l2(g, go) < 1e-2, rel_l2(g, go)
+    gu, _ = vqmc.train_step_gradients(params, psi, h_fn, log_pdf, x, running_average=-2.0, clip=None)
+    gou, _ = et.train_step_gradients(mo, he_flat, x.astype(np.float64), protons.reshape(-1), -2.0, clip=None)
+    assert rel_l2(gu.cpu().numpy().astype(np.float64), gou) < 1e-2
+    lv, (e, p) = vqmc.loss_fn(params, psi, h_fn, x)
+    assert e.shape == p.shape == (x.shape[0], 1) and abs(lv - float((e / p).mean())) < 1e-6
+
+    # --- the optimiser protocol: both steps move the parameters and return (state, loss)
+    opt_init, opt_update, get_params = vqmc.adam(1e-3, model=psi.model)
+    st = opt_init(params)
+    before = flatten_params(params).copy()
+    st, l1 = vqmc.train_step(0, psi, h_fn, log_pdf, opt_update, st, get_params, x, -2.0)
+    st, l2 = vqmc.train_step_uniform(1, psi, h_fn, opt_update, st, get_params, x)
+    after = st.x.cpu().numpy()
+    assert np.isfinite(l1) and np.isfinite(l2) and np.isfinite(after).all()
+    moved = np.abs(after - before)
+    assert 0 < moved.max() < 5e-3     # two Adam steps of size 1e-3
 
 
 def test_loss_fn_efficient_value_matches_sums(he_flat):

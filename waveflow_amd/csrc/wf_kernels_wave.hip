@@ -1062,10 +1062,11 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(WF_OCC_SAMP
                     // first accepted one in sequence order is taken (same distribution as proposing one by one; the acceptance
                     // rate of the reference's bound is 4-6 %, i.e. ~20 sequential table reads per column otherwise).  Each lane
                     // evaluates the whole spline at its own point: the column's coefficients come from LDS, two table rows per lane.
-                    // Bounded (1563 rounds ~ 1e5 proposals): a pathological density cannot hang the GPU.
+                    // Bounded (1563 rounds ~ 1e5 proposals): a pathological density cannot hang the GPU; a walker that exhausts
+                    // the bound comes out as NaN (its later columns, its x and every batch sum over it), not as a plausible 0.5.
                     put(ov, lane, R1{cj});
                     const float* __restrict__ cw = &ov[0][NBK == 1 ? hd * 32 : 0];
-                    float xs = 0.5f;
+                    float xs = __builtin_nanf("");
                     for (int round = 0; round < 1563; ++round) {
                         scalar::Philox prop(seed, (unsigned long long)b);
                         prop.c0 = (unsigned)(round * 64 + lane);

@@ -564,8 +564,9 @@ __global__ __launch_bounds__(Cfg<NBP>::kBlock) void k_sample(const ModelDev* __r
                     for (int j = 1; j < nb; ++j) mx = fmaxf(mx, SCR(j));
                     ymax = mx * (float)(nb + sp.degree);   // params.max() * n_knots (msplines_jax.py:147-150)
                 }
-                // rejection sampling (bounded: a pathological density cannot hang the GPU)
-                float xs = 0.5f;
+                // rejection sampling (bounded: a pathological density cannot hang the GPU; a walker that exhausts the bound is
+                // written as NaN -- visible in every later reduction -- rather than parked at a plausible 0.5)
+                float xs = __builtin_nanf("");
                 for (int it = 0; it < 100000; ++it) {
                     const float xc = rng.uniform(), yc = rng.uniform() * ymax;
                     const Lerp L = make_lerp(xc, sp.n_mesh);

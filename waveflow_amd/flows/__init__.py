@@ -96,10 +96,11 @@ class SerialSpec:
 
 
 def _desc(D, layers=(), box=None, prior=_lib.PRIOR_UNIFORM, p_degree=0, p_knots=0, p_left=None, p_right=None,
-          normal_offset=0.0, constrained_left=(), n_mesh=2000):
-    """Fill a wf_model_desc from specs.  `layers`: list of identical IMADESpec or MADESpec."""
+          normal_offset=0.0, constrained_left=(), n_mesh=None):
+    """Fill a wf_model_desc from specs.  `layers`: list of identical IMADESpec or MADESpec.  `n_mesh`: the prior spline's mesh
+    (n_spline_base_mesh_points); wf_model_desc carries ONE mesh size for the layers' and the prior's tables."""
     d = _lib.ModelDesc()
-    d.n_dim, d.hidden, d.n_flow_layers, d.n_mesh = D, HIDDEN, len(layers), n_mesh
+    d.n_dim, d.hidden, d.n_flow_layers, d.n_mesh = D, HIDDEN, len(layers), (2000 if n_mesh is None else int(n_mesh))
     d.layer_kind = _lib.LAYER_IMADE
     if layers:
         first = layers[0]
@@ -109,6 +110,9 @@ def _desc(D, layers=(), box=None, prior=_lib.PRIOR_UNIFORM, p_degree=0, p_knots=
             d.layer_kind = _lib.LAYER_IMADE
             d.i_degree, d.i_knots, d.i_reg = first.degree, first.knots, first.reg
             d.i_left, d.i_right = _lib.BC.from_dict(first.left), _lib.BC.from_dict(first.right)
+            if n_mesh is not None and int(n_mesh) != int(first.n_mesh) and prior in (_lib.PRIOR_WAVEFLOW, _lib.PRIOR_MFLOW):
+                raise NotImplementedError(f"prior spline mesh ({n_mesh} points) != flow-layer spline mesh ({first.n_mesh}): the fused "
+                                          "model keeps one mesh size; build the two with equal n_spline_base_mesh_points")
             d.n_mesh = first.n_mesh
             d.i_reverse_tol = float(first.tol) if first.tol is not None else 0.0
         else:

@@ -120,6 +120,125 @@ def train_step_efficient(epoch, psi, h_fn, opt_update, opt_state, params, batch,
     return opt_update(epoch, gradients, opt_state), loss_val
 
 
+def _energy_terms(params, psi, h_fn, batch):
+    """One forward sweep: (model, x on the device, H psi, psi, laplacian) as float32 cuda vectors."""
+    model = psi.model
+    model.ensure_params(params)
+    pos = getattr(h_fn, "protons", None)
+    if pos is None:
+        raise TypeError("h_fn must come from waveflow_amd.utils.physics.construct_hamiltonian_function")
+    x, _ = model._to_dev(batch)
+    hpsi, ps, lap = model.hamiltonian(x, pos, return_psi=True, return_laplacian=True)
+    return model, x, hpsi, ps, lap
+
+
+def _reduce_scalars(values, device, group):
+    """SUM all-reduce of a few python floats (fp64 on the wire) -> list of floats; the identity without a group."""
+    import torch
+    from .distributed import all_reduce_moments
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    return all_reduce_moments(t, group).cpu().tolist()
+
+
+def _reduce_gradient(grad, group):
+    import torch
+    from .distributed import all_reduce_gradient_and_moments
+    g, _ = all_reduce_gradient_and_moments(grad, torch.zeros(3, dtype=torch.float64, device=grad.device), group)
+    return g
+
+
+def loss_fn_uniform(params, psi, h_fn, batch):
+    """vqmc.py:143-148: mean(psi * H psi) / mean(psi^2) over a uniformly drawn batch (value only; the gradient treats the
+    denominator as a constant, see train_step_uniform)."""
+    p = helpers._np(psi(params, batch)).reshape(-1, 1).astype(np.float64)
+    e = helpers._np(h_fn(params, batch)).reshape(-1, 1).astype(np.float64)
+    return float((p * e).mean() / (p * p).mean())
+
+
+def loss_and_grad_uniform(params, psi, h_fn, batch, group=None):
+    """value_and_grad(loss_fn_uniform) (vqmc.py:150-154) on the HIP path.  With H psi = -1/2 lap + V psi and the denominator
+    Z = mean(psi^2) under stop_gradient,
+        d loss = 1 / (n Z) * sum_b [ (H psi_b + V_b psi_b) d psi_b  -  1/2 psi_b d lap_b ],     V_b psi_b = H psi_b + 1/2 lap_b
+    (no division by psi), which is one wf_psi_vjp.  Several ranks: n and Z are global (one small all-reduce), then the gradient."""
+    model, x, hpsi, ps, lap = _energy_terms(params, psi, h_fn, batch)
+    d = ps.double()
+    num, den, n = _reduce_scalars([float((d * hpsi.double()).sum()), float((d * d).sum()), float(x.shape[0])], x.device, group)
+    z = den / n
+    scale = 1.0 / (n * z)
+    w_psi = (2.0 * hpsi + 0.5 * lap) * scale
+    w_lap = ps * (-0.5 * scale)
+    grad = _reduce_gradient(model.psi_vjp(x, w_psi, w_lap), group)
+    return (num / n) / z, grad
+
+
+def train_step_uniform(epoch, psi, h_fn, opt_update, opt_state, get_params, batch, group=None):
+    """vqmc.py:150-154 -> (new opt_state, loss)"""
+    loss_val, gradients = loss_and_grad_uniform(get_params(opt_state), psi, h_fn, batch, group=group)
+    return opt_update(epoch, gradients, opt_state), loss_val
+
+
+def loss_fn(params, psi, h_fn, batch):
+    """vqmc.py:157-161 -> (mean of H psi / psi, (H psi [B, 1], psi [B, 1]))"""
+    p = helpers._np(psi(params, batch)).reshape(-1, 1)
+    e = helpers._np(h_fn(params, batch)).reshape(-1, 1)
+    return float((e / p).mean()), (e, p)
+
+
+def train_step_gradients(params, psi, h_fn, log_pdf, batch, running_average, group=None, clip=10.0):
+    """The gradient and loss of vqmc.train_step (vqmc.py:172-187) before the optimiser:
+        energy part   grad of mean(H psi / psi) -- true derivative through psi and through the Laplacian:
+                      d (E / psi) = -1/2 d lap / psi + (V / psi - E / psi^2) d psi = -1/(2 psi) d lap + lap / (2 psi^2) d psi
+        density part  mean_b [ d log_pdf_b * (E_b / psi_b - running_average) ]   (the jacrev of the reference, contracted)
+    summed, then clipped elementwise to [-clip, clip] (the reference's 10; None: unclipped, for tests); loss = mean of E / psi clipped to [-100, 100].
+    -> (flat gradient float32 cuda [n_params], loss)"""
+    import torch
+    if getattr(log_pdf, "model", None) is not psi.model:
+        raise ValueError("psi and log_pdf must be the two closures of one model (model_factory init_fun)")
+    model, x, hpsi, ps, lap = _energy_terms(params, psi, h_fn, batch)
+    ne = hpsi / ps
+    loss_sum, n = _reduce_scalars([float(torch.clamp(ne, -100.0, 100.0).double().sum()), float(x.shape[0])], x.device, group)
+    inv = 1.0 / n
+    w_psi = 0.5 * lap / (ps * ps) * inv
+    w_lap = -0.5 / ps * inv
+    grad = model.psi_vjp(x, w_psi, w_lap)
+    grad = grad + model.logpdf_vjp(x, (ne - float(np.asarray(running_average).reshape(-1)[0])) * inv)
+    grad = _reduce_gradient(grad, group)
+    return (torch.clamp(grad, -clip, clip) if clip is not None else grad), loss_sum / n
+
+
+def train_step(epoch, psi, h_fn, log_pdf, opt_update, opt_state, get_params, batch, running_average, group=None):
+    """vqmc.py:169-187 -> (new opt_state, loss)"""
+    gradients, loss_val = train_step_gradients(get_params(opt_state), psi, h_fn, log_pdf, batch, running_average, group=group)
+    return opt_update(epoch, gradients, opt_state), loss_val
+
+
+def _save_optimizer_state(save_dir, opt_state, epoch):
+    """Adam's moments next to the reference's artefacts (the reference checkpoints parameters only, vqmc.py:96-100, and a restart
+    there begins with a fresh optimiser): `optimizer_state.npz` {m, v, epoch}, rewritten at every checkpoint."""
+    m, v = (t.detach().cpu().numpy() if hasattr(t, "detach") else np.asarray(t) for t in (opt_state.m, opt_state.v))
+    tmp = f"{save_dir}/optimizer_state.tmp.npz"
+    np.savez(tmp, m=m, v=v, epoch=np.int64(epoch))
+    os.replace(tmp, f"{save_dir}/optimizer_state.npz")
+
+
+def _load_optimizer_state(save_dir, opt_state, epoch):
+    """-> True when the moments of exactly this checkpoint epoch were restored."""
+    path = f"{save_dir}/optimizer_state.npz"
+    if not os.path.isfile(path):
+        return False
+    with np.load(path) as z:
+        if int(z["epoch"]) != int(epoch) or z["m"].shape != tuple(opt_state.m.shape):
+            return False
+        m, v = z["m"].astype(np.float32), z["v"].astype(np.float32)
+    if opt_state.on_device:
+        import torch
+        opt_state.m.copy_(torch.as_tensor(m))
+        opt_state.v.copy_(torch.as_tensor(v))
+    else:
+        opt_state.m, opt_state.v = m, v
+    return True
+
+
 class ModelTrainer:
     """vqmc.py:19-119, same constructor arguments, attributes and on-disk artefacts."""
 
@@ -171,6 +290,11 @@ class ModelTrainer:
             import torch
             opt_state.x.copy_(torch.as_tensor(flatten_params(params).astype(np.float32)))
             opt_state.version += 1
+            if not _load_optimizer_state(save_dir, opt_state, start_epoch):
+                # (a directory written by the reference, or by an older run): the moments restart from zero while the step index
+                # -- and with it Adam's bias correction -- continues, so the first ~10 steps are up to 3x the nominal size
+                import warnings
+                warnings.warn(f"{save_dir}/optimizer_state.npz does not match checkpoint epoch {start_epoch}: Adam moments restart from zero")
             loss = np.load(f'{save_dir}/loss.npy').tolist()
             energies = np.load(f'{save_dir}/energies.npy').tolist()
         params = get_params(opt_state)
@@ -201,6 +325,7 @@ class ModelTrainer:
             ckpt_seed, step_seed = int(rng.integers(1 << 31)), int(rng.integers(1 << 31))   # same host stream on every rank
             if (epoch % self.log_every == 0 or epoch == 1) and rank == 0:
                 helpers.create_checkpoint_wavefunc(ckpt_seed, save_dir, psi, sample, params, epoch, loss, energies, system_dict)
+                _save_optimizer_state(save_dir, opt_state, epoch)
             batch = sample(step_seed + 7919 * rank, params, local_batch, exact_inverse=self.exact_sampler)
             opt_state, new_loss = train_step_efficient(epoch, psi, h_fn, opt_update, opt_state, params, batch, running_average,
                                                        group=group)
@@ -288,6 +413,7 @@ class ModelTrainer:
                 ckpt_seed = int(rng.integers(1 << 31))   # (drawn on every rank: the host streams stay aligned)
                 if rank == 0:
                     helpers.create_checkpoint_wavefunc(ckpt_seed, save_dir, psi, sample, params, epoch, loss, energies, system_dict)
+                    _save_optimizer_state(save_dir, opt_state, epoch)   # (fetch() above synchronised: m, v are those after epoch - 1)
                 model.set_params_device(opt_state.x)
             replay()
             if epoch % 100 == 0:
