@@ -237,7 +237,7 @@ def uniform_loss_grad(model, flat, x, protons):
     ps, hpsi, _ = _hpsi(model, p, x, protons)
     loss = (ps * hpsi).mean() / (ps ** 2).mean().detach()
     (g,) = torch.autograd.grad(loss, p)
-    return float(loss), g.detach().numpy()
+    return float(loss.detach()), g.detach().numpy()
 
 
 def train_step_gradients(model, flat, x, protons, running_average, clip=10.0):

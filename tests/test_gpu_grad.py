@@ -531,12 +531,23 @@ def test_abi_error_paths_of_the_gradient_entry_points(he_flat):
     assert L.wf_psi_vjp_workspace_bytes(lp2.model._h, 8) == -2
     xs = torch.rand(8, 2, device="cuda") * 0.8 + 0.1
     assert torch.isfinite(lp2.model.logpdf_vjp(xs, w)).all()
-    # general (non-zeroing) constraint dictionaries: forward works, gradients are not built
-    p3, lp3, _ = model_factory.get_model(n_flow_layers=1, i_constraint_dict_left={0: 0.0, 1: 0.0}, i_constraint_dict_right={0: 1.0})(0, 2)
-    lp3.model.ensure_params(p3)
-    assert np.isfinite(lp3(p3, xs.cpu().numpy())).all()
+    # general homogeneous constraint dictionaries (derivative orders > 0, every value 0 -- tests/test_boundary_constraints.py:30-31 style):
+    # the table-driven kernels carry the boundary map in their tables, gradients included (fp64 finite differences of the C oracle)
+    import oracle
+    p3, lp3, _ = model_factory.get_model(n_flow_layers=1, i_constraint_dict_left={0: 0.0, 2: 0.0, 3: 0.0}, i_constraint_dict_right={0: 1.0},
+                                         prior_constraint_dict_left={0: 0, 2: 0})(0, 2)
+    om3 = oracle.Model(D=2, n_layers=1, i_k=5, i_knots=15, i_reg=0.0, i_left={0: 0.0, 2: 0.0, 3: 0.0}, i_right={0: 1.0}, prior="mflow", p_k=5,
+                       p_knots=15, p_left={0: 0.0, 2: 0.0}, p_right={})
+    X3 = (np.random.default_rng(8).random((96, 2)) * 0.9 + 0.05).astype(np.float32)
+    _directional_check(lp3, p3, om3, X3, seed=12)
+    # a constraint with a non-zero value adds a constant term to the map: the per-walker kernel evaluates it, gradients are not built
+    p4, lp4, _ = model_factory.get_model(n_flow_layers=1, i_constraint_dict_left={0: 0.0, 1: 0.5}, i_constraint_dict_right={0: 1.0})(0, 2)
+    lp4.model.ensure_params(p4)
+    assert np.isfinite(lp4(p4, xs.cpu().numpy())).all()
     with pytest.raises(_lib.WfError):
-        lp3.model.logpdf_vjp(xs, w)
+        lp4.model.logpdf_vjp(xs, w)
+    with pytest.raises(_lib.WfError):
+        lp4.model.set_kernel("mfma")
 
 
 def test_model_without_flow_layers(he_flat):

@@ -81,6 +81,7 @@ struct ModelDev {
     SplineDev isp;                // flow-layer I-spline (IMADE)
     SplineDev psp;                // prior spline: orthogonal-B (WAVEFLOW) or M (MFLOW)
     const float* ob_to_b;         // [nbp][nbp] fp32, zero beyond nb (WAVEFLOW): row a = ob_to_b[a][:]
+    const float* ob_to_b_t;       // the same with the boundary map folded into its rows (wf_model.cpp: bc_map): table-driven kernels
     const float* b_to_ob;         // [nbp][nbp] fp32, zero beyond nb (WAVEFLOW): the sampler's bound (bsplines_jax.py:164-166)
     float reverse_tol;            // IMADE reverse_fun_tol
     NetPlain nets[kMaxNets];      // flow layers 0..n_layers-1, then the prior net
@@ -118,7 +119,8 @@ bool mfma_shape_built(int D, int nbk);
 int mfma_extra_lds_floats(int n_nets);
 int dim0_coef_floats(int n_nets);
 int launch_fold_bias(float* image_dev, int n_nets, int net_floats, int D, int nbk, void* stream);
-int launch_prepare_dim0(const ModelDev* md_dev, int n_nets, int n_mesh, const float* fk_nat_dev, float F_I, float F_P, void* comp_dev,
+int launch_prepare_dim0(const ModelDev* md_dev, int n_nets, int n_mesh, const float* fk_nat_dev, float F_I, float F_P, const float* tab_i_dev,
+                        const float* tab_p_dev, void* comp_dev,
                         void* stream);
 
 // ---- kernel launchers (wf_kernels_*.hip).  mode: 0 = log_pdf, 1 = psi, 2 = flow only (u, logdet)

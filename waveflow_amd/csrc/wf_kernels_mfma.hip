@@ -75,7 +75,7 @@ __global__ __launch_bounds__(64) void k_dim0_coeffs(const ModelDev* __restrict__
         const float* keep = fk_nat + 64;
         float c = 0.0f;
         if (t < nb)
-            for (int a = 0; a < nb; ++a) c = __builtin_fmaf(net.b2[a] * keep[a], md.ob_to_b[a * nbp + t], c);
+            for (int a = 0; a < nb; ++a) c = __builtin_fmaf(net.b2[a] * keep[a], md.ob_to_b_t[a * nbp + t], c);
         sh[t] = c;
         out[t] = c;
         __syncthreads();
@@ -117,7 +117,10 @@ __device__ __forceinline__ float row_dot(const float* __restrict__ row, const fl
     return acc;
 }
 
-__global__ void k_prepare_dim0(const ModelDev* __restrict__ mdp, int nm, const float* __restrict__ coef, f32x4* __restrict__ comp) {
+// tab_i / tab_p: the natural-order tables [orders][n_mesh][nbp] with the boundary map folded into their rows (wf_model.cpp: bc_map; the
+// wave kernels' d_tabI4 / d_tabP3) -- identical to ModelDev's plain ones when the constraints only zero end coefficients
+__global__ void k_prepare_dim0(const ModelDev* __restrict__ mdp, int nm, const float* __restrict__ coef, const float* __restrict__ tab_i,
+                               const float* __restrict__ tab_p, f32x4* __restrict__ comp) {
     const ModelDev& md = *mdp;
     const int n_nets = md.n_layers + ((md.prior_kind == WF_PRIOR_WAVEFLOW || md.prior_kind == WF_PRIOR_MFLOW) ? 1 : 0);
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -132,12 +135,13 @@ __global__ void k_prepare_dim0(const ModelDev* __restrict__ mdp, int nm, const f
     } else if (is_prior && md.prior_kind == WF_PRIOR_WAVEFLOW) {
         const SplineDev& sp = md.psp;
         const int nb = sp.nb, nbp = sp.nbp;
-        out[0] = (c[64] < 0.0f ? -row_dot(sp.tab + (size_t)m * nbp, c, nb) : row_dot(sp.tab + (size_t)m * nbp, c, nb)) * __builtin_amdgcn_rsqf(c[65]);
+        out[0] = (c[64] < 0.0f ? -row_dot(tab_p + (size_t)m * nbp, c, nb) : row_dot(tab_p + (size_t)m * nbp, c, nb)) * __builtin_amdgcn_rsqf(c[65]);
     } else {
         const SplineDev& sp = is_prior ? md.psp : md.isp;
+        const float* __restrict__ tab = is_prior ? tab_p : tab_i;
         const int nb = sp.nb, nbp = sp.nbp;
-        out[0] = row_dot(sp.tab + (size_t)m * nbp, c, nb) * c[64];
-        if (!is_prior) out[1] = row_dot(sp.tab + ((size_t)sp.n_mesh + m) * nbp, c, nb) * c[64];
+        out[0] = row_dot(tab + (size_t)m * nbp, c, nb) * c[64];
+        if (!is_prior) out[1] = row_dot(tab + ((size_t)sp.n_mesh + m) * nbp, c, nb) * c[64];
     }
     comp[gid] = out;
 }
@@ -222,15 +226,15 @@ int launch_fold_bias(float* image_dev, int n_nets, int net_floats, int D, int nb
     return WF_OK;
 }
 
-int launch_prepare_dim0(const ModelDev* md_dev, int n_nets, int n_mesh, const float* fk_nat_dev, float F_I, float F_P, void* comp_dev,
-                        void* stream) {
+int launch_prepare_dim0(const ModelDev* md_dev, int n_nets, int n_mesh, const float* fk_nat_dev, float F_I, float F_P, const float* tab_i_dev,
+                        const float* tab_p_dev, void* comp_dev, void* stream) {
     const int total = n_nets * n_mesh;
     if (total <= 0) return WF_OK;
     // the coefficient block sits behind the tables in the same allocation (wf_model.cpp reserves dim0_coef_floats)
     float* coef = reinterpret_cast<float*>(comp_dev) + (size_t)total * 4;
     hipLaunchKernelGGL(k_dim0_coeffs, dim3(n_nets), dim3(64), 0, (hipStream_t)stream, md_dev, fk_nat_dev, F_I, F_P, coef);
     hipLaunchKernelGGL(k_prepare_dim0, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, md_dev, n_mesh, (const float*)coef,
-                       reinterpret_cast<f32x4*>(comp_dev));
+                       tab_i_dev, tab_p_dev, reinterpret_cast<f32x4*>(comp_dev));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_hip_error((int)e);

@@ -462,7 +462,7 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(kOccFwd<T>,
                 lerp4<W>(tabP, plane, lp, j, t);
                 T val;
                 if (md.prior_kind == WF_PRIOR_WAVEFLOW) {
-                    const PsiHead<T> hd = psi_head<T, NBK>(o, valid, valid_d, kP[j], md.ob_to_b, ov, lane);
+                    const PsiHead<T> hd = psi_head<T, NBK>(o, valid, valid_d, kP[j], md.ob_to_b_t, ov, lane);
                     val = rsum<NBK>(hd.e * lift(t, 0, uc));
                 } else {
                     const SigHead<T> hd = sigmoid_head<T, NBK>(o, valid, valid_d, kP[j], 0.0f);
@@ -738,13 +738,13 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(kOccBwd<T>,
                 const T gv = sel(dl == 0, gv_lo, gv_hi);
                 T go, d1;
                 if (md.prior_kind == WF_PRIOR_WAVEFLOW) {
-                    const PsiHead<T> hd = psi_head<T, NBK>(o, valid, valid_d, kP[j], md.ob_to_b, ov, lane);
+                    const PsiHead<T> hd = psi_head<T, NBK>(o, valid, valid_d, kP[j], md.ob_to_b_t, ov, lane);
                     const T ge = gv * lift(t, 0, uc);
                     const T dotE = rsum<NBK>(ge * hd.e);
                     d1 = rsum<NBK>(hd.e * lift(t, 1, uc));
                     const T gc = (ge - hd.e * dotE) * hd.rN2;
                     put(ov, lane, gc);
-                    const T ga = gemv32_rows<T, NBK>(md.ob_to_b, ov, dl, j);          // abar_a = sum_j cbar_j ob_to_b[a][j]
+                    const T ga = gemv32_rows<T, NBK>(md.ob_to_b_t, ov, dl, j);          // abar_a = sum_j cbar_j ob_to_b[a][j]
                     const T dotA = rsum<NBK>(ga * hd.a);
                     go = ((ga - hd.a * dotA) * hd.rN1) * (valid ? kP[j] * hd.sgn : 0.0f);
                 } else {
@@ -1048,7 +1048,7 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(WF_OCC_SAMP
                     };
                     if (wavefn) {
                         // sample_fun (bsplines_jax.py:144-171): obw = normalised(w @ ob_to_b); ymax = max((obw @ b_to_ob)^2)
-                        const PsiHead<R1> hdw = psi_head<R1, NBK>(o, valid, valid_d, kP[j], md.ob_to_b, ov, lane);
+                        const PsiHead<R1> hdw = psi_head<R1, NBK>(o, valid, valid_d, kP[j], md.ob_to_b_t, ov, lane);
                         cj = hdw.e.c0;
                         put(ov, lane, hdw.e);
                         const float q = gemv32_cols<R1, NBK>(md.b_to_ob, ov, dl, j).c0;

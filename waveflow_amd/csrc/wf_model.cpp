@@ -93,7 +93,11 @@ struct wf_model {
     int64_t scratch_floats = 0;
     float* d_wave = nullptr;         // NetWave images
     float* d_grad_fk = nullptr;      // [2][64] natural-order row factors for the reverse pass (flow rows, prior rows)
-    bool wave_ok = false;            // the wave-cooperative sweeps cover this model (zero-only constraints; > 32 bases: D <= 4)
+    bool wave_ok = false;            // the wave-cooperative sweeps cover this model (homogeneous constraints; > 32 bases: D <= 4)
+    // boundary conditions as a linear map on the coefficient vector (bc_map below): column sums a~ of A, per spline (I layers / prior);
+    // bc_*_ok: homogeneous (no constant term) and every column with a~_j == 0 is entirely zero -> the table-driven kernels apply
+    std::vector<double> bc_i_colsum, bc_p_colsum;
+    bool bc_i_ok = true, bc_p_ok = true;
     bool grad_psi_ok = false;        // wf_psi_vjp (Waveflow prior, IMADE layers)
     int ring2 = 2;                   // coefficient ring of the second-order sweeps (ring_coefs, wf_internal.h): 2 = RF, 1 = R3
     int32_t* d_grad_map = nullptr;   // [n_params]: forward-image entry (over all nets) that holds each parameter, -1 = none
@@ -147,6 +151,71 @@ static void fill_bc(SplineDev& s, const wf_bc& left, const wf_bc& right, const s
         for (int j = 0; j < nd; ++j) s.right_prev[p][j] = T(nd, nb - j - 1, n_mesh - 1);
         s.right_value[p] = T(nd, nb - nd - 1, n_mesh - 1);
     }
+}
+
+// ---- boundary conditions as a linear map.  enforce_boundary_conditions (isplines_jax.py:166-190, msplines_jax.py:155-180,
+// bsplines_jax.py:176-189) overwrites coefficient nd (left) / nb-1-nd (right) of every constraint {nd: value} with
+// (value - sum_{j<nd} T^(nd)_j(end) c_j) / T^(nd)_nd(end), in dictionary order, before the final normalisation: c' = A c + b with A, b
+// fixed per model.  With b == 0 (every value 0; the I-spline's right {0: 1} zeroes the last coefficient, isplines_jax.py:174-179) the
+// normalised spline  sum_j c'_j T_j(x) / sum_j c'_j  equals  sum_j (c_j a~_j) T^_j(x) / sum_j (c_j a~_j)  with a~ = A^T 1 (column sums)
+// and T^_j = (A^T T)_j / a~_j: the same expression the kernels evaluate for "zero the first / last coefficient" (a~ in {0, 1}, T^ = T),
+// so the table-driven kernels (MFMA, wave sweeps, gradients) cover every homogeneous dictionary through their tables and row factors
+// alone.  The per-walker scalar kernel keeps the literal sequence (enforce_bc, wf_scalar_impl.h) and also covers b != 0.
+static void bc_apply(const SplineDev& s, int kind, int nb, std::vector<double>& c) {
+    for (int p = 0; p < s.n_left; ++p) {
+        const int nd = s.left_nd[p];
+        double sum = 0;
+        for (int j = 0; j < nd; ++j) sum += (double)s.left_prev[p][j] * c[j];
+        c[nd] = ((double)s.left_val[p] - sum) / (double)s.left_value[p];
+    }
+    for (int p = 0; p < s.n_right; ++p) {
+        const int nd = s.right_nd[p];
+        if (kind == WF_SPLINE_I && nd == 0) { c[nb - 1] = 0.0; continue; }
+        double sum = 0;
+        for (int j = 0; j < nd; ++j) sum += (double)s.right_prev[p][j] * c[nb - 1 - j];
+        c[nb - nd - 1] = ((double)s.right_val[p] - sum) / (double)s.right_value[p];
+    }
+}
+// -> A [nb][nb] (c' = A c), column sums; false when the map has a constant term or a column that sums to zero without being zero
+static bool bc_map(const SplineDev& s, int kind, int nb, std::vector<double>& A, std::vector<double>& colsum) {
+    A.assign((size_t)nb * nb, 0.0);
+    colsum.assign(nb, 0.0);
+    std::vector<double> c(nb, 0.0);
+    bc_apply(s, kind, nb, c);
+    bool ok = true;
+    for (int i = 0; i < nb; ++i) ok = ok && c[i] == 0.0;
+    for (int j = 0; j < nb; ++j) {
+        std::vector<double> e(nb, 0.0);
+        e[j] = 1.0;
+        bc_apply(s, kind, nb, e);
+        bool all_zero = true;
+        for (int i = 0; i < nb; ++i) {
+            const double a = e[i] - c[i];
+            A[(size_t)i * nb + j] = a;
+            colsum[j] += a;
+            all_zero = all_zero && a == 0.0;
+        }
+        if (all_zero) colsum[j] = 0.0;
+        else if (std::fabs(colsum[j]) < 1e-9) ok = false;
+    }
+    return ok;
+}
+// rows of a table indexed by the coefficient ([orders][nb][n_mesh] fp64, or [nb][cols] with n_mesh := cols, orders := 1): X^_j = (A^T X)_j / a~_j
+static void bc_transform_rows(const std::vector<double>& A, const std::vector<double>& colsum, int nb, int orders, int n_mesh, std::vector<double>& t) {
+    std::vector<double> out(t.size(), 0.0);
+    for (int nd = 0; nd < orders; ++nd)
+        for (int j = 0; j < nb; ++j) {
+            if (colsum[j] == 0.0) continue;
+            double* o = &out[((size_t)nd * nb + j) * n_mesh];
+            for (int i = 0; i < nb; ++i) {
+                const double a = A[(size_t)i * nb + j];
+                if (a == 0.0) continue;
+                const double* src = &t[((size_t)nd * nb + i) * n_mesh];
+                for (int m = 0; m < n_mesh; ++m) o[m] += a * src[m];
+            }
+            for (int m = 0; m < n_mesh; ++m) o[m] /= colsum[j];
+        }
+    t.swap(out);
 }
 
 template <class T>
@@ -240,13 +309,18 @@ static int model_build(wf_model* m) {
         rc = upload_table(m, rows, &md.isp.tab);
         if (rc) return rc;
         md.isp.nb = nb; md.isp.nbp = m->nbp; md.isp.n_mesh = d.n_mesh; md.isp.degree = d.i_degree;
+        fill_bc(md.isp, d.i_left, d.i_right, t64, nb, d.n_mesh);
+        {   // the table-driven kernels read the rows with the boundary map folded in (identical rows for zero-only constraints)
+            std::vector<double> A;
+            m->bc_i_ok = bc_map(md.isp, WF_SPLINE_I, nb, A, m->bc_i_colsum);
+            if (m->bc_i_ok) bc_transform_rows(A, m->bc_i_colsum, nb, 4, d.n_mesh, t64);
+        }
         {   // derivative orders 0..3 for the wave kernels
             std::vector<float> rows4;
             pack_rows(t64, nb, d.n_mesh, 4, m->nbp, rows4);
             rc = upload_table(m, rows4, &m->d_tabI4);
             if (rc) return rc;
         }
-        fill_bc(md.isp, d.i_left, d.i_right, t64, nb, d.n_mesh);
         m->i_nb = nb;
         keep_i64.swap(t64);
     }
@@ -280,6 +354,15 @@ static int model_build(wf_model* m) {
             for (int j = 0; j < nb; ++j) o2b32[(size_t)a * m->nbp + j] = (float)o2b[(size_t)a * nb + j];
         rc = upload_table(m, o2b32, &md.ob_to_b);
         if (rc) return rc;
+        {   // the constraints act on the net's outputs w before c = w @ ob_to_b: fold the map into the matrix's rows (row a = coefficient a)
+            std::vector<double> A;
+            m->bc_p_ok = bc_map(md.psp, WF_SPLINE_B, nb, A, m->bc_p_colsum);
+            if (m->bc_p_ok) bc_transform_rows(A, m->bc_p_colsum, nb, 1, nb, o2b);
+            for (int a = 0; a < nb; ++a)
+                for (int j = 0; j < nb; ++j) o2b32[(size_t)a * m->nbp + j] = (float)o2b[(size_t)a * nb + j];
+            rc = upload_table(m, o2b32, &md.ob_to_b_t);
+            if (rc) return rc;
+        }
         std::vector<float> b2o32((size_t)m->nbp * m->nbp, 0.0f);
         for (int a = 0; a < nb; ++a)
             for (int j = 0; j < nb; ++j) b2o32[(size_t)a * m->nbp + j] = (float)b2o[(size_t)a * nb + j];
@@ -304,13 +387,18 @@ static int model_build(wf_model* m) {
         rc = upload_table(m, rows, &md.psp.tab);
         if (rc) return rc;
         md.psp.nb = nb; md.psp.nbp = m->nbp; md.psp.n_mesh = d.n_mesh; md.psp.degree = d.p_degree;
+        fill_bc(md.psp, d.p_left, d.p_right, t64, nb, d.n_mesh);
+        {
+            std::vector<double> A;
+            m->bc_p_ok = bc_map(md.psp, WF_SPLINE_M, nb, A, m->bc_p_colsum);
+            if (m->bc_p_ok) bc_transform_rows(A, m->bc_p_colsum, nb, 4, d.n_mesh, t64);
+        }
         {
             std::vector<float> rows4;
             pack_rows(t64, nb, d.n_mesh, 4, m->nbp, rows4);
             rc = upload_table(m, rows4, &m->d_tabP3);
             if (rc) return rc;
         }
-        fill_bc(md.psp, d.p_left, d.p_right, t64, nb, d.n_mesh);
         m->p_nb = nb;
         keep_p64.swap(t64);
     }
@@ -489,20 +577,9 @@ static int mfma_net_floats(int D, int nbk) {
     return 128 * S0 + 64 + 4096 + 64 + (D - 1) * nbk * 2048 + 32 * D * nbk;
 }
 
-// all constraints are {0: 0} (or the I-spline's right {0: 1}): they only zero the first / last weight
-static bool bc_only_zeroes(const wf_bc& left, const wf_bc& right, bool is_I) {
-    for (int p = 0; p < left.n; ++p)
-        if (left.n_derivative[p] != 0 || left.value[p] != 0.0f) return false;
-    for (int p = 0; p < right.n; ++p) {
-        if (right.n_derivative[p] != 0) return false;
-        if (is_I ? right.value[p] != 1.0f : right.value[p] != 0.0f) return false;
-    }
-    return true;
-}
-
 // per-row factor: remove_bias scaling (isplines_jax.py:196-202 / msplines_jax.py:186-192) times the
 // 0/1 "kept by the boundary conditions" mask; 0 beyond the real bases.  Layout [half][16] in accumulator order.
-static void row_factors(int kind, bool with_remove_bias, int k, int nb, int nbk, const wf_bc& left, const wf_bc& right, float* out_acc,
+static void row_factors(int kind, bool with_remove_bias, int k, int nb, int nbk, const std::vector<double>& bc_colsum, float* out_acc,
                         float* natural64 = nullptr) {
     std::vector<float> f(64, 0.0f);
     for (int j = 0; j < nb; ++j) f[j] = 1.0f;
@@ -514,8 +591,7 @@ static void row_factors(int kind, bool with_remove_bias, int k, int nb, int nbk,
             f[a] *= fac;
             f[b] *= fac;
         }
-    if (left.n > 0) f[0] = 0.0f;
-    if (right.n > 0) f[nb - 1] = 0.0f;
+    for (int j = 0; j < nb; ++j) f[j] = (float)((double)f[j] * bc_colsum[j]);   // a~ of bc_map: 0 / 1 for zero-only constraints
     for (int kb = 0; kb < nbk; ++kb)
         for (int h = 0; h < 2; ++h)
             for (int r = 0; r < 16; ++r) out_acc[(kb * 2 + h) * 16 + r] = f[32 * kb + acc_row(r, h)];
@@ -621,9 +697,9 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
     const int nbk = m->nbp / 32;
     if (!mfma_shape_built(D, nbk)) return WF_OK;
     const bool imade = d.layer_kind == WF_LAYER_IMADE && d.n_flow_layers > 0;
-    if (imade && !bc_only_zeroes(d.i_left, d.i_right, true)) return WF_OK;
+    if (imade && !m->bc_i_ok) return WF_OK;
     const bool spline_prior = d.prior_kind == WF_PRIOR_WAVEFLOW || d.prior_kind == WF_PRIOR_MFLOW;
-    if (spline_prior && !bc_only_zeroes(d.p_left, d.p_right, false)) return WF_OK;
+    if (spline_prior && !m->bc_p_ok) return WF_OK;
     const int n_nets = (int)m->nets.size();
     const int consts = 64 * nbk + nbk * nbk * 1024;
     const int net_floats = mfma_net_floats(D, nbk);
@@ -648,7 +724,7 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
     std::vector<float> fk_nat(128, 0.0f);
     if (imade) {
         float* fk = m->mfma_consts.data();
-        row_factors(WF_SPLINE_I, true, d.i_degree, m->i_nb, nbk, d.i_left, d.i_right, fk, fk_nat.data());
+        row_factors(WF_SPLINE_I, true, d.i_degree, m->i_nb, nbk, m->bc_i_colsum, fk, fk_nat.data());
         double F = 0;
         for (int i = 0; i < 32 * nbk; ++i) F += fk[i];
         md.F_I = (float)F;
@@ -662,7 +738,7 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
     if (spline_prior) {
         const bool mflow = d.prior_kind == WF_PRIOR_MFLOW;
         float* fk = m->mfma_consts.data() + 32 * nbk;
-        row_factors(mflow ? WF_SPLINE_M : WF_SPLINE_B, mflow, d.p_degree, m->p_nb, nbk, d.p_left, d.p_right, fk, fk_nat.data() + 64);
+        row_factors(mflow ? WF_SPLINE_M : WF_SPLINE_B, mflow, d.p_degree, m->p_nb, nbk, m->bc_p_colsum, fk, fk_nat.data() + 64);
         double F = 0;
         for (int i = 0; i < 32 * nbk; ++i) F += fk[i];
         md.F_P = (float)F;
@@ -717,9 +793,9 @@ static bool wave_capable(const wf_model* m) {
     const wf_model_desc& d = m->desc;
     if (!m->d_wave || (m->nbp == 64 && d.n_dim > 4)) return false;   // (the 64-row sweeps are built for D <= 4)
     const bool imade = d.layer_kind == WF_LAYER_IMADE && d.n_flow_layers > 0;
-    if (imade && (!m->d_tabI4 || !bc_only_zeroes(d.i_left, d.i_right, true))) return false;
+    if (imade && (!m->d_tabI4 || !m->bc_i_ok)) return false;
     const bool spline_prior = d.prior_kind == WF_PRIOR_WAVEFLOW || d.prior_kind == WF_PRIOR_MFLOW;
-    if (spline_prior && (!m->d_tabP3 || !bc_only_zeroes(d.p_left, d.p_right, false))) return false;
+    if (spline_prior && (!m->d_tabP3 || !m->bc_p_ok)) return false;
     return true;
 }
 // ... which is also what the reverse pass and the local energy need (every D the library supports, 2..8, is instantiated)
@@ -765,9 +841,9 @@ static int grad_prepare(wf_model* m) {
     if (m->wave_ok) {
         std::vector<float> fk(128, 0.0f), acc(64);
         if (d.layer_kind == WF_LAYER_IMADE && d.n_flow_layers > 0)
-            row_factors(WF_SPLINE_I, true, d.i_degree, m->i_nb, m->nbp / 32, d.i_left, d.i_right, acc.data(), fk.data());
-        if (d.prior_kind == WF_PRIOR_WAVEFLOW) row_factors(WF_SPLINE_B, false, d.p_degree, m->p_nb, m->nbp / 32, d.p_left, d.p_right, acc.data(), fk.data() + 64);
-        if (d.prior_kind == WF_PRIOR_MFLOW) row_factors(WF_SPLINE_M, true, d.p_degree, m->p_nb, m->nbp / 32, d.p_left, d.p_right, acc.data(), fk.data() + 64);
+            row_factors(WF_SPLINE_I, true, d.i_degree, m->i_nb, m->nbp / 32, m->bc_i_colsum, acc.data(), fk.data());
+        if (d.prior_kind == WF_PRIOR_WAVEFLOW) row_factors(WF_SPLINE_B, false, d.p_degree, m->p_nb, m->nbp / 32, m->bc_p_colsum, acc.data(), fk.data() + 64);
+        if (d.prior_kind == WF_PRIOR_MFLOW) row_factors(WF_SPLINE_M, true, d.p_degree, m->p_nb, m->nbp / 32, m->bc_p_colsum, acc.data(), fk.data() + 64);
         int rc = dev_alloc(m, &m->d_grad_fk, fk.size());
         if (rc) return rc;
         WF_HIP(hipMemcpy(m->d_grad_fk, fk.data(), fk.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -917,7 +993,7 @@ static int apply_params(wf_model* m, const float* flat_dev, void* stream, bool e
         int rc0 = launch_fold_bias(m->d_mfma, (int)m->nets.size(), m->mdev.net_floats, m->desc.n_dim, m->mdev.nbk, stream);
         if (rc0) return rc0;
         // composite tables of output dimension 0 (reads the plain image filled above)
-        int rc = launch_prepare_dim0(m->d_dev, (int)m->nets.size(), m->desc.n_mesh, m->d_fk_nat, m->mdev.F_I, m->mdev.F_P, m->d_comp, stream);
+        int rc = launch_prepare_dim0(m->d_dev, (int)m->nets.size(), m->desc.n_mesh, m->d_fk_nat, m->mdev.F_I, m->mdev.F_P, m->d_tabI4, m->d_tabP3, m->d_comp, stream);
         if (rc) return rc;
     }
     m->params_set = true;
