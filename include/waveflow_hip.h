@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define WF_ABI_VERSION 1
+#define WF_ABI_VERSION 2
 #define WF_MAX_DIM 16
 #define WF_MAX_BC 4
 
@@ -90,6 +90,12 @@ typedef struct {
     int32_t constrained_left[WF_MAX_DIM];
     int32_t n_mesh;             /* n_spline_base_mesh_points (2000) */
     float i_reverse_tol;        /* IMADE reverse_fun_tol (bisection tolerance of the inverse, isplines_jax.py:153-156) */
+    /* set_nn_output_grad_to_zero of the layers' / the prior's conditioner (model_factory.py:55-67, ABI 2):
+     *   bij[d][j] = g_d(x) * head(o[d][j]) + z[d][j],   g_0 = 1, g_d = prod_{i<d} x_i^3  (x: the conditioner's input),
+     * z = zero_params[d][j] (its absolute value under a sigmoid head), before the division by sum_j bij[d][j].
+     * Evaluation: the per-walker and the MFMA kernels; the wave sweeps (small batches, local energy, gradients, sampler) do not
+     * build it: those entry points return WF_ERR_UNSUPPORTED for a gated model. */
+    int32_t i_gate, p_gate;
 } wf_model_desc;
 
 typedef struct wf_model wf_model;

@@ -52,7 +52,8 @@ class _Model(ctypes.Structure):
                 ("i_reg", ctypes.c_float), ("isp", _Spline), ("prior_kind", ctypes.c_int),
                 ("normal_offset", ctypes.c_float), ("psp", _Spline), ("psp_plain", ctypes.c_void_p),
                 ("ob_to_b", ctypes.c_void_p), ("n_constr_left", ctypes.c_int),
-                ("constr_left", ctypes.c_int * MAX_D), ("reverse_tol", ctypes.c_float), ("b_to_ob", ctypes.c_void_p)]
+                ("constr_left", ctypes.c_int * MAX_D), ("reverse_tol", ctypes.c_float), ("b_to_ob", ctypes.c_void_p),
+                ("i_gate", ctypes.c_int), ("p_gate", ctypes.c_int)]
 
 
 @functools.lru_cache(None)
@@ -179,10 +180,13 @@ class Model:
 
     def __init__(self, D, n_layers, layer_kind="imade", box=None, box_L=1.0, i_k=5, i_knots=16, i_reg=0.0,
                  i_left=None, i_right=None, prior="waveflow", p_k=5, p_knots=16, p_left=None, p_right=None,
-                 constr_left=(), normal_offset=0.0, n_mesh=2000, hidden=64, reverse_tol=1e-6):
+                 constr_left=(), normal_offset=0.0, n_mesh=2000, hidden=64, reverse_tol=1e-6, i_gate=False, p_gate=False):
+        """i_gate / p_gate: set_nn_output_grad_to_zero of the layers' / the prior's conditioner (model_factory.py:64-67; the reference
+        holds no saved outputs of a gated model: that branch of the restatement is unpinned)."""
         self.D, self.n_layers, self.hidden = D, n_layers, hidden
         self.keep = []
         m = _Model()
+        m.i_gate, m.p_gate = int(bool(i_gate)), int(bool(p_gate))
         m.D, m.hidden, m.n_layers = D, hidden, n_layers
         m.layer_kind = {"imade": 0, "made": 1}[layer_kind]
         m.box_kind = {None: 0, "mean": 1, "first": 2}[box]

@@ -237,6 +237,7 @@ typedef struct {
     int constr_left[WFO_MAX_D];
     float reverse_tol;          /* IMADE reverse_fun_tol (made.py:44, isplines_jax.py:153-156) */
     const float* b_to_ob;       /* kind 0 prior: [nb][nb], used by the rejection sampler's bound (bsplines_jax.py:164-166) */
+    int i_gate, p_gate;         /* set_nn_output_grad_to_zero of the layers' / the prior's conditioner (model_factory.py:64-67) */
 } wfo_model;
 
 /* X_cached, isplines_jax.py:45-56 / msplines_jax.py:30-41 / bsplines_jax.py:19-30.
@@ -368,17 +369,26 @@ static __thread real* g_cond = 0;
 static __thread real* g_cond2 = 0;
 static inline void cond_note(real v) { if (g_cond && v < *g_cond) *g_cond = v; }
 
-/* calculate_bijection_params, model_factory.py:56-70 (set_nn_output_grad_to_zero=False):
- * bij[d][j] = o[j*D + d]; optional sigmoid; bij /= bij.sum(-1).  Returns pointer past (net, zero_params). */
-static const float* bijection_params(const float* p, int D, int H, int nb, int allow_negative, const real* x,
+/* calculate_bijection_params, model_factory.py:56-70:
+ * bij[d][j] = o[j*D + d]; optional sigmoid (then zero_params -> |zero_params|); with set_nn_output_grad_to_zero (`gate`)
+ * bij = cubed_input_product * bij + zero_params, cubed_input_product[d] = prod_{i<d} x_i^3 (roll of the cumprod, entry 0 set to 1);
+ * bij /= bij.sum(-1).  Returns pointer past (net, zero_params). */
+static const float* bijection_params(const float* p, int D, int H, int nb, int allow_negative, int gate, const real* x,
                                      real* bij /* [D][nb] */) {
     real o[WFO_MAX_D * WFO_MAX_NB];
-    const float* next = conditioner(p, D, H, nb, x, o);
+    const float* next = conditioner(p, D, H, nb, x, o);   /* next: zero_params[D][nb] */
+    real g = C(1.0);
     for (int d = 0; d < D; ++d) {
         real ss = C(0.0), sa = C(0.0);
+        if (d > 0) g = g * (x[d - 1] * x[d - 1] * x[d - 1]);
         for (int j = 0; j < nb; ++j) {
             real v = o[j * D + d];
             if (!allow_negative) v = C(1.0) / (C(1.0) + R_EXP(-v));     /* jax.nn.sigmoid */
+            if (gate) {
+                real z = (real)next[d * nb + j];
+                if (!allow_negative && z < 0) z = -z;
+                v = g * v + z;
+            }
             bij[d * nb + j] = v;
             ss = ss + v;
             sa = sa + (v < 0 ? -v : v);
@@ -393,7 +403,7 @@ static const float* bijection_params(const float* p, int D, int H, int nb, int a
 static const float* imade_direct(const wfo_model* m, const float* p, const real* x, real* y, real* logdet, int* idx) {
     int D = m->D, nb = m->isp.nb;
     real bij[WFO_MAX_D * WFO_MAX_NB];
-    const float* next = bijection_params(p, D, m->hidden, nb, 0, x, bij);
+    const float* next = bijection_params(p, D, m->hidden, nb, 0, m->i_gate, x, bij);
     real ld = C(0.0);
     for (int d = 0; d < D; ++d) {
         real* w = bij + d * nb;
@@ -488,7 +498,7 @@ static real eval_one(const wfo_model* m, const float* params, const float* xin, 
         /* wavefunctions.py:33-71 */
         int nb = m->psp.nb;
         real bij[WFO_MAX_D * WFO_MAX_NB];
-        bijection_params(pp, D, m->hidden, nb, 1, u, bij);
+        bijection_params(pp, D, m->hidden, nb, 1, m->p_gate, u, bij);
         real lp = C(0.0), prod = C(1.0);
         int* pidx = idx ? idx + (size_t)m->n_layers * D * 2 : 0;
         for (int d = 0; d < D; ++d) {
@@ -524,7 +534,7 @@ static real eval_one(const wfo_model* m, const float* params, const float* xin, 
         /* distributions.py:139-163 */
         int nb = m->psp.nb;
         real bij[WFO_MAX_D * WFO_MAX_NB];
-        bijection_params(pp, D, m->hidden, nb, 0, u, bij);
+        bijection_params(pp, D, m->hidden, nb, 0, m->p_gate, u, bij);
         real lp = C(0.0);
         int* pidx = idx ? idx + (size_t)m->n_layers * D * 2 : 0;
         for (int d = 0; d < D; ++d) {
@@ -650,7 +660,7 @@ static const float* imade_inverse(const wfo_model* m, const float* p, const real
     for (int d = 0; d < D; ++d) out[d] = C(0.0);
     for (int d = 0; d < D; ++d) {
         /* exact != 0: the true autoregressive inverse (conditioner on the reconstructed prefix) */
-        if (d == 0 || exact) next = bijection_params(p, D, m->hidden, nb, 0, exact ? out : in, bij);
+        if (d == 0 || exact) next = bijection_params(p, D, m->hidden, nb, 0, m->i_gate, exact ? out : in, bij);
         real* w = bij + d * nb;
         for (int j = 0; j < nb; ++j) w[j] = w[j] + m->i_reg;
         remove_bias(1, m->isp.k, nb, w);
@@ -728,7 +738,7 @@ int wfo_prior_column_density(const wfo_model* m, const float* params, const floa
     real o[WFO_MAX_D], bij[WFO_MAX_D * WFO_MAX_NB];
     for (int d = 0; d < D; ++d) o[d] = (real)outputs[d];
     if (m->prior_kind == 0) {
-        bijection_params(pp, D, H, nb, 1, o, bij);
+        bijection_params(pp, D, H, nb, 1, m->p_gate, o, bij);
         real* w = bij + col * nb;
         enforce_bc(&m->psp, m->psp_plain, 2, w);
         real c[WFO_MAX_NB], ss = C(0.0);
@@ -748,7 +758,7 @@ int wfo_prior_column_density(const wfo_model* m, const float* params, const floa
         *ymax_out = (float)ymax;
         for (int i = 0; i < n; ++i) { real v = spline_apply(&m->psp, 0, c, (real)xs[i], 0); dens[i] = (float)(v * v); }
     } else if (m->prior_kind == 1) {
-        bijection_params(pp, D, H, nb, 0, o, bij);
+        bijection_params(pp, D, H, nb, 0, m->p_gate, o, bij);
         real* w = bij + col * nb;
         remove_bias(0, m->psp.k, nb, w);
         enforce_bc(&m->psp, m->psp.tab, 0, w);

@@ -687,3 +687,56 @@ def test_bench_two_rank_path_on_a_shared_gpu():
     assert d["n_gpus"] == 2 and d["steps"] == 8 and d["scaling"] == "weak" and d["metric"] == "flow log-prob evals/sec"
     assert abs(d["value"] - 2 * 65536 * 8 / (d["ms_per_step"] * 8e-3)) < 1e-6 * d["value"]
     assert "cpu_baseline" not in d and d["roofline"]["bound"] == "mfma"
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_gated_conditioner_heads(kernel):
+    """set_nn_output_grad_to_zero=True (model_factory.py:64-67; tests/test_boundary_constraints.py:30-31 builds get_model with it):
+    bij = prod_{i<d} x_i^3 * head(o) + zero_params.  Oracle: the C restatement of those four lines (unpinned: the reference holds no
+    outputs of a gated model).  Density model (sigmoid heads, |zero_params|) and wavefunction (signed head)."""
+    from waveflow_amd import flows, model_factory, wavefunctions, flatten_params
+    mt = model_factory.get_masked_transform
+    il, ir, pl = {0: 0, 2: 0, 3: 0}, {0: 1}, {0: 0, 2: 0}
+    init = model_factory.get_model(i_constraint_dict_left=il, i_constraint_dict_right=ir, prior_constraint_dict_left=pl, n_flow_layers=2,
+                                   i_spline_reg=0.05, set_nn_output_grad_to_zero=True)
+    params, log_pdf, sample = init(3, 2)
+    log_pdf.model.set_kernel(kernel)
+    om = oracle.Model(D=2, n_layers=2, i_k=5, i_knots=15, i_reg=0.05, i_left=il, i_right=ir, prior="mflow", p_k=5, p_knots=15, p_left=pl,
+                      p_right={}, i_gate=True, p_gate=True)
+    g = np.random.default_rng(21)
+    x = g.random((20000, 2)).astype(np.float32)
+    flat = flatten_params(params)
+    slack = dict(tail=3.0, count=2.0) if kernel == "mfma" else {}
+    as_accurate_as_fp32_reference(log_pdf(params, x), om.log_pdf(flat, x), om.log_pdf(flat, x, f64=True), what="gated get_model", **slack)
+    # the gate is not a no-op: the ungated evaluation of the same parameters differs
+    om0 = oracle.Model(D=2, n_layers=2, i_k=5, i_knots=15, i_reg=0.05, i_left=il, i_right=ir, prior="mflow", p_k=5, p_knots=15, p_left=pl, p_right={})
+    assert np.abs(om0.log_pdf(flat, x[:256]) - om.log_pdf(flat, x[:256])).max() > 1e-2
+    # wavefunction: Waveflow's own default is set_nn_output_grad_to_zero=True (wavefunctions.py:11)
+    init = wavefunctions.Waveflow(
+        flows.Serial(flows.BoxTransformLayer(3.0), *(flows.IMADE(mt(), 6, 23, 0.05, 1e-6, set_nn_output_grad_to_zero=True), flows.Reverse()) * 2),
+        mt(allow_negative_params=True), 6, 23, constraints_dict_left={0: 0}, constraints_dict_right={0: 0}, constrained_dimension_indices_left=[0])
+    params, psi, log_pdf, _ = init(6, 2)
+    log_pdf.model.set_kernel(kernel)
+    om = oracle.Model(D=2, n_layers=2, box="mean", box_L=3.0, i_k=6, i_knots=23, i_reg=0.05, prior="waveflow", p_k=6, p_knots=23,
+                      constr_left=(0,), i_gate=True, p_gate=True)
+    x = sorted_walkers(20000, 2, 3.0, 10)
+    flat = flatten_params(params)
+    as_accurate_as_fp32_reference(log_pdf(params, x), om.log_pdf(flat, x), om.log_pdf(flat, x, f64=True), what="gated waveflow", **slack)
+    pso, pst = om.psi(flat, x), om.psi(flat, x, f64=True)
+    as_accurate_as_fp32_reference(psi(params, x), pso, pst, atol=1e-6 * np.abs(pst).max(), **slack)
+    # inverse round trip through the gated layers (scalar path: the wave sweeps do not build the gate)
+    u = log_pdf.model.flow(x[:512])[0]
+    xb = log_pdf.model.inverse(u, exact=True)
+    assert np.abs(np.asarray(xb.cpu() if hasattr(xb, "cpu") else xb) - x[:512]).max() < 2e-3 * 3.0
+    # the wave sweeps (small batches, gradients, local energy) do not build the gate: refused, never evaluated ungated
+    from waveflow_amd import _lib
+    m = log_pdf.model
+    with pytest.raises(_lib.WfError):
+        m.set_kernel("wave")
+    m.set_kernel("auto")
+    small = np.asarray(log_pdf(params, x[:100]))      # auto: a small batch goes to the per-walker kernel instead
+    np.testing.assert_allclose(small, om.log_pdf(flat, x[:100]), rtol=0, atol=5e-4)
+    with pytest.raises(_lib.WfError):
+        m.logpdf_vjp(x[:16], np.ones(16, np.float32))
+    with pytest.raises(_lib.WfError):
+        m.hamiltonian(x[:16], [0.0, 0.0])

@@ -48,7 +48,7 @@ class ModelDesc(ctypes.Structure):
                 ("i_left", BC), ("i_right", BC), ("prior_kind", ctypes.c_int32), ("p_degree", ctypes.c_int32),
                 ("p_knots", ctypes.c_int32), ("p_left", BC), ("p_right", BC), ("normal_offset", ctypes.c_float),
                 ("n_constrained_left", ctypes.c_int32), ("constrained_left", ctypes.c_int32 * WF_MAX_DIM),
-                ("n_mesh", ctypes.c_int32), ("i_reverse_tol", ctypes.c_float)]
+                ("n_mesh", ctypes.c_int32), ("i_reverse_tol", ctypes.c_float), ("i_gate", ctypes.c_int32), ("p_gate", ctypes.c_int32)]
 
 
 class TrainState(ctypes.Structure):
@@ -158,7 +158,7 @@ def lib():
     L.wf_block_sums.argtypes = [vp, i64, vp, vp, i64, vp]
     L.wf_block_sums_workspace_bytes.restype = i64
     L.wf_block_sums_workspace_bytes.argtypes = [i64]
-    if L.wf_abi_version() != 1:
+    if L.wf_abi_version() != 2:
         raise ImportError("libwaveflow_hip ABI version mismatch")
     _lib = L
     return L

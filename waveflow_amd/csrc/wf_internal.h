@@ -29,6 +29,8 @@ struct NetPlain {
     // the same masked weights in the orientation the reverse pass contracts over (wf_kernels_grad.hip)
     const float* W1n; // [64 in][64 out]   row a = weights out of hidden unit a
     const float* W2n; // [64 in][D][NBP]   row a = weights out of hidden unit a
+    // zero_params of the gated head (model_factory.py:64-67, 84): z[d][j], already |z| under a sigmoid head; zeros without the leaf
+    const float* zero; // [D][NBP]
 };
 
 // One conditioner net in MFMA operand order (see wf_kernels_mfma.hip)
@@ -84,6 +86,7 @@ struct ModelDev {
     const float* ob_to_b_t;       // the same with the boundary map folded into its rows (wf_model.cpp: bc_map): table-driven kernels
     const float* b_to_ob;         // [nbp][nbp] fp32, zero beyond nb (WAVEFLOW): the sampler's bound (bsplines_jax.py:164-166)
     float reverse_tol;            // IMADE reverse_fun_tol
+    int i_gate, p_gate;           // set_nn_output_grad_to_zero of the layers' / the prior's conditioner (wf_model_desc)
     NetPlain nets[kMaxNets];      // flow layers 0..n_layers-1, then the prior net
     NetMfma mnets[kMaxNets];
     NetWave wnets[kMaxNets];
@@ -109,6 +112,7 @@ struct MfmaDev {
     float* dbg;                // diagnostics builds only (WF_DEBUG / WF_STAMP)
     int exact_div;             // 1: x_l / n by IEEE division (set when the multiply-and-correct form is not bit-identical for this n_mesh)
     int prior_quotient;        // debug (env WF_PRIOR_QUOTIENT=1 at model creation): Waveflow prior head in the reference's quotient form
+    int i_gate, p_gate;        // gated heads (wf_model_desc.i_gate / p_gate): zero_params blocks of the net images are live
 };
 
 bool mfma_div_ok(int n_mesh);   // host check of div_by_n (wf_mfma_impl.h) against the division for every x_l in [-1, n_mesh]
@@ -173,8 +177,9 @@ int launch_energy_seeds(int D, int ring_kind, const float* tails, const float* x
 int launch_energy_out(int D, int ring_kind, const float* tails, const float* x, int64_t B, unsigned constrained_mask, const Protons& pr, float* hpsi, float* psi,
                       float* lap, void* stream);
 // One entry of a device weight image as a function of the flat parameter vector:
-//   kind & 0xFF == 0: image float [dst]  = src >= 0 ? (float)(scale * flat[src]) : (float)scale
-//   kind & 0xFF == 1: image halves [dst], [dst_lo] = fp16 pair (hi, lo) of that value, hi + lo = value to 2^-25
+//   kind & 0x0F == 0: image float [dst]  = src >= 0 ? (float)(scale * flat[src]) : (float)scale
+//   kind & 0x0F == 1: image halves [dst], [dst_lo] = fp16 pair (hi, lo) of that value, hi + lo = value to 2^-25
+//   kind & 0x10: |flat[src]| instead of flat[src]
 //   kind >> 8: which image (0 plain, 1 wave, 2 mfma)
 struct PackRec {
     int32_t src, kind;

@@ -208,8 +208,9 @@ __global__ void k_pack(const float* __restrict__ flat, const PackRec* __restrict
     if (i >= n) return;
     PackRec r = recs[i];
     void* __restrict__ image = bases.img[r.kind >> 8];
-    r.kind &= 0xFF;
-    const float v = r.src >= 0 ? (float)(r.scale * (double)flat[r.src]) : (float)r.scale;
+    const bool take_abs = (r.kind & 0x10) != 0;
+    r.kind &= 0x0F;
+    const float v = r.src >= 0 ? (float)(r.scale * (double)(take_abs ? fabsf(flat[r.src]) : flat[r.src])) : (float)r.scale;
     if (r.kind == 0) {
         reinterpret_cast<float*>(image)[r.dst] = v;
     } else {

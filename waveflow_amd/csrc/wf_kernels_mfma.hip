@@ -73,15 +73,17 @@ __global__ __launch_bounds__(64) void k_dim0_coeffs(const ModelDev* __restrict__
         const SplineDev& sp = md.psp;
         const int nb = sp.nb, nbp = sp.nbp;
         const float* keep = fk_nat + 64;
+        // dimension 0 of a gated head: g = 1, w = o + z (model_factory.py:64-67); net.zero holds zeros for an ungated net
+        const bool gate = md.p_gate != 0;
         float c = 0.0f;
         if (t < nb)
-            for (int a = 0; a < nb; ++a) c = __builtin_fmaf(net.b2[a] * keep[a], md.ob_to_b_t[a * nbp + t], c);
+            for (int a = 0; a < nb; ++a) c = __builtin_fmaf((gate ? net.b2[a] + net.zero[a] : net.b2[a]) * keep[a], md.ob_to_b_t[a * nbp + t], c);
         sh[t] = c;
         out[t] = c;
         __syncthreads();
         if (t == 0) {
             float s1 = 0.0f, n2 = 0.0f;
-            for (int j = 0; j < nb; ++j) s1 += net.b2[j];
+            for (int j = 0; j < nb; ++j) s1 += gate ? net.b2[j] + net.zero[j] : net.b2[j];
             for (int i = 0; i < nb; ++i) n2 = __builtin_fmaf(sh[i], sh[i], n2);
             out[64] = (s1 < 0.0f ? -1.0f : 1.0f);
             out[65] = n2;
@@ -92,7 +94,8 @@ __global__ __launch_bounds__(64) void k_dim0_coeffs(const ModelDev* __restrict__
     const int nb = sp.nb;
     const float* fk = fk_nat + (is_prior ? 64 : 0);
     const float reg = is_prior ? 0.0f : md.i_reg, F = is_prior ? F_P : F_I;
-    const float v = t < nb ? 1.0f / (1.0f + expf(-net.b2[t])) : 0.0f;
+    float v = t < nb ? 1.0f / (1.0f + expf(-net.b2[t])) : 0.0f;
+    if ((is_prior ? md.p_gate : md.i_gate) != 0 && t < nb) v = v + net.zero[t];   // gated head, dimension 0: g = 1
     sh[t] = v;
     __syncthreads();
     float s1 = 0.0f, sf = 0.0f;   // every thread repeats the two ordered sums (64 terms): no second barrier

@@ -207,7 +207,8 @@ struct NetOff {
     static constexpr int W2h = b1 + 64;
     static constexpr int W2l = W2h + (D - 1) * NBK * 1024;
     static constexpr int b2 = W2l + (D - 1) * NBK * 1024;
-    static constexpr int total = b2 + 32 * D * NBK;
+    static constexpr int z = b2 + 32 * D * NBK;     // zero_params of a gated head [D][NBK][2][16] (zeros otherwise)
+    static constexpr int total = z + 32 * D * NBK;
 };
 
 // Hidden layers of one conditioner net for the wave's T tiles of 32 walkers.  Written in the order the instructions should issue:
@@ -366,16 +367,21 @@ __device__ __forceinline__ void ispline_eval(const f32x16 (&v)[NBK], const Splin
     logdy = fast_log(__builtin_fmaf(dnum, rS, 1e-7f));
 }
 
-// sigmoid weights of one dimension (NBK blocks) and their two sums: S1 = sum v, Sf = sum v*fk
+// sigmoid weights of one dimension (NBK blocks) and their two sums: S1 = sum v, Sf = sum v*fk.  Gated head (model_factory.py:64-67):
+// v = g * sigmoid(o) + |z|, g = prod_{i<d} x_i^3 of the conditioner's input, z from the net's LDS image.
 template <int NBK>
-__device__ __forceinline__ void sigmoid_block(f32x16 (&o)[NBK], const float* fk_lds /* [NBK][2][16] */, int h, float& S1, float& Sf) {
+__device__ __forceinline__ void sigmoid_block(f32x16 (&o)[NBK], const float* fk_lds /* [NBK][2][16] */, int h, float& S1, float& Sf,
+                                              bool gate = false, float g = 1.0f, const float* z_lds = nullptr) {
     float s1 = 0.0f, sf = 0.0f;
 #pragma unroll
     for (int kb = 0; kb < NBK; ++kb) {
         const f32x16 fk = load16(fk_lds + (kb * 2 + h) * 16);
+        f32x16 zz = fk;
+        if (gate) zz = load16(z_lds + (kb * 2 + h) * 16);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float v = act_sigmoid(o[kb][r]);
+            float v = act_sigmoid(o[kb][r]);
+            if (gate) v = __builtin_fmaf(g, v, zz[r]);
             o[kb][r] = v;
             s1 += v;
             sf = __builtin_fmaf(v, fk[r], sf);
@@ -542,8 +548,16 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
                     logdet[t] = logdet[t] + fast_log(c0[1] + 1e-7f);
                 }
                 STAMP(2);
+                const bool gate_i = !SPEC && mm.i_gate != 0;
+                float gl[T];   // gate of dimension d: prod_{i<d} (layer input)_i^3
+#pragma unroll
+                for (int t = 0; t < T; ++t) gl[t] = 1.0f;
 #pragma unroll
                 for (int d = 1; d < D; ++d) {
+                    if (gate_i) {
+#pragma unroll
+                        for (int t = 0; t < T; ++t) gl[t] = gl[t] * (cur[t][d - 1] * cur[t][d - 1] * cur[t][d - 1]);
+                    }
                     f32x16 v[T][NBK];
 #pragma unroll
                     for (int kb = 0; kb < NBK; ++kb) {
@@ -559,7 +573,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
 #pragma unroll
                     for (int t = 0; t < T; ++t) {
                         float S1, Sf;
-                        sigmoid_block<NBK>(v[t], fkI, h, S1, Sf);
+                        sigmoid_block<NBK>(v[t], fkI, h, S1, Sf, gate_i, gl[t], net + NetOff<D, NBK>::z + d * NBK * 32);
                         const float rs = mm.i_reg * S1;
                         const float rS = __builtin_amdgcn_rcpf(__builtin_fmaf(rs, mm.F_I, Sf));
                         const Lerp Lp = make_lerp(cur[t][d], mm.n_mesh, rn_mesh, exact_div);
@@ -625,11 +639,16 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
                 Frag h2[T][2];
                 f32x16 pend[T];
                 hidden_layers<D, NBK, T>(net, cur, lane, h2, pend);   // the conditioner sees the unclipped u (wavefunctions.py:40)
-                float lp[T], prod[T];
+                float lp[T], prod[T], gp[T];
+                const bool gate_p = !SPEC && mm.p_gate != 0;   // gated head: prod_{i<d} u_i^3 of the conditioner's input, the unclipped u
 #pragma unroll
-                for (int t = 0; t < T; ++t) { lp[t] = 0.0f; prod[t] = 1.0f; }
+                for (int t = 0; t < T; ++t) { lp[t] = 0.0f; prod[t] = 1.0f; gp[t] = 1.0f; }
 #pragma unroll
                 for (int d = 0; d < D; ++d) {
+                    if (gate_p && d > 0) {
+#pragma unroll
+                        for (int t = 0; t < T; ++t) gp[t] = gp[t] * (cur[t][d - 1] * cur[t][d - 1] * cur[t][d - 1]);
+                    }
                     float val[T];   // psi_d (B prior) or the density factor (M prior)
                     float uc[T];
                     Lerp Lp[T];
@@ -652,6 +671,14 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
 #pragma unroll
                         for (int t = 0; t < T; ++t) {
                             float s1 = 0.0f, amax = 0.0f;
+                            if (gate_p) {   // w = g * o + z (signed head: zero_params as they are)
+#pragma unroll
+                                for (int kb = 0; kb < NBK; ++kb) {
+                                    const f32x16 zz = load16(net + NetOff<D, NBK>::z + (d * NBK + kb) * 32 + h * 16);
+#pragma unroll
+                                    for (int r = 0; r < 16; ++r) o[kb][t][r] = __builtin_fmaf(gp[t], o[kb][t][r], zz[r]);
+                                }
+                            }
 #pragma unroll
                             for (int kb = 0; kb < NBK; ++kb) {
                                 const f32x16 keep = load16(fkP + (kb * 2 + h) * 16);
@@ -721,7 +748,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
 #pragma unroll
                         for (int t = 0; t < T; ++t) {
                             float S1, Sf;
-                            sigmoid_block<NBK>(v[t], fkP, h, S1, Sf);
+                            sigmoid_block<NBK>(v[t], fkP, h, S1, Sf, gate_p, gp[t], net + NetOff<D, NBK>::z + d * NBK * 32);
                             SplineRows<NBK, 1> RP;
                             fetch_rows<NBK, 1, false>(RP, mm.tabP, nullptr, Lp[t], h);
                             val[t] = lerp_dot<NBK, 1>(v[t], RP, 0, Lp[t].t) * __builtin_amdgcn_rcpf(Sf);
@@ -824,7 +851,7 @@ int launch_dw(const MfmaDev* mdev, int lds_bytes, int mode, const float* x, int6
     }
     if constexpr (D == 2) {   // the specialised build exists for the two-particle shapes
         if (mdev->box_kind == WF_BOX_MEAN && mdev->layer_kind == WF_LAYER_IMADE && mdev->prior_kind == WF_PRIOR_WAVEFLOW && !mdev->staged &&
-            !mdev->exact_div)
+            !mdev->exact_div && !mdev->i_gate && !mdev->p_gate)
             return launch_dwi<D, NBK, kWaves, T, false, true>(mdev, lds_bytes, mode, x, B, out, u, nullptr, s);
     }
     return launch_dwi<D, NBK, kWaves, T, false, false>(mdev, lds_bytes, mode, x, B, out, u, nullptr, s);

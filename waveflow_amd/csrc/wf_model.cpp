@@ -111,8 +111,10 @@ namespace wf {
 static int64_t plain_fwd_floats(int D, int nbp) {
     return (int64_t)D * kHidden + kHidden + (int64_t)kHidden * kHidden + kHidden + (int64_t)D * nbp * kHidden + (int64_t)D * nbp;
 }
-// ... followed by W1n, W2n
-static int64_t plain_net_floats(int D, int nbp) { return plain_fwd_floats(D, nbp) + (int64_t)kHidden * kHidden + (int64_t)kHidden * D * nbp; }
+// ... followed by W1n, W2n, zero
+static int64_t plain_net_floats(int D, int nbp) {
+    return plain_fwd_floats(D, nbp) + (int64_t)kHidden * kHidden + (int64_t)kHidden * D * nbp + (int64_t)D * nbp;
+}
 
 static int check_bc(const wf_bc& bc, int nb) {
     if (bc.n < 0 || bc.n > WF_MAX_BC) return WF_ERR_INVALID;
@@ -272,6 +274,8 @@ static int model_build(wf_model* m) {
     md.prior_kind = d.prior_kind;
     md.normal_offset = d.normal_offset;
     md.reverse_tol = d.i_reverse_tol > 0.0f ? d.i_reverse_tol : 1.0f / (float)d.n_mesh;   // isplines_jax.py:89-90
+    md.i_gate = (d.i_gate != 0 && d.layer_kind == WF_LAYER_IMADE && d.n_flow_layers > 0) ? 1 : 0;
+    md.p_gate = (d.p_gate != 0 && (d.prior_kind == WF_PRIOR_WAVEFLOW || d.prior_kind == WF_PRIOR_MFLOW)) ? 1 : 0;
     for (int i = 0; i < d.n_constrained_left; ++i) {
         if (d.constrained_left[i] < 0 || d.constrained_left[i] >= D) return WF_ERR_INVALID;
         md.constrained_mask |= 1u << d.constrained_left[i];
@@ -441,7 +445,8 @@ static int model_build(wf_model* m) {
         np.W2t = p; p += (int64_t)D * m->nbp * kHidden;
         np.b2 = p; p += (int64_t)D * m->nbp;
         np.W1n = p; p += (int64_t)kHidden * kHidden;
-        np.W2n = p;
+        np.W2n = p; p += (int64_t)kHidden * D * m->nbp;
+        np.zero = p;
     }
     {
         const int P = wave_passes(D, m->nbp);
@@ -474,6 +479,7 @@ struct ImageWriter {
     std::vector<PackRec>& out;
     uint32_t o;   // running float offset inside the image
     void f32(int64_t src, double scale = 1.0) { out.push_back(PackRec{(int32_t)src, 0, o++, 0u, src >= 0 ? scale : 0.0}); }
+    void f32_abs(int64_t src) { out.push_back(PackRec{(int32_t)src, 0x10, o++, 0u, src >= 0 ? 1.0 : 0.0}); }
     void cst(double value) { out.push_back(PackRec{-1, 0, o++, 0u, value}); }
 };
 struct NetOffsets {   // flat-vector offsets of the leaves of one conditioner (model_factory.py:72-87 leaf order)
@@ -493,6 +499,9 @@ static NetOffsets net_offsets(const wf_model* m, int n) {
     q.b2 = q.W2 + (int64_t)H * q.NO;
     return q;
 }
+
+static bool net_has_sigmoid_head(const wf_model* m, int n);
+static bool net_is_gated(const wf_model* m, int n) { return n == m->desc.n_flow_layers ? m->desc.p_gate != 0 : m->desc.i_gate != 0; }
 
 // Masked, transposed weight image of net n (NetPlain), float offset `base` inside d_plain.
 static void describe_plain_image(const wf_model* m, int n, uint32_t base, std::vector<PackRec>& out) {
@@ -522,6 +531,14 @@ static void describe_plain_image(const wf_model* m, int n, uint32_t base, std::v
         for (int dd = 0; dd < D; ++dd)
             for (int jb = 0; jb < nbp; ++jb)
                 w.f32((jb < nl.n_out && deg_out(dd) >= deg_hidden(a, D)) ? q.W2 + (int64_t)a * q.NO + (jb * D + dd) : -1);
+    // zero_params[d][j] of a gated head (the leaf follows b2; model_factory.py:84), |z| under a sigmoid head (:62-63); zeros otherwise
+    const bool gated = nl.has_zero && net_is_gated(m, n), sig = net_has_sigmoid_head(m, n);
+    for (int dd = 0; dd < D; ++dd)
+        for (int jb = 0; jb < nbp; ++jb) {
+            const int64_t src = (gated && jb < nl.n_out) ? q.b2 + q.NO + (int64_t)dd * nl.n_out + jb : -1;
+            if (sig) w.f32_abs(src);
+            else w.f32(src);
+        }
 }
 
 
@@ -574,7 +591,7 @@ static inline int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h;
 
 static int mfma_net_floats(int D, int nbk) {
     const int S0 = (D + 1) / 2;
-    return 128 * S0 + 64 + 4096 + 64 + (D - 1) * nbk * 2048 + 32 * D * nbk;
+    return 128 * S0 + 64 + 4096 + 64 + (D - 1) * nbk * 2048 + 32 * D * nbk + 32 * D * nbk;   // ..., biases, zero_params
 }
 
 // per-row factor: remove_bias scaling (isplines_jax.py:196-202 / msplines_jax.py:186-192) times the
@@ -686,6 +703,17 @@ static void describe_mfma_image(const wf_model* m, int n, uint32_t base, std::ve
                     if (jb < nl.n_out) w.f32(q.b2 + jb * D + d, c2);
                     else w.cst(sig ? 1e30 : 0.0);
                 }
+    // zero_params of a gated head, accumulator layout like the biases (|z| under a sigmoid head); zeros otherwise
+    const bool gated = nl.has_zero && net_is_gated(m, n);
+    for (int d = 0; d < D; ++d)
+        for (int kb = 0; kb < nbk; ++kb)
+            for (int h = 0; h < 2; ++h)
+                for (int r = 0; r < 16; ++r) {
+                    const int jb = 32 * kb + acc_row(r, h);
+                    const int64_t src = (gated && jb < nl.n_out) ? q.b2 + q.NO + (int64_t)d * nl.n_out + jb : -1;
+                    if (sig) w.f32_abs(src);
+                    else w.f32(src);
+                }
 }
 
 // Decides whether the MFMA kernel covers this model and builds its parameter-independent parts.
@@ -718,6 +746,7 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
     md.n_nets = n_nets; md.net_floats = net_floats; md.const_img_off = net_floats * n_nets; md.const_floats = consts; md.staged = staged;
     md.exact_div = mfma_div_ok(md.n_mesh) ? 0 : 1;
     md.prior_quotient = (getenv("WF_PRIOR_QUOTIENT") && atoi(getenv("WF_PRIOR_QUOTIENT")) != 0) ? 1 : 0;
+    md.i_gate = m->dev.i_gate; md.p_gate = m->dev.p_gate;
     m->mfma_lds_floats = consts + (staged ? net_floats : net_floats * n_nets);
 
     m->mfma_consts.assign(consts, 0.0f);
@@ -792,6 +821,7 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
 static bool wave_capable(const wf_model* m) {
     const wf_model_desc& d = m->desc;
     if (!m->d_wave || (m->nbp == 64 && d.n_dim > 4)) return false;   // (the 64-row sweeps are built for D <= 4)
+    if (m->dev.i_gate || m->dev.p_gate) return false;                 // gated heads: per-walker and MFMA kernels only
     const bool imade = d.layer_kind == WF_LAYER_IMADE && d.n_flow_layers > 0;
     if (imade && (!m->d_tabI4 || !m->bc_i_ok)) return false;
     const bool spline_prior = d.prior_kind == WF_PRIOR_WAVEFLOW || d.prior_kind == WF_PRIOR_MFLOW;

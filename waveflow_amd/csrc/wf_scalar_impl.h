@@ -143,13 +143,16 @@ __device__ __forceinline__ float out_unit(const NetPlain& net, const float (&h)[
     return acc + net.b2[d * NBP + j];
 }
 
-// calculate_bijection_params for dimension d into SCR(0..nb)
+// calculate_bijection_params for dimension d into SCR(0..nb).  gate (set_nn_output_grad_to_zero, model_factory.py:64-67):
+// bij = g * head(o) + z with g = prod_{i<d} x_i^3 of the conditioner's input (the caller's running product) and z = net.zero[d][.]
 template <int NBP>
-__device__ __forceinline__ void bijection_params(const NetPlain& net, const float (&h)[H], int d, int nb, bool sigmoid, float* scr) {
+__device__ __forceinline__ void bijection_params(const NetPlain& net, const float (&h)[H], int d, int nb, bool sigmoid, float* scr,
+                                                 bool gate = false, float g = 1.0f) {
     float ss = 0.0f;
     for (int j = 0; j < nb; ++j) {
         float v = out_unit<NBP>(net, h, d, j);
         if (sigmoid) v = 1.0f / (1.0f + expf(-v));
+        if (gate) v = g * v + net.zero[d * NBP + j];
         SCR(j) = v;
         ss = ss + v;
     }
@@ -165,10 +168,11 @@ __device__ __forceinline__ float imade_direct(const ModelDev& md, const NetPlain
     const int nb = sp.nb;
     const float* tab0 = sp.tab;
     const float* tab1 = sp.tab + (size_t)sp.n_mesh * NBP;
-    float ld = 0.0f;
+    float ld = 0.0f, g = 1.0f;
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-        bijection_params<NBP>(net, h, d, nb, true, scr);
+        if (d > 0) g = g * (x[d - 1] * x[d - 1] * x[d - 1]);
+        bijection_params<NBP>(net, h, d, nb, true, scr, md.i_gate != 0, g);
         for (int j = 0; j < nb; ++j) SCR(j) = SCR(j) + md.i_reg;
         remove_bias(WF_SPLINE_I, sp.degree, nb, scr);
         enforce_bc(sp, WF_SPLINE_I, scr, 0);
@@ -261,11 +265,12 @@ __global__ __launch_bounds__(Cfg<NBP>::kBlock) void k_eval(const ModelDev* __res
                 const int nb = sp.nb;
                 float h[H];
                 hidden_layers<D>(net, cur, scr, h);
-                float lp = 0.0f, prod = 1.0f;
+                float lp = 0.0f, prod = 1.0f, g = 1.0f;
 #pragma unroll
                 for (int d = 0; d < D; ++d) {
-                    bijection_params<NBP>(net, h, d, nb, false, scr);
+                    bijection_params<NBP>(net, h, d, nb, false, scr, md.p_gate != 0, g);
                     enforce_bc(sp, WF_SPLINE_B, scr, 0);
+                    g = g * (cur[d] * cur[d] * cur[d]);   // the gate sees the conditioner's input: the unclipped u
                     cur[d] = clip01(cur[d]);
                     // BSpline_fun.apply_fun: c = w @ ob_to_b; c /= |c|  (bsplines_jax.py:134-135)
                     float ss = 0.0f;
@@ -297,12 +302,13 @@ __global__ __launch_bounds__(Cfg<NBP>::kBlock) void k_eval(const ModelDev* __res
                 const int nb = sp.nb;
                 float h[H];
                 hidden_layers<D>(net, cur, scr, h);
-                float lp = 0.0f;
+                float lp = 0.0f, g = 1.0f;
 #pragma unroll
                 for (int d = 0; d < D; ++d) {
-                    bijection_params<NBP>(net, h, d, nb, true, scr);
+                    bijection_params<NBP>(net, h, d, nb, true, scr, md.p_gate != 0, g);
                     remove_bias(WF_SPLINE_M, sp.degree, nb, scr);
                     enforce_bc(sp, WF_SPLINE_M, scr, 0);
+                    g = g * (cur[d] * cur[d] * cur[d]);
                     cur[d] = clip01(cur[d]);
                     const Lerp L = make_lerp(cur[d], sp.n_mesh);
                     if (idx) { idx[(md.n_layers * D + d) * 2] = L.xl; idx[(md.n_layers * D + d) * 2 + 1] = L.xr; }
@@ -405,12 +411,14 @@ __device__ __forceinline__ void imade_inverse(const ModelDev& md, const NetPlain
     float h[H];
 #pragma unroll
     for (int d = 0; d < D; ++d) out[d] = 0.0f;
+    float g = 1.0f;
 #pragma unroll
     for (int d = 0; d < D; ++d) {
         if (d == 0 || exact) {
             if (exact) hidden_layers<D>(net, out, scr, h); else hidden_layers<D>(net, in, scr, h);
         }
-        bijection_params<NBP>(net, h, d, nb, true, scr);
+        if (d > 0) { const float xp = exact ? out[d - 1] : in[d - 1]; g = g * (xp * xp * xp); }
+        bijection_params<NBP>(net, h, d, nb, true, scr, md.i_gate != 0, g);
         for (int j = 0; j < nb; ++j) SCR(j) = SCR(j) + md.i_reg;
         remove_bias(WF_SPLINE_I, sp.degree, nb, scr);
         enforce_bc(sp, WF_SPLINE_I, scr, 0);
@@ -532,11 +540,13 @@ __global__ __launch_bounds__(Cfg<NBP>::kBlock) void k_sample(const ModelDev* __r
             const SplineDev& sp = md.psp;
             const int nb = sp.nb;
             const bool wavefn = md.prior_kind == WF_PRIOR_WAVEFLOW;
+            float g = 1.0f;
 #pragma unroll
             for (int col = 0; col < D; ++col) {
                 float h[H];
                 hidden_layers<D>(net, cur, scr, h);   // conditioner on the columns drawn so far, zeros elsewhere
-                bijection_params<NBP>(net, h, col, nb, !wavefn, scr);
+                if (col > 0) g = g * (cur[col - 1] * cur[col - 1] * cur[col - 1]);
+                bijection_params<NBP>(net, h, col, nb, !wavefn, scr, md.p_gate != 0, g);
                 float ymax = 0.0f;
                 int row0 = 0;
                 if (wavefn) {

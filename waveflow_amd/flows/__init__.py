@@ -72,6 +72,7 @@ class IMADESpec:
     left: dict
     right: dict
     n_mesh: int = 2000
+    gate: bool = False     # set_nn_output_grad_to_zero (model_factory.py:64-67)
 
 
 @dataclass
@@ -96,7 +97,7 @@ class SerialSpec:
 
 
 def _desc(D, layers=(), box=None, prior=_lib.PRIOR_UNIFORM, p_degree=0, p_knots=0, p_left=None, p_right=None,
-          normal_offset=0.0, constrained_left=(), n_mesh=None):
+          normal_offset=0.0, constrained_left=(), n_mesh=None, p_gate=False):
     """Fill a wf_model_desc from specs.  `layers`: list of identical IMADESpec or MADESpec.  `n_mesh`: the prior spline's mesh
     (n_spline_base_mesh_points); wf_model_desc carries ONE mesh size for the layers' and the prior's tables."""
     d = _lib.ModelDesc()
@@ -115,6 +116,7 @@ def _desc(D, layers=(), box=None, prior=_lib.PRIOR_UNIFORM, p_degree=0, p_knots=
                                           "model keeps one mesh size; build the two with equal n_spline_base_mesh_points")
             d.n_mesh = first.n_mesh
             d.i_reverse_tol = float(first.tol) if first.tol is not None else 0.0
+            d.i_gate = int(bool(first.gate))
         else:
             d.layer_kind = _lib.LAYER_MADE
     if box is not None:
@@ -124,6 +126,7 @@ def _desc(D, layers=(), box=None, prior=_lib.PRIOR_UNIFORM, p_degree=0, p_knots=
     d.p_degree, d.p_knots = p_degree, p_knots
     d.p_left, d.p_right = _lib.BC.from_dict(p_left), _lib.BC.from_dict(p_right)
     d.normal_offset = normal_offset
+    d.p_gate = int(bool(p_gate))
     cl = [int(c) for c in np.asarray(constrained_left).reshape(-1)]
     d.n_constrained_left = len(cl)
     for i, c in enumerate(cl):
@@ -174,13 +177,12 @@ class IMADE(_InitFun):
     def __init__(self, transform, spline_degree=4, n_internal_knots=12, spline_regularization=0.0, reverse_fun_tol=0.0001,
                  constraints_dict_left={0: 0.0}, constraints_dict_right={0: 1.0}, set_nn_output_grad_to_zero=False,
                  n_spline_base_mesh_points=2000):
-        if set_nn_output_grad_to_zero:
-            raise NotImplementedError("set_nn_output_grad_to_zero=True (model_factory.py:64-67) is not built on the HIP path")
         if transform.simple or transform.allow_negative_params:
             raise NotImplementedError("IMADE needs get_masked_transform() (sigmoid head), as in the reference's factories")
         self.transform = transform
         self.spec = IMADESpec(spline_degree, n_internal_knots, float(spline_regularization), reverse_fun_tol,
-                              dict(constraints_dict_left), dict(constraints_dict_right), n_spline_base_mesh_points)
+                              dict(constraints_dict_left), dict(constraints_dict_right), n_spline_base_mesh_points,
+                              bool(set_nn_output_grad_to_zero))
 
     def n_bases(self):
         return self.spec.knots + self.spec.degree  # knots + 2*(k+1) - 2 - k, isplines_jax.py:91-95
@@ -379,8 +381,7 @@ class MFlow(_InitFun):
 
     def __init__(self, transformation, sp_transformation, spline_degree, n_internal_knots, constraints_dict_left={0: 0},
                  constraints_dict_right={0: 0}, set_nn_output_grad_to_zero=False, n_spline_base_mesh_points=2000):
-        if set_nn_output_grad_to_zero:
-            raise NotImplementedError("set_nn_output_grad_to_zero=True is not built on the HIP path")
+        self.gate = bool(set_nn_output_grad_to_zero)
         if sp_transformation.simple or sp_transformation.allow_negative_params:
             raise NotImplementedError("MFlow needs get_masked_transform() for the prior head")
         self.transformation, self.sp = transformation, sp_transformation
@@ -394,7 +395,7 @@ class MFlow(_InitFun):
         nb = self.n + self.k - 2  # msplines_jax.py:72-80: n_knots - k with k-fold end knots
         sparams = self.sp.init_params(g, input_dim, nb)
         model = self.transformation.fused_model(input_dim, prior=_lib.PRIOR_MFLOW, p_degree=self.k, p_knots=self.n,
-                                                p_left=self.left, p_right=self.right, n_mesh=self.n_mesh)
+                                                p_left=self.left, p_right=self.right, n_mesh=self.n_mesh, p_gate=self.gate)
         if model is None:
             raise NotImplementedError("MFlow: the bijector stack must be [Box] + (IMADE, Reverse)*n")
         assert model.p_nb == nb

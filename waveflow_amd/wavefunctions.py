@@ -11,9 +11,7 @@ class Waveflow(_InitFun):
     def __init__(self, transformation, sp_transformation, spline_degree, n_internal_knots, constraints_dict_left={0: 0, 2: 0},
                  constraints_dict_right={0: 0}, constrained_dimension_indices_left=(), constrained_dimension_indices_right=(),
                  set_nn_output_grad_to_zero=True, n_spline_base_mesh_points=2000):
-        if set_nn_output_grad_to_zero:
-            raise NotImplementedError("set_nn_output_grad_to_zero=True (model_factory.py:64-67) is not built on the HIP path; "
-                                      "get_waveflow_model passes False (model_factory.py:143)")
+        self.gate = bool(set_nn_output_grad_to_zero)   # (get_waveflow_model passes False, model_factory.py:143)
         if sp_transformation.simple or not sp_transformation.allow_negative_params:
             raise NotImplementedError("Waveflow needs get_masked_transform(allow_negative_params=True) for the prior head")
         if len(np.asarray(constrained_dimension_indices_right).reshape(-1)):
@@ -31,7 +29,7 @@ class Waveflow(_InitFun):
         sparams = self.sp.init_params(g, input_dim, nb)
         model = self.transformation.fused_model(input_dim, prior=_lib.PRIOR_WAVEFLOW, p_degree=self.k, p_knots=self.n,
                                                 p_left=self.left, p_right=self.right,
-                                                constrained_left=self.constrained_left, n_mesh=self.n_mesh)
+                                                constrained_left=self.constrained_left, n_mesh=self.n_mesh, p_gate=self.gate)
         if model is None:
             raise NotImplementedError("Waveflow: the bijector stack must be [Box] + (IMADE, Reverse)*n")
         assert model.p_nb == nb
