@@ -52,7 +52,7 @@ typedef enum {
 /* spline families: splines/msplines_jax.py, isplines_jax.py, bsplines_jax.py */
 typedef enum { WF_SPLINE_M = 0, WF_SPLINE_I = 1, WF_SPLINE_B = 2, WF_SPLINE_OB = 3 } wf_spline_kind;
 /* bijector layers: flows/bijections/made.py:44-105 (IMADE), :7-41 (MADE) */
-typedef enum { WF_LAYER_IMADE = 0, WF_LAYER_MADE = 1 } wf_layer_kind;
+typedef enum { WF_LAYER_IMADE = 0, WF_LAYER_MADE = 1, WF_LAYER_NSC = 2 } wf_layer_kind;
 /* BoxTransformLayer xu_coord_type: made.py:156-183 ('mean'), :118-137 ('first') */
 typedef enum { WF_BOX_NONE = 0, WF_BOX_MEAN = 1, WF_BOX_FIRST = 2 } wf_box_kind;
 /* density heads: wavefunctions.py:9-112 (Waveflow), flows/distributions.py:116-194 (MFlow),
@@ -96,6 +96,15 @@ typedef struct {
      * Evaluation: the per-walker and the MFMA kernels; the wave sweeps (small batches, local energy, gradients, sampler) do not
      * build it: those entry points return WF_ERR_UNSUPPORTED for a gated model. */
     int32_t i_gate, p_gate;
+    /* layer_kind WF_LAYER_NSC (ABI 2): n_flow_layers NeuralSplineCoupling layers (flows/bijections/neural_splines.py:244-296; K bins,
+     * tail bound B, FCNN conditioners of width hidden_dim), each followed by flows.Reverse when nsc_reverse != 0, under a Normal or
+     * Uniform prior: Flow(Serial(...), Normal()) in one launch per call.  n_dim even, 2..8; K 2..16; hidden 8 or 32.  Parameters:
+     * per layer f1 then f2, each in stax.Dense leaf order W1 [dh][h], b1, W2 [h][h], b2, W3 [h][(3K-1) dh], b3.
+     * wf_logpdf_fwd, wf_flow_fwd, wf_inverse_fwd, wf_sample; everything else returns WF_ERR_UNSUPPORTED for this kind. */
+    int32_t nsc_bins;
+    float nsc_tail_bound;
+    int32_t nsc_hidden;
+    int32_t nsc_reverse;
 } wf_model_desc;
 
 typedef struct wf_model wf_model;

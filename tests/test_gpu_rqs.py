@@ -133,3 +133,79 @@ def test_neural_spline_coupling_layer(dim, K, hidden):
     import torch
     yt, ldt = direct_fun(params, torch.as_tensor(x).cuda())
     assert torch.is_tensor(yt) and np.array_equal(yt.cpu().numpy(), y)
+
+
+@pytest.mark.parametrize("dim,K,hidden,reverse,prior", [(2, 5, 8, True, "normal"), (4, 8, 8, False, "normal"), (6, 5, 32, True, "uniform"),
+                                                        (2, 12, 8, True, "normal")])
+def test_neural_spline_coupling_stack_as_a_model(dim, K, hidden, reverse, prior):
+    """Flow(Serial((NeuralSplineCoupling [, Reverse]) x 3), Normal | Uniform): layer_kind WF_LAYER_NSC, log_pdf of the whole stack from ONE
+    kernel launch, vs the NumPy / C restatement chained layer by layer; flow, inverse and sampler round trips."""
+    import torch
+    from waveflow_amd import flows
+    g = np.random.default_rng(100 + dim)
+    layer = lambda: flows.NeuralSplineCoupling(K=K, B=3, hidden_dim=hidden)
+    items = []
+    for _ in range(3):
+        items += [layer(), flows.Reverse()] if reverse else [layer()]
+    pr = flows.Normal(-0.25) if prior == "normal" else flows.Uniform()
+    init = flows.Flow(flows.Serial(*items), pr, prior_support=None if prior == "normal" else (0.0, 1.0))
+    params, log_pdf, sample = init(7, dim)
+    assert log_pdf.model.desc.layer_kind == 2 and log_pdf.model.n_params > 0
+    scale = lambda net: [tuple(a * (1.5 if a.ndim == 2 else 3e4) for a in l) if l else () for l in net]
+    params = [tuple(scale(net) for net in p) if p else () for p in params]
+    x = g.uniform(-3.4, 3.4, size=(4099, dim)).astype(np.float32)
+    lp, u = log_pdf(params, x, return_sample=True)
+    # oracle: layer by layer
+    z, ld = x.astype(np.float32), np.zeros(len(x))
+    for p in params:
+        if p:
+            z, l = _nsc_oracle(p, z, K, 3.0, False)
+            z = z.astype(np.float32)
+            ld = ld + l
+        else:
+            z = z[:, ::-1]
+    if prior == "normal":
+        want = ld + (-0.5 * (np.log(2 * np.pi) + (z.astype(np.float64) - 0.25) ** 2)).sum(1)
+        zc = z
+    else:
+        want, zc = ld, np.clip(z, 0.0, 1.0)
+    assert np.quantile(np.abs(u - zc), 0.999) < 2e-3 and np.median(np.abs(u - zc)) < 5e-6
+    err = np.abs(lp - want)
+    assert np.median(err) < 2e-5 and np.quantile(err, 0.99) < 5e-3 and err.max() < 0.2, (np.median(err), np.quantile(err, 0.99), err.max())
+    m = log_pdf.model
+    # flow / inverse round trip (exact inverse: a coupling layer conditions on the half it does not change)
+    uf, ldf = m.flow(x)
+    assert np.array_equal(np.asarray(ldf) + 0 * 0, np.asarray(ldf)) and np.abs(np.asarray(ldf) - ld).max() < 0.2
+    xb = np.asarray(m.inverse(uf))
+    e = np.abs(xb - x).max(1)
+    assert np.median(e) < 5e-4 and np.quantile(e, 0.9) < 2e-2
+    # sampler: x = inverse(z), z ~ prior; log_pdf's latent returns z
+    s, lat = sample(3, params, 2000, return_original_samples=True)
+    s, lat = (v.cpu().numpy() if torch.is_tensor(v) else np.asarray(v) for v in (s, lat))
+    assert np.isfinite(s).all() and s.shape == (2000, dim)
+    if prior == "normal":
+        assert abs(lat.mean()) < 0.08 and abs(lat.std() - 1) < 0.08
+    _, u2 = log_pdf(params, s, return_sample=True)
+    d = np.abs(np.asarray(u2) - (lat if prior == "normal" else np.clip(lat, 0, 1))).max(1)
+    assert np.median(d) < 5e-4 and np.quantile(d, 0.9) < 2e-2
+    # what this model kind does not do fails loudly
+    from waveflow_amd import _lib
+    with pytest.raises(_lib.WfError):
+        m.logpdf_vjp(x[:8], np.ones(8, np.float32))
+    with pytest.raises(_lib.WfError):
+        m.set_kernel("mfma")
+
+
+def test_neural_spline_coupling_one_kernel_equals_staged_path(monkeypatch):
+    """The bare layer (wf_nsc_fwd) takes the one-kernel stack for the built shapes; WF_NSC_STAGED=1 keeps the launch-per-half-step path:
+    same function, same arithmetic for the spline, so the two agree to fp32 rounding of the conditioner's sums."""
+    from waveflow_amd import flows
+    g = np.random.default_rng(5)
+    init_fun = flows.NeuralSplineCoupling(K=5, B=3, hidden_dim=8)
+    params, direct_fun, inverse_fun = init_fun(11, 4)
+    params = tuple([tuple(a * (1.5 if a.ndim == 2 else 3e4) for a in l) if l else () for l in net] for net in params)
+    x = g.uniform(-3.5, 3.5, size=(5000, 4)).astype(np.float32)
+    y1, l1 = direct_fun(params, x)
+    monkeypatch.setenv("WF_NSC_STAGED", "1")
+    y2, l2 = direct_fun(params, x)
+    assert np.quantile(np.abs(y1 - y2), 0.999) < 1e-4 and np.quantile(np.abs(l1 - l2), 0.999) < 1e-3

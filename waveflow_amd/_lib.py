@@ -8,7 +8,7 @@ LIB_PATH = os.environ.get("WF_LIB") or os.path.join(HERE, "libwaveflow_hip.so") 
 
 WF_MAX_DIM, WF_MAX_BC = 16, 4
 SPLINE_M, SPLINE_I, SPLINE_B, SPLINE_OB = 0, 1, 2, 3
-LAYER_IMADE, LAYER_MADE = 0, 1
+LAYER_IMADE, LAYER_MADE, LAYER_NSC = 0, 1, 2
 BOX_NONE, BOX_MEAN, BOX_FIRST = 0, 1, 2
 PRIOR_WAVEFLOW, PRIOR_MFLOW, PRIOR_UNIFORM, PRIOR_NORMAL = 0, 1, 2, 3
 KERNEL_AUTO, KERNEL_SCALAR, KERNEL_MFMA, KERNEL_WAVE = 0, 1, 2, 3
@@ -48,7 +48,8 @@ class ModelDesc(ctypes.Structure):
                 ("i_left", BC), ("i_right", BC), ("prior_kind", ctypes.c_int32), ("p_degree", ctypes.c_int32),
                 ("p_knots", ctypes.c_int32), ("p_left", BC), ("p_right", BC), ("normal_offset", ctypes.c_float),
                 ("n_constrained_left", ctypes.c_int32), ("constrained_left", ctypes.c_int32 * WF_MAX_DIM),
-                ("n_mesh", ctypes.c_int32), ("i_reverse_tol", ctypes.c_float), ("i_gate", ctypes.c_int32), ("p_gate", ctypes.c_int32)]
+                ("n_mesh", ctypes.c_int32), ("i_reverse_tol", ctypes.c_float), ("i_gate", ctypes.c_int32), ("p_gate", ctypes.c_int32),
+                ("nsc_bins", ctypes.c_int32), ("nsc_tail_bound", ctypes.c_float), ("nsc_hidden", ctypes.c_int32), ("nsc_reverse", ctypes.c_int32)]
 
 
 class TrainState(ctypes.Structure):

@@ -204,6 +204,16 @@ int launch_vqmc_seeds(const float* x, int64_t B, int D, const Protons& pr, const
                       float inv_count, float* e_loc, float* w_psi, float* w_lap, const float* running_avg_dev, void* stream);
 int launch_rqs(const float* x, const float* uw, const float* uh, const float* ud, int64_t N, int K, int n_deriv, int inverse,
                float left, float right, float bottom, float top, float* y, float* ld, int32_t* bin, void* stream);
+// the coupling stack as a model (wf_kernels_rqs.hip: k_nsc_model): L layers of (f1, f2) conditioner parameters in stax.Dense leaf order
+struct NscModelDev {
+    int D, L, K, hidden, prior_kind, reverse;
+    float tail, normal_offset;
+    const float* params;     // device, [L][2][net_floats]
+    int64_t net_floats;
+};
+bool nsc_model_built(int D, int K, int hidden);
+int launch_nsc_model(const NscModelDev& md, int mode, const float* x, int64_t B, float* out, float* u, void* stream);
+int launch_nsc_latent(int prior_kind, int D, unsigned long long seed, int64_t B, float* z, void* stream);
 int64_t nsc_workspace_floats(int64_t B, int dim, int K);
 int launch_nsc(const float* x, int64_t B, int dim, int K, float tail, int hidden, const float* params, int inverse, float* y, float* logdet,
                float* ws, void* stream);

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include "wf_internal.h"
+#include "wf_scalar_impl.h"   // scalar::Philox
 
 namespace wf {
 
@@ -378,6 +379,259 @@ __global__ void k_nsc_finish(int64_t B, int dim, int dh, const float* __restrict
     }
     for (int d = 0; d < dh; ++d) s += ld_b[b * dh + d];
     logdet[b] = s;
+}
+
+// ---- the coupling stack in one kernel.  Flow(Serial(NeuralSplineCoupling [, Reverse]) x L, Normal | Uniform) -- or one bare layer --
+// with one lane per walker and everything in registers: the walker's D coordinates, the conditioner's hidden units (HID <= 32), the
+// 3K - 1 spline parameters of the coordinate being transformed (K <= KM).  The weights are the same for every lane: the compiler
+// reads them with scalar loads (constant cache), so the kernel's HBM traffic is x in, log_pdf (and u) out: (D + 1) * 4 bytes per
+// walker instead of the (6K + 8) * D * 2 bytes the launch-per-half-step path (launch_nsc) moves through its workspace.
+// unconstrained_RQS on register rows (same arithmetic as k_rqs_reg: widths / heights min + (1 - min K) softmax, knots by running
+// sum with the end knot forced, bin = sum(x >= knot) - 1 clamped, derivative edge constant, identity outside the tails).
+template <int KM>
+__device__ __forceinline__ void rqs_rows(float x, int K, float (&sr)[KM], float (&orow)[KM], const float (&ud)[KM], float tail, bool inverse,
+                                         float& y, float& ld) {
+    const float edge = logf(expf(1 - kMinDerivative) - 1);
+    const float lo = -tail, hi = tail;
+    // (forward: sr = widths, orow = heights; inverse: sr = heights, orow = widths -- min sizes are equal)
+    float mxs = sr[0], mxo = orow[0];
+#pragma unroll
+    for (int i = 1; i < KM; ++i)
+        if (i < K) { mxs = fmaxf(mxs, sr[i]); mxo = fmaxf(mxo, orow[i]); }
+    float ss = 0.0f, so = 0.0f;
+#pragma unroll
+    for (int i = 0; i < KM; ++i)
+        if (i < K) {
+            sr[i] = __builtin_amdgcn_exp2f((sr[i] - mxs) * 1.4426950408889634f);
+            orow[i] = __builtin_amdgcn_exp2f((orow[i] - mxo) * 1.4426950408889634f);
+            ss = ss + sr[i];
+            so = so + orow[i];
+        }
+    const float cs_ = (1 - kMinBinWidth * K) / ss, co_ = (1 - kMinBinHeight * K) / so;
+    int count = x >= lo ? 1 : 0;
+    float cs = 0.0f, co = 0.0f, sprev = lo, oprev = lo;
+    float s_knot = lo, s_size = 1.0f, o_knot = lo, o_size = 1.0f, u0 = edge, u1 = edge;
+#pragma unroll
+    for (int i = 0; i < KM; ++i)
+        if (i < K) {
+            const float wi = __builtin_fmaf(cs_, sr[i], kMinBinWidth), oi = __builtin_fmaf(co_, orow[i], kMinBinHeight);
+            cs = cs + wi;
+            co = co + oi;
+            const bool last = i == K - 1;
+            float sk = (hi - lo) * cs + lo, ok = (hi - lo) * co + lo;
+            if (last) { sk = hi; ok = hi; }
+            const bool ge = x >= (last ? sk + 1e-6f : sk);
+            const bool sel = (count == i + 1 && !ge) || (i == 0 && count == 0) || (last && ge && count == K);
+            if (sel) {
+                s_knot = sprev; s_size = sk - sprev; o_knot = oprev; o_size = ok - oprev;
+                u0 = i == 0 ? edge : ud[i > 0 ? i - 1 : 0];
+                u1 = last ? edge : ud[i];
+            }
+            if (ge) ++count;
+            sprev = sk;
+            oprev = ok;
+        }
+    const float in_cw = inverse ? o_knot : s_knot, in_w = inverse ? o_size : s_size;
+    const float in_ch = inverse ? s_knot : o_knot, in_h = inverse ? s_size : o_size;
+    const float d0 = kMinDerivative + softplus(u0), d1 = kMinDerivative + softplus(u1);
+    const float delta = in_h / in_w;
+    if (inverse) {
+        const float a = (x - in_ch) * (d0 + d1 - 2 * delta) + in_h * (delta - d0);
+        const float bq = in_h * d0 - (x - in_ch) * (d0 + d1 - 2 * delta);
+        const float cq = -delta * (x - in_ch);
+        const float disc = bq * bq - 4 * a * cq;
+        const float root = (2 * cq) / (-bq - sqrtf(disc));
+        y = root * in_w + in_cw;
+        const float t1 = root * (1 - root);
+        const float den = delta + ((d0 + d1 - 2 * delta) * t1);
+        const float num = delta * delta * (d1 * root * root + 2 * delta * t1 + d0 * (1 - root) * (1 - root));
+        ld = -(logf(num) - 2 * logf(den));
+    } else {
+        const float th = (x - in_cw) / in_w;
+        const float t1 = th * (1 - th);
+        const float num = in_h * (delta * th * th + d0 * t1);
+        const float den = delta + ((d0 + d1 - 2 * delta) * t1);
+        y = in_ch + num / den;
+        const float dnum = delta * delta * (d1 * th * th + 2 * delta * t1 + d0 * (1 - th) * (1 - th));
+        ld = logf(dnum) - 2 * logf(den);
+    }
+    if (!(x >= lo && x <= hi)) { y = x; ld = 0.0f; }
+}
+
+// one half-step (neural_splines.py:254-262): the dh coordinates t[] transformed given the dh coordinates c[]
+template <int HID, int KM>
+__device__ __forceinline__ float nsc_half(const float* __restrict__ net, int dh, int K, float tail, bool inverse, const float (&c)[4], float (&t)[4]) {
+    const int per = 3 * K - 1, dout = per * dh;
+    const float* __restrict__ W1 = net;
+    const float* __restrict__ b1 = W1 + dh * HID;
+    const float* __restrict__ W2 = b1 + HID;
+    const float* __restrict__ b2 = W2 + HID * HID;
+    const float* __restrict__ W3 = b2 + HID;
+    const float* __restrict__ b3 = W3 + HID * dout;
+    float h1[HID], h2[HID];
+#pragma unroll
+    for (int j = 0; j < HID; ++j) {
+        float z = b1[j];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+            if (a < dh) z = __builtin_fmaf(c[a], W1[a * HID + j], z);
+        h1[j] = tanhf(z);
+    }
+#pragma unroll
+    for (int j = 0; j < HID; ++j) {
+        float z = b2[j];
+#pragma unroll
+        for (int a = 0; a < HID; ++a) z = __builtin_fmaf(h1[a], W2[a * HID + j], z);
+        h2[j] = tanhf(z);
+    }
+    float logdet = 0.0f;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+        if (d < dh) {
+            // onp.array_split(out, 3, axis=2): K widths, K heights, K - 1 derivatives; the first two soft-maxed and scaled by 2B, the last
+            // soft-plussed (:255-259) -- and unconstrained_RQS normalises them again (the reference's double application is kept)
+            float uw[KM], uh[KM], ud[KM];
+#pragma unroll
+            for (int part = 0; part < 3; ++part) {
+                float o[KM];
+#pragma unroll
+                for (int q = 0; q < KM; ++q) {
+                    o[q] = 0.0f;
+                    if (q < (part == 2 ? K - 1 : K)) {
+                        const int col = d * per + part * K + q;
+                        float z = b3[col];
+#pragma unroll
+                        for (int a = 0; a < HID; ++a) z = __builtin_fmaf(h2[a], W3[a * dout + col], z);
+                        o[q] = z;
+                    }
+                }
+                if (part < 2) {
+                    float mx = o[0];
+#pragma unroll
+                    for (int q = 1; q < KM; ++q)
+                        if (q < K) mx = fmaxf(mx, o[q]);
+                    float sum = 0.0f;
+#pragma unroll
+                    for (int q = 0; q < KM; ++q)
+                        if (q < K) { o[q] = expf(o[q] - mx); sum += o[q]; }
+#pragma unroll
+                    for (int q = 0; q < KM; ++q) {
+                        const float v = q < K ? 2.0f * tail * (o[q] / sum) : 0.0f;
+                        if (part == 0) uw[q] = v; else uh[q] = v;
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < KM; ++q) ud[q] = q < K - 1 ? softplus(o[q]) : 0.0f;
+                }
+            }
+            float y, ld;
+            if (inverse) rqs_rows<KM>(t[d], K, uh, uw, ud, tail, true, y, ld);
+            else rqs_rows<KM>(t[d], K, uw, uh, ud, tail, false, y, ld);
+            t[d] = y;
+            logdet += ld;
+        }
+    return logdet;
+}
+
+// mode 0: log_pdf = prior(z) + logdet; 2: z and logdet (flow only); 3: inverse (x <- z, out = logdet of the inverse)
+template <int HID, int KM>
+__global__ __launch_bounds__(256) void k_nsc_model(NscModelDev md, int mode, const float* __restrict__ xg, int64_t B, float* __restrict__ out,
+                                                   float* __restrict__ ug) {
+    const int D = md.D, dh = D / 2;
+    for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < B; b += (int64_t)gridDim.x * blockDim.x) {
+        float lo[4] = {0, 0, 0, 0}, up[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+            if (a < dh) { lo[a] = xg[b * D + a]; up[a] = xg[b * D + dh + a]; }
+        float logdet = 0.0f;
+        for (int li = 0; li < md.L; ++li) {
+            const int l = mode == 3 ? md.L - 1 - li : li;
+            const float* __restrict__ f1 = md.params + (int64_t)l * 2 * md.net_floats;
+            const float* __restrict__ f2 = f1 + md.net_floats;
+            if (mode != 3) {
+                logdet += nsc_half<HID, KM>(f1, dh, md.K, md.tail, false, lo, up);   // upper' = RQS(upper | f1(lower))
+                logdet += nsc_half<HID, KM>(f2, dh, md.K, md.tail, false, up, lo);   // lower' = RQS(lower | f2(upper'))
+            }
+            if (md.reverse) {   // flows.Reverse (bijections.py): x[:, ::-1] -- after the layer going forward, before it going back
+                float nl[4], nu[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    nl[a] = a < dh ? up[a < dh ? dh - 1 - a : 0] : 0.0f;
+                    nu[a] = a < dh ? lo[a < dh ? dh - 1 - a : 0] : 0.0f;
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a) { lo[a] = nl[a]; up[a] = nu[a]; }
+            }
+            if (mode == 3) {
+                logdet += nsc_half<HID, KM>(f2, dh, md.K, md.tail, true, up, lo);    // lower' = RQS^-1(lower | f2(upper))
+                logdet += nsc_half<HID, KM>(f1, dh, md.K, md.tail, true, lo, up);    // upper' = RQS^-1(upper | f1(lower'))
+            }
+        }
+        float res = logdet;
+        if (mode == 0) {
+            float lp = 0.0f;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+                if (a < dh) {
+                    if (md.prior_kind == WF_PRIOR_NORMAL) {
+                        const float z0 = lo[a] + md.normal_offset, z1 = up[a] + md.normal_offset;
+                        lp = lp + (1.8378770664093453f + z0 * z0) * -0.5f + (1.8378770664093453f + z1 * z1) * -0.5f;
+                    } else {   // Uniform with prior_support (0, 1): the sample is clipped, the density is 1
+                        lo[a] = fminf(fmaxf(lo[a], 0.0f), 1.0f);
+                        up[a] = fminf(fmaxf(up[a], 0.0f), 1.0f);
+                    }
+                }
+            res = lp + logdet;
+        }
+        out[b] = res;
+        if (ug) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+                if (a < dh) { ug[b * D + a] = lo[a]; ug[b * D + dh + a] = up[a]; }
+        }
+    }
+}
+
+template <int HID, int KM>
+int launch_nsc_model_t(const NscModelDev& md, int mode, const float* x, int64_t B, float* out, float* u, hipStream_t s) {
+    int64_t blocks = (B + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL((k_nsc_model<HID, KM>), dim3((unsigned)blocks), dim3(256), 0, s, md, mode, x, B, out, u);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_hip_error((int)e); return WF_ERR_HIP; }
+    return WF_OK;
+}
+
+// z ~ Normal(0, 1)^D (distributions.py:18-19: the offset only enters log_pdf) or Uniform(0, 1)^D; stream (seed, walker) like wf_sample's
+__global__ void k_nsc_latent(int prior_kind, int D, unsigned long long seed, int64_t B, float* __restrict__ z) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    scalar::Philox rng(seed, (unsigned long long)b);
+    for (int d = 0; d < D; ++d) {
+        if (prior_kind == WF_PRIOR_UNIFORM) {
+            z[b * D + d] = rng.uniform();
+        } else {
+            const float u1 = fmaxf(rng.uniform(), 5.9604645e-8f), u2 = rng.uniform();
+            z[b * D + d] = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+        }
+    }
+}
+int launch_nsc_latent(int prior_kind, int D, unsigned long long seed, int64_t B, float* z, void* stream) {
+    if (B == 0) return WF_OK;
+    hipLaunchKernelGGL(k_nsc_latent, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, prior_kind, D, seed, B, z);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_hip_error((int)e); return WF_ERR_HIP; }
+    return WF_OK;
+}
+
+bool nsc_model_built(int D, int K, int hidden) { return D >= 2 && D <= 8 && D % 2 == 0 && K >= 2 && K <= 16 && (hidden == 8 || hidden == 32); }
+
+int launch_nsc_model(const NscModelDev& md, int mode, const float* x, int64_t B, float* out, float* u, void* stream) {
+    if (B == 0) return WF_OK;
+    if (!nsc_model_built(md.D, md.K, md.hidden)) return WF_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    if (md.hidden == 8) return md.K <= 8 ? launch_nsc_model_t<8, 8>(md, mode, x, B, out, u, s) : launch_nsc_model_t<8, 16>(md, mode, x, B, out, u, s);
+    return md.K <= 8 ? launch_nsc_model_t<32, 8>(md, mode, x, B, out, u, s) : launch_nsc_model_t<32, 16>(md, mode, x, B, out, u, s);
 }
 
 int launch_rqs(const float* x, const float* uw, const float* uh, const float* ud, int64_t N, int K, int n_deriv, int inverse, float left,

@@ -96,6 +96,9 @@ struct wf_model {
     bool wave_ok = false;            // the wave-cooperative sweeps cover this model (homogeneous constraints; > 32 bases: D <= 4)
     // boundary conditions as a linear map on the coefficient vector (bc_map below): column sums a~ of A, per spline (I layers / prior);
     // bc_*_ok: homogeneous (no constant term) and every column with a~_j == 0 is entirely zero -> the table-driven kernels apply
+    bool is_nsc = false;             // layer_kind WF_LAYER_NSC: the coupling stack (k_nsc_model), none of the conditioner-net machinery
+    float* d_nsc = nullptr;          // its parameters on the device (the model's own copy)
+    wf::NscModelDev nsc{};
     std::vector<double> bc_i_colsum, bc_p_colsum;
     bool bc_i_ok = true, bc_p_ok = true;
     bool grad_psi_ok = false;        // wf_psi_vjp (Waveflow prior, IMADE layers)
@@ -251,9 +254,35 @@ static constexpr int kTapedLaplacianMaxD = 8;    // largest D whose reverse swee
 static constexpr int64_t kWaveEvalMax = 6144;   // measured crossover ~7000 walkers (scratch/crossover.py)
 namespace wf {
 
+// layer_kind WF_LAYER_NSC: Flow(Serial((NeuralSplineCoupling [, Reverse]) x L), Normal | Uniform)
+static int nsc_build(wf_model* m) {
+    const wf_model_desc& d = m->desc;
+    const int D = d.n_dim, K = d.nsc_bins, h = d.nsc_hidden;
+    if (D < 2 || D > WF_MAX_DIM || (D % 2) != 0) return WF_ERR_INVALID;          // (dim // 2 coordinates per half, neural_splines.py:256)
+    if (d.n_flow_layers < 1 || d.n_flow_layers > kMaxLayers) return WF_ERR_INVALID;
+    if (K < 2 || h < 1 || !(d.nsc_tail_bound > 0.0f)) return WF_ERR_INVALID;
+    if (d.prior_kind != WF_PRIOR_NORMAL && d.prior_kind != WF_PRIOR_UNIFORM) return WF_ERR_UNSUPPORTED;
+    if (!nsc_model_built(D, K, h)) return WF_ERR_UNSUPPORTED;
+    const int dh = D / 2, per = 3 * K - 1;
+    const int64_t net_floats = (int64_t)dh * h + h + (int64_t)h * h + h + (int64_t)h * per * dh + (int64_t)per * dh;
+    m->n_params = net_floats * 2 * d.n_flow_layers;
+    int rc = dev_alloc(m, &m->d_flat, (size_t)m->n_params);
+    if (rc) return rc;
+    rc = dev_alloc(m, &m->d_nsc, (size_t)m->n_params);
+    if (rc) return rc;
+    m->dev = ModelDev{};
+    m->dev.D = D;
+    m->dev.prior_kind = d.prior_kind;
+    m->nbp = 32;
+    m->nsc = NscModelDev{D, d.n_flow_layers, K, h, d.prior_kind, d.nsc_reverse != 0 ? 1 : 0, d.nsc_tail_bound, d.normal_offset, m->d_nsc, net_floats};
+    m->is_nsc = true;
+    return WF_OK;
+}
+
 static int model_build(wf_model* m) {
     const wf_model_desc& d = m->desc;
     const int D = d.n_dim;
+    if (d.layer_kind == WF_LAYER_NSC) return nsc_build(m);
     if (D < 2 || D > WF_MAX_DIM) return WF_ERR_INVALID;
     if (d.hidden != kHidden) return WF_ERR_UNSUPPORTED;
     if (d.n_flow_layers < 0 || d.n_flow_layers > kMaxLayers) return WF_ERR_INVALID;
@@ -1014,6 +1043,12 @@ int wf_model_set_kernel(wf_model* m, int kernel_kind) {
 
 // fills every weight image from a device-resident flat vector (asynchronous on `stream`)
 static int apply_params(wf_model* m, const float* flat_dev, void* stream, bool eval_tables = true) {
+    if (m->is_nsc) {   // the kernel reads the Dense leaves as they are: keep the model's own copy
+        if (m->n_params > 0 && flat_dev != m->d_nsc)
+            WF_HIP(hipMemcpyAsync(m->d_nsc, flat_dev, (size_t)m->n_params * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        m->params_set = true;
+        return WF_OK;
+    }
     {
         int rc = launch_pack(flat_dev, m->d_pack, m->n_pack, m->d_plain, m->d_wave, m->d_mfma, stream);
         if (rc) return rc;
@@ -1067,6 +1102,10 @@ static int check_fwd(const wf_model* m, const void* x, int64_t B, const void* ou
 static int dispatch(const wf_model* m, int mode, const float* x, int64_t B, float* out, float* u, int32_t* idx, void* stream) {
     DeviceGuard g(m->device);
     if (B == 0) return WF_OK;
+    if (m->is_nsc) {
+        if (mode == 1 || idx) return WF_ERR_UNSUPPORTED;
+        return launch_nsc_model(m->nsc, mode, x, B, out, u, stream);
+    }
     // Small batches: one wave per walker (wf_kernels_wave.hip) takes 14 us for up to ~1000 walkers where the MFMA kernel,
     // which first stages its weight images into LDS, takes 38-42 us whatever the batch; from ~7000 walkers on the MFMA
     // kernel's throughput wins (4096: 30 vs 42 us, 8192: 46 vs 42 us).  The wave kernel does
@@ -1122,6 +1161,7 @@ int wf_layer_fwd(const wf_model* m, int layer, const float* u_in_dev, int64_t B,
     int rc = check_fwd(m, u_in_dev, B, y_dev);
     if (rc) return rc;
     if (layer < 0 || layer >= m->desc.n_flow_layers || (B > 0 && !logdet_dev)) return WF_ERR_INVALID;
+    if (m->is_nsc) return WF_ERR_UNSUPPORTED;
     DeviceGuard g(m->device);
     if (B == 0) return WF_OK;
     return launch_scalar_layer(m->dev, m->d_dev, layer, u_in_dev, B, y_dev, logdet_dev, bin_idx_dev, stream);
@@ -1142,6 +1182,11 @@ int wf_inverse_fwd(const wf_model* m, const float* u_dev, int64_t B, float* x_de
     if (rc) return rc;
     DeviceGuard g(m->device);
     if (B == 0) return WF_OK;
+    if (m->is_nsc) {   // a coupling layer's inverse is exact either way; the log-det of the inverse goes to the model's scratch
+        rc = ensure_scratch(m, B);
+        if (rc) return rc;
+        return launch_nsc_model(m->nsc, 3, u_dev, B, m->d_scratch, x_dev, stream);
+    }
     if (m->wave_ok && B <= wave_sample_max())
         return launch_wave_sample(m->dev, m->d_dev, m->d_tabI4, m->d_tabP3, m->d_grad_fk, 0, 0ull, u_dev, B, x_dev, nullptr, exact, nullptr, stream);
     return launch_scalar_inverse(m->dev, m->d_dev, u_dev, B, x_dev, exact, stream);
@@ -1152,6 +1197,14 @@ int wf_sample(const wf_model* m, uint64_t seed, int64_t B, float* x_dev, float* 
     if (rc) return rc;
     DeviceGuard g(m->device);
     if (B == 0) return WF_OK;
+    if (m->is_nsc) {   // z ~ prior (Philox, keyed like the other samplers), x = inverse(z)
+        rc = ensure_scratch(m, B * (m->desc.n_dim + 1));
+        if (rc) return rc;
+        float* z = latent_dev ? latent_dev : m->d_scratch + B;
+        rc = launch_nsc_latent(m->desc.prior_kind, m->desc.n_dim, (unsigned long long)seed, B, z, stream);
+        if (rc) return rc;
+        return launch_nsc_model(m->nsc, 3, z, B, m->d_scratch, x_dev, stream);
+    }
     if (m->wave_ok && B <= wave_sample_max())
         return launch_wave_sample(m->dev, m->d_dev, m->d_tabI4, m->d_tabP3, m->d_grad_fk, 1, (unsigned long long)seed, nullptr, B, x_dev, latent_dev,
                                   exact, nullptr, stream);
@@ -1500,6 +1553,14 @@ int wf_nsc_fwd(const float* x_dev, int64_t B, int32_t dim, int32_t K, float tail
     if (workspace_bytes < wf_nsc_workspace_bytes(B, dim, K)) return WF_ERR_INVALID;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return WF_ERR_NO_DEVICE;
+    // the shapes the one-kernel stack is built for (every reference default) never touch the workspace; WF_NSC_STAGED=1 forces the
+    // launch-per-half-step path (the only one for other widths / bin counts)
+    if (nsc_model_built(dim, K, hidden) && !getenv("WF_NSC_STAGED")) {
+        const int dh = dim / 2, per = 3 * K - 1;
+        const int64_t net_floats = (int64_t)dh * hidden + hidden + (int64_t)hidden * hidden + hidden + (int64_t)hidden * per * dh + (int64_t)per * dh;
+        const NscModelDev md{dim, 1, K, hidden, WF_PRIOR_NORMAL, 0, tail_bound, 0.0f, params_dev, net_floats};
+        return launch_nsc_model(md, inverse ? 3 : 2, x_dev, B, logdet_dev, y_dev, stream);
+    }
     return launch_nsc(x_dev, B, dim, K, tail_bound, hidden, params_dev, inverse, y_dev, logdet_dev, (float*)workspace_dev, stream);
 }
 

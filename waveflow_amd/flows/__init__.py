@@ -81,6 +81,14 @@ class MADESpec:
 
 
 @dataclass
+class NSCSpec:
+    """NeuralSplineCoupling(K, B, hidden_dim) (neural_splines.py:244)"""
+    K: int
+    B: float
+    hidden: int
+
+
+@dataclass
 class BoxSpec:
     box_side: float
     kind: str
@@ -132,6 +140,22 @@ def _desc(D, layers=(), box=None, prior=_lib.PRIOR_UNIFORM, p_degree=0, p_knots=
     for i, c in enumerate(cl):
         d.constrained_left[i] = c
     return d
+
+
+def parse_nsc_serial(spec):
+    """SerialSpec -> (NSCSpec, n_layers, reverse) if it is NeuralSplineCoupling * n or (NeuralSplineCoupling, Reverse) * n, else None."""
+    items = list(spec.items)
+    if not items or not isinstance(items[0], NSCSpec):
+        return None
+    reverse = len(items) > 1 and isinstance(items[1], ReverseSpec)
+    step = 2 if reverse else 1
+    if len(items) % step:
+        return None
+    for i, it in enumerate(items):
+        want_rev = reverse and i % 2 == 1
+        if want_rev != isinstance(it, ReverseSpec) or (not want_rev and it != items[0]):
+            return None
+    return items[0], len(items) // step, reverse
 
 
 def parse_serial(spec):
@@ -286,6 +310,17 @@ class Serial(_InitFun):
         return [f.init_params(g, input_dim) for f in self.init_funs]
 
     def fused_model(self, input_dim, **prior_kw):
+        nsc = parse_nsc_serial(self.spec)
+        if nsc is not None:   # the coupling stack as a model (wf_model_desc.layer_kind = WF_LAYER_NSC): Normal / Uniform priors
+            first, n, reverse = nsc
+            if prior_kw.get("prior", _lib.PRIOR_UNIFORM) not in (_lib.PRIOR_NORMAL, _lib.PRIOR_UNIFORM):
+                raise NotImplementedError("NeuralSplineCoupling stacks are built under flows.Flow(.., Normal() | Uniform())")
+            d = _lib.ModelDesc()
+            d.n_dim, d.hidden, d.n_flow_layers, d.n_mesh, d.layer_kind = input_dim, HIDDEN, n, 2000, _lib.LAYER_NSC
+            d.prior_kind = prior_kw.get("prior", _lib.PRIOR_UNIFORM)
+            d.normal_offset = float(prior_kw.get("normal_offset", 0.0))
+            d.nsc_bins, d.nsc_tail_bound, d.nsc_hidden, d.nsc_reverse = first.K, first.B, first.hidden, int(reverse)
+            return DeviceModel(d)
         parsed = parse_serial(self.spec)
         if parsed is None:
             return None

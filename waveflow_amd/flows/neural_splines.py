@@ -71,6 +71,16 @@ class NeuralSplineCoupling:
         if network is not FCNN:
             raise NotImplementedError("NeuralSplineCoupling is built with the reference's FCNN conditioner")
         self.K, self.B, self.hidden = int(K), float(B), int(hidden_dim)
+        from . import NSCSpec
+        self.spec = NSCSpec(self.K, self.B, self.hidden)   # lets flows.Serial / flows.Flow fuse a stack of these into one model
+
+    def init_params(self, rng, dim):
+        from . import as_generator
+        if dim % 2:
+            raise ValueError("NeuralSplineCoupling needs an even number of dimensions")
+        g = as_generator(rng)
+        dh, per = dim // 2, 3 * self.K - 1
+        return (self._init_net(g, dh, per * dh), self._init_net(g, dh, per * dh))
 
     def _init_net(self, g, din, dout):
         h = self.hidden
@@ -82,9 +92,7 @@ class NeuralSplineCoupling:
         from . import as_generator
         if dim % 2:
             raise ValueError("NeuralSplineCoupling needs an even number of dimensions")
-        g = as_generator(rng)
-        dh, per = dim // 2, 3 * self.K - 1
-        params = (self._init_net(g, dh, per * dh), self._init_net(g, dh, per * dh))
+        params = self.init_params(rng, dim)
         K, tail, hidden = self.K, self.B, self.hidden
 
         def run(params, x, inverse):
