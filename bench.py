@@ -177,7 +177,7 @@ def main():
     ap.add_argument("--kernel", default="auto", choices=["auto", "scalar", "mfma", "wave"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary legs (33-knot variant, batch 256, D = 8, 1-thread CPU)")
-    ap.add_argument("--workload", default="he_logpdf", choices=["he_logpdf", "rqs", "vqmc"],
+    ap.add_argument("--workload", default="he_logpdf", choices=["he_logpdf", "rqs", "vqmc", "nsc"],
                     help="he_logpdf: the BASELINE metric (default).  rqs: the RQS bijector kernel alone (SURVEY row a12), an "
                          "HBM-bound elementwise op: 2 dims x `--batch` walkers, 32 bins")
     args = ap.parse_args()
@@ -185,6 +185,8 @@ def main():
         return main_rqs(args)
     if args.workload == "vqmc":
         return main_vqmc(args)
+    if args.workload == "nsc":
+        return main_nsc(args)
 
     import torch
     import torch.distributed as dist
@@ -347,6 +349,60 @@ def main_rqs(args):
         "config": {"workload": f"unconstrained RQS forward (neural_splines.py:16-71), K=32 bins, {N} elements (2 dims x {args.batch} walkers)"},
         "roofline": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
                      "kernel": "k_rqs_reg<32>", "kernel_ms": kern_ms, "bytes_per_eval": bytes_per}}), flush=True)
+
+
+def main_nsc(args):
+    """Secondary line: log_pdf of Flow(Serial((NeuralSplineCoupling(K=5, B=3, hidden_dim=8), Reverse) x 3), Normal()) in two dimensions --
+    the reference's defaults (neural_splines.py:244) -- over `--batch` walkers: one launch of k_nsc_model<8, 8> (single GPU)."""
+    import torch
+    from waveflow_amd import flows
+    L, K, H, D = 3, 5, 8, 2
+    items = []
+    for _ in range(L):
+        items += [flows.NeuralSplineCoupling(K=K, B=3, hidden_dim=H), flows.Reverse()]
+    params, log_pdf, _ = flows.Flow(flows.Serial(*items), flows.Normal())(7, D)
+    params = [tuple([tuple(a * (1.5 if a.ndim == 2 else 3e4) for a in l) if l else () for l in net] for net in p) if p else () for p in params]
+    m = log_pdf.model
+    m.ensure_params(params)
+    B = args.batch
+    x = (torch.rand(B, D, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1234)) * 6.8 - 3.4).contiguous()
+    for _ in range(args.warmup + 1):
+        m.log_pdf(x)
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()
+        m.log_pdf(x)
+        b.record()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    bytes_per = (D + 1) * 4                      # x in, log_pdf out: the weights come through the scalar cache
+    gbs = B * bytes_per / (kern_ms * 1e-3) / 1e9
+    # the launch-per-half-step path of the bare layer, for comparison: (3K - 1) * 2 * 4 bytes of spline parameters per coordinate through HBM
+    one = flows.NeuralSplineCoupling(K=K, B=3, hidden_dim=H)
+    p1, direct_fun, _ = one(3, D)
+    os.environ["WF_NSC_STAGED"] = "1"
+    for _ in range(3):
+        direct_fun(p1, x)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(10):
+        direct_fun(p1, x)
+    torch.cuda.synchronize()
+    staged_ms = (time.perf_counter() - t1) / 10 * 1e3
+    del os.environ["WF_NSC_STAGED"]
+    print(json.dumps({
+        "metric": "coupling-flow log_pdf evals/sec", "value": B * args.steps / dt, "unit": "evals/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"Flow(Serial((NeuralSplineCoupling(K={K}, B=3, hidden_dim={H}), Reverse) x {L}), Normal()) log_pdf, D={D}, {B} walkers"},
+        "roofline": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
+                     "kernel": "k_nsc_model<8, 8, 1, 5>", "kernel_ms": kern_ms, "bytes_per_eval": bytes_per,
+                     "note": "12 bytes per walker against ~3 600 VALU instructions (three layers of two half-steps: two tanh layers, two soft-maxes and a "
+                             "soft-plus, the spline's own soft-max and logs): the launch is bounded by instruction issue, not by HBM; see DESIGN 4.4"},
+        "one_layer_staged_path_ms": staged_ms, "one_layer_share_of_fused_ms": kern_ms / L}), flush=True)
 
 
 def main_vqmc(args):

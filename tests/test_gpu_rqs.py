@@ -187,7 +187,7 @@ def test_neural_spline_coupling_stack_as_a_model(dim, K, hidden, reverse, prior)
         assert abs(lat.mean()) < 0.08 and abs(lat.std() - 1) < 0.08
     _, u2 = log_pdf(params, s, return_sample=True)
     d = np.abs(np.asarray(u2) - (lat if prior == "normal" else np.clip(lat, 0, 1))).max(1)
-    assert np.median(d) < 5e-4 and np.quantile(d, 0.9) < 2e-2
+    assert np.median(d) < 1e-3 and np.quantile(d, 0.9) < 2e-2     # (three layers: three times the one-layer round-trip bound above)
     # what this model kind does not do fails loudly
     from waveflow_amd import _lib
     with pytest.raises(_lib.WfError):

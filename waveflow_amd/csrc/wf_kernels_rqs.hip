@@ -388,6 +388,11 @@ __global__ void k_nsc_finish(int64_t B, int dim, int dh, const float* __restrict
 // walker instead of the (6K + 8) * D * 2 bytes the launch-per-half-step path (launch_nsc) moves through its workspace.
 // unconstrained_RQS on register rows (same arithmetic as k_rqs_reg: widths / heights min + (1 - min K) softmax, knots by running
 // sum with the end knot forced, bin = sum(x >= knot) - 1 clamped, derivative edge constant, identity outside the tails).
+// fast transcendentals of the one-kernel stack: hardware exp2 / log2 / rcp (1 ulp), tanh = 1 - 2 / (e^{2x} + 1) (2^-23 absolute)
+__device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ __forceinline__ float flog(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+__device__ __forceinline__ float ftanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x * 2.8853900817779268f) + 1.0f); }
+
 template <int KM>
 __device__ __forceinline__ void rqs_rows(float x, int K, float (&sr)[KM], float (&orow)[KM], const float (&ud)[KM], float tail, bool inverse,
                                          float& y, float& ld) {
@@ -407,7 +412,7 @@ __device__ __forceinline__ void rqs_rows(float x, int K, float (&sr)[KM], float 
             ss = ss + sr[i];
             so = so + orow[i];
         }
-    const float cs_ = (1 - kMinBinWidth * K) / ss, co_ = (1 - kMinBinHeight * K) / so;
+    const float cs_ = (1 - kMinBinWidth * K) * __builtin_amdgcn_rcpf(ss), co_ = (1 - kMinBinHeight * K) * __builtin_amdgcn_rcpf(so);
     int count = x >= lo ? 1 : 0;
     float cs = 0.0f, co = 0.0f, sprev = lo, oprev = lo;
     float s_knot = lo, s_size = 1.0f, o_knot = lo, o_size = 1.0f, u0 = edge, u1 = edge;
@@ -434,7 +439,8 @@ __device__ __forceinline__ void rqs_rows(float x, int K, float (&sr)[KM], float 
     const float in_cw = inverse ? o_knot : s_knot, in_w = inverse ? o_size : s_size;
     const float in_ch = inverse ? s_knot : o_knot, in_h = inverse ? s_size : o_size;
     const float d0 = kMinDerivative + softplus(u0), d1 = kMinDerivative + softplus(u1);
-    const float delta = in_h / in_w;
+    const float rw = __builtin_amdgcn_rcpf(in_w);
+    const float delta = inverse ? in_h / in_w : in_h * rw;   // (the inverse keeps IEEE division / sqrt: its error is amplified by 1 / slope)
     if (inverse) {
         const float a = (x - in_ch) * (d0 + d1 - 2 * delta) + in_h * (delta - d0);
         const float bq = in_h * d0 - (x - in_ch) * (d0 + d1 - 2 * delta);
@@ -447,20 +453,21 @@ __device__ __forceinline__ void rqs_rows(float x, int K, float (&sr)[KM], float 
         const float num = delta * delta * (d1 * root * root + 2 * delta * t1 + d0 * (1 - root) * (1 - root));
         ld = -(logf(num) - 2 * logf(den));
     } else {
-        const float th = (x - in_cw) / in_w;
+        const float th = (x - in_cw) * rw;
         const float t1 = th * (1 - th);
         const float num = in_h * (delta * th * th + d0 * t1);
         const float den = delta + ((d0 + d1 - 2 * delta) * t1);
-        y = in_ch + num / den;
+        y = in_ch + num * __builtin_amdgcn_rcpf(den);
         const float dnum = delta * delta * (d1 * th * th + 2 * delta * t1 + d0 * (1 - th) * (1 - th));
-        ld = logf(dnum) - 2 * logf(den);
+        ld = flog(dnum) - 2 * flog(den);
     }
     if (!(x >= lo && x <= hi)) { y = x; ld = 0.0f; }
 }
 
 // one half-step (neural_splines.py:254-262): the dh coordinates t[] transformed given the dh coordinates c[]
 template <int HID, int KM>
-__device__ __forceinline__ float nsc_half(const float* __restrict__ net, int dh, int K, float tail, bool inverse, const float (&c)[4], float (&t)[4]) {
+__device__ __forceinline__ float nsc_half(const float* __restrict__ net, const int dh, const int K, float tail, bool inverse, const float (&c)[4],
+                                          float (&t)[4]) {
     const int per = 3 * K - 1, dout = per * dh;
     const float* __restrict__ W1 = net;
     const float* __restrict__ b1 = W1 + dh * HID;
@@ -475,14 +482,14 @@ __device__ __forceinline__ float nsc_half(const float* __restrict__ net, int dh,
 #pragma unroll
         for (int a = 0; a < 4; ++a)
             if (a < dh) z = __builtin_fmaf(c[a], W1[a * HID + j], z);
-        h1[j] = tanhf(z);
+        h1[j] = ftanh(z);
     }
 #pragma unroll
     for (int j = 0; j < HID; ++j) {
         float z = b2[j];
 #pragma unroll
         for (int a = 0; a < HID; ++a) z = __builtin_fmaf(h1[a], W2[a * HID + j], z);
-        h2[j] = tanhf(z);
+        h2[j] = ftanh(z);
     }
     float logdet = 0.0f;
 #pragma unroll
@@ -513,10 +520,11 @@ __device__ __forceinline__ float nsc_half(const float* __restrict__ net, int dh,
                     float sum = 0.0f;
 #pragma unroll
                     for (int q = 0; q < KM; ++q)
-                        if (q < K) { o[q] = expf(o[q] - mx); sum += o[q]; }
+                        if (q < K) { o[q] = fexp(o[q] - mx); sum += o[q]; }
+                    const float sc = 2.0f * tail * __builtin_amdgcn_rcpf(sum);
 #pragma unroll
                     for (int q = 0; q < KM; ++q) {
-                        const float v = q < K ? 2.0f * tail * (o[q] / sum) : 0.0f;
+                        const float v = q < K ? sc * o[q] : 0.0f;
                         if (part == 0) uw[q] = v; else uh[q] = v;
                     }
                 } else {
@@ -534,10 +542,11 @@ __device__ __forceinline__ float nsc_half(const float* __restrict__ net, int dh,
 }
 
 // mode 0: log_pdf = prior(z) + logdet; 2: z and logdet (flow only); 3: inverse (x <- z, out = logdet of the inverse)
-template <int HID, int KM>
+// DHT / KT != 0: the half width and the bin count as compile-time constants (the reference's shapes), every guard folds away
+template <int HID, int KM, int DHT = 0, int KT = 0>
 __global__ __launch_bounds__(256) void k_nsc_model(NscModelDev md, int mode, const float* __restrict__ xg, int64_t B, float* __restrict__ out,
                                                    float* __restrict__ ug) {
-    const int D = md.D, dh = D / 2;
+    const int dh = DHT ? DHT : md.D / 2, D = 2 * dh, nK = KT ? KT : md.K;
     for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < B; b += (int64_t)gridDim.x * blockDim.x) {
         float lo[4] = {0, 0, 0, 0}, up[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -549,8 +558,8 @@ __global__ __launch_bounds__(256) void k_nsc_model(NscModelDev md, int mode, con
             const float* __restrict__ f1 = md.params + (int64_t)l * 2 * md.net_floats;
             const float* __restrict__ f2 = f1 + md.net_floats;
             if (mode != 3) {
-                logdet += nsc_half<HID, KM>(f1, dh, md.K, md.tail, false, lo, up);   // upper' = RQS(upper | f1(lower))
-                logdet += nsc_half<HID, KM>(f2, dh, md.K, md.tail, false, up, lo);   // lower' = RQS(lower | f2(upper'))
+                logdet += nsc_half<HID, KM>(f1, dh, nK, md.tail, false, lo, up);   // upper' = RQS(upper | f1(lower))
+                logdet += nsc_half<HID, KM>(f2, dh, nK, md.tail, false, up, lo);   // lower' = RQS(lower | f2(upper'))
             }
             if (md.reverse) {   // flows.Reverse (bijections.py): x[:, ::-1] -- after the layer going forward, before it going back
                 float nl[4], nu[4];
@@ -563,8 +572,8 @@ __global__ __launch_bounds__(256) void k_nsc_model(NscModelDev md, int mode, con
                 for (int a = 0; a < 4; ++a) { lo[a] = nl[a]; up[a] = nu[a]; }
             }
             if (mode == 3) {
-                logdet += nsc_half<HID, KM>(f2, dh, md.K, md.tail, true, up, lo);    // lower' = RQS^-1(lower | f2(upper))
-                logdet += nsc_half<HID, KM>(f1, dh, md.K, md.tail, true, lo, up);    // upper' = RQS^-1(upper | f1(lower'))
+                logdet += nsc_half<HID, KM>(f2, dh, nK, md.tail, true, up, lo);    // lower' = RQS^-1(lower | f2(upper))
+                logdet += nsc_half<HID, KM>(f1, dh, nK, md.tail, true, lo, up);    // upper' = RQS^-1(upper | f1(lower'))
             }
         }
         float res = logdet;
@@ -592,11 +601,11 @@ __global__ __launch_bounds__(256) void k_nsc_model(NscModelDev md, int mode, con
     }
 }
 
-template <int HID, int KM>
+template <int HID, int KM, int DHT = 0, int KT = 0>
 int launch_nsc_model_t(const NscModelDev& md, int mode, const float* x, int64_t B, float* out, float* u, hipStream_t s) {
     int64_t blocks = (B + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL((k_nsc_model<HID, KM>), dim3((unsigned)blocks), dim3(256), 0, s, md, mode, x, B, out, u);
+    hipLaunchKernelGGL((k_nsc_model<HID, KM, DHT, KT>), dim3((unsigned)blocks), dim3(256), 0, s, md, mode, x, B, out, u);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_hip_error((int)e); return WF_ERR_HIP; }
     return WF_OK;
@@ -630,6 +639,8 @@ int launch_nsc_model(const NscModelDev& md, int mode, const float* x, int64_t B,
     if (B == 0) return WF_OK;
     if (!nsc_model_built(md.D, md.K, md.hidden)) return WF_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
+    if (md.hidden == 8 && md.K == 5 && md.D == 2) return launch_nsc_model_t<8, 8, 1, 5>(md, mode, x, B, out, u, s);   // NeuralSplineCoupling()'s defaults
+    if (md.hidden == 8 && md.K == 5 && md.D == 4) return launch_nsc_model_t<8, 8, 2, 5>(md, mode, x, B, out, u, s);
     if (md.hidden == 8) return md.K <= 8 ? launch_nsc_model_t<8, 8>(md, mode, x, B, out, u, s) : launch_nsc_model_t<8, 16>(md, mode, x, B, out, u, s);
     return md.K <= 8 ? launch_nsc_model_t<32, 8>(md, mode, x, B, out, u, s) : launch_nsc_model_t<32, 16>(md, mode, x, B, out, u, s);
 }
