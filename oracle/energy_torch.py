@@ -51,8 +51,13 @@ def table_spline(x, c, tab, nd=0):
 class TorchWaveflow:
     """Waveflow (B-spline prior, IMADE layers, 'mean' or 'first' box) in torch; parameters = flat reference leaf order."""
 
-    def __init__(self, D, n_layers, box, box_L, k, knots, i_reg, constr_left, dtype=torch.float64, n_mesh=2000):
+    def __init__(self, D, n_layers, box, box_L, k, knots, i_reg, constr_left, dtype=torch.float64, n_mesh=2000, i_left=None, i_right=None,
+                 p_left=None, p_right=None):
+        """i_left / i_right / p_left / p_right: general {n_derivative: value} dictionaries (None: the zero-only defaults {0: 0} / {0: 1} and
+        {0: 0} / {0: 0}, evaluated as a 0/1 mask); enforced literally, in dictionary order, as enforce_boundary_conditions does."""
         self.D, self.n_layers, self.box, self.L, self.k, self.i_reg, self.dtype = D, n_layers, box, float(box_L), k, float(i_reg), dtype
+        self.i_bc = None if i_left is None and i_right is None else ({0: 0.0} if i_left is None else i_left, {0: 1.0} if i_right is None else i_right)
+        self.p_bc = None if p_left is None and p_right is None else ({0: 0.0} if p_left is None else p_left, {0: 0.0} if p_right is None else p_right)
         self.constr_left = tuple(constr_left)
         I = oracle.table(oracle.KIND_I, k, knots, n_mesh)
         Bt, OB, b2o, o2b = oracle.ortho_b(k, knots, n_mesh)
@@ -64,6 +69,23 @@ class TorchWaveflow:
         dh = torch.arange(H) % (D - 1)
         dout = torch.arange(D) - 1
         self.masks = [(dh[None, :] >= din[:, None]).to(dtype), (dh[None, :] >= dh[:, None]).to(dtype), (dout[None, :] >= dh[:, None]).to(dtype)]
+
+    @staticmethod
+    def _enforce(w, tab, left, right, is_I):
+        """enforce_boundary_conditions before its final normalisation (isplines_jax.py:166-190, bsplines_jax.py:176-189): coefficient nd
+        (left) / nb-1-nd (right) <- (value - sum_{j<nd} T^(nd)_j(end) c_j) / T^(nd)_nd(end).  w: [..., nb]; tab: [4][nb][n_mesh]."""
+        nb = w.shape[-1]
+        cols = list(w.unbind(-1))
+        for nd, val in left.items():
+            acc = sum(tab[nd, j, 0] * cols[j] for j in range(nd)) if nd else 0.0
+            cols[nd] = (val - acc) / tab[nd, nd, 0] + 0 * cols[nd]
+        for nd, val in right.items():
+            if is_I and nd == 0:
+                cols[nb - 1] = 0 * cols[nb - 1]
+                continue
+            acc = sum(tab[nd, nb - 1 - j, -1] * cols[nb - 1 - j] for j in range(nd)) if nd else 0.0
+            cols[nb - nd - 1] = (val - acc) / tab[nd, nb - nd - 1, -1] + 0 * cols[nb - nd - 1]
+        return torch.stack(cols, -1)
 
     def _net(self, p, off, n_out):
         D, H = self.D, 64
@@ -129,8 +151,11 @@ class TorchWaveflow:
             w = w * scale
             w = w / w.sum(-1, keepdim=True)
             # enforce_boundary_conditions {0:0} / {0:1}
-            keep = torch.ones(nb, dtype=dt); keep[0] = 0; keep[-1] = 0
-            w = w * keep
+            if self.i_bc is None:
+                keep = torch.ones(nb, dtype=dt); keep[0] = 0; keep[-1] = 0
+                w = w * keep
+            else:
+                w = self._enforce(w, self.I, self.i_bc[0], self.i_bc[1], True)
             w = w / w.sum(-1, keepdim=True)
             y = table_spline(u, w, self.I, 0)
             dy = table_spline(u, w, self.I, 1)
@@ -139,8 +164,11 @@ class TorchWaveflow:
         nbp = self.p_nb
         net, off = self._net(p, off, nbp)
         w = self._conditioner(net, u, nbp, False)
-        keep = torch.ones(nbp, dtype=dt); keep[0] = 0; keep[-1] = 0
-        w = w * keep
+        if self.p_bc is None:
+            keep = torch.ones(nbp, dtype=dt); keep[0] = 0; keep[-1] = 0
+            w = w * keep
+        else:
+            w = self._enforce(w, self.Bplain, self.p_bc[0], self.p_bc[1], False)
         w = w / torch.sqrt((w ** 2).sum(-1, keepdim=True))
         c = w @ self.o2b
         c = c / torch.sqrt((c ** 2).sum(-1, keepdim=True))

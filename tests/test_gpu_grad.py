@@ -582,6 +582,46 @@ def test_model_without_flow_layers(he_flat):
     assert (u - lat).abs().max().item() < 1e-4 and bool(torch.isfinite(lp).all())
 
 
+def test_wavefunction_with_derivative_constraints_energy_and_gradients():
+    """General homogeneous boundary dictionaries through the wave sweeps: psi, H psi, the Laplacian and both vector-Jacobian products of a
+    Waveflow whose layers and prior carry derivative constraints ({0: 0, 1: 0} / {0: 1, 1: 0}; {0: 0, 2: 0} / {0: 0, 1: 0}), vs the torch
+    oracle that enforces the dictionaries literally (sequential overwrite, as the reference does) and differentiates with autograd."""
+    import torch
+    from oracle import energy_torch as et
+    from waveflow_amd import flatten_params, flows, model_factory, wavefunctions
+    mt = model_factory.get_masked_transform
+    il, ir, pl, pr = {0: 0.0, 1: 0.0}, {0: 1.0, 1: 0.0}, {0: 0, 2: 0}, {0: 0, 1: 0}
+    init = wavefunctions.Waveflow(
+        flows.Serial(flows.BoxTransformLayer(3.0), *(flows.IMADE(mt(), 6, 23, 0.05, 1e-6, il, ir), flows.Reverse()) * 2),
+        mt(allow_negative_params=True), 6, 23, constraints_dict_left=pl, constraints_dict_right=pr, constrained_dimension_indices_left=[0],
+        set_nn_output_grad_to_zero=False)
+    params, psi, log_pdf, _ = init(4, 2)
+    flat = flatten_params(params)
+    mo = et.TorchWaveflow(2, 2, "mean", 3.0, 6, 23, 0.05, (0,), dtype=torch.float64, i_left=il, i_right=ir, p_left=pl, p_right=pr)
+    x = sorted_walkers(160, 2, 2.7, 13)
+    m = psi.model
+    m.ensure_params(params)
+    assert m.desc.i_left.n == 2 and m.desc.p_left.n == 2
+    xt = torch.as_tensor(x, dtype=torch.float64)
+    for kernel in ("scalar", "mfma", "wave"):
+        m.set_kernel(kernel)
+        np.testing.assert_allclose(psi(params, x), mo.psi(flat, xt).numpy(), rtol=0, atol=3e-5 * float(mo.psi(flat, xt).abs().max()))
+        np.testing.assert_allclose(log_pdf(params, x), mo.log_pdf(flat, xt).numpy(), rtol=0, atol=3e-3)
+    m.set_kernel("auto")
+    hp, ps, lap = m.hamiltonian(x, [0.0, 0.0], return_psi=True, return_laplacian=True)
+    ho, po, lo = et.hamiltonian(mo, flat, x.astype(np.float64), [0.0, 0.0])
+    np.testing.assert_allclose(lap, lo, rtol=0, atol=3e-3 * np.abs(lo).max())
+    np.testing.assert_allclose(hp, ho, rtol=0, atol=3e-3 * np.abs(ho).max())
+    g = np.random.default_rng(2)
+    w1, w2 = g.normal(size=len(x)).astype(np.float32), g.normal(size=len(x)).astype(np.float32)
+    got = m.psi_vjp(x, w1, 0.1 * w2).cpu().numpy().astype(np.float64)
+    want = et.psi_vjp(mo, flat, x.astype(np.float64), w1, 0.1 * w2)
+    assert rel_l2(got, want) < 5e-3, rel_l2(got, want)
+    got = m.logpdf_vjp(x, w1).cpu().numpy().astype(np.float64)
+    want = et.logpdf_vjp(mo, flat, x.astype(np.float64), w1)
+    assert rel_l2(got, want) < 2e-3, rel_l2(got, want)
+
+
 def test_trained_energy_respects_the_variational_bound(tmp_path):
     """Known answer for the derivative path (unpinned in the reference): the lowest antisymmetric eigenvalue of the 1-D
     soft-Coulomb He Hamiltonian in the box [-10, 10]^2 is -1.8161 (finite-difference diagonalisation, scratch/he1d_exact.py).

@@ -735,7 +735,7 @@ def test_gated_conditioner_heads(kernel):
         m.set_kernel("wave")
     m.set_kernel("auto")
     small = np.asarray(log_pdf(params, x[:100]))      # auto: a small batch goes to the per-walker kernel instead
-    np.testing.assert_allclose(small, om.log_pdf(flat, x[:100]), rtol=0, atol=5e-4)
+    as_accurate_as_fp32_reference(small, om.log_pdf(flat, x[:100]), om.log_pdf(flat, x[:100], f64=True), what="gated, batch of 100 (per-walker kernel)")
     with pytest.raises(_lib.WfError):
         m.logpdf_vjp(x[:16], np.ones(16, np.float32))
     with pytest.raises(_lib.WfError):
