@@ -200,7 +200,7 @@ int wf_sample(const wf_model* m, uint64_t seed, int64_t B, float* x_dev, float* 
  * with physics.laplacian (:50-52, trace of jax.hessian -- the table lerp differentiates to the next cached derivative table,
  * isplines_jax.py:60-66) and the one-dimensional soft-Coulomb physics.get_potential (:60-76) for `n_protons` <= 8 protons at
  * `protons_host`.  hpsi_dev[B]; psi_dev[B] and laplacian_dev[B] may be NULL.  The local energy of vqmc.loss_fn_efficient
- * (vqmc.py:193-200) is hpsi / (psi + 1e-8).  WF_PRIOR_WAVEFLOW models with IMADE layers, zero-only boundary constraints;
+ * (vqmc.py:193-200) is hpsi / (psi + 1e-8).  WF_PRIOR_WAVEFLOW models with IMADE layers, homogeneous boundary constraints (every value 0 apart from the I-spline's right {0: 1}), ungated heads;
  * D = 2..8 with <= 32 bases per dimension, D = 2..4 with 33..64. */
 int wf_hamiltonian_fwd(const wf_model* m, const float* x_dev, int64_t B, const float* protons_host, int32_t n_protons,
                        float* hpsi_dev, float* psi_dev, float* laplacian_dev, void* stream);
@@ -212,7 +212,7 @@ int wf_hamiltonian_fwd(const wf_model* m, const float* x_dev, int64_t B, const f
  * reference where they only enter multiplied by their mask).  The table lerp differentiates to the next cached table and
  * the order beyond the last cached one clamps to it (JAX's out-of-range index semantics at isplines_jax.py:65).
  * workspace: wf_psi_vjp_workspace_bytes(m, B) bytes suffice for any B (larger batches are processed in chunks of what the
- * workspace holds).  Same model coverage as wf_hamiltonian_fwd, zero-only boundary constraints. */
+ * workspace holds).  Same model coverage as wf_hamiltonian_fwd. */
 int64_t wf_psi_vjp_workspace_bytes(const wf_model* m, int64_t B);
 int wf_psi_vjp(const wf_model* m, const float* x_dev, int64_t B, const float* w_psi_dev, const float* w_lap_dev, float* grad_dev,
                void* workspace_dev, int64_t workspace_bytes, void* stream);
@@ -276,7 +276,7 @@ int wf_mle_train_step(wf_model* m, const wf_train_state* st, const float* x_dev,
                       void* workspace_dev, int64_t workspace_bytes, void* stream);
 
 /* Parameter gradient of the log-density: grad_dev[p] = sum_b w_dev[b] * d log_pdf_b / d theta_p for every model wf_logpdf_fwd
- * evaluates with zero-only constraints and <= 32 bases per dimension (or <= 64 for D <= 4) (IMADE or MADE layers; Waveflow, M-spline, Normal or Uniform
+ * evaluates with homogeneous constraints, ungated heads and <= 32 bases per dimension (or <= 64 for D <= 4) (IMADE or MADE layers; Waveflow, M-spline, Normal or Uniform
  * prior).  With w = -1/B this is the gradient of benchmark_tests.loss (benchmark_tests.py:84-87, 98-101); with per-walker
  * weights it is the jacrev(log_pdf) contraction of vqmc.train_step (vqmc.py:175-180). */
 int64_t wf_logpdf_vjp_workspace_bytes(const wf_model* m, int64_t B);
