@@ -20,13 +20,14 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), name
     assert declared == set(_lib.EXPORTS)
-    assert _lib.lib().wf_abi_version() == 1
+    assert _lib.lib().wf_abi_version() == 2     # round 2: gate flags and the coupling-stack fields appended to wf_model_desc
 
 
 def test_desc_struct_matches_header_layout():
     # 4-byte fields only; guards against drift between _lib.ModelDesc and wf_model_desc
     assert ctypes.sizeof(_lib.BC) == 4 + 4 * 4 + 4 * 4
-    assert ctypes.sizeof(_lib.ModelDesc) == 4 * 9 + 2 * 36 + 4 * 3 + 2 * 36 + 4 + 4 + 16 * 4 + 4 + 4
+    assert ctypes.sizeof(_lib.ModelDesc) == 4 * 9 + 2 * 36 + 4 * 3 + 2 * 36 + 4 + 4 + 16 * 4 + 4 + 4 + 2 * 4 + 4 * 4   # ... i_gate, p_gate; nsc_*
+    assert _lib.ModelDesc.i_gate.offset == _lib.ModelDesc.i_reverse_tol.offset + 4 and _lib.ModelDesc.nsc_reverse.offset == ctypes.sizeof(_lib.ModelDesc) - 4
     # wf_train_state: six pointers + int32 (padded to 8)
     assert ctypes.sizeof(_lib.TrainState) == 6 * 8 + 8 and _lib.TrainState.ring_len.offset == 48 and _lib.TrainState.defer_eval_tables.offset == 52
 
@@ -79,3 +80,33 @@ def test_inversion_count():
     from waveflow_amd.utils.coordinates import get_num_inversion_count
     c = np.array([[1.0, 2.5, 2.0, -3.0], [0.0, -1.5, 2.0, -3.0], [0.0, 1.0, 2.0, 3.0]])
     assert get_num_inversion_count(c).tolist() == [4, 4, 0]
+
+
+def test_round2_host_logic_specs_and_optimizer_state(tmp_path):
+    """Host-side pieces added in round 2 (no GPU): coupling-stack parsing, the one-mesh rule, Adam moments next to the checkpoints."""
+    from waveflow_amd import vqmc
+    from waveflow_amd.flows import IMADESpec, NSCSpec, ReverseSpec, SerialSpec, parse_nsc_serial, parse_serial, _desc
+    a = NSCSpec(5, 3.0, 8)
+    assert parse_nsc_serial(SerialSpec([a, ReverseSpec(), a, ReverseSpec()])) == (a, 2, True)
+    assert parse_nsc_serial(SerialSpec([a, a, a])) == (a, 3, False)
+    assert parse_nsc_serial(SerialSpec([a, ReverseSpec(), a])) is None                    # ragged
+    assert parse_nsc_serial(SerialSpec([a, NSCSpec(8, 3.0, 8)])) is None                   # layers differ
+    assert parse_nsc_serial(SerialSpec([IMADESpec(5, 15, 0.0, 1e-6, {}, {}), ReverseSpec()])) is None
+    assert parse_serial(SerialSpec([a, ReverseSpec()])) is None                            # not a conditioner-net stack either way
+    # one mesh size per fused model: a prior spline on another mesh than the layers' is refused, not silently re-meshed
+    lay = IMADESpec(5, 15, 0.0, 1e-6, {0: 0.0}, {0: 1.0}, 1000)
+    with pytest.raises(NotImplementedError):
+        _desc(2, [lay], prior=_lib.PRIOR_MFLOW, p_degree=5, p_knots=15, n_mesh=2000)
+    d = _desc(2, [lay], prior=_lib.PRIOR_MFLOW, p_degree=5, p_knots=15, n_mesh=1000, p_gate=True)
+    assert d.n_mesh == 1000 and d.p_gate == 1 and d.i_gate == 0
+    assert _desc(2, [IMADESpec(5, 15, 0.0, 1e-6, {}, {}, 2000, True)]).i_gate == 1
+    # optimiser state: saved per checkpoint epoch, restored only for exactly that epoch and shape
+    st = vqmc.OptState(None, np.zeros(7, np.float32), np.arange(7, dtype=np.float32), np.arange(7, dtype=np.float32) ** 2)
+    vqmc._save_optimizer_state(str(tmp_path), st, 300)
+    fresh = vqmc.OptState(None, np.zeros(7, np.float32), np.zeros(7, np.float32), np.zeros(7, np.float32))
+    assert not vqmc._load_optimizer_state(str(tmp_path), fresh, 299) and fresh.m.sum() == 0
+    assert vqmc._load_optimizer_state(str(tmp_path), fresh, 300)
+    assert np.array_equal(fresh.m, st.m) and np.array_equal(fresh.v, st.v)
+    other = vqmc.OptState(None, np.zeros(8, np.float32), np.zeros(8, np.float32), np.zeros(8, np.float32))
+    assert not vqmc._load_optimizer_state(str(tmp_path), other, 300)
+    assert not vqmc._load_optimizer_state(str(tmp_path / "nowhere"), fresh, 300)
