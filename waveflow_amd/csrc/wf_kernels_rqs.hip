@@ -475,63 +475,64 @@ __device__ __forceinline__ float nsc_half(const float* __restrict__ net, const i
     const float* __restrict__ b2 = W2 + HID * HID;
     const float* __restrict__ W3 = b2 + HID;
     const float* __restrict__ b3 = W3 + HID * dout;
+    // Input unit outermost everywhere: the weights a unit feeds forward are contiguous in the stax.Dense layout ([in][out]), i.e. one wide
+    // scalar load per unit instead of one dword per (unit, output), and few of them are live at a time (SGPR budget ~100).
     float h1[HID], h2[HID];
 #pragma unroll
-    for (int j = 0; j < HID; ++j) {
-        float z = b1[j];
+    for (int j = 0; j < HID; ++j) h1[j] = b1[j];
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
-            if (a < dh) z = __builtin_fmaf(c[a], W1[a * HID + j], z);
-        h1[j] = ftanh(z);
+    for (int a = 0; a < 4; ++a)
+        if (a < dh) {
+#pragma unroll
+            for (int j = 0; j < HID; ++j) h1[j] = __builtin_fmaf(c[a], W1[a * HID + j], h1[j]);
+        }
+#pragma unroll
+    for (int j = 0; j < HID; ++j) { h1[j] = ftanh(h1[j]); h2[j] = b2[j]; }
+#pragma unroll
+    for (int a = 0; a < HID; ++a) {
+#pragma unroll
+        for (int j = 0; j < HID; ++j) h2[j] = __builtin_fmaf(h1[a], W2[a * HID + j], h2[j]);
     }
 #pragma unroll
-    for (int j = 0; j < HID; ++j) {
-        float z = b2[j];
-#pragma unroll
-        for (int a = 0; a < HID; ++a) z = __builtin_fmaf(h1[a], W2[a * HID + j], z);
-        h2[j] = ftanh(z);
-    }
+    for (int j = 0; j < HID; ++j) h2[j] = ftanh(h2[j]);
     float logdet = 0.0f;
 #pragma unroll
     for (int d = 0; d < 4; ++d)
         if (d < dh) {
             // onp.array_split(out, 3, axis=2): K widths, K heights, K - 1 derivatives; the first two soft-maxed and scaled by 2B, the last
             // soft-plussed (:255-259) -- and unconstrained_RQS normalises them again (the reference's double application is kept)
+            float o[3 * KM];   // the coordinate's 3K - 1 outputs, contiguous columns d * per ..
+#pragma unroll
+            for (int q = 0; q < 3 * KM; ++q) o[q] = q < per ? b3[d * per + q] : 0.0f;
+#pragma unroll
+            for (int a = 0; a < HID; ++a) {
+#pragma unroll
+                for (int q = 0; q < 3 * KM; ++q)
+                    if (q < per) o[q] = __builtin_fmaf(h2[a], W3[a * dout + d * per + q], o[q]);
+            }
             float uw[KM], uh[KM], ud[KM];
 #pragma unroll
-            for (int part = 0; part < 3; ++part) {
-                float o[KM];
+            for (int part = 0; part < 2; ++part) {
+                float e[KM];
+                float mx = o[part * K];
+#pragma unroll
+                for (int q = 1; q < KM; ++q)
+                    if (q < K) mx = fmaxf(mx, o[part * K + q]);
+                float sum = 0.0f;
 #pragma unroll
                 for (int q = 0; q < KM; ++q) {
-                    o[q] = 0.0f;
-                    if (q < (part == 2 ? K - 1 : K)) {
-                        const int col = d * per + part * K + q;
-                        float z = b3[col];
-#pragma unroll
-                        for (int a = 0; a < HID; ++a) z = __builtin_fmaf(h2[a], W3[a * dout + col], z);
-                        o[q] = z;
-                    }
+                    e[q] = 0.0f;
+                    if (q < K) { e[q] = fexp(o[part * K + q] - mx); sum += e[q]; }
                 }
-                if (part < 2) {
-                    float mx = o[0];
+                const float sc = 2.0f * tail * __builtin_amdgcn_rcpf(sum);
 #pragma unroll
-                    for (int q = 1; q < KM; ++q)
-                        if (q < K) mx = fmaxf(mx, o[q]);
-                    float sum = 0.0f;
-#pragma unroll
-                    for (int q = 0; q < KM; ++q)
-                        if (q < K) { o[q] = fexp(o[q] - mx); sum += o[q]; }
-                    const float sc = 2.0f * tail * __builtin_amdgcn_rcpf(sum);
-#pragma unroll
-                    for (int q = 0; q < KM; ++q) {
-                        const float v = q < K ? sc * o[q] : 0.0f;
-                        if (part == 0) uw[q] = v; else uh[q] = v;
-                    }
-                } else {
-#pragma unroll
-                    for (int q = 0; q < KM; ++q) ud[q] = q < K - 1 ? softplus(o[q]) : 0.0f;
+                for (int q = 0; q < KM; ++q) {
+                    const float v = q < K ? sc * e[q] : 0.0f;
+                    if (part == 0) uw[q] = v; else uh[q] = v;
                 }
             }
+#pragma unroll
+            for (int q = 0; q < KM; ++q) ud[q] = q < K - 1 ? softplus(o[2 * K + q]) : 0.0f;
             float y, ld;
             if (inverse) rqs_rows<KM>(t[d], K, uh, uw, ud, tail, true, y, ld);
             else rqs_rows<KM>(t[d], K, uw, uh, ud, tail, false, y, ld);
