@@ -400,8 +400,9 @@ def main_nsc(args):
         "config": {"workload": f"Flow(Serial((NeuralSplineCoupling(K={K}, B=3, hidden_dim={H}), Reverse) x {L}), Normal()) log_pdf, D={D}, {B} walkers"},
         "roofline": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
                      "kernel": "k_nsc_model<8, 8, 1, 5>", "kernel_ms": kern_ms, "bytes_per_eval": bytes_per,
-                     "note": "12 bytes per walker against ~3 600 VALU instructions (three layers of two half-steps: two tanh layers, two soft-maxes and a "
-                             "soft-plus, the spline's own soft-max and logs): the launch is bounded by instruction issue, not by HBM; see DESIGN 4.4"},
+                     "note": "12 bytes per walker against ~9 500 vector instructions (three layers of two half-steps of 1 584: two tanh layers, two soft-maxes and a "
+                             "soft-plus, the spline's own soft-max, search and logs): the launch is bounded by instruction issue (DESIGN 4.4: ~70 % of "
+                             "that bound), not by HBM"},
         "one_layer_staged_path_ms": staged_ms, "one_layer_share_of_fused_ms": kern_ms / L}), flush=True)
 
 
