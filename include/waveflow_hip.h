@@ -93,8 +93,9 @@ typedef struct {
     /* set_nn_output_grad_to_zero of the layers' / the prior's conditioner (model_factory.py:55-67, ABI 2):
      *   bij[d][j] = g_d(x) * head(o[d][j]) + z[d][j],   g_0 = 1, g_d = prod_{i<d} x_i^3  (x: the conditioner's input),
      * z = zero_params[d][j] (its absolute value under a sigmoid head), before the division by sum_j bij[d][j].
-     * Evaluation: the per-walker and the MFMA kernels; the wave sweeps (small batches, local energy, gradients, sampler) do not
-     * build it: those entry points return WF_ERR_UNSUPPORTED for a gated model. */
+     * Evaluation: every forward kernel (per-walker, MFMA, the wave forward sweep: small batches and wf_hamiltonian_fwd, where the gate
+     * travels as a jet).  The reverse sweep, the wave sampler and the fused training steps do not build it: the gradient and
+     * training entry points return WF_ERR_UNSUPPORTED for a gated model; wf_sample / wf_inverse_fwd use the per-walker kernel. */
     int32_t i_gate, p_gate;
     /* layer_kind WF_LAYER_NSC (ABI 2): n_flow_layers NeuralSplineCoupling layers (flows/bijections/neural_splines.py:244-296; K bins,
      * tail bound B, FCNN conditioners of width hidden_dim), each followed by flows.Reverse when nsc_reverse != 0, under a Normal or
@@ -200,7 +201,7 @@ int wf_sample(const wf_model* m, uint64_t seed, int64_t B, float* x_dev, float* 
  * with physics.laplacian (:50-52, trace of jax.hessian -- the table lerp differentiates to the next cached derivative table,
  * isplines_jax.py:60-66) and the one-dimensional soft-Coulomb physics.get_potential (:60-76) for `n_protons` <= 8 protons at
  * `protons_host`.  hpsi_dev[B]; psi_dev[B] and laplacian_dev[B] may be NULL.  The local energy of vqmc.loss_fn_efficient
- * (vqmc.py:193-200) is hpsi / (psi + 1e-8).  WF_PRIOR_WAVEFLOW models with IMADE layers, homogeneous boundary constraints (every value 0 apart from the I-spline's right {0: 1}), ungated heads;
+ * (vqmc.py:193-200) is hpsi / (psi + 1e-8).  WF_PRIOR_WAVEFLOW models with IMADE layers, homogeneous boundary constraints (every value 0 apart from the I-spline's right {0: 1}), gated heads included;
  * D = 2..8 with <= 32 bases per dimension, D = 2..4 with 33..64. */
 int wf_hamiltonian_fwd(const wf_model* m, const float* x_dev, int64_t B, const float* protons_host, int32_t n_protons,
                        float* hpsi_dev, float* psi_dev, float* laplacian_dev, void* stream);

@@ -52,10 +52,11 @@ class TorchWaveflow:
     """Waveflow (B-spline prior, IMADE layers, 'mean' or 'first' box) in torch; parameters = flat reference leaf order."""
 
     def __init__(self, D, n_layers, box, box_L, k, knots, i_reg, constr_left, dtype=torch.float64, n_mesh=2000, i_left=None, i_right=None,
-                 p_left=None, p_right=None):
+                 p_left=None, p_right=None, i_gate=False, p_gate=False):
         """i_left / i_right / p_left / p_right: general {n_derivative: value} dictionaries (None: the zero-only defaults {0: 0} / {0: 1} and
         {0: 0} / {0: 0}, evaluated as a 0/1 mask); enforced literally, in dictionary order, as enforce_boundary_conditions does."""
         self.D, self.n_layers, self.box, self.L, self.k, self.i_reg, self.dtype = D, n_layers, box, float(box_L), k, float(i_reg), dtype
+        self.i_gate, self.p_gate = bool(i_gate), bool(p_gate)   # set_nn_output_grad_to_zero (model_factory.py:64-67)
         self.i_bc = None if i_left is None and i_right is None else ({0: 0.0} if i_left is None else i_left, {0: 1.0} if i_right is None else i_right)
         self.p_bc = None if p_left is None and p_right is None else ({0: 0.0} if p_left is None else p_left, {0: 0.0} if p_right is None else p_right)
         self.constr_left = tuple(constr_left)
@@ -94,10 +95,10 @@ class TorchWaveflow:
         for s in sizes:
             parts.append(p[o:o + s]); o += s
         W0, b0, W1, b1, W2, b2 = parts[0].view(D, H), parts[1], parts[2].view(H, H), parts[3], parts[4].view(H, n_out * D), parts[5]
-        return (W0, b0, W1, b1, W2, b2), o
+        return (W0, b0, W1, b1, W2, b2, parts[6].view(D, n_out)), o
 
-    def _conditioner(self, net, x, n_out, sigmoid):
-        W0, b0, W1, b1, W2, b2 = net
+    def _conditioner(self, net, x, n_out, sigmoid, gate=False):
+        W0, b0, W1, b1, W2, b2, zero = net
         m0, m1, m2 = self.masks
         h = torch.tanh(x @ (W0 * m0) + b0)
         h = torch.tanh(h @ (W1 * m1) + b1)
@@ -105,6 +106,10 @@ class TorchWaveflow:
         p = o.view(-1, n_out, self.D).transpose(1, 2)                  # [B, D, n_out]
         if sigmoid:
             p = torch.sigmoid(p)
+            zero = zero.abs()
+        if gate:   # cubed_input_product = roll(cumprod(x^3), 1) with entry 0 set to 1 (model_factory.py:65-67)
+            g = torch.cat([torch.ones_like(x[:, :1]), torch.cumprod(x ** 3, -1)[:, :-1]], -1)
+            p = g[..., None] * p + zero
         return p / p.sum(-1, keepdim=True)
 
     def psi(self, flat, x):
@@ -142,7 +147,7 @@ class TorchWaveflow:
         nb = self.i_nb
         for _ in range(self.n_layers):
             net, off = self._net(p, off, nb)
-            w = self._conditioner(net, u, nb, True) + self.i_reg
+            w = self._conditioner(net, u, nb, True, self.i_gate) + self.i_reg
             # remove_bias (isplines_jax.py:196-202)
             scale = torch.ones(nb, dtype=dt)
             for i in range(k):
@@ -163,7 +168,7 @@ class TorchWaveflow:
             u = y.flip(-1)
         nbp = self.p_nb
         net, off = self._net(p, off, nbp)
-        w = self._conditioner(net, u, nbp, False)
+        w = self._conditioner(net, u, nbp, False, self.p_gate)
         if self.p_bc is None:
             keep = torch.ones(nbp, dtype=dt); keep[0] = 0; keep[-1] = 0
             w = w * keep

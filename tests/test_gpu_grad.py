@@ -622,6 +622,47 @@ def test_wavefunction_with_derivative_constraints_energy_and_gradients():
     assert rel_l2(got, want) < 2e-3, rel_l2(got, want)
 
 
+@pytest.mark.parametrize("D", [2, 3])
+def test_gated_wavefunction_energy_vs_autograd_oracle(D):
+    """wavefunctions.Waveflow with its own default set_nn_output_grad_to_zero=True (gated layers and prior): psi, H psi and the Laplacian
+    from the wave forward sweep (the gate prod_{i<d} x_i^3 travels as a jet) against the torch oracle with the same four lines of
+    model_factory.py:64-67; also through the R3 directional sweep (WF_ENERGY_R3)."""
+    import os
+    import torch
+    from oracle import energy_torch as et
+    from waveflow_amd import flatten_params, flows, model_factory, wavefunctions
+    mt = model_factory.get_masked_transform
+    init = wavefunctions.Waveflow(
+        flows.Serial(flows.BoxTransformLayer(3.0), *(flows.IMADE(mt(), 6, 23, 0.05, 1e-6, set_nn_output_grad_to_zero=True), flows.Reverse()) * 2),
+        mt(allow_negative_params=True), 6, 23, constraints_dict_left={0: 0}, constraints_dict_right={0: 0},
+        constrained_dimension_indices_left=list(range(D - 1)))
+    params, psi, log_pdf, _ = init(6, D)
+    flat = flatten_params(params)
+    mo = et.TorchWaveflow(D, 2, "mean", 3.0, 6, 23, 0.05, tuple(range(D - 1)), dtype=torch.float64, i_gate=True, p_gate=True)
+    x = sorted_walkers(96, D, 2.7, 17)
+    m = psi.model
+    m.ensure_params(params)
+    pr = [0.0] * D
+    ho, po, lo = et.hamiltonian(mo, flat, x.astype(np.float64), pr)
+    for kernel in ("scalar", "wave"):
+        m.set_kernel(kernel)
+        np.testing.assert_allclose(psi(params, x), po, rtol=0, atol=3e-5 * np.abs(po).max())
+    m.set_kernel("auto")
+    hp, ps, lap = m.hamiltonian(x, pr, return_psi=True, return_laplacian=True)
+    np.testing.assert_allclose(ps, po, rtol=0, atol=3e-5 * np.abs(po).max())
+    np.testing.assert_allclose(lap, lo, rtol=0, atol=3e-3 * np.abs(lo).max())
+    np.testing.assert_allclose(hp, ho, rtol=0, atol=3e-3 * np.abs(ho).max())
+    os.environ["WF_ENERGY_R3"] = "1"
+    try:
+        hp3, _, lap3 = m.hamiltonian(x, pr, return_psi=True, return_laplacian=True)
+    finally:
+        del os.environ["WF_ENERGY_R3"]
+    np.testing.assert_allclose(lap3, lo, rtol=0, atol=3e-3 * np.abs(lo).max())
+    # the ungated model with the same parameters has another Laplacian: the gate is not a no-op
+    mo0 = et.TorchWaveflow(D, 2, "mean", 3.0, 6, 23, 0.05, tuple(range(D - 1)), dtype=torch.float64)
+    assert np.abs(et.hamiltonian(mo0, flat, x.astype(np.float64), pr)[2] - lo).max() > 1e-2 * np.abs(lo).max()
+
+
 def test_trained_energy_respects_the_variational_bound(tmp_path):
     """Known answer for the derivative path (unpinned in the reference): the lowest antisymmetric eigenvalue of the 1-D
     soft-Coulomb He Hamiltonian in the box [-10, 10]^2 is -1.8161 (finite-difference diagonalisation, scratch/he1d_exact.py).

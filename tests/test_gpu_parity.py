@@ -728,15 +728,17 @@ def test_gated_conditioner_heads(kernel):
     u = log_pdf.model.flow(x[:512])[0]
     xb = log_pdf.model.inverse(u, exact=True)
     assert np.abs(np.asarray(xb.cpu() if hasattr(xb, "cpu") else xb) - x[:512]).max() < 2e-3 * 3.0
-    # the wave sweeps (small batches, gradients, local energy) do not build the gate: refused, never evaluated ungated
+    # the wave forward sweep carries the gate (small batches, local energy: test_gated_wavefunction_energy_vs_autograd_oracle); the
+    # reverse sweep and the wave sampler do not: gradients are refused, never evaluated ungated
     from waveflow_amd import _lib
     m = log_pdf.model
-    with pytest.raises(_lib.WfError):
-        m.set_kernel("wave")
+    m.set_kernel("wave")
+    as_accurate_as_fp32_reference(log_pdf(params, x[:3000]), om.log_pdf(flat, x[:3000]), om.log_pdf(flat, x[:3000], f64=True), what="gated, wave kernel")
+    as_accurate_as_fp32_reference(psi(params, x[:3000]), pso[:3000], pst[:3000], atol=1e-6 * np.abs(pst).max(), what="gated psi, wave kernel")
     m.set_kernel("auto")
-    small = np.asarray(log_pdf(params, x[:100]))      # auto: a small batch goes to the per-walker kernel instead
-    as_accurate_as_fp32_reference(small, om.log_pdf(flat, x[:100]), om.log_pdf(flat, x[:100], f64=True), what="gated, batch of 100 (per-walker kernel)")
+    small = np.asarray(log_pdf(params, x[:100]))
+    as_accurate_as_fp32_reference(small, om.log_pdf(flat, x[:100]), om.log_pdf(flat, x[:100], f64=True), what="gated, batch of 100 (auto)")
     with pytest.raises(_lib.WfError):
         m.logpdf_vjp(x[:16], np.ones(16, np.float32))
     with pytest.raises(_lib.WfError):
-        m.hamiltonian(x[:16], [0.0, 0.0])
+        m.psi_vjp(x[:16], np.ones(16, np.float32), np.ones(16, np.float32))

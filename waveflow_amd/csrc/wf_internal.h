@@ -53,6 +53,7 @@ struct NetWave {
     const float4_t* W1b;    // [16][64]: lane a,  group g: (W1*mask1)[a][j = 4g..4g+3]
     const float4_t* W2f;    // [P][16][64]: lane (dl, j), group g: (W2*mask2)[a = 4g..][column of (2p+dl, j)]
     const float4_t* W2b;    // [P][16][64]: lane a, group g: (W2*mask2)[a][columns of lanes c = 4g..4g+3 of pass p]
+    const float* z;         // [P][64]: zero_params of a gated head in the lane order of b2 (|z| under a sigmoid head); zeros otherwise
 };
 
 struct SplineDev {

@@ -261,10 +261,12 @@ __device__ __forceinline__ T hidden_fwd(const NetWave& net, const T (&x)[D], flo
 template <class T> struct SigHead {
     T p, rS0, rQ, c;
 };
+// gate (forward sweep only): p = gq * sigmoid(o) + z, the gated head of model_factory.py:64-67 (gq: the jet of prod_{i<d} x_i^3)
 template <class T, int NBK = 1>
-__device__ __forceinline__ SigHead<T> sigmoid_head(T o, bool valid, bool valid_d, float g, float reg) {
+__device__ __forceinline__ SigHead<T> sigmoid_head(T o, bool valid, bool valid_d, float g, float reg, bool gate = false, T gq = T{}, float z = 0.0f) {
     SigHead<T> h;
     h.p = valid ? rsigmoid(o) : cst<T>(0.0f);
+    if (gate && valid) h.p = gq * h.p + z;
     T S0 = rsum<NBK>(h.p);
     if (!valid_d) S0 = cst<T>(1.0f);
     h.rS0 = rrcp(S0);
@@ -294,9 +296,11 @@ template <class T> struct PsiHead {
     float sgn;
 };
 template <class T, int NBK = 1>
-__device__ __forceinline__ PsiHead<T> psi_head(T o, bool valid, bool valid_d, float keep, const float* __restrict__ o2b, float (*ov)[64], int lane) {
+__device__ __forceinline__ PsiHead<T> psi_head(T o, bool valid, bool valid_d, float keep, const float* __restrict__ o2b, float (*ov)[64], int lane,
+                                               bool gate = false, T gq = T{}, float z = 0.0f) {
     PsiHead<T> h;
     h.o = valid ? o : cst<T>(0.0f);
+    if (gate && valid) h.o = gq * o + z;
     h.sgn = rsumf<NBK>(h.o.c0) < 0.0f ? -1.0f : 1.0f;
     const T w = h.o * (valid ? keep * h.sgn : 0.0f);
     T N1 = rsum<NBK>(w * w);
@@ -398,6 +402,8 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(kOccFwd<T>,
                     if (lane == d) tput(tape, l, RW::U + d, cur[d]);
             }
             hidden_fwd<D, T>(net, cur, vec, lane, tape, l, taped);
+            const bool gate_i = md.i_gate != 0;
+            T grun = cst<T>(1.0f);   // gated heads: the jet of prod_{i<d} (layer input)_i^3, advanced pass by pass
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 const int d = NBK == 1 ? 2 * p + dl : p;
@@ -405,11 +411,23 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(kOccFwd<T>,
                 const T o = gemv<T>(net.W2f + p * 1024, vec, lane) + net.b2[p * 64 + lane];
                 if (taped && valid_d) tput(tape, l, RW::O + d * W + j, o);   // the reverse sweep reads it back and stores its adjoint here
                 const T u = NBK == 1 ? sel(dl == 0, cur[2 * p < D ? 2 * p : 0], cur[2 * p + 1 < D ? 2 * p + 1 : 0]) : cur[p];
+                T gq = grun;
+                if (gate_i) {
+                    if constexpr (NBK == 1) {
+                        const T c0 = cur[2 * p < D ? 2 * p : 0];
+                        const T g_odd = grun * (c0 * c0 * c0);
+                        gq = sel(dl == 0, grun, g_odd);
+                        const T c1 = cur[2 * p + 1 < D ? 2 * p + 1 : 0];
+                        grun = g_odd * (c1 * c1 * c1);
+                    } else {
+                        grun = grun * (cur[p] * cur[p] * cur[p]);
+                    }
+                }
                 T y, ld;
                 if (imade) {
                     const int nb = md.isp.nb;
                     const bool valid = valid_d && j < nb;
-                    const SigHead<T> hd = sigmoid_head<T, NBK>(o, valid, valid_d, gI[j], md.i_reg);
+                    const SigHead<T> hd = sigmoid_head<T, NBK>(o, valid, valid_d, gI[j], md.i_reg, gate_i, gq, net.z[p * 64 + lane]);
                     const Lerp lp = make_lerp(u.c0, n_mesh);
                     float t[4];
                     lerp4<W>(tabI, plane, lp, j, t);
@@ -449,12 +467,26 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(kOccFwd<T>,
                     if (lane == d) tput(tape, NP, RW::U + d, cur[d]);
             }
             hidden_fwd<D, T>(net, cur, vec, lane, tape, NP, taped);
+            const bool gate_p = md.p_gate != 0;
+            T grun = cst<T>(1.0f);   // (the gate sees the conditioner's input: the unclipped u)
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 const int d = NBK == 1 ? 2 * p + dl : p;
                 const bool valid_d = d < D, valid = valid_d && j < nb;
                 const T o = gemv<T>(net.W2f + p * 1024, vec, lane) + net.b2[p * 64 + lane];
                 if (taped && valid_d) tput(tape, NP, RW::O + d * W + j, o);
+                T gq = grun;
+                if (gate_p) {
+                    if constexpr (NBK == 1) {
+                        const T c0 = cur[2 * p < D ? 2 * p : 0];
+                        const T g_odd = grun * (c0 * c0 * c0);
+                        gq = sel(dl == 0, grun, g_odd);
+                        const T c1 = cur[2 * p + 1 < D ? 2 * p + 1 : 0];
+                        grun = g_odd * (c1 * c1 * c1);
+                    } else {
+                        grun = grun * (cur[p] * cur[p] * cur[p]);
+                    }
+                }
                 bool inside;
                 const T uc = clip01(NBK == 1 ? sel(dl == 0, cur[2 * p < D ? 2 * p : 0], cur[2 * p + 1 < D ? 2 * p + 1 : 0]) : cur[p], inside);
                 const Lerp lp = make_lerp(uc.c0, n_mesh);
@@ -462,10 +494,10 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(kOccFwd<T>,
                 lerp4<W>(tabP, plane, lp, j, t);
                 T val;
                 if (md.prior_kind == WF_PRIOR_WAVEFLOW) {
-                    const PsiHead<T> hd = psi_head<T, NBK>(o, valid, valid_d, kP[j], md.ob_to_b_t, ov, lane);
+                    const PsiHead<T> hd = psi_head<T, NBK>(o, valid, valid_d, kP[j], md.ob_to_b_t, ov, lane, gate_p, gq, net.z[p * 64 + lane]);
                     val = rsum<NBK>(hd.e * lift(t, 0, uc));
                 } else {
-                    const SigHead<T> hd = sigmoid_head<T, NBK>(o, valid, valid_d, kP[j], 0.0f);
+                    const SigHead<T> hd = sigmoid_head<T, NBK>(o, valid, valid_d, kP[j], 0.0f, gate_p, gq, net.z[p * 64 + lane]);
                     val = rsum<NBK>(hd.c * lift(t, 0, uc));
                 }
                 if constexpr (NBK == 1) {

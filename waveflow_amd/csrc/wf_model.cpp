@@ -94,6 +94,8 @@ struct wf_model {
     float* d_wave = nullptr;         // NetWave images
     float* d_grad_fk = nullptr;      // [2][64] natural-order row factors for the reverse pass (flow rows, prior rows)
     bool wave_ok = false;            // the wave-cooperative sweeps cover this model (homogeneous constraints; > 32 bases: D <= 4)
+    bool wave_eval_ok = false;       // ... its forward sweep does (small-batch log_pdf / psi, local energy): also with gated heads, which the
+                                     // reverse sweep, the wave sampler and the fused training steps do not build
     // boundary conditions as a linear map on the coefficient vector (bc_map below): column sums a~ of A, per spline (I layers / prior);
     // bc_*_ok: homogeneous (no constant term) and every column with a~_j == 0 is entirely zero -> the table-driven kernels apply
     bool is_nsc = false;             // layer_kind WF_LAYER_NSC: the coupling stack (k_nsc_model), none of the conditioner-net machinery
@@ -491,7 +493,8 @@ static int model_build(wf_model* m) {
             nw.W1f = reinterpret_cast<const float4_t*>(p); p += 4096;
             nw.W1b = reinterpret_cast<const float4_t*>(p); p += 4096;
             nw.W2f = reinterpret_cast<const float4_t*>(p); p += (int64_t)P * 4096;
-            nw.W2b = reinterpret_cast<const float4_t*>(p);
+            nw.W2b = reinterpret_cast<const float4_t*>(p); p += (int64_t)P * 4096;
+            nw.z = p;
         }
     }
     rc = dev_alloc(m, &m->d_dev, 1);
@@ -574,7 +577,7 @@ static void describe_plain_image(const wf_model* m, int n, uint32_t base, std::v
 // Wave-kernel image of net n (NetWave): W0 [D][64], b0, b1, b2 [P][64], W1f, W1b [16][64][4], W2f, W2b [P][16][64][4]
 static int64_t wave_net_floats(int D, int nbp) {
     const int P = wave_passes(D, nbp);
-    return (int64_t)D * kHidden + 2 * kHidden + (int64_t)P * 64 + 2 * 4096 + (int64_t)P * 2 * 4096;
+    return (int64_t)D * kHidden + 2 * kHidden + (int64_t)P * 64 + 2 * 4096 + (int64_t)P * 2 * 4096 + (int64_t)P * 64;   // ..., z
 }
 
 static void describe_wave_image(const wf_model* m, int n, uint32_t base, std::vector<PackRec>& out) {
@@ -613,6 +616,15 @@ static void describe_wave_image(const wf_model* m, int n, uint32_t base, std::ve
         for (int g = 0; g < 16; ++g)
             for (int a = 0; a < 64; ++a)
                 for (int e = 0; e < 4; ++e) w.f32(w2m(a, p, 4 * g + e));
+    // zero_params of a gated head in the lane order of b2 (|z| under a sigmoid head); zeros otherwise
+    const bool gated = nl.has_zero && net_is_gated(m, n), sig = net_has_sigmoid_head(m, n);
+    for (int p = 0; p < P; ++p)
+        for (int c = 0; c < 64; ++c) {
+            const int d = wide ? p : 2 * p + (c >> 5), jb = wide ? c : (c & 31);
+            const int64_t src = (gated && d < D && jb < nl.n_out) ? q.b2 + q.NO + (int64_t)d * nl.n_out + jb : -1;
+            if (sig) w.f32_abs(src);
+            else w.f32(src);
+        }
 }
 
 // ---------------------------------------------------------------------------- MFMA kernel images
@@ -847,10 +859,10 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
 }
 
 // The wave-cooperative kernels (wf_kernels_wave.hip): <= 32 bases, constraints that only zero the end weights.
-static bool wave_capable(const wf_model* m) {
+static bool wave_capable(const wf_model* m, bool forward_only = false) {
     const wf_model_desc& d = m->desc;
     if (!m->d_wave || (m->nbp == 64 && d.n_dim > 4)) return false;   // (the 64-row sweeps are built for D <= 4)
-    if (m->dev.i_gate || m->dev.p_gate) return false;                 // gated heads: per-walker and MFMA kernels only
+    if (!forward_only && (m->dev.i_gate || m->dev.p_gate)) return false;   // gated heads: forward sweep only
     const bool imade = d.layer_kind == WF_LAYER_IMADE && d.n_flow_layers > 0;
     if (imade && (!m->d_tabI4 || !m->bc_i_ok)) return false;
     const bool spline_prior = d.prior_kind == WF_PRIOR_WAVEFLOW || d.prior_kind == WF_PRIOR_MFLOW;
@@ -897,7 +909,8 @@ static int grad_prepare(wf_model* m) {
         if (rc) return rc;
     }
     m->wave_ok = wave_capable(m);
-    if (m->wave_ok) {
+    m->wave_eval_ok = wave_capable(m, true);
+    if (m->wave_eval_ok) {
         std::vector<float> fk(128, 0.0f), acc(64);
         if (d.layer_kind == WF_LAYER_IMADE && d.n_flow_layers > 0)
             row_factors(WF_SPLINE_I, true, d.i_degree, m->i_nb, m->nbp / 32, m->bc_i_colsum, acc.data(), fk.data());
@@ -907,7 +920,7 @@ static int grad_prepare(wf_model* m) {
         if (rc) return rc;
         WF_HIP(hipMemcpy(m->d_grad_fk, fk.data(), fk.size() * sizeof(float), hipMemcpyHostToDevice));
     }
-    if (m->wave_ok) {
+    if (m->wave_eval_ok) {
         // scratch for the small-batch wave path (tails of up to kWaveEvalMax walkers, first or second order) is reserved here
         // so that those calls never allocate: they can be captured in a hipGraph
         int rc = ensure_scratch(m, kWaveEvalMax * std::max(wave_tail_floats(D, 0), wave_tail_floats(D, 1)));
@@ -1036,7 +1049,7 @@ int wf_model_n_bases(const wf_model* m, int which) {
 int wf_model_set_kernel(wf_model* m, int kernel_kind) {
     if (!m || kernel_kind < WF_KERNEL_AUTO || kernel_kind > WF_KERNEL_WAVE) return WF_ERR_INVALID;
     if (kernel_kind == WF_KERNEL_MFMA && !m->mfma_ok) return WF_ERR_UNSUPPORTED;
-    if (kernel_kind == WF_KERNEL_WAVE && !m->wave_ok) return WF_ERR_UNSUPPORTED;
+    if (kernel_kind == WF_KERNEL_WAVE && !m->wave_eval_ok) return WF_ERR_UNSUPPORTED;
     m->kernel_kind = kernel_kind;
     return WF_OK;
 }
@@ -1110,7 +1123,7 @@ static int dispatch(const wf_model* m, int mode, const float* x, int64_t B, floa
     // which first stages its weight images into LDS, takes 38-42 us whatever the batch; from ~7000 walkers on the MFMA
     // kernel's throughput wins (4096: 30 vs 42 us, 8192: 46 vs 42 us).  The wave kernel does
     // not report bin indices.
-    const bool wave_fits = m->wave_ok && !idx;
+    const bool wave_fits = m->wave_eval_ok && !idx;
     const bool use_wave = wave_fits && (m->kernel_kind == WF_KERNEL_WAVE || (m->kernel_kind == WF_KERNEL_AUTO && B <= kWaveEvalMax));
     if (m->kernel_kind == WF_KERNEL_WAVE && !use_wave) return WF_ERR_UNSUPPORTED;
     if (use_wave) {
@@ -1234,7 +1247,7 @@ int wf_hamiltonian_fwd(const wf_model* m, const float* x_dev, int64_t B, const f
     if (rc) return rc;
     if (n_protons < 0 || n_protons > 8 || (n_protons > 0 && !protons_host)) return WF_ERR_INVALID;
     if (m->desc.prior_kind != WF_PRIOR_WAVEFLOW) return WF_ERR_INVALID;
-    if (!m->wave_ok || !m->d_tabP3 || !m->d_grad_fk) return WF_ERR_UNSUPPORTED;
+    if (!m->wave_eval_ok || !m->d_tabP3 || !m->d_grad_fk) return WF_ERR_UNSUPPORTED;
     if (m->desc.n_flow_layers > 0 && m->desc.layer_kind != WF_LAYER_IMADE) return WF_ERR_UNSUPPORTED;
     Protons pr{};
     pr.n = n_protons;
