@@ -110,3 +110,31 @@ def test_round2_host_logic_specs_and_optimizer_state(tmp_path):
     other = vqmc.OptState(None, np.zeros(8, np.float32), np.zeros(8, np.float32), np.zeros(8, np.float32))
     assert not vqmc._load_optimizer_state(str(tmp_path), other, 300)
     assert not vqmc._load_optimizer_state(str(tmp_path / "nowhere"), fresh, 300)
+
+
+def test_table_cache_files_are_the_reference_fixture_files(tmp_path, golden):
+    """utils/table_cache.py writes the reference's cache (isplines_jax.py:115, bsplines_jax.py:76-80 naming); for (k = 5, 16 internal knots,
+    2000 mesh points) the reference ships its own files (waveflow/tests/splines/cached_bases/{I,B}, packed in tests/golden): same names,
+    same shapes, I and plain-B values bit-equal, orthogonal tables and change-of-basis matrices to 1e-10."""
+    from waveflow_amd.utils import table_cache as tc
+    g = golden["ref_tables_k5_n16"]
+    assert tc.cache_file_names("I", 5, 16)["nd"][1] == "degree_5_niknots_21_nmp_2000_nd_1.npy"
+    nb = tc.cache_file_names("B", 5, 16)
+    assert nb["nd"][0] == "b_degree_5_niknots_21_nmp_2000_nd_0.npy" and nb["ob"][3] == "ob_degree_5_niknots_21_nmp_2000_nd_3.npy"
+    assert nb["b_to_ob"] == "degree_5_niknots_21_nmp_2000_b_to_ob.npy" and nb["ob_to_b"] == "degree_5_niknots_21_nmp_2000_ob_to_b.npy"
+    wi = tc.write_cached_bases(str(tmp_path / "I"), "I", 5, 16)
+    wb = tc.write_cached_bases(str(tmp_path / "B"), "B", 5, 16)
+    assert len(wi) == 4 and len(wb) == 10
+    I = tc.load_cached_bases(str(tmp_path / "I"), "I", 5, 16)
+    B, OB, b2o, o2b = tc.load_cached_bases(str(tmp_path / "B"), "B", 5, 16)
+    for nd in range(4):
+        assert I[nd].dtype == np.float64 and I[nd].shape == g[f"I_nd{nd}"].shape and np.array_equal(I[nd], g[f"I_nd{nd}"])
+        assert B[nd].shape == g[f"B_nd{nd}"].shape and np.array_equal(B[nd], g[f"B_nd{nd}"])
+        sub = OB[nd][:, g["OB_cols"]]
+        assert np.abs(sub - g[f"OB_nd{nd}_sub"]).max() <= 1e-10 * max(1.0, np.abs(g[f"OB_nd{nd}_sub"]).max())
+    assert np.abs(b2o - g["b_to_ob"]).max() <= 1e-10 * np.abs(g["b_to_ob"]).max()
+    assert np.abs(o2b - g["ob_to_b"]).max() <= 1e-10 * np.abs(g["ob_to_b"]).max()
+    m = tc.write_cached_bases(str(tmp_path / "M"), "M", 3, 15)
+    assert os.path.basename(m[0]) == "degree_3_niknots_16_nmp_2000_nd_0.npy" and np.load(m[0]).shape == (16, 2000)   # n_knots - k = 15 + 2 (k - 1) - k
+    with pytest.raises(FileNotFoundError):
+        tc.load_cached_bases(str(tmp_path / "I"), "I", 6, 23)
