@@ -176,12 +176,6 @@ def parse_serial(spec):
     return box, layers
 
 
-def _not_yet(name):
-    def f(*a, **k):
-        raise NotImplementedError(f"{name} is not built on the HIP path; there is deliberately no CPU fallback")
-    return f
-
-
 def _flip(a):
     return a.flip(-1) if hasattr(a, "flip") else np.ascontiguousarray(np.asarray(a)[..., ::-1])
 
