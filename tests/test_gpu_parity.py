@@ -728,8 +728,8 @@ def test_gated_conditioner_heads(kernel):
     u = log_pdf.model.flow(x[:512])[0]
     xb = log_pdf.model.inverse(u, exact=True)
     assert np.abs(np.asarray(xb.cpu() if hasattr(xb, "cpu") else xb) - x[:512]).max() < 2e-3 * 3.0
-    # the wave forward sweep carries the gate (small batches, local energy: test_gated_wavefunction_energy_vs_autograd_oracle); the
-    # reverse sweep and the wave sampler do not: gradients are refused, never evaluated ungated
+    # the wave sweeps carry the gate too (small batches here; local energy and gradients: test_gated_wavefunction_energy_vs_autograd_oracle);
+    # the fused training steps and the wave sampler do not build it and say so
     from waveflow_amd import _lib
     m = log_pdf.model
     m.set_kernel("wave")
@@ -738,7 +738,6 @@ def test_gated_conditioner_heads(kernel):
     m.set_kernel("auto")
     small = np.asarray(log_pdf(params, x[:100]))
     as_accurate_as_fp32_reference(small, om.log_pdf(flat, x[:100]), om.log_pdf(flat, x[:100], f64=True), what="gated, batch of 100 (auto)")
-    with pytest.raises(_lib.WfError):
-        m.logpdf_vjp(x[:16], np.ones(16, np.float32))
-    with pytest.raises(_lib.WfError):
-        m.psi_vjp(x[:16], np.ones(16, np.float32), np.ones(16, np.float32))
+    assert np.isfinite(m.logpdf_vjp(x[:16], np.ones(16, np.float32)).cpu().numpy()).all()
+    L = _lib.lib()
+    assert L.wf_vqmc_train_step_workspace_bytes(m._h, 128) == -2 and L.wf_mle_train_step_workspace_bytes(m._h, 128) == -2

@@ -31,6 +31,7 @@ struct NetPlain {
     const float* W2n; // [64 in][D][NBP]   row a = weights out of hidden unit a
     // zero_params of the gated head (model_factory.py:64-67, 84): z[d][j], already |z| under a sigmoid head; zeros without the leaf
     const float* zero; // [D][NBP]
+    const float* zero_raw; // [D][NBP]: the leaf as it is (its sign scales the gradient of a sigmoid head's |z|)
 };
 
 // One conditioner net in MFMA operand order (see wf_kernels_mfma.hip)
@@ -162,7 +163,10 @@ int launch_wgrad(int D, int nbp, int ring_kind, int n_nets, int64_t n_samples, c
 int launch_wave_fwd(const ModelDev& md, const ModelDev* md_dev, int ring_kind, const float* tabI4, const float* tabP4, const float* fk_nat,
                     const float* x, int64_t B, float* ws, float* tails, int taped, void* stream);
 int launch_wave_bwd(const ModelDev& md, const ModelDev* md_dev, int mode, int ring_kind, const float* tabI4, const float* tabP4,
-                    const float* fk_nat, int64_t B, const float* w1, const float* w2, float* ws, const float* tails, void* stream);
+                    const float* fk_nat, int64_t B, const float* w1, const float* w2, float* ws, const float* tails, float* zws, void* stream);
+// gated heads: zero_params gradient.  zws [n_samples][n_rows] (k_wave_bwd) -> zgrad [n_rows] (+)=, in a fixed order; then into the flat gradient
+int launch_zgrad_reduce(const float* zws, int64_t n_samples, int n_rows, int accumulate, float* zpart, float* zgrad, void* stream);
+int launch_zgrad_scatter(const float* zgrad, int n_rows, const int32_t* zmap, const int32_t* zraw_off, const float* plain, float* grad_flat, void* stream);
 int launch_wave_energy(const ModelDev& md, const ModelDev* md_dev, const float* tabI4, const float* tabP4, const float* fk_nat, const float* x,
                        int64_t B, const Protons& pr, float* hpsi, float* psi, float* lap, float* tail_ws, void* stream);
 int launch_wave_sample(const ModelDev& md, const ModelDev* md_dev, const float* tabI4, const float* tabP4, const float* fk_nat, int draw,

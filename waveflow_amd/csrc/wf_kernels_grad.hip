@@ -220,6 +220,36 @@ __global__ void k_pack(const float* __restrict__ flat, const PackRec* __restrict
     }
 }
 
+// ---- zero_params gradient of gated heads: the reverse sweep leaves one adjoint per (sample, head lane) in zws; two-stage sum over the samples
+// in a fixed order (bitwise reproducible like the weight gradients), then the entries go to their leaves of the flat gradient
+constexpr int kZSplit = 64;
+__global__ void k_zgrad_stage1(const float* __restrict__ zws, int64_t n_samples, int n_rows, float* __restrict__ zpart) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x, q = blockIdx.y;
+    if (r >= n_rows) return;
+    const int64_t lo = n_samples * q / kZSplit, hi = n_samples * (q + 1) / kZSplit;
+    float s = 0.0f;
+    for (int64_t i = lo; i < hi; ++i) s += zws[i * n_rows + r];
+    zpart[(int64_t)q * n_rows + r] = s;
+}
+__global__ void k_zgrad_stage2(const float* __restrict__ zpart, int n_rows, int accumulate, float* __restrict__ zgrad) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    float s = accumulate ? zgrad[r] : 0.0f;
+    for (int q = 0; q < kZSplit; ++q) s += zpart[(int64_t)q * n_rows + r];
+    zgrad[r] = s;
+}
+// flat[zmap[r]] = zgrad[r] (* sign of the raw leaf where the head uses |zero_params|: zraw_off[r] >= 0 is its offset in the plain image)
+__global__ void k_zgrad_scatter(const float* __restrict__ zgrad, int n_rows, const int32_t* __restrict__ zmap, const int32_t* __restrict__ zraw_off,
+                                const float* __restrict__ plain, float* __restrict__ flat) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    const int32_t t = zmap[r];
+    if (t < 0) return;
+    float g = zgrad[r];
+    if (zraw_off[r] >= 0 && plain[zraw_off[r]] < 0.0f) g = -g;
+    flat[t] = g;
+}
+
 // ---- Adam as in jax.example_libraries.optimizers.adam (vqmc.py:136), step index i as passed to opt_update
 __global__ void k_adam(float* __restrict__ x, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n, float c1, float c2,
                        float step_size, float b1, float b2, float eps, const unsigned long long* __restrict__ step_dev) {
@@ -361,6 +391,23 @@ int launch_wgrad(int D, int nbp, int ring_kind, int n_nets, int64_t n_samples, c
         default: return WF_ERR_UNSUPPORTED;
     }
 #undef CALLK
+}
+
+int launch_zgrad_reduce(const float* zws, int64_t n_samples, int n_rows, int accumulate, float* zpart, float* zgrad, void* stream) {
+    if (n_rows <= 0) return WF_OK;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_zgrad_stage1, dim3((n_rows + 255) / 256, kZSplit), dim3(256), 0, s, zws, n_samples, n_rows, zpart);
+    hipLaunchKernelGGL(k_zgrad_stage2, dim3((n_rows + 255) / 256), dim3(256), 0, s, (const float*)zpart, n_rows, accumulate, zgrad);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_hip_error((int)e); return WF_ERR_HIP; }
+    return WF_OK;
+}
+int launch_zgrad_scatter(const float* zgrad, int n_rows, const int32_t* zmap, const int32_t* zraw_off, const float* plain, float* grad_flat, void* stream) {
+    if (n_rows <= 0) return WF_OK;
+    hipLaunchKernelGGL(k_zgrad_scatter, dim3((n_rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, zgrad, n_rows, zmap, zraw_off, plain, grad_flat);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_hip_error((int)e); return WF_ERR_HIP; }
+    return WF_OK;
 }
 
 int launch_pack(const float* flat_dev, const PackRec* recs, int64_t n, void* plain, void* wave, void* mfma, void* stream) {

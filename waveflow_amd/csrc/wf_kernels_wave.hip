@@ -260,12 +260,14 @@ __device__ __forceinline__ T hidden_fwd(const NetWave& net, const T (&x)[D], flo
 // state of one sigmoid head lane (IMADE layer or M-spline prior): c = g (p / S0 + reg) / Q, see wf_kernels_grad.hip
 template <class T> struct SigHead {
     T p, rS0, rQ, c;
+    T s;   // sigmoid(o) itself (== p unless the head is gated)
 };
 // gate (forward sweep only): p = gq * sigmoid(o) + z, the gated head of model_factory.py:64-67 (gq: the jet of prod_{i<d} x_i^3)
 template <class T, int NBK = 1>
 __device__ __forceinline__ SigHead<T> sigmoid_head(T o, bool valid, bool valid_d, float g, float reg, bool gate = false, T gq = T{}, float z = 0.0f) {
     SigHead<T> h;
     h.p = valid ? rsigmoid(o) : cst<T>(0.0f);
+    h.s = h.p;
     if (gate && valid) h.p = gq * h.p + z;
     T S0 = rsum<NBK>(h.p);
     if (!valid_d) S0 = cst<T>(1.0f);
@@ -278,12 +280,17 @@ __device__ __forceinline__ SigHead<T> sigmoid_head(T o, bool valid, bool valid_d
     return h;
 }
 // reverse of the head: cbar (this lane) -> obar (this lane)
+// Gated head (p = gq * sigmoid(o) + z): obar = (pbar * gq) * s (1 - s); *pbar_out (if given) receives pbar, the adjoint of p, from
+// which the caller takes the adjoints of the gate (pbar * s, summed over the rows) and of z (pbar itself).
 template <class T, int NBK = 1>
-__device__ __forceinline__ T sigmoid_head_bwd(const SigHead<T>& h, T gc, bool valid, float g) {
+__device__ __forceinline__ T sigmoid_head_bwd(const SigHead<T>& h, T gc, bool valid, float g, bool gate = false, T gq = T{}, T* pbar_out = nullptr) {
     const T dotC = rsum<NBK>(gc * h.c);
     const T gw0 = ((gc - dotC) * h.rQ) * (valid ? g : 0.0f);
     const T dot0 = rsum<NBK>(gw0 * (h.p * h.rS0));
-    return valid ? ((gw0 - dot0) * h.rS0) * (h.p * (1.0f - h.p)) : cst<T>(0.0f);
+    const T pbar = valid ? (gw0 - dot0) * h.rS0 : cst<T>(0.0f);
+    if (pbar_out) *pbar_out = pbar;
+    if (gate) return valid ? (pbar * gq) * (h.s * (1.0f - h.s)) : cst<T>(0.0f);
+    return valid ? pbar * (h.p * (1.0f - h.p)) : cst<T>(0.0f);
 }
 
 // psi head lane state (wavefunctions.py:54-71, bsplines_jax.py:127-137 with zero-only constraints).  The reference divides the
@@ -683,11 +690,34 @@ __device__ __forceinline__ void hidden_bwd(const NetWave& net, T hb2, float (*ve
 }
 
 // mode 0: sum_b w1[b] log_pdf_b;  mode 1: sum_b (w1[b] psi_b + w2[b] laplacian_b)
+// Reverse of the gates G_d = prod_{i<d} x_i^3 of a gated head (G_0 = 1): gl[d][.] holds the adjoint of G_d collected from the heads
+// (d = 1 .. D-1); adds the adjoints of the conditioner's inputs x to gX.  Uniform work, done by every lane.
+template <int D, class T>
+__device__ __forceinline__ void gate_chain_bwd(const T (&x)[D], const float (*gl)[T::NC], T (&gX)[D]) {
+    T Gf[D];
+    Gf[0] = cst<T>(1.0f);
+#pragma unroll
+    for (int d = 1; d < D; ++d) Gf[d] = Gf[d - 1] * (x[d - 1] * x[d - 1] * x[d - 1]);
+    T acc = cst<T>(0.0f);
+#pragma unroll
+    for (int d = D - 1; d >= 1; --d) {
+        float c[T::NC];
+#pragma unroll
+        for (int k = 0; k < T::NC; ++k) c[k] = gl[d][k];
+        acc = acc + from_arr((T*)nullptr, c);                         // the whole adjoint of G_d
+        const T x2 = x[d - 1] * x[d - 1];
+        gX[d - 1] = gX[d - 1] + (acc * Gf[d - 1]) * (x2 * 3.0f);      // G_d = G_{d-1} x_{d-1}^3
+        acc = acc * (x2 * x[d - 1]);
+    }
+}
+
 template <int D, class T, int NBK = 1>
 __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(kOccBwd<T>, kOccBwd<T>))) void k_wave_bwd(const ModelDev* __restrict__ mdp, int mode, const float* __restrict__ tabI, const float* __restrict__ tabP,
                                                    const float* __restrict__ fk_nat, int64_t B, const float* __restrict__ w1, const float* __restrict__ w2,
-                                                   float* __restrict__ ws, const float* __restrict__ tails) {
+                                                   float* __restrict__ ws, const float* __restrict__ tails, float* __restrict__ zws) {
+    // zws (gated models only, else null): [sample][net][pass][lane] adjoint of zero_params per head lane, summed over the samples afterwards
     __shared__ float lds[kWaves][2][T::NC][64];
+    __shared__ float glds[kWaves][D][T::NC];   // gated heads: adjoints of the gates of one net, per dimension
     const ModelDev& md = *mdp;
     constexpr int DIRS = kDirs<T, D>;
     constexpr int P = NBK == 1 ? (D + 1) / 2 : D, W = 32 * NBK;
@@ -732,11 +762,26 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(kOccBwd<T>,
 #pragma unroll
             for (int d = 0; d < D; ++d) cur[d] = tail_get<T>(tl, Tail<D>::U + d);
             T hb2 = cst<T>(0.0f);
+            const bool gate_p = md.p_gate != 0;
+            T grun = cst<T>(1.0f);
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 const int d = NBK == 1 ? 2 * p + dl : p;
                 const bool valid_d = d < D, valid = valid_d && j < nb;
                 const T o = valid_d ? tget<T>(tape, NP, RW::O + d * W + j) : cst<T>(0.0f);   // head pre-activation, left by the forward sweep
+                T gq = grun;
+                if (gate_p) {   // the gate of this lane's dimension, as in the forward sweep
+                    if constexpr (NBK == 1) {
+                        const T c0 = cur[2 * p < D ? 2 * p : 0];
+                        const T g_odd = grun * (c0 * c0 * c0);
+                        gq = sel(dl == 0, grun, g_odd);
+                        const T c1 = cur[2 * p + 1 < D ? 2 * p + 1 : 0];
+                        grun = g_odd * (c1 * c1 * c1);
+                    } else {
+                        grun = grun * (cur[p] * cur[p] * cur[p]);
+                    }
+                }
+                T zbar = cst<T>(0.0f), gqb = cst<T>(0.0f);
                 bool inside;
                 const T uc = clip01(NBK == 1 ? sel(dl == 0, cur[2 * p < D ? 2 * p : 0], cur[2 * p + 1 < D ? 2 * p + 1 : 0]) : cur[p], inside);
                 const Lerp lp = make_lerp(uc.c0, n_mesh);
@@ -770,7 +815,7 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(kOccBwd<T>,
                 const T gv = sel(dl == 0, gv_lo, gv_hi);
                 T go, d1;
                 if (md.prior_kind == WF_PRIOR_WAVEFLOW) {
-                    const PsiHead<T> hd = psi_head<T, NBK>(o, valid, valid_d, kP[j], md.ob_to_b_t, ov, lane);
+                    const PsiHead<T> hd = psi_head<T, NBK>(o, valid, valid_d, kP[j], md.ob_to_b_t, ov, lane, gate_p, gq, net.z[p * 64 + lane]);
                     const T ge = gv * lift(t, 0, uc);
                     const T dotE = rsum<NBK>(ge * hd.e);
                     d1 = rsum<NBK>(hd.e * lift(t, 1, uc));
@@ -779,10 +824,23 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(kOccBwd<T>,
                     const T ga = gemv32_rows<T, NBK>(md.ob_to_b_t, ov, dl, j);          // abar_a = sum_j cbar_j ob_to_b[a][j]
                     const T dotA = rsum<NBK>(ga * hd.a);
                     go = ((ga - hd.a * dotA) * hd.rN1) * (valid ? kP[j] * hd.sgn : 0.0f);
+                    if (gate_p) {   // w = gq * o + z: `go` so far is wbar
+                        zbar = go;
+                        gqb = rsum<NBK>(go * o);
+                        go = go * gq;
+                    }
                 } else {
-                    const SigHead<T> hd = sigmoid_head<T, NBK>(o, valid, valid_d, kP[j], 0.0f);
+                    const SigHead<T> hd = sigmoid_head<T, NBK>(o, valid, valid_d, kP[j], 0.0f, gate_p, gq, net.z[p * 64 + lane]);
                     d1 = rsum<NBK>(hd.c * lift(t, 1, uc));
-                    go = sigmoid_head_bwd<T, NBK>(hd, gv * lift(t, 0, uc), valid, kP[j]);
+                    go = sigmoid_head_bwd<T, NBK>(hd, gv * lift(t, 0, uc), valid, kP[j], gate_p, gq, &zbar);
+                    if (gate_p) gqb = rsum<NBK>(zbar * hd.s);
+                }
+                if (gate_p) {
+                    if (valid_d && j == 0) {
+#pragma unroll
+                        for (int k = 0; k < T::NC; ++k) glds[wv][d][k] = coef(gqb, k);
+                    }
+                    if (zws) zws[((s * n_nets + NP) * P + p) * 64 + lane] = coef(zbar, T::NC - 1);
                 }
                 const T gu = (valid_d && inside) ? gv * d1 : cst<T>(0.0f);
                 if constexpr (NBK == 1) {
@@ -797,6 +855,11 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(kOccBwd<T>,
                 hb2 = hb2 + gemv<T, false, WF_GEMV_UNROLL_BWD>(net.W2b + p * 1024, ov, lane);
             }
             hidden_bwd<D, T>(net, hb2, vec, lane, tape, NP, gU);
+            if (gate_p) {   // the gates see the conditioner's input: the unclipped u
+                __builtin_amdgcn_wave_barrier();
+                gate_chain_bwd<D, T>(cur, glds[wv], gU);
+                __builtin_amdgcn_wave_barrier();
+            }
         } else if (md.prior_kind == WF_PRIOR_NORMAL) {
 #pragma unroll
             for (int d = 0; d < D; ++d) gU[d] = gOut * ((tail_get<T>(tl, Tail<D>::U + d) + md.normal_offset) * -1.0f);
@@ -813,18 +876,32 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(kOccBwd<T>,
 #pragma unroll
             for (int d = 0; d < D; ++d) gU[d] = cst<T>(0.0f);
             T hb2 = cst<T>(0.0f);
+            const bool gate_i = md.i_gate != 0;
+            T grun = cst<T>(1.0f);
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 const int d = NBK == 1 ? 2 * p + dl : p;
                 const bool valid_d = d < D;
                 const T o = valid_d ? tget<T>(tape, l, RW::O + d * W + j) : cst<T>(0.0f);
                 const T u = NBK == 1 ? sel(dl == 0, U[2 * p < D ? 2 * p : 0], U[2 * p + 1 < D ? 2 * p + 1 : 0]) : U[p];
+                T gq = grun;
+                if (gate_i) {
+                    if constexpr (NBK == 1) {
+                        const T c0 = U[2 * p < D ? 2 * p : 0];
+                        const T g_odd = grun * (c0 * c0 * c0);
+                        gq = sel(dl == 0, grun, g_odd);
+                        const T c1 = U[2 * p + 1 < D ? 2 * p + 1 : 0];
+                        grun = g_odd * (c1 * c1 * c1);
+                    } else {
+                        grun = grun * (U[p] * U[p] * U[p]);
+                    }
+                }
                 const T gy = NBK == 1 ? sel(dl == 0, gY[2 * p < D ? 2 * p : 0], gY[2 * p + 1 < D ? 2 * p + 1 : 0]) : gY[p];
                 T go, gu;
                 if (imade) {
                     const int nb = md.isp.nb;
                     const bool valid = valid_d && j < nb;
-                    const SigHead<T> hd = sigmoid_head<T, NBK>(o, valid, valid_d, gI[j], md.i_reg);
+                    const SigHead<T> hd = sigmoid_head<T, NBK>(o, valid, valid_d, gI[j], md.i_reg, gate_i, gq, net.z[p * 64 + lane]);
                     const Lerp lp = make_lerp(u.c0, n_mesh);
                     float t[4];
                     lerp4<W>(tabI, plane, lp, j, t);
@@ -833,7 +910,16 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(kOccBwd<T>,
                     const T y2 = rsum<NBK>(hd.c * lift(t, 2, u));
                     const T gdy = gLD * rrcp(dy + 1e-7f);
                     gu = valid_d ? gy * dy + gdy * y2 : cst<T>(0.0f);
-                    go = sigmoid_head_bwd<T, NBK>(hd, gy * b0 + gdy * b1, valid, gI[j]);
+                    T zbar = cst<T>(0.0f);
+                    go = sigmoid_head_bwd<T, NBK>(hd, gy * b0 + gdy * b1, valid, gI[j], gate_i, gq, &zbar);
+                    if (gate_i) {
+                        const T gqb = rsum<NBK>(zbar * hd.s);
+                        if (valid_d && j == 0) {
+#pragma unroll
+                            for (int k = 0; k < T::NC; ++k) glds[wv][d][k] = coef(gqb, k);
+                        }
+                        if (zws) zws[((s * n_nets + l) * P + p) * 64 + lane] = coef(zbar, T::NC - 1);
+                    }
                 } else {
                     const T lw = from_lane(o, dl * 32), bias = from_lane(o, dl * 32 + 1);
                     const T e = rexp(cst<T>(0.0f) - lw);
@@ -855,6 +941,11 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(kOccBwd<T>,
                 hb2 = hb2 + gemv<T, false, WF_GEMV_UNROLL_BWD>(net.W2b + p * 1024, ov, lane);
             }
             hidden_bwd<D, T>(net, hb2, vec, lane, tape, l, gU);
+            if (gate_i) {
+                __builtin_amdgcn_wave_barrier();
+                gate_chain_bwd<D, T>(U, glds[wv], gU);
+                __builtin_amdgcn_wave_barrier();
+            }
         }
     }
 }
@@ -1166,9 +1257,9 @@ int run_fwd(const ModelDev* md_dev, const float* tabI4, const float* tabP4, cons
 }
 template <int D, class T, int NBK = 1>
 int run_bwd(const ModelDev* md_dev, int mode, const float* tabI4, const float* tabP4, const float* fk_nat, int64_t B, const float* w1, const float* w2,
-            float* ws, const float* tails, hipStream_t s) {
+            float* ws, const float* tails, float* zws, hipStream_t s) {
     const int64_t n_samples = B * kDirs<T, D>;
-    hipLaunchKernelGGL((k_wave_bwd<D, T, NBK>), dim3(wave_grid(n_samples)), dim3(kWB), 0, s, md_dev, mode, tabI4, tabP4, fk_nat, B, w1, w2, ws, tails);
+    hipLaunchKernelGGL((k_wave_bwd<D, T, NBK>), dim3(wave_grid(n_samples)), dim3(kWB), 0, s, md_dev, mode, tabI4, tabP4, fk_nat, B, w1, w2, ws, tails, zws);
     return finish();
 }
 
@@ -1215,11 +1306,11 @@ int launch_wave_fwd(const ModelDev& md, const ModelDev* md_dev, int ring_kind, c
 }
 
 int launch_wave_bwd(const ModelDev& md, const ModelDev* md_dev, int mode, int ring_kind, const float* tabI4, const float* tabP4,
-                    const float* fk_nat, int64_t B, const float* w1, const float* w2, float* ws, const float* tails, void* stream) {
+                    const float* fk_nat, int64_t B, const float* w1, const float* w2, float* ws, const float* tails, float* zws, void* stream) {
     hipStream_t s = (hipStream_t)stream;
-#define CALLK(DD, K) (ring_kind == 2 ? run_bwd<DD, RF<rf_block(DD)>, K>(md_dev, mode, tabI4, tabP4, fk_nat, B, w1, w2, ws, tails, s)  \
-                      : ring_kind == 1 ? run_bwd<DD, R3, K>(md_dev, mode, tabI4, tabP4, fk_nat, B, w1, w2, ws, tails, s) \
-                                       : run_bwd<DD, R1, K>(md_dev, mode, tabI4, tabP4, fk_nat, B, w1, w2, ws, tails, s))
+#define CALLK(DD, K) (ring_kind == 2 ? run_bwd<DD, RF<rf_block(DD)>, K>(md_dev, mode, tabI4, tabP4, fk_nat, B, w1, w2, ws, tails, zws, s)  \
+                      : ring_kind == 1 ? run_bwd<DD, R3, K>(md_dev, mode, tabI4, tabP4, fk_nat, B, w1, w2, ws, tails, zws, s) \
+                                       : run_bwd<DD, R1, K>(md_dev, mode, tabI4, tabP4, fk_nat, B, w1, w2, ws, tails, zws, s))
 #define CALL(DD) CALLK(DD, 1)
 #define CALL64(DD) CALLK(DD, 2)
     if (md.nbp == 64) { WF_WAVE_DISPATCH64(CALL64) }

@@ -108,6 +108,12 @@ struct wf_model {
     int32_t* d_grad_map = nullptr;   // [n_params]: forward-image entry (over all nets) that holds each parameter, -1 = none
     float* d_grad_partial = nullptr; // per-split partial gradient images of k_wgrad
     float* d_grad_img = nullptr;     // [n_nets * fwd image floats]: gradient accumulator in forward-image layout
+    // gated heads: gradient of the zero_params leaves (rows = n_nets * passes * 64 head lanes of the wave layout)
+    int z_rows = 0;
+    float* d_zpart = nullptr;        // [64 splits][z_rows]
+    float* d_zgrad = nullptr;        // [z_rows]
+    int32_t* d_zmap = nullptr;       // row -> index of its leaf entry in the flat vector (-1: padding lane / ungated net)
+    int32_t* d_zraw_off = nullptr;   // row -> offset of the raw leaf value in the plain image for |z| heads (-1: signed head)
 };
 
 namespace wf {
@@ -118,7 +124,7 @@ static int64_t plain_fwd_floats(int D, int nbp) {
 }
 // ... followed by W1n, W2n, zero
 static int64_t plain_net_floats(int D, int nbp) {
-    return plain_fwd_floats(D, nbp) + (int64_t)kHidden * kHidden + (int64_t)kHidden * D * nbp + (int64_t)D * nbp;
+    return plain_fwd_floats(D, nbp) + (int64_t)kHidden * kHidden + (int64_t)kHidden * D * nbp + 2 * (int64_t)D * nbp;   // ..., zero, zero_raw
 }
 
 static int check_bc(const wf_bc& bc, int nb) {
@@ -477,7 +483,8 @@ static int model_build(wf_model* m) {
         np.b2 = p; p += (int64_t)D * m->nbp;
         np.W1n = p; p += (int64_t)kHidden * kHidden;
         np.W2n = p; p += (int64_t)kHidden * D * m->nbp;
-        np.zero = p;
+        np.zero = p; p += (int64_t)D * m->nbp;
+        np.zero_raw = p;
     }
     {
         const int P = wave_passes(D, m->nbp);
@@ -571,6 +578,8 @@ static void describe_plain_image(const wf_model* m, int n, uint32_t base, std::v
             if (sig) w.f32_abs(src);
             else w.f32(src);
         }
+    for (int dd = 0; dd < D; ++dd)   // the same leaf without the |.| (zero_raw)
+        for (int jb = 0; jb < nbp; ++jb) w.f32((gated && jb < nl.n_out) ? q.b2 + q.NO + (int64_t)dd * nl.n_out + jb : -1);
 }
 
 
@@ -870,7 +879,7 @@ static bool wave_capable(const wf_model* m, bool forward_only = false) {
     return true;
 }
 // ... which is also what the reverse pass and the local energy need (every D the library supports, 2..8, is instantiated)
-static bool grad_capable(const wf_model* m) { return m->wave_ok && !m->nets.empty(); }
+static bool grad_capable(const wf_model* m) { return m->wave_eval_ok && !m->nets.empty(); }   // (gated heads included: run_vjp_chunks)
 
 // Describes every weight image (PackRec lists on the device) and derives the gradient scatter map: forward-image entry ->
 // flat parameter (masked and padding entries have no source: no gradient).
@@ -945,6 +954,37 @@ static int grad_prepare(wf_model* m) {
     int rc = dev_alloc(m, &m->d_grad_map, inv.size());
     if (rc) return rc;
     WF_HIP(hipMemcpy(m->d_grad_map, inv.data(), inv.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (m->dev.i_gate || m->dev.p_gate) {
+        // zero_params gradient rows in the wave layout: row = (net * P + p) * 64 + lane  <->  leaf entry (d, jb) of that net
+        const int P = wave_passes(D, m->nbp);
+        const bool wide = m->nbp == 64;
+        m->z_rows = n_nets * P * 64;
+        std::vector<int32_t> zmap((size_t)m->z_rows, -1), zoff((size_t)m->z_rows, -1);
+        for (int n = 0; n < n_nets; ++n) {
+            const NetLayout& nl = m->nets[n];
+            if (!nl.has_zero || !net_is_gated(m, n)) continue;
+            const NetOffsets q = net_offsets(m, n);
+            const bool sig = net_has_sigmoid_head(m, n);
+            for (int p = 0; p < P; ++p)
+                for (int c = 0; c < 64; ++c) {
+                    const int dd = wide ? p : 2 * p + (c >> 5), jb = wide ? c : (c & 31);
+                    if (dd >= D || jb >= nl.n_out) continue;
+                    const size_t r = ((size_t)n * P + p) * 64 + c;
+                    zmap[r] = (int32_t)(q.b2 + q.NO + (int64_t)dd * nl.n_out + jb);
+                    if (sig) zoff[r] = (int32_t)(m->plain_off[n] + (m->dev.nets[n].zero_raw - m->dev.nets[n].W0) + (int64_t)dd * m->nbp + jb);
+                }
+        }
+        rc = dev_alloc(m, &m->d_zmap, zmap.size());
+        if (rc) return rc;
+        WF_HIP(hipMemcpy(m->d_zmap, zmap.data(), zmap.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        rc = dev_alloc(m, &m->d_zraw_off, zoff.size());
+        if (rc) return rc;
+        WF_HIP(hipMemcpy(m->d_zraw_off, zoff.data(), zoff.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        rc = dev_alloc(m, &m->d_zpart, (size_t)64 * m->z_rows);
+        if (rc) return rc;
+        rc = dev_alloc(m, &m->d_zgrad, (size_t)m->z_rows);
+        if (rc) return rc;
+    }
     rc = dev_alloc(m, &m->d_grad_partial, (size_t)wgrad_partial_floats(n_nets, fwd));
     if (rc) return rc;
     return dev_alloc(m, &m->d_grad_img, map.size());
@@ -1272,7 +1312,8 @@ static int64_t vjp_bytes_per_walker(const wf_model* m, bool second_order) {
     const int D = m->desc.n_dim;
     const int kind = second_order ? m->ring2 : 0;
     const int64_t samples = ring_samples(D, kind), nc = ring_coefs(D, kind);
-    return (samples * ((int64_t)m->nets.size() * grad_ws_rows(D, m->nbp) * nc) + wave_tail_floats(D, kind) + 4) * (int64_t)sizeof(float);
+    const int64_t zrows = m->z_rows;   // gated heads: one zero_params adjoint per (sample, head lane)
+    return (samples * ((int64_t)m->nets.size() * grad_ws_rows(D, m->nbp) * nc + zrows) + wave_tail_floats(D, kind) + 4) * (int64_t)sizeof(float);
 }
 
 static int64_t vjp_ws_bytes(const wf_model* m, int64_t B, bool second_order) {
@@ -1301,6 +1342,7 @@ static int run_vjp_chunks(const wf_model* m, int mode, bool second_order, const 
     float* tape = (float*)workspace_dev;
     float* tails = tape + chunk * samples_per * n_nets * grad_ws_rows(D, m->nbp) * nc;
     float* per_walker = tails + chunk * wave_tail_floats(D, kind);   // [4][chunk]
+    float* zws = m->z_rows ? per_walker + 4 * chunk : nullptr;        // [chunk * samples_per][z_rows]
     if (B == 0) {   // the gradient of an empty batch is zero
         WF_HIP(hipMemsetAsync(grad_dev, 0, (size_t)m->n_params * sizeof(float), s));
         return WF_OK;
@@ -1329,16 +1371,23 @@ static int run_vjp_chunks(const wf_model* m, int mode, bool second_order, const 
             cw1 = wp;
         }
         rc = launch_wave_bwd(m->dev, m->d_dev, (mode == 0 || mode == 3) ? 0 : 1, kind, m->d_tabI4, m->d_tabP3, m->d_grad_fk, bc, cw1, cw2, tape,
-                             tails, stream);
+                             tails, zws, stream);
         if (rc) return rc;
+        if (zws) {
+            rc = launch_zgrad_reduce(zws, bc * samples_per, m->z_rows, c0 > 0, m->d_zpart, m->d_zgrad, stream);
+            if (rc) return rc;
+        }
         rc = launch_wgrad(D, m->nbp, kind, n_nets, bc * samples_per, tape, m->d_grad_partial, c0 > 0, m->d_grad_img, fwd,
                           single ? &split : nullptr, stream);
         if (rc) return rc;
     }
     if (defer_gather_split) *defer_gather_split = single ? split : 0;
-    if (single && defer_gather_split) return WF_OK;   // the caller reads m->d_grad_partial itself (launch_adam_partials)
-    if (single) return launch_grad_gather_partials(m->d_grad_partial, split, n_img, m->d_grad_map, m->n_params, grad_dev, stream);
-    return launch_grad_gather(m->d_grad_img, m->d_grad_map, m->n_params, grad_dev, stream);
+    if (single && defer_gather_split) return WF_OK;   // the caller reads m->d_grad_partial itself (launch_adam_partials; ungated models only)
+    int rc = single ? launch_grad_gather_partials(m->d_grad_partial, split, n_img, m->d_grad_map, m->n_params, grad_dev, stream)
+                    : launch_grad_gather(m->d_grad_img, m->d_grad_map, m->n_params, grad_dev, stream);
+    if (rc || !zws) return rc;
+    // the zero_params leaves (the gather wrote 0 there: they reach no weight-image entry)
+    return launch_zgrad_scatter(m->d_zgrad, m->z_rows, m->d_zmap, m->d_zraw_off, m->d_plain, grad_dev, stream);
 }
 
 int64_t wf_psi_vjp_workspace_bytes(const wf_model* m, int64_t B) { return vjp_ws_bytes(m, B, true); }
@@ -1407,7 +1456,7 @@ static int adam_from_sweep(wf_model* m, const wf_train_state* st, const float* g
 
 int64_t wf_vqmc_train_step_workspace_bytes(const wf_model* m, int64_t batch) {
     if (!m || batch < 1) return WF_ERR_INVALID;
-    if (!m->d_grad_map || !m->grad_psi_ok || batch > kWaveSampleMax) return WF_ERR_UNSUPPORTED;
+    if (!m->d_grad_map || !m->grad_psi_ok || !m->wave_ok || batch > kWaveSampleMax) return WF_ERR_UNSUPPORTED;   // (wave_ok: ungated, wave sampler)
     return align256(batch * m->desc.n_dim * 4) + align256(batch * 4) + align256(m->n_params * 4) + 256 + align256(block_sums_ws_bytes(batch)) +
            vjp_ws_bytes(m, batch, true);
 }
@@ -1487,7 +1536,7 @@ int wf_vqmc_train_step_apply(wf_model* m, const wf_train_state* st, const double
                              void* stream) {
     if (!m || !st || !reduce_dev) return WF_ERR_INVALID;
     if (!st->params_dev || !st->m_dev || !st->v_dev || !st->counter_dev || !st->loss_ring_dev || st->ring_len < 1) return WF_ERR_INVALID;
-    if (!m->d_grad_map) return WF_ERR_UNSUPPORTED;
+    if (!m->d_grad_map || m->z_rows) return WF_ERR_UNSUPPORTED;
     DeviceGuard g(m->device);
     int rc = launch_adam_reduced(st->params_dev, reduce_dev, st->m_dev, st->v_dev, m->n_params, step_size, b1, b2, eps,
                                  (const unsigned long long*)st->counter_dev, stream);
@@ -1499,7 +1548,7 @@ int wf_vqmc_train_step_apply(wf_model* m, const wf_train_state* st, const double
 
 int64_t wf_mle_train_step_workspace_bytes(const wf_model* m, int64_t N) {
     if (!m || N < 1) return WF_ERR_INVALID;
-    if (!m->d_grad_map) return WF_ERR_UNSUPPORTED;
+    if (!m->d_grad_map || m->z_rows) return WF_ERR_UNSUPPORTED;   // (gated heads: the step's Adam reads the weight images only)
     return align256(N * 4) + align256(m->n_params * 4) + 256 + align256(block_sums_ws_bytes(N)) + vjp_ws_bytes(m, N, false);
 }
 
