@@ -72,8 +72,8 @@ def sorted_uniform(B, D, seed):
     return torch.sort(x, dim=-1).values.contiguous()
 
 
-def kernel_ms(model, x, n=20, warm=5):
-    """Mean HIP-event time of wf_logpdf_fwd on the current stream."""
+def kernel_ms(model, x, n=50, warm=150):
+    """Mean HIP-event time of wf_logpdf_fwd on the current stream (150 untimed launches first: the sustained-clock regime, see --warmup)."""
     import torch
     for _ in range(warm):
         model.log_pdf(x)
@@ -171,8 +171,11 @@ def cpu_baseline(flat, x_host, budget_s=10.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    # Defaults: 300 untimed + 200 timed steps (0.15 s of GPU time).  The warm-up is long on purpose: from an idle GPU the first ~60 back-to-back
+    # launches of the headline kernel take 0.29 - 0.32 ms, from ~200 on 0.259 ms (scratch/time_warm.py, profiles/r02_warmup.txt: the device
+    # reaches its sustained clocks only under sustained load); a VQMC job sits in the second regime.
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=300)
     ap.add_argument("--batch", type=int, default=1 << 20, help="walkers per GPU")
     ap.add_argument("--kernel", default="auto", choices=["auto", "scalar", "mfma", "wave"])
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -391,7 +391,21 @@ __device__ __forceinline__ void sigmoid_block(f32x16 (&o)[NBK], const float* fk_
     Sf = xhalf_sum(sf);
 }
 
-#ifdef WF_STAMP
+#if defined(WF_STAMP) && defined(WF_STAMP_TILE)
+// per-tile variant: slot (iteration & 7) accumulates the wave's elapsed cycles of that iteration of the tile loop (slot 0 includes the prologue)
+#define STAMP(k)                                                                                   \
+    do {                                                                                           \
+        if ((k) == 6) {                                                                            \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+            unsigned long long t_;                                                                 \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");             \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+            stamp_acc[stamp_iter & 7] += t_ - stamp_last;                                          \
+            stamp_last = t_;                                                                       \
+            ++stamp_iter;                                                                          \
+        }                                                                                          \
+    } while (0)
+#elif defined(WF_STAMP)
 #define STAMP(k)                                                                                   \
     do {                                                                                           \
         __builtin_amdgcn_sched_barrier(0);                                                         \
@@ -444,6 +458,12 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
     constexpr int kThreads = kWaves * 64;
     const int box_kind = SPEC ? (int)WF_BOX_MEAN : mm.box_kind, layer_kind = SPEC ? (int)WF_LAYER_IMADE : mm.layer_kind;
     const int prior_kind = SPEC ? (int)WF_PRIOR_WAVEFLOW : mm.prior_kind, staged = SPEC ? 0 : mm.staged, exact_div = SPEC ? 0 : mm.exact_div;
+    // Resident mode hands the workgroup's tiles to its waves through a counter in LDS instead of a fixed share per wave: the SIMD's issue
+    // arbitration favours its oldest wave (measured with per-tile s_memtime stamps: at 16 waves the first tile of SIMD slot 0 takes 39 k
+    // cycles, that of slot 3 151 k), so with equal shares the old waves leave early and the last tiles run at one or two waves per SIMD --
+    // a quarter of the launch time was that tail.  Every wave leaves the loop when the counter passes the workgroup's share.
+    __shared__ int next_slot;
+    if (threadIdx.x == 0) next_slot = 0;
     stage_floats<kThreads>(mm.image + mm.const_img_off, lds, mm.const_floats);
     if (!staged) stage_floats<kThreads>(mm.image, lds + mm.const_floats, mm.net_floats * mm.n_nets);
     __syncthreads();
@@ -462,7 +482,9 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
     const float rn_mesh = 1.0f / (float)(mm.n_mesh - 1);
 #ifdef WF_STAMP
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
+    [[maybe_unused]] int stamp_iter = 0;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
+    [[maybe_unused]] const unsigned long long stamp_t0 = stamp_last;
 #endif
 
 #ifdef WF_STAGGER
@@ -471,14 +493,31 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
     // per SIMD slot keeps them out of phase (there is no barrier after this point in resident mode).
     for (int q = 0; q < ((wave >> 2) & 3); ++q) __builtin_amdgcn_s_sleep(WF_STAGGER);
 #endif
-    for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    // this workgroup's chunks: blockIdx.x, blockIdx.x + gridDim.x, ...; a slot = (chunk, wave position) = T tiles
+    const int64_t my_chunks = n_chunks > (int64_t)blockIdx.x ? (n_chunks - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    const int my_slots = (int)(my_chunks * kWaves);
+    for (int it = 0;; ++it) {
+        int64_t chunk;
+        int wpos;
+        if (staged) {   // (barriers inside the loop: every wave walks the same chunks)
+            chunk = (int64_t)blockIdx.x + (int64_t)it * gridDim.x;
+            wpos = wave;
+            if (chunk >= n_chunks) break;
+        } else {
+            int q = 0;
+            if (lane == 0) q = __hip_atomic_fetch_add(&next_slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            q = __builtin_amdgcn_readfirstlane(q);
+            if (q >= my_slots) break;
+            chunk = (int64_t)blockIdx.x + (int64_t)(q / kWaves) * gridDim.x;
+            wpos = q % kWaves;
+        }
         float cur[T][D], nxt[T][D], logdet[T];
         int64_t w[T];
         bool valid[T];
         int32_t* idx[T];
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-            const int64_t tile = (chunk * kWaves + wave) * T + t;    // may be >= n_tiles in the last chunk: computed, never stored
+            const int64_t tile = (chunk * kWaves + wpos) * T + t;    // may be >= n_tiles in the last chunk: computed, never stored
             w[t] = tile * 32 + j;
             valid[t] = w[t] < B;
             const int64_t wl = valid[t] ? w[t] : B - 1;
@@ -812,7 +851,11 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
 #ifdef WF_STAMP
     if (mm.dbg && lane == 0) {
         unsigned long long* g = reinterpret_cast<unsigned long long*>(mm.dbg) + ((size_t)blockIdx.x * kWaves + wave) * 8;
+#ifdef WF_STAMP_SPAN   // absolute start / finish of the wave's tile loop and its number of iterations
+        g[0] = stamp_t0; g[1] = stamp_last; g[2] = (unsigned long long)stamp_iter;
+#else
         for (int k = 0; k < 8; ++k) g[k] = stamp_acc[k];
+#endif
     }
 #endif
 }
