@@ -246,6 +246,8 @@ def main():
         _lib.check(L.wf_block_sums(P(lp), B, P(sums), P(ws), ws.numel(), sp), "wf_block_sums")
         if use_dist:   # one RCCL all-reduce of 3 doubles per step, asynchronous: completed in fence(), inside the timed region
             pending.append(dist.all_reduce(sums, op=dist.ReduceOp.SUM, async_op=True))
+            if len(pending) > 32:      # bound the number of outstanding collectives: a stream-side wait on one that finished long ago
+                pending.pop(0).wait()
 
     def fence():
         for w in pending:
