@@ -93,11 +93,9 @@ typedef struct {
     /* set_nn_output_grad_to_zero of the layers' / the prior's conditioner (model_factory.py:55-67, ABI 2):
      *   bij[d][j] = g_d(x) * head(o[d][j]) + z[d][j],   g_0 = 1, g_d = prod_{i<d} x_i^3  (x: the conditioner's input),
      * z = zero_params[d][j] (its absolute value under a sigmoid head), before the division by sum_j bij[d][j].
-     * Evaluation: every forward kernel (per-walker, MFMA, the wave forward sweep: small batches and wf_hamiltonian_fwd, where the gate
-     * travels as a jet).  Gradients: wf_psi_vjp, wf_logpdf_vjp, wf_logpdf_loss_grad, wf_vqmc_loss_grad, zero_params leaves included
-     * (d|z| = sign(z) under a sigmoid head).  Not built for a gated model: the fused training steps (wf_vqmc_train_step*,
-     * wf_mle_train_step: WF_ERR_UNSUPPORTED -- step with wf_vqmc_loss_grad + wf_adam_step instead) and the wave sampler
-     * (wf_sample / wf_inverse_fwd use the per-walker kernel). */
+     * Built everywhere: the three forward kernels (in the wave sweep the gate travels as a jet: wf_hamiltonian_fwd), inverse and both
+     * samplers, the gradient entry points (zero_params leaves included; d|z| = sign(z) under a sigmoid head) and the fused training
+     * steps.  The oracle for this branch restates the four reference lines; the reference ships no output of a gated model (unpinned). */
     int32_t i_gate, p_gate;
     /* layer_kind WF_LAYER_NSC (ABI 2): n_flow_layers NeuralSplineCoupling layers (flows/bijections/neural_splines.py:244-296; K bins,
      * tail bound B, FCNN conditioners of width hidden_dim), each followed by flows.Reverse when nsc_reverse != 0, under a Normal or

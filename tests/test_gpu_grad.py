@@ -708,7 +708,49 @@ def test_gated_wavefunction_energy_vs_autograd_oracle(D):
     sums, grad = m.vqmc_loss_grad(x, pr, running_average=-1.0)
     lo_, go_, _ = et.vqmc_loss_grad(mo, flat, x.astype(np.float64), pr, -1.0)
     assert rel_l2(grad.cpu().numpy().astype(np.float64), go_) < 1e-2
-    assert L.wf_vqmc_train_step_workspace_bytes(m._h, 128) == -2
+    # ---- the fused training step (sampler -> loss + gradient -> Adam -> image refill; wf_vqmc_train_step) on the gated model: two steps
+    # replayed from one hipGraph equal the same sequence issued call by call (sampler with the step's stream, wf_vqmc_loss_grad, wf_adam_step)
+    assert L.wf_vqmc_train_step_workspace_bytes(m._h, 128) > 0
+    seed, Bt, lr = 77, 128, 1e-3
+
+    def fresh():
+        xs = torch.as_tensor(flat).cuda()
+        return xs, torch.zeros_like(xs), torch.zeros_like(xs)
+
+    xa, ma, va = fresh()
+    st = m.make_train_state(xa, ma, va, 0, ring_len=8)
+    m.set_params_device(xa)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        m.train_step(st, seed, Bt, pr, lr, exact_sampler=True)     # warm-up: workspace allocation
+        xa.copy_(torch.as_tensor(flat)); ma.zero_(); va.zero_(); st["counter"].zero_(); st["ring"].zero_()
+        m.set_params_device(xa)
+        side.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            m.train_step(st, seed, Bt, pr, lr, exact_sampler=True)
+    torch.cuda.current_stream().wait_stream(side)
+    graph.replay(); graph.replay()
+    torch.cuda.synchronize()
+    assert int(st["counter"].item()) == 2
+    ring = st["ring"].cpu().numpy()
+    xb, mb, vb = fresh()
+    means = []
+    for i in range(2):
+        m.set_params_device(xb)
+        # the step's sampler stream: seed advanced by the step counter (wf_kernels_wave.hip: seed += counter * 0x9E3779B97F4A7C15)
+        xs_i = m.sample((seed + i * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF, Bt, exact=True)
+        sums_i, grad_i = m.vqmc_loss_grad(xs_i, pr, running_average=0.0)
+        m.adam_step(xb, grad_i, mb, vb, i, lr)
+        means.append(float(sums_i[0] / sums_i[2]))
+    torch.cuda.synchronize()
+    # (Adam's bias corrections come from the host's powf in one path and the device's in the other: last-bit differences of the step size)
+    assert np.abs(xa.cpu().numpy() - xb.cpu().numpy()).max() <= 2e-9 + 1e-6 * lr
+    assert np.allclose([ring[0, 0] / ring[0, 2], ring[1, 0] / ring[1, 2]], means, rtol=1e-6)
+    moved = np.abs(xa.cpu().numpy() - flat)
+    assert moved[is_zero].max() > 1e-4 and moved[~is_zero].max() > 1e-4        # Adam moved the zero_params leaves too
+    m.set_params(flat)
 
 
 def zero_leaf_mask(params):

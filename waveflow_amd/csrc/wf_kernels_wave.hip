@@ -1063,9 +1063,15 @@ __device__ __forceinline__ void wave_serial_inverse(const ModelDev& md, const fl
         if (md.layer_kind == WF_LAYER_IMADE) {
             const int nb = md.isp.nb, n_mesh = md.isp.n_mesh;
             const float tol = md.reverse_tol;
+            const bool gate_i = md.i_gate != 0;
+            float gq = 1.0f;   // gated heads: prod_{i<d} x_i^3 of the vector the conditioner sees (made.py:88: the values being inverted, or the prefix)
 #pragma unroll
             for (int d = 0; d < D; ++d) {
                 const int p = NBK == 1 ? d >> 1 : d, hd = NBK == 1 ? (d & 1) : 0;
+                if (gate_i && d > 0) {
+                    const float xp = exact ? cur[d - 1] : nxt[d - 1];
+                    gq = gq * (xp * xp * xp);
+                }
                 R1 o;
                 if (d == 0) {
                     // output dimension 0 sees no input (MADE mask, model_factory.py:15-18): its head is the bias alone
@@ -1080,7 +1086,7 @@ __device__ __forceinline__ void wave_serial_inverse(const ModelDev& md, const fl
                     o = gemv<R1, true>(net.W2f + p * 1024, vec, lane) + net.b2[p * 64 + lane];
                 }
                 const bool valid_d = (NBK == 1 ? 2 * p + dl : p) < D, valid = valid_d && j < nb;
-                const SigHead<R1> hdw = sigmoid_head<R1, NBK>(o, valid, valid_d, gI[j], md.i_reg);
+                const SigHead<R1> hdw = sigmoid_head<R1, NBK>(o, valid, valid_d, gI[j], md.i_reg, gate_i, R1{gq}, net.z[p * 64 + lane]);
                 cur[d] = ispline_inverse<NBK>(tabI, n_mesh, nb, hdw.c.c0, nxt[d], tol, hd, ov, lane);
             }
         } else {
@@ -1148,9 +1154,11 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(WF_OCC_SAMP
                 const NetWave& net = md.wnets[md.n_layers];
                 const int nb = md.psp.nb, n_mesh = md.psp.n_mesh;
                 const bool wavefn = md.prior_kind == WF_PRIOR_WAVEFLOW;
+                float gcol = 1.0f;
 #pragma unroll
                 for (int col = 0; col < D; ++col) {
                     const int p = NBK == 1 ? col >> 1 : col, hd = NBK == 1 ? (col & 1) : 0;
+                    if (md.p_gate != 0 && col > 0) gcol = gcol * (cur[col - 1] * cur[col - 1] * cur[col - 1]);   // gated head: prod of the drawn columns' cubes
                     R1 o;
                     if (col == 0) {
                         o = R1{net.b2[lane]};   // column 0 is conditioned on nothing: bias only
@@ -1171,13 +1179,13 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(WF_OCC_SAMP
                     };
                     if (wavefn) {
                         // sample_fun (bsplines_jax.py:144-171): obw = normalised(w @ ob_to_b); ymax = max((obw @ b_to_ob)^2)
-                        const PsiHead<R1> hdw = psi_head<R1, NBK>(o, valid, valid_d, kP[j], md.ob_to_b_t, ov, lane);
+                        const PsiHead<R1> hdw = psi_head<R1, NBK>(o, valid, valid_d, kP[j], md.ob_to_b_t, ov, lane, md.p_gate != 0, R1{gcol}, net.z[p * 64 + lane]);
                         cj = hdw.e.c0;
                         put(ov, lane, hdw.e);
                         const float q = gemv32_cols<R1, NBK>(md.b_to_ob, ov, dl, j).c0;
                         ymax = col_max(valid ? q * q : 0.0f);
                     } else {
-                        const SigHead<R1> hdw = sigmoid_head<R1, NBK>(o, valid, valid_d, kP[j], 0.0f);
+                        const SigHead<R1> hdw = sigmoid_head<R1, NBK>(o, valid, valid_d, kP[j], 0.0f, md.p_gate != 0, R1{gcol}, net.z[p * 64 + lane]);
                         cj = hdw.c.c0;
                         ymax = col_max(valid ? cj : 0.0f) * (float)(nb + md.psp.degree);   // msplines_jax.py:147-150
                     }

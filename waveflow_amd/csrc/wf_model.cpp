@@ -93,9 +93,7 @@ struct wf_model {
     int64_t scratch_floats = 0;
     float* d_wave = nullptr;         // NetWave images
     float* d_grad_fk = nullptr;      // [2][64] natural-order row factors for the reverse pass (flow rows, prior rows)
-    bool wave_ok = false;            // the wave-cooperative sweeps cover this model (homogeneous constraints; > 32 bases: D <= 4)
-    bool wave_eval_ok = false;       // ... its forward sweep does (small-batch log_pdf / psi, local energy): also with gated heads, which the
-                                     // reverse sweep, the wave sampler and the fused training steps do not build
+    bool wave_ok = false;            // the wave-cooperative sweeps and sampler cover this model (homogeneous constraints, gated heads included; > 32 bases: D <= 4)
     // boundary conditions as a linear map on the coefficient vector (bc_map below): column sums a~ of A, per spline (I layers / prior);
     // bc_*_ok: homogeneous (no constant term) and every column with a~_j == 0 is entirely zero -> the table-driven kernels apply
     bool is_nsc = false;             // layer_kind WF_LAYER_NSC: the coupling stack (k_nsc_model), none of the conditioner-net machinery
@@ -868,10 +866,9 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
 }
 
 // The wave-cooperative kernels (wf_kernels_wave.hip): <= 32 bases, constraints that only zero the end weights.
-static bool wave_capable(const wf_model* m, bool forward_only = false) {
+static bool wave_capable(const wf_model* m) {
     const wf_model_desc& d = m->desc;
     if (!m->d_wave || (m->nbp == 64 && d.n_dim > 4)) return false;   // (the 64-row sweeps are built for D <= 4)
-    if (!forward_only && (m->dev.i_gate || m->dev.p_gate)) return false;   // gated heads: forward sweep only
     const bool imade = d.layer_kind == WF_LAYER_IMADE && d.n_flow_layers > 0;
     if (imade && (!m->d_tabI4 || !m->bc_i_ok)) return false;
     const bool spline_prior = d.prior_kind == WF_PRIOR_WAVEFLOW || d.prior_kind == WF_PRIOR_MFLOW;
@@ -879,7 +876,7 @@ static bool wave_capable(const wf_model* m, bool forward_only = false) {
     return true;
 }
 // ... which is also what the reverse pass and the local energy need (every D the library supports, 2..8, is instantiated)
-static bool grad_capable(const wf_model* m) { return m->wave_eval_ok && !m->nets.empty(); }   // (gated heads included: run_vjp_chunks)
+static bool grad_capable(const wf_model* m) { return m->wave_ok && !m->nets.empty(); }   // (gated heads included: run_vjp_chunks)
 
 // Describes every weight image (PackRec lists on the device) and derives the gradient scatter map: forward-image entry ->
 // flat parameter (masked and padding entries have no source: no gradient).
@@ -918,8 +915,7 @@ static int grad_prepare(wf_model* m) {
         if (rc) return rc;
     }
     m->wave_ok = wave_capable(m);
-    m->wave_eval_ok = wave_capable(m, true);
-    if (m->wave_eval_ok) {
+    if (m->wave_ok) {
         std::vector<float> fk(128, 0.0f), acc(64);
         if (d.layer_kind == WF_LAYER_IMADE && d.n_flow_layers > 0)
             row_factors(WF_SPLINE_I, true, d.i_degree, m->i_nb, m->nbp / 32, m->bc_i_colsum, acc.data(), fk.data());
@@ -929,7 +925,7 @@ static int grad_prepare(wf_model* m) {
         if (rc) return rc;
         WF_HIP(hipMemcpy(m->d_grad_fk, fk.data(), fk.size() * sizeof(float), hipMemcpyHostToDevice));
     }
-    if (m->wave_eval_ok) {
+    if (m->wave_ok) {
         // scratch for the small-batch wave path (tails of up to kWaveEvalMax walkers, first or second order) is reserved here
         // so that those calls never allocate: they can be captured in a hipGraph
         int rc = ensure_scratch(m, kWaveEvalMax * std::max(wave_tail_floats(D, 0), wave_tail_floats(D, 1)));
@@ -1089,7 +1085,7 @@ int wf_model_n_bases(const wf_model* m, int which) {
 int wf_model_set_kernel(wf_model* m, int kernel_kind) {
     if (!m || kernel_kind < WF_KERNEL_AUTO || kernel_kind > WF_KERNEL_WAVE) return WF_ERR_INVALID;
     if (kernel_kind == WF_KERNEL_MFMA && !m->mfma_ok) return WF_ERR_UNSUPPORTED;
-    if (kernel_kind == WF_KERNEL_WAVE && !m->wave_eval_ok) return WF_ERR_UNSUPPORTED;
+    if (kernel_kind == WF_KERNEL_WAVE && !m->wave_ok) return WF_ERR_UNSUPPORTED;
     m->kernel_kind = kernel_kind;
     return WF_OK;
 }
@@ -1163,7 +1159,7 @@ static int dispatch(const wf_model* m, int mode, const float* x, int64_t B, floa
     // which first stages its weight images into LDS, takes 38-42 us whatever the batch; from ~7000 walkers on the MFMA
     // kernel's throughput wins (4096: 30 vs 42 us, 8192: 46 vs 42 us).  The wave kernel does
     // not report bin indices.
-    const bool wave_fits = m->wave_eval_ok && !idx;
+    const bool wave_fits = m->wave_ok && !idx;
     const bool use_wave = wave_fits && (m->kernel_kind == WF_KERNEL_WAVE || (m->kernel_kind == WF_KERNEL_AUTO && B <= kWaveEvalMax));
     if (m->kernel_kind == WF_KERNEL_WAVE && !use_wave) return WF_ERR_UNSUPPORTED;
     if (use_wave) {
@@ -1287,7 +1283,7 @@ int wf_hamiltonian_fwd(const wf_model* m, const float* x_dev, int64_t B, const f
     if (rc) return rc;
     if (n_protons < 0 || n_protons > 8 || (n_protons > 0 && !protons_host)) return WF_ERR_INVALID;
     if (m->desc.prior_kind != WF_PRIOR_WAVEFLOW) return WF_ERR_INVALID;
-    if (!m->wave_eval_ok || !m->d_tabP3 || !m->d_grad_fk) return WF_ERR_UNSUPPORTED;
+    if (!m->wave_ok || !m->d_tabP3 || !m->d_grad_fk) return WF_ERR_UNSUPPORTED;
     if (m->desc.n_flow_layers > 0 && m->desc.layer_kind != WF_LAYER_IMADE) return WF_ERR_UNSUPPORTED;
     Protons pr{};
     pr.n = n_protons;
@@ -1456,7 +1452,7 @@ static int adam_from_sweep(wf_model* m, const wf_train_state* st, const float* g
 
 int64_t wf_vqmc_train_step_workspace_bytes(const wf_model* m, int64_t batch) {
     if (!m || batch < 1) return WF_ERR_INVALID;
-    if (!m->d_grad_map || !m->grad_psi_ok || !m->wave_ok || batch > kWaveSampleMax) return WF_ERR_UNSUPPORTED;   // (wave_ok: ungated, wave sampler)
+    if (!m->d_grad_map || !m->grad_psi_ok || !m->wave_ok || batch > kWaveSampleMax) return WF_ERR_UNSUPPORTED;
     return align256(batch * m->desc.n_dim * 4) + align256(batch * 4) + align256(m->n_params * 4) + 256 + align256(block_sums_ws_bytes(batch)) +
            vjp_ws_bytes(m, batch, true);
 }
@@ -1487,9 +1483,9 @@ int wf_vqmc_train_step(wf_model* m, const wf_train_state* st, uint64_t seed, int
                                 exact_sampler, counter, stream);
     if (rc) return rc;
     // mean local energy and its gradient under the custom tangent rule, running average from the device scalar
-    int split = 0;
+    int split = 0;   // (gated heads: no deferred gather -- the flat gradient gets its zero_params entries, Adam reads it)
     rc = run_vjp_chunks(m, 2, true, x, batch, nullptr, nullptr, &pr, 0.0f, 1.0f / (float)batch, e_loc, grad, p, vjp_bytes, stream,
-                        st->running_average_dev, &split);
+                        st->running_average_dev, m->z_rows ? nullptr : &split);
     if (rc) return rc;
     rc = adam_from_sweep(m, st, grad, split, step_size, b1, b2, eps, stream);
     if (rc) return rc;
@@ -1524,7 +1520,7 @@ int wf_vqmc_train_step_local(wf_model* m, const wf_train_state* st, uint64_t see
     if (rc) return rc;
     int split = 0;
     rc = run_vjp_chunks(m, 2, true, x, batch_local, nullptr, nullptr, &pr, 0.0f, inv_global_batch, e_loc, grad, p, vjp_bytes, stream,
-                        st->running_average_dev, &split);
+                        st->running_average_dev, m->z_rows ? nullptr : &split);
     if (rc) return rc;
     const int64_t n_img = plain_fwd_floats(D, m->nbp) * (int64_t)m->nets.size();
     rc = launch_pack_reduce_buffer(m->d_grad_partial, split, n_img, m->d_grad_map, grad, m->n_params, reduce_dev, stream);
@@ -1536,7 +1532,7 @@ int wf_vqmc_train_step_apply(wf_model* m, const wf_train_state* st, const double
                              void* stream) {
     if (!m || !st || !reduce_dev) return WF_ERR_INVALID;
     if (!st->params_dev || !st->m_dev || !st->v_dev || !st->counter_dev || !st->loss_ring_dev || st->ring_len < 1) return WF_ERR_INVALID;
-    if (!m->d_grad_map || m->z_rows) return WF_ERR_UNSUPPORTED;
+    if (!m->d_grad_map) return WF_ERR_UNSUPPORTED;
     DeviceGuard g(m->device);
     int rc = launch_adam_reduced(st->params_dev, reduce_dev, st->m_dev, st->v_dev, m->n_params, step_size, b1, b2, eps,
                                  (const unsigned long long*)st->counter_dev, stream);
@@ -1548,7 +1544,7 @@ int wf_vqmc_train_step_apply(wf_model* m, const wf_train_state* st, const double
 
 int64_t wf_mle_train_step_workspace_bytes(const wf_model* m, int64_t N) {
     if (!m || N < 1) return WF_ERR_INVALID;
-    if (!m->d_grad_map || m->z_rows) return WF_ERR_UNSUPPORTED;   // (gated heads: the step's Adam reads the weight images only)
+    if (!m->d_grad_map) return WF_ERR_UNSUPPORTED;
     return align256(N * 4) + align256(m->n_params * 4) + 256 + align256(block_sums_ws_bytes(N)) + vjp_ws_bytes(m, N, false);
 }
 
@@ -1567,7 +1563,8 @@ int wf_mle_train_step(wf_model* m, const wf_train_state* st, const float* x_dev,
     const int64_t vjp_bytes = workspace_bytes - (p - (char*)workspace_dev);
     // loss = -mean log_pdf (benchmark_tests.py:84-87): value from the forward sweep, gradient from the reverse sweep
     int split = 0;
-    int rc = run_vjp_chunks(m, 3, false, x_dev, N, nullptr, nullptr, nullptr, 0.0f, -1.0f / (float)N, lp, grad, p, vjp_bytes, stream, nullptr, &split);
+    int rc = run_vjp_chunks(m, 3, false, x_dev, N, nullptr, nullptr, nullptr, 0.0f, -1.0f / (float)N, lp, grad, p, vjp_bytes, stream, nullptr,
+                            m->z_rows ? nullptr : &split);
     if (rc) return rc;
     rc = adam_from_sweep(m, st, grad, split, step_size, b1, b2, eps, stream);
     if (rc) return rc;
