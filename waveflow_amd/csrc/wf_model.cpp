@@ -779,7 +779,7 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
     const int n_nets = (int)m->nets.size();
     const int consts = 64 * nbk + nbk * nbk * 1024;
     const int net_floats = mfma_net_floats(D, nbk);
-    const int64_t lds_cap = 160 * 1024 / 4;   // floats
+    const int64_t lds_cap = 160 * 1024 / 4 - 64;   // floats (the kernel also holds a few bytes of static LDS: its tile counter)
     int staged;
     if ((int64_t)consts + (int64_t)net_floats * n_nets <= lds_cap) staged = 0;        // every net resident
     else if ((int64_t)consts + net_floats <= lds_cap) staged = 1;                     // one slot, re-staged per chunk
