@@ -635,29 +635,30 @@ def test_wavefunction_with_derivative_constraints_energy_and_gradients():
     assert rel_l2(got, want) < 2e-3, rel_l2(got, want)
 
 
-@pytest.mark.parametrize("D", [2, 3])
-def test_gated_wavefunction_energy_vs_autograd_oracle(D):
+@pytest.mark.parametrize("D,knots", [(2, 23), (3, 23), (2, 33), (4, 23)])
+def test_gated_wavefunction_energy_vs_autograd_oracle(D, knots):
     """wavefunctions.Waveflow with its own default set_nn_output_grad_to_zero=True (gated layers and prior): psi, H psi and the Laplacian
     from the wave forward sweep (the gate prod_{i<d} x_i^3 travels as a jet) against the torch oracle with the same four lines of
-    model_factory.py:64-67; also through the R3 directional sweep (WF_ENERGY_R3)."""
+    model_factory.py:64-67; also through the R3 directional sweep (WF_ENERGY_R3).  33 knots: the 64-row layouts (two row blocks per
+    dimension); D = 4: the MFMA kernel's staged mode."""
     import os
     import torch
     from oracle import energy_torch as et
     from waveflow_amd import flatten_params, flows, model_factory, wavefunctions
     mt = model_factory.get_masked_transform
     init = wavefunctions.Waveflow(
-        flows.Serial(flows.BoxTransformLayer(3.0), *(flows.IMADE(mt(), 6, 23, 0.05, 1e-6, set_nn_output_grad_to_zero=True), flows.Reverse()) * 2),
-        mt(allow_negative_params=True), 6, 23, constraints_dict_left={0: 0}, constraints_dict_right={0: 0},
+        flows.Serial(flows.BoxTransformLayer(3.0), *(flows.IMADE(mt(), 6, knots, 0.05, 1e-6, set_nn_output_grad_to_zero=True), flows.Reverse()) * 2),
+        mt(allow_negative_params=True), 6, knots, constraints_dict_left={0: 0}, constraints_dict_right={0: 0},
         constrained_dimension_indices_left=list(range(D - 1)))
     params, psi, log_pdf, _ = init(6, D)
     flat = flatten_params(params)
-    mo = et.TorchWaveflow(D, 2, "mean", 3.0, 6, 23, 0.05, tuple(range(D - 1)), dtype=torch.float64, i_gate=True, p_gate=True)
-    x = sorted_walkers(96, D, 2.7, 17)
+    mo = et.TorchWaveflow(D, 2, "mean", 3.0, 6, knots, 0.05, tuple(range(D - 1)), dtype=torch.float64, i_gate=True, p_gate=True)
+    x = sorted_walkers(96 if D < 4 else 48, D, 2.7, 17)
     m = psi.model
     m.ensure_params(params)
     pr = [0.0] * D
     ho, po, lo = et.hamiltonian(mo, flat, x.astype(np.float64), pr)
-    for kernel in ("scalar", "wave"):
+    for kernel in ("scalar", "wave", "mfma"):
         m.set_kernel(kernel)
         np.testing.assert_allclose(psi(params, x), po, rtol=0, atol=3e-5 * np.abs(po).max())
     m.set_kernel("auto")
@@ -672,13 +673,13 @@ def test_gated_wavefunction_energy_vs_autograd_oracle(D):
         del os.environ["WF_ENERGY_R3"]
     np.testing.assert_allclose(lap3, lo, rtol=0, atol=3e-3 * np.abs(lo).max())
     # the ungated model with the same parameters has another Laplacian: the gate is not a no-op
-    mo0 = et.TorchWaveflow(D, 2, "mean", 3.0, 6, 23, 0.05, tuple(range(D - 1)), dtype=torch.float64)
+    mo0 = et.TorchWaveflow(D, 2, "mean", 3.0, 6, knots, 0.05, tuple(range(D - 1)), dtype=torch.float64)
     assert np.abs(et.hamiltonian(mo0, flat, x.astype(np.float64), pr)[2] - lo).max() > 1e-2 * np.abs(lo).max()
     # ---- reverse sweep: the gate's adjoint reaches x (through prod x_i^3) and the zero_params leaves get their gradient
     g = np.random.default_rng(3)
     w1, w2 = g.normal(size=len(x)).astype(np.float32), g.normal(size=len(x)).astype(np.float32)
     is_zero = zero_leaf_mask(params)
-    assert is_zero.sum() == (2 * (6 + 23) + (6 + 23 - 1)) * D
+    assert is_zero.sum() == (2 * (6 + knots) + (6 + knots - 1)) * D
     for wl in (np.zeros_like(w2), 0.1 * w2):          # psi only (first-order ring for the Laplacian weight 0 too), psi + Laplacian
         got = m.psi_vjp(x, w1, wl).cpu().numpy().astype(np.float64)
         want = et.psi_vjp(mo, flat, x.astype(np.float64), w1, wl)

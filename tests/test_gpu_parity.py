@@ -301,22 +301,24 @@ def test_mflow_and_flow_density_heads_vs_oracle(golden, kernel):
     chk(log_pdf(params, X), om, params)
 
 
+@pytest.mark.parametrize("D,knots", [(2, 16), (3, 34)])
 @pytest.mark.parametrize("kernel", KERNELS_ALL)
-def test_general_boundary_constraint_dicts(kernel):
+def test_general_boundary_constraint_dicts(kernel, D, knots):
     """tests/test_boundary_constraints.py:30-31 style dicts: {0:0, 2:0, 3:0} left, {0:0} right on the prior.  Every kernel: the
-    table-driven ones (mfma, wave) carry the boundary map in their tables (wf_model.cpp: bc_map)."""
+    table-driven ones (mfma, wave) carry the boundary map in their tables (wf_model.cpp: bc_map).  (3, 34): three particles, 39 / 38 bases (the orthogonalisation needs an even number of B bases, ortho_splines.py:61-63)
+    per dimension, i.e. the two-row-block layouts."""
     from waveflow_amd import flows, model_factory, wavefunctions, flatten_params
     mt = model_factory.get_masked_transform
     left, right = {0: 0, 2: 0, 3: 0}, {0: 0, 1: 0}
     init = wavefunctions.Waveflow(
-        flows.Serial(flows.BoxTransformLayer(2.0), flows.IMADE(mt(), 5, 16, 0.01, 1e-6, {0: 0.0, 1: 0.0}, {0: 1.0, 1: 0.0}), flows.Reverse()),
-        mt(allow_negative_params=True), 5, 16, constraints_dict_left=left, constraints_dict_right=right,
-        constrained_dimension_indices_left=[0], set_nn_output_grad_to_zero=False)
-    params, psi, log_pdf, _ = init(5, 2)
+        flows.Serial(flows.BoxTransformLayer(2.0), flows.IMADE(mt(), 5, knots, 0.01, 1e-6, {0: 0.0, 1: 0.0}, {0: 1.0, 1: 0.0}), flows.Reverse()),
+        mt(allow_negative_params=True), 5, knots, constraints_dict_left=left, constraints_dict_right=right,
+        constrained_dimension_indices_left=list(range(D - 1)), set_nn_output_grad_to_zero=False)
+    params, psi, log_pdf, _ = init(5, D)
     log_pdf.model.set_kernel(kernel)     # (no skip: a kernel that refuses this model fails the test)
-    om = oracle.Model(D=2, n_layers=1, box="mean", box_L=2.0, i_k=5, i_knots=16, i_reg=0.01, i_left={0: 0.0, 1: 0.0},
-                      i_right={0: 1.0, 1: 0.0}, prior="waveflow", p_k=5, p_knots=16, p_left=left, p_right=right, constr_left=(0,))
-    x = sorted_walkers(20000, 2, 2.0, 9)
+    om = oracle.Model(D=D, n_layers=1, box="mean", box_L=2.0, i_k=5, i_knots=knots, i_reg=0.01, i_left={0: 0.0, 1: 0.0},
+                      i_right={0: 1.0, 1: 0.0}, prior="waveflow", p_k=5, p_knots=knots, p_left=left, p_right=right, constr_left=tuple(range(D - 1)))
+    x = sorted_walkers(20000, D, 2.0, 9)
     flat = flatten_params(params)
     # A random-init toy (one layer, 16 knots on a box of 2).  On THIS model the MFMA kernel is measurably less accurate than fp32 arithmetic,
     # with zero-only dictionaries as much as with these (scratch/bc_diag.py, 20 000 walkers: outside 1e-5 relative 441 - 475 vs the fp32
