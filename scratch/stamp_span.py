@@ -19,3 +19,6 @@ for slot in range(W // 4):
 fin = (t1 - start).reshape(-1)
 print("  finish time percentiles 1/25/50/75/99/100: " + " ".join("%.0f" % v for v in np.percentile(fin, [1, 25, 50, 75, 99, 100])))
 print("  per workgroup: last finish - first finish: mean %.0f cycles; workgroup finish (max) mean %.0f, max over workgroups %.0f" % ((t1.max(1) - t1.min(1)).mean(), (t1.max(1) - start).mean(), (t1.max(1) - start).max()))
+rt = g[..., 3]
+wg_fin = rt.max(1)            # finish of each workgroup, 10 ns ticks
+print("  workgroup finish on the constant clock: spread (max - min) %.1f us, std %.1f us; quartiles rel. to the first: %s us" % ((wg_fin.max() - wg_fin.min()) / 100.0, wg_fin.std() / 100.0, " ".join("%.1f" % ((v - wg_fin.min()) / 100.0) for v in np.percentile(wg_fin, [25, 50, 75, 90, 99]))))

@@ -851,8 +851,10 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
 #ifdef WF_STAMP
     if (mm.dbg && lane == 0) {
         unsigned long long* g = reinterpret_cast<unsigned long long*>(mm.dbg) + ((size_t)blockIdx.x * kWaves + wave) * 8;
-#ifdef WF_STAMP_SPAN   // absolute start / finish of the wave's tile loop and its number of iterations
+#ifdef WF_STAMP_SPAN   // absolute start / finish of the wave's tile loop and its number of iterations; [3]: finish on the 100 MHz
+        // constant clock (s_memrealtime), which unlike s_memtime is comparable between workgroups on different XCDs
         g[0] = stamp_t0; g[1] = stamp_last; g[2] = (unsigned long long)stamp_iter;
+        { unsigned long long rt_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_)::"memory"); g[3] = rt_; }
 #else
         for (int k = 0; k < 8; ++k) g[k] = stamp_acc[k];
 #endif
