@@ -21,7 +21,7 @@ def main():
         o = os.path.join(B.OBJ, s + ".o")
         if s in units:
             o = os.path.join(out_dir, f"{name}_{s}.o")
-            cmd = [B._hipcc()] + B.FLAGS + (B.MFMA_FLAGS if "mfma" in s else []) + flags + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", os.path.join(B.CSRC, s), "-o", o]
+            cmd = [B._hipcc()] + B.FLAGS + (B.MFMA_FLAGS if ("mfma" in s or "etile" in s) else []) + flags + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", os.path.join(B.CSRC, s), "-o", o]
             if "--save-temps" in os.environ.get("WF_VARIANT_OPTS", ""):
                 cmd += ["-save-temps=obj"]
             subprocess.run(cmd, check=True, cwd=out_dir)

@@ -11,7 +11,7 @@ OBJ = os.path.join(CSRC, "_obj")
 
 SOURCES = ["wf_tables.cpp", "wf_model.cpp", "wf_kernels_scalar.hip", "wf_scalar_inst_d2.hip", "wf_scalar_inst_d3.hip", "wf_scalar_inst_d4.hip", "wf_scalar_inst_d56.hip",
            "wf_scalar_inst_d78.hip", "wf_scalar_inst_n64.hip", "wf_kernels_mfma.hip", "wf_mfma_inst_d2.hip", "wf_mfma_inst_d2t2.hip", "wf_mfma_inst_d34.hip",
-           "wf_mfma_inst_d567.hip", "wf_mfma_inst_d8.hip", "wf_mfma_inst_k2.hip", "wf_kernels_rqs.hip", "wf_kernels_grad.hip", "wf_kernels_wave.hip"]
+           "wf_mfma_inst_d567.hip", "wf_mfma_inst_d8.hip", "wf_mfma_inst_k2.hip", "wf_kernels_rqs.hip", "wf_kernels_grad.hip", "wf_kernels_wave.hip", "wf_kernels_etile.hip"]
 # -ffp-contract=off: the index arithmetic and the table lerp keep the reference's separate
 # multiply / add roundings; dot products that may fuse say so with explicit fmaf / MFMA.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
@@ -29,11 +29,11 @@ def _hipcc():
 
 def _deps(src):
     d = [os.path.join(CSRC, src), os.path.join(CSRC, "wf_internal.h"), os.path.join(HERE, "..", "include", "waveflow_hip.h")]
-    if "mfma" in src:
+    if "mfma" in src or "etile" in src:
         d.append(os.path.join(CSRC, "wf_mfma_impl.h"))
     if "grad" in src or "wave" in src:
         d.append(os.path.join(CSRC, "wf_ring.h"))
-    if "scalar" in src or "wave" in src:   # (the wave sampler shares Philox and the box reverse with the one-lane kernels)
+    if "scalar" in src or "wave" in src or "rqs" in src:   # (the wave sampler shares Philox and the box reverse with the one-lane kernels)
         d.append(os.path.join(CSRC, "wf_scalar_impl.h"))
     return [p for p in d if os.path.exists(p)]
 
@@ -71,7 +71,7 @@ def build(force=False, verbose=False):
     for s in srcs:
         o = os.path.join(OBJ, s + ".o")
         if force or not os.path.exists(o) or any(os.path.getmtime(o) < os.path.getmtime(d) for d in _deps(s)):
-            cmd = [_hipcc()] + FLAGS + (MFMA_FLAGS if "mfma" in s else []) + (["-x", "hip"] if s.endswith(".cpp") else [])
+            cmd = [_hipcc()] + FLAGS + (MFMA_FLAGS if ("mfma" in s or "etile" in s) else []) + (["-x", "hip"] if s.endswith(".cpp") else [])
             cmd += ["-c", os.path.join(CSRC, s), "-o", o]
             jobs.append(cmd)
 

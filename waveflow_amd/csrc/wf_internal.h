@@ -141,6 +141,10 @@ struct Protons {
     float pos[8];
     int n;
 };
+// local energy of large batches on the matrix cores (wf_kernels_etile.hip): D = 2, <= 32 bases, mean box, IMADE + Waveflow prior, ungated
+int64_t energy_tile_floats(int64_t B);
+int launch_energy_tile(const MfmaDev* mdev, const ModelDev& md, const float* tabI4, const float* tabP4, const float* fk_nat, const float* x, int64_t B,
+                       const Protons& pr, float* hpsi, float* psi, float* lap, float* ws, void* stream);
 // The sweeps run over a coefficient ring (wf_ring.h).  kind 0: R1 (first order); 1: R3 (one sample per walker and direction,
 // 3 coefficients); 2: RF<K> (one sample per walker and block of K directions, K + 2 coefficients); 3: RF<D> (one sample per walker).
 // The taped sweeps use kind 2 with K = D up to 5 coordinates; beyond, the 8..10 live floats per value of RF<D> spill hundreds of registers

@@ -1,0 +1,465 @@
+// wf_kernels_etile.hip -- local energy of large batches on the matrix cores (gfx950).
+//
+// H psi = -1/2 laplacian(psi) + V psi (physics.py:50-52, 79-93) needs psi with its gradient and Laplacian with respect to the walker's
+// coordinates.  The wave kernels (wf_kernels_wave.hip) carry that (value, gradient, Laplacian / 2) jet through the model with one wave per
+// walker; their conditioner products are LDS-fed GEMVs.  For large batches of the two-particle family this file splits the work by what
+// the hardware is good at, one launch pair per conditioner net:
+//
+//   k_etile_cond   32 walkers per wave tile, the conditioner of ONE net on the matrix cores: the jet's four channels are four extra
+//                  column groups of the same split-fp16 MFMA products k_mfma issues (the weight operand is shared: mfma_step<4>), the
+//                  activations r(x) = 1 / (2^x + 1) propagate the jet on the VALU.  Derivative channels are unbounded, fp16 is not: every
+//                  (walker, channel) column is scaled by a power of two around each product (exact).  Output: the head's pre-activation
+//                  jets, [row][channel][walker] in HBM (for the prior: already multiplied by ob_to_b).
+//   k_etile_flow / k_etile_prior   one LANE per walker: sigmoid head, normalisations, table lerps of derivative orders 0..3 and the
+//                  log-determinant as jet arithmetic in registers; row sums are sequential loops (no cross-lane traffic), the walker
+//                  index is the fastest-moving one of every array (coalesced).
+//
+// State between launches (SoA, walker fastest): u_0, u_1, log det as jets; 12 floats per walker.  Jet traffic through HBM: 2 x 512 B per
+// walker and net.  Same function as k_wave_fwd<2, RF<2>> + k_energy_out (same derivative rule of the table lerp: order nd -> table nd + 1),
+// checked against it and against the torch oracle (tests/test_gpu_energy.py).  Coverage: D = 2, <= 32 bases, mean-type box, IMADE layers,
+// Waveflow prior, ungated heads (every homogeneous boundary dictionary: the tables carry the map); everything else stays on the wave kernel.
+#include "wf_mfma_impl.h"
+
+namespace wf {
+
+namespace {
+using namespace mfma;
+
+struct J {   // value, d/dx0, d/dx1, laplacian / 2
+    float v, a, b, h;
+};
+__device__ __forceinline__ J jc(float c) { return J{c, 0.0f, 0.0f, 0.0f}; }
+__device__ __forceinline__ J operator+(J x, J y) { return J{x.v + y.v, x.a + y.a, x.b + y.b, x.h + y.h}; }
+__device__ __forceinline__ J operator-(J x, J y) { return J{x.v - y.v, x.a - y.a, x.b - y.b, x.h - y.h}; }
+__device__ __forceinline__ J operator+(J x, float c) { return J{x.v + c, x.a, x.b, x.h}; }
+__device__ __forceinline__ J operator*(J x, float c) { return J{x.v * c, x.a * c, x.b * c, x.h * c}; }
+__device__ __forceinline__ J operator*(J x, J y) {
+    return J{x.v * y.v, x.v * y.a + y.v * x.a, x.v * y.b + y.v * x.b, x.v * y.h + y.v * x.h + (x.a * y.a + x.b * y.b)};
+}
+// f(x) from f, f', f'' at x.v
+__device__ __forceinline__ J japply(J x, float f, float f1, float f2) {
+    return J{f, f1 * x.a, f1 * x.b, f1 * x.h + 0.5f * f2 * (x.a * x.a + x.b * x.b)};
+}
+__device__ __forceinline__ J jrcp(J x) { const float f = 1.0f / x.v; return japply(x, f, -f * f, 2.0f * f * f * f); }
+__device__ __forceinline__ J jlog(J x) { const float f1 = 1.0f / x.v; return japply(x, logf(x.v), f1, -f1 * f1); }
+__device__ __forceinline__ J jrsqrt(J x) { const float f = rsqrtf(x.v), q = 1.0f / x.v; return japply(x, f, -0.5f * f * q, 0.75f * f * q * q); }
+__device__ __forceinline__ J jexp_half(J x) { const float f = expf(0.5f * x.v); return japply(x, f, 0.5f * f, 0.25f * f); }
+// r(x) = 1 / (2^x + 1): the activation of the MFMA images (tanh = 1 - 2 r with 2 log2(e) folded into the weights; sigmoid = r with -log2(e))
+__device__ __forceinline__ J jr(J x) {
+    const float r = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x.v) + 1.0f);
+    const float r1 = -0.6931471805599453f * r * (1.0f - r);
+    return japply(x, r, r1, -0.6931471805599453f * r1 * (1.0f - 2.0f * r));
+}
+// table function of a jet argument: value t0, first / second derivative t1 / t2 (the lerps of the next two cached orders)
+__device__ __forceinline__ J jlift(float t0, float t1, float t2, J u) { return japply(u, t0, t1, t2); }
+
+// state arrays: st[(slot * 4 + c) * B + w]
+__device__ __forceinline__ J st_load(const float* __restrict__ st, int slot, int64_t B, int64_t w) {
+    const float* p = st + (int64_t)slot * 4 * B + w;
+    return J{p[0], p[B], p[2 * B], p[3 * B]};
+}
+__device__ __forceinline__ void st_store(float* __restrict__ st, int slot, int64_t B, int64_t w, J x) {
+    float* p = st + (int64_t)slot * 4 * B + w;
+    p[0] = x.v; p[B] = x.a; p[2 * B] = x.b; p[3 * B] = x.h;
+}
+
+#ifndef WF_ETILE_WAVES
+#define WF_ETILE_WAVES 4
+#endif
+constexpr int kCondWaves = WF_ETILE_WAVES;   // 4: one wave per SIMD -- the four channel chains hold ~430 registers (accumulators in AGPRs)
+using O2 = NetOff<2, 1>;
+
+// ---------------------------------------------------------------------------- conditioner of one net, jets on the matrix cores
+// one power of two per (walker, channel) so that the largest of the column's 64 (or 32) entries lies in [0.5, 1)
+__device__ __forceinline__ int col_exponent(float amax) {
+    const float m = xhalf_max(amax);
+    return m > 0.0f ? __builtin_amdgcn_frexp_expf(m) : 0;
+}
+// xs jets of one 32-unit block (4 channels x 16 registers) -> r jets, in place
+__device__ __forceinline__ void act_block(f32x16 (&x)[4]) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float rr = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x[0][r]) + 1.0f);
+        const float r1 = -0.6931471805599453f * rr * (1.0f - rr);
+        const float r2 = -0.6931471805599453f * r1 * (1.0f - 2.0f * rr);
+        const float g0 = x[1][r], g1 = x[2][r], hh = x[3][r];
+        x[0][r] = rr;
+        x[1][r] = r1 * g0;
+        x[2][r] = r1 * g1;
+        x[3][r] = __builtin_fmaf(r1, hh, 0.5f * r2 * __builtin_fmaf(g0, g0, g1 * g1));
+    }
+}
+// two blocks of r jets -> B fragments of the next layer, derivative channels scaled by 2^-e[c] (e[0] = 0: r lies in (0, 1))
+__device__ __forceinline__ void to_frags(const f32x16 (&blk0)[4], const f32x16 (&blk1)[4], Frag (&f)[4][2], int (&e)[4]) {
+    e[0] = 0;
+#pragma unroll
+    for (int c = 1; c < 4; ++c) {
+        float amax = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) amax = fmaxf(amax, fmaxf(fabsf(blk0[c][r]), fabsf(blk1[c][r])));
+        e[c] = col_exponent(amax);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float sc = __builtin_amdgcn_ldexpf(1.0f, -e[c]);
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float r8[8];
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) r8[jj] = (ob == 0 ? blk0[c][8 * s + jj] : blk1[c][8 * s + jj]) * sc;
+                split8(r8, f[c][ob].hi[s], f[c][ob].lo[s]);
+            }
+    }
+}
+__device__ __forceinline__ void unscale(f32x16 (&acc)[4], const int (&e)[4]) {
+#pragma unroll
+    for (int c = 1; c < 4; ++c) {
+        const float sc = __builtin_amdgcn_ldexpf(1.0f, e[c]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = acc[c][r] * sc;
+    }
+}
+__device__ __forceinline__ void init_acc(f32x16 (&acc)[4], const float* bias16) {
+    acc[0] = load16(bias16);
+#pragma unroll
+    for (int c = 1; c < 4; ++c) acc[c] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+}
+
+template <bool PRIOR>
+__global__ __launch_bounds__(kCondWaves * 64) void k_etile_cond(const MfmaDev mm, int net_index, const float* __restrict__ st, int64_t B,
+                                                                float* __restrict__ oj, float* __restrict__ s1buf) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ int next_tile;
+    constexpr int kThreads = kCondWaves * 64;
+    if (threadIdx.x == 0) next_tile = 0;
+    stage_floats<kThreads>(mm.image + mm.const_img_off, lds, mm.const_floats);
+    stage_floats<kThreads>(mm.image + (size_t)net_index * mm.net_floats, lds + mm.const_floats, mm.net_floats);
+    __syncthreads();
+    const float* net = lds + mm.const_floats;
+    const float* fkP = lds + 32;
+    const _Float16* obh = reinterpret_cast<const _Float16*>(lds + 64);
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 31, h = lane >> 5;
+    const int64_t n_tiles = (B + 31) >> 5;
+    // this workgroup's tiles: blockIdx.x, blockIdx.x + gridDim.x, ... handed to its waves through a counter (oldest-wave-first arbitration)
+    const int64_t my_tiles = n_tiles > (int64_t)blockIdx.x ? (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    for (;;) {
+        int q = 0;
+        if (lane == 0) q = __hip_atomic_fetch_add(&next_tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        q = __builtin_amdgcn_readfirstlane(q);
+        if (q >= my_tiles) break;
+        const int64_t tile = (int64_t)blockIdx.x + (int64_t)q * gridDim.x;
+        const int64_t w = tile * 32 + j;
+        const bool valid = w < B;
+        const int64_t wl = valid ? w : B - 1;
+        const J u0 = st_load(st, 0, B, wl), u1 = st_load(st, 1, B, wl);
+        const float in0[4] = {u0.v, u0.a, u0.b, u0.h}, in1[4] = {u1.v, u1.a, u1.b, u1.h};
+        // ---- layer 1 (f32 MFMA, K = 2: the two coordinates), both 32-unit blocks
+        f32x16 a0[4], a1[4];
+        init_acc(a0, net + O2::b0 + (0 * 2 + h) * 16);
+        init_acc(a1, net + O2::b0 + (1 * 2 + h) * 16);
+        {
+            const float w0 = net[O2::W0 + 0 * 64 + lane], w1 = net[O2::W0 + 1 * 64 + lane];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                a0[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, h ? in1[c] : in0[c], a0[c], 0, 0, 0);
+                a1[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, h ? in1[c] : in0[c], a1[c], 0, 0, 0);
+            }
+        }
+        act_block(a0);
+        act_block(a1);
+        Frag f[4][2];
+        int e[4];
+        to_frags(a0, a1, f, e);
+        // ---- layer 2
+        const _Float16* W1h = reinterpret_cast<const _Float16*>(net + O2::W1h);
+        const _Float16* W1l = reinterpret_cast<const _Float16*>(net + O2::W1l);
+        init_acc(a0, net + O2::b1 + (0 + h) * 16);
+        init_acc(a1, net + O2::b1 + (2 + h) * 16);
+        dense64_block<4>(W1h, W1l, f, a0, lane);
+        dense64_block<4>(W1h + 2048, W1l + 2048, f, a1, lane);
+        unscale(a0, e);
+        unscale(a1, e);
+        act_block(a0);
+        act_block(a1);
+        to_frags(a0, a1, f, e);
+        // ---- output block of dimension 1 (dimension 0 is table-driven: k_prepare_dim0)
+        const _Float16* W2h = reinterpret_cast<const _Float16*>(net + O2::W2h);
+        const _Float16* W2l = reinterpret_cast<const _Float16*>(net + O2::W2l);
+        init_acc(a0, net + O2::b2 + (1 * 2 + h) * 16);
+        dense64_block<4>(W2h, W2l, f, a0, lane);
+        unscale(a0, e);
+        if (PRIOR) {
+            // w = o * keep (jets); c = w @ ob_to_b on the matrix cores, every channel scaled (the head is unbounded); sum of the raw
+            // outputs for the sign (model_factory.py:69, sign form as in k_mfma)
+            float s1 = 0.0f;
+            const f32x16 keep = load16(fkP + h * 16);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s1 += a0[0][r];
+            s1 = xhalf_sum(s1);
+            if (valid && h == 0) s1buf[w] = s1;
+            Frag of[4];
+            int eo[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float amax = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    a0[c][r] = a0[c][r] * keep[r];
+                    amax = fmaxf(amax, fabsf(a0[c][r]));
+                }
+                eo[c] = col_exponent(amax);
+                const float sc = __builtin_amdgcn_ldexpf(1.0f, -eo[c]);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    float r8[8];
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) r8[jj] = a0[c][8 * s + jj] * sc;
+                    split8(r8, of[c].hi[s], of[c].lo[s]);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                f32x16 acc = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const f16x8 ah = *reinterpret_cast<const f16x8*>(obh + (s * 64 + lane) * 8);
+                    const f16x8 al = *reinterpret_cast<const f16x8*>(obh + 1024 + (s * 64 + lane) * 8);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, of[c].hi[s], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, of[c].lo[s], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, of[c].hi[s], acc, 0, 0, 0);
+                }
+                const float sc = __builtin_amdgcn_ldexpf(1.0f, eo[c]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a0[c][r] = acc[r] * sc;
+            }
+        }
+        // ---- store: oj[(row * 4 + c) * B + w], row = accumulator row of register r in lane half h
+        if (valid) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) oj[((int64_t)row * 4 + c) * B + w] = a0[c][r];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------- lane-per-walker stages
+struct LerpN {
+    int il, ir;
+    float t;
+};
+__device__ __forceinline__ LerpN nlerp(float x, int n_mesh) {
+    const Lerp L = make_lerp(x, n_mesh, 1.0f / (float)(n_mesh - 1), 1);
+    return LerpN{L.il, L.ir, L.t};
+}
+
+// BoxTransformLayer, mean type, two particles (made.py:156-183) as jets of (x0, x1)
+__global__ void k_etile_box(const float* __restrict__ xg, int64_t B, float L, float* __restrict__ st) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float tol = 1e-7f;
+    const J x0 = J{xg[b * 2], 1.0f, 0.0f, 0.0f}, x1 = J{xg[b * 2 + 1], 0.0f, 1.0f, 0.0f};
+    const J mean = (x0 + x1) * 0.5f;
+    const J l = mean - x0, wd = x1 - x0;
+    J ld = jc(0.0f);
+    const J space = jc(2 * L);
+    const J diff = x1 - x0;
+    const J u0 = diff * jrcp(space + tol);
+    ld = ld - jlog(space + tol);
+    const J den = (jc(2 * L) - wd) + tol;
+    const J u1 = ((mean + L) - l) * jrcp(den);
+    ld = ld - jlog(den);
+    st_store(st, 0, B, b, u0);
+    st_store(st, 1, B, b, u1);
+    st_store(st, 2, B, b, ld);
+}
+
+// One IMADE layer behind its conditioner (made.py:66-81) + Reverse: dimension 0 from the composite table, dimension 1 from the head jets
+__global__ __launch_bounds__(256) void k_etile_flow(const float4_t* __restrict__ comp /* this net: [n_mesh] {Y, Y', Y'', Y'''} */,
+                                                    const float* __restrict__ tabI /* [4][n_mesh][32] */, const float* __restrict__ gI, int nb,
+                                                    int n_mesh, float reg, const float* __restrict__ oj, int64_t B, float* __restrict__ st) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const J u0 = st_load(st, 0, B, b), u1 = st_load(st, 1, B, b);
+    J ld = st_load(st, 2, B, b);
+    // ---- dimension 0
+    J y0;
+    {
+        const LerpN L = nlerp(u0.v, n_mesh);
+        const float4_t ca = comp[L.il], cb = comp[L.ir];
+        const float t0 = __builtin_fmaf(cb.x - ca.x, L.t, ca.x), t1 = __builtin_fmaf(cb.y - ca.y, L.t, ca.y);
+        const float t2 = __builtin_fmaf(cb.z - ca.z, L.t, ca.z), t3 = __builtin_fmaf(cb.w - ca.w, L.t, ca.w);
+        y0 = jlift(t0, t1, t2, u0);
+        ld = ld + jlog(jlift(t1, t2, t3, u0) + 1e-7f);
+    }
+    // ---- dimension 1: c_j = g_j (v_j / S0 + reg) / Q (calculate_bijection_params, + reg, remove_bias, boundary map: wf_model.cpp).
+    // One pass over the rows: with V_k = sum_j v_j g_j B^(k)_j, R_k = sum_j g_j B^(k)_j, Qv = sum_j v_j g_j, G = sum_j g_j, S0 = sum_j v_j the
+    // numerators are N_k = V_k / S0 + reg R_k and the normaliser Q = Qv / S0 + reg G.  Four rows per step: the lane's table rows come as
+    // 16-byte loads (8 per step: 4 orders x the two mesh rows; rows >= nb are zero padding).
+    const LerpN L = nlerp(u1.v, n_mesh);
+    const size_t plane = (size_t)n_mesh * 32;
+    const float* rl = tabI + (size_t)L.il * 32;
+    const float* rr = tabI + (size_t)L.ir * 32;
+    J S0 = jc(0.0f), V0 = jc(0.0f), V1 = jc(0.0f), Qv = jc(0.0f);
+    float r0[3] = {0.0f, 0.0f, 0.0f}, r1[3] = {0.0f, 0.0f, 0.0f}, G = 0.0f;   // sum_j g_j t_j^(k), k = 0..2 and 1..3: R_k = lift of them
+    for (int j0 = 0; j0 < nb; j0 += 4) {
+        float4_t ta[4], tb[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            ta[k] = *reinterpret_cast<const float4_t*>(rl + k * plane + j0);
+            tb[k] = *reinterpret_cast<const float4_t*>(rr + k * plane + j0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int jr_ = j0 + q;
+            if (jr_ >= nb) break;
+            const float* p = oj + (int64_t)jr_ * 4 * B + b;
+            const J v = jr(J{p[0], p[B], p[2 * B], p[3 * B]});
+            const float g = gI[jr_];
+            float t[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float a = q == 0 ? ta[k].x : (q == 1 ? ta[k].y : (q == 2 ? ta[k].z : ta[k].w));
+                const float bb = q == 0 ? tb[k].x : (q == 1 ? tb[k].y : (q == 2 ? tb[k].z : tb[k].w));
+                t[k] = __builtin_fmaf(bb - a, L.t, a) * g;   // g_j folded into the row
+            }
+            S0 = S0 + v;
+            Qv = Qv + v * g;
+            V0 = V0 + v * jlift(t[0], t[1], t[2], u1);
+            V1 = V1 + v * jlift(t[1], t[2], t[3], u1);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { r0[k] += t[k]; r1[k] += t[k + 1]; }
+            G += g;
+        }
+    }
+    const J rS0 = jrcp(S0);
+    const J N0 = V0 * rS0 + jlift(r0[0], r0[1], r0[2], u1) * reg;
+    const J N1 = V1 * rS0 + jlift(r1[0], r1[1], r1[2], u1) * reg;
+    const J Q = Qv * rS0 + reg * G;
+    const J rQ = jrcp(Q);
+    const J y1 = N0 * rQ;
+    ld = ld + jlog(N1 * rQ + 1e-7f);
+    st_store(st, 0, B, b, y1);   // Reverse (bijections.py:337-340)
+    st_store(st, 1, B, b, y0);
+    st_store(st, 2, B, b, ld);
+}
+
+// Waveflow prior (wavefunctions.py:54-71) + H psi (physics.py:60-93)
+__global__ __launch_bounds__(256) void k_etile_prior(const float4_t* __restrict__ comp /* prior: {P, P', P''} with sign and norm */,
+                                                     const float* __restrict__ tabP /* [4][n_mesh][32] orthogonal B */, int nb, int n_mesh,
+                                                     unsigned constrained_mask, const float* __restrict__ oj, const float* __restrict__ s1buf,
+                                                     const float* __restrict__ st, const float* __restrict__ xg, int64_t B, const Protons pr,
+                                                     float* __restrict__ hpsi, float* __restrict__ psi_out, float* __restrict__ lap_out) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const J u0 = st_load(st, 0, B, b), u1 = st_load(st, 1, B, b), ld = st_load(st, 2, B, b);
+    // the spline sees the clipped coordinate (:45): outside [0, 1] it is a constant
+    const J uc0 = (u0.v < 0.0f) ? jc(0.0f) : (u0.v > 1.0f ? jc(1.0f) : u0);
+    const J uc1 = (u1.v < 0.0f) ? jc(0.0f) : (u1.v > 1.0f ? jc(1.0f) : u1);
+    J val0;
+    {
+        const LerpN L = nlerp(uc0.v, n_mesh);
+        const float4_t ca = comp[L.il], cb = comp[L.ir];
+        val0 = jlift(__builtin_fmaf(cb.x - ca.x, L.t, ca.x), __builtin_fmaf(cb.y - ca.y, L.t, ca.y), __builtin_fmaf(cb.z - ca.z, L.t, ca.z), uc0);
+    }
+    const LerpN L = nlerp(uc1.v, n_mesh);
+    const size_t plane = (size_t)n_mesh * 32;
+    const float* rl = tabP + (size_t)L.il * 32;
+    const float* rr = tabP + (size_t)L.ir * 32;
+    J N2 = jc(0.0f), dot = jc(0.0f);
+    for (int i0 = 0; i0 < nb; i0 += 4) {
+        float4_t ta[3], tb[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            ta[k] = *reinterpret_cast<const float4_t*>(rl + k * plane + i0);
+            tb[k] = *reinterpret_cast<const float4_t*>(rr + k * plane + i0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = i0 + q;
+            if (i >= nb) break;
+            const float* p = oj + (int64_t)i * 4 * B + b;
+            const J c = J{p[0], p[B], p[2 * B], p[3 * B]};
+            float t[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float a = q == 0 ? ta[k].x : (q == 1 ? ta[k].y : (q == 2 ? ta[k].z : ta[k].w));
+                const float bb = q == 0 ? tb[k].x : (q == 1 ? tb[k].y : (q == 2 ? tb[k].z : tb[k].w));
+                t[k] = __builtin_fmaf(bb - a, L.t, a);
+            }
+            N2 = N2 + c * c;
+            dot = dot + c * jlift(t[0], t[1], t[2], uc1);
+        }
+    }
+    const float sgn = s1buf[b] < 0.0f ? -1.0f : 1.0f;
+    const J val1 = (dot * jrsqrt(N2)) * sgn;
+    const float sc0 = (constrained_mask & 1u) ? 0.70710678118654752f : 1.0f, sc1 = (constrained_mask & 2u) ? 0.70710678118654752f : 1.0f;
+    const J psi = ((val0 * sc0) * (val1 * sc1)) * jexp_half(ld);
+    const float lap = 2.0f * psi.h;
+    float V = 0.0f;   // physics.py:60-76
+    for (int p = 0; p < pr.n; ++p)
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const float r = pr.pos[p] - xg[b * 2 + d];
+            V -= 1.0f / sqrtf(1.0f + r * r);
+        }
+    {
+        const float r = xg[b * 2 + 1] - xg[b * 2];
+        V += 1.0f / sqrtf(1.0f + r * r);
+    }
+    hpsi[b] = -0.5f * lap + V * psi.v;
+    if (psi_out) psi_out[b] = psi.v;
+    if (lap_out) lap_out[b] = lap;
+}
+
+int check() {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_hip_error((int)e);
+        return WF_ERR_HIP;
+    }
+    return WF_OK;
+}
+
+}  // namespace
+
+// workspace: state (12 floats), head jets (128 floats), the sign sum (1 float) per walker
+int64_t energy_tile_floats(int64_t B) { return B * (12 + 128 + 1); }
+
+// mdev: the model's MFMA description (resident or not: one net is staged per launch); md: ModelDev on the host (spline sizes, masks)
+int launch_energy_tile(const MfmaDev* mdev, const ModelDev& md, const float* tabI4, const float* tabP4, const float* fk_nat, const float* x, int64_t B,
+                       const Protons& pr, float* hpsi, float* psi, float* lap, float* ws, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (B == 0) return WF_OK;
+    float* st = ws;
+    float* oj = st + 12 * B;
+    float* s1 = oj + 128 * B;
+    const unsigned lane_blocks = (unsigned)((B + 255) / 256);
+    const int lds_bytes = (mdev->const_floats + mdev->net_floats) * (int)sizeof(float);
+    static int configured = -1;
+    if (lds_bytes > configured) {
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_etile_cond<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_etile_cond<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e1 != hipSuccess || e2 != hipSuccess) { set_hip_error((int)(e1 != hipSuccess ? e1 : e2)); return WF_ERR_HIP; }
+        configured = lds_bytes;
+    }
+    const int64_t n_tiles = (B + 31) / 32;
+    const unsigned cond_blocks = (unsigned)std::min<int64_t>((n_tiles + kCondWaves - 1) / kCondWaves, 256 * 4);
+    hipLaunchKernelGGL(k_etile_box, dim3(lane_blocks), dim3(256), 0, s, x, B, md.box_L, st);
+    for (int l = 0; l < md.n_layers; ++l) {
+        hipLaunchKernelGGL(k_etile_cond<false>, dim3(cond_blocks), dim3(kCondWaves * 64), lds_bytes, s, *mdev, l, (const float*)st, B, oj, s1);
+        hipLaunchKernelGGL(k_etile_flow, dim3(lane_blocks), dim3(256), 0, s, mdev->comp + (size_t)l * mdev->n_mesh, tabI4, fk_nat, md.isp.nb,
+                           md.isp.n_mesh, md.i_reg, (const float*)oj, B, st);
+    }
+    hipLaunchKernelGGL(k_etile_cond<true>, dim3(cond_blocks), dim3(kCondWaves * 64), lds_bytes, s, *mdev, md.n_layers, (const float*)st, B, oj, s1);
+    hipLaunchKernelGGL(k_etile_prior, dim3(lane_blocks), dim3(256), 0, s, mdev->comp + (size_t)md.n_layers * mdev->n_mesh, tabP4, md.psp.nb,
+                       md.psp.n_mesh, md.constrained_mask, (const float*)oj, (const float*)s1, (const float*)st, x, B, pr, hpsi, psi, lap);
+    return check();
+}
+
+}  // namespace wf

@@ -139,12 +139,20 @@ __global__ void k_prepare_dim0(const ModelDev* __restrict__ mdp, int nm, const f
         const SplineDev& sp = md.psp;
         const int nb = sp.nb, nbp = sp.nbp;
         out[0] = (c[64] < 0.0f ? -row_dot(tab_p + (size_t)m * nbp, c, nb) : row_dot(tab_p + (size_t)m * nbp, c, nb)) * __builtin_amdgcn_rsqf(c[65]);
+        // derivative orders 1, 2 with the same sign and norm: the jet of psi_0 (local energy on the matrix cores, wf_kernels_etile.hip)
+        const float sn = (c[64] < 0.0f ? -1.0f : 1.0f) * __builtin_amdgcn_rsqf(c[65]);
+        out[1] = row_dot(tab_p + ((size_t)sp.n_mesh + m) * nbp, c, nb) * sn;
+        out[2] = row_dot(tab_p + ((size_t)2 * sp.n_mesh + m) * nbp, c, nb) * sn;
     } else {
         const SplineDev& sp = is_prior ? md.psp : md.isp;
         const float* __restrict__ tab = is_prior ? tab_p : tab_i;
         const int nb = sp.nb, nbp = sp.nbp;
         out[0] = row_dot(tab + (size_t)m * nbp, c, nb) * c[64];
-        if (!is_prior) out[1] = row_dot(tab + ((size_t)sp.n_mesh + m) * nbp, c, nb) * c[64];
+        if (!is_prior) {
+            out[1] = row_dot(tab + ((size_t)sp.n_mesh + m) * nbp, c, nb) * c[64];
+            out[2] = row_dot(tab + ((size_t)2 * sp.n_mesh + m) * nbp, c, nb) * c[64];   // orders 2, 3: jets of y_0 and of log dy_0
+            out[3] = row_dot(tab + ((size_t)3 * sp.n_mesh + m) * nbp, c, nb) * c[64];
+        }
     }
     comp[gid] = out;
 }

@@ -258,6 +258,7 @@ static int wave_passes(int D, int nbp) { return nbp == 32 ? (D + 1) / 2 : D; }  
 static int ensure_scratch(const wf_model* cm, int64_t floats);
 static constexpr int kTapedLaplacianMaxD = 8;    // largest D whose reverse sweep runs in RF (measured, scratch/grad_ab.py)
 static constexpr int64_t kWaveEvalMax = 6144;   // measured crossover ~7000 walkers (scratch/crossover.py)
+static constexpr int64_t kEnergyTileMin = 16384; // H psi: the tile path (8 launches, staged weight images) from here on
 namespace wf {
 
 // layer_kind WF_LAYER_NSC: Flow(Serial((NeuralSplineCoupling [, Reverse]) x L), Normal | Uniform)
@@ -1292,6 +1293,26 @@ int wf_hamiltonian_fwd(const wf_model* m, const float* x_dev, int64_t B, const f
     if (B == 0) return WF_OK;
     const int D = m->desc.n_dim;
     const int64_t chunk = std::min<int64_t>(B, (int64_t)1 << 20);
+    // Large batches of the two-particle family: conditioner jets on the matrix cores + lane-per-walker heads (wf_kernels_etile.hip).
+    // WF_ENERGY_TILE_MIN (read per call) moves the switch point; 0 disables the path.
+    {
+        const char* e = getenv("WF_ENERGY_TILE_MIN");
+        const int64_t tile_min = e ? atoll(e) : kEnergyTileMin;
+        const wf_model_desc& d = m->desc;
+        const bool family = D == 2 && m->nbp == 32 && m->mfma_ok && d.box_kind == WF_BOX_MEAN && d.layer_kind == WF_LAYER_IMADE &&
+                            d.n_flow_layers > 0 && !m->dev.i_gate && !m->dev.p_gate && !getenv("WF_ENERGY_R3");
+        if (family && tile_min > 0 && B >= tile_min) {
+            rc = ensure_scratch(m, energy_tile_floats(chunk));
+            if (rc) return rc;
+            for (int64_t c0 = 0; c0 < B; c0 += chunk) {
+                const int64_t bc = std::min(chunk, B - c0);
+                rc = launch_energy_tile(&m->mdev, m->dev, m->d_tabI4, m->d_tabP3, m->d_grad_fk, x_dev + c0 * D, bc, pr, hpsi_dev + c0,
+                                        psi_dev ? psi_dev + c0 : nullptr, laplacian_dev ? laplacian_dev + c0 : nullptr, m->d_scratch, stream);
+                if (rc) return rc;
+            }
+            return WF_OK;
+        }
+    }
     rc = ensure_scratch(m, chunk * wave_tail_floats(D, 1));
     if (rc) return rc;
     for (int64_t c0 = 0; c0 < B; c0 += chunk) {
