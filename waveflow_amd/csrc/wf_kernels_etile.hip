@@ -281,7 +281,7 @@ __global__ void k_etile_box(const float* __restrict__ xg, int64_t B, float L, fl
 
 // One IMADE layer behind its conditioner (made.py:66-81) + Reverse: dimension 0 from the composite table, dimension 1 from the head jets
 __global__ __launch_bounds__(256) void k_etile_flow(const float4_t* __restrict__ comp /* this net: [n_mesh] {Y, Y', Y'', Y'''} */,
-                                                    const float* __restrict__ tabI /* [4][n_mesh][32] */, const float* __restrict__ gI, int nb,
+                                                    const float* __restrict__ tabI /* [n_mesh][8 row chunks][4 orders][4 rows] */, const float* __restrict__ gI, int nb,
                                                     int n_mesh, float reg, const float* __restrict__ oj, int64_t B, float* __restrict__ st) {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
@@ -302,17 +302,16 @@ __global__ __launch_bounds__(256) void k_etile_flow(const float4_t* __restrict__
     // numerators are N_k = V_k / S0 + reg R_k and the normaliser Q = Qv / S0 + reg G.  Four rows per step: the lane's table rows come as
     // 16-byte loads (8 per step: 4 orders x the two mesh rows; rows >= nb are zero padding).
     const LerpN L = nlerp(u1.v, n_mesh);
-    const size_t plane = (size_t)n_mesh * 32;
-    const float* rl = tabI + (size_t)L.il * 32;
-    const float* rr = tabI + (size_t)L.ir * 32;
+    const float4_t* rl = reinterpret_cast<const float4_t*>(tabI + (size_t)L.il * 128);   // [8 chunks][4 orders] float4
+    const float4_t* rr = reinterpret_cast<const float4_t*>(tabI + (size_t)L.ir * 128);
     J S0 = jc(0.0f), V0 = jc(0.0f), V1 = jc(0.0f), Qv = jc(0.0f);
     float r0[3] = {0.0f, 0.0f, 0.0f}, r1[3] = {0.0f, 0.0f, 0.0f}, G = 0.0f;   // sum_j g_j t_j^(k), k = 0..2 and 1..3: R_k = lift of them
     for (int j0 = 0; j0 < nb; j0 += 4) {
         float4_t ta[4], tb[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            ta[k] = *reinterpret_cast<const float4_t*>(rl + k * plane + j0);
-            tb[k] = *reinterpret_cast<const float4_t*>(rr + k * plane + j0);
+            ta[k] = rl[j0 + k];     // (chunk j0 / 4) * 4 + k
+            tb[k] = rr[j0 + k];
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -351,7 +350,7 @@ __global__ __launch_bounds__(256) void k_etile_flow(const float4_t* __restrict__
 
 // Waveflow prior (wavefunctions.py:54-71) + H psi (physics.py:60-93)
 __global__ __launch_bounds__(256) void k_etile_prior(const float4_t* __restrict__ comp /* prior: {P, P', P''} with sign and norm */,
-                                                     const float* __restrict__ tabP /* [4][n_mesh][32] orthogonal B */, int nb, int n_mesh,
+                                                     const float* __restrict__ tabP /* orthogonal B, [n_mesh][8][4][4] like tabI */, int nb, int n_mesh,
                                                      unsigned constrained_mask, const float* __restrict__ oj, const float* __restrict__ s1buf,
                                                      const float* __restrict__ st, const float* __restrict__ xg, int64_t B, const Protons pr,
                                                      float* __restrict__ hpsi, float* __restrict__ psi_out, float* __restrict__ lap_out) {
@@ -368,16 +367,15 @@ __global__ __launch_bounds__(256) void k_etile_prior(const float4_t* __restrict_
         val0 = jlift(__builtin_fmaf(cb.x - ca.x, L.t, ca.x), __builtin_fmaf(cb.y - ca.y, L.t, ca.y), __builtin_fmaf(cb.z - ca.z, L.t, ca.z), uc0);
     }
     const LerpN L = nlerp(uc1.v, n_mesh);
-    const size_t plane = (size_t)n_mesh * 32;
-    const float* rl = tabP + (size_t)L.il * 32;
-    const float* rr = tabP + (size_t)L.ir * 32;
+    const float4_t* rl = reinterpret_cast<const float4_t*>(tabP + (size_t)L.il * 128);
+    const float4_t* rr = reinterpret_cast<const float4_t*>(tabP + (size_t)L.ir * 128);
     J N2 = jc(0.0f), dot = jc(0.0f);
     for (int i0 = 0; i0 < nb; i0 += 4) {
         float4_t ta[3], tb[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            ta[k] = *reinterpret_cast<const float4_t*>(rl + k * plane + i0);
-            tb[k] = *reinterpret_cast<const float4_t*>(rr + k * plane + i0);
+            ta[k] = rl[i0 + k];
+            tb[k] = rr[i0 + k];
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {

@@ -86,6 +86,10 @@ struct wf_model {
     void* d_comp = nullptr;          // composite tables [n_nets][n_mesh] float4
     const float* d_tabI4 = nullptr;  // [4][n_mesh][nbp]: I-spline derivative orders 0..3 (local energy)
     const float* d_tabP3 = nullptr;  // [4][n_mesh][nbp]: orthogonal-B derivative orders 0..3 (the energy uses 0..2)
+    // the same two tables regrouped for the lane-per-walker heads of wf_kernels_etile.hip (nbp == 32 only): [n_mesh][8 row chunks][4 orders][4 rows],
+    // so that the four orders of four rows of one mesh point are one 64-byte segment
+    const float* d_tabI4c = nullptr;
+    const float* d_tabP4c = nullptr;
     float* d_flat = nullptr;         // staging copy of a host parameter vector (wf_model_set_params)
     wf::PackRec* d_pack = nullptr;   // descriptions of every entry of the plain, wave and mfma images
     int64_t n_pack = 0;
@@ -251,6 +255,15 @@ static int upload_table(wf_model* m, const std::vector<float>& h, const float** 
 }
 
 static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::vector<double>& p64, const std::vector<double>& o2b);
+// [4][n_mesh][32] -> [n_mesh][8][4][4] (see d_tabI4c)
+static int upload_chunked(wf_model* m, const std::vector<float>& rows4, int n_mesh, const float** out) {
+    std::vector<float> c((size_t)n_mesh * 128);
+    for (int mm = 0; mm < n_mesh; ++mm)
+        for (int ch = 0; ch < 8; ++ch)
+            for (int k = 0; k < 4; ++k)
+                for (int q = 0; q < 4; ++q) c[(((size_t)mm * 8 + ch) * 4 + k) * 4 + q] = rows4[((size_t)k * n_mesh + mm) * 32 + 4 * ch + q];
+    return upload_table(m, c, out);
+}
 static int grad_prepare(wf_model* m);
 static int64_t wave_net_floats(int D, int nbp);
 static int wave_passes(int D, int nbp) { return nbp == 32 ? (D + 1) / 2 : D; }   // output passes: 2 dimensions x 32 rows, or 1 x 64
@@ -360,6 +373,10 @@ static int model_build(wf_model* m) {
             pack_rows(t64, nb, d.n_mesh, 4, m->nbp, rows4);
             rc = upload_table(m, rows4, &m->d_tabI4);
             if (rc) return rc;
+            if (m->nbp == 32) {
+                rc = upload_chunked(m, rows4, d.n_mesh, &m->d_tabI4c);
+                if (rc) return rc;
+            }
         }
         m->i_nb = nb;
         keep_i64.swap(t64);
@@ -387,6 +404,10 @@ static int model_build(wf_model* m) {
             pack_rows(ob64, nb, d.n_mesh, 4, m->nbp, rows3);
             rc = upload_table(m, rows3, &m->d_tabP3);
             if (rc) return rc;
+            if (m->nbp == 32) {
+                rc = upload_chunked(m, rows3, d.n_mesh, &m->d_tabP4c);
+                if (rc) return rc;
+            }
         }
         fill_bc(md.psp, d.p_left, d.p_right, b64, nb, d.n_mesh);  // BCs use the plain-B table, bsplines_jax.py:176-189
         std::vector<float> o2b32((size_t)m->nbp * m->nbp, 0.0f);   // full [nbp][nbp]: the wave kernels contract over all 32 rows
@@ -1300,13 +1321,13 @@ int wf_hamiltonian_fwd(const wf_model* m, const float* x_dev, int64_t B, const f
         const int64_t tile_min = e ? atoll(e) : kEnergyTileMin;
         const wf_model_desc& d = m->desc;
         const bool family = D == 2 && m->nbp == 32 && m->mfma_ok && d.box_kind == WF_BOX_MEAN && d.layer_kind == WF_LAYER_IMADE &&
-                            d.n_flow_layers > 0 && !m->dev.i_gate && !m->dev.p_gate && !getenv("WF_ENERGY_R3");
+                            d.n_flow_layers > 0 && !m->dev.i_gate && !m->dev.p_gate && m->d_tabI4c && m->d_tabP4c && !getenv("WF_ENERGY_R3");
         if (family && tile_min > 0 && B >= tile_min) {
             rc = ensure_scratch(m, energy_tile_floats(chunk));
             if (rc) return rc;
             for (int64_t c0 = 0; c0 < B; c0 += chunk) {
                 const int64_t bc = std::min(chunk, B - c0);
-                rc = launch_energy_tile(&m->mdev, m->dev, m->d_tabI4, m->d_tabP3, m->d_grad_fk, x_dev + c0 * D, bc, pr, hpsi_dev + c0,
+                rc = launch_energy_tile(&m->mdev, m->dev, m->d_tabI4c, m->d_tabP4c, m->d_grad_fk, x_dev + c0 * D, bc, pr, hpsi_dev + c0,
                                         psi_dev ? psi_dev + c0 : nullptr, laplacian_dev ? laplacian_dev + c0 : nullptr, m->d_scratch, stream);
                 if (rc) return rc;
             }
