@@ -5,16 +5,19 @@
 // walker; their conditioner products are LDS-fed GEMVs.  For large batches of the two-particle family this file splits the work by what
 // the hardware is good at, one launch pair per conditioner net:
 //
-//   k_etile_cond   32 walkers per wave tile, the conditioner of ONE net on the matrix cores: the jet's four channels are four extra
-//                  column groups of the same split-fp16 MFMA products k_mfma issues (the weight operand is shared: mfma_step<4>), the
-//                  activations r(x) = 1 / (2^x + 1) propagate the jet on the VALU.  Derivative channels are unbounded, fp16 is not: every
+//   k_etile_cond   32 walkers per wave tile, the conditioner of ONE net on the matrix cores.  With two particles the MADE masks leave the
+//                  conditioner ONE input (hidden degrees arange(64) % (D - 1) = 0: model_factory.py:15): every hidden and output unit is a
+//                  function of the scalar u_0, so what travels is its Taylor triple (f, f', f'') in u_0 -- three channels = three extra
+//                  column groups of the same split-fp16 MFMA products k_mfma issues (the weight operand is shared: mfma_step<3>); the
+//                  activations r(x) = 1 / (2^x + 1) propagate the triple on the VALU.  Derivative channels are unbounded, fp16 is not: every
 //                  (walker, channel) column is scaled by a power of two around each product (exact).  Output: the head's pre-activation
-//                  jets, [row][channel][walker] in HBM (for the prior: already multiplied by ob_to_b).
+//                  triples, [row][channel][walker] in HBM (for the prior: already multiplied by ob_to_b); the head kernels turn them into
+//                  jets in (x0, x1) with the chain rule through the jet of u_0.
 //   k_etile_flow / k_etile_prior   one LANE per walker: sigmoid head, normalisations, table lerps of derivative orders 0..3 and the
 //                  log-determinant as jet arithmetic in registers; row sums are sequential loops (no cross-lane traffic), the walker
 //                  index is the fastest-moving one of every array (coalesced).
 //
-// State between launches (SoA, walker fastest): u_0, u_1, log det as jets; 12 floats per walker.  Jet traffic through HBM: 2 x 512 B per
+// State between launches (SoA, walker fastest): u_0, u_1, log det as jets; 12 floats per walker.  Head triples through HBM: 2 x 384 B per
 // walker and net.  Same function as k_wave_fwd<2, RF<2>> + k_energy_out (same derivative rule of the table lerp: order nd -> table nd + 1),
 // checked against it and against the torch oracle (tests/test_gpu_energy.py).  Coverage: D = 2, <= 32 bases, mean-type box, IMADE layers,
 // Waveflow prior, ungated heads (every homogeneous boundary dictionary: the tables carry the map); everything else stays on the wave kernel.
@@ -24,6 +27,7 @@ namespace wf {
 
 namespace {
 using namespace mfma;
+constexpr int NCH = 3;   // channels of the conditioner: (f, df/du0, d2f/du0^2)
 
 struct J {   // value, d/dx0, d/dx1, laplacian / 2
     float v, a, b, h;
@@ -75,32 +79,31 @@ __device__ __forceinline__ int col_exponent(float amax) {
     const float m = xhalf_max(amax);
     return m > 0.0f ? __builtin_amdgcn_frexp_expf(m) : 0;
 }
-// xs jets of one 32-unit block (4 channels x 16 registers) -> r jets, in place
-__device__ __forceinline__ void act_block(f32x16 (&x)[4]) {
+// (x, x', x'') of one 32-unit block (3 channels x 16 registers) -> (r, r' x', r' x'' + r'' x'^2), in place
+__device__ __forceinline__ void act_block(f32x16 (&x)[NCH]) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const float rr = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x[0][r]) + 1.0f);
         const float r1 = -0.6931471805599453f * rr * (1.0f - rr);
         const float r2 = -0.6931471805599453f * r1 * (1.0f - 2.0f * rr);
-        const float g0 = x[1][r], g1 = x[2][r], hh = x[3][r];
+        const float x1 = x[1][r], x2 = x[2][r];
         x[0][r] = rr;
-        x[1][r] = r1 * g0;
-        x[2][r] = r1 * g1;
-        x[3][r] = __builtin_fmaf(r1, hh, 0.5f * r2 * __builtin_fmaf(g0, g0, g1 * g1));
+        x[1][r] = r1 * x1;
+        x[2][r] = __builtin_fmaf(r1, x2, r2 * (x1 * x1));
     }
 }
 // two blocks of r jets -> B fragments of the next layer, derivative channels scaled by 2^-e[c] (e[0] = 0: r lies in (0, 1))
-__device__ __forceinline__ void to_frags(const f32x16 (&blk0)[4], const f32x16 (&blk1)[4], Frag (&f)[4][2], int (&e)[4]) {
+__device__ __forceinline__ void to_frags(const f32x16 (&blk0)[NCH], const f32x16 (&blk1)[NCH], Frag (&f)[NCH][2], int (&e)[NCH]) {
     e[0] = 0;
 #pragma unroll
-    for (int c = 1; c < 4; ++c) {
+    for (int c = 1; c < NCH; ++c) {
         float amax = 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) amax = fmaxf(amax, fmaxf(fabsf(blk0[c][r]), fabsf(blk1[c][r])));
         e[c] = col_exponent(amax);
     }
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < NCH; ++c) {
         const float sc = __builtin_amdgcn_ldexpf(1.0f, -e[c]);
 #pragma unroll
         for (int ob = 0; ob < 2; ++ob)
@@ -113,18 +116,18 @@ __device__ __forceinline__ void to_frags(const f32x16 (&blk0)[4], const f32x16 (
             }
     }
 }
-__device__ __forceinline__ void unscale(f32x16 (&acc)[4], const int (&e)[4]) {
+__device__ __forceinline__ void unscale(f32x16 (&acc)[NCH], const int (&e)[NCH]) {
 #pragma unroll
-    for (int c = 1; c < 4; ++c) {
+    for (int c = 1; c < NCH; ++c) {
         const float sc = __builtin_amdgcn_ldexpf(1.0f, e[c]);
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[c][r] = acc[c][r] * sc;
     }
 }
-__device__ __forceinline__ void init_acc(f32x16 (&acc)[4], const float* bias16) {
+__device__ __forceinline__ void init_acc(f32x16 (&acc)[NCH], const float* bias16) {
     acc[0] = load16(bias16);
 #pragma unroll
-    for (int c = 1; c < 4; ++c) acc[c] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int c = 1; c < NCH; ++c) acc[c] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 }
 
 template <bool PRIOR>
@@ -154,32 +157,33 @@ __global__ __launch_bounds__(kCondWaves * 64) void k_etile_cond(const MfmaDev mm
         const int64_t w = tile * 32 + j;
         const bool valid = w < B;
         const int64_t wl = valid ? w : B - 1;
-        const J u0 = st_load(st, 0, B, wl), u1 = st_load(st, 1, B, wl);
-        const float in0[4] = {u0.v, u0.a, u0.b, u0.h}, in1[4] = {u1.v, u1.a, u1.b, u1.h};
-        // ---- layer 1 (f32 MFMA, K = 2: the two coordinates), both 32-unit blocks
-        f32x16 a0[4], a1[4];
+        // the conditioner's inputs: (u_0, u_1) values; the Taylor seed in u_0 is (u_0, 1, 0) (u_1 reaches no hidden unit: masked weights)
+        const float u0v = st[wl], u1v = st[(int64_t)4 * B + wl];
+        const float in0[2] = {u0v, 1.0f}, in1[2] = {u1v, 0.0f};
+        // ---- layer 1 (f32 MFMA, K = 2: the two coordinates), both 32-unit blocks; the second-derivative channel starts at zero
+        f32x16 a0[NCH], a1[NCH];
         init_acc(a0, net + O2::b0 + (0 * 2 + h) * 16);
         init_acc(a1, net + O2::b0 + (1 * 2 + h) * 16);
         {
             const float w0 = net[O2::W0 + 0 * 64 + lane], w1 = net[O2::W0 + 1 * 64 + lane];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < 2; ++c) {
                 a0[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, h ? in1[c] : in0[c], a0[c], 0, 0, 0);
                 a1[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, h ? in1[c] : in0[c], a1[c], 0, 0, 0);
             }
         }
         act_block(a0);
         act_block(a1);
-        Frag f[4][2];
-        int e[4];
+        Frag f[NCH][2];
+        int e[NCH];
         to_frags(a0, a1, f, e);
         // ---- layer 2
         const _Float16* W1h = reinterpret_cast<const _Float16*>(net + O2::W1h);
         const _Float16* W1l = reinterpret_cast<const _Float16*>(net + O2::W1l);
         init_acc(a0, net + O2::b1 + (0 + h) * 16);
         init_acc(a1, net + O2::b1 + (2 + h) * 16);
-        dense64_block<4>(W1h, W1l, f, a0, lane);
-        dense64_block<4>(W1h + 2048, W1l + 2048, f, a1, lane);
+        dense64_block<NCH>(W1h, W1l, f, a0, lane);
+        dense64_block<NCH>(W1h + 2048, W1l + 2048, f, a1, lane);
         unscale(a0, e);
         unscale(a1, e);
         act_block(a0);
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(kCondWaves * 64) void k_etile_cond(const MfmaDev mm
         const _Float16* W2h = reinterpret_cast<const _Float16*>(net + O2::W2h);
         const _Float16* W2l = reinterpret_cast<const _Float16*>(net + O2::W2l);
         init_acc(a0, net + O2::b2 + (1 * 2 + h) * 16);
-        dense64_block<4>(W2h, W2l, f, a0, lane);
+        dense64_block<NCH>(W2h, W2l, f, a0, lane);
         unscale(a0, e);
         if (PRIOR) {
             // w = o * keep (jets); c = w @ ob_to_b on the matrix cores, every channel scaled (the head is unbounded); sum of the raw
@@ -200,10 +204,10 @@ __global__ __launch_bounds__(kCondWaves * 64) void k_etile_cond(const MfmaDev mm
             for (int r = 0; r < 16; ++r) s1 += a0[0][r];
             s1 = xhalf_sum(s1);
             if (valid && h == 0) s1buf[w] = s1;
-            Frag of[4];
-            int eo[4];
+            Frag of[NCH];
+            int eo[NCH];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < NCH; ++c) {
                 float amax = 0.0f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(kCondWaves * 64) void k_etile_cond(const MfmaDev mm
                 }
             }
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < NCH; ++c) {
                 f32x16 acc = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
@@ -236,13 +240,13 @@ __global__ __launch_bounds__(kCondWaves * 64) void k_etile_cond(const MfmaDev mm
                 for (int r = 0; r < 16; ++r) a0[c][r] = acc[r] * sc;
             }
         }
-        // ---- store: oj[(row * 4 + c) * B + w], row = accumulator row of register r in lane half h
+        // ---- store: oj[(row * 3 + c) * B + w], row = accumulator row of register r in lane half h
         if (valid) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) oj[((int64_t)row * 4 + c) * B + w] = a0[c][r];
+                for (int c = 0; c < NCH; ++c) oj[((int64_t)row * NCH + c) * B + w] = a0[c][r];
             }
         }
     }
@@ -317,8 +321,8 @@ __global__ __launch_bounds__(256) void k_etile_flow(const float4_t* __restrict__
         for (int q = 0; q < 4; ++q) {
             const int jr_ = j0 + q;
             if (jr_ >= nb) break;
-            const float* p = oj + (int64_t)jr_ * 4 * B + b;
-            const J v = jr(J{p[0], p[B], p[2 * B], p[3 * B]});
+            const float* p = oj + (int64_t)jr_ * NCH * B + b;
+            const J v = jr(japply(u0, p[0], p[B], p[2 * B]));     // the head's triple in u_0 -> jet in (x0, x1)
             const float g = gI[jr_];
             float t[4];
 #pragma unroll
@@ -381,8 +385,8 @@ __global__ __launch_bounds__(256) void k_etile_prior(const float4_t* __restrict_
         for (int q = 0; q < 4; ++q) {
             const int i = i0 + q;
             if (i >= nb) break;
-            const float* p = oj + (int64_t)i * 4 * B + b;
-            const J c = J{p[0], p[B], p[2 * B], p[3 * B]};
+            const float* p = oj + (int64_t)i * NCH * B + b;
+            const J c = japply(u0, p[0], p[B], p[2 * B]);        // (the conditioner sees the unclipped u_0, wavefunctions.py:40)
             float t[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -426,8 +430,8 @@ int check() {
 
 }  // namespace
 
-// workspace: state (12 floats), head jets (128 floats), the sign sum (1 float) per walker
-int64_t energy_tile_floats(int64_t B) { return B * (12 + 128 + 1); }
+// workspace: state (12 floats), head triples (96 floats), the sign sum (1 float) per walker
+int64_t energy_tile_floats(int64_t B) { return B * (12 + 32 * NCH + 1); }
 
 // mdev: the model's MFMA description (resident or not: one net is staged per launch); md: ModelDev on the host (spline sizes, masks)
 int launch_energy_tile(const MfmaDev* mdev, const ModelDev& md, const float* tabI4, const float* tabP4, const float* fk_nat, const float* x, int64_t B,
@@ -436,7 +440,7 @@ int launch_energy_tile(const MfmaDev* mdev, const ModelDev& md, const float* tab
     if (B == 0) return WF_OK;
     float* st = ws;
     float* oj = st + 12 * B;
-    float* s1 = oj + 128 * B;
+    float* s1 = oj + (int64_t)32 * NCH * B;
     const unsigned lane_blocks = (unsigned)((B + 255) / 256);
     const int lds_bytes = (mdev->const_floats + mdev->net_floats) * (int)sizeof(float);
     static int configured = -1;
