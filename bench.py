@@ -436,6 +436,15 @@ def main_vqmc(args):
     n = max(args.steps // 5, 5)
     t_grad = timed(lambda: model.vqmc_loss_grad(x, protons, -1.8), n)
     t_h = timed(lambda: model.hamiltonian(x, protons), n)
+    # H psi at the BASELINE batch (2^20 walkers: config 5's payload per GPU): the matrix-core tile path (wf_kernels_etile.hip, default from
+    # 16 384 walkers on) and, beside it, the wave kernel on the same batch (WF_ENERGY_TILE_MIN=0)
+    xb = walkers(1 << 20, 4321).cuda()
+    for _ in range(20):
+        model.hamiltonian(xb, protons)
+    t_h20 = timed(lambda: model.hamiltonian(xb, protons), 20)
+    os.environ["WF_ENERGY_TILE_MIN"] = "0"
+    t_h20_wave = timed(lambda: model.hamiltonian(xb, protons), 3)
+    del os.environ["WF_ENERGY_TILE_MIN"]
     # the dominant kernel of the gradient, timed with events
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
     for a, b in ev:
@@ -456,7 +465,10 @@ def main_vqmc(args):
         "ms_per_step": t_grad * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"1D He (shipped checkpoint): loss_fn_efficient + gradient over {B} walkers (vqmc.py:193-221); also H psi and "
                                "whole training steps at batch 128", "walkers": B},
-        "hpsi_walkers_per_s": B / t_h, "train_steps_per_s_batch128": 1.0 / t_train, "train_ms_per_step_batch128": t_train * 1e3,
+        "hpsi_walkers_per_s": B / t_h,
+        "hpsi_2pow20": {"walkers_per_s": (1 << 20) / t_h20, "ms": t_h20 * 1e3, "kernels": "k_etile_cond<*> x 4 + k_etile_flow x 3 + k_etile_prior + k_etile_box",
+                        "wave_kernel_walkers_per_s": (1 << 20) / t_h20_wave},
+        "train_steps_per_s_batch128": 1.0 / t_train, "train_ms_per_step_batch128": t_train * 1e3,
         "roofline": {"bound": "valu", "achieved": B * VQMC_BWD_FLOP_PER_WALKER / (VQMC_BWD_SHARE * step_ms * 1e-3) / 1e12, "peak": PEAK_F32_MATRIX_TFLOPS,
                      "unit": "TFLOP/s", "frac": B * VQMC_BWD_FLOP_PER_WALKER / (VQMC_BWD_SHARE * step_ms * 1e-3) / 1e12 / PEAK_F32_MATRIX_TFLOPS,
                      "traffic": None, "kernel": "k_wave_bwd<2, RF<2>>", "kernel_ms": VQMC_BWD_SHARE * step_ms,

@@ -137,3 +137,81 @@ def test_laplacian_where_the_prior_output_sum_vanishes():
     assert torch.isfinite(grad).all() and np.isfinite(sums.cpu().numpy()).all()
     el = h / (ps + 1e-8)
     np.testing.assert_allclose(sums.cpu().numpy()[0] / 64, el.astype(np.float64).mean(), rtol=1e-3)
+
+
+def _tile_and_wave(model, x, protons, monkeypatch):
+    """(H psi, psi, laplacian) of x through the matrix-core tile path (forced) and through the wave kernel (tile path disabled)."""
+    out = []
+    for tile_min in ("1", "0"):
+        monkeypatch.setenv("WF_ENERGY_TILE_MIN", tile_min)
+        out.append([np.asarray(t, dtype=np.float64) for t in model.hamiltonian(x, protons, return_psi=True, return_laplacian=True)])
+    monkeypatch.delenv("WF_ENERGY_TILE_MIN")
+    return out
+
+
+def test_local_energy_on_the_matrix_cores_vs_oracle_and_wave_kernel(golden, he_flat, monkeypatch):
+    """wf_hamiltonian_fwd of large two-particle batches: conditioner Taylor channels on the matrix cores + lane-per-walker heads
+    (wf_kernels_etile.hip).  Same yardstick as test_hamiltonian_vs_autograd_oracle for the oracle; against the wave kernel on a large,
+    ragged batch; the switch itself (default threshold, WF_ENERGY_TILE_MIN)."""
+    import torch
+    from oracle import energy_torch as et
+    from waveflow_amd.utils import physics
+    params, psi, log_pdf, sample = he(he_flat)
+    m = psi.model
+    m.ensure_params(params)
+    protons = physics.system_catalogue[1]["He"][0].reshape(-1)
+    x = np.concatenate([np.sort(golden["he_golden"]["sample_points"], -1), sorted_walkers(250, 2, 10.0, 5)]).astype(np.float32)
+    (hp, ps, lap), (hw, pw, lw) = _tile_and_wave(m, x, protons, monkeypatch)
+    ho64, po64, lo64 = et.hamiltonian(et.he_model(torch.float64), he_flat, x.astype(np.float64), protons)
+    ho32, po32, lo32 = et.hamiltonian(et.he_model(torch.float32), he_flat, x, protons)
+    np.testing.assert_allclose(ps, po64, rtol=0, atol=3e-5)
+    scale = np.abs(lo64).max()
+    e_g, e_o = np.abs(lap - lo64), np.abs(lo32 - lo64)
+    assert np.median(e_g) <= 3 * np.median(e_o) + 1e-6 * scale, (np.median(e_g), np.median(e_o))
+    assert e_g.max() <= 6 * e_o.max() + 1e-4 * scale, (e_g.max(), e_o.max(), scale)
+    np.testing.assert_allclose(hp, ho64, rtol=0, atol=6 * np.abs(ho32 - ho64).max() + 1e-4 * np.abs(ho64).max())
+    # a large batch that is not a multiple of the 32-walker tile, walkers up to the box edge (clipped prior arguments included)
+    xb = sorted_walkers(70001, 2, 10.0, 21)
+    (hp, ps, lap), (hw, pw, lw) = _tile_and_wave(m, xb, protons, monkeypatch)
+    assert np.isfinite(hp).all()
+    for a, b in ((ps, pw), (lap, lw), (hp, hw)):
+        d = np.abs(a - b)
+        assert d.max() <= 2e-4 * np.abs(b).max() and np.median(d) <= 1e-7 * np.abs(b).max(), (d.max() / np.abs(b).max(), np.median(d) / np.abs(b).max())
+    # default switch: 70 001 walkers take the tile path (same numbers as forcing it), 5 000 the wave kernel
+    h_default = np.asarray(m.hamiltonian(xb, protons), dtype=np.float64)
+    assert np.array_equal(h_default, hp)
+    h_small = np.asarray(m.hamiltonian(xb[:5000], protons), dtype=np.float64)
+    assert np.array_equal(h_small, hw[:5000])
+
+
+def test_local_energy_tile_path_other_models(monkeypatch):
+    """The tile path on models the He checkpoint does not exercise: derivative boundary constraints (the regrouped tables carry the
+    boundary map), one and two layers, another box and knot count; a model outside the family (first-type box) keeps the wave kernel."""
+    from waveflow_amd import flows, model_factory, wavefunctions
+    mt = model_factory.get_masked_transform
+    il, ir, pl, pr = {0: 0.0, 1: 0.0}, {0: 1.0, 1: 0.0}, {0: 0, 2: 0}, {0: 0, 1: 0}
+    cases = [
+        dict(L=3.0, n=2, k=6, kn=23, il=il, ir=ir, pl=pl, pr=pr),
+        dict(L=2.0, n=1, k=5, kn=16, il={0: 0.0}, ir={0: 1.0}, pl={0: 0}, pr={0: 0}),
+    ]
+    for c in cases:
+        init = wavefunctions.Waveflow(
+            flows.Serial(flows.BoxTransformLayer(c["L"]), *(flows.IMADE(mt(), c["k"], c["kn"], 0.05, 1e-6, c["il"], c["ir"]), flows.Reverse()) * c["n"]),
+            mt(allow_negative_params=True), c["k"], c["kn"], constraints_dict_left=c["pl"], constraints_dict_right=c["pr"],
+            constrained_dimension_indices_left=[0], set_nn_output_grad_to_zero=False)
+        params, psi, log_pdf, _ = init(4, 2)
+        m = psi.model
+        m.ensure_params(params)
+        x = sorted_walkers(4097, 2, 0.95 * c["L"], 13)
+        (hp, ps, lap), (hw, pw, lw) = _tile_and_wave(m, x, [0.0, 0.0], monkeypatch)
+        for a, b in ((ps, pw), (lap, lw), (hp, hw)):
+            d = np.abs(a - b)
+            assert np.isfinite(a).all() and d.max() <= 5e-4 * np.abs(b).max() and np.median(d) <= 1e-6 * np.abs(b).max(), (c, d.max() / np.abs(b).max())
+    # first-type box: not in the family -- forcing the tile path changes nothing
+    init = model_factory.get_waveflow_model(2, n_flow_layers=1, box_size=2, xu_coord_type="first")
+    params, psi, log_pdf, _ = init(1, 2)
+    m = psi.model
+    m.ensure_params(params)
+    x = sorted_walkers(512, 2, 1.9, 3)
+    (hp, _, _), (hw, _, _) = _tile_and_wave(m, x, [0.0, 0.0], monkeypatch)
+    assert np.array_equal(hp, hw)
