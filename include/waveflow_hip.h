@@ -201,8 +201,10 @@ int wf_sample(const wf_model* m, uint64_t seed, int64_t B, float* x_dev, float* 
  * with physics.laplacian (:50-52, trace of jax.hessian -- the table lerp differentiates to the next cached derivative table,
  * isplines_jax.py:60-66) and the one-dimensional soft-Coulomb physics.get_potential (:60-76) for `n_protons` <= 8 protons at
  * `protons_host`.  hpsi_dev[B]; psi_dev[B] and laplacian_dev[B] may be NULL.  The local energy of vqmc.loss_fn_efficient
-  * (vqmc.py:193-200) is hpsi / (psi + 1e-8).  Batches of >= 16384 walkers of two-particle models (<= 32 bases, mean-type box, ungated) run on the
- * matrix cores (wf_kernels_etile.hip; WF_ENERGY_TILE_MIN moves the switch), everything else on the wave-cooperative kernel: same function.  WF_PRIOR_WAVEFLOW models with IMADE layers, homogeneous boundary constraints (every value 0 apart from the I-spline's right {0: 1}), gated heads included;
+ * (vqmc.py:193-200) is hpsi / (psi + 1e-8).  Batches of >= 16384 walkers of two-particle models (<= 32 bases, mean-type box, ungated) run on the
+ * matrix cores (wf_kernels_etile.hip; WF_ENERGY_TILE_MIN moves the switch), everything else on the wave-cooperative kernel: same function.
+ * Coverage: WF_PRIOR_WAVEFLOW models with IMADE layers, homogeneous boundary constraints (every value 0 apart from the I-spline's right
+ * {0: 1}), gated heads included;
  * D = 2..8 with <= 32 bases per dimension, D = 2..4 with 33..64. */
 int wf_hamiltonian_fwd(const wf_model* m, const float* x_dev, int64_t B, const float* protons_host, int32_t n_protons,
                        float* hpsi_dev, float* psi_dev, float* laplacian_dev, void* stream);
