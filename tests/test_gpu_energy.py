@@ -180,6 +180,12 @@ def test_local_energy_on_the_matrix_cores_vs_oracle_and_wave_kernel(golden, he_f
     # default switch: 70 001 walkers take the tile path (same numbers as forcing it), 5 000 the wave kernel
     h_default = np.asarray(m.hamiltonian(xb, protons), dtype=np.float64)
     assert np.array_equal(h_default, hp)
+    # launch after launch the same bits (the conditioner kernel mixes MFMA chains with VALU work like k_mfma: same build rule)
+    import torch
+    xt = torch.as_tensor(sorted_walkers(1 << 18, 2, 10.0, 77)).cuda()
+    first = m.hamiltonian(xt, protons).clone()
+    for _ in range(12):
+        assert torch.equal(m.hamiltonian(xt, protons), first)
     h_small = np.asarray(m.hamiltonian(xb[:5000], protons), dtype=np.float64)
     assert np.array_equal(h_small, hw[:5000])
 
