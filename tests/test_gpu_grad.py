@@ -553,14 +553,28 @@ def test_abi_error_paths_of_the_gradient_entry_points(he_flat):
     om5 = oracle.Model(D=2, n_layers=1, i_k=5, i_knots=15, i_reg=0.0, i_left={0: 0.0, 2: 0.0, 3: 0.0}, i_right={0: 1.0}, prior="mflow", p_k=5,
                        p_knots=15, p_left={0: 0.0, 2: 0.0}, p_right={}, i_gate=True, p_gate=True)
     _directional_check(lp5, p5, om5, X3, seed=13)
-    # a constraint with a non-zero value adds a constant term to the map: the per-walker kernel evaluates it, gradients are not built
-    p4, lp4, _ = model_factory.get_model(n_flow_layers=1, i_constraint_dict_left={0: 0.0, 1: 0.5}, i_constraint_dict_right={0: 1.0})(0, 2)
-    lp4.model.ensure_params(p4)
-    assert np.isfinite(lp4(p4, xs.cpu().numpy())).all()
+    # a constraint with a non-zero value adds a constant term b to the map.  I- and M-spline coefficients reach the constraints normalised
+    # (sum 1), so the table-driven kernels fold b into the linear part (A + b 1^T: wf_model.cpp bc_map), gradients included
+    p4, lp4, _ = model_factory.get_model(n_flow_layers=1, i_constraint_dict_left={0: 0.0, 1: 0.5}, i_constraint_dict_right={0: 1.0, 1: 0.25},
+                                         prior_constraint_dict_left={0: 0.3})(0, 2)
+    om4 = oracle.Model(D=2, n_layers=1, i_k=5, i_knots=15, i_reg=0.0, i_left={0: 0.0, 1: 0.5}, i_right={0: 1.0, 1: 0.25}, prior="mflow", p_k=5,
+                       p_knots=15, p_left={0: 0.3}, p_right={})
+    _directional_check(lp4, p4, om4, X3, seed=14)
+    # the B-spline prior's coefficients carry no normalisation there: the per-walker kernel evaluates such a dictionary, the table-driven
+    # kernels and the gradients refuse it
+    from waveflow_amd import flows, wavefunctions
+    mt = model_factory.get_masked_transform
+    init6 = wavefunctions.Waveflow(flows.Serial(flows.BoxTransformLayer(1.0)), mt(allow_negative_params=True), 5, 16,
+                                   constraints_dict_left={0: 0.1}, constraints_dict_right={0: 0}, constrained_dimension_indices_left=[0],
+                                   set_nn_output_grad_to_zero=False)
+    p6, psi6, lp6, _ = init6(0, 2)
+    lp6.model.ensure_params(p6)
+    x6 = sorted_walkers(8, 2, 1.0, 3)
+    assert np.isfinite(lp6(p6, x6)).all()
     with pytest.raises(_lib.WfError):
-        lp4.model.logpdf_vjp(xs, w)
+        lp6.model.logpdf_vjp(torch.as_tensor(x6).cuda(), w)
     with pytest.raises(_lib.WfError):
-        lp4.model.set_kernel("mfma")
+        lp6.model.set_kernel("mfma")
 
 
 def test_model_without_flow_layers(he_flat):

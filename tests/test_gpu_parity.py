@@ -331,6 +331,30 @@ def test_general_boundary_constraint_dicts(kernel, D, knots):
     as_accurate_as_fp32_reference(psi(params, x), pso, pst, atol=1e-6 * np.abs(pst).max(), **slack)
 
 
+@pytest.mark.parametrize("kernel", KERNELS_ALL)
+def test_boundary_constraints_with_nonzero_values(kernel):
+    """Dictionaries with a non-zero value on the normalised splines (I layers: first derivative 0.5 / 0.25 at the ends, M prior: value 0.3
+    at the left end).  The per-walker kernel runs the literal overwrite sequence (isplines_jax.py:158-194, msplines_jax.py:156-184); the
+    table-driven kernels carry the constant term folded into their tables (wf_model.cpp: bc_map) -- all against the C oracle's literal form."""
+    import os
+    from conftest import GOLDEN
+    from waveflow_amd import model_factory, flatten_params
+    X = np.load(os.path.join(GOLDEN, "circles_x256.npy")).astype(np.float32)
+    il, ir, pl = {0: 0.0, 1: 0.5}, {0: 1.0, 1: 0.25}, {0: 0.3}
+    init = model_factory.get_model(n_flow_layers=2, i_spline_reg=0.02, i_constraint_dict_left=il, i_constraint_dict_right=ir, prior_constraint_dict_left=pl)
+    params, log_pdf, _ = init(4, 2)
+    log_pdf.model.set_kernel(kernel)     # (no skip)
+    om = oracle.Model(D=2, n_layers=2, i_k=5, i_knots=15, i_reg=0.02, i_left=il, i_right=ir, prior="mflow", p_k=5, p_knots=15, p_left=pl, p_right={})
+    f = flatten_params(params)
+    lp, u = log_pdf(params, X, return_sample=True)
+    as_accurate_as_fp32_reference(lp, om.log_pdf(f, X), om.log_pdf(f, X, f64=True))
+    close(u, om.log_pdf(f, X, return_u=True)[1], rtol=0, atol=5e-6)
+    # the constant term matters on this model: the zero-valued dictionaries give another density
+    om0 = oracle.Model(D=2, n_layers=2, i_k=5, i_knots=15, i_reg=0.02, i_left={0: 0.0, 1: 0.0}, i_right={0: 1.0, 1: 0.0}, prior="mflow", p_k=5,
+                       p_knots=15, p_left={0: 0.0}, p_right={})
+    assert np.abs(om0.log_pdf(f, X, f64=True) - om.log_pdf(f, X, f64=True)).max() > 1e-2
+
+
 @pytest.mark.parametrize("kernel", KERNELS)
 def test_full_size_properties(he_flat, kernel):
     """BASELINE size (2^20 walkers): properties that need no oracle at that size."""

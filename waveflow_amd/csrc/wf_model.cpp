@@ -175,7 +175,7 @@ static void fill_bc(SplineDev& s, const wf_bc& left, const wf_bc& right, const s
 // normalised spline  sum_j c'_j T_j(x) / sum_j c'_j  equals  sum_j (c_j a~_j) T^_j(x) / sum_j (c_j a~_j)  with a~ = A^T 1 (column sums)
 // and T^_j = (A^T T)_j / a~_j: the same expression the kernels evaluate for "zero the first / last coefficient" (a~ in {0, 1}, T^ = T),
 // so the table-driven kernels (MFMA, wave sweeps, gradients) cover every homogeneous dictionary through their tables and row factors
-// alone.  The per-walker scalar kernel keeps the literal sequence (enforce_bc, wf_scalar_impl.h) and also covers b != 0.
+// alone.  The per-walker scalar kernel keeps the literal sequence (enforce_bc, wf_scalar_impl.h) and also covers the B-spline prior with b != 0.
 static void bc_apply(const SplineDev& s, int kind, int nb, std::vector<double>& c) {
     for (int p = 0; p < s.n_left; ++p) {
         const int nd = s.left_nd[p];
@@ -191,27 +191,32 @@ static void bc_apply(const SplineDev& s, int kind, int nb, std::vector<double>& 
         c[nb - nd - 1] = ((double)s.right_val[p] - sum) / (double)s.right_value[p];
     }
 }
-// -> A [nb][nb] (c' = A c), column sums; false when the map has a constant term or a column that sums to zero without being zero
+// -> A [nb][nb] (c' = A c), column sums; false when the map keeps a constant term or has a column that sums to zero without being zero
 static bool bc_map(const SplineDev& s, int kind, int nb, std::vector<double>& A, std::vector<double>& colsum) {
     A.assign((size_t)nb * nb, 0.0);
     colsum.assign(nb, 0.0);
     std::vector<double> c(nb, 0.0);
     bc_apply(s, kind, nb, c);
-    bool ok = true;
-    for (int i = 0; i < nb; ++i) ok = ok && c[i] == 0.0;
+    bool ok = true, constant = false;
+    for (int i = 0; i < nb; ++i) constant = constant || c[i] != 0.0;
+    // A constant term b (a constraint with a non-zero value).  The I- and M-spline coefficients enter the constraints normalised
+    // (remove_bias ends with p / sum p: isplines_jax.py:196-202, msplines_jax.py:186-192), so b = b (1^T c) and the map is the linear
+    // A + b 1^T on them; the B-spline prior's c = w @ ob_to_b carries no normalisation, and stays with the per-walker kernel.
+    const bool fold = constant && (kind == WF_SPLINE_I || kind == WF_SPLINE_M);
+    if (constant && !fold) ok = false;
     for (int j = 0; j < nb; ++j) {
         std::vector<double> e(nb, 0.0);
         e[j] = 1.0;
         bc_apply(s, kind, nb, e);
         bool all_zero = true;
         for (int i = 0; i < nb; ++i) {
-            const double a = e[i] - c[i];
+            const double a = e[i] - c[i] + (fold ? c[i] : 0.0);
             A[(size_t)i * nb + j] = a;
             colsum[j] += a;
             all_zero = all_zero && a == 0.0;
         }
         if (all_zero) colsum[j] = 0.0;
-        else if (std::fabs(colsum[j]) < 1e-9) ok = false;
+        else if (std::fabs(colsum[j]) < 1e-9 || (fold && colsum[j] < 0.0)) ok = false;   // (the kernels' row factors of a folded map stay positive)
     }
     return ok;
 }
