@@ -457,6 +457,40 @@ def test_mfma_kernel_is_bit_reproducible_other_shapes(D, knots):
         assert torch.equal(m.log_pdf(x), first)
 
 
+@pytest.mark.parametrize("D,knots", [(2, 23), (3, 23), (2, 33)])
+def test_mfma_support_clamped_table_reads_change_no_bit(D, knots):
+    """The MFMA kernel reads every 4-row piece of a spline-table row at the mesh index clamped to the piece's support (wf_model.cpp:
+    piece_bounds; walkers outside the support then share two cache lines).  Outside its support a basis row holds the bits of the clamped
+    entry, so log_pdf, psi, u and the bin indices must equal, bit for bit, those of a model created with the clamp switched off
+    (WF_MFMA_NO_BAND at creation) -- also with derivative constraints folded into the tables."""
+    torch = _torch()
+    from waveflow_amd import flows, model_factory, wavefunctions
+
+    def build():
+        if D == 3:   # general boundary dictionaries: the folded tables mix rows next to the ends
+            mt = model_factory.get_masked_transform
+            init = wavefunctions.Waveflow(
+                flows.Serial(flows.BoxTransformLayer(2.0), flows.IMADE(mt(), 6, knots, 0.01, 1e-6, {0: 0.0, 1: 0.0}, {0: 1.0, 1: 0.0}), flows.Reverse()),
+                mt(allow_negative_params=True), 5, knots + 1, constraints_dict_left={0: 0, 2: 0, 3: 0}, constraints_dict_right={0: 0, 1: 0},
+                constrained_dimension_indices_left=[0, 1], set_nn_output_grad_to_zero=False)
+            return init(5, D)
+        return model_factory.get_waveflow_model(D, base_spline_degree=6, i_spline_degree=6, n_prior_internal_knots=knots, n_i_internal_knots=knots,
+                                                i_spline_reg=0.05, n_flow_layers=3, box_size=2.0)(11, D)
+    x = torch.from_numpy(sorted_walkers(1 << 16, D, 2.0, 7)).cuda()
+    outs = []
+    for off in (False, True):
+        with _with_env(**({"WF_MFMA_NO_BAND": 1} if off else {})):
+            params, psi, log_pdf, _ = build()
+            m = log_pdf.model
+            m.ensure_params(params)
+        m.set_kernel("mfma")
+        lp, u, idx = m.log_pdf(x, return_sample=True, return_bin_idx=True)
+        outs.append((lp, u, idx, m.psi(x)))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert torch.isfinite(outs[0][0]).all()
+
+
 @pytest.mark.parametrize("kernel", KERNELS_ALL)
 @pytest.mark.parametrize("config", ["C1", "C2", "C3", "C3-33", "C4"])
 def test_strict_on_the_well_conditioned_subset(golden, he_flat, kernel, config):

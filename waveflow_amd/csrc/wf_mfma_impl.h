@@ -26,6 +26,7 @@ namespace mfma {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using i32x2 = __attribute__((ext_vector_type(2))) int;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 
@@ -52,6 +53,15 @@ __device__ __forceinline__ f32x16 load16g(const float* p) {
 #else
 #define load16g load16
 #endif
+#ifdef WF_ABL_TAB
+__device__ __forceinline__ f32x4 load4g(const float* p) {
+    const float c = (float)(size_t)p * 1e-20f;
+    return f32x4{c, c, c, c};
+}
+#else
+__device__ __forceinline__ f32x4 load4g(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+#endif
+__device__ __forceinline__ float uniform_f(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
 __device__ __forceinline__ float xhalf_max(float v) {
     const unsigned u = __float_as_uint(v);
     const auto s = __builtin_amdgcn_permlane32_swap(u, u, false, false);
@@ -317,9 +327,19 @@ struct SplineRows {
     f32x16 a[NO][NBK], b[NO][NBK];
     float rl[NO], rr[NO];
 };
-// tab: [mesh][NO][NBK][half][16]; rs: [mesh][NO] (read when RS)
+// tab: [mesh][NO][NBK][half][16]; rs: [mesh][NO] (read when RS); bnd (LDS): [NBK][half][4][lo, hi] support bounds of the 4-row pieces
+// (wf_model.cpp: piece_bounds).  Every 16-byte piece is read at the mesh index clamped to the piece's support: outside it the table
+// holds the bits of the clamped entry, so the value is the one at the walker's own index, and the walkers outside a piece's
+// support (about 60 % at 29 bases) read two shared, L1-resident lines instead of a line of their own from L2.
+__device__ __forceinline__ int med3i(int x, int lo, int hi) {
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(lo), "v"(hi));
+    return r;
+}
 template <int NBK, int NO, bool RS>
-__device__ __forceinline__ void fetch_rows(SplineRows<NBK, NO>& R, const float* __restrict__ tab, const float* __restrict__ rs, const Lerp& Lp, int h) {
+__device__ __forceinline__ void fetch_rows(SplineRows<NBK, NO>& R, const float* __restrict__ tab, const float* __restrict__ rs, const Lerp& Lp, int h,
+                                           const float* bnd) {
+#ifdef WF_NO_BAND
     const float* tl = tab + (size_t)Lp.il * (32 * NBK * NO) + h * 16;
     const float* tr = tab + (size_t)Lp.ir * (32 * NBK * NO) + h * 16;
 #pragma unroll
@@ -329,6 +349,25 @@ __device__ __forceinline__ void fetch_rows(SplineRows<NBK, NO>& R, const float* 
             R.a[o][kb] = load16g(tl + (o * NBK + kb) * 32);
             R.b[o][kb] = load16g(tr + (o * NBK + kb) * 32);
         }
+#else
+#pragma unroll
+    for (int kb = 0; kb < NBK; ++kb) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const i32x2 lh = *reinterpret_cast<const i32x2*>(bnd + ((kb * 2 + h) * 4 + q) * 2);
+            // byte offsets in 32 bits next to the uniform base: one address register per piece (tables are < 4 GB: 2000 mesh points x 512 B)
+            const unsigned ol = (unsigned)med3i(Lp.il, lh[0], lh[1]) * (128u * NBK * NO) + (unsigned)(kb * 128 + h * 64 + q * 16);
+            const unsigned orr = (unsigned)med3i(Lp.ir, lh[0], lh[1]) * (128u * NBK * NO) + (unsigned)(kb * 128 + h * 64 + q * 16);
+            const char* tb = reinterpret_cast<const char*>(tab);
+#pragma unroll
+            for (int o = 0; o < NO; ++o) {
+                const f32x4 a = load4g(reinterpret_cast<const float*>(tb + ol + o * NBK * 128)), b = load4g(reinterpret_cast<const float*>(tb + orr + o * NBK * 128));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { R.a[o][kb][q * 4 + e] = a[e]; R.b[o][kb][q * 4 + e] = b[e]; }
+            }
+        }
+    }
+#endif
 #pragma unroll
     for (int o = 0; o < NO; ++o) {
         R.rl[o] = RS ? rs[(size_t)Lp.il * NO + o] : 0.0f;
@@ -473,6 +512,8 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
     const float* fkI = lds;                        // [NBK][2][16] remove_bias * keep factors of the flow-layer I-spline
     const float* fkP = lds + 32 * NBK;             // [NBK][2][16] prior: keep (B) or remove_bias * keep (M)
     const float* ob2b = lds + 64 * NBK;            // [NBK out][NBK in]{hi, lo}[2 K steps][64][8 halves] ob_to_b in f16-MFMA A order
+    const float* bndI = ob2b + NBK * NBK * 1024;   // int32 [NBK][2][4][lo, hi]: support bounds of the table pieces (fetch_rows)
+    const float* bndP = bndI + 16 * NBK;
     float* slots = lds + mm.const_floats;
     const int64_t n_tiles = (B + 31) >> 5;
     constexpr int kTilesPerChunk = kWaves * T;
@@ -480,6 +521,8 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
     const int idx_stride = (mm.n_layers + 1) * D * 2;
     const float L = mm.box_L, tol = 1e-7f;
     const float rn_mesh = 1.0f / (float)(mm.n_mesh - 1);
+    // wave-uniform terms of the mean-type box transform's first step, held in scalar registers (the compiler hoists them into vector ones)
+    const float box_space0 = uniform_f(2 * L + tol), box_log0 = uniform_f(fast_log(2 * L + tol));
 #ifdef WF_STAMP
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
     [[maybe_unused]] int stamp_iter = 0;
@@ -541,8 +584,8 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
 #pragma unroll
                 for (int i = 0; i < D - 1; ++i) {
                     const float diff = cur[t][i + 1] - cur[t][i];
-                    nxt[t][i] = diff / (space_left + tol);
-                    ld = ld - fast_log(space_left + tol);
+                    nxt[t][i] = diff / (i == 0 ? box_space0 : space_left + tol);
+                    ld = ld - (i == 0 ? box_log0 : fast_log(space_left + tol));
                     space_left = space_left - diff;
                 }
                 nxt[t][D - 1] = (mean + L - l) / (2 * L - wd + tol);
@@ -618,7 +661,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
                         const Lerp Lp = make_lerp(cur[t][d], mm.n_mesh, rn_mesh, exact_div);
                         if (IDX && idx[t]) { idx[t][(l * D + d) * 2] = Lp.xl; idx[t][(l * D + d) * 2 + 1] = Lp.xr; }
                         SplineRows<NBK, 2> R;
-                        fetch_rows<NBK, 2, true>(R, mm.tabI, mm.rsI, Lp, h);
+                        fetch_rows<NBK, 2, true>(R, mm.tabI, mm.rsI, Lp, h, bndI);
                         float ld;
                         ispline_eval<NBK>(v[t], R, Lp.t, rS, rs, nxt[t][d], ld);
                         logdet[t] = logdet[t] + ld;
@@ -769,7 +812,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
                             }
                             const float rnorm = __builtin_amdgcn_rsqf(xhalf_sum(n2));
                             SplineRows<NBK, 1> RP;   // prior rows [mesh][kb][h][16], nd 0
-                            fetch_rows<NBK, 1, false>(RP, mm.tabP, nullptr, Lp[t], h);
+                            fetch_rows<NBK, 1, false>(RP, mm.tabP, nullptr, Lp[t], h, bndP);
                             const float v0 = lerp_dot<NBK, 1>(c, RP, 0, Lp[t].t) * rnorm;
                             val[t] = (s1 < 0.0f && !mm.prior_quotient) ? -v0 : v0;
                         }
@@ -789,7 +832,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
                             float S1, Sf;
                             sigmoid_block<NBK>(v[t], fkP, h, S1, Sf, gate_p, gp[t], net + NetOff<D, NBK>::z + d * NBK * 32);
                             SplineRows<NBK, 1> RP;
-                            fetch_rows<NBK, 1, false>(RP, mm.tabP, nullptr, Lp[t], h);
+                            fetch_rows<NBK, 1, false>(RP, mm.tabP, nullptr, Lp[t], h, bndP);
                             val[t] = lerp_dot<NBK, 1>(v[t], RP, 0, Lp[t].t) * __builtin_amdgcn_rcpf(Sf);
                         }
                     }

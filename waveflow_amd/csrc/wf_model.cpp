@@ -713,6 +713,29 @@ static void pack_rows_acc(const std::vector<double>& t64, int nb, int n_mesh, in
         }
 }
 
+// Support bounds of the 4-row pieces of a pack_rows_acc table: for piece q of (block kb, half h), bnd[((kb*2+h)*4+q)*2+0] = the
+// last mesh index up to which the piece's entries (every order) equal those at mesh point 0, bnd[((kb*2+h)*4+q)*2+1] = the first one
+// from which they equal those at the last mesh point.  Spline bases have local support (I-splines: 0 below, their full value above),
+// so a read at clamp(m, lo, hi) returns the bits of the read at m, and walkers outside a piece's support share two cache lines
+// instead of touching their own: found by comparing the table's actual fp32 entries, whatever the boundary map or the row factors made of them.
+static void piece_bounds(const std::vector<float>& rows, int n_mesh, int n_orders, int nbk, int32_t* bnd) {
+    auto piece = [&](int m, int nd, int kb, int h, int q) { return &rows[((((size_t)m * n_orders + nd) * nbk + kb) * 2 + h) * 16 + 4 * q]; };
+    for (int kb = 0; kb < nbk; ++kb)
+        for (int h = 0; h < 2; ++h)
+            for (int q = 0; q < 4; ++q) {
+                auto same = [&](int m, int ref) {
+                    for (int nd = 0; nd < n_orders; ++nd)
+                        if (memcmp(piece(m, nd, kb, h, q), piece(ref, nd, kb, h, q), 4 * sizeof(float)) != 0) return false;
+                    return true;
+                };
+                int lo = 0, hi = n_mesh - 1;
+                while (lo + 1 < n_mesh && same(lo + 1, 0)) ++lo;
+                while (hi - 1 >= 0 && same(hi - 1, n_mesh - 1)) --hi;
+                bnd[((kb * 2 + h) * 4 + q) * 2 + 0] = lo;
+                bnd[((kb * 2 + h) * 4 + q) * 2 + 1] = hi;
+            }
+}
+
 static bool net_has_sigmoid_head(const wf_model* m, int n) {
     const bool is_prior = n == m->desc.n_flow_layers;
     if (is_prior) return m->desc.prior_kind == WF_PRIOR_MFLOW;
@@ -804,7 +827,7 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
     const bool spline_prior = d.prior_kind == WF_PRIOR_WAVEFLOW || d.prior_kind == WF_PRIOR_MFLOW;
     if (spline_prior && !m->bc_p_ok) return WF_OK;
     const int n_nets = (int)m->nets.size();
-    const int consts = 64 * nbk + nbk * nbk * 1024;
+    const int consts = 64 * nbk + nbk * nbk * 1024 + 32 * nbk;   // fkI, fkP, ob_to_b image, piece bounds (flow table, prior table)
     const int net_floats = mfma_net_floats(D, nbk);
     const int64_t lds_cap = 160 * 1024 / 4 - 64;   // floats (the kernel also holds a few bytes of static LDS: its tile counter)
     int staged;
@@ -825,6 +848,8 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
     m->mfma_lds_floats = consts + (staged ? net_floats : net_floats * n_nets);
 
     m->mfma_consts.assign(consts, 0.0f);
+    int32_t* bnd = reinterpret_cast<int32_t*>(m->mfma_consts.data() + 64 * nbk + nbk * nbk * 1024);   // [2 tables][nbk][2 halves][4 pieces][lo, hi]
+    for (int i = 0; i < 32 * nbk; ++i) bnd[i] = (i & 1) ? d.n_mesh - 1 : 0;   // (no clamp until a table says otherwise)
     std::vector<float> fk_nat(128, 0.0f);
     if (imade) {
         float* fk = m->mfma_consts.data();
@@ -834,6 +859,7 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
         md.F_I = (float)F;
         std::vector<float> rows, rowsum;
         pack_rows_acc(i64, m->i_nb, d.n_mesh, 2, nbk, fk, rows, &rowsum);
+        if (!getenv("WF_MFMA_NO_BAND")) piece_bounds(rows, d.n_mesh, 2, nbk, bnd);   // (the switch: tests compare both, bit for bit)
         int rc = upload_table(m, rows, &md.tabI);
         if (rc) return rc;
         rc = upload_table(m, rowsum, &md.rsI);
@@ -849,6 +875,7 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
         std::vector<float> rows;
         // M prior: the row factors are folded into the table; B prior: they act on the weights before ob_to_b
         pack_rows_acc(p64, m->p_nb, d.n_mesh, 1, nbk, mflow ? fk : nullptr, rows, nullptr);
+        if (!getenv("WF_MFMA_NO_BAND")) piece_bounds(rows, d.n_mesh, 1, nbk, bnd + 16 * nbk);
         int rc = upload_table(m, rows, &md.tabP);
         if (rc) return rc;
         if (!mflow) {
