@@ -213,6 +213,14 @@ def test_local_energy_tile_path_other_models(monkeypatch):
         for a, b in ((ps, pw), (lap, lw), (hp, hw)):
             d = np.abs(a - b)
             assert np.isfinite(a).all() and d.max() <= 5e-4 * np.abs(b).max() and np.median(d) <= 1e-6 * np.abs(b).max(), (c, d.max() / np.abs(b).max())
+        # the head kernels read every table chunk at the mesh index clamped to the chunk's support (wf_model.cpp: upload_chunked): the same
+        # bits as the reads at the walker's own index (a model created with the clamp switched off)
+        monkeypatch.setenv("WF_MFMA_NO_BAND", "1")
+        params2, psi2, _, _ = init(4, 2)
+        psi2.model.ensure_params(params2)
+        monkeypatch.delenv("WF_MFMA_NO_BAND")
+        (hp2, ps2, lap2), _ = _tile_and_wave(psi2.model, x, [0.0, 0.0], monkeypatch)
+        assert np.array_equal(hp2, hp) and np.array_equal(ps2, ps) and np.array_equal(lap2, lap)
     # first-type box: not in the family -- forcing the tile path changes nothing
     init = model_factory.get_waveflow_model(2, n_flow_layers=1, box_size=2, xu_coord_type="first")
     params, psi, log_pdf, _ = init(1, 2)

@@ -306,11 +306,14 @@ __global__ __launch_bounds__(256) void k_etile_flow(const float4_t* __restrict__
     // numerators are N_k = V_k / S0 + reg R_k and the normaliser Q = Qv / S0 + reg G.  Four rows per step: the lane's table rows come as
     // 16-byte loads (8 per step: 4 orders x the two mesh rows; rows >= nb are zero padding).
     const LerpN L = nlerp(u1.v, n_mesh);
-    const float4_t* rl = reinterpret_cast<const float4_t*>(tabI + (size_t)L.il * 128);   // [8 chunks][4 orders] float4
-    const float4_t* rr = reinterpret_cast<const float4_t*>(tabI + (size_t)L.ir * 128);
+    const int* bnd = reinterpret_cast<const int*>(tabI + (size_t)n_mesh * 128);   // [8 chunks][lo, hi] behind the table (wf_model.cpp: upload_chunked)
     J S0 = jc(0.0f), V0 = jc(0.0f), V1 = jc(0.0f), Qv = jc(0.0f);
     float r0[3] = {0.0f, 0.0f, 0.0f}, r1[3] = {0.0f, 0.0f, 0.0f}, G = 0.0f;   // sum_j g_j t_j^(k), k = 0..2 and 1..3: R_k = lift of them
     for (int j0 = 0; j0 < nb; j0 += 4) {
+        // the chunk at the mesh index clamped to its support: the same bits, and the walkers outside the support read two shared lines
+        const int lo = bnd[j0 >> 1], hi = bnd[(j0 >> 1) + 1];
+        const float4_t* rl = reinterpret_cast<const float4_t*>(tabI + (size_t)min(max(L.il, lo), hi) * 128);   // [8 chunks][4 orders] float4
+        const float4_t* rr = reinterpret_cast<const float4_t*>(tabI + (size_t)min(max(L.ir, lo), hi) * 128);
         float4_t ta[4], tb[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -371,10 +374,12 @@ __global__ __launch_bounds__(256) void k_etile_prior(const float4_t* __restrict_
         val0 = jlift(__builtin_fmaf(cb.x - ca.x, L.t, ca.x), __builtin_fmaf(cb.y - ca.y, L.t, ca.y), __builtin_fmaf(cb.z - ca.z, L.t, ca.z), uc0);
     }
     const LerpN L = nlerp(uc1.v, n_mesh);
-    const float4_t* rl = reinterpret_cast<const float4_t*>(tabP + (size_t)L.il * 128);
-    const float4_t* rr = reinterpret_cast<const float4_t*>(tabP + (size_t)L.ir * 128);
+    const int* bnd = reinterpret_cast<const int*>(tabP + (size_t)n_mesh * 128);
     J N2 = jc(0.0f), dot = jc(0.0f);
     for (int i0 = 0; i0 < nb; i0 += 4) {
+        const int lo = bnd[i0 >> 1], hi = bnd[(i0 >> 1) + 1];
+        const float4_t* rl = reinterpret_cast<const float4_t*>(tabP + (size_t)min(max(L.il, lo), hi) * 128);
+        const float4_t* rr = reinterpret_cast<const float4_t*>(tabP + (size_t)min(max(L.ir, lo), hi) * 128);
         float4_t ta[3], tb[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {

@@ -260,13 +260,28 @@ static int upload_table(wf_model* m, const std::vector<float>& h, const float** 
 }
 
 static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::vector<double>& p64, const std::vector<double>& o2b);
-// [4][n_mesh][32] -> [n_mesh][8][4][4] (see d_tabI4c)
+// [4][n_mesh][32] -> [n_mesh][8][4][4] (see d_tabI4c), + the chunks' support bounds
 static int upload_chunked(wf_model* m, const std::vector<float>& rows4, int n_mesh, const float** out) {
     std::vector<float> c((size_t)n_mesh * 128);
     for (int mm = 0; mm < n_mesh; ++mm)
         for (int ch = 0; ch < 8; ++ch)
             for (int k = 0; k < 4; ++k)
                 for (int q = 0; q < 4; ++q) c[(((size_t)mm * 8 + ch) * 4 + k) * 4 + q] = rows4[((size_t)k * n_mesh + mm) * 32 + 4 * ch + q];
+    // behind the table: int32 [8 chunks][lo, hi], the support bounds of the chunks (as piece_bounds below: a chunk read at clamp(m, lo, hi)
+    // returns the bits of the chunk at m; the lane-per-walker kernels of the energy path clamp, and walkers outside a chunk's support share lines)
+    std::vector<int32_t> bnd(16);
+    for (int ch = 0; ch < 8; ++ch) {
+        auto same = [&](int a, int b) { return memcmp(&c[((size_t)a * 8 + ch) * 16], &c[((size_t)b * 8 + ch) * 16], 16 * sizeof(float)) == 0; };
+        int lo = 0, hi = n_mesh - 1;
+        if (!getenv("WF_MFMA_NO_BAND")) {
+            while (lo + 1 < n_mesh && same(lo + 1, 0)) ++lo;
+            while (hi - 1 >= 0 && same(hi - 1, n_mesh - 1)) --hi;
+        }
+        bnd[2 * ch] = lo;
+        bnd[2 * ch + 1] = hi;
+    }
+    c.resize(c.size() + 16);
+    memcpy(&c[(size_t)n_mesh * 128], bnd.data(), 16 * sizeof(int32_t));
     return upload_table(m, c, out);
 }
 static int grad_prepare(wf_model* m);
