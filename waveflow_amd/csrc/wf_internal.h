@@ -105,7 +105,7 @@ struct MfmaDev {
     const float* image;        // global image: n_nets net images (net_floats each), then the constants block
     int n_nets, net_floats;
     int const_img_off;         // float offset of the constants block inside the image
-    int const_floats;          // fkI[nbk][2][16], fkP[nbk][2][16], ob_to_b image [nbk][nbk]{hi, lo}[2 K steps][64 lanes][8 halves], piece bounds int32 [2 tables][nbk][2][4][lo, hi]
+    int const_floats;          // fkI[nbk][2][16], fkP[nbk][2][16], ob_to_b image [nbk][nbk]{hi, lo}[2 K steps][64 lanes][8 halves], piece bounds int32 [2 tables][nbk][2][16]
     int staged;                // 0: every net resident in LDS; 1: one LDS slot, nets re-staged per chunk of tiles
     const float* tabI;         // [n_mesh][nd 0..1][nbk][half][16] fp32: fk_row * I_row, accumulator row order
     const float* rsI;          // [n_mesh][nd 0..1]: sum over rows of tabI

@@ -61,7 +61,12 @@ __device__ __forceinline__ f32x4 load4g(const float* p) {
 #else
 __device__ __forceinline__ f32x4 load4g(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 #endif
-__device__ __forceinline__ float uniform_f(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
+// a wave-uniform float into a scalar register (the builtin is folded away when the compiler knows the value to be uniform, and the value stays in a vector register)
+__device__ __forceinline__ float uniform_f(float v) {
+    float r;
+    asm("v_readfirstlane_b32 %0, %1" : "=s"(r) : "v"(v));
+    return r;
+}
 __device__ __forceinline__ float xhalf_max(float v) {
     const unsigned u = __float_as_uint(v);
     const auto s = __builtin_amdgcn_permlane32_swap(u, u, false, false);
@@ -327,7 +332,7 @@ struct SplineRows {
     f32x16 a[NO][NBK], b[NO][NBK];
     float rl[NO], rr[NO];
 };
-// tab: [mesh][NO][NBK][half][16]; rs: [mesh][NO] (read when RS); bnd (LDS): [NBK][half][4][lo, hi] support bounds of the 4-row pieces
+// tab: [mesh][NO][NBK][half][16]; rs: [mesh][NO] (read when RS); bnd (LDS): [NBK][half][16: 4 x (lo, hi), 8 unused] support bounds of the 4-row pieces
 // (wf_model.cpp: piece_bounds).  Every 16-byte piece is read at the mesh index clamped to the piece's support: outside it the table
 // holds the bits of the clamped entry, so the value is the one at the walker's own index, and the walkers outside a piece's
 // support (about 60 % at 29 bases) read two shared, L1-resident lines instead of a line of their own from L2.
@@ -354,7 +359,7 @@ __device__ __forceinline__ void fetch_rows(SplineRows<NBK, NO>& R, const float* 
     for (int kb = 0; kb < NBK; ++kb) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const i32x2 lh = *reinterpret_cast<const i32x2*>(bnd + ((kb * 2 + h) * 4 + q) * 2);
+            const i32x2 lh = *reinterpret_cast<const i32x2*>(bnd + (kb * 2 + h) * 16 + q * 2);
             // byte offsets in 32 bits next to the uniform base: one address register per piece (tables are < 4 GB: 2000 mesh points x 512 B)
             const unsigned ol = (unsigned)med3i(Lp.il, lh[0], lh[1]) * (128u * NBK * NO) + (unsigned)(kb * 128 + h * 64 + q * 16);
             const unsigned orr = (unsigned)med3i(Lp.ir, lh[0], lh[1]) * (128u * NBK * NO) + (unsigned)(kb * 128 + h * 64 + q * 16);
@@ -512,8 +517,8 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
     const float* fkI = lds;                        // [NBK][2][16] remove_bias * keep factors of the flow-layer I-spline
     const float* fkP = lds + 32 * NBK;             // [NBK][2][16] prior: keep (B) or remove_bias * keep (M)
     const float* ob2b = lds + 64 * NBK;            // [NBK out][NBK in]{hi, lo}[2 K steps][64][8 halves] ob_to_b in f16-MFMA A order
-    const float* bndI = ob2b + NBK * NBK * 1024;   // int32 [NBK][2][4][lo, hi]: support bounds of the table pieces (fetch_rows)
-    const float* bndP = bndI + 16 * NBK;
+    const float* bndI = ob2b + NBK * NBK * 1024;   // int32 [NBK][2][16]: support bounds of the table pieces (fetch_rows), at the lane stride of fkI / fkP
+    const float* bndP = bndI + 32 * NBK;
     float* slots = lds + mm.const_floats;
     const int64_t n_tiles = (B + 31) >> 5;
     constexpr int kTilesPerChunk = kWaves * T;
@@ -522,7 +527,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
     const float L = mm.box_L, tol = 1e-7f;
     const float rn_mesh = 1.0f / (float)(mm.n_mesh - 1);
     // wave-uniform terms of the mean-type box transform's first step, held in scalar registers (the compiler hoists them into vector ones)
-    const float box_space0 = uniform_f(2 * L + tol), box_log0 = uniform_f(fast_log(2 * L + tol));
+    const float box_space0 = uniform_f(2 * L + tol), box_nlog0 = uniform_f(0.0f - fast_log(2 * L + tol));
 #ifdef WF_STAMP
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
     [[maybe_unused]] int stamp_iter = 0;
@@ -585,7 +590,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
                 for (int i = 0; i < D - 1; ++i) {
                     const float diff = cur[t][i + 1] - cur[t][i];
                     nxt[t][i] = diff / (i == 0 ? box_space0 : space_left + tol);
-                    ld = ld - (i == 0 ? box_log0 : fast_log(space_left + tol));
+                    ld = i == 0 ? box_nlog0 : ld - fast_log(space_left + tol);   // (0 - log: the same bits)
                     space_left = space_left - diff;
                 }
                 nxt[t][D - 1] = (mean + L - l) / (2 * L - wd + tol);

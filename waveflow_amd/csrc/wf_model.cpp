@@ -728,8 +728,8 @@ static void pack_rows_acc(const std::vector<double>& t64, int nb, int n_mesh, in
         }
 }
 
-// Support bounds of the 4-row pieces of a pack_rows_acc table: for piece q of (block kb, half h), bnd[((kb*2+h)*4+q)*2+0] = the
-// last mesh index up to which the piece's entries (every order) equal those at mesh point 0, bnd[((kb*2+h)*4+q)*2+1] = the first one
+// Support bounds of the 4-row pieces of a pack_rows_acc table: for piece q of (block kb, half h), bnd[(kb*2+h)*16+q*2+0] = the
+// last mesh index up to which the piece's entries (every order) equal those at mesh point 0, bnd[(kb*2+h)*16+q*2+1] = the first one
 // from which they equal those at the last mesh point.  Spline bases have local support (I-splines: 0 below, their full value above),
 // so a read at clamp(m, lo, hi) returns the bits of the read at m, and walkers outside a piece's support share two cache lines
 // instead of touching their own: found by comparing the table's actual fp32 entries, whatever the boundary map or the row factors made of them.
@@ -746,8 +746,8 @@ static void piece_bounds(const std::vector<float>& rows, int n_mesh, int n_order
                 int lo = 0, hi = n_mesh - 1;
                 while (lo + 1 < n_mesh && same(lo + 1, 0)) ++lo;
                 while (hi - 1 >= 0 && same(hi - 1, n_mesh - 1)) --hi;
-                bnd[((kb * 2 + h) * 4 + q) * 2 + 0] = lo;
-                bnd[((kb * 2 + h) * 4 + q) * 2 + 1] = hi;
+                bnd[(kb * 2 + h) * 16 + q * 2 + 0] = lo;
+                bnd[(kb * 2 + h) * 16 + q * 2 + 1] = hi;
             }
 }
 
@@ -842,7 +842,7 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
     const bool spline_prior = d.prior_kind == WF_PRIOR_WAVEFLOW || d.prior_kind == WF_PRIOR_MFLOW;
     if (spline_prior && !m->bc_p_ok) return WF_OK;
     const int n_nets = (int)m->nets.size();
-    const int consts = 64 * nbk + nbk * nbk * 1024 + 32 * nbk;   // fkI, fkP, ob_to_b image, piece bounds (flow table, prior table)
+    const int consts = 64 * nbk + nbk * nbk * 1024 + 64 * nbk;   // fkI, fkP, ob_to_b image, piece bounds (flow table, prior table)
     const int net_floats = mfma_net_floats(D, nbk);
     const int64_t lds_cap = 160 * 1024 / 4 - 64;   // floats (the kernel also holds a few bytes of static LDS: its tile counter)
     int staged;
@@ -863,8 +863,8 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
     m->mfma_lds_floats = consts + (staged ? net_floats : net_floats * n_nets);
 
     m->mfma_consts.assign(consts, 0.0f);
-    int32_t* bnd = reinterpret_cast<int32_t*>(m->mfma_consts.data() + 64 * nbk + nbk * nbk * 1024);   // [2 tables][nbk][2 halves][4 pieces][lo, hi]
-    for (int i = 0; i < 32 * nbk; ++i) bnd[i] = (i & 1) ? d.n_mesh - 1 : 0;   // (no clamp until a table says otherwise)
+    int32_t* bnd = reinterpret_cast<int32_t*>(m->mfma_consts.data() + 64 * nbk + nbk * nbk * 1024);   // [2 tables][nbk][2 halves][16: 4 pieces x (lo, hi), 8 unused -- the lane stride of the fk blocks]
+    for (int i = 0; i < 64 * nbk; ++i) bnd[i] = (i & 1) ? d.n_mesh - 1 : 0;   // (no clamp until a table says otherwise)
     std::vector<float> fk_nat(128, 0.0f);
     if (imade) {
         float* fk = m->mfma_consts.data();
@@ -890,7 +890,7 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
         std::vector<float> rows;
         // M prior: the row factors are folded into the table; B prior: they act on the weights before ob_to_b
         pack_rows_acc(p64, m->p_nb, d.n_mesh, 1, nbk, mflow ? fk : nullptr, rows, nullptr);
-        if (!getenv("WF_MFMA_NO_BAND")) piece_bounds(rows, d.n_mesh, 1, nbk, bnd + 16 * nbk);
+        if (!getenv("WF_MFMA_NO_BAND")) piece_bounds(rows, d.n_mesh, 1, nbk, bnd + 32 * nbk);
         int rc = upload_table(m, rows, &md.tabP);
         if (rc) return rc;
         if (!mflow) {
