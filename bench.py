@@ -94,7 +94,7 @@ def extra_legs(model, flat):
     m33 = seeded_model(2, 33, "mfma")
     x = sorted_uniform(1 << 20, 2, 1234).cuda()
     ms = kernel_ms(m33, x)
-    out["variant_33knot"] = {"evals_per_s": (1 << 20) / (ms * 1e-3), "kernel_ms": ms, "kernel": "k_mfma<2,2,16,1>",
+    out["variant_33knot"] = {"evals_per_s": (1 << 20) / (ms * 1e-3), "kernel_ms": ms, "kernel": "k_mfma<2,2,12,1>",
                              "workload": "He, 33 knots (32 intervals), 2^20 walkers, seeded parameters"}
     del m33
     # C2: the reference's batch size, one call (shipped checkpoint); AUTO routes it to the wave kernel

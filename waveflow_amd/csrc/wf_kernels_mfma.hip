@@ -197,11 +197,12 @@ __global__ void k_fold_bias(float* __restrict__ image, int net_floats, int D, in
     }
 }
 
-int waves_per_group(int tiles) {
+int waves_per_group(int tiles, int nbk) {
     const char* e = getenv("WF_MFMA_WAVES");
     const int v = e ? atoi(e) : 0;
     if (tiles == 2) return (v == 4 || v == 8) ? v : 8;
-    return (v == 8 || v == 12 || v == 16) ? v : 16;
+    // (two row blocks per dimension: 0.347 ms at 12 waves, 0.354 at 16, 0.369 at 8 -- scratch/time_waves.py, 33-knot He, 2^20 walkers)
+    return (v == 8 || v == 12 || v == 16) ? v : (nbk == 2 ? 12 : 16);
 }
 int tiles_per_wave() {
     const char* e = getenv("WF_MFMA_TILES");
@@ -260,10 +261,10 @@ int launch_mfma(int D, int nbk, const MfmaDev* mdev, int lds_bytes, int mode, co
 #define GO(DD, KK, WW) return launch_dw<DD, KK, WW, 1>(mdev, lds_bytes, mode, x, B, out, u, idx, s)
     if (D == 2 && nbk == 1) {   // the headline shape: several workgroup shapes are built (tuning / reproducibility test)
         if (tiles_per_wave() == 2 && !idx) {   // (bin indices: one-tile kernels only)
-            if (waves_per_group(2) == 4) return launch_dw<2, 1, 4, 2>(mdev, lds_bytes, mode, x, B, out, u, idx, s);
+            if (waves_per_group(2, 1) == 4) return launch_dw<2, 1, 4, 2>(mdev, lds_bytes, mode, x, B, out, u, idx, s);
             return launch_dw<2, 1, 8, 2>(mdev, lds_bytes, mode, x, B, out, u, idx, s);
         }
-        switch (waves_per_group(1)) {
+        switch (waves_per_group(1, 1)) {
             case 8: GO(2, 1, 8);
             case 12: GO(2, 1, 12);
             default: GO(2, 1, 16);
@@ -283,7 +284,7 @@ int launch_mfma(int D, int nbk, const MfmaDev* mdev, int lds_bytes, int mode, co
     if (nbk == 2) {
         switch (D) {
             case 2:
-                switch (waves_per_group(1)) {
+                switch (waves_per_group(1, 2)) {
                     case 8: GO(2, 2, 8);
                     case 12: GO(2, 2, 12);
                     default: GO(2, 2, 16);

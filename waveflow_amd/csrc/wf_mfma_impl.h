@@ -109,7 +109,8 @@ __device__ __forceinline__ Lerp make_lerp(float x, int n_mesh, float rn, int exa
     L.il = wrap_clamp(L.xl, n_mesh);
     L.ir = wrap_clamp(L.xr, n_mesh);
     const float dx = x - div_by_n(fl, (float)n_points, rn, exact_div);
-    L.t = dx * (float)n_points;
+    // y = y_l + (y_r - y_l) * t with both ends from one row is y_l whatever t: t = 0 then, and the right end need not be read (fetch_block)
+    L.t = L.il == L.ir ? 0.0f : dx * (float)n_points;
     return L;
 }
 
@@ -324,89 +325,111 @@ __device__ __forceinline__ void out_block_first(const float* net, Frag (&h2)[T][
     mfma_step<T>(W2h, W2l, 1, 1, h2, o, lane);
 }
 
-// The table rows of one spline evaluation of one walker half: x_l and x_r rows, NO derivative orders (NO = 2: value and first
-// derivative of the flow-layer I-spline; 1: the prior), NBK blocks of 16 floats each, plus the row sums.  Fetched as a unit so that
-// the requests can be issued long before the weights exist (the rows depend on the layer INPUT only).
-template <int NBK, int NO>
-struct SplineRows {
-    f32x16 a[NO][NBK], b[NO][NBK];
-    float rl[NO], rr[NO];
-};
-// tab: [mesh][NO][NBK][half][16]; rs: [mesh][NO] (read when RS); bnd (LDS): [NBK][half][16: 4 x (lo, hi), 8 unused] support bounds of the 4-row pieces
-// (wf_model.cpp: piece_bounds).  Every 16-byte piece is read at the mesh index clamped to the piece's support: outside it the table
-// holds the bits of the clamped entry, so the value is the one at the walker's own index, and the walkers outside a piece's
-// support (about 60 % at 29 bases) read two shared, L1-resident lines instead of a line of their own from L2.
+// tab: [mesh][8 NBK pieces][NO][side: m, m + 1][4 rows] (wf_model.cpp: pack_rows_pairs); rs: [mesh][NO] (read when RS); bnd (LDS):
+// [NBK][half][16: 4 x (lo, hi), 8 unused] support bounds of the lane's pieces (piece_bounds).  One record = both lerp ends and all
+// orders of four rows: a lane reads four records per block, each at the mesh index clamped to the piece's support -- outside it the
+// table holds the bits of the clamped record, so the values are those at the walker's own index, and the walkers outside a piece's
+// support (about 60 % at 29 bases) read two shared, L1-resident records instead of one of their own from L2.  The right end is the
+// record's second side when x_r = x_l + 1; x_r = x_l needs no right end (Lerp::t is 0 then); anything else (the reference's negative
+// indices wrap around, isplines_jax.py:48-49) fetches the right end from its own record (FAR instantiations).
 __device__ __forceinline__ int med3i(int x, int lo, int hi) {
     int r;
     asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(lo), "v"(hi));
     return r;
 }
-template <int NBK, int NO, bool RS>
-__device__ __forceinline__ void fetch_rows(SplineRows<NBK, NO>& R, const float* __restrict__ tab, const float* __restrict__ rs, const Lerp& Lp, int h,
-                                           const float* bnd) {
-#ifdef WF_NO_BAND
-    const float* tl = tab + (size_t)Lp.il * (32 * NBK * NO) + h * 16;
-    const float* tr = tab + (size_t)Lp.ir * (32 * NBK * NO) + h * 16;
+// the four records of 32-row block kb of one walker half
+template <int NBK, int NO, bool FAR>
+__device__ __forceinline__ void fetch_block(f32x16 (&A)[NO], f32x16 (&Bv)[NO], const float* __restrict__ tab, const Lerp& Lp, int h, const float* bnd, int kb) {
+    const char* tb = reinterpret_cast<const char*>(tab);
+    constexpr unsigned kRec = 32u * NO, kMesh = 8u * NBK * kRec;   // bytes per record / per mesh point; 32-bit offsets (tables are < 4 GB)
+    const bool far = FAR && Lp.ir != Lp.il && Lp.ir != Lp.il + 1;
 #pragma unroll
-    for (int o = 0; o < NO; ++o)
-#pragma unroll
-        for (int kb = 0; kb < NBK; ++kb) {
-            R.a[o][kb] = load16g(tl + (o * NBK + kb) * 32);
-            R.b[o][kb] = load16g(tr + (o * NBK + kb) * 32);
+    for (int q = 0; q < 4; ++q) {
+        const i32x2 lh = *reinterpret_cast<const i32x2*>(bnd + (kb * 2 + h) * 16 + q * 2);
+        const unsigned off = (unsigned)med3i(Lp.il, lh[0], lh[1]) * kMesh + (unsigned)(8 * kb + 2 * q + h) * kRec;
+        unsigned offb = off + 16u;
+        if (FAR) {
+            const unsigned offr = (unsigned)med3i(Lp.ir, lh[0], lh[1]) * kMesh + (unsigned)(8 * kb + 2 * q + h) * kRec;
+            offb = far ? offr : offb;
         }
-#else
 #pragma unroll
-    for (int kb = 0; kb < NBK; ++kb) {
+        for (int o = 0; o < NO; ++o) {
+            const f32x4 a = load4g(reinterpret_cast<const float*>(tb + off + o * 32)), b = load4g(reinterpret_cast<const float*>(tb + offb + o * 32));
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const i32x2 lh = *reinterpret_cast<const i32x2*>(bnd + (kb * 2 + h) * 16 + q * 2);
-            // byte offsets in 32 bits next to the uniform base: one address register per piece (tables are < 4 GB: 2000 mesh points x 512 B)
-            const unsigned ol = (unsigned)med3i(Lp.il, lh[0], lh[1]) * (128u * NBK * NO) + (unsigned)(kb * 128 + h * 64 + q * 16);
-            const unsigned orr = (unsigned)med3i(Lp.ir, lh[0], lh[1]) * (128u * NBK * NO) + (unsigned)(kb * 128 + h * 64 + q * 16);
-            const char* tb = reinterpret_cast<const char*>(tab);
+            for (int e = 0; e < 4; ++e) { A[o][q * 4 + e] = a[e]; Bv[o][q * 4 + e] = b[e]; }
+        }
+    }
+}
+// sum over the walker's 32 * NBK rows of v_r * lerp(T'_r) for NO derivative orders (summed over the two lane halves); the products
+// follow the records' arrival order.  rsum (may be null): the row sums [mesh][NO] -> rl, rr.  One block per dimension: all records are
+// requested first, the row sums behind them.  Two blocks: the row sums first, then block by block -- the second block's records are
+// requested when the first block's products are done (both blocks in flight are 128 registers: spills at 12 and 16 waves).
+// (scratch/time_waves.py, r02 notes in DESIGN.md: each form is 3 - 6 % slower in the other case.)
+template <int NBK, int NO, bool FAR>
+__device__ __forceinline__ void rows_lerp_dot(const f32x16 (&v)[NBK], const float* __restrict__ tab, const Lerp& Lp, int h, const float* bnd, float (&out)[NO],
+                                              const float* __restrict__ rsum = nullptr, float* rl = nullptr, float* rr = nullptr) {
+    auto row_sums = [&]() {
+        if (rsum) {
 #pragma unroll
             for (int o = 0; o < NO; ++o) {
-                const f32x4 a = load4g(reinterpret_cast<const float*>(tb + ol + o * NBK * 128)), b = load4g(reinterpret_cast<const float*>(tb + orr + o * NBK * 128));
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { R.a[o][kb][q * 4 + e] = a[e]; R.b[o][kb][q * 4 + e] = b[e]; }
+                rl[o] = rsum[(size_t)Lp.il * NO + o];
+                rr[o] = rsum[(size_t)Lp.ir * NO + o];
             }
         }
-    }
-#endif
+    };
+    float part[NO];
 #pragma unroll
-    for (int o = 0; o < NO; ++o) {
-        R.rl[o] = RS ? rs[(size_t)Lp.il * NO + o] : 0.0f;
-        R.rr[o] = RS ? rs[(size_t)Lp.ir * NO + o] : 0.0f;
-    }
-}
-
-// sum over the walker's 32 * NBK rows of v_r * lerp(T'_r) for derivative order o (summed over the two lane halves)
-template <int NBK, int NO>
-__device__ __forceinline__ float lerp_dot(const f32x16 (&v)[NBK], const SplineRows<NBK, NO>& R, int o, float t) {
-    float part = 0.0f;
+    for (int o = 0; o < NO; ++o) part[o] = 0.0f;
+    if (NBK > 1) row_sums();
 #pragma unroll
     for (int kb = 0; kb < NBK; ++kb) {
-        float sa0 = 0.0f, sa1 = 0.0f, sb0 = 0.0f, sb1 = 0.0f;
+        f32x16 A[NO], Bv[NO];
+        if (kb > 0) __builtin_amdgcn_sched_barrier(0);
+        fetch_block<NBK, NO, FAR>(A, Bv, tab, Lp, h, bnd, kb);
+        if (NBK == 1) row_sums();
+        float sa[NO][2], sb[NO][2];
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-            sa0 = __builtin_fmaf(v[kb][r], R.a[o][kb][r], sa0);
-            sb0 = __builtin_fmaf(v[kb][r], R.b[o][kb][r], sb0);
-            sa1 = __builtin_fmaf(v[kb][r + 1], R.a[o][kb][r + 1], sa1);
-            sb1 = __builtin_fmaf(v[kb][r + 1], R.b[o][kb][r + 1], sb1);
+        for (int o = 0; o < NO; ++o) sa[o][0] = sa[o][1] = sb[o][0] = sb[o][1] = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2)
+#pragma unroll
+            for (int o = 0; o < NO; ++o) {
+                sa[o][0] = __builtin_fmaf(v[kb][r], A[o][r], sa[o][0]);
+                sb[o][0] = __builtin_fmaf(v[kb][r], Bv[o][r], sb[o][0]);
+                sa[o][1] = __builtin_fmaf(v[kb][r + 1], A[o][r + 1], sa[o][1]);
+                sb[o][1] = __builtin_fmaf(v[kb][r + 1], Bv[o][r + 1], sb[o][1]);
+            }
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+            const float Aa = sa[o][0] + sa[o][1], Bb = sb[o][0] + sb[o][1];
+            part[o] += __builtin_fmaf(Bb - Aa, Lp.t, Aa);
         }
-        const float A = sa0 + sa1, Bv = sb0 + sb1;
-        part += __builtin_fmaf(Bv - A, t, A);
     }
-    return xhalf_sum(part);
+#pragma unroll
+    for (int o = 0; o < NO; ++o) out[o] = xhalf_sum(part[o]);
+}
+// any lane of the wave whose right end is not its left record's second side (negative indices: rare) -> the FAR instantiation, for the
+// whole evaluation (a branch around the fetch alone would make every row live at its end)
+__device__ __forceinline__ bool any_far(const Lerp& Lp) { return __builtin_amdgcn_ballot_w64(Lp.ir != Lp.il && Lp.ir != Lp.il + 1) != 0; }
+
+// the prior's sum_r v_r * lerp(row_r): one-order table
+template <int NBK>
+__device__ __forceinline__ float rows_dot(const f32x16 (&v)[NBK], const float* __restrict__ tab, const Lerp& Lp, int h, const float* bnd) {
+    float out[1];
+    if (!any_far(Lp)) rows_lerp_dot<NBK, 1, false>(v, tab, Lp, h, bnd, out);
+    else rows_lerp_dot<NBK, 1, true>(v, tab, Lp, h, bnd, out);
+    return out[0];
 }
 
-// y and log(dy + 1e-7) of one I-spline block from its weights v (unnormalised), rS = 1/sum(q), rs = reg * S1.
+// y and log(dy + 1e-7) of one I-spline block from its weights v (unnormalised), rS = 1/sum(q), rs = reg * S1; rsum: [mesh][2] row sums
 template <int NBK>
-__device__ __forceinline__ void ispline_eval(const f32x16 (&v)[NBK], const SplineRows<NBK, 2>& R, float t, float rS, float rs, float& y, float& logdy) {
-    float ynum = lerp_dot<NBK, 2>(v, R, 0, t);
-    float dnum = lerp_dot<NBK, 2>(v, R, 1, t);
-    ynum = __builtin_fmaf(rs, __builtin_fmaf(R.rr[0] - R.rl[0], t, R.rl[0]), ynum);
-    dnum = __builtin_fmaf(rs, __builtin_fmaf(R.rr[1] - R.rl[1], t, R.rl[1]), dnum);
+__device__ __forceinline__ void ispline_eval(const f32x16 (&v)[NBK], const float* __restrict__ tab, const float* __restrict__ rsum, const Lerp& Lp, int h,
+                                             const float* bnd, float rS, float rs, float& y, float& logdy) {
+    float num[2], rl[2], rr[2];
+    if (!any_far(Lp)) rows_lerp_dot<NBK, 2, false>(v, tab, Lp, h, bnd, num, rsum, rl, rr);
+    else rows_lerp_dot<NBK, 2, true>(v, tab, Lp, h, bnd, num, rsum, rl, rr);
+    const float ynum = __builtin_fmaf(rs, __builtin_fmaf(rr[0] - rl[0], Lp.t, rl[0]), num[0]);
+    const float dnum = __builtin_fmaf(rs, __builtin_fmaf(rr[1] - rl[1], Lp.t, rl[1]), num[1]);
     y = ynum * rS;
     logdy = fast_log(__builtin_fmaf(dnum, rS, 1e-7f));
 }
@@ -517,7 +540,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
     const float* fkI = lds;                        // [NBK][2][16] remove_bias * keep factors of the flow-layer I-spline
     const float* fkP = lds + 32 * NBK;             // [NBK][2][16] prior: keep (B) or remove_bias * keep (M)
     const float* ob2b = lds + 64 * NBK;            // [NBK out][NBK in]{hi, lo}[2 K steps][64][8 halves] ob_to_b in f16-MFMA A order
-    const float* bndI = ob2b + NBK * NBK * 1024;   // int32 [NBK][2][16]: support bounds of the table pieces (fetch_rows), at the lane stride of fkI / fkP
+    const float* bndI = ob2b + NBK * NBK * 1024;   // int32 [NBK][2][16]: support bounds of the table pieces (fetch_block), at the lane stride of fkI / fkP
     const float* bndP = bndI + 32 * NBK;
     float* slots = lds + mm.const_floats;
     const int64_t n_tiles = (B + 31) >> 5;
@@ -665,10 +688,8 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
                         const float rS = __builtin_amdgcn_rcpf(__builtin_fmaf(rs, mm.F_I, Sf));
                         const Lerp Lp = make_lerp(cur[t][d], mm.n_mesh, rn_mesh, exact_div);
                         if (IDX && idx[t]) { idx[t][(l * D + d) * 2] = Lp.xl; idx[t][(l * D + d) * 2 + 1] = Lp.xr; }
-                        SplineRows<NBK, 2> R;
-                        fetch_rows<NBK, 2, true>(R, mm.tabI, mm.rsI, Lp, h, bndI);
                         float ld;
-                        ispline_eval<NBK>(v[t], R, Lp.t, rS, rs, nxt[t][d], ld);
+                        ispline_eval<NBK>(v[t], mm.tabI, mm.rsI, Lp, h, bndI, rS, rs, nxt[t][d], ld);
                         logdet[t] = logdet[t] + ld;
                     }
                     STAMP(5);
@@ -816,9 +837,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
                                 for (int r = 0; r < 16; ++r) n2 = __builtin_fmaf(c[ko][r], c[ko][r], n2);
                             }
                             const float rnorm = __builtin_amdgcn_rsqf(xhalf_sum(n2));
-                            SplineRows<NBK, 1> RP;   // prior rows [mesh][kb][h][16], nd 0
-                            fetch_rows<NBK, 1, false>(RP, mm.tabP, nullptr, Lp[t], h, bndP);
-                            const float v0 = lerp_dot<NBK, 1>(c, RP, 0, Lp[t].t) * rnorm;
+                            const float v0 = rows_dot<NBK>(c, mm.tabP, Lp[t], h, bndP) * rnorm;
                             val[t] = (s1 < 0.0f && !mm.prior_quotient) ? -v0 : v0;
                         }
                     } else {
@@ -836,9 +855,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
                         for (int t = 0; t < T; ++t) {
                             float S1, Sf;
                             sigmoid_block<NBK>(v[t], fkP, h, S1, Sf, gate_p, gp[t], net + NetOff<D, NBK>::z + d * NBK * 32);
-                            SplineRows<NBK, 1> RP;
-                            fetch_rows<NBK, 1, false>(RP, mm.tabP, nullptr, Lp[t], h, bndP);
-                            val[t] = lerp_dot<NBK, 1>(v[t], RP, 0, Lp[t].t) * __builtin_amdgcn_rcpf(Sf);
+                            val[t] = rows_dot<NBK>(v[t], mm.tabP, Lp[t], h, bndP) * __builtin_amdgcn_rcpf(Sf);
                         }
                     }
 #pragma unroll

@@ -706,42 +706,48 @@ static void row_factors(int kind, bool with_remove_bias, int k, int nb, int nbk,
         for (int j = 0; j < 64; ++j) natural64[j] = f[j];
 }
 
-// [n_mesh][n_orders][nbk][half][16], each row scaled by fk (acc layout [kb][h][16], may be null); rowsum (may be null): [n_mesh][n_orders]
-static void pack_rows_acc(const std::vector<double>& t64, int nb, int n_mesh, int n_orders, int nbk, const float* fk_acc,
-                          std::vector<float>& out, std::vector<float>* rowsum) {
-    out.assign((size_t)n_mesh * n_orders * nbk * 32, 0.0f);
+// Spline table of the MFMA kernel: [n_mesh][8 * nbk pieces][n_orders][2 sides][4 rows].  Piece p = natural rows 4p .. 4p+3 (a lane of
+// walker half h holds the pieces 8 kb + 2q + h, q = 0..3, of every 32-row block in its accumulator registers); side 0 = mesh point m,
+// side 1 = mesh point min(m + 1, n_mesh - 1): the two ends of the reference's lerp (isplines_jax.py:45-56) and both derivative orders of
+// a piece are one 64-byte record (32 bytes for the one-order prior table), so a lane's four records are all it reads for a spline
+// evaluation.  Rows scaled by fk (acc layout [kb][h][16], may be null); rowsum (may be null): [n_mesh][n_orders].
+static void pack_rows_pairs(const std::vector<double>& t64, int nb, int n_mesh, int n_orders, int nbk, const float* fk_acc,
+                            std::vector<float>& out, std::vector<float>* rowsum) {
+    const int n_pieces = 8 * nbk;
+    out.assign((size_t)n_mesh * n_pieces * n_orders * 8, 0.0f);
     if (rowsum) rowsum->assign((size_t)n_mesh * n_orders, 0.0f);
+    auto entry = [&](int nd, int row, int m) {
+        const float t = (float)t64[((size_t)nd * nb + row) * n_mesh + m];   // the reference's fp32 table entry
+        if (!fk_acc) return t;
+        const int kb = row >> 5, w = row & 31, h = (w >> 2) & 1, r = (w & 3) + 4 * (w >> 3);   // acc_row(r, h) == w
+        return (float)((double)fk_acc[(kb * 2 + h) * 16 + r] * (double)t);
+    };
     for (int m = 0; m < n_mesh; ++m)
         for (int nd = 0; nd < n_orders; ++nd) {
             double rs = 0.0;
-            for (int kb = 0; kb < nbk; ++kb)
-                for (int h = 0; h < 2; ++h)
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = 32 * kb + acc_row(r, h);
-                        if (row >= nb) continue;
-                        const float t = (float)t64[((size_t)nd * nb + row) * n_mesh + m];   // the reference's fp32 table entry
-                        const float v = fk_acc ? (float)((double)fk_acc[(kb * 2 + h) * 16 + r] * (double)t) : t;
-                        out[((((size_t)m * n_orders + nd) * nbk + kb) * 2 + h) * 16 + r] = v;
-                        rs += (double)v;
-                    }
+            for (int row = 0; row < nb; ++row) {
+                const int pc = row >> 2, e = row & 3;
+                for (int sd = 0; sd < 2; ++sd)
+                    out[((((size_t)m * n_pieces + pc) * n_orders + nd) * 2 + sd) * 4 + e] = entry(nd, row, std::min(m + sd, n_mesh - 1));
+                rs += (double)entry(nd, row, m);
+            }
             if (rowsum) (*rowsum)[(size_t)m * n_orders + nd] = (float)rs;
         }
 }
 
-// Support bounds of the 4-row pieces of a pack_rows_acc table: for piece q of (block kb, half h), bnd[(kb*2+h)*16+q*2+0] = the
-// last mesh index up to which the piece's entries (every order) equal those at mesh point 0, bnd[(kb*2+h)*16+q*2+1] = the first one
-// from which they equal those at the last mesh point.  Spline bases have local support (I-splines: 0 below, their full value above),
-// so a read at clamp(m, lo, hi) returns the bits of the read at m, and walkers outside a piece's support share two cache lines
-// instead of touching their own: found by comparing the table's actual fp32 entries, whatever the boundary map or the row factors made of them.
+// Support bounds of the records of a pack_rows_pairs table: for piece 8 kb + 2q + h, bnd[(kb*2+h)*16+q*2+0] = the last mesh index up
+// to which the piece's record equals the one at mesh point 0, bnd[(kb*2+h)*16+q*2+1] = the first one from which it equals the one
+// at the last mesh point.  Spline bases have local support (I-splines: 0 below it, their full value above), so a read at
+// clamp(m, lo, hi) returns the bits of the read at m, and the walkers outside a piece's support share two records instead of
+// touching their own: found by comparing the table's actual fp32 entries, whatever the boundary map or the row factors made of them.
 static void piece_bounds(const std::vector<float>& rows, int n_mesh, int n_orders, int nbk, int32_t* bnd) {
-    auto piece = [&](int m, int nd, int kb, int h, int q) { return &rows[((((size_t)m * n_orders + nd) * nbk + kb) * 2 + h) * 16 + 4 * q]; };
+    const int n_pieces = 8 * nbk, rec = n_orders * 8;
     for (int kb = 0; kb < nbk; ++kb)
         for (int h = 0; h < 2; ++h)
             for (int q = 0; q < 4; ++q) {
+                const int pc = 8 * kb + 2 * q + h;
                 auto same = [&](int m, int ref) {
-                    for (int nd = 0; nd < n_orders; ++nd)
-                        if (memcmp(piece(m, nd, kb, h, q), piece(ref, nd, kb, h, q), 4 * sizeof(float)) != 0) return false;
-                    return true;
+                    return memcmp(&rows[((size_t)m * n_pieces + pc) * rec], &rows[((size_t)ref * n_pieces + pc) * rec], rec * sizeof(float)) == 0;
                 };
                 int lo = 0, hi = n_mesh - 1;
                 while (lo + 1 < n_mesh && same(lo + 1, 0)) ++lo;
@@ -873,7 +879,7 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
         for (int i = 0; i < 32 * nbk; ++i) F += fk[i];
         md.F_I = (float)F;
         std::vector<float> rows, rowsum;
-        pack_rows_acc(i64, m->i_nb, d.n_mesh, 2, nbk, fk, rows, &rowsum);
+        pack_rows_pairs(i64, m->i_nb, d.n_mesh, 2, nbk, fk, rows, &rowsum);
         if (!getenv("WF_MFMA_NO_BAND")) piece_bounds(rows, d.n_mesh, 2, nbk, bnd);   // (the switch: tests compare both, bit for bit)
         int rc = upload_table(m, rows, &md.tabI);
         if (rc) return rc;
@@ -889,7 +895,7 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
         md.F_P = (float)F;
         std::vector<float> rows;
         // M prior: the row factors are folded into the table; B prior: they act on the weights before ob_to_b
-        pack_rows_acc(p64, m->p_nb, d.n_mesh, 1, nbk, mflow ? fk : nullptr, rows, nullptr);
+        pack_rows_pairs(p64, m->p_nb, d.n_mesh, 1, nbk, mflow ? fk : nullptr, rows, nullptr);
         if (!getenv("WF_MFMA_NO_BAND")) piece_bounds(rows, d.n_mesh, 1, nbk, bnd + 32 * nbk);
         int rc = upload_table(m, rows, &md.tabP);
         if (rc) return rc;
