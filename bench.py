@@ -31,9 +31,9 @@ PEAK_HBM_GBS = 8000.0
 MFMA_F16_PER_TILE, MFMA_F32_PER_TILE = 150, 8
 MFMA_FLOP_PER_EVAL = (MFMA_F16_PER_TILE * 32768 + MFMA_F32_PER_TILE * 4096) / 32
 # HBM bytes of one 2^20-walker log_pdf launch from the PMC passes of this command (separate rocprofv3 --pmc runs, scratch/pmc.sh):
-# FETCH_SIZE 8908 KB + WRITE_SIZE 4096 KB.  The walker read is 8 B per lane, not the 16 B-per-lane stream the guide's x2 FETCH_SIZE
+# FETCH_SIZE 10659 KB + WRITE_SIZE 4096 KB.  The walker read is 8 B per lane, not the 16 B-per-lane stream the guide's x2 FETCH_SIZE
 # correction is calibrated on (the sum already equals the 12.6 MB of algorithmic bytes), so no correction is applied.
-PMC_TRAFFIC = {"bytes": (8908 + 4096) * 1024, "source": "profiles/r02_pmc_summary.txt"}
+PMC_TRAFFIC = {"bytes": (10659 + 4096) * 1024, "source": "profiles/r02_pmc_summary.txt"}
 # reverse sweep of one walker, He, in the (value, gradient, Laplacian) algebra RF<2> = 4 channels: per net 2 dense 64x64 products
 # (+ the 32x32 change of basis of the prior, forward and transposed, for 2 dimensions), FMA = 2 FLOP
 VQMC_BWD_FLOP_PER_WALKER = 2 * (4 * 2 * 64 * 64 * 4 + 2 * 2 * 32 * 32 * 4)
