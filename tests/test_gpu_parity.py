@@ -457,6 +457,33 @@ def test_mfma_kernel_is_bit_reproducible_other_shapes(D, knots):
         assert torch.equal(m.log_pdf(x), first)
 
 
+@pytest.mark.parametrize("kernel", KERNELS_ALL)
+def test_walkers_outside_the_box_wrap_like_the_reference(he_flat, kernel):
+    """A walker whose first electron sits outside the box has a negative last flow coordinate: x_l = floor(u * 1999) = -1 is a negative
+    index, which jnp wraps to the last mesh point while x_r = 0 (isplines_jax.py:48-49; oracle wrap_clamp).  The table-driven kernels
+    reach such a pair of mesh rows through their own path (k_mfma: the FAR instantiation, whose right lerp end comes from its own record).
+    Bin indices, u and log_pdf against the C oracle; walkers inside the box ride in the same waves."""
+    params, psi, log_pdf, om = he_models(he_flat, kernel)
+    g = np.random.default_rng(5)
+    x = sorted_walkers(4096, 2, 10.0, 31)
+    out = g.random(4096) < 0.25
+    x[out, 0] = -10.0 - g.uniform(1e-4, 4e-3, out.sum()).astype(np.float32)     # u_1 of the box layer in (-1/1999, 0): x_l = -1, x_r = 0
+    log_pdf.model.ensure_params(params)
+    if kernel == "wave":
+        lp, u = log_pdf.model.log_pdf(x, return_sample=True)
+        lpo, uo = om.log_pdf(he_flat, x, return_u=True)
+    else:
+        lp, u, idx = log_pdf.model.log_pdf(x, return_sample=True, return_bin_idx=True)
+        lpo, uo, idxo = om.log_pdf(he_flat, x, return_u=True, return_idx=True)
+        assert (idxo[out, 0] < 0).any(), "the batch holds no negative index"
+        assert np.array_equal(idx[:, 0], idxo[:, 0])            # layer 0: bit-identical inputs
+        assert (idx != idxo).any(axis=(2, 3)).mean(axis=0).max() < 5e-3   # deeper layers: an index may flip at a mesh boundary (last-ulp inputs)
+    fin = np.isfinite(lpo)
+    assert np.array_equal(np.isfinite(lp), fin)
+    close(u[fin], uo[fin], rtol=0, atol=5e-6)
+    as_accurate_as_fp32_reference(lp[fin], lpo[fin], om.log_pdf(he_flat, x, f64=True)[fin])
+
+
 @pytest.mark.parametrize("D,knots", [(2, 23), (3, 23), (2, 33)])
 def test_mfma_support_clamped_table_reads_change_no_bit(D, knots):
     """The MFMA kernel reads every 4-row piece of a spline-table row at the mesh index clamped to the piece's support (wf_model.cpp:
