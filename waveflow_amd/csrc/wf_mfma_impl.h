@@ -360,6 +360,27 @@ __device__ __forceinline__ void fetch_block(f32x16 (&A)[NO], f32x16 (&Bv)[NO], c
         }
     }
 }
+// part[o] += lerp of (sum_r v_r a_r, sum_r v_r b_r) for one block's rows: two partial sums per end (even / odd registers), in register order
+template <int NO>
+__device__ __forceinline__ void block_dot(const f32x16& v, const f32x16 (&A)[NO], const f32x16 (&Bv)[NO], float t, float (&part)[NO]) {
+    float sa[NO][2], sb[NO][2];
+#pragma unroll
+    for (int o = 0; o < NO; ++o) sa[o][0] = sa[o][1] = sb[o][0] = sb[o][1] = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; r += 2)
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+            sa[o][0] = __builtin_fmaf(v[r], A[o][r], sa[o][0]);
+            sb[o][0] = __builtin_fmaf(v[r], Bv[o][r], sb[o][0]);
+            sa[o][1] = __builtin_fmaf(v[r + 1], A[o][r + 1], sa[o][1]);
+            sb[o][1] = __builtin_fmaf(v[r + 1], Bv[o][r + 1], sb[o][1]);
+        }
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+        const float Aa = sa[o][0] + sa[o][1], Bb = sb[o][0] + sb[o][1];
+        part[o] += __builtin_fmaf(Bb - Aa, t, Aa);
+    }
+}
 // sum over the walker's 32 * NBK rows of v_r * lerp(T'_r) for NO derivative orders (summed over the two lane halves); the products
 // follow the records' arrival order.  rsum (may be null): the row sums [mesh][NO] -> rl, rr.  One block per dimension: all records are
 // requested first, the row sums behind them.  Two blocks: the row sums first, then block by block -- the second block's records are
@@ -387,23 +408,7 @@ __device__ __forceinline__ void rows_lerp_dot(const f32x16 (&v)[NBK], const floa
         if (kb > 0) __builtin_amdgcn_sched_barrier(0);
         fetch_block<NBK, NO, FAR>(A, Bv, tab, Lp, h, bnd, kb);
         if (NBK == 1) row_sums();
-        float sa[NO][2], sb[NO][2];
-#pragma unroll
-        for (int o = 0; o < NO; ++o) sa[o][0] = sa[o][1] = sb[o][0] = sb[o][1] = 0.0f;
-#pragma unroll
-        for (int r = 0; r < 16; r += 2)
-#pragma unroll
-            for (int o = 0; o < NO; ++o) {
-                sa[o][0] = __builtin_fmaf(v[kb][r], A[o][r], sa[o][0]);
-                sb[o][0] = __builtin_fmaf(v[kb][r], Bv[o][r], sb[o][0]);
-                sa[o][1] = __builtin_fmaf(v[kb][r + 1], A[o][r + 1], sa[o][1]);
-                sb[o][1] = __builtin_fmaf(v[kb][r + 1], Bv[o][r + 1], sb[o][1]);
-            }
-#pragma unroll
-        for (int o = 0; o < NO; ++o) {
-            const float Aa = sa[o][0] + sa[o][1], Bb = sb[o][0] + sb[o][1];
-            part[o] += __builtin_fmaf(Bb - Aa, Lp.t, Aa);
-        }
+        block_dot<NO>(v[kb], A, Bv, Lp.t, part);
     }
 #pragma unroll
     for (int o = 0; o < NO; ++o) out[o] = xhalf_sum(part[o]);
@@ -678,8 +683,8 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
                         for (int t = 0; t < T; ++t) v[t][kb] = o[t];
                     }
                     STAMP(3);
-                    // (Requesting the table rows before the output MFMAs -- they depend on the layer input only -- costs 64 * NBK live
-                    // registers per tile: measured slower at every workgroup shape, r02 notes in DESIGN.md.)
+                    // (Requesting the table rows before the output MFMAs, or before the sigmoids -- they depend on the layer input only --
+                    // costs 64 * NBK live registers per tile: spills at 12 and 16 waves, -2 % at 8; r02 notes in DESIGN.md.)
 #pragma unroll
                     for (int t = 0; t < T; ++t) {
                         float S1, Sf;
