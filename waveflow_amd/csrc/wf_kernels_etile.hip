@@ -70,6 +70,9 @@ __device__ __forceinline__ void st_store(float* __restrict__ st, int slot, int64
 #ifndef WF_ETILE_WAVES
 #define WF_ETILE_WAVES 4
 #endif
+#ifndef WF_ETILE_OCC
+#define WF_ETILE_OCC 1   // workgroups per CU the register budget is sized for
+#endif
 constexpr int kCondWaves = WF_ETILE_WAVES;   // 4: one wave per SIMD -- the four channel chains hold ~430 registers (accumulators in AGPRs)
 using O2 = NetOff<2, 1>;
 
@@ -131,7 +134,7 @@ __device__ __forceinline__ void init_acc(f32x16 (&acc)[NCH], const float* bias16
 }
 
 template <bool PRIOR>
-__global__ __launch_bounds__(kCondWaves * 64) void k_etile_cond(const MfmaDev mm, int net_index, const float* __restrict__ st, int64_t B,
+__global__ __launch_bounds__(kCondWaves * 64, WF_ETILE_OCC) void k_etile_cond(const MfmaDev mm, int net_index, const float* __restrict__ st, int64_t B,
                                                                 float* __restrict__ oj, float* __restrict__ s1buf) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ int next_tile;
