@@ -243,13 +243,13 @@ __global__ __launch_bounds__(kCondWaves * 64, WF_ETILE_OCC) void k_etile_cond(co
                 for (int r = 0; r < 16; ++r) a0[c][r] = acc[r] * sc;
             }
         }
-        // ---- store: oj[(row * 3 + c) * B + w], row = accumulator row of register r in lane half h
+        // ---- store: oj[tile][row][c][32 walkers] (one contiguous 12 KB block per tile), row = accumulator row of register r in lane half h
         if (valid) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
 #pragma unroll
-                for (int c = 0; c < NCH; ++c) oj[((int64_t)row * NCH + c) * B + w] = a0[c][r];
+                for (int c = 0; c < NCH; ++c) oj[(tile * (32 * NCH) + row * NCH + c) * 32 + j] = a0[c][r];
             }
         }
     }
@@ -327,8 +327,8 @@ __global__ __launch_bounds__(256) void k_etile_flow(const float4_t* __restrict__
         for (int q = 0; q < 4; ++q) {
             const int jr_ = j0 + q;
             if (jr_ >= nb) break;
-            const float* p = oj + (int64_t)jr_ * NCH * B + b;
-            const J v = jr(japply(u0, p[0], p[B], p[2 * B]));     // the head's triple in u_0 -> jet in (x0, x1)
+            const float* p = oj + ((b >> 5) * (32 * NCH) + jr_ * NCH) * 32 + (b & 31);     // [tile][row][channel][32 walkers]
+            const J v = jr(japply(u0, p[0], p[32], p[64]));     // the head's triple in u_0 -> jet in (x0, x1)
             const float g = gI[jr_];
             float t[4];
 #pragma unroll
@@ -393,8 +393,8 @@ __global__ __launch_bounds__(256) void k_etile_prior(const float4_t* __restrict_
         for (int q = 0; q < 4; ++q) {
             const int i = i0 + q;
             if (i >= nb) break;
-            const float* p = oj + (int64_t)i * NCH * B + b;
-            const J c = japply(u0, p[0], p[B], p[2 * B]);        // (the conditioner sees the unclipped u_0, wavefunctions.py:40)
+            const float* p = oj + ((b >> 5) * (32 * NCH) + i * NCH) * 32 + (b & 31);
+            const J c = japply(u0, p[0], p[32], p[64]);        // (the conditioner sees the unclipped u_0, wavefunctions.py:40)
             float t[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -439,7 +439,7 @@ int check() {
 }  // namespace
 
 // workspace: state (12 floats), head triples (96 floats), the sign sum (1 float) per walker
-int64_t energy_tile_floats(int64_t B) { return B * (12 + 32 * NCH + 1); }
+int64_t energy_tile_floats(int64_t B) { return B * (12 + 1) + ((B + 31) / 32) * 32 * (32 * NCH); }   // state, s1, head triples of whole tiles
 
 // mdev: the model's MFMA description (resident or not: one net is staged per launch); md: ModelDev on the host (spline sizes, masks)
 int launch_energy_tile(const MfmaDev* mdev, const ModelDev& md, const float* tabI4, const float* tabP4, const float* fk_nat, const float* x, int64_t B,
@@ -447,8 +447,8 @@ int launch_energy_tile(const MfmaDev* mdev, const ModelDev& md, const float* tab
     hipStream_t s = (hipStream_t)stream;
     if (B == 0) return WF_OK;
     float* st = ws;
-    float* oj = st + 12 * B;
-    float* s1 = oj + (int64_t)32 * NCH * B;
+    float* s1 = st + 12 * B;
+    float* oj = s1 + B;
     const unsigned lane_blocks = (unsigned)((B + 255) / 256);
     const int lds_bytes = (mdev->const_floats + mdev->net_floats) * (int)sizeof(float);
     static int configured = -1;
