@@ -71,9 +71,9 @@ __device__ __forceinline__ void st_store(float* __restrict__ st, int slot, int64
 #define WF_ETILE_WAVES 4
 #endif
 #ifndef WF_ETILE_OCC
-#define WF_ETILE_OCC 1   // workgroups per CU the register budget is sized for
+#define WF_ETILE_OCC 2   // workgroups per CU the register budget is sized for: 256 registers, two waves per SIMD (the per-lane store addresses spill: 23 reloads per tile)
 #endif
-constexpr int kCondWaves = WF_ETILE_WAVES;   // 4: one wave per SIMD -- the four channel chains hold ~430 registers (accumulators in AGPRs)
+constexpr int kCondWaves = WF_ETILE_WAVES;   // 4 waves per workgroup, WF_ETILE_OCC workgroups per CU (unbounded, the three channel chains take 324 registers: one wave per SIMD)
 using O2 = NetOff<2, 1>;
 
 // ---------------------------------------------------------------------------- conditioner of one net, jets on the matrix cores
@@ -244,7 +244,11 @@ __global__ __launch_bounds__(kCondWaves * 64, WF_ETILE_OCC) void k_etile_cond(co
             }
         }
         // ---- store: oj[tile][row][c][32 walkers] (one contiguous 12 KB block per tile), row = accumulator row of register r in lane half h
+#ifdef WF_ABL_OJ   // ablation build (timing only): the head triples are computed, not stored
+        if (valid && a0[0][0] == 12345.678f) {
+#else
         if (valid) {
+#endif
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * h;

@@ -292,6 +292,7 @@ static int ensure_scratch(const wf_model* cm, int64_t floats);
 static constexpr int kTapedLaplacianMaxD = 8;    // largest D whose reverse sweep runs in RF (measured, scratch/grad_ab.py)
 static constexpr int64_t kWaveEvalMax = 6144;   // measured crossover ~7000 walkers (scratch/crossover.py)
 static constexpr int64_t kEnergyTileMin = 16384; // H psi: the tile path (8 launches, staged weight images) from here on
+static constexpr int64_t kEnergyTileChunk = (int64_t)1 << 19;   // walkers per pass of the tile path (WF_ENERGY_TILE_CHUNK; 2^20 walkers: 1.20 ms in two passes, 1.30 in one, 1.34 in four)
 namespace wf {
 
 // layer_kind WF_LAYER_NSC: Flow(Serial((NeuralSplineCoupling [, Reverse]) x L), Normal | Uniform)
@@ -1376,10 +1377,14 @@ int wf_hamiltonian_fwd(const wf_model* m, const float* x_dev, int64_t B, const f
         const bool family = D == 2 && m->nbp == 32 && m->mfma_ok && d.box_kind == WF_BOX_MEAN && d.layer_kind == WF_LAYER_IMADE &&
                             d.n_flow_layers > 0 && !m->dev.i_gate && !m->dev.p_gate && m->d_tabI4c && m->d_tabP4c && !getenv("WF_ENERGY_R3");
         if (family && tile_min > 0 && B >= tile_min) {
-            rc = ensure_scratch(m, energy_tile_floats(chunk));
+            // the conditioner and the head kernels exchange 384 B per walker and net through the scratch buffer: chunks that keep it
+            // (and its re-use by the next net and the next chunk) inside the 256 MB memory-side cache instead of HBM
+            const char* ec = getenv("WF_ENERGY_TILE_CHUNK");
+            const int64_t tchunk = std::min<int64_t>(B, std::max<int64_t>(ec ? atoll(ec) : kEnergyTileChunk, 1024));
+            rc = ensure_scratch(m, energy_tile_floats(tchunk));
             if (rc) return rc;
-            for (int64_t c0 = 0; c0 < B; c0 += chunk) {
-                const int64_t bc = std::min(chunk, B - c0);
+            for (int64_t c0 = 0; c0 < B; c0 += tchunk) {
+                const int64_t bc = std::min(tchunk, B - c0);
                 rc = launch_energy_tile(&m->mdev, m->dev, m->d_tabI4c, m->d_tabP4c, m->d_grad_fk, x_dev + c0 * D, bc, pr, hpsi_dev + c0,
                                         psi_dev ? psi_dev + c0 : nullptr, laplacian_dev ? laplacian_dev + c0 : nullptr, m->d_scratch, stream);
                 if (rc) return rc;
