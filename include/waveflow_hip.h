@@ -202,7 +202,8 @@ int wf_sample(const wf_model* m, uint64_t seed, int64_t B, float* x_dev, float* 
  * isplines_jax.py:60-66) and the one-dimensional soft-Coulomb physics.get_potential (:60-76) for `n_protons` <= 8 protons at
  * `protons_host`.  hpsi_dev[B]; psi_dev[B] and laplacian_dev[B] may be NULL.  The local energy of vqmc.loss_fn_efficient
  * (vqmc.py:193-200) is hpsi / (psi + 1e-8).  Batches of >= 16384 walkers of two-particle models (<= 32 bases, mean-type box, ungated) run on the
- * matrix cores (wf_kernels_etile.hip; WF_ENERGY_TILE_MIN moves the switch), everything else on the wave-cooperative kernel: same function.
+ * matrix cores in passes of 2^19 walkers (wf_kernels_etile.hip; WF_ENERGY_TILE_MIN moves the switch, WF_ENERGY_TILE_CHUNK the pass size),
+ * everything else on the wave-cooperative kernel: same function.
  * Coverage: WF_PRIOR_WAVEFLOW models with IMADE layers, boundary constraints the spline tables carry (prior: every value 0; I layers: any
  * value, the coefficients being normalised), gated heads included;
  * D = 2..8 with <= 32 bases per dimension, D = 2..4 with 33..64. */
