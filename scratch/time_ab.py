@@ -38,7 +38,7 @@ for r in range(rounds):
     for lib in libs:
         env = dict(os.environ)
         if lib != "default":
-            env["WF_LIB"] = os.path.join(ROOT, "scratch", "variants", f"libwf_{lib}.so")
+            env["WF_LIB"] = os.path.join(ROOT, "scratch", "variants", f"libwf_{lib}.so"); env["WF_LIB_EXPERIMENT"] = "1"
         else:
             env.pop("WF_LIB", None)
         out = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True).stdout

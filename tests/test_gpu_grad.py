@@ -953,14 +953,25 @@ def test_deferred_evaluation_tables_contract(he_flat):
         small = m.psi(x[:2000])
         m.set_kernel("mfma")
         before = m.psi(x)
+        # H psi of a large batch (>= 16384 walkers: the matrix-core tile path reads the MFMA image and the composite tables) straight
+        # after the steps -- the header promises wf_hamiltonian_fwd needs no refresh: while the tables are stale it stays on the wave sweeps
+        xe = torch.as_tensor(sorted_walkers(20000, 2, 9.0, 5)).cuda()
+        h_before = torch.stack(m.hamiltonian(xe, protons, return_psi=True, return_laplacian=True))
         m.set_params_device(flat)
         after = m.psi(x)
+        h_after = torch.stack(m.hamiltonian(xe, protons, return_psi=True, return_laplacian=True))
         m.set_kernel("auto")
-        out[defer] = (flat.clone(), small, before, after, st["ring"].clone())
+        out[defer] = (flat.clone(), small, before, after, st["ring"].clone(), h_before, h_after)
     # same trajectory either way; the wave kernel and the refreshed large-batch kernel agree in both
     assert torch.equal(out[False][0], out[True][0]) and torch.equal(out[False][4], out[True][4])
     assert torch.equal(out[False][1], out[True][1]) and torch.equal(out[False][3], out[True][3])
     assert torch.equal(out[False][2], out[False][3])            # not deferred: current on exit
     assert not torch.equal(out[True][2], out[True][3])          # deferred: stale until the refresh
+    # H psi, psi, laplacian of 20000 walkers: identical trajectories -> the refreshed (tile-path) values are bit-equal in both runs, the
+    # not-deferred run takes the tile path before and after, and the deferred run's wave-sweep values agree with the tile path's
+    assert torch.equal(out[False][6], out[True][6]) and torch.equal(out[False][5], out[False][6])
+    for k in range(3):
+        a, b = out[True][5][k].double(), out[True][6][k].double()
+        assert torch.isfinite(a).all() and float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()), (k, float((a - b).abs().max()), float(b.abs().max()))
     # (two fp32 kernels, each within 2.5e-5 of max|psi| of the reference's golden grid: their difference is bounded by the sum)
     np.testing.assert_allclose(out[True][3][:2000].cpu().numpy(), out[True][1].cpu().numpy(), rtol=0, atol=4e-5 * float(out[True][1].abs().max()))

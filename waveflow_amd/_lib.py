@@ -4,7 +4,12 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("WF_LIB") or os.path.join(HERE, "libwaveflow_hip.so")   # WF_LIB: experiment builds (scratch/)
+DEFAULT_LIB = os.path.join(HERE, "libwaveflow_hip.so")
+# WF_LIB: experiment builds under scratch/variants only (A/B timing scripts).  It is honoured only together with WF_LIB_EXPERIMENT=1 and the
+# loaded path is reported on stderr: tests/conftest.py builds and validates the default library, nothing else.
+if os.environ.get("WF_LIB") and os.environ.get("WF_LIB_EXPERIMENT") != "1":
+    raise ImportError("WF_LIB is set without WF_LIB_EXPERIMENT=1: refusing to load a library other than " + DEFAULT_LIB)
+LIB_PATH = os.environ.get("WF_LIB") or DEFAULT_LIB
 
 WF_MAX_DIM, WF_MAX_BC = 16, 4
 SPLINE_M, SPLINE_I, SPLINE_B, SPLINE_OB = 0, 1, 2, 3
@@ -80,6 +85,9 @@ def lib():
     # PyTorch ships its own libamdhip64.so.7; importing torch first makes this library bind to that same
     # HIP runtime (one runtime per process: streams and device pointers are shared with torch).
     import torch  # noqa: F401
+    if LIB_PATH != DEFAULT_LIB:
+        import sys
+        print(f"waveflow_amd: experiment library {LIB_PATH}", file=sys.stderr)
     L = ctypes.CDLL(LIB_PATH)
     vp, i32, i64, f32p = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p
     L.wf_abi_version.restype = i32

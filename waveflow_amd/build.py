@@ -16,8 +16,11 @@ SOURCES = ["wf_tables.cpp", "wf_model.cpp", "wf_kernels_scalar.hip", "wf_scalar_
 # multiply / add roundings; dot products that may fuse say so with explicit fmaf / MFMA.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 FLAGS += os.environ.get("WF_CXXFLAGS", "").split()  # experiment switches (-DWF_...)
-# No packed-FP32 VALU code (v_pk_fma_f32 ...) in the translation units of the MFMA kernel: wf_mfma_impl.h, DESIGN.md §9.
-MFMA_FLAGS = ["-fno-slp-vectorize"]
+# No packed-FP32 VALU code (v_pk_fma_f32 ...) in the translation units of the MFMA kernels: wf_mfma_impl.h, DESIGN.md §9.  The SLP
+# vectorizer is one source of it, instruction selection of two-element float vectors another (the box transform's differences came out as
+# v_pk_add_f32 in the D >= 3 builds): the target feature is switched off for these units (the host pass does not know the feature and says
+# so on stderr; harmless), and isa_guard.check() disassembles the linked library and refuses it if one is left.
+MFMA_FLAGS = ["-fno-slp-vectorize", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 
 
 def _hipcc():
@@ -88,7 +91,19 @@ def build(force=False, verbose=False):
             list(ex.map(run, jobs))
     objs = [os.path.join(OBJ, s + ".o") for s in srcs]
     if jobs or force or not os.path.exists(LIB) or any(os.path.getmtime(LIB) < os.path.getmtime(o) for o in objs):
-        run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+        tmp = LIB + ".tmp"
+        run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs)
+        if os.environ.get("WF_SKIP_ISA_GUARD") != "1":   # (scratch builds of deliberately packed variants only)
+            import importlib.util   # (by path: this file also runs as a script)
+            spec = importlib.util.spec_from_file_location("wf_isa_guard", os.path.join(HERE, "isa_guard.py"))
+            isa_guard = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(isa_guard)
+            try:
+                isa_guard.check(tmp)
+            except Exception:
+                os.remove(tmp)
+                raise
+        os.replace(tmp, LIB)
     with open(STAMP, "w") as f:
         f.write(_flags_text())
     return LIB

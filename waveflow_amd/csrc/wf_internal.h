@@ -232,4 +232,11 @@ int64_t block_sums_ws_bytes(int64_t B);
 
 void set_hip_error(int e);
 
+// hipFuncAttributeMaxDynamicSharedMemorySize of one kernel, remembered per device: `slots` is that kernel's own table (zero-initialised
+// static, one entry per device ordinal).  The attribute is per device and the call is idempotent, so two threads racing on one entry
+// both set a value >= what they need; a model on a second GPU of the process gets its own call.
+constexpr int kMaxDevices = 64;
+struct DynLdsSlots { int bytes[kMaxDevices]; };
+int ensure_dynamic_lds(const void* kernel, int lds_bytes, DynLdsSlots* slots);
+
 }  // namespace wf

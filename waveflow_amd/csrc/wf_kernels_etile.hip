@@ -455,13 +455,9 @@ int launch_energy_tile(const MfmaDev* mdev, const ModelDev& md, const float* tab
     float* oj = s1 + B;
     const unsigned lane_blocks = (unsigned)((B + 255) / 256);
     const int lds_bytes = (mdev->const_floats + mdev->net_floats) * (int)sizeof(float);
-    static int configured = -1;
-    if (lds_bytes > configured) {
-        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_etile_cond<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_etile_cond<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        if (e1 != hipSuccess || e2 != hipSuccess) { set_hip_error((int)(e1 != hipSuccess ? e1 : e2)); return WF_ERR_HIP; }
-        configured = lds_bytes;
-    }
+    static DynLdsSlots cfg_flow{}, cfg_prior{};
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(k_etile_cond<false>), lds_bytes, &cfg_flow)) return rc;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(k_etile_cond<true>), lds_bytes, &cfg_prior)) return rc;
     const int64_t n_tiles = (B + 31) / 32;
     const unsigned cond_blocks = (unsigned)std::min<int64_t>((n_tiles + kCondWaves - 1) / kCondWaves, 256 * 4);
     hipLaunchKernelGGL(k_etile_box, dim3(lane_blocks), dim3(256), 0, s, x, B, md.box_L, st);

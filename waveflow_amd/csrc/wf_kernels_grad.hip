@@ -246,7 +246,10 @@ __global__ void k_zgrad_scatter(const float* __restrict__ zgrad, int n_rows, con
     const int32_t t = zmap[r];
     if (t < 0) return;
     float g = zgrad[r];
-    if (zraw_off[r] >= 0 && plain[zraw_off[r]] < 0.0f) g = -g;
+    if (zraw_off[r] >= 0) {   // d|z|/dz = sign(z), 0 at z = 0 (as jnp.abs differentiates)
+        const float raw = plain[zraw_off[r]];
+        g = raw < 0.0f ? -g : (raw > 0.0f ? g : 0.0f);
+    }
     flat[t] = g;
 }
 

@@ -663,12 +663,9 @@ int launch_rqs(const float* x, const float* uw, const float* uh, const float* ud
     const int lds_bytes = kRqsBlock * (K + 1) * (int)sizeof(float);
     int64_t blocks = (N + kRqsBlock - 1) / kRqsBlock;
     if (blocks > 256 * 8) blocks = 256 * 8;
-    static int configured = 0;
-    if (lds_bytes > 64 * 1024 && lds_bytes > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rqs), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        if (e != hipSuccess) { set_hip_error((int)e); return WF_ERR_HIP; }
-        configured = lds_bytes;
-    }
+    static DynLdsSlots cfg{};
+    if (lds_bytes > 64 * 1024)
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(k_rqs), lds_bytes, &cfg)) return rc;
     hipLaunchKernelGGL(k_rqs, dim3((unsigned)blocks), dim3(kRqsBlock), lds_bytes, (hipStream_t)stream, x, uw, uh, ud, N, K, n_deriv, inverse,
                        left, right, bottom, top, y, ld, bin);
     hipError_t e = hipGetLastError();

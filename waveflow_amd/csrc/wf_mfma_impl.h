@@ -934,16 +934,8 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
 
 template <int D, int NBK, int kWaves, int T, bool IDX, bool SPEC>
 int launch_dwi(const MfmaDev* mdev, int lds_bytes, int mode, const float* x, int64_t B, float* out, float* u, int32_t* idx, hipStream_t s) {
-    static int configured_bytes = -1;
-    if (lds_bytes > configured_bytes) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_mfma<D, NBK, kWaves, T, IDX, SPEC>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           lds_bytes);
-        if (e != hipSuccess) {
-            set_hip_error((int)e);
-            return WF_ERR_HIP;
-        }
-        configured_bytes = lds_bytes;
-    }
+    static DynLdsSlots cfg{};   // (one table per instantiation)
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(k_mfma<D, NBK, kWaves, T, IDX, SPEC>), lds_bytes, &cfg)) return rc;
     const int64_t n_tiles = (B + 31) / 32;
     int64_t grid = (n_tiles + kWaves * T - 1) / (kWaves * T);
     if (grid > 256) grid = 256;  // one persistent workgroup per CU

@@ -22,6 +22,24 @@ namespace wf {
 static thread_local int g_last_hip = 0;
 void set_hip_error(int e) { g_last_hip = e; }
 
+int ensure_dynamic_lds(const void* kernel, int lds_bytes, DynLdsSlots* slots) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = -1;
+    int* slot = dev >= 0 ? &slots->bytes[dev] : nullptr;
+    const int have = slot ? __atomic_load_n(slot, __ATOMIC_RELAXED) : 0;
+    if (slot && lds_bytes <= have) return WF_OK;
+    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (e != hipSuccess) {
+        set_hip_error((int)e);
+        return WF_ERR_HIP;
+    }
+    if (slot) {   // keep the maximum (another thread may have stored a larger request meanwhile)
+        int cur = have;
+        while (cur < lds_bytes && !__atomic_compare_exchange_n(slot, &cur, lds_bytes, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    }
+    return WF_OK;
+}
+
 #define WF_HIP(call)                                   \
     do {                                               \
         hipError_t e_ = (call);                        \
@@ -66,6 +84,10 @@ struct wf_model {
     std::vector<wf::NetLayout> nets;  // flow layers then (optionally) the prior net
     int64_t n_params = 0;
     bool params_set = false;
+    // a deferred training step (wf_train_state.defer_eval_tables) refreshed the weight images only: the MFMA image then holds unfolded
+    // biases and the composite dimension-0 tables are those of older parameters.  Cleared by the next full refresh; while it is set,
+    // wf_hamiltonian_fwd stays on the wave sweeps (which read neither) -- include/waveflow_hip.h promises it needs no refresh.
+    bool eval_tables_stale = false;
     wf::ModelDev dev{};
     std::vector<void*> allocs;
     // device images
@@ -1186,6 +1208,7 @@ static int apply_params(wf_model* m, const float* flat_dev, void* stream, bool e
         int rc = launch_prepare_dim0(m->d_dev, (int)m->nets.size(), m->desc.n_mesh, m->d_fk_nat, m->mdev.F_I, m->mdev.F_P, m->d_tabI4, m->d_tabP3, m->d_comp, stream);
         if (rc) return rc;
     }
+    if (m->mfma_ok) m->eval_tables_stale = !eval_tables;
     m->params_set = true;
     return WF_OK;
 }
@@ -1376,7 +1399,7 @@ int wf_hamiltonian_fwd(const wf_model* m, const float* x_dev, int64_t B, const f
         const wf_model_desc& d = m->desc;
         const bool family = D == 2 && m->nbp == 32 && m->mfma_ok && d.box_kind == WF_BOX_MEAN && d.layer_kind == WF_LAYER_IMADE &&
                             d.n_flow_layers > 0 && !m->dev.i_gate && !m->dev.p_gate && m->d_tabI4c && m->d_tabP4c && !getenv("WF_ENERGY_R3");
-        if (family && tile_min > 0 && B >= tile_min) {
+        if (family && tile_min > 0 && B >= tile_min && !m->eval_tables_stale) {
             // the conditioner and the head kernels exchange 384 B per walker and net through the scratch buffer: chunks that keep it
             // (and its re-use by the next net and the next chunk) inside the 256 MB memory-side cache instead of HBM
             const char* ec = getenv("WF_ENERGY_TILE_CHUNK");

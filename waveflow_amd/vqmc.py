@@ -107,9 +107,13 @@ def loss_and_grad_efficient(params, psi, h_fn, batch, running_average, group=Non
     if pos is None:
         raise TypeError("h_fn must come from waveflow_amd.utils.physics.construct_hamiltonian_function")
     # the tangent rule's 1 / batch factor is applied on the device, so the global count is needed up front
-    n_global = global_count(int(batch.shape[0]), f"cuda:{model.device}", group)
+    # `group=None` means NOT distributed in every function of this module (as in ModelTrainer): no collective is entered, whatever
+    # process group happens to be initialised -- a rank that passes None must not wait in an all-reduce its peers never reach.
+    # Sharded walkers: pass the group explicitly (torch.distributed.group.WORLD for the default one).
+    n_global = global_count(int(batch.shape[0]), f"cuda:{model.device}", group) if group is not None else int(batch.shape[0])
     sums, grad = model.vqmc_loss_grad(batch, pos, float(np.asarray(running_average).reshape(-1)[0]), global_count=n_global)
-    grad, sums = all_reduce_gradient_and_moments(grad, sums, group)   # one collective per step
+    if group is not None:
+        grad, sums = all_reduce_gradient_and_moments(grad, sums, group)   # one collective per step
     s = sums.cpu().tolist()
     return s[0] / s[2], grad, moments_to_stats(s)
 
@@ -133,7 +137,9 @@ def _energy_terms(params, psi, h_fn, batch):
 
 
 def _reduce_scalars(values, device, group):
-    """SUM all-reduce of a few python floats (fp64 on the wire) -> list of floats; the identity without a group."""
+    """SUM all-reduce of a few python floats (fp64 on the wire) -> list of floats; the identity for group=None (see loss_and_grad_efficient)."""
+    if group is None:
+        return [float(v) for v in values]
     import torch
     from .distributed import all_reduce_moments
     t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
@@ -141,6 +147,8 @@ def _reduce_scalars(values, device, group):
 
 
 def _reduce_gradient(grad, group):
+    if group is None:
+        return grad
     import torch
     from .distributed import all_reduce_gradient_and_moments
     g, _ = all_reduce_gradient_and_moments(grad, torch.zeros(3, dtype=torch.float64, device=grad.device), group)
