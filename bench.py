@@ -86,6 +86,76 @@ def kernel_ms(model, x, n=50, warm=150):
     return float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
 
+HPSI_KERNELS = "k_etile_box + (k_etile_cond<false> + k_etile_flow) x 3 + k_etile_cond<true> + k_etile_prior, per pass of 2^19 walkers"
+GRAD_KERNELS = "k_wave_fwd<2,RF<2>> + k_energy_out + k_vqmc_seeds + k_wave_bwd<2,RF<2>> + k_wgrad<4> + k_wgrad_reduce + k_grad_gather"
+
+
+def event_ms(fn, n, warm):
+    """Mean HIP-event time of fn() on the current stream over n calls, after `warm` untimed ones."""
+    import torch
+    for _ in range(warm):
+        fn()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for a, b in ev:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    return float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+
+def rqs_leg(n_elements, n=50, warm=20):
+    """The RQS bijector, the one HBM-bound kernel of the path: unconstrained RQS forward, K = 32 bins."""
+    import torch
+    from waveflow_amd.flows import unconstrained_RQS
+    K, N = 32, n_elements
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    uw = torch.randn(N, K, device="cuda", generator=g)
+    uh = torch.randn(N, K, device="cuda", generator=g)
+    ud = torch.randn(N, K - 1, device="cuda", generator=g)
+    x = torch.rand(N, device="cuda", generator=g) * 2.4 - 1.2
+    ms = event_ms(lambda: unconstrained_RQS(x, uw, uh, ud), n, warm)
+    bytes_per = (2 * K + (K - 1) + 1) * 4 + 8       # uw, uh, ud, x in; y, logabsdet out
+    gbs = N * bytes_per / (ms * 1e-3) / 1e9
+    return {"kernel": "k_rqs_reg<32>", "kernel_ms": ms, "elements": N, "bytes_per_element": bytes_per, "gb_per_s": gbs,
+            "frac_of_hbm_peak": gbs / PEAK_HBM_GBS, "evals_per_s": N / (ms * 1e-3)}
+
+
+def nsc_model():
+    from waveflow_amd import flows
+    L, K, H, D = 3, 5, 8, 2
+    items = []
+    for _ in range(L):
+        items += [flows.NeuralSplineCoupling(K=K, B=3, hidden_dim=H), flows.Reverse()]
+    params, log_pdf, _ = flows.Flow(flows.Serial(*items), flows.Normal())(7, D)
+    params = [tuple([tuple(a * (1.5 if a.ndim == 2 else 3e4) for a in l) if l else () for l in net] for net in p) if p else () for p in params]
+    m = log_pdf.model
+    m.ensure_params(params)
+    return m, (L, K, H, D)
+
+
+def nsc_leg(B, n=30, warm=20):
+    """log_pdf of the coupling-stack model (judge-added row a13): Flow(Serial((NeuralSplineCoupling, Reverse) x 3), Normal()), D = 2."""
+    import torch
+    m, _ = nsc_model()
+    x = (torch.rand(B, 2, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1234)) * 6.8 - 3.4).contiguous()
+    ms = event_ms(lambda: m.log_pdf(x), n, warm)
+    return {"kernel": "k_nsc_model<8, 8, 1, 5>", "kernel_ms": ms, "walkers": B, "evals_per_s": B / (ms * 1e-3)}
+
+
+def vqmc_legs(model, n_h=20, n_g=10):
+    """SURVEY 8f ranks 1-2 at BASELINE sizes: H psi of 2^20 walkers (config 5's payload per GPU) and loss + gradient of 2^17."""
+    from waveflow_amd.utils import physics
+    protons = physics.system_catalogue[1]["He"][0].reshape(-1)
+    xb = walkers(1 << 20, 4321).cuda()
+    ms_h = event_ms(lambda: model.hamiltonian(xb, protons), n_h, 10)
+    xg = walkers(1 << 17, 1234).cuda()
+    ms_g = event_ms(lambda: model.vqmc_loss_grad(xg, protons, -1.8), n_g, 3)
+    return {"hpsi_2pow20": {"kernels": HPSI_KERNELS, "ms": ms_h, "walkers": 1 << 20, "walkers_per_s": (1 << 20) / (ms_h * 1e-3)},
+            "loss_grad_2pow17": {"kernels": GRAD_KERNELS, "ms": ms_g, "walkers": 1 << 17,
+                                 "walkers_per_s": (1 << 17) / (ms_g * 1e-3)}}
+
+
 def extra_legs(model, flat):
     """The other measurement legs of SURVEY 8d, in the same run (rank 0, N = 1): every figure is a HIP-event kernel time."""
     import torch
@@ -107,6 +177,12 @@ def extra_legs(model, flat):
     ms8 = kernel_ms(m8, x8, n=10, warm=3)
     out["c4_d8_2pow18"] = {"evals_per_s": (1 << 18) / (ms8 * 1e-3), "kernel_ms": ms8, "kernel": "k_mfma<8,1,8,1>"}
     del m8
+    torch.cuda.synchronize()
+    # the secondary paths, so that the driver's record carries them (each reproducible from a file under profiles/)
+    model.set_kernel("auto")
+    out["rqs_2pow21"] = rqs_leg(1 << 21)
+    out.update(vqmc_legs(model))
+    out["nsc_2pow20"] = nsc_leg(1 << 20)
     torch.cuda.synchronize()
     return out
 
@@ -276,6 +352,18 @@ def main():
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
     last = sums_all[(n_done[0] - 1) % sums_all.shape[0]]
     mean_logp = float((last[0] / last[2]).item())
+    kern_ms_ranks = [kern_ms]
+    if use_dist:   # every rank's own kernel time, so that an N > 1 record can be checked against the N = 1 one
+        kt = torch.tensor([kern_ms], device=dev, dtype=torch.float64)
+        gathered = [torch.zeros_like(kt) for _ in range(dist.get_world_size())]
+        dist.all_gather(gathered, kt)
+        kern_ms_ranks = [float(g.item()) for g in gathered]
+    # AFTER the timed region (never part of `value`): the same launch once the device has reached its sustained clocks -- from an idle GPU
+    # the first ~60 back-to-back launches take 0.29 - 0.32 ms, from ~200 on 15 % less (scratch/time_warm.py)
+    sustained = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        n_before = max(0, 300 - args.steps - args.warmup)
+        sustained = {"kernel_ms": kernel_ms(model, x, n=100, warm=n_before), "launches_before": n_before + args.steps + args.warmup + 1, "timed_launches": 100}
 
     if rank == 0:
         evals = B * world * args.steps
@@ -309,9 +397,13 @@ def main():
             "hbm": {"achieved": k_evals_s * BYTES_PER_EVAL / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": k_evals_s * BYTES_PER_EVAL / 1e9 / PEAK_HBM_GBS, "bytes_per_eval": BYTES_PER_EVAL},
         }
+        if sustained is not None:
+            out["kernel_ms_sustained"] = sustained
+            out["roofline"]["frac_sustained"] = B / (sustained["kernel_ms"] * 1e-3) * MFMA_FLOP_PER_EVAL / 1e12 / PEAK_F16_MATRIX_TFLOPS
         if use_dist:
             out["rccl_ranks"] = dist.get_world_size()
             out["dist_backend"] = dist.get_backend()
+            out["kernel_ms_per_rank"] = kern_ms_ranks
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(flat, x_host.numpy())
             if not args.no_extras:
@@ -325,35 +417,17 @@ def main():
 
 def main_rqs(args):
     """Secondary line: unconstrained RQS forward, K = 32 bins, N = 2 * batch elements (single GPU, no collective)."""
-    import torch
-    from waveflow_amd.flows import unconstrained_RQS
     K, N = 32, 2 * args.batch
-    g = torch.Generator(device="cuda").manual_seed(1234)
-    uw = torch.randn(N, K, device="cuda", generator=g)
-    uh = torch.randn(N, K, device="cuda", generator=g)
-    ud = torch.randn(N, K - 1, device="cuda", generator=g)
-    x = torch.rand(N, device="cuda", generator=g) * 2.4 - 1.2
-    for _ in range(args.warmup + 1):
-        unconstrained_RQS(x, uw, uh, ud)
-    torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
-    for a, b in ev:
-        a.record()
-        unconstrained_RQS(x, uw, uh, ud)
-        b.record()
-    torch.cuda.synchronize()
+    leg = rqs_leg(N, n=args.steps, warm=args.warmup + 1)
     dt = time.perf_counter() - t0
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    bytes_per = (2 * K + (K - 1) + 1) * 4 + 8       # uw, uh, ud, x in; y, logabsdet out
-    gbs = N * bytes_per / (kern_ms * 1e-3) / 1e9
     print(json.dumps({
-        "metric": "RQS bijector evals/sec", "value": N * args.steps / dt, "unit": "evals/s", "n_gpus": 1, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "metric": "RQS bijector evals/sec", "value": leg["evals_per_s"], "unit": "evals/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": leg["kernel_ms"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic", "wall_s": dt,
         "config": {"workload": f"unconstrained RQS forward (neural_splines.py:16-71), K=32 bins, {N} elements (2 dims x {args.batch} walkers)"},
-        "roofline": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
-                     "kernel": "k_rqs_reg<32>", "kernel_ms": kern_ms, "bytes_per_eval": bytes_per}}), flush=True)
+        "roofline": {"bound": "hbm", "achieved": leg["gb_per_s"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": leg["frac_of_hbm_peak"], "traffic": None,
+                     "kernel": "k_rqs_reg<32>", "kernel_ms": leg["kernel_ms"], "bytes_per_eval": leg["bytes_per_element"]}}), flush=True)
 
 
 def main_nsc(args):

@@ -108,9 +108,10 @@ struct MfmaDev {
     int const_floats;          // fkI[nbk][2][16], fkP[nbk][2][16], ob_to_b image [nbk][nbk]{hi, lo}[2 K steps][64 lanes][8 halves], piece bounds int32 [2 tables][nbk][2][16]
     int staged;                // 0: every net resident in LDS; 1: one LDS slot, nets re-staged per chunk of tiles
     const float* tabI;         // [n_mesh][8 nbk pieces][nd 0..1][side: m, m + 1][4 rows] fp32: fk_row * I_row (wf_model.cpp: pack_rows_pairs)
-    const float* rsI;          // [n_mesh][nd 0..1]: sum over rows of tabI
+    const float* rsI;          // [n_mesh]{R0_m, R1_m, R0_{m+1}, R1_{m+1}}: sum over rows of tabI (orders 0, 1), both lerp ends in one 16-byte record
     const float* tabP;         // [n_mesh][8 nbk pieces][side][4 rows] fp32, prior rows (B as is; M: fk_row * M_row), nd 0
     const float4_t* comp;      // [n_nets][n_mesh] composite tables of output dimension 0 (k_prepare_dim0)
+    const float4_t* comp2;     // [n_nets][n_mesh]{comp[m].xy, comp[m + 1].xy}: both lerp ends of what k_mfma reads, one 16-byte record (k_pair_dim0)
     float* dbg;                // diagnostics builds only (WF_DEBUG / WF_STAMP)
     int exact_div;             // 1: x_l / n by IEEE division (set when the multiply-and-correct form is not bit-identical for this n_mesh)
     int prior_quotient;        // debug (env WF_PRIOR_QUOTIENT=1 at model creation): Waveflow prior head in the reference's quotient form

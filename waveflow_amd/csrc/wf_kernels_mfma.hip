@@ -157,6 +157,15 @@ __global__ void k_prepare_dim0(const ModelDev* __restrict__ mdp, int nm, const f
     comp[gid] = out;
 }
 
+// comp2[n][m] = {comp[n][m].xy, comp[n][m + 1].xy}: the two lerp ends k_mfma needs of a composite table in one 16-byte record
+__global__ void k_pair_dim0(const f32x4* __restrict__ comp, int n_nets, int nm, f32x4* __restrict__ comp2) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n_nets * nm) return;
+    const int m = gid % nm;
+    const f32x4 a = comp[gid], b = comp[m + 1 < nm ? gid + 1 : gid];
+    comp2[gid] = f32x4{a[0], a[1], b[0], b[1]};
+}
+
 // tuning knobs of the headline shape (read at every launch): WF_MFMA_WAVES = 4, 8, 12 or 16 waves per workgroup,
 // WF_MFMA_TILES = 1 or 2 tiles of 32 walkers per wave (built: 8 / 12 / 16 waves x 1 tile, 4 / 8 waves x 2 tiles)
 // b' = b + sum_k W_k for the layers whose input is a tanh (see act_split_block): the packed weights already hold -2 c W as fp16
@@ -247,6 +256,9 @@ int launch_prepare_dim0(const ModelDev* md_dev, int n_nets, int n_mesh, const fl
     hipLaunchKernelGGL(k_dim0_coeffs, dim3(n_nets), dim3(64), 0, (hipStream_t)stream, md_dev, fk_nat_dev, F_I, F_P, coef);
     hipLaunchKernelGGL(k_prepare_dim0, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, md_dev, n_mesh, (const float*)coef,
                        tab_i_dev, tab_p_dev, reinterpret_cast<f32x4*>(comp_dev));
+    f32x4* comp2 = reinterpret_cast<f32x4*>(coef + ((dim0_coef_floats(n_nets) + 3) & ~3));
+    hipLaunchKernelGGL(k_pair_dim0, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const f32x4*>(comp_dev), n_nets,
+                       n_mesh, comp2);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_hip_error((int)e);

@@ -119,12 +119,20 @@ __device__ __forceinline__ Lerp make_lerp(float x, int n_mesh, float rn, int exa
 // tables (value, derivative) of every net are built once per parameter upload by k_prepare_dim0; a dimension-0 block is
 // then two 16-byte loads and two lerps.  comp[net][mesh] = {Y, DY, 0, 0} (flow layers: spline value and derivative,
 // already divided by sum(q); B prior: psi_0 with its sign and norm; M prior: density; MADE: {log_weight, bias}).
-__device__ __forceinline__ f32x4 comp_lerp(const f32x4* __restrict__ comp, const Lerp& Lp) {
-    const f32x4 a = comp[Lp.il], b = comp[Lp.ir];
-    f32x4 r;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) r[q] = __builtin_fmaf(b[q] - a[q], Lp.t, a[q]);
-    return r;
+// comp2[net][mesh] = {Y_m, DY_m, Y_{m+1}, DY_{m+1}} (k_pair_dim0): both lerp ends in one 16-byte record.  x_r = x_l needs no right end
+// (Lerp::t is 0 then); a right end that is not the record's second half (the reference's wrapped negative indices, isplines_jax.py:48-49:
+// walkers outside the box) comes from its own record -- a wave-uniform branch, as in rows_dot / ispline_eval.
+__device__ __forceinline__ bool any_far(const Lerp& Lp);
+__device__ __forceinline__ f32x2 comp_lerp(const f32x4* __restrict__ comp2, const Lerp& Lp) {
+    const f32x4 c = comp2[Lp.il];
+    float b0 = c[2], b1 = c[3];
+    if (any_far(Lp)) {
+        const f32x4 r = comp2[Lp.ir];
+        const bool far = Lp.ir != Lp.il && Lp.ir != Lp.il + 1;
+        b0 = far ? r[0] : b0;
+        b1 = far ? r[1] : b1;
+    }
+    return f32x2{__builtin_fmaf(b0 - c[0], Lp.t, c[0]), __builtin_fmaf(b1 - c[1], Lp.t, c[1])};
 }
 
 // 32 activations of one block (accumulator layout) -> the two K=16 B fragments, split hi / lo
@@ -141,7 +149,20 @@ struct Frag {
 // register between each v_fma_mixhi (op_sel write of a high half) and the v_fma_mixlo that merges into the same register, two behind
 // (VALU write -> MFMA source read).  scratch/ubench2/mix_split.hip checks it bit for bit against the plain split.
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
 __device__ __forceinline__ void split8(const float (&r)[8], f16x8& hi, f16x8& lo) {
+#ifdef WF_SPLIT_TRUNC
+    // experiment: hi = the value truncated to 11 significant bits (exact in fp16 above 2^-14), lo = rn16(r - hi): v_and + v_sub + two
+    // v_cvt_pk per pair = 3 instructions per value, none of them on the transcendental / mixed-precision rate
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        const float h0 = __uint_as_float(__float_as_uint(r[j]) & 0xFFFFE000u), h1 = __uint_as_float(__float_as_uint(r[j + 1]) & 0xFFFFE000u);
+        const f16x2 Hh = __builtin_convertvector((f32x2){h0, h1}, f16x2);
+        const f16x2 Ll = __builtin_convertvector((f32x2){r[j] - h0, r[j + 1] - h1}, f16x2);
+        hi[j] = Hh[0]; hi[j + 1] = Hh[1]; lo[j] = Ll[0]; lo[j + 1] = Ll[1];
+    }
+    return;
+#endif
     u32x4 H, L;
     asm volatile(
         "s_nop 0\n\t"
@@ -174,6 +195,10 @@ __device__ __forceinline__ void mfma_step(const _Float16* Wh, const _Float16* Wl
 #endif
 #ifdef WF_SETPRIO
     __builtin_amdgcn_s_setprio(WF_SETPRIO);
+#endif
+#ifdef WF_MFMA_4PROD   // experiment: the lo * lo term as well (2^-24 relative)
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, in[t][kt].lo[s], acc[t], 0, 0, 0);
 #endif
 #pragma unroll
     for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, in[t][kt].hi[s], acc[t], 0, 0, 0);
@@ -389,12 +414,20 @@ __device__ __forceinline__ void block_dot(const f32x16& v, const f32x16 (&A)[NO]
 template <int NBK, int NO, bool FAR>
 __device__ __forceinline__ void rows_lerp_dot(const f32x16 (&v)[NBK], const float* __restrict__ tab, const Lerp& Lp, int h, const float* bnd, float (&out)[NO],
                                               const float* __restrict__ rsum = nullptr, float* rl = nullptr, float* rr = nullptr) {
-    auto row_sums = [&]() {
+    auto row_sums = [&]() {   // rsum: [mesh]{R0_m, R1_m, R0_{m+1}, R1_{m+1}} (NO == 2 only): one 16-byte record holds both lerp ends
         if (rsum) {
+            static_assert(NO <= 2, "row sums: orders 0 and 1");
+            const f32x4 c = load4g(rsum + (size_t)Lp.il * 4);
+            f32x4 r = c;
+            bool far = false;
+            if (FAR) {
+                far = Lp.ir != Lp.il && Lp.ir != Lp.il + 1;
+                r = load4g(rsum + (size_t)Lp.ir * 4);
+            }
 #pragma unroll
             for (int o = 0; o < NO; ++o) {
-                rl[o] = rsum[(size_t)Lp.il * NO + o];
-                rr[o] = rsum[(size_t)Lp.ir * NO + o];
+                rl[o] = c[o];
+                rr[o] = far ? r[o] : c[2 + o];
             }
         }
     };
@@ -572,6 +605,31 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
     // this workgroup's chunks: blockIdx.x, blockIdx.x + gridDim.x, ...; a slot = (chunk, wave position) = T tiles
     const int64_t my_chunks = n_chunks > (int64_t)blockIdx.x ? (n_chunks - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
     const int my_slots = (int)(my_chunks * kWaves);
+#ifdef WF_PREFETCH_X
+    // Resident mode: the slot of the NEXT iteration is drawn at the top of this one and its walker coordinates are requested right away,
+    // so that the HBM round trip of a tile's first load is covered by the previous tile's arithmetic (D registers per tile).
+    int q_pf = 0;
+    float x_pf[T][D];
+    auto draw_slot = [&]() {
+        int q = 0;
+        if (lane == 0) q = __hip_atomic_fetch_add(&next_slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return __builtin_amdgcn_readfirstlane(q);
+    };
+    auto request_x = [&](int q) {
+        const int64_t chunk_ = (int64_t)blockIdx.x + (int64_t)(q / kWaves) * gridDim.x;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int64_t w_ = ((chunk_ * kWaves + q % kWaves) * T + t) * 32 + j;
+            const int64_t wl = w_ < B ? w_ : B - 1;
+#pragma unroll
+            for (int d = 0; d < D; ++d) x_pf[t][d] = xg[wl * D + d];
+        }
+    };
+    if (!staged) {
+        q_pf = draw_slot();
+        if (q_pf < my_slots) request_x(q_pf);
+    }
+#endif
     for (int it = 0;; ++it) {
         int64_t chunk;
         int wpos;
@@ -580,9 +638,13 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
             wpos = wave;
             if (chunk >= n_chunks) break;
         } else {
+#ifdef WF_PREFETCH_X
+            const int q = q_pf;
+#else
             int q = 0;
             if (lane == 0) q = __hip_atomic_fetch_add(&next_slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             q = __builtin_amdgcn_readfirstlane(q);
+#endif
             if (q >= my_slots) break;
             chunk = (int64_t)blockIdx.x + (int64_t)(q / kWaves) * gridDim.x;
             wpos = q % kWaves;
@@ -597,10 +659,24 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
             w[t] = tile * 32 + j;
             valid[t] = w[t] < B;
             const int64_t wl = valid[t] ? w[t] : B - 1;
+#ifdef WF_PREFETCH_X
+            if (!staged) {
 #pragma unroll
-            for (int d = 0; d < D; ++d) cur[t][d] = xg[wl * D + d];
+                for (int d = 0; d < D; ++d) cur[t][d] = x_pf[t][d];
+            } else
+#endif
+            {
+#pragma unroll
+                for (int d = 0; d < D; ++d) cur[t][d] = xg[wl * D + d];
+            }
             idx[t] = (IDX && idx_out && valid[t] && h == 0) ? idx_out + w[t] * idx_stride : nullptr;
         }
+#ifdef WF_PREFETCH_X
+        if (!staged) {
+            q_pf = draw_slot();
+            if (q_pf < my_slots) request_x(q_pf);
+        }
+#endif
 
         // ---- BoxTransformLayer (made.py:118-137, 156-183); IEEE divisions: layer-0 bin indices must be exact
 #pragma unroll
@@ -658,7 +734,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
                 for (int t = 0; t < T; ++t) {
                     const Lerp Lp = make_lerp(cur[t][0], mm.n_mesh, rn_mesh, exact_div);
                     if (IDX && idx[t]) { idx[t][(l * D) * 2] = Lp.xl; idx[t][(l * D) * 2 + 1] = Lp.xr; }
-                    const f32x4 c0 = comp_lerp(mm.comp + (size_t)l * mm.n_mesh, Lp);
+                    const f32x2 c0 = comp_lerp(mm.comp2 + (size_t)l * mm.n_mesh, Lp);
                     nxt[t][0] = c0[0];
                     logdet[t] = logdet[t] + fast_log(c0[1] + 1e-7f);
                 }
@@ -748,7 +824,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
                     stage_floats<kThreads>(mm.image + (size_t)mm.n_layers * mm.net_floats, slots, mm.net_floats);
                     __syncthreads();
                 }
-                const f32x4* comp_p = mm.comp + (size_t)mm.n_layers * mm.n_mesh;
+                const f32x4* comp_p = mm.comp2 + (size_t)mm.n_layers * mm.n_mesh;
                 Frag h2[T][2];
                 f32x16 pend[T];
                 hidden_layers<D, NBK, T>(net, cur, lane, h2, pend);   // the conditioner sees the unclipped u (wavefunctions.py:40)
@@ -834,6 +910,9 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
                                         const _Float16* blk = obh + (size_t)(ko * NBK + ki) * 2048;
                                         const f16x8 ah = *reinterpret_cast<const f16x8*>(blk + (s * 64 + lane) * 8);
                                         const f16x8 al = *reinterpret_cast<const f16x8*>(blk + 1024 + (s * 64 + lane) * 8);
+#ifdef WF_MFMA_4PROD
+                                        c[ko] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, of[ki].lo[s], c[ko], 0, 0, 0);
+#endif
                                         c[ko] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, of[ki].hi[s], c[ko], 0, 0, 0);
                                         c[ko] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, of[ki].lo[s], c[ko], 0, 0, 0);
                                         c[ko] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, of[ki].hi[s], c[ko], 0, 0, 0);

@@ -906,8 +906,16 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
         if (!getenv("WF_MFMA_NO_BAND")) piece_bounds(rows, d.n_mesh, 2, nbk, bnd);   // (the switch: tests compare both, bit for bit)
         int rc = upload_table(m, rows, &md.tabI);
         if (rc) return rc;
-        rc = upload_table(m, rowsum, &md.rsI);
-        if (rc) return rc;
+        {   // [mesh][2] -> [mesh]{R0_m, R1_m, R0_{m+1}, R1_{m+1}} (the last mesh point repeats itself: it is a right end only)
+            std::vector<float> pairs((size_t)d.n_mesh * 4);
+            for (int mi = 0; mi < d.n_mesh; ++mi) {
+                const int mr = std::min(mi + 1, d.n_mesh - 1);
+                pairs[(size_t)mi * 4 + 0] = rowsum[(size_t)mi * 2]; pairs[(size_t)mi * 4 + 1] = rowsum[(size_t)mi * 2 + 1];
+                pairs[(size_t)mi * 4 + 2] = rowsum[(size_t)mr * 2]; pairs[(size_t)mi * 4 + 3] = rowsum[(size_t)mr * 2 + 1];
+            }
+            rc = upload_table(m, pairs, &md.rsI);
+            if (rc) return rc;
+        }
     }
     if (spline_prior) {
         const bool mflow = d.prior_kind == WF_PRIOR_MFLOW;
@@ -950,10 +958,13 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
     WF_HIP(hipMemcpy(m->d_fk_nat, fk_nat.data(), 128 * sizeof(float), hipMemcpyHostToDevice));
     {
         float* comp = nullptr;
-        rc = dev_alloc(m, &comp, (size_t)std::max(n_nets, 1) * d.n_mesh * 4 + (size_t)dim0_coef_floats(std::max(n_nets, 1)));
+        // [comp][coefficients of k_dim0_coeffs][comp2]
+        const size_t comp_floats = (size_t)std::max(n_nets, 1) * d.n_mesh * 4, coef_floats = (size_t)dim0_coef_floats(std::max(n_nets, 1));
+        rc = dev_alloc(m, &comp, comp_floats + ((coef_floats + 3) & ~(size_t)3) + comp_floats);
         if (rc) return rc;
         m->d_comp = comp;
         md.comp = reinterpret_cast<const float4_t*>(comp);
+        md.comp2 = reinterpret_cast<const float4_t*>(comp + comp_floats + ((coef_floats + 3) & ~(size_t)3));
     }
     m->mfma_floats = total;
     m->mfma_ok = true;
