@@ -89,6 +89,10 @@ def strict_on_well_conditioned_subset(gpu, oracle32, truth, cond, what=""):
     print(f"[strict {what}] {sub.sum()} of {sub.size} walkers well conditioned: pass 1e-5 rel vs fp64: HIP {r_g:.4f} fp32-oracle {r_o:.4f}; "
           f"max |err| HIP {e_g.max():.2e} oracle {e_o.max():.2e}; direct HIP vs oracle32 within 1e-5 rel: {direct:.4f}")
     assert r_g >= r_o - 0.005 - 3 * np.sqrt(r_o * (1 - r_o) / sub.sum()), (r_g, r_o)   # (3 sigma of a rate over sub.sum() walkers)
+    # the DIRECT statement of the north star on this subset, HIP against the fp32 oracle itself: two fp32 evaluations that each pass
+    # 1e-5 relative against exact arithmetic at rate r_o differ from EACH OTHER by more than that a little more often (measured at
+    # 2^20 walkers, r_o = 0.962: scalar kernel 0.980, MFMA kernel 0.940, wave kernel 0.95) -- floor: r_o - 0.06 (- 3 sigma)
+    assert direct >= r_o - 0.06 - 3 * np.sqrt(r_o * (1 - r_o) / sub.sum()), (direct, r_o)
     assert np.quantile(e_g, 0.99) <= 1.1 * max(np.quantile(e_o, 0.99), np.quantile(rel, 0.99)), (np.quantile(e_g, 0.99), np.quantile(e_o, 0.99))
     assert e_g.max() <= 2 * max(e_o.max(), rel.max()), (e_g.max(), e_o.max())
 

@@ -57,6 +57,42 @@ __device__ __forceinline__ J jr(J x) {
 // table function of a jet argument: value t0, first / second derivative t1 / t2 (the lerps of the next two cached orders)
 __device__ __forceinline__ J jlift(float t0, float t1, float t2, J u) { return japply(u, t0, t1, t2); }
 
+// ---- Two-variable Taylor algebra for the heads.  Behind the conditioner everything a head sums over its rows is SEPARABLE in the layer's two
+// inputs: the weights v_j are functions of s = u_0 alone (the conditioner's Taylor triple), the table rows T_j functions of t = u_1 alone.
+// So the row loop accumulates plain scalars -- sum_j v_j^(a)(s) g_j T_j^(k)(t) for the few (a, k) the second-order expansion needs -- and
+// the quotients, logarithms and the change to (x0, x1) jets are done ONCE per walker on the six partials {f, f_s, f_t, f_ss, f_st, f_tt}
+// (true partial derivatives), instead of carrying a four-channel (x0, x1) jet through every row (3 x fewer vector instructions per row).
+struct T2 {
+    float f, s, t, ss, st, tt;
+};
+__device__ __forceinline__ T2 operator*(T2 a, T2 b) {
+    return T2{a.f * b.f, a.f * b.s + a.s * b.f, a.f * b.t + a.t * b.f, a.f * b.ss + 2.0f * (a.s * b.s) + a.ss * b.f,
+              a.f * b.st + a.s * b.t + a.t * b.s + a.st * b.f, a.f * b.tt + 2.0f * (a.t * b.t) + a.tt * b.f};
+}
+__device__ __forceinline__ T2 operator+(T2 a, float c) { return T2{a.f + c, a.s, a.t, a.ss, a.st, a.tt}; }
+__device__ __forceinline__ T2 operator*(T2 a, float c) { return T2{a.f * c, a.s * c, a.t * c, a.ss * c, a.st * c, a.tt * c}; }
+// g(a) from g, g', g'' at a.f
+__device__ __forceinline__ T2 t2apply(T2 a, float g0, float g1, float g2) {
+    return T2{g0, g1 * a.s, g1 * a.t, g1 * a.ss + g2 * (a.s * a.s), g1 * a.st + g2 * (a.s * a.t), g1 * a.tt + g2 * (a.t * a.t)};
+}
+__device__ __forceinline__ T2 t2rcp(T2 a) { const float g = 1.0f / a.f; return t2apply(a, g, -g * g, 2.0f * g * g * g); }
+__device__ __forceinline__ T2 t2log(T2 a) { const float g1 = 1.0f / a.f; return t2apply(a, logf(a.f), g1, -g1 * g1); }
+__device__ __forceinline__ T2 t2rsqrt(T2 a) { const float g = rsqrtf(a.f), q = 1.0f / a.f; return t2apply(a, g, -0.5f * g * q, 0.75f * g * q * q); }
+// F(s(x), t(x)) as a jet in (x0, x1): chain rule through the jets of s and t (h = Laplacian / 2)
+__device__ __forceinline__ J t2jet(T2 F, J s, J t) {
+    return J{F.f, F.s * s.a + F.t * t.a, F.s * s.b + F.t * t.b,
+             F.s * s.h + F.t * t.h + 0.5f * (F.ss * (s.a * s.a + s.b * s.b) + 2.0f * F.st * (s.a * t.a + s.b * t.b) + F.tt * (t.a * t.a + t.b * t.b))};
+}
+// r(x) = 1 / (2^x + 1) of a pre-activation triple (x, x', x'') in s -> (r, r', r'')
+__device__ __forceinline__ void r_triple(float x0, float x1, float x2, float& v0, float& v1, float& v2) {
+    const float r = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x0) + 1.0f);
+    const float r1 = -0.6931471805599453f * r * (1.0f - r);
+    const float r2 = -0.6931471805599453f * r1 * (1.0f - 2.0f * r);
+    v0 = r;
+    v1 = r1 * x1;
+    v2 = __builtin_fmaf(r1, x2, r2 * (x1 * x1));
+}
+
 // state arrays: st[(slot * 4 + c) * B + w]
 __device__ __forceinline__ J st_load(const float* __restrict__ st, int slot, int64_t B, int64_t w) {
     const float* p = st + (int64_t)slot * 4 * B + w;
@@ -290,6 +326,22 @@ __global__ void k_etile_box(const float* __restrict__ xg, int64_t B, float L, fl
     st_store(st, 2, B, b, ld);
 }
 
+// y_1 = N_0 / Q and log(dy_1 + 1e-7) from the row sums of one flow head (see T2): N_k(s, t) = V_k(s, t) / S(s) + reg R_k(t), k = 0 (value) and 1
+// (derivative in t), Q(s) = Qv(s) / S(s) + reg G
+__device__ __forceinline__ void flow_head_finish(const float (&S)[3], const float (&Qv)[3], const float (&R)[4], float G, const float (&V0)[4],
+                                                 const float (&V1)[3], const float (&V2)[2], float reg, J u0, J u1, J& y1, J& ld) {
+    const T2 iS = t2rcp(T2{S[0], S[1], 0.0f, S[2], 0.0f, 0.0f});
+    const T2 Q = T2{Qv[0], Qv[1], 0.0f, Qv[2], 0.0f, 0.0f} * iS + reg * G;
+    const T2 rQ = t2rcp(Q);
+    // numerator k: partials of V_k are V[a][k + b]
+    T2 N0 = T2{V0[0], V1[0], V0[1], V2[0], V1[1], V0[2]} * iS;
+    N0.f += reg * R[0]; N0.t += reg * R[1]; N0.tt += reg * R[2];
+    T2 N1 = T2{V0[1], V1[1], V0[2], V2[1], V1[2], V0[3]} * iS;
+    N1.f += reg * R[1]; N1.t += reg * R[2]; N1.tt += reg * R[3];
+    y1 = t2jet(N0 * rQ, u0, u1);
+    ld = ld + t2jet(t2log(N1 * rQ + 1e-7f), u0, u1);
+}
+
 // One IMADE layer behind its conditioner (made.py:66-81) + Reverse: dimension 0 from the composite table, dimension 1 from the head jets
 __global__ __launch_bounds__(256) void k_etile_flow(const float4_t* __restrict__ comp /* this net: [n_mesh] {Y, Y', Y'', Y'''} */,
                                                     const float* __restrict__ tabI /* [n_mesh][8 row chunks][4 orders][4 rows] */, const float* __restrict__ gI, int nb,
@@ -314,8 +366,10 @@ __global__ __launch_bounds__(256) void k_etile_flow(const float4_t* __restrict__
     // 16-byte loads (8 per step: 4 orders x the two mesh rows; rows >= nb are zero padding).
     const LerpN L = nlerp(u1.v, n_mesh);
     const int* bnd = reinterpret_cast<const int*>(tabI + (size_t)n_mesh * 128);   // [8 chunks][lo, hi] behind the table (wf_model.cpp: upload_chunked)
-    J S0 = jc(0.0f), V0 = jc(0.0f), V1 = jc(0.0f), Qv = jc(0.0f);
-    float r0[3] = {0.0f, 0.0f, 0.0f}, r1[3] = {0.0f, 0.0f, 0.0f}, G = 0.0f;   // sum_j g_j t_j^(k), k = 0..2 and 1..3: R_k = lift of them
+    // sums over the rows (see T2): S^(a) = sum v_j^(a), Qv^(a) = sum g_j v_j^(a), V[a][k] = sum v_j^(a) g_j T_j^(k) for a + k <= 3 (k <= 3 - a ... the
+    // nine pairs the two numerators need), R[k] = sum g_j T_j^(k), G = sum g_j
+    float S[3] = {0.0f, 0.0f, 0.0f}, Qv[3] = {0.0f, 0.0f, 0.0f}, R[4] = {0.0f, 0.0f, 0.0f, 0.0f}, G = 0.0f;
+    float V0[4] = {0.0f, 0.0f, 0.0f, 0.0f}, V1[3] = {0.0f, 0.0f, 0.0f}, V2[2] = {0.0f, 0.0f};   // V[a][k]: a = 0: k 0..3, a = 1: k 0..2, a = 2: k 0..1
     for (int j0 = 0; j0 < nb; j0 += 4) {
         // the chunk at the mesh index clamped to its support: the same bits, and the walkers outside the support read two shared lines
         const int lo = bnd[j0 >> 1], hi = bnd[(j0 >> 1) + 1];
@@ -332,7 +386,8 @@ __global__ __launch_bounds__(256) void k_etile_flow(const float4_t* __restrict__
             const int jr_ = j0 + q;
             if (jr_ >= nb) break;
             const float* p = oj + ((b >> 5) * (32 * NCH) + jr_ * NCH) * 32 + (b & 31);     // [tile][row][channel][32 walkers]
-            const J v = jr(japply(u0, p[0], p[32], p[64]));     // the head's triple in u_0 -> jet in (x0, x1)
+            float v0, v1, v2;
+            r_triple(p[0], p[32], p[64], v0, v1, v2);       // the head's weight and its first two derivatives in u_0
             const float g = gI[jr_];
             float t[4];
 #pragma unroll
@@ -341,22 +396,19 @@ __global__ __launch_bounds__(256) void k_etile_flow(const float4_t* __restrict__
                 const float bb = q == 0 ? tb[k].x : (q == 1 ? tb[k].y : (q == 2 ? tb[k].z : tb[k].w));
                 t[k] = __builtin_fmaf(bb - a, L.t, a) * g;   // g_j folded into the row
             }
-            S0 = S0 + v;
-            Qv = Qv + v * g;
-            V0 = V0 + v * jlift(t[0], t[1], t[2], u1);
-            V1 = V1 + v * jlift(t[1], t[2], t[3], u1);
+            S[0] += v0; S[1] += v1; S[2] += v2;
+            Qv[0] = __builtin_fmaf(v0, g, Qv[0]); Qv[1] = __builtin_fmaf(v1, g, Qv[1]); Qv[2] = __builtin_fmaf(v2, g, Qv[2]);
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { r0[k] += t[k]; r1[k] += t[k + 1]; }
+            for (int k = 0; k < 4; ++k) { V0[k] = __builtin_fmaf(v0, t[k], V0[k]); R[k] += t[k]; }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) V1[k] = __builtin_fmaf(v1, t[k], V1[k]);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) V2[k] = __builtin_fmaf(v2, t[k], V2[k]);
             G += g;
         }
     }
-    const J rS0 = jrcp(S0);
-    const J N0 = V0 * rS0 + jlift(r0[0], r0[1], r0[2], u1) * reg;
-    const J N1 = V1 * rS0 + jlift(r1[0], r1[1], r1[2], u1) * reg;
-    const J Q = Qv * rS0 + reg * G;
-    const J rQ = jrcp(Q);
-    const J y1 = N0 * rQ;
-    ld = ld + jlog(N1 * rQ + 1e-7f);
+    J y1;
+    flow_head_finish(S, Qv, R, G, V0, V1, V2, reg, u0, u1, y1, ld);
     st_store(st, 0, B, b, y1);   // Reverse (bijections.py:337-340)
     st_store(st, 1, B, b, y0);
     st_store(st, 2, B, b, ld);
@@ -382,7 +434,8 @@ __global__ __launch_bounds__(256) void k_etile_prior(const float4_t* __restrict_
     }
     const LerpN L = nlerp(uc1.v, n_mesh);
     const int* bnd = reinterpret_cast<const int*>(tabP + (size_t)n_mesh * 128);
-    J N2 = jc(0.0f), dot = jc(0.0f);
+    // sums over the rows (see T2): D[a][k] = sum c_i^(a)(s) B_i^(k)(t), a + k <= 2; |c|^2 and its first two derivatives in s from cc, cc', c'c', cc''
+    float D0[3] = {0.0f, 0.0f, 0.0f}, D1[2] = {0.0f, 0.0f}, D2 = 0.0f, cc = 0.0f, cc1 = 0.0f, c1c1 = 0.0f, cc2 = 0.0f;
     for (int i0 = 0; i0 < nb; i0 += 4) {
         const int lo = bnd[i0 >> 1], hi = bnd[(i0 >> 1) + 1];
         const float4_t* rl = reinterpret_cast<const float4_t*>(tabP + (size_t)min(max(L.il, lo), hi) * 128);
@@ -398,7 +451,7 @@ __global__ __launch_bounds__(256) void k_etile_prior(const float4_t* __restrict_
             const int i = i0 + q;
             if (i >= nb) break;
             const float* p = oj + ((b >> 5) * (32 * NCH) + i * NCH) * 32 + (b & 31);
-            const J c = japply(u0, p[0], p[32], p[64]);        // (the conditioner sees the unclipped u_0, wavefunctions.py:40)
+            const float c0 = p[0], c1 = p[32], c2 = p[64];        // c_i and its derivatives in the unclipped u_0 (wavefunctions.py:40)
             float t[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -406,12 +459,17 @@ __global__ __launch_bounds__(256) void k_etile_prior(const float4_t* __restrict_
                 const float bb = q == 0 ? tb[k].x : (q == 1 ? tb[k].y : (q == 2 ? tb[k].z : tb[k].w));
                 t[k] = __builtin_fmaf(bb - a, L.t, a);
             }
-            N2 = N2 + c * c;
-            dot = dot + c * jlift(t[0], t[1], t[2], uc1);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) D0[k] = __builtin_fmaf(c0, t[k], D0[k]);
+            D1[0] = __builtin_fmaf(c1, t[0], D1[0]); D1[1] = __builtin_fmaf(c1, t[1], D1[1]);
+            D2 = __builtin_fmaf(c2, t[0], D2);
+            cc = __builtin_fmaf(c0, c0, cc); cc1 = __builtin_fmaf(c0, c1, cc1); c1c1 = __builtin_fmaf(c1, c1, c1c1); cc2 = __builtin_fmaf(c0, c2, cc2);
         }
     }
     const float sgn = s1buf[b] < 0.0f ? -1.0f : 1.0f;
-    const J val1 = (dot * jrsqrt(N2)) * sgn;
+    const T2 N2 = T2{cc, 2.0f * cc1, 0.0f, 2.0f * (c1c1 + cc2), 0.0f, 0.0f};
+    const T2 dotp = T2{D0[0], D1[0], D0[1], D2, D1[1], D0[2]};
+    const J val1 = t2jet(dotp * t2rsqrt(N2), u0, uc1) * sgn;
     const float sc0 = (constrained_mask & 1u) ? 0.70710678118654752f : 1.0f, sc1 = (constrained_mask & 2u) ? 0.70710678118654752f : 1.0f;
     const J psi = ((val0 * sc0) * (val1 * sc1)) * jexp_half(ld);
     const float lap = 2.0f * psi.h;
