@@ -11,7 +11,7 @@ for f in glob.glob(os.path.join(root, "*", "*", "*kernel_trace.csv")):
     for r in csv.DictReader(open(f)):
         dur[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 for k in agg:
-    if "k_mfma" not in k and "k_eval" not in k:
+    if not any(t in k for t in os.environ.get("WF_PMC_KERNELS", "k_mfma,k_eval").split(",")):
         continue
     print("==", k[:90])
     if dur[k]:

@@ -35,9 +35,10 @@ def test_hamiltonian_vs_autograd_oracle(golden, he_flat):
     # oracle's own deviation as the yardstick (same idea as tests/test_gpu_parity.py)
     scale = np.abs(lo64).max()
     e_g, e_o = np.abs(lap - lo64), np.abs(lo32 - lo64)
+    # (the wave kernel on this 500-walker batch: measured 2.2 x the fp32 torch oracle's own worst deviation from fp64, median 0.9 x)
     assert np.median(e_g) <= 3 * np.median(e_o) + 1e-6 * scale, (np.median(e_g), np.median(e_o))
-    assert e_g.max() <= 6 * e_o.max() + 1e-4 * scale, (e_g.max(), e_o.max(), scale)
-    np.testing.assert_allclose(hp, ho64, rtol=0, atol=6 * np.abs(ho32 - ho64).max() + 1e-4 * np.abs(ho64).max())
+    assert e_g.max() <= 4 * e_o.max() + 2e-5 * scale, (e_g.max(), e_o.max(), scale)
+    np.testing.assert_allclose(hp, ho64, rtol=0, atol=4 * np.abs(ho32 - ho64).max() + 2e-5 * np.abs(ho64).max())
     # local energy as vqmc.loss_fn_efficient forms it (vqmc.py:193-200)
     el = hp / (ps + 1e-8)
     assert np.isfinite(el).all()
@@ -167,9 +168,18 @@ def test_local_energy_on_the_matrix_cores_vs_oracle_and_wave_kernel(golden, he_f
     np.testing.assert_allclose(ps, po64, rtol=0, atol=3e-5)
     scale = np.abs(lo64).max()
     e_g, e_o = np.abs(lap - lo64), np.abs(lo32 - lo64)
+    # (round 3: the one-kernel form k_efused; measured 1.6 x the fp32 torch oracle's own worst deviation from fp64, median 1.6 x)
     assert np.median(e_g) <= 3 * np.median(e_o) + 1e-6 * scale, (np.median(e_g), np.median(e_o))
-    assert e_g.max() <= 6 * e_o.max() + 1e-4 * scale, (e_g.max(), e_o.max(), scale)
-    np.testing.assert_allclose(hp, ho64, rtol=0, atol=6 * np.abs(ho32 - ho64).max() + 1e-4 * np.abs(ho64).max())
+    assert e_g.max() <= 3 * e_o.max() + 2e-5 * scale, (e_g.max(), e_o.max(), scale)
+    np.testing.assert_allclose(hp, ho64, rtol=0, atol=3 * np.abs(ho32 - ho64).max() + 2e-5 * np.abs(ho64).max())
+    # the launch-per-net form of the same path (conditioner kernel -> exchange buffer -> head kernel; what models whose nets do not fit LDS
+    # together take): same oracle bound, and the two forms agree
+    monkeypatch.setenv("WF_ENERGY_FUSED", "0")
+    (hq, pq, lq), _ = _tile_and_wave(m, x, protons, monkeypatch)
+    monkeypatch.delenv("WF_ENERGY_FUSED")
+    assert np.abs(lq - lo64).max() <= 3 * e_o.max() + 2e-5 * scale and not np.array_equal(lq, lap)
+    for a, b in ((pq, ps), (lq, lap), (hq, hp)):
+        assert np.abs(a - b).max() <= 1e-4 * np.abs(b).max(), np.abs(a - b).max() / np.abs(b).max()
     # a large batch that is not a multiple of the 32-walker tile, walkers up to the box edge (clipped prior arguments included)
     xb = sorted_walkers(70001, 2, 10.0, 21)
     (hp, ps, lap), (hw, pw, lw) = _tile_and_wave(m, xb, protons, monkeypatch)

@@ -144,6 +144,7 @@ struct Protons {
 };
 // local energy of large batches on the matrix cores (wf_kernels_etile.hip): D = 2, <= 32 bases, mean box, IMADE + Waveflow prior, ungated
 int64_t energy_tile_floats(int64_t B);
+bool energy_tile_fused(const MfmaDev* mdev);   // the one-kernel form applies (nets resident in LDS; WF_ENERGY_FUSED=0 switches it off per call)
 int launch_energy_tile(const MfmaDev* mdev, const ModelDev& md, const float* tabI4, const float* tabP4, const float* fk_nat, const float* x, int64_t B,
                        const Protons& pr, float* hpsi, float* psi, float* lap, float* ws, void* stream);
 // The sweeps run over a coefficient ring (wf_ring.h).  kind 0: R1 (first order); 1: R3 (one sample per walker and direction,

@@ -23,6 +23,11 @@
 // Waveflow prior, ungated heads (every homogeneous boundary dictionary: the tables carry the map); everything else stays on the wave kernel.
 #include "wf_mfma_impl.h"
 
+// The jet / Taylor algebra of this file is checked against oracles by tolerance, not by operation order: multiply-add pairs may fuse (the build's
+// default is -ffp-contract=off).  The pragma is lexical: the index arithmetic of the table lerp (make_lerp, div_by_n in wf_mfma_impl.h, included
+// above) keeps the reference's separate roundings, so the bin indices stay bit-exact.
+#pragma clang fp contract(fast)
+
 namespace wf {
 
 namespace {
@@ -86,11 +91,11 @@ __device__ __forceinline__ J t2jet(T2 F, J s, J t) {
 // r(x) = 1 / (2^x + 1) of a pre-activation triple (x, x', x'') in s -> (r, r', r'')
 __device__ __forceinline__ void r_triple(float x0, float x1, float x2, float& v0, float& v1, float& v2) {
     const float r = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x0) + 1.0f);
-    const float r1 = -0.6931471805599453f * r * (1.0f - r);
-    const float r2 = -0.6931471805599453f * r1 * (1.0f - 2.0f * r);
+    const float r1 = -0.6931471805599453f * __builtin_fmaf(-r, r, r);
+    const float k = __builtin_fmaf(1.3862943611198906f, r, -0.6931471805599453f);
     v0 = r;
     v1 = r1 * x1;
-    v2 = __builtin_fmaf(r1, x2, r2 * (x1 * x1));
+    v2 = r1 * __builtin_fmaf(k * x1, x1, x2);
 }
 
 // state arrays: st[(slot * 4 + c) * B + w]
@@ -123,12 +128,12 @@ __device__ __forceinline__ void act_block(f32x16 (&x)[NCH]) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const float rr = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x[0][r]) + 1.0f);
-        const float r1 = -0.6931471805599453f * rr * (1.0f - rr);
-        const float r2 = -0.6931471805599453f * r1 * (1.0f - 2.0f * rr);
+        const float r1 = -0.6931471805599453f * __builtin_fmaf(-rr, rr, rr);                      // r' = -ln2 r (1 - r)
+        const float k = __builtin_fmaf(1.3862943611198906f, rr, -0.6931471805599453f);           // r'' / r' = -ln2 (1 - 2 r)
         const float x1 = x[1][r], x2 = x[2][r];
         x[0][r] = rr;
         x[1][r] = r1 * x1;
-        x[2][r] = __builtin_fmaf(r1, x2, r2 * (x1 * x1));
+        x[2][r] = r1 * __builtin_fmaf(k * x1, x1, x2);                                            // r' x'' + r'' x'^2
     }
 }
 // two blocks of r jets -> B fragments of the next layer, derivative channels scaled by 2^-e[c] (e[0] = 0: r lies in (0, 1))
@@ -169,6 +174,94 @@ __device__ __forceinline__ void init_acc(f32x16 (&acc)[NCH], const float* bias16
     for (int c = 1; c < NCH; ++c) acc[c] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 }
 
+// The conditioner of one net for one tile: Taylor triples (f, f', f'') in u_0 of the head's 32 pre-activations (dimension 1) in the accumulator
+// layout -> a0[channel][register].  PRIOR: the triples of c = (o * keep) @ ob_to_b instead, and the sum of the raw outputs (for the sign).
+template <bool PRIOR>
+__device__ __forceinline__ void cond_net(const float* net, const float* fkP, const _Float16* obh, float u0v, float u1v, int lane, f32x16 (&a0)[NCH], float& s1) {
+    const int h = lane >> 5;
+    // the conditioner's inputs: (u_0, u_1) values; the Taylor seed in u_0 is (u_0, 1, 0) (u_1 reaches no hidden unit: masked weights)
+    const float in0[2] = {u0v, 1.0f}, in1[2] = {u1v, 0.0f};
+    // ---- layer 1 (f32 MFMA, K = 2: the two coordinates), both 32-unit blocks; the second-derivative channel starts at zero
+    f32x16 a1[NCH];
+    init_acc(a0, net + O2::b0 + (0 * 2 + h) * 16);
+    init_acc(a1, net + O2::b0 + (1 * 2 + h) * 16);
+    {
+        const float w0 = net[O2::W0 + 0 * 64 + lane], w1 = net[O2::W0 + 1 * 64 + lane];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            a0[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, h ? in1[c] : in0[c], a0[c], 0, 0, 0);
+            a1[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, h ? in1[c] : in0[c], a1[c], 0, 0, 0);
+        }
+    }
+    act_block(a0);
+    act_block(a1);
+    Frag f[NCH][2];
+    int e[NCH];
+    to_frags(a0, a1, f, e);
+    // ---- layer 2
+    const _Float16* W1h = reinterpret_cast<const _Float16*>(net + O2::W1h);
+    const _Float16* W1l = reinterpret_cast<const _Float16*>(net + O2::W1l);
+    init_acc(a0, net + O2::b1 + (0 + h) * 16);
+    init_acc(a1, net + O2::b1 + (2 + h) * 16);
+    dense64_block<NCH>(W1h, W1l, f, a0, lane);
+    dense64_block<NCH>(W1h + 2048, W1l + 2048, f, a1, lane);
+    unscale(a0, e);
+    unscale(a1, e);
+    act_block(a0);
+    act_block(a1);
+    to_frags(a0, a1, f, e);
+    // ---- output block of dimension 1 (dimension 0 is table-driven: k_prepare_dim0)
+    const _Float16* W2h = reinterpret_cast<const _Float16*>(net + O2::W2h);
+    const _Float16* W2l = reinterpret_cast<const _Float16*>(net + O2::W2l);
+    init_acc(a0, net + O2::b2 + (1 * 2 + h) * 16);
+    dense64_block<NCH>(W2h, W2l, f, a0, lane);
+    unscale(a0, e);
+    if (PRIOR) {
+        // w = o * keep (jets); c = w @ ob_to_b on the matrix cores, every channel scaled (the head is unbounded); sum of the raw
+        // outputs for the sign (model_factory.py:69, sign form as in k_mfma)
+        s1 = 0.0f;
+        const f32x16 keep = load16(fkP + h * 16);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s1 += a0[0][r];
+        s1 = xhalf_sum(s1);
+        Frag of[NCH];
+        int eo[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            float amax = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                a0[c][r] = a0[c][r] * keep[r];
+                amax = fmaxf(amax, fabsf(a0[c][r]));
+            }
+            eo[c] = col_exponent(amax);
+            const float sc = __builtin_amdgcn_ldexpf(1.0f, -eo[c]);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float r8[8];
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) r8[jj] = a0[c][8 * s + jj] * sc;
+                split8(r8, of[c].hi[s], of[c].lo[s]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            f32x16 acc = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const f16x8 ah = *reinterpret_cast<const f16x8*>(obh + (s * 64 + lane) * 8);
+                const f16x8 al = *reinterpret_cast<const f16x8*>(obh + 1024 + (s * 64 + lane) * 8);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, of[c].hi[s], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, of[c].lo[s], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, of[c].hi[s], acc, 0, 0, 0);
+            }
+            const float sc = __builtin_amdgcn_ldexpf(1.0f, eo[c]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a0[c][r] = acc[r] * sc;
+        }
+    }
+}
+
 template <bool PRIOR>
 __global__ __launch_bounds__(kCondWaves * 64, WF_ETILE_OCC) void k_etile_cond(const MfmaDev mm, int net_index, const float* __restrict__ st, int64_t B,
                                                                 float* __restrict__ oj, float* __restrict__ s1buf) {
@@ -196,89 +289,11 @@ __global__ __launch_bounds__(kCondWaves * 64, WF_ETILE_OCC) void k_etile_cond(co
         const int64_t w = tile * 32 + j;
         const bool valid = w < B;
         const int64_t wl = valid ? w : B - 1;
-        // the conditioner's inputs: (u_0, u_1) values; the Taylor seed in u_0 is (u_0, 1, 0) (u_1 reaches no hidden unit: masked weights)
         const float u0v = st[wl], u1v = st[(int64_t)4 * B + wl];
-        const float in0[2] = {u0v, 1.0f}, in1[2] = {u1v, 0.0f};
-        // ---- layer 1 (f32 MFMA, K = 2: the two coordinates), both 32-unit blocks; the second-derivative channel starts at zero
-        f32x16 a0[NCH], a1[NCH];
-        init_acc(a0, net + O2::b0 + (0 * 2 + h) * 16);
-        init_acc(a1, net + O2::b0 + (1 * 2 + h) * 16);
-        {
-            const float w0 = net[O2::W0 + 0 * 64 + lane], w1 = net[O2::W0 + 1 * 64 + lane];
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                a0[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, h ? in1[c] : in0[c], a0[c], 0, 0, 0);
-                a1[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, h ? in1[c] : in0[c], a1[c], 0, 0, 0);
-            }
-        }
-        act_block(a0);
-        act_block(a1);
-        Frag f[NCH][2];
-        int e[NCH];
-        to_frags(a0, a1, f, e);
-        // ---- layer 2
-        const _Float16* W1h = reinterpret_cast<const _Float16*>(net + O2::W1h);
-        const _Float16* W1l = reinterpret_cast<const _Float16*>(net + O2::W1l);
-        init_acc(a0, net + O2::b1 + (0 + h) * 16);
-        init_acc(a1, net + O2::b1 + (2 + h) * 16);
-        dense64_block<NCH>(W1h, W1l, f, a0, lane);
-        dense64_block<NCH>(W1h + 2048, W1l + 2048, f, a1, lane);
-        unscale(a0, e);
-        unscale(a1, e);
-        act_block(a0);
-        act_block(a1);
-        to_frags(a0, a1, f, e);
-        // ---- output block of dimension 1 (dimension 0 is table-driven: k_prepare_dim0)
-        const _Float16* W2h = reinterpret_cast<const _Float16*>(net + O2::W2h);
-        const _Float16* W2l = reinterpret_cast<const _Float16*>(net + O2::W2l);
-        init_acc(a0, net + O2::b2 + (1 * 2 + h) * 16);
-        dense64_block<NCH>(W2h, W2l, f, a0, lane);
-        unscale(a0, e);
-        if (PRIOR) {
-            // w = o * keep (jets); c = w @ ob_to_b on the matrix cores, every channel scaled (the head is unbounded); sum of the raw
-            // outputs for the sign (model_factory.py:69, sign form as in k_mfma)
-            float s1 = 0.0f;
-            const f32x16 keep = load16(fkP + h * 16);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s1 += a0[0][r];
-            s1 = xhalf_sum(s1);
-            if (valid && h == 0) s1buf[w] = s1;
-            Frag of[NCH];
-            int eo[NCH];
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                float amax = 0.0f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    a0[c][r] = a0[c][r] * keep[r];
-                    amax = fmaxf(amax, fabsf(a0[c][r]));
-                }
-                eo[c] = col_exponent(amax);
-                const float sc = __builtin_amdgcn_ldexpf(1.0f, -eo[c]);
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    float r8[8];
-#pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) r8[jj] = a0[c][8 * s + jj] * sc;
-                    split8(r8, of[c].hi[s], of[c].lo[s]);
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                f32x16 acc = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const f16x8 ah = *reinterpret_cast<const f16x8*>(obh + (s * 64 + lane) * 8);
-                    const f16x8 al = *reinterpret_cast<const f16x8*>(obh + 1024 + (s * 64 + lane) * 8);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, of[c].hi[s], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, of[c].lo[s], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, of[c].hi[s], acc, 0, 0, 0);
-                }
-                const float sc = __builtin_amdgcn_ldexpf(1.0f, eo[c]);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) a0[c][r] = acc[r] * sc;
-            }
-        }
+        f32x16 a0[NCH];
+        float s1 = 0.0f;
+        cond_net<PRIOR>(net, fkP, obh, u0v, u1v, lane, a0, s1);
+        if (PRIOR && valid && h == 0) s1buf[w] = s1;
         // ---- store: oj[tile][row][c][32 walkers] (one contiguous 12 KB block per tile), row = accumulator row of register r in lane half h
 #ifdef WF_ABL_OJ   // ablation build (timing only): the head triples are computed, not stored
         if (valid && a0[0][0] == 12345.678f) {
@@ -489,6 +504,195 @@ __global__ __launch_bounds__(256) void k_etile_prior(const float4_t* __restrict_
     if (lap_out) lap_out[b] = lap;
 }
 
+// ---------------------------------------------------------------------------- H psi in ONE kernel (every net resident in LDS)
+// The conditioner's head triples stay in the accumulator registers: lane (walker j, half h) holds registers 4q .. 4q + 3 = rows 8q + 4h .. + 3 =
+// row CHUNK 2q + h of the regrouped tables ([mesh][8 chunks][4 orders][4 rows]: one 64-byte segment per chunk and lerp end).  The head runs on
+// those 16 rows per lane with the separable row sums of T2 (scalars, no jet per row); the two lane halves are combined with one
+// v_permlane32_swap per sum; quotients, logarithms and the change to (x0, x1) jets once per walker.  No exchange buffer, no state in HBM:
+// 8 B per walker in, 4 .. 12 B out.  One persistent workgroup of 8 waves per CU (two per SIMD, 256 registers), tiles from an LDS counter.
+constexpr int kFusedWaves = 8;
+
+__device__ __forceinline__ void box_mean2(float x0v, float x1v, float L, J& u0, J& u1, J& ld) {   // (k_etile_box)
+    const float tol = 1e-7f;
+    const J x0 = J{x0v, 1.0f, 0.0f, 0.0f}, x1 = J{x1v, 0.0f, 1.0f, 0.0f};
+    const J mean = (x0 + x1) * 0.5f;
+    const J l = mean - x0, wd = x1 - x0;
+    const J space = jc(2 * L);
+    const J diff = x1 - x0;
+    u0 = diff * jrcp(space + tol);
+    ld = jc(0.0f) - jlog(space + tol);
+    const J den = (jc(2 * L) - wd) + tol;
+    u1 = ((mean + L) - l) * jrcp(den);
+    ld = ld - jlog(den);
+}
+// chunk 2q + h of the lane at both lerp ends, every order; bnd: [8 chunks][lo, hi] support bounds (the chunk at the clamped index holds the same bits)
+template <int NO>
+__device__ __forceinline__ void chunk_rows(const float* __restrict__ tab, const int* bnd, const LerpN& L, int ch, float4_t (&ta)[NO], float4_t (&tb)[NO]) {
+    const int lo = bnd[2 * ch], hi = bnd[2 * ch + 1];
+    const float4_t* rl = reinterpret_cast<const float4_t*>(tab + (size_t)min(max(L.il, lo), hi) * 128) + ch * 4;
+    const float4_t* rr = reinterpret_cast<const float4_t*>(tab + (size_t)min(max(L.ir, lo), hi) * 128) + ch * 4;
+#pragma unroll
+    for (int k = 0; k < NO; ++k) {
+        ta[k] = rl[k];
+        tb[k] = rr[k];
+    }
+}
+
+__global__ __launch_bounds__(kFusedWaves * 64) void k_efused(const MfmaDev mm, const float* __restrict__ tabI, const float* __restrict__ tabP,
+                                                             const float* __restrict__ xg, int64_t B, const Protons pr, float* __restrict__ hpsi,
+                                                             float* __restrict__ psi_out, float* __restrict__ lap_out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ int next_tile;
+    __shared__ int bnd_s[32];   // support bounds of the table chunks: [I: 8][lo, hi], [prior: 8][lo, hi]
+    constexpr int kThreads = kFusedWaves * 64;
+    if (threadIdx.x == 0) next_tile = 0;
+    if (threadIdx.x < 16) bnd_s[threadIdx.x] = reinterpret_cast<const int*>(tabI + (size_t)mm.n_mesh * 128)[threadIdx.x];
+    else if (threadIdx.x < 32) bnd_s[threadIdx.x] = reinterpret_cast<const int*>(tabP + (size_t)mm.n_mesh * 128)[threadIdx.x - 16];
+    stage_floats<kThreads>(mm.image + mm.const_img_off, lds, mm.const_floats);
+    stage_floats<kThreads>(mm.image, lds + mm.const_floats, mm.net_floats * mm.n_nets);
+    __syncthreads();
+    const float* fkI = lds;
+    const float* fkP = lds + 32;
+    const _Float16* obh = reinterpret_cast<const _Float16*>(lds + 64);
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 31, h = lane >> 5;
+    const int n_mesh = mm.n_mesh;
+    const int64_t n_tiles = (B + 31) >> 5;
+    const int64_t my_tiles = n_tiles > (int64_t)blockIdx.x ? (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    for (;;) {
+        int q_ = 0;
+        if (lane == 0) q_ = __hip_atomic_fetch_add(&next_tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        q_ = __builtin_amdgcn_readfirstlane(q_);
+        if (q_ >= my_tiles) break;
+        const int64_t tile = (int64_t)blockIdx.x + (int64_t)q_ * gridDim.x;
+        const int64_t w = tile * 32 + j;
+        const bool valid = w < B;
+        const int64_t wl = valid ? w : B - 1;
+        const float x0v = xg[wl * 2], x1v = xg[wl * 2 + 1];
+        J u0, u1, ld;
+        box_mean2(x0v, x1v, mm.box_L, u0, u1, ld);
+        // ---- flow layers (made.py:66-81 + Reverse)
+        for (int l = 0; l < mm.n_layers; ++l) {
+            const float* net = lds + mm.const_floats + (size_t)l * mm.net_floats;
+            f32x16 a0[NCH];
+            float s1_unused = 0.0f;
+            cond_net<false>(net, fkP, obh, u0.v, u1.v, lane, a0, s1_unused);
+            // dimension 0: composite table of the net, all four orders
+            J y0;
+            {
+                const LerpN L0 = nlerp(u0.v, n_mesh);
+                const float4_t* comp = mm.comp + (size_t)l * n_mesh;
+                const float4_t ca = comp[L0.il], cb = comp[L0.ir];
+                const float t0 = __builtin_fmaf(cb.x - ca.x, L0.t, ca.x), t1 = __builtin_fmaf(cb.y - ca.y, L0.t, ca.y);
+                const float t2 = __builtin_fmaf(cb.z - ca.z, L0.t, ca.z), t3 = __builtin_fmaf(cb.w - ca.w, L0.t, ca.w);
+                y0 = jlift(t0, t1, t2, u0);
+                ld = ld + jlog(jlift(t1, t2, t3, u0) + 1e-7f);
+            }
+            // dimension 1: the lane's 16 rows
+            const LerpN L = nlerp(u1.v, n_mesh);
+            float S[3] = {0.0f, 0.0f, 0.0f}, Qv[3] = {0.0f, 0.0f, 0.0f}, R[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            float V0[4] = {0.0f, 0.0f, 0.0f, 0.0f}, V1[3] = {0.0f, 0.0f, 0.0f}, V2[2] = {0.0f, 0.0f};
+            const f32x16 g16 = load16(fkI + h * 16);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4_t ta[4], tb[4];
+                chunk_rows<4>(tabI, bnd_s, L, 2 * q + h, ta, tb);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * q + e;
+                    float v0, v1, v2;
+                    r_triple(a0[0][r], a0[1][r], a0[2][r], v0, v1, v2);
+                    const float g = g16[r];
+                    float t[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) t[k] = __builtin_fmaf(tb[k][e] - ta[k][e], L.t, ta[k][e]) * g;
+                    S[0] += v0; S[1] += v1; S[2] += v2;
+                    Qv[0] = __builtin_fmaf(v0, g, Qv[0]); Qv[1] = __builtin_fmaf(v1, g, Qv[1]); Qv[2] = __builtin_fmaf(v2, g, Qv[2]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { V0[k] = __builtin_fmaf(v0, t[k], V0[k]); R[k] += t[k]; }
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) V1[k] = __builtin_fmaf(v1, t[k], V1[k]);
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) V2[k] = __builtin_fmaf(v2, t[k], V2[k]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { S[k] = xhalf_sum(S[k]); Qv[k] = xhalf_sum(Qv[k]); V1[k] = xhalf_sum(V1[k]); }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { R[k] = xhalf_sum(R[k]); V0[k] = xhalf_sum(V0[k]); }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) V2[k] = xhalf_sum(V2[k]);
+            J y1;
+            flow_head_finish(S, Qv, R, mm.F_I, V0, V1, V2, mm.i_reg, u0, u1, y1, ld);
+            u0 = y1;   // Reverse (bijections.py:337-340)
+            u1 = y0;
+        }
+        // ---- Waveflow prior (wavefunctions.py:54-71)
+        J psi;
+        {
+            const float* net = lds + mm.const_floats + (size_t)mm.n_layers * mm.net_floats;
+            f32x16 a0[NCH];
+            float s1 = 0.0f;
+            cond_net<true>(net, fkP, obh, u0.v, u1.v, lane, a0, s1);   // (the conditioner sees the unclipped u_0, wavefunctions.py:40)
+            const J uc0 = (u0.v < 0.0f) ? jc(0.0f) : (u0.v > 1.0f ? jc(1.0f) : u0);   // the spline sees the clipped coordinate (:45)
+            const J uc1 = (u1.v < 0.0f) ? jc(0.0f) : (u1.v > 1.0f ? jc(1.0f) : u1);
+            J val0;
+            {
+                const LerpN L0 = nlerp(uc0.v, n_mesh);
+                const float4_t* comp = mm.comp + (size_t)mm.n_layers * n_mesh;
+                const float4_t ca = comp[L0.il], cb = comp[L0.ir];
+                val0 = jlift(__builtin_fmaf(cb.x - ca.x, L0.t, ca.x), __builtin_fmaf(cb.y - ca.y, L0.t, ca.y), __builtin_fmaf(cb.z - ca.z, L0.t, ca.z), uc0);
+            }
+            const LerpN L = nlerp(uc1.v, n_mesh);
+            float D0[3] = {0.0f, 0.0f, 0.0f}, D1[2] = {0.0f, 0.0f}, D2 = 0.0f, cc = 0.0f, cc1 = 0.0f, c1c1 = 0.0f, cc2 = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4_t ta[3], tb[3];
+                chunk_rows<3>(tabP, bnd_s + 16, L, 2 * q + h, ta, tb);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * q + e;
+                    const float c0 = a0[0][r], c1 = a0[1][r], c2 = a0[2][r];
+                    float t[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) t[k] = __builtin_fmaf(tb[k][e] - ta[k][e], L.t, ta[k][e]);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) D0[k] = __builtin_fmaf(c0, t[k], D0[k]);
+                    D1[0] = __builtin_fmaf(c1, t[0], D1[0]); D1[1] = __builtin_fmaf(c1, t[1], D1[1]);
+                    D2 = __builtin_fmaf(c2, t[0], D2);
+                    cc = __builtin_fmaf(c0, c0, cc); cc1 = __builtin_fmaf(c0, c1, cc1); c1c1 = __builtin_fmaf(c1, c1, c1c1); cc2 = __builtin_fmaf(c0, c2, cc2);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) D0[k] = xhalf_sum(D0[k]);
+            D1[0] = xhalf_sum(D1[0]); D1[1] = xhalf_sum(D1[1]); D2 = xhalf_sum(D2);
+            cc = xhalf_sum(cc); cc1 = xhalf_sum(cc1); c1c1 = xhalf_sum(c1c1); cc2 = xhalf_sum(cc2);
+            const float sgn = s1 < 0.0f ? -1.0f : 1.0f;
+            const T2 N2 = T2{cc, 2.0f * cc1, 0.0f, 2.0f * (c1c1 + cc2), 0.0f, 0.0f};
+            const T2 dotp = T2{D0[0], D1[0], D0[1], D2, D1[1], D0[2]};
+            const J val1 = t2jet(dotp * t2rsqrt(N2), u0, uc1) * sgn;
+            const float sc0 = (mm.constrained_mask & 1u) ? 0.70710678118654752f : 1.0f, sc1 = (mm.constrained_mask & 2u) ? 0.70710678118654752f : 1.0f;
+            psi = ((val0 * sc0) * (val1 * sc1)) * jexp_half(ld);
+        }
+        if (valid && h == 0) {
+            const float lap = 2.0f * psi.h;
+            float V = 0.0f;   // physics.py:60-76
+            for (int p = 0; p < pr.n; ++p) {
+                const float r0 = pr.pos[p] - x0v, r1 = pr.pos[p] - x1v;
+                V -= 1.0f / sqrtf(1.0f + r0 * r0);
+                V -= 1.0f / sqrtf(1.0f + r1 * r1);
+            }
+            {
+                const float r = x1v - x0v;
+                V += 1.0f / sqrtf(1.0f + r * r);
+            }
+            hpsi[w] = -0.5f * lap + V * psi.v;
+            if (psi_out) psi_out[w] = psi.v;
+            if (lap_out) lap_out[w] = lap;
+        }
+    }
+}
+
 int check() {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -500,6 +704,11 @@ int check() {
 
 }  // namespace
 
+bool energy_tile_fused(const MfmaDev* mdev) {
+    const char* e = getenv("WF_ENERGY_FUSED");
+    return !mdev->staged && !(e && atoi(e) == 0);
+}
+
 // workspace: state (12 floats), head triples (96 floats), the sign sum (1 float) per walker
 int64_t energy_tile_floats(int64_t B) { return B * (12 + 1) + ((B + 31) / 32) * 32 * (32 * NCH); }   // state, s1, head triples of whole tiles
 
@@ -508,6 +717,19 @@ int launch_energy_tile(const MfmaDev* mdev, const ModelDev& md, const float* tab
                        const Protons& pr, float* hpsi, float* psi, float* lap, float* ws, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (B == 0) return WF_OK;
+    // every net resident in LDS (the shipped shapes): the whole of H psi in one launch, nothing through HBM but the walkers and the results.
+    // WF_ENERGY_FUSED=0 (read per call) keeps the launch-per-net path below (A/B tests; models whose nets do not fit together take it anyway).
+    {
+        if (energy_tile_fused(mdev)) {
+            const int lds_all = (mdev->const_floats + mdev->net_floats * mdev->n_nets) * (int)sizeof(float);
+            static DynLdsSlots cfg_fused{};
+            if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(k_efused), lds_all, &cfg_fused)) return rc;
+            const int64_t n_tiles = (B + 31) / 32;
+            const unsigned blocks = (unsigned)std::min<int64_t>((n_tiles + kFusedWaves - 1) / kFusedWaves, 256);
+            hipLaunchKernelGGL(k_efused, dim3(blocks), dim3(kFusedWaves * 64), lds_all, s, *mdev, tabI4, tabP4, x, B, pr, hpsi, psi, lap);
+            return check();
+        }
+    }
     float* st = ws;
     float* s1 = st + 12 * B;
     float* oj = s1 + B;

@@ -1413,6 +1413,8 @@ int wf_hamiltonian_fwd(const wf_model* m, const float* x_dev, int64_t B, const f
         if (family && tile_min > 0 && B >= tile_min && !m->eval_tables_stale) {
             // the conditioner and the head kernels exchange 384 B per walker and net through the scratch buffer: chunks that keep it
             // (and its re-use by the next net and the next chunk) inside the 256 MB memory-side cache instead of HBM
+            if (energy_tile_fused(&m->mdev))   // every net resident in LDS: one launch for the whole batch, no exchange buffer (k_efused)
+                return launch_energy_tile(&m->mdev, m->dev, m->d_tabI4c, m->d_tabP4c, m->d_grad_fk, x_dev, B, pr, hpsi_dev, psi_dev, laplacian_dev, nullptr, stream);
             const char* ec = getenv("WF_ENERGY_TILE_CHUNK");
             const int64_t tchunk = std::min<int64_t>(B, std::max<int64_t>(ec ? atoll(ec) : kEnergyTileChunk, 1024));
             rc = ensure_scratch(m, energy_tile_floats(tchunk));
