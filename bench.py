@@ -31,9 +31,9 @@ PEAK_HBM_GBS = 8000.0
 MFMA_F16_PER_TILE, MFMA_F32_PER_TILE = 150, 8
 MFMA_FLOP_PER_EVAL = (MFMA_F16_PER_TILE * 32768 + MFMA_F32_PER_TILE * 4096) / 32
 # HBM bytes of one 2^20-walker log_pdf launch from the PMC passes of this command (separate rocprofv3 --pmc runs, scratch/pmc.sh):
-# FETCH_SIZE 10659 KB + WRITE_SIZE 4096 KB.  The walker read is 8 B per lane, not the 16 B-per-lane stream the guide's x2 FETCH_SIZE
+# FETCH_SIZE 10706 KB + WRITE_SIZE 4096 KB.  The walker read is 8 B per lane, not the 16 B-per-lane stream the guide's x2 FETCH_SIZE
 # correction is calibrated on (the sum already equals the 12.6 MB of algorithmic bytes), so no correction is applied.
-PMC_TRAFFIC = {"bytes": (10659 + 4096) * 1024, "source": "profiles/r02_pmc_summary.txt"}
+PMC_TRAFFIC = {"bytes": (10706 + 4096) * 1024, "source": "profiles/r03_pmc_summary.txt"}
 # reverse sweep of one walker, He, in the (value, gradient, Laplacian) algebra RF<2> = 4 channels: per net 2 dense 64x64 products
 # (+ the 32x32 change of basis of the prior, forward and transposed, for 2 dimensions), FMA = 2 FLOP
 VQMC_BWD_FLOP_PER_WALKER = 2 * (4 * 2 * 64 * 64 * 4 + 2 * 2 * 32 * 32 * 4)
@@ -86,7 +86,7 @@ def kernel_ms(model, x, n=50, warm=150):
     return float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
 
-HPSI_KERNELS = "k_etile_box + (k_etile_cond<false> + k_etile_flow) x 3 + k_etile_cond<true> + k_etile_prior, per pass of 2^19 walkers"
+HPSI_KERNELS = "k_efused (one launch: box + 3 x (conditioner Taylor channels on the matrix cores + head) + prior + H psi)"
 GRAD_KERNELS = "k_wave_fwd<2,RF<2>> + k_energy_out + k_vqmc_seeds + k_wave_bwd<2,RF<2>> + k_wgrad<4> + k_wgrad_reduce + k_grad_gather"
 
 
@@ -540,7 +540,7 @@ def main_vqmc(args):
         "config": {"workload": f"1D He (shipped checkpoint): loss_fn_efficient + gradient over {B} walkers (vqmc.py:193-221); also H psi and "
                                "whole training steps at batch 128", "walkers": B},
         "hpsi_walkers_per_s": B / t_h,
-        "hpsi_2pow20": {"walkers_per_s": (1 << 20) / t_h20, "ms": t_h20 * 1e3, "kernels": "k_etile_cond<*> x 4 + k_etile_flow x 3 + k_etile_prior + k_etile_box",
+        "hpsi_2pow20": {"walkers_per_s": (1 << 20) / t_h20, "ms": t_h20 * 1e3, "kernels": HPSI_KERNELS,
                         "wave_kernel_walkers_per_s": (1 << 20) / t_h20_wave},
         "train_steps_per_s_batch128": 1.0 / t_train, "train_ms_per_step_batch128": t_train * 1e3,
         "roofline": {"bound": "valu", "achieved": B * VQMC_BWD_FLOP_PER_WALKER / (VQMC_BWD_SHARE * step_ms * 1e-3) / 1e12, "peak": PEAK_F32_MATRIX_TFLOPS,

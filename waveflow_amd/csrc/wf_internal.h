@@ -106,7 +106,8 @@ struct MfmaDev {
     int n_nets, net_floats;
     int const_img_off;         // float offset of the constants block inside the image
     int const_floats;          // fkI[nbk][2][16], fkP[nbk][2][16], ob_to_b image [nbk][nbk]{hi, lo}[2 K steps][64 lanes][8 halves], piece bounds int32 [2 tables][nbk][2][16]
-    int staged;                // 0: every net resident in LDS; 1: one LDS slot, nets re-staged per chunk of tiles
+    int staged;                // 0: every net resident in LDS; 1: one LDS slot, nets re-staged per super-chunk of tiles
+    int staged_groups;         // staged mode: tile groups per wave and super-chunk (set per launch, 1 .. kStagedGroups)
     const float* tabI;         // [n_mesh][8 nbk pieces][nd 0..1][side: m, m + 1][4 rows] fp32: fk_row * I_row (wf_model.cpp: pack_rows_pairs)
     const float* rsI;          // [n_mesh]{R0_m, R1_m, R0_{m+1}, R1_{m+1}}: sum over rows of tabI (orders 0, 1), both lerp ends in one 16-byte record
     const float* tabP;         // [n_mesh][8 nbk pieces][side][4 rows] fp32, prior rows (B as is; M: fk_row * M_row), nd 0
@@ -118,6 +119,7 @@ struct MfmaDev {
     int i_gate, p_gate;        // gated heads (wf_model_desc.i_gate / p_gate): zero_params blocks of the net images are live
 };
 
+constexpr int kStagedGroups = 4;   // staged mode: a wave's tile groups whose state waits in LDS between two nets (LDS: waves x groups x T x (D + 1) x 128 B)
 bool mfma_div_ok(int n_mesh);   // host check of div_by_n (wf_mfma_impl.h) against the division for every x_l in [-1, n_mesh]
 
 int launch_mfma(int D, int nbk, const MfmaDev* mdev, int lds_bytes, int mode, const float* x, int64_t B, float* out, float* u,

@@ -605,79 +605,25 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
     // this workgroup's chunks: blockIdx.x, blockIdx.x + gridDim.x, ...; a slot = (chunk, wave position) = T tiles
     const int64_t my_chunks = n_chunks > (int64_t)blockIdx.x ? (n_chunks - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
     const int my_slots = (int)(my_chunks * kWaves);
-#ifdef WF_PREFETCH_X
-    // Resident mode: the slot of the NEXT iteration is drawn at the top of this one and its walker coordinates are requested right away,
-    // so that the HBM round trip of a tile's first load is covered by the previous tile's arithmetic (D registers per tile).
-    int q_pf = 0;
-    float x_pf[T][D];
-    auto draw_slot = [&]() {
-        int q = 0;
-        if (lane == 0) q = __hip_atomic_fetch_add(&next_slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        return __builtin_amdgcn_readfirstlane(q);
-    };
-    auto request_x = [&](int q) {
-        const int64_t chunk_ = (int64_t)blockIdx.x + (int64_t)(q / kWaves) * gridDim.x;
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-            const int64_t w_ = ((chunk_ * kWaves + q % kWaves) * T + t) * 32 + j;
-            const int64_t wl = w_ < B ? w_ : B - 1;
-#pragma unroll
-            for (int d = 0; d < D; ++d) x_pf[t][d] = xg[wl * D + d];
-        }
-    };
-    if (!staged) {
-        q_pf = draw_slot();
-        if (q_pf < my_slots) request_x(q_pf);
-    }
-#endif
-    for (int it = 0;; ++it) {
-        int64_t chunk;
-        int wpos;
-        if (staged) {   // (barriers inside the loop: every wave walks the same chunks)
-            chunk = (int64_t)blockIdx.x + (int64_t)it * gridDim.x;
-            wpos = wave;
-            if (chunk >= n_chunks) break;
-        } else {
-#ifdef WF_PREFETCH_X
-            const int q = q_pf;
-#else
-            int q = 0;
-            if (lane == 0) q = __hip_atomic_fetch_add(&next_slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            q = __builtin_amdgcn_readfirstlane(q);
-#endif
-            if (q >= my_slots) break;
-            chunk = (int64_t)blockIdx.x + (int64_t)(q / kWaves) * gridDim.x;
-            wpos = q % kWaves;
-        }
-        float cur[T][D], nxt[T][D], logdet[T];
-        int64_t w[T];
-        bool valid[T];
-        int32_t* idx[T];
+    // ---- the pieces of one tile pass (lambdas: inlined).  Resident mode strings them together per tile; staged mode runs them net by net
+    // over a super-chunk of tiles whose state waits in LDS, so that a net is staged once per super-chunk.
+    auto tile_ids = [&](int64_t chunk, int wpos, int64_t (&w)[T], bool (&valid)[T], int32_t* (&idx)[T]) __attribute__((always_inline)) {
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             const int64_t tile = (chunk * kWaves + wpos) * T + t;    // may be >= n_tiles in the last chunk: computed, never stored
             w[t] = tile * 32 + j;
             valid[t] = w[t] < B;
-            const int64_t wl = valid[t] ? w[t] : B - 1;
-#ifdef WF_PREFETCH_X
-            if (!staged) {
-#pragma unroll
-                for (int d = 0; d < D; ++d) cur[t][d] = x_pf[t][d];
-            } else
-#endif
-            {
-#pragma unroll
-                for (int d = 0; d < D; ++d) cur[t][d] = xg[wl * D + d];
-            }
             idx[t] = (IDX && idx_out && valid[t] && h == 0) ? idx_out + w[t] * idx_stride : nullptr;
         }
-#ifdef WF_PREFETCH_X
-        if (!staged) {
-            q_pf = draw_slot();
-            if (q_pf < my_slots) request_x(q_pf);
+    };
+    auto load_box = [&](const int64_t (&w)[T], const bool (&valid)[T], float (&cur)[T][D], float (&logdet)[T]) __attribute__((always_inline)) {
+        float nxt[T][D];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int64_t wl = valid[t] ? w[t] : B - 1;
+#pragma unroll
+            for (int d = 0; d < D; ++d) cur[t][d] = xg[wl * D + d];
         }
-#endif
-
         // ---- BoxTransformLayer (made.py:118-137, 156-183); IEEE divisions: layer-0 bin indices must be exact
 #pragma unroll
         for (int t = 0; t < T; ++t) {
@@ -715,14 +661,10 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
             logdet[t] = ld;
         }
 
-        // ---- flow layers
-        for (int l = 0; l < mm.n_layers; ++l) {
-            const float* net = slots + (staged ? 0 : l * mm.net_floats);
-            if (staged) {
-                __syncthreads();   // every wave is done with the previous occupant of the slot
-                stage_floats<kThreads>(mm.image + (size_t)l * mm.net_floats, slots, mm.net_floats);
-                __syncthreads();
-            }
+    };
+    auto flow_layer = [&](int l, const float* net, float (&cur)[T][D], float (&logdet)[T], int32_t* (&idx)[T]) __attribute__((always_inline)) {
+        float nxt[T][D];
+        {
             Frag h2[T][2];
             f32x16 pend[T];
             STAMP(0);
@@ -809,8 +751,12 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
             for (int t = 0; t < T; ++t)
 #pragma unroll
                 for (int d = 0; d < D; ++d) cur[t][d] = nxt[t][D - 1 - d];  // Reverse (bijections.py:337-340)
-        }
-
+                }
+    };
+    auto head_store = [&](const float* net_prior, float (&cur)[T][D], float (&logdet)[T], const int64_t (&w)[T], const bool (&valid)[T],
+                          int32_t* (&idx)[T]) __attribute__((always_inline)) {
+        float nxt[T][D];
+        const float* net = net_prior;
         // ---- density head
         float result[T];
 #pragma unroll
@@ -818,12 +764,6 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
         if (mode != 2) {
             if (prior_kind == WF_PRIOR_WAVEFLOW || prior_kind == WF_PRIOR_MFLOW) {
                 const bool wavefn = prior_kind == WF_PRIOR_WAVEFLOW;
-                const float* net = slots + (staged ? 0 : mm.n_layers * mm.net_floats);
-                if (staged) {
-                    __syncthreads();
-                    stage_floats<kThreads>(mm.image + (size_t)mm.n_layers * mm.net_floats, slots, mm.net_floats);
-                    __syncthreads();
-                }
                 const f32x4* comp_p = mm.comp2 + (size_t)mm.n_layers * mm.n_mesh;
                 Frag h2[T][2];
                 f32x16 pend[T];
@@ -995,7 +935,72 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
                     for (int d = 0; d < D; ++d) u_out[w[t] * D + d] = cur[t][d];
                 }
             }
-        STAMP(6);
+    };
+
+    if (!staged) {
+        for (;;) {
+            int q = 0;
+            if (lane == 0) q = __hip_atomic_fetch_add(&next_slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            q = __builtin_amdgcn_readfirstlane(q);
+            if (q >= my_slots) break;
+            const int64_t chunk = (int64_t)blockIdx.x + (int64_t)(q / kWaves) * gridDim.x;
+            float cur[T][D], logdet[T];
+            int64_t w[T];
+            bool valid[T];
+            int32_t* idx[T];
+            tile_ids(chunk, q % kWaves, w, valid, idx);
+            load_box(w, valid, cur, logdet);
+            for (int l = 0; l < mm.n_layers; ++l) flow_layer(l, slots + (size_t)l * mm.net_floats, cur, logdet, idx);
+            head_store(slots + (size_t)mm.n_layers * mm.net_floats, cur, logdet, w, valid, idx);
+            STAMP(6);
+        }
+    } else {
+        // Staged mode (the nets do not fit LDS together): ONE slot.  A super-chunk = kWaves * T * tps tiles; every wave walks its tps
+        // tile groups through net after net, the (D + 1) floats of a walker's state between two nets wait in LDS ([wave][group][T][D + 1][32]),
+        // and the slot is re-staged between two barriers once per net and super-chunk (round 2 re-staged it per chunk of kWaves * T tiles).
+        float* state = slots + mm.net_floats + (size_t)wave * kStagedGroups * T * (D + 1) * 32;
+        const int tps = mm.staged_groups;                       // tile groups per wave and super-chunk, 1 .. kStagedGroups (host: by the batch)
+        const int64_t n_super = (n_chunks + tps - 1) / tps;
+        const bool prior_net = mode != 2 && (prior_kind == WF_PRIOR_WAVEFLOW || prior_kind == WF_PRIOR_MFLOW);
+        for (int64_t sc = blockIdx.x; sc < n_super; sc += gridDim.x) {
+            for (int p = 0; p <= mm.n_layers; ++p) {
+                if (p < mm.n_layers || prior_net) {
+                    __syncthreads();   // every wave is done with the previous occupant of the slot
+                    stage_floats<kThreads>(mm.image + (size_t)p * mm.net_floats, slots, mm.net_floats);
+                    __syncthreads();
+                }
+                for (int g = 0; g < tps; ++g) {
+                    const int64_t chunk = sc * tps + g;
+                    if (chunk >= n_chunks) break;
+                    float cur[T][D], logdet[T];
+                    int64_t w[T];
+                    bool valid[T];
+                    int32_t* idx[T];
+                    tile_ids(chunk, wave, w, valid, idx);
+                    float* st = state + (size_t)g * T * (D + 1) * 32;
+                    if (p == 0) load_box(w, valid, cur, logdet);
+                    else {
+#pragma unroll
+                        for (int t = 0; t < T; ++t) {
+#pragma unroll
+                            for (int d = 0; d < D; ++d) cur[t][d] = st[(t * (D + 1) + d) * 32 + j];
+                            logdet[t] = st[(t * (D + 1) + D) * 32 + j];
+                        }
+                    }
+                    if (p < mm.n_layers) {
+                        flow_layer(p, slots, cur, logdet, idx);
+                        if (h == 0) {
+#pragma unroll
+                            for (int t = 0; t < T; ++t) {
+#pragma unroll
+                                for (int d = 0; d < D; ++d) st[(t * (D + 1) + d) * 32 + j] = cur[t][d];
+                                st[(t * (D + 1) + D) * 32 + j] = logdet[t];
+                            }
+                        }
+                    } else head_store(slots, cur, logdet, w, valid, idx);
+                }
+            }
+        }
     }
 #ifdef WF_STAMP
     if (mm.dbg && lane == 0) {
@@ -1016,9 +1021,16 @@ int launch_dwi(const MfmaDev* mdev, int lds_bytes, int mode, const float* x, int
     static DynLdsSlots cfg{};   // (one table per instantiation)
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(k_mfma<D, NBK, kWaves, T, IDX, SPEC>), lds_bytes, &cfg)) return rc;
     const int64_t n_tiles = (B + 31) / 32;
-    int64_t grid = (n_tiles + kWaves * T - 1) / (kWaves * T);
+    const int64_t n_chunks = (n_tiles + kWaves * T - 1) / (kWaves * T);
+    MfmaDev md = *mdev;
+    int64_t grid = n_chunks;
+    if (md.staged) {   // tile groups per wave and super-chunk: as many as keep 256 workgroups busy, at most kStagedGroups (the LDS state area)
+        int64_t g = (n_chunks + 255) / 256;
+        md.staged_groups = (int)(g < 1 ? 1 : (g > kStagedGroups ? kStagedGroups : g));
+        grid = (n_chunks + md.staged_groups - 1) / md.staged_groups;
+    }
     if (grid > 256) grid = 256;  // one persistent workgroup per CU
-    hipLaunchKernelGGL((k_mfma<D, NBK, kWaves, T, IDX, SPEC>), dim3((unsigned)grid), dim3(kWaves * 64), lds_bytes, s, *mdev, mode, x, B, out, u, idx);
+    hipLaunchKernelGGL((k_mfma<D, NBK, kWaves, T, IDX, SPEC>), dim3((unsigned)grid), dim3(kWaves * 64), lds_bytes, s, md, mode, x, B, out, u, idx);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_hip_error((int)e);

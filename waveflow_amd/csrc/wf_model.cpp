@@ -876,7 +876,7 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
     const int64_t lds_cap = 160 * 1024 / 4 - 64;   // floats (the kernel also holds a few bytes of static LDS: its tile counter)
     int staged;
     if ((int64_t)consts + (int64_t)net_floats * n_nets <= lds_cap) staged = 0;        // every net resident
-    else if ((int64_t)consts + net_floats <= lds_cap) staged = 1;                     // one slot, re-staged per chunk
+    else if ((int64_t)consts + net_floats + 16 * kStagedGroups * (D + 1) * 32 <= lds_cap) staged = 1;   // one slot + the state area, re-staged per super-chunk
     else return WF_OK;
     const int64_t total = (int64_t)net_floats * n_nets + consts;
 
@@ -889,7 +889,9 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
     md.exact_div = mfma_div_ok(md.n_mesh) ? 0 : 1;
     md.prior_quotient = (getenv("WF_PRIOR_QUOTIENT") && atoi(getenv("WF_PRIOR_QUOTIENT")) != 0) ? 1 : 0;
     md.i_gate = m->dev.i_gate; md.p_gate = m->dev.p_gate;
-    m->mfma_lds_floats = consts + (staged ? net_floats : net_floats * n_nets);
+    // staged mode: one net slot + the state area of the super-chunk (16 waves x kStagedGroups tile groups x (D + 1) x 32 floats: the
+    // built staged shapes run 8 waves of one tile; sized for the largest workgroup)
+    m->mfma_lds_floats = consts + (staged ? net_floats + 16 * kStagedGroups * (D + 1) * 32 : net_floats * n_nets);
 
     m->mfma_consts.assign(consts, 0.0f);
     int32_t* bnd = reinterpret_cast<int32_t*>(m->mfma_consts.data() + 64 * nbk + nbk * nbk * 1024);   // [2 tables][nbk][2 halves][16: 4 pieces x (lo, hi), 8 unused -- the lane stride of the fk blocks]
