@@ -34,6 +34,37 @@ def test_unconstrained_rqs_vs_oracle(K, N):
     np.testing.assert_allclose(y, yo, rtol=0, atol=2e-5)
 
 
+@pytest.mark.parametrize("K", [4, 8, 32])
+def test_rqs_bin_search_is_bit_exact_on_injected_knots(K):
+    """searchsorted (neural_splines.py:11-13: sum(x >= knots) - 1, eps on the last knot) in isolation.  The mismatches the test above
+    tolerates come from the KNOTS (two expf implementations in the soft-max), not from the search: with equal unnormalised widths the
+    soft-max is exactly 1 / K in any implementation (exp(0) = 1, K a power of two), the knots of kernel and oracle are the same fp32
+    numbers, and then every bin index must agree -- on the knots themselves, on their fp32 neighbours, at both ends of the interval
+    and at the tail bound."""
+    from waveflow_amd.flows import unconstrained_RQS
+    ideal = (-1.0 + 2.0 * np.arange(K + 1) / K).astype(np.float32)           # the knots up to the rounding of the cumulative sum
+    pts = [ideal]
+    for _ in range(4):                                                        # +- 1 .. 4 ulp around every knot
+        pts.append(np.nextafter(pts[-1], np.float32(2.0)))
+    lo = ideal
+    for _ in range(4):
+        lo = np.nextafter(lo, np.float32(-2.0))
+        pts.append(lo)
+    x = np.concatenate(pts + [np.random.default_rng(5).uniform(-1.05, 1.05, size=50000).astype(np.float32),
+                              np.array([-1.0, 1.0, np.nextafter(np.float32(1.0), np.float32(2.0)), np.nextafter(np.float32(-1.0), np.float32(-2.0))], np.float32)])
+    N = x.size
+    uw = np.zeros((N, K), np.float32)
+    uh = np.random.default_rng(6).normal(size=(N, K)).astype(np.float32)     # heights and derivatives do not enter the forward search
+    ud = np.random.default_rng(7).normal(size=(N, K - 1)).astype(np.float32)
+    y, ld, b = unconstrained_RQS(x, uw, uh, ud, tail_bound=1.0, return_bin_idx=True)
+    yo, ldo, bo = oracle.rqs_batch(x, uw, uh, ud, left=-1.0, right=1.0, bottom=-1.0, top=1.0)
+    assert np.array_equal(b, bo), (int((b != bo).sum()), x[b != bo][:8], b[b != bo][:8], bo[b != bo][:8])
+    inside = np.abs(x) <= 1.0
+    assert b[inside].min() == 0 and b[inside].max() == K - 1 and np.all(b[~inside] == -1)
+    # every bin is hit, and the knots themselves belong to the bin on their right (x >= knot), the last one to the last bin (eps)
+    assert np.array_equal(np.unique(b[inside]), np.arange(K))
+
+
 @pytest.mark.parametrize("K", [8, 32])
 def test_rqs_inverse_roundtrip_and_explicit_derivatives(K):
     from waveflow_amd.flows import RQS
@@ -171,11 +202,14 @@ def test_neural_spline_coupling_stack_as_a_model(dim, K, hidden, reverse, prior)
         want, zc = ld, np.clip(z, 0.0, 1.0)
     assert np.quantile(np.abs(u - zc), 0.999) < 2e-3 and np.median(np.abs(u - zc)) < 5e-6
     err = np.abs(lp - want)
-    assert np.median(err) < 2e-5 and np.quantile(err, 0.99) < 5e-3 and err.max() < 0.2, (np.median(err), np.quantile(err, 0.99), err.max())
+    # (measured, scratch/nsc_err_diag.py, profiles/r03_nsc_error_vs_conditioning.txt: median 2 - 4e-6, 99th percentile 0.5 - 1.1e-4, worst walker
+    # 2.7 - 4.3e-4, i.e. within 3 x (99 %) / 30 x (worst) of what a ONE-ulp change of the input does to the restatement's own result: the
+    # biases of this test model are scaled by 3e4, so a few walkers sit where the conditioner is steep)
+    assert np.median(err) < 2e-5 and np.quantile(err, 0.99) < 1e-3 and err.max() < 2e-2, (np.median(err), np.quantile(err, 0.99), err.max())
     m = log_pdf.model
     # flow / inverse round trip (exact inverse: a coupling layer conditions on the half it does not change)
     uf, ldf = m.flow(x)
-    assert np.array_equal(np.asarray(ldf) + 0 * 0, np.asarray(ldf)) and np.abs(np.asarray(ldf) - ld).max() < 0.2
+    assert np.array_equal(np.asarray(ldf) + 0 * 0, np.asarray(ldf)) and np.abs(np.asarray(ldf) - ld).max() < 2e-2
     xb = np.asarray(m.inverse(uf))
     e = np.abs(xb - x).max(1)
     assert np.median(e) < 5e-4 and np.quantile(e, 0.9) < 2e-2

@@ -87,6 +87,8 @@ struct ModelDev {
     const float* ob_to_b;         // [nbp][nbp] fp32, zero beyond nb (WAVEFLOW): row a = ob_to_b[a][:]
     const float* ob_to_b_t;       // the same with the boundary map folded into its rows (wf_model.cpp: bc_map): table-driven kernels
     const float* b_to_ob;         // [nbp][nbp] fp32, zero beyond nb (WAVEFLOW): the sampler's bound (bsplines_jax.py:164-166)
+    const float* p_cb;            // [nbp] or null: constant term of the B prior's boundary map, b @ ob_to_b (a constraint with a non-zero value,
+                                  // bsplines_jax.py:173-199): c = (A o) @ ob_to_b + (sum o) * p_cb -- the net's outputs reach the constraints divided by their sum
     float reverse_tol;            // IMADE reverse_fun_tol
     int i_gate, p_gate;           // set_nn_output_grad_to_zero of the layers' / the prior's conditioner (wf_model_desc)
     NetPlain nets[kMaxNets];      // flow layers 0..n_layers-1, then the prior net
@@ -117,6 +119,7 @@ struct MfmaDev {
     int exact_div;             // 1: x_l / n by IEEE division (set when the multiply-and-correct form is not bit-identical for this n_mesh)
     int prior_quotient;        // debug (env WF_PRIOR_QUOTIENT=1 at model creation): Waveflow prior head in the reference's quotient form
     int i_gate, p_gate;        // gated heads (wf_model_desc.i_gate / p_gate): zero_params blocks of the net images are live
+    int p_bias;                // the B prior's boundary map has a constant term: cbP[nbk][2][16] (accumulator layout) sits at the end of the constants block
 };
 
 constexpr int kStagedGroups = 4;   // staged mode: a wave's tile groups whose state waits in LDS between two nets (LDS: waves x groups x T x (D + 1) x 128 B)

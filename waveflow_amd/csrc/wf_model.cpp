@@ -126,6 +126,7 @@ struct wf_model {
     float* d_nsc = nullptr;          // its parameters on the device (the model's own copy)
     wf::NscModelDev nsc{};
     std::vector<double> bc_i_colsum, bc_p_colsum;
+    std::vector<float> p_cb;          // constant term of the B prior's boundary map times ob_to_b, natural order [nbp] (empty: homogeneous constraints)
     bool bc_i_ok = true, bc_p_ok = true;
     bool grad_psi_ok = false;        // wf_psi_vjp (Waveflow prior, IMADE layers)
     int ring2 = 2;                   // coefficient ring of the second-order sweeps (ring_coefs, wf_internal.h): 2 = RF, 1 = R3
@@ -214,7 +215,7 @@ static void bc_apply(const SplineDev& s, int kind, int nb, std::vector<double>& 
     }
 }
 // -> A [nb][nb] (c' = A c), column sums; false when the map keeps a constant term or has a column that sums to zero without being zero
-static bool bc_map(const SplineDev& s, int kind, int nb, std::vector<double>& A, std::vector<double>& colsum) {
+static bool bc_map(const SplineDev& s, int kind, int nb, std::vector<double>& A, std::vector<double>& colsum, std::vector<double>* bconst = nullptr) {
     A.assign((size_t)nb * nb, 0.0);
     colsum.assign(nb, 0.0);
     std::vector<double> c(nb, 0.0);
@@ -223,9 +224,13 @@ static bool bc_map(const SplineDev& s, int kind, int nb, std::vector<double>& A,
     for (int i = 0; i < nb; ++i) constant = constant || c[i] != 0.0;
     // A constant term b (a constraint with a non-zero value).  The I- and M-spline coefficients enter the constraints normalised
     // (remove_bias ends with p / sum p: isplines_jax.py:196-202, msplines_jax.py:186-192), so b = b (1^T c) and the map is the linear
-    // A + b 1^T on them; the B-spline prior's c = w @ ob_to_b carries no normalisation, and stays with the per-walker kernel.
+    // A + b 1^T on them.  The B-spline prior's weights reach the constraints divided by their signed sum S (model_factory.py:69) and are
+    // normalised only afterwards: w' = (A o + S b) / S, so the kernels carry b as a separate term (bconst; round 3) scaled by S = sum o.
     const bool fold = constant && (kind == WF_SPLINE_I || kind == WF_SPLINE_M);
-    if (constant && !fold) ok = false;
+    if (constant && !fold) {
+        if (bconst) *bconst = c;
+        else ok = false;
+    }
     for (int j = 0; j < nb; ++j) {
         std::vector<double> e(nb, 0.0);
         e[j] = 1.0;
@@ -459,8 +464,18 @@ static int model_build(wf_model* m) {
         rc = upload_table(m, o2b32, &md.ob_to_b);
         if (rc) return rc;
         {   // the constraints act on the net's outputs w before c = w @ ob_to_b: fold the map into the matrix's rows (row a = coefficient a)
-            std::vector<double> A;
-            m->bc_p_ok = bc_map(md.psp, WF_SPLINE_B, nb, A, m->bc_p_colsum);
+            std::vector<double> A, bconst;
+            m->bc_p_ok = bc_map(md.psp, WF_SPLINE_B, nb, A, m->bc_p_colsum, &bconst);
+            if (m->bc_p_ok && !bconst.empty()) {   // constant term: cb = b @ ob_to_b (the matrix as it is, before the map is folded into its rows)
+                m->p_cb.assign(m->nbp, 0.0f);
+                for (int i = 0; i < nb; ++i) {
+                    double acc = 0;
+                    for (int a = 0; a < nb; ++a) acc += bconst[a] * o2b[(size_t)a * nb + i];
+                    m->p_cb[i] = (float)acc;
+                }
+                rc = upload_table(m, m->p_cb, &md.p_cb);
+                if (rc) return rc;
+            }
             if (m->bc_p_ok) bc_transform_rows(A, m->bc_p_colsum, nb, 1, nb, o2b);
             for (int a = 0; a < nb; ++a)
                 for (int j = 0; j < nb; ++j) o2b32[(size_t)a * m->nbp + j] = (float)o2b[(size_t)a * nb + j];
@@ -871,7 +886,7 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
     const bool spline_prior = d.prior_kind == WF_PRIOR_WAVEFLOW || d.prior_kind == WF_PRIOR_MFLOW;
     if (spline_prior && !m->bc_p_ok) return WF_OK;
     const int n_nets = (int)m->nets.size();
-    const int consts = 64 * nbk + nbk * nbk * 1024 + 64 * nbk;   // fkI, fkP, ob_to_b image, piece bounds (flow table, prior table)
+    const int consts = 64 * nbk + nbk * nbk * 1024 + 64 * nbk + 32 * nbk;   // fkI, fkP, ob_to_b image, piece bounds (flow table, prior table), cbP (constant term of the B prior's boundary map)
     const int net_floats = mfma_net_floats(D, nbk);
     const int64_t lds_cap = 160 * 1024 / 4 - 64;   // floats (the kernel also holds a few bytes of static LDS: its tile counter)
     int staged;
@@ -889,6 +904,7 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
     md.exact_div = mfma_div_ok(md.n_mesh) ? 0 : 1;
     md.prior_quotient = (getenv("WF_PRIOR_QUOTIENT") && atoi(getenv("WF_PRIOR_QUOTIENT")) != 0) ? 1 : 0;
     md.i_gate = m->dev.i_gate; md.p_gate = m->dev.p_gate;
+    md.p_bias = (d.prior_kind == WF_PRIOR_WAVEFLOW && !m->p_cb.empty()) ? 1 : 0;
     // staged mode: one net slot + the state area of the super-chunk (16 waves x kStagedGroups tile groups x (D + 1) x 32 floats: the
     // built staged shapes run 8 waves of one tile; sized for the largest workgroup)
     m->mfma_lds_floats = consts + (staged ? net_floats + 16 * kStagedGroups * (D + 1) * 32 : net_floats * n_nets);
@@ -896,6 +912,12 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
     m->mfma_consts.assign(consts, 0.0f);
     int32_t* bnd = reinterpret_cast<int32_t*>(m->mfma_consts.data() + 64 * nbk + nbk * nbk * 1024);   // [2 tables][nbk][2 halves][16: 4 pieces x (lo, hi), 8 unused -- the lane stride of the fk blocks]
     for (int i = 0; i < 64 * nbk; ++i) bnd[i] = (i & 1) ? d.n_mesh - 1 : 0;   // (no clamp until a table says otherwise)
+    if (md.p_bias) {   // cbP[kb][h][r] = p_cb[row of register r in lane half h of block kb]
+        float* cb = m->mfma_consts.data() + 64 * nbk + nbk * nbk * 1024 + 64 * nbk;
+        for (int kb = 0; kb < nbk; ++kb)
+            for (int hh = 0; hh < 2; ++hh)
+                for (int r = 0; r < 16; ++r) cb[(kb * 2 + hh) * 16 + r] = m->p_cb[32 * kb + acc_row(r, hh)];
+    }
     std::vector<float> fk_nat(128, 0.0f);
     if (imade) {
         float* fk = m->mfma_consts.data();
@@ -1411,7 +1433,7 @@ int wf_hamiltonian_fwd(const wf_model* m, const float* x_dev, int64_t B, const f
         const int64_t tile_min = e ? atoll(e) : kEnergyTileMin;
         const wf_model_desc& d = m->desc;
         const bool family = D == 2 && m->nbp == 32 && m->mfma_ok && d.box_kind == WF_BOX_MEAN && d.layer_kind == WF_LAYER_IMADE &&
-                            d.n_flow_layers > 0 && !m->dev.i_gate && !m->dev.p_gate && m->d_tabI4c && m->d_tabP4c && !getenv("WF_ENERGY_R3");
+                            d.n_flow_layers > 0 && !m->dev.i_gate && !m->dev.p_gate && m->d_tabI4c && m->d_tabP4c && !m->mdev.p_bias && !getenv("WF_ENERGY_R3");
         if (family && tile_min > 0 && B >= tile_min && !m->eval_tables_stale) {
             // the conditioner and the head kernels exchange 384 B per walker and net through the scratch buffer: chunks that keep it
             // (and its re-use by the next net and the next chunk) inside the 256 MB memory-side cache instead of HBM
