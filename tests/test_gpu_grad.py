@@ -560,9 +560,11 @@ def test_abi_error_paths_of_the_gradient_entry_points(he_flat):
     om4 = oracle.Model(D=2, n_layers=1, i_k=5, i_knots=15, i_reg=0.0, i_left={0: 0.0, 1: 0.5}, i_right={0: 1.0, 1: 0.25}, prior="mflow", p_k=5,
                        p_knots=15, p_left={0: 0.3}, p_right={})
     _directional_check(lp4, p4, om4, X3, seed=14)
-    # the B-spline prior's coefficients carry no normalisation there: the per-walker kernel evaluates such a dictionary, the table-driven
-    # kernels and the gradients refuse it
-    from waveflow_amd import flows, wavefunctions
+    # the B-spline prior's coefficients reach the constraints divided by their signed sum and are normalised afterwards: its constant term
+    # travels as a separate vector (round 3: c = (A o) @ ob_to_b + (sum o) (b @ ob_to_b)) -- table-driven kernels and gradients cover it
+    # (test_wavefunction_with_a_nonzero_boundary_value_on_the_prior); here: the flow-free model of the reference's boundary test
+    from oracle import energy_torch as et
+    from waveflow_amd import flatten_params, flows, wavefunctions
     mt = model_factory.get_masked_transform
     init6 = wavefunctions.Waveflow(flows.Serial(flows.BoxTransformLayer(1.0)), mt(allow_negative_params=True), 5, 16,
                                    constraints_dict_left={0: 0.1}, constraints_dict_right={0: 0}, constrained_dimension_indices_left=[0],
@@ -570,11 +572,15 @@ def test_abi_error_paths_of_the_gradient_entry_points(he_flat):
     p6, psi6, lp6, _ = init6(0, 2)
     lp6.model.ensure_params(p6)
     x6 = sorted_walkers(8, 2, 1.0, 3)
-    assert np.isfinite(lp6(p6, x6)).all()
-    with pytest.raises(_lib.WfError):
-        lp6.model.logpdf_vjp(torch.as_tensor(x6).cuda(), w)
-    with pytest.raises(_lib.WfError):
-        lp6.model.set_kernel("mfma")
+    mo6 = et.TorchWaveflow(2, 0, "mean", 1.0, 5, 16, 0.0, (0,), dtype=torch.float64, p_left={0: 0.1}, p_right={0: 0.0})
+    f6 = flatten_params(p6)
+    for kernel in ("scalar", "mfma", "wave"):
+        lp6.model.set_kernel(kernel)
+        np.testing.assert_allclose(lp6(p6, x6), mo6.log_pdf(f6, torch.as_tensor(x6, dtype=torch.float64)).numpy(), rtol=0, atol=2e-3, err_msg=kernel)
+    lp6.model.set_kernel("auto")
+    got = lp6.model.logpdf_vjp(torch.as_tensor(x6).cuda(), w).cpu().numpy().astype(np.float64)      # (w: eight ones)
+    want = et.logpdf_vjp(mo6, f6, x6.astype(np.float64), np.ones(8, np.float32))
+    assert rel_l2(got, want) < 2e-3, rel_l2(got, want)
 
 
 def test_model_without_flow_layers(he_flat):
@@ -647,6 +653,78 @@ def test_wavefunction_with_derivative_constraints_energy_and_gradients():
     got = m.logpdf_vjp(x, w1).cpu().numpy().astype(np.float64)
     want = et.logpdf_vjp(mo, flat, x.astype(np.float64), w1)
     assert rel_l2(got, want) < 2e-3, rel_l2(got, want)
+
+
+@pytest.mark.parametrize("D", [2, 3])
+def test_wavefunction_with_a_nonzero_boundary_value_on_the_prior(D):
+    """A boundary dictionary with a NON-ZERO value on the B-spline prior (bsplines_jax.py:173-199: value 0.2 and first derivative 8 at the left end, -0.1 / -5 at the right one):
+    the net's outputs reach the constraints divided by their signed sum S (model_factory.py:69), w' = (A o + S b) / S, so the table-driven
+    kernels carry the constant term as c = (A o) @ ob_to_b + S (b @ ob_to_b) -- k_mfma (accumulator update), the wave sweeps (psi, H psi,
+    Laplacian) and the reverse sweeps (both vector-Jacobian products: the term reaches every raw output through S and the weights through
+    the norm).  Against the torch oracle, which enforces the dictionaries literally, and the per-walker kernel's literal sequence."""
+    import torch
+    from oracle import energy_torch as et
+    from waveflow_amd import flatten_params, flows, model_factory, wavefunctions
+    mt = model_factory.get_masked_transform
+    il, ir, pl, pr = {0: 0.0}, {0: 1.0}, {0: 0.2, 1: 8.0}, {0: -0.1, 1: -5.0}
+    init = wavefunctions.Waveflow(
+        flows.Serial(flows.BoxTransformLayer(3.0), *(flows.IMADE(mt(), 6, 23, 0.05, 1e-6, il, ir), flows.Reverse()) * 2),
+        mt(allow_negative_params=True), 6, 23, constraints_dict_left=pl, constraints_dict_right=pr, constrained_dimension_indices_left=list(range(D - 1)),
+        set_nn_output_grad_to_zero=False)
+    params, psi, log_pdf, _ = init(5, D)
+    flat = flatten_params(params)
+    mo = et.TorchWaveflow(D, 2, "mean", 3.0, 6, 23, 0.05, tuple(range(D - 1)), dtype=torch.float64, i_left=il, i_right=ir, p_left=pl, p_right=pr)
+    mo0 = et.TorchWaveflow(D, 2, "mean", 3.0, 6, 23, 0.05, tuple(range(D - 1)), dtype=torch.float64, i_left=il, i_right=ir, p_left={0: 0.0, 1: 0.0},
+                           p_right={0: 0.0, 1: 0.0})
+    x = sorted_walkers(160, D, 2.7, 13)
+    xt = torch.as_tensor(x, dtype=torch.float64)
+    m = psi.model
+    m.ensure_params(params)
+    po = mo.psi(flat, xt).numpy()
+    assert np.abs(po - mo0.psi(flat, xt).numpy()).max() > 2e-2 * np.abs(po).max()      # the constant term matters on this model
+    for kernel in ("scalar", "mfma", "wave"):
+        m.set_kernel(kernel)     # (no skip: every kernel covers the dictionary)
+        np.testing.assert_allclose(psi(params, x), po, rtol=0, atol=3e-5 * float(np.abs(po).max()), err_msg=kernel)
+        # (log of psi^2 + 1e-7 near the nodes: fp32 against the fp64 oracle; the literal per-walker kernel misses 3e-3 on one D = 3 walker at -18)
+        np.testing.assert_allclose(log_pdf(params, x), mo.log_pdf(flat, xt).numpy(), rtol=3e-4, atol=3e-3, err_msg=kernel)
+    m.set_kernel("auto")
+    # a large batch goes through k_mfma (the composite dimension-0 tables carry the term too): against the wave kernel
+    xb = sorted_walkers(20000, D, 2.7, 14)
+    m.set_kernel("mfma"); p_m = psi(params, xb)
+    m.set_kernel("wave"); p_w = psi(params, xb)
+    m.set_kernel("auto")
+    assert np.abs(p_m - p_w).max() <= 5e-5 * np.abs(p_w).max()
+    hp, ps, lap = m.hamiltonian(x, [0.0] * D, return_psi=True, return_laplacian=True)
+    ho, _, lo = et.hamiltonian(mo, flat, x.astype(np.float64), [0.0] * D)
+    np.testing.assert_allclose(lap, lo, rtol=0, atol=3e-3 * np.abs(lo).max())
+    np.testing.assert_allclose(hp, ho, rtol=0, atol=3e-3 * np.abs(ho).max())
+    # 20 000 walkers: H psi stays on the wave sweeps (the matrix-core tile path leaves this family out), finite and consistent with psi
+    hb, pb, _ = m.hamiltonian(xb, [0.0] * D, return_psi=True, return_laplacian=True)
+    assert np.isfinite(np.asarray(hb)).all() and np.abs(np.asarray(pb) - p_w).max() <= 5e-5 * np.abs(p_w).max()
+    g = np.random.default_rng(2)
+    w1, w2 = g.normal(size=len(x)).astype(np.float32), g.normal(size=len(x)).astype(np.float32)
+    got = m.psi_vjp(x, w1, 0.1 * w2).cpu().numpy().astype(np.float64)
+    want = et.psi_vjp(mo, flat, x.astype(np.float64), w1, 0.1 * w2)
+    assert rel_l2(got, want) < 5e-3, rel_l2(got, want)
+    got = m.logpdf_vjp(x, w1).cpu().numpy().astype(np.float64)
+    want = et.logpdf_vjp(mo, flat, x.astype(np.float64), w1)
+    assert rel_l2(got, want) < 2e-3, rel_l2(got, want)
+    # the wave sampler evaluates the same head: direct(sample) is the latent point it drew (exact inverse), and the columns it draws follow
+    # this psi^2 -- the one-lane-per-walker sampler (literal sequence) draws from the same distribution
+    if D == 2:
+        from scipy import stats
+        xs, lat = m.sample(3, 4000, return_latent=True, exact=True)
+        _, u = log_pdf(params, xs.cpu().numpy(), return_sample=True)
+        d = np.abs(np.asarray(u) - lat.cpu().numpy()).max(1)
+        assert np.median(d) < 1e-4 and np.quantile(d, 0.99) < 5e-3, (np.median(d), np.quantile(d, 0.99))
+        import os
+        os.environ["WF_WAVE_SAMPLE_MAX"] = "0"
+        try:
+            xs2, lat2 = m.sample(4, 4000, return_latent=True, exact=True)
+        finally:
+            del os.environ["WF_WAVE_SAMPLE_MAX"]
+        for c in range(2):
+            assert stats.ks_2samp(lat[:, c].cpu().numpy(), lat2[:, c].cpu().numpy()).pvalue > 1e-4
 
 
 @pytest.mark.parametrize("D,knots", [(2, 23), (3, 23), (2, 33), (4, 23)])

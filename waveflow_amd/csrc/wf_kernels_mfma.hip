@@ -76,8 +76,14 @@ __global__ __launch_bounds__(64) void k_dim0_coeffs(const ModelDev* __restrict__
         // dimension 0 of a gated head: g = 1, w = o + z (model_factory.py:64-67); net.zero holds zeros for an ungated net
         const bool gate = md.p_gate != 0;
         float c = 0.0f;
-        if (t < nb)
+        if (t < nb) {
             for (int a = 0; a < nb; ++a) c = __builtin_fmaf((gate ? net.b2[a] + net.zero[a] : net.b2[a]) * keep[a], md.ob_to_b_t[a * nbp + t], c);
+            if (md.p_cb) {   // constant term of the boundary map (a constraint with a non-zero value): + (sum of the raw outputs) * cb
+                float sraw = 0.0f;
+                for (int jj = 0; jj < nb; ++jj) sraw += gate ? net.b2[jj] + net.zero[jj] : net.b2[jj];
+                c = __builtin_fmaf(sraw, md.p_cb[t], c);
+            }
+        }
         sh[t] = c;
         out[t] = c;
         __syncthreads();

@@ -300,11 +300,12 @@ __device__ __forceinline__ T sigmoid_head_bwd(const SigHead<T>& h, T gc, bool va
 // rounding into Laplacians of 1e3..inf while the function itself is smooth.
 template <class T> struct PsiHead {
     T o, rN1, rN2, a, e;
+    T sabs;      // |S| = sgn * sum of the raw outputs (used with a constant term of the boundary map only)
     float sgn;
 };
 template <class T, int NBK = 1>
 __device__ __forceinline__ PsiHead<T> psi_head(T o, bool valid, bool valid_d, float keep, const float* __restrict__ o2b, float (*ov)[64], int lane,
-                                               bool gate = false, T gq = T{}, float z = 0.0f) {
+                                               bool gate = false, T gq = T{}, float z = 0.0f, const float* __restrict__ cb = nullptr) {
     PsiHead<T> h;
     h.o = valid ? o : cst<T>(0.0f);
     if (gate && valid) h.o = gq * o + z;
@@ -315,7 +316,14 @@ __device__ __forceinline__ PsiHead<T> psi_head(T o, bool valid, bool valid_d, fl
     h.rN1 = rrsqrt(N1);
     h.a = w * h.rN1;
     put(ov, lane, h.a);
-    const T c = gemv32_cols<T, NBK>(o2b, ov, lane >> 5, NBK == 1 ? (lane & 31) : lane);   // c_j = sum_a a_a ob_to_b[a][j]
+    T c = gemv32_cols<T, NBK>(o2b, ov, lane >> 5, NBK == 1 ? (lane & 31) : lane);   // c_j = sum_a a_a ob_to_b[a][j]
+    h.sabs = cst<T>(0.0f);
+    if (cb) {
+        // a boundary constraint with a non-zero value (bsplines_jax.py:173-199): the weights reach the constraints divided by their sum S
+        // (model_factory.py:69), w' = (A o + S b) / S, so sign(S) w' M is proportional to a M + (|S| / |o keep|) (b M), b M = cb
+        h.sabs = rsum<NBK>(h.o) * h.sgn;
+        c = c + (h.sabs * h.rN1) * cb[NBK == 1 ? (lane & 31) : lane];
+    }
     T N2 = rsum<NBK>(c * c);
     if (!valid_d) N2 = cst<T>(1.0f);
     h.rN2 = rrsqrt(N2);
@@ -501,7 +509,7 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(kOccFwd<T>,
                 lerp4<W>(tabP, plane, lp, j, t);
                 T val;
                 if (md.prior_kind == WF_PRIOR_WAVEFLOW) {
-                    const PsiHead<T> hd = psi_head<T, NBK>(o, valid, valid_d, kP[j], md.ob_to_b_t, ov, lane, gate_p, gq, net.z[p * 64 + lane]);
+                    const PsiHead<T> hd = psi_head<T, NBK>(o, valid, valid_d, kP[j], md.ob_to_b_t, ov, lane, gate_p, gq, net.z[p * 64 + lane], md.p_cb);
                     val = rsum<NBK>(hd.e * lift(t, 0, uc));
                 } else {
                     const SigHead<T> hd = sigmoid_head<T, NBK>(o, valid, valid_d, kP[j], 0.0f, gate_p, gq, net.z[p * 64 + lane]);
@@ -815,7 +823,7 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(kOccBwd<T>,
                 const T gv = sel(dl == 0, gv_lo, gv_hi);
                 T go, d1;
                 if (md.prior_kind == WF_PRIOR_WAVEFLOW) {
-                    const PsiHead<T> hd = psi_head<T, NBK>(o, valid, valid_d, kP[j], md.ob_to_b_t, ov, lane, gate_p, gq, net.z[p * 64 + lane]);
+                    const PsiHead<T> hd = psi_head<T, NBK>(o, valid, valid_d, kP[j], md.ob_to_b_t, ov, lane, gate_p, gq, net.z[p * 64 + lane], md.p_cb);
                     const T ge = gv * lift(t, 0, uc);
                     const T dotE = rsum<NBK>(ge * hd.e);
                     d1 = rsum<NBK>(hd.e * lift(t, 1, uc));
@@ -823,7 +831,15 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(kOccBwd<T>,
                     put(ov, lane, gc);
                     const T ga = gemv32_rows<T, NBK>(md.ob_to_b_t, ov, dl, j);          // abar_a = sum_j cbar_j ob_to_b[a][j]
                     const T dotA = rsum<NBK>(ga * hd.a);
-                    go = ((ga - hd.a * dotA) * hd.rN1) * (valid ? kP[j] * hd.sgn : 0.0f);
+                    T wbar = (ga - hd.a * dotA) * hd.rN1;
+                    T sbar = cst<T>(0.0f);
+                    if (md.p_cb) {   // c = a M + beta cb, beta = |S| rN1: betabar = <cbar, cb>; through rN1 = |w|^-1 into w, through |S| into every raw output
+                        const T bbar = rsum<NBK>(gc * md.p_cb[NBK == 1 ? (lane & 31) : lane]);
+                        wbar = wbar - hd.a * ((bbar * hd.sabs) * (hd.rN1 * hd.rN1));
+                        sbar = (bbar * hd.rN1) * hd.sgn;
+                    }
+                    go = wbar * (valid ? kP[j] * hd.sgn : 0.0f);
+                    if (md.p_cb && valid) go = go + sbar;
                     if (gate_p) {   // w = gq * o + z: `go` so far is wbar
                         zbar = go;
                         gqb = rsum<NBK>(go * o);
@@ -1179,7 +1195,7 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(WF_OCC_SAMP
                     };
                     if (wavefn) {
                         // sample_fun (bsplines_jax.py:144-171): obw = normalised(w @ ob_to_b); ymax = max((obw @ b_to_ob)^2)
-                        const PsiHead<R1> hdw = psi_head<R1, NBK>(o, valid, valid_d, kP[j], md.ob_to_b_t, ov, lane, md.p_gate != 0, R1{gcol}, net.z[p * 64 + lane]);
+                        const PsiHead<R1> hdw = psi_head<R1, NBK>(o, valid, valid_d, kP[j], md.ob_to_b_t, ov, lane, md.p_gate != 0, R1{gcol}, net.z[p * 64 + lane], md.p_cb);
                         cj = hdw.e.c0;
                         put(ov, lane, hdw.e);
                         const float q = gemv32_cols<R1, NBK>(md.b_to_ob, ov, dl, j).c0;

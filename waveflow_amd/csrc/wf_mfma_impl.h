@@ -580,6 +580,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
     const float* ob2b = lds + 64 * NBK;            // [NBK out][NBK in]{hi, lo}[2 K steps][64][8 halves] ob_to_b in f16-MFMA A order
     const float* bndI = ob2b + NBK * NBK * 1024;   // int32 [NBK][2][16]: support bounds of the table pieces (fetch_block), at the lane stride of fkI / fkP
     const float* bndP = bndI + 32 * NBK;
+    const float* cbP = bndP + 32 * NBK;            // [NBK][2][16] constant term of the B prior's boundary map times ob_to_b (mm.p_bias)
     float* slots = lds + mm.const_floats;
     const int64_t n_tiles = (B + 31) >> 5;
     constexpr int kTilesPerChunk = kWaves * T;
@@ -857,6 +858,12 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
                                         c[ko] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, of[ki].lo[s], c[ko], 0, 0, 0);
                                         c[ko] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, of[ki].hi[s], c[ko], 0, 0, 0);
                                     }
+                                if (!SPEC && mm.p_bias) {   // a boundary constraint with a non-zero value: c += (sum o) * cb, in the scaled units of c
+                                    const float bs = scale * s1;
+                                    const f32x16 cb = load16(cbP + (ko * 2 + h) * 16);
+#pragma unroll
+                                    for (int r = 0; r < 16; ++r) c[ko][r] = __builtin_fmaf(bs, cb[r], c[ko][r]);
+                                }
 #pragma unroll
                                 for (int r = 0; r < 16; ++r) n2 = __builtin_fmaf(c[ko][r], c[ko][r], n2);
                             }
@@ -1049,7 +1056,7 @@ int launch_dw(const MfmaDev* mdev, int lds_bytes, int mode, const float* x, int6
     }
     if constexpr (D == 2) {   // the specialised build exists for the two-particle shapes
         if (mdev->box_kind == WF_BOX_MEAN && mdev->layer_kind == WF_LAYER_IMADE && mdev->prior_kind == WF_PRIOR_WAVEFLOW && !mdev->staged &&
-            !mdev->exact_div && !mdev->i_gate && !mdev->p_gate)
+            !mdev->exact_div && !mdev->i_gate && !mdev->p_gate && !mdev->p_bias)
             return launch_dwi<D, NBK, kWaves, T, false, true>(mdev, lds_bytes, mode, x, B, out, u, nullptr, s);
     }
     return launch_dwi<D, NBK, kWaves, T, false, false>(mdev, lds_bytes, mode, x, B, out, u, nullptr, s);
