@@ -47,3 +47,19 @@ for mode in ("fused", "pernet"):
     print("%-7s 2^20 walkers: %.4f ms per call = %.3e walkers/s   bit-reproducible: %s" % (mode, ms, (1 << 20) / ms * 1e3, same))
     for k in env:
         del os.environ[k]
+
+# BASELINE's "32-bin" variant (33 knots: two 32-row blocks per dimension), seeded parameters: the one-kernel form against the wave kernel
+m33 = bench.seeded_model(2, 33, "auto")
+xs = sorted_walkers(50001, 2, 10.0, 3)
+os.environ["WF_ENERGY_TILE_MIN"] = "1"
+a = [np.asarray(t, dtype=np.float64) for t in m33.hamiltonian(xs, protons, return_psi=True, return_laplacian=True)]
+os.environ["WF_ENERGY_TILE_MIN"] = "0"
+b = [np.asarray(t, dtype=np.float64) for t in m33.hamiltonian(xs, protons, return_psi=True, return_laplacian=True)]
+for k, nm in enumerate(("hpsi", "psi", "lap")):
+    d = np.abs(a[k] - b[k]); sc = np.abs(b[k]).max()
+    print("33 knots: fused vs wave %-4s: max %.2e median %.2e of the batch maximum" % (nm, d.max() / sc, np.median(d) / sc))
+for mode, tm in (("fused", "1"), ("wave", "0")):
+    os.environ["WF_ENERGY_TILE_MIN"] = tm
+    ms = bench.event_ms(lambda: m33.hamiltonian(xt, protons), 10 if mode == "fused" else 3, 5 if mode == "fused" else 1)
+    print("33 knots %-5s 2^20 walkers: %.4f ms per call = %.3e walkers/s" % (mode, ms, (1 << 20) / ms * 1e3))
+del os.environ["WF_ENERGY_TILE_MIN"]

@@ -209,6 +209,8 @@ def test_local_energy_tile_path_other_models(monkeypatch):
     cases = [
         dict(L=3.0, n=2, k=6, kn=23, il=il, ir=ir, pl=pl, pr=pr),
         dict(L=2.0, n=1, k=5, kn=16, il={0: 0.0}, ir={0: 1.0}, pl={0: 0}, pr={0: 0}),
+        # 33 knots = 39 / 38 bases: two 32-row blocks per dimension (BASELINE's "32-bin" variant of C3) -- the one-kernel form only
+        dict(L=10.0, n=3, k=6, kn=33, il={0: 0.0}, ir={0: 1.0}, pl={0: 0}, pr={0: 0}),
     ]
     for c in cases:
         init = wavefunctions.Waveflow(

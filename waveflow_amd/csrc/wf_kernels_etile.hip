@@ -174,19 +174,22 @@ __device__ __forceinline__ void init_acc(f32x16 (&acc)[NCH], const float* bias16
     for (int c = 1; c < NCH; ++c) acc[c] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 }
 
-// The conditioner of one net for one tile: Taylor triples (f, f', f'') in u_0 of the head's 32 pre-activations (dimension 1) in the accumulator
-// layout -> a0[channel][register].  PRIOR: the triples of c = (o * keep) @ ob_to_b instead, and the sum of the raw outputs (for the sign).
-template <bool PRIOR>
-__device__ __forceinline__ void cond_net(const float* net, const float* fkP, const _Float16* obh, float u0v, float u1v, int lane, f32x16 (&a0)[NCH], float& s1) {
+// The conditioner of one net for one tile, in pieces (NBK = 32-row blocks per dimension: 1 for <= 32 bases, 2 for <= 64).
+//   cond_hidden   the two hidden layers: B fragments (split fp16, derivative channels scaled by 2^-e) of the second hidden layer's activations
+//   cond_out      one 32-row output block of dimension 1: Taylor triples (f, f', f'') in u_0 of the head's pre-activations, accumulator layout
+//   prior_c       the prior head's c = (o * keep) @ ob_to_b as triples, one 32-row block of c at a time, + the sum of the raw outputs (sign)
+template <int NBK>
+__device__ __forceinline__ void cond_hidden(const float* net, float u0v, float u1v, int lane, Frag (&f)[NCH][2], int (&e)[NCH]) {
+    using O = NetOff<2, NBK>;
     const int h = lane >> 5;
     // the conditioner's inputs: (u_0, u_1) values; the Taylor seed in u_0 is (u_0, 1, 0) (u_1 reaches no hidden unit: masked weights)
     const float in0[2] = {u0v, 1.0f}, in1[2] = {u1v, 0.0f};
     // ---- layer 1 (f32 MFMA, K = 2: the two coordinates), both 32-unit blocks; the second-derivative channel starts at zero
-    f32x16 a1[NCH];
-    init_acc(a0, net + O2::b0 + (0 * 2 + h) * 16);
-    init_acc(a1, net + O2::b0 + (1 * 2 + h) * 16);
+    f32x16 a0[NCH], a1[NCH];
+    init_acc(a0, net + O::b0 + (0 * 2 + h) * 16);
+    init_acc(a1, net + O::b0 + (1 * 2 + h) * 16);
     {
-        const float w0 = net[O2::W0 + 0 * 64 + lane], w1 = net[O2::W0 + 1 * 64 + lane];
+        const float w0 = net[O::W0 + 0 * 64 + lane], w1 = net[O::W0 + 1 * 64 + lane];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             a0[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, h ? in1[c] : in0[c], a0[c], 0, 0, 0);
@@ -195,14 +198,12 @@ __device__ __forceinline__ void cond_net(const float* net, const float* fkP, con
     }
     act_block(a0);
     act_block(a1);
-    Frag f[NCH][2];
-    int e[NCH];
     to_frags(a0, a1, f, e);
     // ---- layer 2
-    const _Float16* W1h = reinterpret_cast<const _Float16*>(net + O2::W1h);
-    const _Float16* W1l = reinterpret_cast<const _Float16*>(net + O2::W1l);
-    init_acc(a0, net + O2::b1 + (0 + h) * 16);
-    init_acc(a1, net + O2::b1 + (2 + h) * 16);
+    const _Float16* W1h = reinterpret_cast<const _Float16*>(net + O::W1h);
+    const _Float16* W1l = reinterpret_cast<const _Float16*>(net + O::W1l);
+    init_acc(a0, net + O::b1 + (0 + h) * 16);
+    init_acc(a1, net + O::b1 + (2 + h) * 16);
     dense64_block<NCH>(W1h, W1l, f, a0, lane);
     dense64_block<NCH>(W1h + 2048, W1l + 2048, f, a1, lane);
     unscale(a0, e);
@@ -210,55 +211,91 @@ __device__ __forceinline__ void cond_net(const float* net, const float* fkP, con
     act_block(a0);
     act_block(a1);
     to_frags(a0, a1, f, e);
-    // ---- output block of dimension 1 (dimension 0 is table-driven: k_prepare_dim0)
-    const _Float16* W2h = reinterpret_cast<const _Float16*>(net + O2::W2h);
-    const _Float16* W2l = reinterpret_cast<const _Float16*>(net + O2::W2l);
-    init_acc(a0, net + O2::b2 + (1 * 2 + h) * 16);
-    dense64_block<NCH>(W2h, W2l, f, a0, lane);
+}
+// output block kb of dimension 1 (dimension 0 is table-driven: k_prepare_dim0)
+template <int NBK>
+__device__ __forceinline__ void cond_out(const float* net, const Frag (&f)[NCH][2], const int (&e)[NCH], int kb, int lane, f32x16 (&a0)[NCH]) {
+    using O = NetOff<2, NBK>;
+    const int h = lane >> 5;
+    const _Float16* W2h = reinterpret_cast<const _Float16*>(net + O::W2h);
+    const _Float16* W2l = reinterpret_cast<const _Float16*>(net + O::W2l);
+    init_acc(a0, net + O::b2 + ((1 * NBK + kb) * 2 + h) * 16);
+    dense64_block<NCH>(W2h + kb * 2048, W2l + kb * 2048, f, a0, lane);
     unscale(a0, e);
-    if (PRIOR) {
-        // w = o * keep (jets); c = w @ ob_to_b on the matrix cores, every channel scaled (the head is unbounded); sum of the raw
-        // outputs for the sign (model_factory.py:69, sign form as in k_mfma)
-        s1 = 0.0f;
-        const f32x16 keep = load16(fkP + h * 16);
+}
+// the prior head behind cond_out: of[ki][c] = fragments of w = o * keep (every (walker, channel) column of the 32 * NBK rows scaled by one power of
+// two: the head is unbounded), eo[c] the exponents, s1 = sum of the raw outputs (model_factory.py:69: its sign, as in k_mfma)
+template <int NBK>
+__device__ __forceinline__ void prior_frags(f32x16 (&o)[NBK][NCH], const float* fkP, int lane, Frag (&of)[NBK][NCH], int (&eo)[NCH], float& s1) {
+    const int h = lane >> 5;
+    s1 = 0.0f;
+    float amax[NCH] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s1 += a0[0][r];
-        s1 = xhalf_sum(s1);
-        Frag of[NCH];
-        int eo[NCH];
+    for (int kb = 0; kb < NBK; ++kb) {
+        const f32x16 keep = load16(fkP + (kb * 2 + h) * 16);
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            float amax = 0.0f;
+        for (int r = 0; r < 16; ++r) s1 += o[kb][0][r];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                a0[c][r] = a0[c][r] * keep[r];
-                amax = fmaxf(amax, fabsf(a0[c][r]));
+                o[kb][c][r] = o[kb][c][r] * keep[r];
+                amax[c] = fmaxf(amax[c], fabsf(o[kb][c][r]));
             }
-            eo[c] = col_exponent(amax);
-            const float sc = __builtin_amdgcn_ldexpf(1.0f, -eo[c]);
+    }
+    s1 = xhalf_sum(s1);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        eo[c] = col_exponent(amax[c]);
+        const float sc = __builtin_amdgcn_ldexpf(1.0f, -eo[c]);
+#pragma unroll
+        for (int kb = 0; kb < NBK; ++kb)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 float r8[8];
 #pragma unroll
-                for (int jj = 0; jj < 8; ++jj) r8[jj] = a0[c][8 * s + jj] * sc;
-                split8(r8, of[c].hi[s], of[c].lo[s]);
+                for (int jj = 0; jj < 8; ++jj) r8[jj] = o[kb][c][8 * s + jj] * sc;
+                split8(r8, of[kb][c].hi[s], of[kb][c].lo[s]);
             }
-        }
+    }
+}
+// block ko of c = w @ ob_to_b (obh: [ko][ki]{hi 1024, lo 1024} halves in f16-MFMA A order), three channels
+template <int NBK>
+__device__ __forceinline__ void prior_c_block(const _Float16* obh, const Frag (&of)[NBK][NCH], const int (&eo)[NCH], int ko, int lane, f32x16 (&cblk)[NCH]) {
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            f32x16 acc = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int c = 0; c < NCH; ++c) {
+        f32x16 acc = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int ki = 0; ki < NBK; ++ki)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const f16x8 ah = *reinterpret_cast<const f16x8*>(obh + (s * 64 + lane) * 8);
-                const f16x8 al = *reinterpret_cast<const f16x8*>(obh + 1024 + (s * 64 + lane) * 8);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, of[c].hi[s], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, of[c].lo[s], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, of[c].hi[s], acc, 0, 0, 0);
+                const _Float16* blk = obh + (size_t)(ko * NBK + ki) * 2048;
+                const f16x8 ah = *reinterpret_cast<const f16x8*>(blk + (s * 64 + lane) * 8);
+                const f16x8 al = *reinterpret_cast<const f16x8*>(blk + 1024 + (s * 64 + lane) * 8);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, of[ki][c].hi[s], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, of[ki][c].lo[s], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, of[ki][c].hi[s], acc, 0, 0, 0);
             }
-            const float sc = __builtin_amdgcn_ldexpf(1.0f, eo[c]);
+        const float sc = __builtin_amdgcn_ldexpf(1.0f, eo[c]);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) a0[c][r] = acc[r] * sc;
-        }
+        for (int r = 0; r < 16; ++r) cblk[c][r] = acc[r] * sc;
+    }
+}
+// the whole conditioner for <= 32 bases (the launch-per-net path): head triples (PRIOR: of c) in a0, the sum of the raw outputs in s1
+template <bool PRIOR>
+__device__ __forceinline__ void cond_net(const float* net, const float* fkP, const _Float16* obh, float u0v, float u1v, int lane, f32x16 (&a0)[NCH], float& s1) {
+    Frag f[NCH][2];
+    int e[NCH];
+    cond_hidden<1>(net, u0v, u1v, lane, f, e);
+    if (!PRIOR) {
+        cond_out<1>(net, f, e, 0, lane, a0);
+    } else {
+        f32x16 o[1][NCH];
+        cond_out<1>(net, f, e, 0, lane, o[0]);
+        Frag of[1][NCH];
+        int eo[NCH];
+        prior_frags<1>(o, fkP, lane, of, eo, s1);
+        prior_c_block<1>(obh, of, eo, 0, lane, a0);
     }
 }
 
@@ -527,33 +564,89 @@ __device__ __forceinline__ void box_mean2(float x0v, float x1v, float L, J& u0, 
 }
 // chunk 2q + h of the lane at both lerp ends, every order; bnd: [8 chunks][lo, hi] support bounds (the chunk at the clamped index holds the same bits)
 template <int NO>
-__device__ __forceinline__ void chunk_rows(const float* __restrict__ tab, const int* bnd, const LerpN& L, int ch, float4_t (&ta)[NO], float4_t (&tb)[NO]) {
+__device__ __forceinline__ void chunk_rows(const float* __restrict__ tab, int mesh_stride, const int* bnd, const LerpN& L, int ch, float4_t (&ta)[NO], float4_t (&tb)[NO]) {
     const int lo = bnd[2 * ch], hi = bnd[2 * ch + 1];
-    const float4_t* rl = reinterpret_cast<const float4_t*>(tab + (size_t)min(max(L.il, lo), hi) * 128) + ch * 4;
-    const float4_t* rr = reinterpret_cast<const float4_t*>(tab + (size_t)min(max(L.ir, lo), hi) * 128) + ch * 4;
+    const float4_t* rl = reinterpret_cast<const float4_t*>(tab + (size_t)min(max(L.il, lo), hi) * mesh_stride) + ch * 4;
+    const float4_t* rr = reinterpret_cast<const float4_t*>(tab + (size_t)min(max(L.ir, lo), hi) * mesh_stride) + ch * 4;
 #pragma unroll
     for (int k = 0; k < NO; ++k) {
         ta[k] = rl[k];
         tb[k] = rr[k];
     }
 }
+// row sums of one flow head (see T2) over the lane's 16 rows of block kb
+struct FlowSums {
+    float S[3], Qv[3], R[4], V0[4], V1[3], V2[2];
+};
+__device__ __forceinline__ void flow_rows(FlowSums& a, const f32x16 (&o)[NCH], const f32x16& g16, const float* __restrict__ tabI, int mesh_stride, const int* bnd,
+                                          const LerpN& L, int kb, int h) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float4_t ta[4], tb[4];
+        chunk_rows<4>(tabI, mesh_stride, bnd, L, 8 * kb + 2 * q + h, ta, tb);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = 4 * q + e;
+            float v0, v1, v2;
+            r_triple(o[0][r], o[1][r], o[2][r], v0, v1, v2);
+            const float g = g16[r];
+            float t[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t[k] = __builtin_fmaf(tb[k][e] - ta[k][e], L.t, ta[k][e]) * g;
+            a.S[0] += v0; a.S[1] += v1; a.S[2] += v2;
+            a.Qv[0] = __builtin_fmaf(v0, g, a.Qv[0]); a.Qv[1] = __builtin_fmaf(v1, g, a.Qv[1]); a.Qv[2] = __builtin_fmaf(v2, g, a.Qv[2]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { a.V0[k] = __builtin_fmaf(v0, t[k], a.V0[k]); a.R[k] += t[k]; }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) a.V1[k] = __builtin_fmaf(v1, t[k], a.V1[k]);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) a.V2[k] = __builtin_fmaf(v2, t[k], a.V2[k]);
+        }
+    }
+}
+struct PriorSums {
+    float D0[3], D1[2], D2, cc, cc1, c1c1, cc2;
+};
+__device__ __forceinline__ void prior_rows(PriorSums& a, const f32x16 (&c)[NCH], const float* __restrict__ tabP, int mesh_stride, const int* bnd, const LerpN& L,
+                                           int kb, int h) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float4_t ta[3], tb[3];
+        chunk_rows<3>(tabP, mesh_stride, bnd, L, 8 * kb + 2 * q + h, ta, tb);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = 4 * q + e;
+            const float c0 = c[0][r], c1 = c[1][r], c2 = c[2][r];
+            float t[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) t[k] = __builtin_fmaf(tb[k][e] - ta[k][e], L.t, ta[k][e]);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) a.D0[k] = __builtin_fmaf(c0, t[k], a.D0[k]);
+            a.D1[0] = __builtin_fmaf(c1, t[0], a.D1[0]); a.D1[1] = __builtin_fmaf(c1, t[1], a.D1[1]);
+            a.D2 = __builtin_fmaf(c2, t[0], a.D2);
+            a.cc = __builtin_fmaf(c0, c0, a.cc); a.cc1 = __builtin_fmaf(c0, c1, a.cc1); a.c1c1 = __builtin_fmaf(c1, c1, a.c1c1); a.cc2 = __builtin_fmaf(c0, c2, a.cc2);
+        }
+    }
+}
 
+template <int NBK>
 __global__ __launch_bounds__(kFusedWaves * 64) void k_efused(const MfmaDev mm, const float* __restrict__ tabI, const float* __restrict__ tabP,
                                                              const float* __restrict__ xg, int64_t B, const Protons pr, float* __restrict__ hpsi,
                                                              float* __restrict__ psi_out, float* __restrict__ lap_out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ int next_tile;
-    __shared__ int bnd_s[32];   // support bounds of the table chunks: [I: 8][lo, hi], [prior: 8][lo, hi]
+    __shared__ int bnd_s[32 * NBK];   // support bounds of the table chunks: [I: 8 NBK][lo, hi], [prior: 8 NBK][lo, hi]
     constexpr int kThreads = kFusedWaves * 64;
+    constexpr int kMeshStride = 128 * NBK;   // floats per mesh point of the regrouped tables: [8 NBK chunks][4 orders][4 rows]
     if (threadIdx.x == 0) next_tile = 0;
-    if (threadIdx.x < 16) bnd_s[threadIdx.x] = reinterpret_cast<const int*>(tabI + (size_t)mm.n_mesh * 128)[threadIdx.x];
-    else if (threadIdx.x < 32) bnd_s[threadIdx.x] = reinterpret_cast<const int*>(tabP + (size_t)mm.n_mesh * 128)[threadIdx.x - 16];
+    if (threadIdx.x < 16 * NBK) bnd_s[threadIdx.x] = reinterpret_cast<const int*>(tabI + (size_t)mm.n_mesh * kMeshStride)[threadIdx.x];
+    else if (threadIdx.x < 32 * NBK) bnd_s[threadIdx.x] = reinterpret_cast<const int*>(tabP + (size_t)mm.n_mesh * kMeshStride)[threadIdx.x - 16 * NBK];
     stage_floats<kThreads>(mm.image + mm.const_img_off, lds, mm.const_floats);
     stage_floats<kThreads>(mm.image, lds + mm.const_floats, mm.net_floats * mm.n_nets);
     __syncthreads();
     const float* fkI = lds;
-    const float* fkP = lds + 32;
-    const _Float16* obh = reinterpret_cast<const _Float16*>(lds + 64);
+    const float* fkP = lds + 32 * NBK;
+    const _Float16* obh = reinterpret_cast<const _Float16*>(lds + 64 * NBK);
     const int lane = threadIdx.x & 63;
     const int j = lane & 31, h = lane >> 5;
     const int n_mesh = mm.n_mesh;
@@ -574,9 +667,9 @@ __global__ __launch_bounds__(kFusedWaves * 64) void k_efused(const MfmaDev mm, c
         // ---- flow layers (made.py:66-81 + Reverse)
         for (int l = 0; l < mm.n_layers; ++l) {
             const float* net = lds + mm.const_floats + (size_t)l * mm.net_floats;
-            f32x16 a0[NCH];
-            float s1_unused = 0.0f;
-            cond_net<false>(net, fkP, obh, u0.v, u1.v, lane, a0, s1_unused);
+            Frag f[NCH][2];
+            int e[NCH];
+            cond_hidden<NBK>(net, u0.v, u1.v, lane, f, e);
             // dimension 0: composite table of the net, all four orders
             J y0;
             {
@@ -588,42 +681,23 @@ __global__ __launch_bounds__(kFusedWaves * 64) void k_efused(const MfmaDev mm, c
                 y0 = jlift(t0, t1, t2, u0);
                 ld = ld + jlog(jlift(t1, t2, t3, u0) + 1e-7f);
             }
-            // dimension 1: the lane's 16 rows
+            // dimension 1: the lane's 16 rows of every 32-row block
             const LerpN L = nlerp(u1.v, n_mesh);
-            float S[3] = {0.0f, 0.0f, 0.0f}, Qv[3] = {0.0f, 0.0f, 0.0f}, R[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            float V0[4] = {0.0f, 0.0f, 0.0f, 0.0f}, V1[3] = {0.0f, 0.0f, 0.0f}, V2[2] = {0.0f, 0.0f};
-            const f32x16 g16 = load16(fkI + h * 16);
+            FlowSums a = {};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float4_t ta[4], tb[4];
-                chunk_rows<4>(tabI, bnd_s, L, 2 * q + h, ta, tb);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = 4 * q + e;
-                    float v0, v1, v2;
-                    r_triple(a0[0][r], a0[1][r], a0[2][r], v0, v1, v2);
-                    const float g = g16[r];
-                    float t[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) t[k] = __builtin_fmaf(tb[k][e] - ta[k][e], L.t, ta[k][e]) * g;
-                    S[0] += v0; S[1] += v1; S[2] += v2;
-                    Qv[0] = __builtin_fmaf(v0, g, Qv[0]); Qv[1] = __builtin_fmaf(v1, g, Qv[1]); Qv[2] = __builtin_fmaf(v2, g, Qv[2]);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) { V0[k] = __builtin_fmaf(v0, t[k], V0[k]); R[k] += t[k]; }
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) V1[k] = __builtin_fmaf(v1, t[k], V1[k]);
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) V2[k] = __builtin_fmaf(v2, t[k], V2[k]);
-                }
+            for (int kb = 0; kb < NBK; ++kb) {
+                f32x16 o[NCH];
+                cond_out<NBK>(net, f, e, kb, lane, o);
+                flow_rows(a, o, load16(fkI + (kb * 2 + h) * 16), tabI, kMeshStride, bnd_s, L, kb, h);
             }
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { S[k] = xhalf_sum(S[k]); Qv[k] = xhalf_sum(Qv[k]); V1[k] = xhalf_sum(V1[k]); }
+            for (int k = 0; k < 3; ++k) { a.S[k] = xhalf_sum(a.S[k]); a.Qv[k] = xhalf_sum(a.Qv[k]); a.V1[k] = xhalf_sum(a.V1[k]); }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { R[k] = xhalf_sum(R[k]); V0[k] = xhalf_sum(V0[k]); }
+            for (int k = 0; k < 4; ++k) { a.R[k] = xhalf_sum(a.R[k]); a.V0[k] = xhalf_sum(a.V0[k]); }
 #pragma unroll
-            for (int k = 0; k < 2; ++k) V2[k] = xhalf_sum(V2[k]);
+            for (int k = 0; k < 2; ++k) a.V2[k] = xhalf_sum(a.V2[k]);
             J y1;
-            flow_head_finish(S, Qv, R, mm.F_I, V0, V1, V2, mm.i_reg, u0, u1, y1, ld);
+            flow_head_finish(a.S, a.Qv, a.R, mm.F_I, a.V0, a.V1, a.V2, mm.i_reg, u0, u1, y1, ld);
             u0 = y1;   // Reverse (bijections.py:337-340)
             u1 = y0;
         }
@@ -631,9 +705,18 @@ __global__ __launch_bounds__(kFusedWaves * 64) void k_efused(const MfmaDev mm, c
         J psi;
         {
             const float* net = lds + mm.const_floats + (size_t)mm.n_layers * mm.net_floats;
-            f32x16 a0[NCH];
             float s1 = 0.0f;
-            cond_net<true>(net, fkP, obh, u0.v, u1.v, lane, a0, s1);   // (the conditioner sees the unclipped u_0, wavefunctions.py:40)
+            Frag of[NBK][NCH];
+            int eo[NCH];
+            {
+                Frag f[NCH][2];
+                int e[NCH];
+                cond_hidden<NBK>(net, u0.v, u1.v, lane, f, e);   // (the conditioner sees the unclipped u_0, wavefunctions.py:40)
+                f32x16 o[NBK][NCH];
+#pragma unroll
+                for (int kb = 0; kb < NBK; ++kb) cond_out<NBK>(net, f, e, kb, lane, o[kb]);
+                prior_frags<NBK>(o, fkP, lane, of, eo, s1);
+            }
             const J uc0 = (u0.v < 0.0f) ? jc(0.0f) : (u0.v > 1.0f ? jc(1.0f) : u0);   // the spline sees the clipped coordinate (:45)
             const J uc1 = (u1.v < 0.0f) ? jc(0.0f) : (u1.v > 1.0f ? jc(1.0f) : u1);
             J val0;
@@ -644,32 +727,20 @@ __global__ __launch_bounds__(kFusedWaves * 64) void k_efused(const MfmaDev mm, c
                 val0 = jlift(__builtin_fmaf(cb.x - ca.x, L0.t, ca.x), __builtin_fmaf(cb.y - ca.y, L0.t, ca.y), __builtin_fmaf(cb.z - ca.z, L0.t, ca.z), uc0);
             }
             const LerpN L = nlerp(uc1.v, n_mesh);
-            float D0[3] = {0.0f, 0.0f, 0.0f}, D1[2] = {0.0f, 0.0f}, D2 = 0.0f, cc = 0.0f, cc1 = 0.0f, c1c1 = 0.0f, cc2 = 0.0f;
+            PriorSums a = {};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float4_t ta[3], tb[3];
-                chunk_rows<3>(tabP, bnd_s + 16, L, 2 * q + h, ta, tb);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = 4 * q + e;
-                    const float c0 = a0[0][r], c1 = a0[1][r], c2 = a0[2][r];
-                    float t[3];
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) t[k] = __builtin_fmaf(tb[k][e] - ta[k][e], L.t, ta[k][e]);
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) D0[k] = __builtin_fmaf(c0, t[k], D0[k]);
-                    D1[0] = __builtin_fmaf(c1, t[0], D1[0]); D1[1] = __builtin_fmaf(c1, t[1], D1[1]);
-                    D2 = __builtin_fmaf(c2, t[0], D2);
-                    cc = __builtin_fmaf(c0, c0, cc); cc1 = __builtin_fmaf(c0, c1, cc1); c1c1 = __builtin_fmaf(c1, c1, c1c1); cc2 = __builtin_fmaf(c0, c2, cc2);
-                }
+            for (int ko = 0; ko < NBK; ++ko) {
+                f32x16 cblk[NCH];
+                prior_c_block<NBK>(obh, of, eo, ko, lane, cblk);
+                prior_rows(a, cblk, tabP, kMeshStride, bnd_s + 16 * NBK, L, ko, h);
             }
 #pragma unroll
-            for (int k = 0; k < 3; ++k) D0[k] = xhalf_sum(D0[k]);
-            D1[0] = xhalf_sum(D1[0]); D1[1] = xhalf_sum(D1[1]); D2 = xhalf_sum(D2);
-            cc = xhalf_sum(cc); cc1 = xhalf_sum(cc1); c1c1 = xhalf_sum(c1c1); cc2 = xhalf_sum(cc2);
+            for (int k = 0; k < 3; ++k) a.D0[k] = xhalf_sum(a.D0[k]);
+            a.D1[0] = xhalf_sum(a.D1[0]); a.D1[1] = xhalf_sum(a.D1[1]); a.D2 = xhalf_sum(a.D2);
+            a.cc = xhalf_sum(a.cc); a.cc1 = xhalf_sum(a.cc1); a.c1c1 = xhalf_sum(a.c1c1); a.cc2 = xhalf_sum(a.cc2);
             const float sgn = s1 < 0.0f ? -1.0f : 1.0f;
-            const T2 N2 = T2{cc, 2.0f * cc1, 0.0f, 2.0f * (c1c1 + cc2), 0.0f, 0.0f};
-            const T2 dotp = T2{D0[0], D1[0], D0[1], D2, D1[1], D0[2]};
+            const T2 N2 = T2{a.cc, 2.0f * a.cc1, 0.0f, 2.0f * (a.c1c1 + a.cc2), 0.0f, 0.0f};
+            const T2 dotp = T2{a.D0[0], a.D1[0], a.D0[1], a.D2, a.D1[1], a.D0[2]};
             const J val1 = t2jet(dotp * t2rsqrt(N2), u0, uc1) * sgn;
             const float sc0 = (mm.constrained_mask & 1u) ? 0.70710678118654752f : 1.0f, sc1 = (mm.constrained_mask & 2u) ? 0.70710678118654752f : 1.0f;
             psi = ((val0 * sc0) * (val1 * sc1)) * jexp_half(ld);
@@ -706,7 +777,9 @@ int check() {
 
 bool energy_tile_fused(const MfmaDev* mdev) {
     const char* e = getenv("WF_ENERGY_FUSED");
-    return !mdev->staged && !(e && atoi(e) == 0);
+    // (two row blocks per dimension: the static LDS of k_efused<2> -- 256 B of chunk bounds -- has to fit beside the resident nets too)
+    const bool fits = (mdev->const_floats + mdev->net_floats * mdev->n_nets) * 4 + 512 <= 160 * 1024;
+    return !mdev->staged && fits && !(e && atoi(e) == 0);
 }
 
 // workspace: state (12 floats), head triples (96 floats), the sign sum (1 float) per walker
@@ -722,11 +795,17 @@ int launch_energy_tile(const MfmaDev* mdev, const ModelDev& md, const float* tab
     {
         if (energy_tile_fused(mdev)) {
             const int lds_all = (mdev->const_floats + mdev->net_floats * mdev->n_nets) * (int)sizeof(float);
-            static DynLdsSlots cfg_fused{};
-            if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(k_efused), lds_all, &cfg_fused)) return rc;
             const int64_t n_tiles = (B + 31) / 32;
             const unsigned blocks = (unsigned)std::min<int64_t>((n_tiles + kFusedWaves - 1) / kFusedWaves, 256);
-            hipLaunchKernelGGL(k_efused, dim3(blocks), dim3(kFusedWaves * 64), lds_all, s, *mdev, tabI4, tabP4, x, B, pr, hpsi, psi, lap);
+            if (mdev->nbk == 1) {
+                static DynLdsSlots cfg1{};
+                if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(k_efused<1>), lds_all, &cfg1)) return rc;
+                hipLaunchKernelGGL(k_efused<1>, dim3(blocks), dim3(kFusedWaves * 64), lds_all, s, *mdev, tabI4, tabP4, x, B, pr, hpsi, psi, lap);
+            } else {
+                static DynLdsSlots cfg2{};
+                if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(k_efused<2>), lds_all, &cfg2)) return rc;
+                hipLaunchKernelGGL(k_efused<2>, dim3(blocks), dim3(kFusedWaves * 64), lds_all, s, *mdev, tabI4, tabP4, x, B, pr, hpsi, psi, lap);
+            }
             return check();
         }
     }

@@ -287,18 +287,19 @@ static int upload_table(wf_model* m, const std::vector<float>& h, const float** 
 }
 
 static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::vector<double>& p64, const std::vector<double>& o2b);
-// [4][n_mesh][32] -> [n_mesh][8][4][4] (see d_tabI4c), + the chunks' support bounds
-static int upload_chunked(wf_model* m, const std::vector<float>& rows4, int n_mesh, const float** out) {
-    std::vector<float> c((size_t)n_mesh * 128);
+// [4][n_mesh][nbp] -> [n_mesh][nbp / 4 chunks][4 orders][4 rows] (see d_tabI4c), + the chunks' support bounds
+static int upload_chunked(wf_model* m, const std::vector<float>& rows4, int n_mesh, int nbp, const float** out) {
+    const int chunks = nbp / 4, stride = nbp * 4;   // floats per mesh point
+    std::vector<float> c((size_t)n_mesh * stride);
     for (int mm = 0; mm < n_mesh; ++mm)
-        for (int ch = 0; ch < 8; ++ch)
+        for (int ch = 0; ch < chunks; ++ch)
             for (int k = 0; k < 4; ++k)
-                for (int q = 0; q < 4; ++q) c[(((size_t)mm * 8 + ch) * 4 + k) * 4 + q] = rows4[((size_t)k * n_mesh + mm) * 32 + 4 * ch + q];
-    // behind the table: int32 [8 chunks][lo, hi], the support bounds of the chunks (as piece_bounds below: a chunk read at clamp(m, lo, hi)
-    // returns the bits of the chunk at m; the lane-per-walker kernels of the energy path clamp, and walkers outside a chunk's support share lines)
-    std::vector<int32_t> bnd(16);
-    for (int ch = 0; ch < 8; ++ch) {
-        auto same = [&](int a, int b) { return memcmp(&c[((size_t)a * 8 + ch) * 16], &c[((size_t)b * 8 + ch) * 16], 16 * sizeof(float)) == 0; };
+                for (int q = 0; q < 4; ++q) c[(((size_t)mm * chunks + ch) * 4 + k) * 4 + q] = rows4[((size_t)k * n_mesh + mm) * nbp + 4 * ch + q];
+    // behind the table: int32 [chunks][lo, hi], the support bounds of the chunks (as piece_bounds below: a chunk read at clamp(m, lo, hi)
+    // returns the bits of the chunk at m; the head code of the energy path clamps, and walkers outside a chunk's support share lines)
+    std::vector<int32_t> bnd(2 * chunks);
+    for (int ch = 0; ch < chunks; ++ch) {
+        auto same = [&](int a, int b) { return memcmp(&c[((size_t)a * chunks + ch) * 16], &c[((size_t)b * chunks + ch) * 16], 16 * sizeof(float)) == 0; };
         int lo = 0, hi = n_mesh - 1;
         if (!getenv("WF_MFMA_NO_BAND")) {
             while (lo + 1 < n_mesh && same(lo + 1, 0)) ++lo;
@@ -307,8 +308,8 @@ static int upload_chunked(wf_model* m, const std::vector<float>& rows4, int n_me
         bnd[2 * ch] = lo;
         bnd[2 * ch + 1] = hi;
     }
-    c.resize(c.size() + 16);
-    memcpy(&c[(size_t)n_mesh * 128], bnd.data(), 16 * sizeof(int32_t));
+    c.resize(c.size() + 2 * chunks);
+    memcpy(&c[(size_t)n_mesh * stride], bnd.data(), 2 * chunks * sizeof(int32_t));
     return upload_table(m, c, out);
 }
 static int grad_prepare(wf_model* m);
@@ -421,10 +422,8 @@ static int model_build(wf_model* m) {
             pack_rows(t64, nb, d.n_mesh, 4, m->nbp, rows4);
             rc = upload_table(m, rows4, &m->d_tabI4);
             if (rc) return rc;
-            if (m->nbp == 32) {
-                rc = upload_chunked(m, rows4, d.n_mesh, &m->d_tabI4c);
-                if (rc) return rc;
-            }
+            rc = upload_chunked(m, rows4, d.n_mesh, m->nbp, &m->d_tabI4c);   // (the matrix-core energy path: D = 2 only, but the tables are small)
+            if (rc) return rc;
         }
         m->i_nb = nb;
         keep_i64.swap(t64);
@@ -452,10 +451,8 @@ static int model_build(wf_model* m) {
             pack_rows(ob64, nb, d.n_mesh, 4, m->nbp, rows3);
             rc = upload_table(m, rows3, &m->d_tabP3);
             if (rc) return rc;
-            if (m->nbp == 32) {
-                rc = upload_chunked(m, rows3, d.n_mesh, &m->d_tabP4c);
-                if (rc) return rc;
-            }
+            rc = upload_chunked(m, rows3, d.n_mesh, m->nbp, &m->d_tabP4c);
+            if (rc) return rc;
         }
         fill_bc(md.psp, d.p_left, d.p_right, b64, nb, d.n_mesh);  // BCs use the plain-B table, bsplines_jax.py:176-189
         std::vector<float> o2b32((size_t)m->nbp * m->nbp, 0.0f);   // full [nbp][nbp]: the wave kernels contract over all 32 rows
@@ -1432,7 +1429,8 @@ int wf_hamiltonian_fwd(const wf_model* m, const float* x_dev, int64_t B, const f
         const char* e = getenv("WF_ENERGY_TILE_MIN");
         const int64_t tile_min = e ? atoll(e) : kEnergyTileMin;
         const wf_model_desc& d = m->desc;
-        const bool family = D == 2 && m->nbp == 32 && m->mfma_ok && d.box_kind == WF_BOX_MEAN && d.layer_kind == WF_LAYER_IMADE &&
+        // (<= 32 bases: the one-kernel form or, if the nets do not fit LDS together, the launch-per-net form; 33 .. 64 bases: the one-kernel form only)
+        const bool family = D == 2 && (m->nbp == 32 || (m->nbp == 64 && m->mfma_ok && energy_tile_fused(&m->mdev))) && m->mfma_ok && d.box_kind == WF_BOX_MEAN && d.layer_kind == WF_LAYER_IMADE &&
                             d.n_flow_layers > 0 && !m->dev.i_gate && !m->dev.p_gate && m->d_tabI4c && m->d_tabP4c && !m->mdev.p_bias && !getenv("WF_ENERGY_R3");
         if (family && tile_min > 0 && B >= tile_min && !m->eval_tables_stale) {
             // the conditioner and the head kernels exchange 384 B per walker and net through the scratch buffer: chunks that keep it
