@@ -562,7 +562,8 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int kThreads = kWaves * 64;
     const int box_kind = SPEC ? (int)WF_BOX_MEAN : mm.box_kind, layer_kind = SPEC ? (int)WF_LAYER_IMADE : mm.layer_kind;
-    const int prior_kind = SPEC ? (int)WF_PRIOR_WAVEFLOW : mm.prior_kind, staged = SPEC ? 0 : mm.staged, exact_div = SPEC ? 0 : mm.exact_div;
+    // (SPEC at D = 2: every net resident, a compile-time fact of that family; SPEC at D > 2 -- the electron chains -- may run staged)
+    const int prior_kind = SPEC ? (int)WF_PRIOR_WAVEFLOW : mm.prior_kind, staged = (SPEC && D == 2) ? 0 : mm.staged, exact_div = SPEC ? 0 : mm.exact_div;
     // Resident mode hands the workgroup's tiles to its waves through a counter in LDS instead of a fixed share per wave: the SIMD's issue
     // arbitration favours its oldest wave (measured with per-tile s_memtime stamps: at 16 waves the first tile of SIMD slot 0 takes 39 k
     // cycles, that of slot 3 151 k), so with equal shares the old waves leave early and the last tiles run at one or two waves per SIMD --
@@ -688,6 +689,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
                 for (int t = 0; t < T; ++t) gl[t] = 1.0f;
 #pragma unroll
                 for (int d = 1; d < D; ++d) {
+                    if (D > 4) __builtin_amdgcn_sched_barrier(0);   // long chains: one dimension at a time (the scheduler otherwise keeps the records of several dimensions in flight: 29 -> 218 spilled registers at 12 waves)
                     if (gate_i) {
 #pragma unroll
                         for (int t = 0; t < T; ++t) gl[t] = gl[t] * (cur[t][d - 1] * cur[t][d - 1] * cur[t][d - 1]);
@@ -775,6 +777,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
                 for (int t = 0; t < T; ++t) { lp[t] = 0.0f; prod[t] = 1.0f; gp[t] = 1.0f; }
 #pragma unroll
                 for (int d = 0; d < D; ++d) {
+                    if (D > 4) __builtin_amdgcn_sched_barrier(0);
                     if (gate_p && d > 0) {
 #pragma unroll
                         for (int t = 0; t < T; ++t) gp[t] = gp[t] * (cur[t][d - 1] * cur[t][d - 1] * cur[t][d - 1]);
@@ -1054,8 +1057,8 @@ int launch_dw(const MfmaDev* mdev, int lds_bytes, int mode, const float* x, int6
         if constexpr (T == 1) return launch_dwi<D, NBK, kWaves, 1, true, false>(mdev, lds_bytes, mode, x, B, out, u, idx, s);
         else return WF_ERR_UNSUPPORTED;
     }
-    if constexpr (D == 2) {   // the specialised build exists for the two-particle shapes
-        if (mdev->box_kind == WF_BOX_MEAN && mdev->layer_kind == WF_LAYER_IMADE && mdev->prior_kind == WF_PRIOR_WAVEFLOW && !mdev->staged &&
+    if constexpr (D == 2 || (D == 8 && NBK == 1)) {   // the specialised build exists for the two-particle shapes and for the 8-electron chain (config C4)
+        if (mdev->box_kind == WF_BOX_MEAN && mdev->layer_kind == WF_LAYER_IMADE && mdev->prior_kind == WF_PRIOR_WAVEFLOW && (D > 2 || !mdev->staged) &&
             !mdev->exact_div && !mdev->i_gate && !mdev->p_gate && !mdev->p_bias)
             return launch_dwi<D, NBK, kWaves, T, false, true>(mdev, lds_bytes, mode, x, B, out, u, nullptr, s);
     }
