@@ -119,6 +119,7 @@ struct MfmaDev {
     int exact_div;             // 1: x_l / n by IEEE division (set when the multiply-and-correct form is not bit-identical for this n_mesh)
     int prior_quotient;        // debug (env WF_PRIOR_QUOTIENT=1 at model creation): Waveflow prior head in the reference's quotient form
     int i_gate, p_gate;        // gated heads (wf_model_desc.i_gate / p_gate): zero_params blocks of the net images are live
+    int timg_off, tnet_floats, tconst_off;   // transposed operand images of the gradient path behind the constants block (float offsets in `image`; -1: not built)
     int p_bias;                // the B prior's boundary map has a constant term: cbP[nbk][2][16] (accumulator layout) sits at the end of the constants block
 };
 
@@ -149,9 +150,18 @@ struct Protons {
 };
 // local energy of large batches on the matrix cores (wf_kernels_etile.hip): D = 2, <= 32 bases, mean box, IMADE + Waveflow prior, ungated
 int64_t energy_tile_floats(int64_t B);
-bool energy_tile_fused(const MfmaDev* mdev);   // the one-kernel form applies (nets resident in LDS; WF_ENERGY_FUSED=0 switches it off per call)
+bool energy_tile_fused(const MfmaDev* mdev);
+// parameter gradients of psi and its Laplacian on the matrix cores (two-particle family, <= 32 bases; wf_kernels_etile.hip: k_ebwd, k_ewgrad)
+bool energy_vjp_capable(const MfmaDev* mdev);
+int64_t energy_vjp_floats_per_walker(int n_nets);
+int64_t energy_vjp_fixed_floats();
+int energy_vjp_gacc_floats(int n_nets);
+int launch_energy_vjp(const MfmaDev* mdev, const ModelDev& md, const float* tabI4, const float* tabP4, const float* x, int64_t B, int mode, const float* w_psi,
+                      const float* w_lap, const Protons& pr, float running_avg, const float* running_avg_dev, float inv_count, float* e_loc, float* ws,
+                      float* gacc, int accumulate, void* stream);
+int launch_energy_vjp_finish(const float* gacc, int n_nets, const int* offs, const float* c2, float* flat, int64_t n_params, void* stream);   // the one-kernel form applies (nets resident in LDS; WF_ENERGY_FUSED=0 switches it off per call)
 int launch_energy_tile(const MfmaDev* mdev, const ModelDev& md, const float* tabI4, const float* tabP4, const float* fk_nat, const float* x, int64_t B,
-                       const Protons& pr, float* hpsi, float* psi, float* lap, float* ws, void* stream);
+                       const Protons& pr, float* hpsi, float* psi, float* lap, float* ws, void* stream, float* st_out = nullptr);
 // The sweeps run over a coefficient ring (wf_ring.h).  kind 0: R1 (first order); 1: R3 (one sample per walker and direction,
 // 3 coefficients); 2: RF<K> (one sample per walker and block of K directions, K + 2 coefficients); 3: RF<D> (one sample per walker).
 // The taped sweeps use kind 2 with K = D up to 5 coordinates; beyond, the 8..10 live floats per value of RF<D> spill hundreds of registers

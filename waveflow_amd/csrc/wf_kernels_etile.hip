@@ -22,6 +22,7 @@
 // checked against it and against the torch oracle (tests/test_gpu_energy.py).  Coverage: D = 2, <= 32 bases, mean-type box, IMADE layers,
 // Waveflow prior, ungated heads (every homogeneous boundary dictionary: the tables carry the map); everything else stays on the wave kernel.
 #include "wf_mfma_impl.h"
+#include "wf_etile_adjoint.h"
 
 // The jet / Taylor algebra of this file is checked against oracles by tolerance, not by operation order: multiply-add pairs may fuse (the build's
 // default is -ffp-contract=off).  The pragma is lexical: the index arithmetic of the table lerp (make_lerp, div_by_n in wf_mfma_impl.h, included
@@ -632,7 +633,9 @@ __device__ __forceinline__ void prior_rows(PriorSums& a, const f32x16 (&c)[NCH],
 template <int NBK>
 __global__ __launch_bounds__(kFusedWaves * 64) void k_efused(const MfmaDev mm, const float* __restrict__ tabI, const float* __restrict__ tabP,
                                                              const float* __restrict__ xg, int64_t B, const Protons pr, float* __restrict__ hpsi,
-                                                             float* __restrict__ psi_out, float* __restrict__ lap_out) {
+                                                             float* __restrict__ psi_out, float* __restrict__ lap_out, float* __restrict__ st_out) {
+    // st_out (may be null): the (u_0, u_1, log det) jets at the input of every net, [net][slot][channel][B] -- what the gradient path's
+    // per-net reverse kernels (k_ebwd) restart from
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ int next_tile;
     __shared__ int bnd_s[32 * NBK];   // support bounds of the table chunks: [I: 8 NBK][lo, hi], [prior: 8 NBK][lo, hi]
@@ -667,6 +670,11 @@ __global__ __launch_bounds__(kFusedWaves * 64) void k_efused(const MfmaDev mm, c
         // ---- flow layers (made.py:66-81 + Reverse)
         for (int l = 0; l < mm.n_layers; ++l) {
             const float* net = lds + mm.const_floats + (size_t)l * mm.net_floats;
+            if (st_out && valid && h == 0) {
+                st_store(st_out + (size_t)l * 12 * B, 0, B, w, u0);
+                st_store(st_out + (size_t)l * 12 * B, 1, B, w, u1);
+                st_store(st_out + (size_t)l * 12 * B, 2, B, w, ld);
+            }
             Frag f[NCH][2];
             int e[NCH];
             cond_hidden<NBK>(net, u0.v, u1.v, lane, f, e);
@@ -705,6 +713,11 @@ __global__ __launch_bounds__(kFusedWaves * 64) void k_efused(const MfmaDev mm, c
         J psi;
         {
             const float* net = lds + mm.const_floats + (size_t)mm.n_layers * mm.net_floats;
+            if (st_out && valid && h == 0) {
+                st_store(st_out + (size_t)mm.n_layers * 12 * B, 0, B, w, u0);
+                st_store(st_out + (size_t)mm.n_layers * 12 * B, 1, B, w, u1);
+                st_store(st_out + (size_t)mm.n_layers * 12 * B, 2, B, w, ld);
+            }
             float s1 = 0.0f;
             Frag of[NBK][NCH];
             int eo[NCH];
@@ -764,6 +777,611 @@ __global__ __launch_bounds__(kFusedWaves * 64) void k_efused(const MfmaDev mm, c
     }
 }
 
+// ============================================================================ parameter gradients on the matrix cores (vqmc.py:193-221)
+// grad[p] = sum_b ( w_psi[b] d psi_b / d theta_p + w_lap[b] d laplacian_b / d theta_p ) for the two-particle family (<= 32 bases), batch by batch:
+//   k_efused (st_out)   forward, leaves the (u_0, u_1, log det) jets at the input of every net
+//   k_ebwd<PRIOR>       one launch per net, last net first: recomputes the net's forward from its input jets, pulls the adjoint of its output
+//                       jets back through the head algebra (wf_etile_adjoint.h) to adjoint head triples, through the conditioner with TRANSPOSED
+//                       operand images on the matrix cores (three channels, like the forward), writes the adjoint of the net's input jets for the
+//                       next launch and DUMPS, per 32-walker tile, the operands of the weight-gradient products: activations X1, X2 and adjoints
+//                       Y1, Y2, Y3 as [channel][unit][32 walkers] blocks (coalesced: a register of the accumulator layout is two 128-byte rows)
+//   k_ewgrad            dW[k][u] = sum_walkers sum_channels X_c[k][w] Y_c[u][w]: the walker axis is the K of this product and the dumps hold it
+//                       contiguous, so both MFMA operands are plain 32-byte reads; split-fp16 products, per-split partial sums (fixed order)
+//   k_ebias, k_egrad_reduce, k_egrad_scatter   bias / input-layer sums, reduction over the splits, scales and folds back to the flat leaf order
+using JA = adj::Jt<float>;
+using TA = adj::T2t<float>;
+constexpr int kBwdWaves = 8;
+// dump block of one tile (floats): X1 [3][64][32], X2 [3][64][32], Y1 [2][64][32], Y2 [3][64][32], Y3 [3][32][32], Y30 [32][32], S [32]
+constexpr int kDX1 = 0, kDX2 = 6144, kDY1 = 12288, kDY2 = 16384, kDY3 = 22528, kDY30 = 25600, kDS = 26624, kDumpFloats = 26656;
+
+__device__ __forceinline__ JA ja_load(const float* __restrict__ st, int slot, int64_t B, int64_t w) {
+    const float* p = st + (int64_t)slot * 4 * B + w;
+    return JA{p[0], p[B], p[2 * B], p[3 * B]};
+}
+__device__ __forceinline__ void ja_store(float* __restrict__ st, int slot, int64_t B, int64_t w, JA x) {
+    float* p = st + (int64_t)slot * 4 * B + w;
+    p[0] = x.v; p[B] = x.a; p[2 * B] = x.b; p[3 * B] = x.h;
+}
+__device__ __forceinline__ float r_of(float x) { return __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x) + 1.0f); }
+// register r of lane (walker j, half h) of a 32-unit block -> dump[(unit0 + row) * 32 + j]
+__device__ __forceinline__ void dump_block(float* __restrict__ d, int unit0, const f32x16& v, int j, int h) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) d[(unit0 + (r & 3) + 8 * (r >> 2) + 4 * h) * 32 + j] = v[r];
+}
+// one 32-row block of triples -> fragments of K = 32 (two K steps), derivative channels scaled (as to_frags, one block)
+__device__ __forceinline__ void to_frags1(const f32x16 (&blk)[NCH], Frag (&f)[NCH][2], int (&e)[NCH]) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        float amax = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) amax = fmaxf(amax, fabsf(blk[c][r]));
+        e[c] = col_exponent(amax);
+        const float sc = __builtin_amdgcn_ldexpf(1.0f, -e[c]);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float r8[8];
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) r8[jj] = blk[c][8 * s + jj] * sc;
+            split8(r8, f[c][0].hi[s], f[c][0].lo[s]);
+        }
+    }
+}
+// two blocks, every channel scaled (adjoints are unbounded in every channel)
+__device__ __forceinline__ void to_frags_all(const f32x16 (&blk0)[NCH], const f32x16 (&blk1)[NCH], Frag (&f)[NCH][2], int (&e)[NCH]) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        float amax = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) amax = fmaxf(amax, fmaxf(fabsf(blk0[c][r]), fabsf(blk1[c][r])));
+        e[c] = col_exponent(amax);
+        const float sc = __builtin_amdgcn_ldexpf(1.0f, -e[c]);
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float r8[8];
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) r8[jj] = (ob == 0 ? blk0[c][8 * s + jj] : blk1[c][8 * s + jj]) * sc;
+                split8(r8, f[c][ob].hi[s], f[c][ob].lo[s]);
+            }
+    }
+}
+__device__ __forceinline__ void unscale_all(f32x16 (&acc)[NCH], const int (&e)[NCH]) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const float sc = __builtin_amdgcn_ldexpf(1.0f, e[c]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = acc[c][r] * sc;
+    }
+}
+// (x, x', x'') and the adjoint of (r, r' x', r' x'' + r'' x'^2) -> adjoint of (x, x', x''), in place in g
+__device__ __forceinline__ void act_block_bwd(const f32x16 (&x)[NCH], f32x16 (&g)[NCH]) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float a, b, c;
+        adj::r_triple_bwd(r_of(x[0][r]), x[1][r], x[2][r], g[0][r], g[1][r], g[2][r], a, b, c);
+        g[0][r] = a; g[1][r] = b; g[2][r] = c;
+    }
+}
+// extended row sums of a flow head over the lane's 16 rows (dimension 1: triples from the conditioner; CONST: dimension 0, (bias, 0, 0))
+template <bool CONST>
+__device__ __forceinline__ void flow_rows_ext(adj::FlowSumsT<float>& a, const f32x16 (&o)[NCH], const f32x16& g16, const float* __restrict__ tabI, const int* bnd,
+                                              const LerpN& L, int h) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float4_t ta[4], tb[4];
+        chunk_rows<4>(tabI, 128, bnd, L, 2 * q + h, ta, tb);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = 4 * q + e;
+            float v0, v1 = 0.0f, v2 = 0.0f;
+            if (CONST) v0 = r_of(o[0][r]);
+            else adj::r_triple(r_of(o[0][r]), o[1][r], o[2][r], v0, v1, v2);
+            const float g = g16[r];
+            float t[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t[k] = __builtin_fmaf(tb[k][e] - ta[k][e], L.t, ta[k][e]) * g;
+            a.s[0] += v0; a.qv[0] = __builtin_fmaf(v0, g, a.qv[0]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { a.v0[k] = __builtin_fmaf(v0, t[k], a.v0[k]); a.r[k] += t[k]; }
+            if (!CONST) {
+                a.s[1] += v1; a.s[2] += v2;
+                a.qv[1] = __builtin_fmaf(v1, g, a.qv[1]); a.qv[2] = __builtin_fmaf(v2, g, a.qv[2]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) a.v1[k] = __builtin_fmaf(v1, t[k], a.v1[k]);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) a.v2[k] = __builtin_fmaf(v2, t[k], a.v2[k]);
+            }
+        }
+    }
+}
+__device__ __forceinline__ void flow_sums_xhalf(adj::FlowSumsT<float>& a) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { a.s[k] = xhalf_sum(a.s[k]); a.qv[k] = xhalf_sum(a.qv[k]); a.v2[k] = xhalf_sum(a.v2[k]); }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { a.r[k] = xhalf_sum(a.r[k]); a.v0[k] = xhalf_sum(a.v0[k]); a.v1[k] = xhalf_sum(a.v1[k]); }
+}
+// adjoint head triples of the lane's rows from the adjoints of the row sums (ab: summed over the halves already, the same in both)
+template <bool CONST>
+__device__ __forceinline__ void flow_rows_bwd(const adj::FlowSumsT<float>& ab, const f32x16 (&o)[NCH], const f32x16& g16, const float* __restrict__ tabI,
+                                              const int* bnd, const LerpN& L, int h, f32x16 (&ob)[NCH]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float4_t ta[4], tb[4];
+        chunk_rows<4>(tabI, 128, bnd, L, 2 * q + h, ta, tb);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = 4 * q + e;
+            const float g = g16[r];
+            float t[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t[k] = __builtin_fmaf(tb[k][e] - ta[k][e], L.t, ta[k][e]) * g;
+            float vb0 = __builtin_fmaf(g, ab.qv[0], ab.s[0]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) vb0 = __builtin_fmaf(ab.v0[k], t[k], vb0);
+            const float rr = r_of(o[0][r]);
+            if (CONST) {
+                ob[0][r] = vb0 * adj::r_derivs(rr).r1;
+                ob[1][r] = 0.0f; ob[2][r] = 0.0f;
+            } else {
+                float vb1 = __builtin_fmaf(g, ab.qv[1], ab.s[1]), vb2 = __builtin_fmaf(g, ab.qv[2], ab.s[2]);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) vb1 = __builtin_fmaf(ab.v1[k], t[k], vb1);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) vb2 = __builtin_fmaf(ab.v2[k], t[k], vb2);
+                float x0b, x1b, x2b;
+                adj::r_triple_bwd(rr, o[1][r], o[2][r], vb0, vb1, vb2, x0b, x1b, x2b);
+                ob[0][r] = x0b; ob[1][r] = x1b; ob[2][r] = x2b;
+            }
+        }
+    }
+}
+// the prior's rows: extended sums from the triples of c (CONST: channel 0 only), and back
+template <bool CONST>
+__device__ __forceinline__ void prior_rows_ext(adj::PriorSumsT<float>& a, const f32x16 (&c)[NCH], const float* __restrict__ tabP, const int* bnd, const LerpN& L, int h) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float4_t ta[4], tb[4];
+        chunk_rows<4>(tabP, 128, bnd, L, 2 * q + h, ta, tb);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = 4 * q + e;
+            const float c0 = c[0][r];
+            float t[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t[k] = __builtin_fmaf(tb[k][e] - ta[k][e], L.t, ta[k][e]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a.d0[k] = __builtin_fmaf(c0, t[k], a.d0[k]);
+            a.cc = __builtin_fmaf(c0, c0, a.cc);
+            if (!CONST) {
+                const float c1 = c[1][r], c2 = c[2][r];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) a.d1[k] = __builtin_fmaf(c1, t[k], a.d1[k]);
+                a.d2[0] = __builtin_fmaf(c2, t[0], a.d2[0]); a.d2[1] = __builtin_fmaf(c2, t[1], a.d2[1]);
+                a.cc1 = __builtin_fmaf(c0, c1, a.cc1); a.c1c1 = __builtin_fmaf(c1, c1, a.c1c1); a.cc2 = __builtin_fmaf(c0, c2, a.cc2);
+            }
+        }
+    }
+}
+__device__ __forceinline__ void prior_sums_xhalf(adj::PriorSumsT<float>& a) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a.d0[k] = xhalf_sum(a.d0[k]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) a.d1[k] = xhalf_sum(a.d1[k]);
+    a.d2[0] = xhalf_sum(a.d2[0]); a.d2[1] = xhalf_sum(a.d2[1]);
+    a.cc = xhalf_sum(a.cc); a.cc1 = xhalf_sum(a.cc1); a.c1c1 = xhalf_sum(a.c1c1); a.cc2 = xhalf_sum(a.cc2);
+}
+template <bool CONST>
+__device__ __forceinline__ void prior_rows_bwd(const adj::PriorSumsT<float>& ab, const f32x16 (&c)[NCH], const float* __restrict__ tabP, const int* bnd,
+                                               const LerpN& L, int h, f32x16 (&cb)[NCH]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float4_t ta[3], tb[3];
+        chunk_rows<3>(tabP, 128, bnd, L, 2 * q + h, ta, tb);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = 4 * q + e;
+            float t[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) t[k] = __builtin_fmaf(tb[k][e] - ta[k][e], L.t, ta[k][e]);
+            const float c0 = c[0][r];
+            float b0 = 2.0f * ab.cc * c0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) b0 = __builtin_fmaf(ab.d0[k], t[k], b0);
+            if (CONST) {
+                cb[0][r] = b0; cb[1][r] = 0.0f; cb[2][r] = 0.0f;
+            } else {
+                const float c1 = c[1][r], c2 = c[2][r];
+                cb[0][r] = b0 + ab.cc1 * c1 + ab.cc2 * c2;
+                cb[1][r] = ab.d1[0] * t[0] + ab.d1[1] * t[1] + ab.cc1 * c0 + 2.0f * ab.c1c1 * c1;
+                cb[2][r] = ab.d2[0] * t[0] + ab.cc2 * c0;
+            }
+        }
+    }
+}
+// w @ ob_to_b for one 32-row block of triples (every channel scaled); obh: hi halves, lo at + 1024
+__device__ __forceinline__ void ob_product(const _Float16* obh, f32x16 (&w)[NCH], int lane, f32x16 (&c)[NCH]) {
+    Frag f[NCH][2];
+    int e[NCH];
+    to_frags1(w, f, e);
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        f32x16 acc = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(obh + (s * 64 + lane) * 8);
+            const f16x8 al = *reinterpret_cast<const f16x8*>(obh + 1024 + (s * 64 + lane) * 8);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, f[ch][0].hi[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, f[ch][0].lo[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, f[ch][0].hi[s], acc, 0, 0, 0);
+        }
+        const float sc = __builtin_amdgcn_ldexpf(1.0f, e[ch]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[ch][r] = acc[r] * sc;
+    }
+}
+
+template <bool PRIOR>
+__global__ __launch_bounds__(kBwdWaves * 64) void k_ebwd(const MfmaDev mm, int net_index, const float* __restrict__ tabI, const float* __restrict__ tabP,
+                                                          const float* __restrict__ st_in, float* __restrict__ adjb, const float* __restrict__ w_psi,
+                                                          const float* __restrict__ w_lap, int64_t B, float* __restrict__ dump) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ int next_tile;
+    __shared__ int bnd_s[32];
+    constexpr int kThreads = kBwdWaves * 64;
+    if (threadIdx.x == 0) next_tile = 0;
+    if (threadIdx.x < 16) bnd_s[threadIdx.x] = reinterpret_cast<const int*>(tabI + (size_t)mm.n_mesh * 128)[threadIdx.x];
+    else if (threadIdx.x < 32) bnd_s[threadIdx.x] = reinterpret_cast<const int*>(tabP + (size_t)mm.n_mesh * 128)[threadIdx.x - 16];
+    float* net_l = lds + mm.const_floats;
+    float* tnet_l = net_l + mm.net_floats;
+    float* tcon_l = tnet_l + mm.tnet_floats;
+    stage_floats<kThreads>(mm.image + mm.const_img_off, lds, mm.const_floats);
+    stage_floats<kThreads>(mm.image + (size_t)net_index * mm.net_floats, net_l, mm.net_floats);
+    stage_floats<kThreads>(mm.image + mm.timg_off + (size_t)net_index * mm.tnet_floats, tnet_l, mm.tnet_floats);
+    stage_floats<kThreads>(mm.image + mm.tconst_off, tcon_l, 1024);
+    __syncthreads();
+    const float* net = net_l;
+    const float* fkI = lds;
+    const float* fkP = lds + 32;
+    const _Float16* obh = reinterpret_cast<const _Float16*>(lds + 64);
+    const _Float16* TW1h = reinterpret_cast<const _Float16*>(tnet_l);
+    const _Float16* TW1l = reinterpret_cast<const _Float16*>(tnet_l + 2048);
+    const _Float16* TW2h = reinterpret_cast<const _Float16*>(tnet_l + 4096);
+    const _Float16* TW2l = reinterpret_cast<const _Float16*>(tnet_l + 5120);
+    const float* TW0 = tnet_l + 6144;
+    const _Float16* obT = reinterpret_cast<const _Float16*>(tcon_l);
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 31, h = lane >> 5;
+    const int n_mesh = mm.n_mesh;
+    const int64_t n_tiles = (B + 31) >> 5;
+    const int64_t my_tiles = n_tiles > (int64_t)blockIdx.x ? (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    for (;;) {
+        int q_ = 0;
+        if (lane == 0) q_ = __hip_atomic_fetch_add(&next_tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        q_ = __builtin_amdgcn_readfirstlane(q_);
+        if (q_ >= my_tiles) break;
+        const int64_t tile = (int64_t)blockIdx.x + (int64_t)q_ * gridDim.x;
+        const int64_t w = tile * 32 + j;
+        const bool valid = w < B;
+        const int64_t wl = valid ? w : B - 1;
+        float* dmp = dump + (size_t)tile * kDumpFloats;
+        const JA u0 = ja_load(st_in, 0, B, wl), u1 = ja_load(st_in, 1, B, wl);
+        // ---- the net's forward, with what the reverse needs kept: z2 (second hidden layer's pre-activation triples), o (head triples)
+        f32x16 z2a[NCH], z2b[NCH], o[NCH];
+        {
+            using O = NetOff<2, 1>;
+            const float in0[2] = {u0.v, 1.0f}, in1[2] = {u1.v, 0.0f};
+            f32x16 a0[NCH], a1[NCH];
+            init_acc(a0, net + O::b0 + (0 * 2 + h) * 16);
+            init_acc(a1, net + O::b0 + (1 * 2 + h) * 16);
+            const float w0 = net[O::W0 + 0 * 64 + lane], w1 = net[O::W0 + 1 * 64 + lane];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                a0[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, h ? in1[c] : in0[c], a0[c], 0, 0, 0);
+                a1[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, h ? in1[c] : in0[c], a1[c], 0, 0, 0);
+            }
+            act_block(a0);
+            act_block(a1);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) { dump_block(dmp + kDX1 + c * 2048, 0, a0[c], j, h); dump_block(dmp + kDX1 + c * 2048, 32, a1[c], j, h); }
+            Frag f[NCH][2];
+            int e[NCH];
+            to_frags(a0, a1, f, e);
+            const _Float16* W1h = reinterpret_cast<const _Float16*>(net + O::W1h);
+            const _Float16* W1l = reinterpret_cast<const _Float16*>(net + O::W1l);
+            init_acc(z2a, net + O::b1 + (0 + h) * 16);
+            init_acc(z2b, net + O::b1 + (2 + h) * 16);
+            dense64_block<NCH>(W1h, W1l, f, z2a, lane);
+            dense64_block<NCH>(W1h + 2048, W1l + 2048, f, z2b, lane);
+            unscale(z2a, e);
+            unscale(z2b, e);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) { a0[c] = z2a[c]; a1[c] = z2b[c]; }
+            act_block(a0);
+            act_block(a1);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) { dump_block(dmp + kDX2 + c * 2048, 0, a0[c], j, h); dump_block(dmp + kDX2 + c * 2048, 32, a1[c], j, h); }
+            to_frags(a0, a1, f, e);
+            cond_out<1>(net, f, e, 0, lane, o);
+        }
+        if (h == 0) dmp[kDS + j] = u0.v;
+        // ---- head: forward sums, pullback to adjoint head triples ob (dimension 1) and ob0 (dimension 0, channel 0)
+        f32x16 ob[NCH], ob0;
+        JA u0b = adj::jzero<float>(), u1b = adj::jzero<float>(), ldb = adj::jzero<float>();
+        if (!PRIOR) {
+            const JA y1b = valid ? ja_load(adjb, 0, B, wl) : adj::jzero<float>(), y0b = valid ? ja_load(adjb, 1, B, wl) : adj::jzero<float>();
+            ldb = valid ? ja_load(adjb, 2, B, wl) : adj::jzero<float>();
+            const f32x16 g16 = load16(fkI + h * 16);
+            const LerpN L1 = nlerp(u1.v, n_mesh), L0 = nlerp(u0.v, n_mesh);
+            f32x16 o0[NCH];
+            o0[0] = load16(net + NetOff<2, 1>::b2 + (0 * 2 + h) * 16);   // dimension 0: the bias alone (empty mask)
+            adj::FlowSumsT<float> s1 = adj::flow_sums_zero<float>(), s0 = adj::flow_sums_zero<float>();
+            flow_rows_ext<false>(s1, o, g16, tabI, bnd_s, L1, h);
+            flow_rows_ext<true>(s0, o0, g16, tabI, bnd_s, L0, h);
+            flow_sums_xhalf(s1);
+            flow_sums_xhalf(s0);
+            JA y1, dl1, y0, dl0;
+            const adj::FlowHeadFwd<float> f1 = adj::flow_head_fwd(s1, mm.F_I, mm.i_reg, u0, u1, y1, dl1);
+            const adj::FlowHeadFwd<float> f0 = adj::flow_head_fwd(s0, mm.F_I, mm.i_reg, u0, u0, y0, dl0);
+            adj::FlowSumsT<float> ab1 = adj::flow_sums_zero<float>(), ab0 = adj::flow_sums_zero<float>();
+            JA sb = adj::jzero<float>(), tb = adj::jzero<float>(), sb0 = adj::jzero<float>(), tb0 = adj::jzero<float>();
+            float tv1 = 0.0f, tv0 = 0.0f;
+            adj::flow_head_bwd(s1, f1, mm.F_I, mm.i_reg, u0, u1, y1b, ldb, ab1, sb, tb, tv1);
+            adj::flow_head_bwd(s0, f0, mm.F_I, mm.i_reg, u0, u0, y0b, ldb, ab0, sb0, tb0, tv0);
+            u0b = JA{tv0, sb.a + sb0.a + tb0.a, sb.b + sb0.b + tb0.b, sb.h + sb0.h + tb0.h};
+            u1b = JA{tv1, tb.a, tb.b, tb.h};
+            flow_rows_bwd<false>(ab1, o, g16, tabI, bnd_s, L1, h, ob);
+            f32x16 t0[NCH];
+            flow_rows_bwd<true>(ab0, o0, g16, tabI, bnd_s, L0, h, t0);
+            ob0 = t0[0];
+        } else {
+            const float wp = valid ? w_psi[wl] : 0.0f, wlp = valid ? w_lap[wl] : 0.0f;
+            const JA ld = ja_load(st_in, 2, B, wl);
+            const JA psib = JA{wp, 0.0f, 0.0f, 2.0f * wlp};
+            const f32x16 keep = load16(fkP + h * 16);
+            // dimension 1: c = (o keep) @ ob_to_b as triples; dimension 0: the bias alone
+            float s1 = 0.0f, s0 = 0.0f;
+            f32x16 wv[NCH], c1[NCH], w0v[NCH], c0[NCH];
+            const f32x16 b20 = load16(net + NetOff<2, 1>::b2 + (0 * 2 + h) * 16);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s1 += o[0][r]; s0 += b20[r]; }
+            s1 = xhalf_sum(s1);
+            s0 = xhalf_sum(s0);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { wv[c][r] = o[c][r] * keep[r]; w0v[c][r] = c == 0 ? b20[r] * keep[r] : 0.0f; }
+            ob_product(obh, wv, lane, c1);
+            ob_product(obh, w0v, lane, c0);
+            const float sg1 = s1 < 0.0f ? -1.0f : 1.0f, sg0 = s0 < 0.0f ? -1.0f : 1.0f;
+            const bool in0 = u0.v >= 0.0f && u0.v <= 1.0f, in1 = u1.v >= 0.0f && u1.v <= 1.0f;
+            const JA uc0 = in0 ? u0 : JA{u0.v < 0.0f ? 0.0f : 1.0f, 0.0f, 0.0f, 0.0f}, uc1 = in1 ? u1 : JA{u1.v < 0.0f ? 0.0f : 1.0f, 0.0f, 0.0f, 0.0f};
+            const LerpN L1 = nlerp(uc1.v, n_mesh), L0 = nlerp(uc0.v, n_mesh);
+            adj::PriorSumsT<float> p1 = adj::prior_sums_zero<float>(), p0 = adj::prior_sums_zero<float>();
+            prior_rows_ext<false>(p1, c1, tabP, bnd_s + 16, L1, h);
+            prior_rows_ext<true>(p0, c0, tabP, bnd_s + 16, L0, h);
+            prior_sums_xhalf(p1);
+            prior_sums_xhalf(p0);
+            JA val1, val0;
+            const adj::PriorHeadFwd<float> f1 = adj::prior_head_fwd(p1, sg1, u0, uc1, val1);
+            const adj::PriorHeadFwd<float> f0 = adj::prior_head_fwd(p0, sg0, u0, uc0, val0);
+            const float sc0 = (mm.constrained_mask & 1u) ? 0.70710678118654752f : 1.0f, sc1 = (mm.constrained_mask & 2u) ? 0.70710678118654752f : 1.0f;
+            const float ev = __expf(0.5f * ld.v);
+            const JA E = adj::japply(ld, ev, 0.5f * ev, 0.25f * ev);
+            const JA A = val0 * sc0, Bv = val1 * sc1, P = adj::jmul(A, Bv);
+            JA Pb = adj::jzero<float>(), Eb = adj::jzero<float>(), Ab = adj::jzero<float>(), Bb = adj::jzero<float>();
+            adj::jmul_bwd(E, psib, Pb);
+            adj::jmul_bwd(P, psib, Eb);
+            adj::jfun_bwd(ld, 0.5f * ev, 0.25f * ev, 0.125f * ev, Eb, ldb);
+            adj::jmul_bwd(Bv, Pb, Ab);
+            adj::jmul_bwd(A, Pb, Bb);
+            adj::PriorSumsT<float> ab1 = adj::prior_sums_zero<float>(), ab0 = adj::prior_sums_zero<float>();
+            JA sb = adj::jzero<float>(), tb1 = adj::jzero<float>(), sb0 = adj::jzero<float>(), tb0 = adj::jzero<float>();
+            float tv1 = 0.0f, tv0 = 0.0f;
+            adj::prior_head_bwd(p1, f1, sg1, u0, uc1, Bb * sc1, ab1, sb, tb1, tv1);
+            adj::prior_head_bwd(p0, f0, sg0, u0, uc0, Ab * sc0, ab0, sb0, tb0, tv0);
+            u0b = JA{in0 ? tv0 : 0.0f, sb.a + sb0.a + (in0 ? tb0.a : 0.0f), sb.b + sb0.b + (in0 ? tb0.b : 0.0f), sb.h + sb0.h + (in0 ? tb0.h : 0.0f)};
+            u1b = in1 ? JA{tv1, tb1.a, tb1.b, tb1.h} : adj::jzero<float>();
+            // rows back: adjoint of c -> through ob_to_b transposed -> adjoint of the raw outputs
+            f32x16 cb[NCH], wb[NCH];
+            prior_rows_bwd<false>(ab1, c1, tabP, bnd_s + 16, L1, h, cb);
+            ob_product(obT, cb, lane, wb);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ob[c][r] = wb[c][r] * keep[r];
+            prior_rows_bwd<true>(ab0, c0, tabP, bnd_s + 16, L0, h, cb);
+            ob_product(obT, cb, lane, wb);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ob0[r] = wb[0][r] * keep[r];
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) dump_block(dmp + kDY3 + c * 1024, 0, ob[c], j, h);
+        dump_block(dmp + kDY30, 0, ob0, j, h);
+        // ---- conditioner, reverse: hbar2 = W2' obar, zbar2 = act'(z2) hbar2, hbar1 = W1' zbar2, zbar1 = act'(z1) hbar1
+        f32x16 g0[NCH], g1[NCH];
+        {
+            Frag f[NCH][2];
+            int e[NCH];
+            to_frags1(ob, f, e);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) { g0[c] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; g1[c] = g0[c]; }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                mfma_step<NCH>(TW2h, TW2l, 0, s, f, g0, lane);
+                mfma_step<NCH>(TW2h + 1024, TW2l + 1024, 0, s, f, g1, lane);
+            }
+            unscale_all(g0, e);
+            unscale_all(g1, e);
+            act_block_bwd(z2a, g0);
+            act_block_bwd(z2b, g1);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) { dump_block(dmp + kDY2 + c * 2048, 0, g0[c], j, h); dump_block(dmp + kDY2 + c * 2048, 32, g1[c], j, h); }
+            to_frags_all(g0, g1, f, e);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) { g0[c] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; g1[c] = g0[c]; }
+            dense64_block<NCH>(TW1h, TW1l, f, g0, lane);
+            dense64_block<NCH>(TW1h + 2048, TW1l + 2048, f, g1, lane);
+            unscale_all(g0, e);
+            unscale_all(g1, e);
+        }
+        {
+            using O = NetOff<2, 1>;
+            const float in0[2] = {u0.v, 1.0f}, in1[2] = {u1.v, 0.0f};
+            f32x16 a0[NCH], a1[NCH];
+            init_acc(a0, net + O::b0 + (0 * 2 + h) * 16);
+            init_acc(a1, net + O::b0 + (1 * 2 + h) * 16);
+            const float w0 = net[O::W0 + 0 * 64 + lane], w1 = net[O::W0 + 1 * 64 + lane];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                a0[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, h ? in1[c] : in0[c], a0[c], 0, 0, 0);
+                a1[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, h ? in1[c] : in0[c], a1[c], 0, 0, 0);
+            }
+            act_block_bwd(a0, g0);
+            act_block_bwd(a1, g1);
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) { dump_block(dmp + kDY1 + c * 2048, 0, g0[c], j, h); dump_block(dmp + kDY1 + c * 2048, 32, g1[c], j, h); }
+        {
+            const f32x16 wa = load16(TW0 + (0 * 2 + h) * 16), wb2 = load16(TW0 + (1 * 2 + h) * 16);
+            float sbar = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sbar = __builtin_fmaf(wa[r], g0[0][r], __builtin_fmaf(wb2[r], g1[0][r], sbar));
+            u0b.v += xhalf_sum(sbar);
+        }
+        if (valid && h == 0) {
+            ja_store(adjb, 0, B, w, u0b);
+            ja_store(adjb, 1, B, w, u1b);
+            ja_store(adjb, 2, B, w, ldb);
+        }
+    }
+}
+
+// ---- weight-gradient products of one net from the tile dumps.  Gradient block of a net (floats, in the units of the MFMA image):
+//   GW0 [64] (d / d W0'[0][u]), Gb0 [64], GW1 [64][64] (k, u), Gb1 [64], GW2 [64][32] (k, row), Gb2 of dimension 1 [32], of dimension 0 [32]
+constexpr int kGW0 = 0, kGb0 = 64, kGW1 = 128, kGb1 = 4224, kGW2 = 4288, kGb21 = 6336, kGb20 = 6368, kGFloats = 6400;
+constexpr int kESplit = 128;   // partial sums along the tile axis (summed in split order: bitwise reproducible)
+// one wave = one 32 x 32 output block of dW1 (jobs 0..3: mb, nb) or dW2 (jobs 4, 5: mb) over the tiles of its split
+__global__ __launch_bounds__(64) void k_ewgrad(const float* __restrict__ dump, int64_t n_tiles, float* __restrict__ partial) {
+    const int job = blockIdx.y, split = blockIdx.x, lane = threadIdx.x;
+    const bool w2 = job >= 4;
+    const int mb = w2 ? job - 4 : job >> 1, nb = w2 ? 0 : job & 1;
+    const int xoff = w2 ? kDX2 : kDX1, yoff = w2 ? kDY3 : kDY2, ystride = w2 ? 1024 : 2048;
+    const int m = lane & 31, hs = lane >> 5;
+    f32x16 acc = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int64_t t0 = n_tiles * split / kESplit, t1 = n_tiles * (split + 1) / kESplit;
+    for (int64_t t = t0; t < t1; ++t) {
+        const float* d = dump + (size_t)t * kDumpFloats;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const float* xa = d + xoff + c * 2048 + (32 * mb + m) * 32 + 16 * st + 8 * hs;
+                const float* yb = d + yoff + c * ystride + (32 * nb + m) * 32 + 16 * st + 8 * hs;
+                const float4_t x0 = *reinterpret_cast<const float4_t*>(xa), x1 = *reinterpret_cast<const float4_t*>(xa + 4);
+                const float4_t y0 = *reinterpret_cast<const float4_t*>(yb), y1 = *reinterpret_cast<const float4_t*>(yb + 4);
+                const float xr[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w}, yr[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
+                // one power of two per lane and operand keeps the fp16 pairs in range (adjoints are unbounded); exact, undone after the products
+                float ax = 0.0f, ay = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { ax = fmaxf(ax, fabsf(xr[i])); ay = fmaxf(ay, fabsf(yr[i])); }
+                // (the scale must be common to a whole K step of one operand ROW for A and COLUMN for B: a lane holds exactly the 8 k's of its row /
+                // column and half h the other 8, so reduce over the two halves)
+                ax = xhalf_max(ax); ay = xhalf_max(ay);
+                const int ex = ax > 0.0f ? __builtin_amdgcn_frexp_expf(ax) : 0, ey = ay > 0.0f ? __builtin_amdgcn_frexp_expf(ay) : 0;
+                const float sx = __builtin_amdgcn_ldexpf(1.0f, -ex), sy = __builtin_amdgcn_ldexpf(1.0f, -ey);
+                float xs[8], ys[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { xs[i] = xr[i] * sx; ys[i] = yr[i] * sy; }
+                f16x8 xh, xl, yh, yl;
+                split8(xs, xh, xl);
+                split8(ys, yh, yl);
+                f32x16 p = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                p = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, yh, p, 0, 0, 0);
+                p = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, yl, p, 0, 0, 0);
+                p = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, yh, p, 0, 0, 0);
+                // undo the scales: row scale of register r's row lives in another lane (row = acc_row(r, h)), column scale in this lane's column
+                // -> the row exponents are exchanged through LDS-free lane reads
+                const float cy = __builtin_amdgcn_ldexpf(1.0f, ey);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * hs;
+                    const int exr = __shfl(ex, row);    // lane `row` (half 0) holds the exponent of A's row `row`
+                    acc[r] = __builtin_fmaf(p[r] * cy, __builtin_amdgcn_ldexpf(1.0f, exr), acc[r]);
+                }
+            }
+    }
+    float* g = partial + (size_t)split * kGFloats;
+    const int ncols = w2 ? 32 : 64, base = w2 ? kGW2 : kGW1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) g[base + (32 * mb + (r & 3) + 8 * (r >> 2) + 4 * hs) * ncols + 32 * nb + m] = acc[r];
+}
+// bias and input-layer sums: thread = one row of Gb0 / GW0 / Gb1 / Gb2 (dimension 1) / Gb2 (dimension 0), over the tiles of its split
+__global__ __launch_bounds__(256) void k_ebias(const float* __restrict__ dump, int64_t n_tiles, float* __restrict__ partial) {
+    const int split = blockIdx.x, t = threadIdx.x;
+    int off, row, out;
+    bool w0 = false;
+    if (t < 64) { off = kDY1; row = t; out = kGb0 + t; }
+    else if (t < 128) { off = kDY1; row = t - 64; out = kGW0 + row; w0 = true; }
+    else if (t < 192) { off = kDY2; row = t - 128; out = kGb1 + row; }
+    else if (t < 224) { off = kDY3; row = t - 192; out = kGb21 + row; }
+    else { off = kDY30; row = t - 224; out = kGb20 + row; }
+    float acc = 0.0f;
+    const int64_t t0 = n_tiles * split / kESplit, t1 = n_tiles * (split + 1) / kESplit;
+    for (int64_t ti = t0; ti < t1; ++ti) {
+        const float* d = dump + (size_t)ti * kDumpFloats;
+        const float4_t* y = reinterpret_cast<const float4_t*>(d + off + row * 32);
+        if (!w0) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const float4_t v = y[q]; acc += (v.x + v.y) + (v.z + v.w); }
+        } else {   // d / d W0'[0][u] = sum_w zbar1_0[u][w] s_w + zbar1_1[u][w]   (the seed of the conditioner's input is (s, 1, 0))
+            const float4_t* y1 = reinterpret_cast<const float4_t*>(d + off + 2048 + row * 32);
+            const float4_t* sv = reinterpret_cast<const float4_t*>(d + kDS);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float4_t v = y[q], u = y1[q], s4 = sv[q];
+                acc += (__builtin_fmaf(v.x, s4.x, u.x) + __builtin_fmaf(v.y, s4.y, u.y)) + (__builtin_fmaf(v.z, s4.z, u.z) + __builtin_fmaf(v.w, s4.w, u.w));
+            }
+        }
+    }
+    partial[(size_t)split * kGFloats + out] = acc;
+}
+__global__ void k_egrad_reduce(const float* __restrict__ partial, int accumulate, float* __restrict__ gacc) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= kGFloats) return;
+    float sacc = accumulate ? gacc[i] : 0.0f;
+    for (int p = 0; p < kESplit; ++p) sacc += partial[(size_t)p * kGFloats + i];
+    gacc[i] = sacc;
+}
+struct ENetOff {
+    int W0, b0, W1, b1, W2, b2, NO, n_out;
+    float c2;   // scale of the head's pre-activation: -log2(e) under a sigmoid head, 1 otherwise
+};
+struct ENetOffs {
+    ENetOff n[8];
+};
+__global__ void k_fill_zero(float* __restrict__ p, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0.0f;
+}
+// image units -> the reference's leaves: scales of describe_mfma_image, and the column sums folded into the biases behind a tanh (k_fold_bias)
+__global__ void k_egrad_scatter(const float* __restrict__ gacc, int n_nets, const ENetOffs offs, float* __restrict__ flat) {
+    const int net = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (net >= n_nets || i >= kGFloats) return;
+    const ENetOff q = offs.n[net];
+    const float* g = gacc + (size_t)net * kGFloats;
+    const float c1 = 2.8853900817779268f;
+    if (i < 64) flat[q.W0 + i] = c1 * g[kGW0 + i];                                  // W0[0][u]
+    else if (i < 128) flat[q.b0 + (i - 64)] = c1 * g[i];
+    else if (i < kGb1) { const int e = i - kGW1, u = e & 63; flat[q.W1 + e] = -2.0f * c1 * g[i] + c1 * g[kGb1 + u]; }
+    else if (i < kGW2) flat[q.b1 + (i - kGb1)] = c1 * g[i];
+    else if (i < kGb21) {
+        const int e = i - kGW2, k = e >> 5, jb = e & 31;
+        if (jb < q.n_out) flat[q.W2 + k * q.NO + (jb * 2 + 1)] = -2.0f * q.c2 * g[i] + q.c2 * g[kGb21 + jb];
+    } else if (i < kGb20) { const int jb = i - kGb21; if (jb < q.n_out) flat[q.b2 + jb * 2 + 1] = q.c2 * g[i]; }
+    else { const int jb = i - kGb20; if (jb < q.n_out) flat[q.b2 + jb * 2 + 0] = q.c2 * g[i]; }
+}
+
 int check() {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -787,7 +1405,7 @@ int64_t energy_tile_floats(int64_t B) { return B * (12 + 1) + ((B + 31) / 32) * 
 
 // mdev: the model's MFMA description (resident or not: one net is staged per launch); md: ModelDev on the host (spline sizes, masks)
 int launch_energy_tile(const MfmaDev* mdev, const ModelDev& md, const float* tabI4, const float* tabP4, const float* fk_nat, const float* x, int64_t B,
-                       const Protons& pr, float* hpsi, float* psi, float* lap, float* ws, void* stream) {
+                       const Protons& pr, float* hpsi, float* psi, float* lap, float* ws, void* stream, float* st_out) {
     hipStream_t s = (hipStream_t)stream;
     if (B == 0) return WF_OK;
     // every net resident in LDS (the shipped shapes): the whole of H psi in one launch, nothing through HBM but the walkers and the results.
@@ -800,11 +1418,11 @@ int launch_energy_tile(const MfmaDev* mdev, const ModelDev& md, const float* tab
             if (mdev->nbk == 1) {
                 static DynLdsSlots cfg1{};
                 if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(k_efused<1>), lds_all, &cfg1)) return rc;
-                hipLaunchKernelGGL(k_efused<1>, dim3(blocks), dim3(kFusedWaves * 64), lds_all, s, *mdev, tabI4, tabP4, x, B, pr, hpsi, psi, lap);
+                hipLaunchKernelGGL(k_efused<1>, dim3(blocks), dim3(kFusedWaves * 64), lds_all, s, *mdev, tabI4, tabP4, x, B, pr, hpsi, psi, lap, st_out);
             } else {
                 static DynLdsSlots cfg2{};
                 if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(k_efused<2>), lds_all, &cfg2)) return rc;
-                hipLaunchKernelGGL(k_efused<2>, dim3(blocks), dim3(kFusedWaves * 64), lds_all, s, *mdev, tabI4, tabP4, x, B, pr, hpsi, psi, lap);
+                hipLaunchKernelGGL(k_efused<2>, dim3(blocks), dim3(kFusedWaves * 64), lds_all, s, *mdev, tabI4, tabP4, x, B, pr, hpsi, psi, lap, st_out);
             }
             return check();
         }
@@ -828,6 +1446,72 @@ int launch_energy_tile(const MfmaDev* mdev, const ModelDev& md, const float* tab
     hipLaunchKernelGGL(k_etile_cond<true>, dim3(cond_blocks), dim3(kCondWaves * 64), lds_bytes, s, *mdev, md.n_layers, (const float*)st, B, oj, s1);
     hipLaunchKernelGGL(k_etile_prior, dim3(lane_blocks), dim3(256), 0, s, mdev->comp + (size_t)md.n_layers * mdev->n_mesh, tabP4, md.psp.nb,
                        md.psp.n_mesh, md.constrained_mask, (const float*)oj, (const float*)s1, (const float*)st, x, B, pr, hpsi, psi, lap);
+    return check();
+}
+
+
+// ---- host side of the matrix-core gradient path
+bool energy_vjp_capable(const MfmaDev* mdev) { return mdev->timg_off >= 0 && mdev->nbk == 1 && energy_tile_fused(mdev) && !mdev->p_bias && !mdev->i_gate && !mdev->p_gate; }
+// floats of workspace per walker of a chunk (whole tiles), + the fixed part
+int64_t energy_vjp_floats_per_walker(int n_nets) { return (int64_t)n_nets * 12 + 12 + 4 + kDumpFloats / 32; }
+int64_t energy_vjp_fixed_floats() { return (int64_t)kESplit * kGFloats + kDumpFloats + 128; }
+int energy_vjp_gacc_floats(int n_nets) { return n_nets * kGFloats; }
+
+// One chunk of walkers (B a multiple of 32 except for the last chunk of a batch): forward with the per-net input jets, seeds (mode 2: from H psi of
+// this very sweep, e_loc is written; mode 1: w_psi / w_lap given), reverse net by net with the weight-gradient products behind each net.
+// gacc [n_nets][kGFloats]: accumulated over the chunks of a batch (accumulate = 0 for the first one).
+int launch_energy_vjp(const MfmaDev* mdev, const ModelDev& md, const float* tabI4, const float* tabP4, const float* x, int64_t B, int mode, const float* w_psi,
+                      const float* w_lap, const Protons& pr, float running_avg, const float* running_avg_dev, float inv_count, float* e_loc, float* ws,
+                      float* gacc, int accumulate, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (B == 0) return WF_OK;
+    const int n_nets = mdev->n_nets;
+    const int64_t n_tiles = (B + 31) / 32;
+    float* st = ws;                                  // [n_nets][12][B]
+    float* adjb = st + (size_t)n_nets * 12 * B;      // [12][B]
+    float* hpsi = adjb + 12 * B;
+    float* psi = hpsi + B;
+    float* wp = psi + B;
+    float* wl = wp + B;
+    float* dump = ws + (((size_t)(n_nets * 12 + 12 + 4) * B + 63) / 64) * 64;   // (64-float alignment: the dump rows are read as 16-byte groups)
+    float* partial = dump + (size_t)n_tiles * kDumpFloats;
+    int rc = launch_energy_tile(mdev, md, tabI4, tabP4, nullptr, x, B, pr, hpsi, psi, nullptr, nullptr, stream, st);
+    if (rc) return rc;
+    if (mode == 2) {
+        rc = launch_vqmc_seeds(x, B, 2, pr, hpsi, psi, running_avg, inv_count, e_loc, wp, wl, running_avg_dev, stream);
+        if (rc) return rc;
+        w_psi = wp;
+        w_lap = wl;
+    }
+    const int lds_bytes = (mdev->const_floats + mdev->net_floats + mdev->tnet_floats + 1024) * (int)sizeof(float);
+    static DynLdsSlots cfg_p{}, cfg_f{};
+    if (int r2 = ensure_dynamic_lds(reinterpret_cast<const void*>(k_ebwd<true>), lds_bytes, &cfg_p)) return r2;
+    if (int r2 = ensure_dynamic_lds(reinterpret_cast<const void*>(k_ebwd<false>), lds_bytes, &cfg_f)) return r2;
+    const unsigned blocks = (unsigned)std::min<int64_t>((n_tiles + kBwdWaves - 1) / kBwdWaves, 256);
+    for (int n = n_nets - 1; n >= 0; --n) {
+        const float* st_n = st + (size_t)n * 12 * B;
+        if (n == n_nets - 1)
+            hipLaunchKernelGGL(k_ebwd<true>, dim3(blocks), dim3(kBwdWaves * 64), lds_bytes, s, *mdev, n, tabI4, tabP4, st_n, adjb, w_psi, w_lap, B, dump);
+        else
+            hipLaunchKernelGGL(k_ebwd<false>, dim3(blocks), dim3(kBwdWaves * 64), lds_bytes, s, *mdev, n, tabI4, tabP4, st_n, adjb, w_psi, w_lap, B, dump);
+        hipLaunchKernelGGL(k_ewgrad, dim3(kESplit, 6), dim3(64), 0, s, (const float*)dump, n_tiles, partial);
+        hipLaunchKernelGGL(k_ebias, dim3(kESplit), dim3(256), 0, s, (const float*)dump, n_tiles, partial);
+        hipLaunchKernelGGL(k_egrad_reduce, dim3((kGFloats + 255) / 256), dim3(256), 0, s, (const float*)partial, accumulate, gacc + (size_t)n * kGFloats);
+    }
+    return check();
+}
+
+// gacc -> flat gradient in the reference's leaf order (every entry written: zero first, then the live leaves)
+int launch_energy_vjp_finish(const float* gacc, int n_nets, const int* offs /* [n_nets][8]: W0, b0, W1, b1, W2, b2, NO, n_out */, const float* c2, float* flat,
+                             int64_t n_params, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    ENetOffs o{};
+    for (int n = 0; n < n_nets && n < 8; ++n) {
+        const int* q = offs + 8 * n;
+        o.n[n] = ENetOff{q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], c2[n]};
+    }
+    hipLaunchKernelGGL(k_fill_zero, dim3((unsigned)((n_params + 255) / 256)), dim3(256), 0, s, flat, n_params);
+    hipLaunchKernelGGL(k_egrad_scatter, dim3((kGFloats + 255) / 256, n_nets), dim3(256), 0, s, gacc, n_nets, o, flat);
     return check();
 }
 

@@ -119,6 +119,7 @@ struct wf_model {
     int64_t scratch_floats = 0;
     float* d_wave = nullptr;         // NetWave images
     float* d_grad_fk = nullptr;      // [2][64] natural-order row factors for the reverse pass (flow rows, prior rows)
+    float* d_egacc = nullptr;        // [n_nets][6400] gradient blocks of the matrix-core gradient path, accumulated over the chunks of a batch
     bool wave_ok = false;            // the wave-cooperative sweeps and sampler cover this model (homogeneous constraints, gated heads included; > 32 bases: D <= 4)
     // boundary conditions as a linear map on the coefficient vector (bc_map below): column sums a~ of A, per spline (I layers / prior);
     // bc_*_ok: homogeneous (no constant term) and every column with a~_j == 0 is entirely zero -> the table-driven kernels apply
@@ -319,6 +320,7 @@ static int wave_passes(int D, int nbp) { return nbp == 32 ? (D + 1) / 2 : D; }  
 static int ensure_scratch(const wf_model* cm, int64_t floats);
 static constexpr int kTapedLaplacianMaxD = 8;    // largest D whose reverse sweep runs in RF (measured, scratch/grad_ab.py)
 static constexpr int64_t kWaveEvalMax = 6144;   // measured crossover ~7000 walkers (scratch/crossover.py)
+static constexpr int64_t kGradTileMin = 16384;    // psi / Laplacian gradients: the matrix-core path (k_ebwd, k_ewgrad) from here on
 static constexpr int64_t kEnergyTileMin = 16384; // H psi: the tile path (8 launches, staged weight images) from here on
 static constexpr int64_t kEnergyTileChunk = (int64_t)1 << 19;   // walkers per pass of the tile path (WF_ENERGY_TILE_CHUNK; 2^20 walkers: 1.20 ms in two passes, 1.30 in one, 1.34 in four)
 namespace wf {
@@ -872,6 +874,45 @@ static void describe_mfma_image(const wf_model* m, int n, uint32_t base, std::ve
 
 // Decides whether the MFMA kernel covers this model and builds its parameter-independent parts.
 // i64 / p64: the fp64 tables already built by model_build (I: [4][nb][n_mesh]; prior: OB or M), o2b: [nb][nb].
+// Transposed operand images of net n for the reverse sweep of the matrix-core gradient path (k_ebwd, wf_kernels_etile.hip; D = 2, <= 32 bases):
+// hbar_1[k] = sum_u W1'[k][u] zbar_2[u] and hbar_2[k] = sum_j W2'[k][j] obar[j] are MFMA products whose A operand is the weight matrix with the
+// INPUT unit on the row, same entries and scales as the forward image.  Layout (floats, base = float offset inside d_mfma):
+//   TW1 hi [ob 2][t 2][s 2][lane 64][8 halves] (2048 floats), TW1 lo (2048), TW2 hi [ob 2][s 2][64][8] (1024), TW2 lo (1024), W0'[0][unit] in
+//   accumulator layout [ob][h][16] (64): the adjoint of the conditioner's input s is sum_u W0'[0][u] zbar_1[u].
+constexpr int kTNetFloats = 2048 + 2048 + 1024 + 1024 + 64;
+static void describe_mfma_image_t(const wf_model* m, int n, uint32_t base, std::vector<PackRec>& out) {
+    const int D = m->desc.n_dim, H = kHidden;
+    const NetLayout& nl = m->nets[n];
+    const NetOffsets q = net_offsets(m, n);
+    const double c1 = 2.0 * 1.4426950408889634074;
+    const double c2 = net_has_sigmoid_head(m, n) ? -1.4426950408889634074 : 1.0;
+    ImageWriter w{out, base};
+    auto f16_block = [&](uint32_t n_pairs, auto&& src_of) {
+        uint32_t hi = 2 * w.o, lo = hi + n_pairs;
+        for (uint32_t e = 0; e < n_pairs; ++e) {
+            const std::pair<int64_t, double> sv = src_of(e);
+            out.push_back(PackRec{(int32_t)sv.first, 1, hi++, lo++, sv.first >= 0 ? sv.second : 0.0});
+        }
+        w.o += n_pairs;
+    };
+    // A[m = input unit k = 32 ob + (lane & 31)][kk = output unit u = 32 t + acc_row(8 s + j, lane >> 5)] = W1'[k][u]
+    f16_block(4096, [&](uint32_t e) {
+        const int j = e & 7, lane = (e >> 3) & 63, s_ = (e >> 9) & 1, t = (e >> 10) & 1, ob = (e >> 11) & 1;
+        const int k = 32 * ob + (lane & 31), u = 32 * t + acc_row(8 * s_ + j, lane >> 5);
+        return std::make_pair(deg_hidden(u, D) >= deg_hidden(k, D) ? q.W1 + (int64_t)k * H + u : (int64_t)-1, -2.0 * c1);
+    });
+    // A[m = hidden unit k][kk = basis row jb = acc_row(8 s + j, lane >> 5)] = W2'[k][(jb, d = 1)]
+    f16_block(2048, [&](uint32_t e) {
+        const int j = e & 7, lane = (e >> 3) & 63, s_ = (e >> 9) & 1, ob = (e >> 10) & 1;
+        const int k = 32 * ob + (lane & 31), jb = acc_row(8 * s_ + j, lane >> 5);
+        const bool live = jb < nl.n_out && deg_out(1) >= deg_hidden(k, D);
+        return std::make_pair(live ? q.W2 + (int64_t)k * q.NO + (jb * D + 1) : (int64_t)-1, -2.0 * c2);
+    });
+    for (int ob = 0; ob < 2; ++ob)
+        for (int h = 0; h < 2; ++h)
+            for (int r = 0; r < 16; ++r) w.f32(q.W0 + 32 * ob + acc_row(r, h), c1);   // W0[k = 0][unit]
+}
+
 static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::vector<double>& p64, const std::vector<double>& o2b) {
     const wf_model_desc& d = m->desc;
     const int D = d.n_dim;
@@ -890,7 +931,10 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
     if ((int64_t)consts + (int64_t)net_floats * n_nets <= lds_cap) staged = 0;        // every net resident
     else if ((int64_t)consts + net_floats + 16 * kStagedGroups * (D + 1) * 32 <= lds_cap) staged = 1;   // one slot + the state area, re-staged per super-chunk
     else return WF_OK;
-    const int64_t total = (int64_t)net_floats * n_nets + consts;
+    // the matrix-core gradient path (two particles, <= 32 bases, Waveflow prior, IMADE layers): transposed operand images behind the constants block
+    const bool timg = D == 2 && nbk == 1 && d.prior_kind == WF_PRIOR_WAVEFLOW && (d.layer_kind == WF_LAYER_IMADE || d.n_flow_layers == 0);
+    const int tconsts = 1024;   // ob_to_b transposed: hi [s 2][lane 64][8 halves] (512 floats), lo (512)
+    const int64_t total = (int64_t)net_floats * n_nets + consts + (timg ? (int64_t)kTNetFloats * n_nets + tconsts : 0);
 
     MfmaDev& md = m->mdev;
     md = MfmaDev{};
@@ -902,6 +946,9 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
     md.prior_quotient = (getenv("WF_PRIOR_QUOTIENT") && atoi(getenv("WF_PRIOR_QUOTIENT")) != 0) ? 1 : 0;
     md.i_gate = m->dev.i_gate; md.p_gate = m->dev.p_gate;
     md.p_bias = (d.prior_kind == WF_PRIOR_WAVEFLOW && !m->p_cb.empty()) ? 1 : 0;
+    md.timg_off = timg ? net_floats * n_nets + consts : -1;
+    md.tnet_floats = kTNetFloats;
+    md.tconst_off = timg ? md.timg_off + kTNetFloats * n_nets : -1;
     // staged mode: one net slot + the state area of the super-chunk (16 waves x kStagedGroups tile groups x (D + 1) x 32 floats: the
     // built staged shapes run 8 waves of one tile; sized for the largest workgroup)
     m->mfma_lds_floats = consts + (staged ? net_floats + 16 * kStagedGroups * (D + 1) * 32 : net_floats * n_nets);
@@ -992,6 +1039,22 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
     // the constants block does not depend on the parameters: upload it once
     WF_HIP(hipMemset(m->d_mfma, 0, (size_t)total * sizeof(float)));
     WF_HIP(hipMemcpy(m->d_mfma + md.const_img_off, m->mfma_consts.data(), m->mfma_consts.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (timg && spline_prior) {
+        // wbar[a] = sum_i M[a][i] cbar[i] (M = ob_to_b with the boundary map folded in, as the forward image holds it): A[m = a = lane & 31][kk = i = acc_row(8 s + j, lane >> 5)]
+        std::vector<float> tc(tconsts, 0.0f);
+        _Float16* o = reinterpret_cast<_Float16*>(tc.data());
+        const int nb = m->p_nb;
+        for (int s_ = 0; s_ < 2; ++s_)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int a = lane & 31, i = acc_row(8 * s_ + j, lane >> 5);
+                    const float v = (i < nb && a < nb) ? (float)o2b[(size_t)a * nb + i] : 0.0f;
+                    const _Float16 hi = (_Float16)v;
+                    o[(s_ * 64 + lane) * 8 + j] = hi;
+                    o[1024 + (s_ * 64 + lane) * 8 + j] = (_Float16)(v - (float)hi);
+                }
+        WF_HIP(hipMemcpy(m->d_mfma + md.tconst_off, tc.data(), tc.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     return WF_OK;
 }
 
@@ -1018,6 +1081,7 @@ static int pack_prepare(wf_model* m, std::vector<PackRec>& plain) {
         describe_plain_image(m, n, (uint32_t)m->plain_off[n], plain);
         if (m->d_wave) describe_wave_image(m, n, (uint32_t)(wave_net_floats(D, m->nbp) * n), wave);
         if (m->mfma_ok) describe_mfma_image(m, n, (uint32_t)((int64_t)m->mdev.net_floats * n), mfma);
+        if (m->mfma_ok && m->mdev.timg_off >= 0) describe_mfma_image_t(m, n, (uint32_t)(m->mdev.timg_off + (int64_t)m->mdev.tnet_floats * n), mfma);
     }
     std::vector<PackRec> all;
     all.reserve(plain.size() + wave.size() + mfma.size());
@@ -1066,6 +1130,10 @@ static int grad_prepare(wf_model* m) {
     // One taped sample per walker in RF (value, gradient, Laplacian / 2: D + 2 channels), or D samples in R3 (3 channels each).
     // Fixed per model, because workspace sizes depend on it; WF_GRAD_R3 (read here) selects R3 for A/B tests.
     m->ring2 = (getenv("WF_GRAD_R3") || D > kTapedLaplacianMaxD) ? 1 : 2;
+    if (m->grad_psi_ok && m->mfma_ok && energy_vjp_capable(&m->mdev)) {
+        int rc = dev_alloc(m, &m->d_egacc, (size_t)energy_vjp_gacc_floats((int)m->nets.size()));
+        if (rc) return rc;
+    }
     const int n_nets = (int)m->nets.size();
     const int64_t fwd = plain_fwd_floats(D, m->nbp);
     // the plain description lists net n's forward-orientation entries first (plain_net_floats per net)
@@ -1500,6 +1568,38 @@ static int run_vjp_chunks(const wf_model* m, int mode, bool second_order, const 
     if (B == 0) {   // the gradient of an empty batch is zero
         WF_HIP(hipMemsetAsync(grad_dev, 0, (size_t)m->n_params * sizeof(float), s));
         return WF_OK;
+    }
+    // Large batches of the two-particle family (the family of the one-kernel H psi, <= 32 bases): forward, reverse and weight-gradient products on the
+    // matrix cores (wf_kernels_etile.hip: k_efused with the per-net input jets, k_ebwd per net, k_ewgrad).  WF_GRAD_TILE_MIN (read per call) moves the
+    // switch point; 0 disables the path.
+    if ((mode == 1 || mode == 2) && second_order && m->d_egacc) {
+        const char* e = getenv("WF_GRAD_TILE_MIN");
+        const int64_t tile_min = e ? atoll(e) : kGradTileMin;
+        const wf_model_desc& d = m->desc;
+        const bool family = D == 2 && m->nbp == 32 && m->mfma_ok && d.box_kind == WF_BOX_MEAN && d.layer_kind == WF_LAYER_IMADE && d.n_flow_layers > 0 &&
+                            d.prior_kind == WF_PRIOR_WAVEFLOW && m->d_tabI4c && m->d_tabP4c && !m->eval_tables_stale && energy_vjp_capable(&m->mdev);
+        const int64_t per = energy_vjp_floats_per_walker(n_nets) * (int64_t)sizeof(float), fixed = energy_vjp_fixed_floats() * (int64_t)sizeof(float);
+        const int64_t tchunk = workspace_bytes > fixed ? ((workspace_bytes - fixed) / per) / 32 * 32 : 0;
+        if (family && tile_min > 0 && B >= tile_min && tchunk >= 32) {
+            Protons none{};
+            for (int64_t c0 = 0; c0 < B; c0 += tchunk) {
+                const int64_t bc = std::min(tchunk, B - c0);
+                int rc = launch_energy_vjp(&m->mdev, m->dev, m->d_tabI4c, m->d_tabP4c, x_dev + c0 * D, bc, mode, w1 ? w1 + c0 : nullptr, w2 ? w2 + c0 : nullptr,
+                                           pr ? *pr : none, running_average, running_average_dev, inv_count, e_loc_dev ? e_loc_dev + c0 : nullptr,
+                                           (float*)workspace_dev, m->d_egacc, c0 > 0, stream);
+                if (rc) return rc;
+            }
+            std::vector<int> offs((size_t)n_nets * 8);
+            std::vector<float> c2((size_t)n_nets);
+            for (int n = 0; n < n_nets; ++n) {
+                const NetOffsets q = net_offsets(m, n);
+                int* o = &offs[(size_t)n * 8];
+                o[0] = (int)q.W0; o[1] = (int)q.b0; o[2] = (int)q.W1; o[3] = (int)q.b1; o[4] = (int)q.W2; o[5] = (int)q.b2; o[6] = q.NO; o[7] = m->nets[n].n_out;
+                c2[n] = net_has_sigmoid_head(m, n) ? -1.4426950408889634f : 1.0f;
+            }
+            if (defer_gather_split) *defer_gather_split = 0;   // the gradient is in grad_dev
+            return launch_energy_vjp_finish(m->d_egacc, n_nets, offs.data(), c2.data(), grad_dev, m->n_params, stream);
+        }
     }
     const bool single = B <= chunk;   // one chunk: the partial images are summed by the gather itself (one launch less)
     int split = 0;
