@@ -59,6 +59,61 @@ def test_vqmc_loss_grad_vs_oracle(golden, he_flat):
     assert rel_l2(grad.cpu().numpy().astype(np.float64), go) < 5e-3
 
 
+def test_gradients_on_the_matrix_cores_vs_oracle_and_wave_sweeps(golden, he_flat, monkeypatch):
+    """value_and_grad(loss_fn_efficient) (vqmc.py:193-221) for large two-particle batches: forward, per-net reverse kernels and weight-gradient
+    products on the matrix cores (wf_kernels_etile.hip: k_efused, k_ebwd, k_ewgrad; head pullbacks: wf_etile_adjoint.h, checked on the CPU by
+    tests/test_etile_adjoint.py).  Forced on a small batch (partial tile included) against the torch autograd oracle; on 50 001 walkers against the
+    wave sweeps (psi_vjp with random weights, and the loss + gradient entry point on walkers from the model's own sampler); several chunks; the
+    switch itself; bitwise reproducibility."""
+    import torch
+    from oracle import energy_torch as et
+    from waveflow_amd import _lib
+    from waveflow_amd.utils import physics
+    params, psi, log_pdf, sample = he(he_flat)
+    m = psi.model
+    m.ensure_params(params)
+    protons = physics.system_catalogue[1]["He"][0].reshape(-1)
+    x = np.sort(golden["he_golden"]["sample_points"], -1)[:171].astype(np.float32)       # 5 tiles + 11 walkers
+    monkeypatch.setenv("WF_GRAD_TILE_MIN", "1")
+    sums, grad = m.vqmc_loss_grad(x, protons, running_average=-2.5)
+    lo, go, elo = et.vqmc_loss_grad(et.he_model(torch.float64), he_flat, x.astype(np.float64), protons, -2.5)
+    s = sums.cpu().numpy()
+    assert abs(s[0] / s[2] - lo) < 1e-3 * max(1.0, np.abs(elo).mean())
+    assert rel_l2(grad.cpu().numpy().astype(np.float64), go) < 5e-3, rel_l2(grad.cpu().numpy().astype(np.float64), go)
+    g = np.random.default_rng(5)
+    w1, w2 = g.normal(size=len(x)).astype(np.float32), (0.1 * g.normal(size=len(x))).astype(np.float32)
+    got = m.psi_vjp(x, w1, w2).cpu().numpy().astype(np.float64)
+    want = et.psi_vjp(et.he_model(torch.float64), he_flat, x.astype(np.float64), w1, w2)
+    assert rel_l2(got, want) < 5e-3, rel_l2(got, want)
+    # a large ragged batch: against the wave sweeps (fp32 both: 1.6e-5 measured), bit-reproducible, and in several chunks
+    xb = torch.as_tensor(sorted_walkers(50001, 2, 9.5, 7)).cuda()
+    wb1 = torch.as_tensor(g.normal(size=50001).astype(np.float32)).cuda()
+    wb2 = torch.as_tensor((0.1 * g.normal(size=50001)).astype(np.float32)).cuda()
+    tile = m.psi_vjp(xb, wb1, wb2)
+    assert torch.equal(tile, m.psi_vjp(xb, wb1, wb2))
+    monkeypatch.setenv("WF_GRAD_TILE_MIN", "0")
+    wave = m.psi_vjp(xb, wb1, wb2)
+    monkeypatch.delenv("WF_GRAD_TILE_MIN")
+    assert torch.equal(m.psi_vjp(xb, wb1, wb2), tile)                      # default switch: 50 001 walkers take the matrix-core path
+    assert rel_l2(tile.cpu().numpy(), wave.cpu().numpy()) < 2e-4 and not torch.equal(tile, wave)
+    L = _lib.lib()
+    ws = torch.empty(40 * 1024 * 1024, device="cuda", dtype=torch.uint8)    # room for ~ 9 000 walkers per chunk
+    grad = torch.empty(m.n_params, device="cuda")
+    monkeypatch.setenv("WF_GRAD_TILE_MIN", "1")
+    rc = L.wf_psi_vjp(m._h, xb.data_ptr(), 50001, wb1.data_ptr(), wb2.data_ptr(), grad.data_ptr(), ws.data_ptr(), ws.numel(), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert rel_l2(grad.cpu().numpy(), tile.cpu().numpy()) < 1e-4
+    # the loss + gradient entry point on walkers from |psi|^2 (where E_L is well conditioned)
+    xs = m.sample(11, 40000, exact=True)
+    st, gt = m.vqmc_loss_grad(xs, protons, -1.8)
+    monkeypatch.setenv("WF_GRAD_TILE_MIN", "0")
+    sw, gw = m.vqmc_loss_grad(xs, protons, -1.8)
+    monkeypatch.delenv("WF_GRAD_TILE_MIN")
+    np.testing.assert_allclose(st.cpu().numpy(), sw.cpu().numpy(), rtol=1e-4)
+    assert rel_l2(gt.cpu().numpy(), gw.cpu().numpy()) < 2e-3, rel_l2(gt.cpu().numpy(), gw.cpu().numpy())
+
+
 def test_psi_vjp_chunks_and_errors(he_flat):
     import torch
     from waveflow_amd import _lib

@@ -787,7 +787,8 @@ __global__ __launch_bounds__(kFusedWaves * 64) void k_efused(const MfmaDev mm, c
 //                       Y1, Y2, Y3 as [channel][unit][32 walkers] blocks (coalesced: a register of the accumulator layout is two 128-byte rows)
 //   k_ewgrad            dW[k][u] = sum_walkers sum_channels X_c[k][w] Y_c[u][w]: the walker axis is the K of this product and the dumps hold it
 //                       contiguous, so both MFMA operands are plain 32-byte reads; split-fp16 products, per-split partial sums (fixed order)
-//   k_ebias, k_egrad_reduce, k_egrad_scatter   bias / input-layer sums, reduction over the splits, scales and folds back to the flat leaf order
+//                       (bias and input-layer sums ride along: the same reads)
+//   k_egrad_reduce, k_egrad_scatter   reduction over the splits; scales and folds back to the flat leaf order
 using JA = adj::Jt<float>;
 using TA = adj::T2t<float>;
 constexpr int kBwdWaves = 8;
@@ -1115,25 +1116,36 @@ __global__ __launch_bounds__(kBwdWaves * 64) void k_ebwd(const MfmaDev mm, int n
             const LerpN L1 = nlerp(u1.v, n_mesh), L0 = nlerp(u0.v, n_mesh);
             f32x16 o0[NCH];
             o0[0] = load16(net + NetOff<2, 1>::b2 + (0 * 2 + h) * 16);   // dimension 0: the bias alone (empty mask)
-            adj::FlowSumsT<float> s1 = adj::flow_sums_zero<float>(), s0 = adj::flow_sums_zero<float>();
-            flow_rows_ext<false>(s1, o, g16, tabI, bnd_s, L1, h);
-            flow_rows_ext<true>(s0, o0, g16, tabI, bnd_s, L0, h);
-            flow_sums_xhalf(s1);
-            flow_sums_xhalf(s0);
-            JA y1, dl1, y0, dl0;
-            const adj::FlowHeadFwd<float> f1 = adj::flow_head_fwd(s1, mm.F_I, mm.i_reg, u0, u1, y1, dl1);
-            const adj::FlowHeadFwd<float> f0 = adj::flow_head_fwd(s0, mm.F_I, mm.i_reg, u0, u0, y0, dl0);
-            adj::FlowSumsT<float> ab1 = adj::flow_sums_zero<float>(), ab0 = adj::flow_sums_zero<float>();
-            JA sb = adj::jzero<float>(), tb = adj::jzero<float>(), sb0 = adj::jzero<float>(), tb0 = adj::jzero<float>();
-            float tv1 = 0.0f, tv0 = 0.0f;
-            adj::flow_head_bwd(s1, f1, mm.F_I, mm.i_reg, u0, u1, y1b, ldb, ab1, sb, tb, tv1);
-            adj::flow_head_bwd(s0, f0, mm.F_I, mm.i_reg, u0, u0, y0b, ldb, ab0, sb0, tb0, tv0);
+            // dimension 0 first, then dimension 1: the two heads share nothing but the incoming adjoints, and their sums / intermediates need not be live together
+            JA sb0 = adj::jzero<float>(), tb0 = adj::jzero<float>();
+            float tv0 = 0.0f;
+            {
+                adj::FlowSumsT<float> s0 = adj::flow_sums_zero<float>();
+                flow_rows_ext<true>(s0, o0, g16, tabI, bnd_s, L0, h);
+                flow_sums_xhalf(s0);
+                JA y0, dl0;
+                const adj::FlowHeadFwd<float> f0 = adj::flow_head_fwd(s0, mm.F_I, mm.i_reg, u0, u0, y0, dl0);
+                adj::FlowSumsT<float> ab0 = adj::flow_sums_zero<float>();
+                adj::flow_head_bwd(s0, f0, mm.F_I, mm.i_reg, u0, u0, y0b, ldb, ab0, sb0, tb0, tv0);
+                f32x16 t0[NCH];
+                flow_rows_bwd<true>(ab0, o0, g16, tabI, bnd_s, L0, h, t0);
+                ob0 = t0[0];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            JA sb = adj::jzero<float>(), tb = adj::jzero<float>();
+            float tv1 = 0.0f;
+            {
+                adj::FlowSumsT<float> s1 = adj::flow_sums_zero<float>();
+                flow_rows_ext<false>(s1, o, g16, tabI, bnd_s, L1, h);
+                flow_sums_xhalf(s1);
+                JA y1, dl1;
+                const adj::FlowHeadFwd<float> f1 = adj::flow_head_fwd(s1, mm.F_I, mm.i_reg, u0, u1, y1, dl1);
+                adj::FlowSumsT<float> ab1 = adj::flow_sums_zero<float>();
+                adj::flow_head_bwd(s1, f1, mm.F_I, mm.i_reg, u0, u1, y1b, ldb, ab1, sb, tb, tv1);
+                flow_rows_bwd<false>(ab1, o, g16, tabI, bnd_s, L1, h, ob);
+            }
             u0b = JA{tv0, sb.a + sb0.a + tb0.a, sb.b + sb0.b + tb0.b, sb.h + sb0.h + tb0.h};
             u1b = JA{tv1, tb.a, tb.b, tb.h};
-            flow_rows_bwd<false>(ab1, o, g16, tabI, bnd_s, L1, h, ob);
-            f32x16 t0[NCH];
-            flow_rows_bwd<true>(ab0, o0, g16, tabI, bnd_s, L0, h, t0);
-            ob0 = t0[0];
         } else {
             const float wp = valid ? w_psi[wl] : 0.0f, wlp = valid ? w_lap[wl] : 0.0f;
             const JA ld = ja_load(st_in, 2, B, wl);
@@ -1261,90 +1273,146 @@ __global__ __launch_bounds__(kBwdWaves * 64) void k_ebwd(const MfmaDev mm, int n
 //   GW0 [64] (d / d W0'[0][u]), Gb0 [64], GW1 [64][64] (k, u), Gb1 [64], GW2 [64][32] (k, row), Gb2 of dimension 1 [32], of dimension 0 [32]
 constexpr int kGW0 = 0, kGb0 = 64, kGW1 = 128, kGb1 = 4224, kGW2 = 4288, kGb21 = 6336, kGb20 = 6368, kGFloats = 6400;
 constexpr int kESplit = 128;   // partial sums along the tile axis (summed in split order: bitwise reproducible)
-// one wave = one 32 x 32 output block of dW1 (jobs 0..3: mb, nb) or dW2 (jobs 4, 5: mb) over the tiles of its split
-__global__ __launch_bounds__(64) void k_ewgrad(const float* __restrict__ dump, int64_t n_tiles, float* __restrict__ partial) {
-    const int job = blockIdx.y, split = blockIdx.x, lane = threadIdx.x;
-    const bool w2 = job >= 4;
-    const int mb = w2 ? job - 4 : job >> 1, nb = w2 ? 0 : job & 1;
-    const int xoff = w2 ? kDX2 : kDX1, yoff = w2 ? kDY3 : kDY2, ystride = w2 ? 1024 : 2048;
-    const int m = lane & 31, hs = lane >> 5;
-    f32x16 acc = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const int64_t t0 = n_tiles * split / kESplit, t1 = n_tiles * (split + 1) / kESplit;
-    for (int64_t t = t0; t < t1; ++t) {
-        const float* d = dump + (size_t)t * kDumpFloats;
+// 8 fp32 values of one operand row / column and K half -> fp16 pairs scaled by one power of two per row / column (exact; the adjoints are
+// unbounded).  The scale must be common to the 16 k's of a K step: a lane holds 8 of them, its partner lane (other half) the other 8.
+__device__ __forceinline__ int split_scaled(const float* __restrict__ p, f16x8& hi, f16x8& lo) {
+    const float4_t a = *reinterpret_cast<const float4_t*>(p), b = *reinterpret_cast<const float4_t*>(p + 4);
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    float mx = 0.0f;
 #pragma unroll
-        for (int c = 0; c < NCH; ++c)
+    for (int i = 0; i < 8; ++i) mx = fmaxf(mx, fabsf(v[i]));
+    mx = xhalf_max(mx);
+    const int ex = mx > 0.0f ? __builtin_amdgcn_frexp_expf(mx) : 0;
+    const float sc = __builtin_amdgcn_ldexpf(1.0f, -ex);
+    float vs[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) vs[i] = v[i] * sc;
+    split8(vs, hi, lo);
+    return ex;
+}
+// acc += 2^(ex_row + ey_col) * (three split products): the row exponent of register r's row (acc_row(r, h)) lives in lane `row`
+__device__ __forceinline__ void mfma3_unscaled(f32x16& acc, const f16x8& xh, const f16x8& xl, int ex, const f16x8& yh, const f16x8& yl, int ey, int hs) {
+    f32x16 p = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    p = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, yh, p, 0, 0, 0);
+    p = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, yl, p, 0, 0, 0);
+    p = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, yh, p, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hs;
+        acc[r] = __builtin_fmaf(p[r], __builtin_amdgcn_ldexpf(1.0f, __shfl(ex, row) + ey), acc[r]);
+    }
+}
+// Workgroup = 4 waves on one (split, job); job 0: dW1 (64 x 64: four blocks) with Gb1, Gb0 and GW0; job 1: dW2 (64 x 32: two blocks) with both Gb2.
+// A wave takes every fourth tile of the split; every operand row is read once per tile and net; the four waves' sums meet in LDS in wave order.
+__global__ __launch_bounds__(256, 2) void k_ewgrad(const float* __restrict__ dump, int64_t n_tiles, float* __restrict__ partial) {
+    __shared__ float red[4][64 * 64 + 3 * 64];
+    const int job = blockIdx.y, split = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 31, hs = lane >> 5;
+    const f32x16 z16 = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    f32x16 acc[2][2] = {{z16, z16}, {z16, z16}};
+    float bias[2] = {0.0f, 0.0f}, bias0[2] = {0.0f, 0.0f}, gw0[2] = {0.0f, 0.0f}, bias20 = 0.0f;
+    const int64_t t0 = n_tiles * split / kESplit, t1 = n_tiles * (split + 1) / kESplit;
+    for (int64_t t = t0 + wave; t < t1; t += 4) {
+        const float* d = dump + (size_t)t * kDumpFloats;
+        if (job == 0) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    const int col = 16 * st + 8 * hs;
+                    f16x8 xh[2], xl[2], yh[2], yl[2];
+                    int ex[2], ey[2];
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        ex[b] = split_scaled(d + kDX1 + c * 2048 + (32 * b + m) * 32 + col, xh[b], xl[b]);
+                        const float* yp = d + kDY2 + c * 2048 + (32 * b + m) * 32 + col;
+                        ey[b] = split_scaled(yp, yh[b], yl[b]);
+                        if (c == 0) {   // Gb1[u] = sum_w zbar2_0[u][w]
+                            const float4_t a = *reinterpret_cast<const float4_t*>(yp), bq = *reinterpret_cast<const float4_t*>(yp + 4);
+                            bias[b] += ((a.x + a.y) + (a.z + a.w)) + ((bq.x + bq.y) + (bq.z + bq.w));
+                        }
+                    }
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                        for (int nb = 0; nb < 2; ++nb) mfma3_unscaled(acc[mb][nb], xh[mb], xl[mb], ex[mb], yh[nb], yl[nb], ey[nb], hs);
+                }
+            // input layer: Gb0[u] = sum_w zbar1_0[u][w], GW0[u] = sum_w zbar1_0[u][w] s_w + zbar1_1[u][w]   (seed of the conditioner's input: (s, 1, 0))
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
-                const float* xa = d + xoff + c * 2048 + (32 * mb + m) * 32 + 16 * st + 8 * hs;
-                const float* yb = d + yoff + c * ystride + (32 * nb + m) * 32 + 16 * st + 8 * hs;
-                const float4_t x0 = *reinterpret_cast<const float4_t*>(xa), x1 = *reinterpret_cast<const float4_t*>(xa + 4);
-                const float4_t y0 = *reinterpret_cast<const float4_t*>(yb), y1 = *reinterpret_cast<const float4_t*>(yb + 4);
-                const float xr[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w}, yr[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
-                // one power of two per lane and operand keeps the fp16 pairs in range (adjoints are unbounded); exact, undone after the products
-                float ax = 0.0f, ay = 0.0f;
+                const int col = 16 * st + 8 * hs;
+                const float4_t s0 = *reinterpret_cast<const float4_t*>(d + kDS + col), s1 = *reinterpret_cast<const float4_t*>(d + kDS + col + 4);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) { ax = fmaxf(ax, fabsf(xr[i])); ay = fmaxf(ay, fabsf(yr[i])); }
-                // (the scale must be common to a whole K step of one operand ROW for A and COLUMN for B: a lane holds exactly the 8 k's of its row /
-                // column and half h the other 8, so reduce over the two halves)
-                ax = xhalf_max(ax); ay = xhalf_max(ay);
-                const int ex = ax > 0.0f ? __builtin_amdgcn_frexp_expf(ax) : 0, ey = ay > 0.0f ? __builtin_amdgcn_frexp_expf(ay) : 0;
-                const float sx = __builtin_amdgcn_ldexpf(1.0f, -ex), sy = __builtin_amdgcn_ldexpf(1.0f, -ey);
-                float xs[8], ys[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) { xs[i] = xr[i] * sx; ys[i] = yr[i] * sy; }
-                f16x8 xh, xl, yh, yl;
-                split8(xs, xh, xl);
-                split8(ys, yh, yl);
-                f32x16 p = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-                p = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, yh, p, 0, 0, 0);
-                p = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, yl, p, 0, 0, 0);
-                p = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, yh, p, 0, 0, 0);
-                // undo the scales: row scale of register r's row lives in another lane (row = acc_row(r, h)), column scale in this lane's column
-                // -> the row exponents are exchanged through LDS-free lane reads
-                const float cy = __builtin_amdgcn_ldexpf(1.0f, ey);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * hs;
-                    const int exr = __shfl(ex, row);    // lane `row` (half 0) holds the exponent of A's row `row`
-                    acc[r] = __builtin_fmaf(p[r] * cy, __builtin_amdgcn_ldexpf(1.0f, exr), acc[r]);
+                for (int b = 0; b < 2; ++b) {
+                    const float* y0 = d + kDY1 + (32 * b + m) * 32 + col;
+                    const float4_t a = *reinterpret_cast<const float4_t*>(y0), bq = *reinterpret_cast<const float4_t*>(y0 + 4);
+                    const float4_t c4 = *reinterpret_cast<const float4_t*>(y0 + 2048), d4 = *reinterpret_cast<const float4_t*>(y0 + 2052);
+                    bias0[b] += ((a.x + a.y) + (a.z + a.w)) + ((bq.x + bq.y) + (bq.z + bq.w));
+                    gw0[b] += (__builtin_fmaf(a.x, s0.x, c4.x) + __builtin_fmaf(a.y, s0.y, c4.y)) + (__builtin_fmaf(a.z, s0.z, c4.z) + __builtin_fmaf(a.w, s0.w, c4.w)) +
+                              (__builtin_fmaf(bq.x, s1.x, d4.x) + __builtin_fmaf(bq.y, s1.y, d4.y)) + (__builtin_fmaf(bq.z, s1.z, d4.z) + __builtin_fmaf(bq.w, s1.w, d4.w));
                 }
             }
-    }
-    float* g = partial + (size_t)split * kGFloats;
-    const int ncols = w2 ? 32 : 64, base = w2 ? kGW2 : kGW1;
+        } else {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) g[base + (32 * mb + (r & 3) + 8 * (r >> 2) + 4 * hs) * ncols + 32 * nb + m] = acc[r];
-}
-// bias and input-layer sums: thread = one row of Gb0 / GW0 / Gb1 / Gb2 (dimension 1) / Gb2 (dimension 0), over the tiles of its split
-__global__ __launch_bounds__(256) void k_ebias(const float* __restrict__ dump, int64_t n_tiles, float* __restrict__ partial) {
-    const int split = blockIdx.x, t = threadIdx.x;
-    int off, row, out;
-    bool w0 = false;
-    if (t < 64) { off = kDY1; row = t; out = kGb0 + t; }
-    else if (t < 128) { off = kDY1; row = t - 64; out = kGW0 + row; w0 = true; }
-    else if (t < 192) { off = kDY2; row = t - 128; out = kGb1 + row; }
-    else if (t < 224) { off = kDY3; row = t - 192; out = kGb21 + row; }
-    else { off = kDY30; row = t - 224; out = kGb20 + row; }
-    float acc = 0.0f;
-    const int64_t t0 = n_tiles * split / kESplit, t1 = n_tiles * (split + 1) / kESplit;
-    for (int64_t ti = t0; ti < t1; ++ti) {
-        const float* d = dump + (size_t)ti * kDumpFloats;
-        const float4_t* y = reinterpret_cast<const float4_t*>(d + off + row * 32);
-        if (!w0) {
+            for (int c = 0; c < NCH; ++c)
 #pragma unroll
-            for (int q = 0; q < 8; ++q) { const float4_t v = y[q]; acc += (v.x + v.y) + (v.z + v.w); }
-        } else {   // d / d W0'[0][u] = sum_w zbar1_0[u][w] s_w + zbar1_1[u][w]   (the seed of the conditioner's input is (s, 1, 0))
-            const float4_t* y1 = reinterpret_cast<const float4_t*>(d + off + 2048 + row * 32);
-            const float4_t* sv = reinterpret_cast<const float4_t*>(d + kDS);
+                for (int st = 0; st < 2; ++st) {
+                    const int col = 16 * st + 8 * hs;
+                    f16x8 xh[2], xl[2], yh, yl;
+                    int ex[2];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const float4_t v = y[q], u = y1[q], s4 = sv[q];
-                acc += (__builtin_fmaf(v.x, s4.x, u.x) + __builtin_fmaf(v.y, s4.y, u.y)) + (__builtin_fmaf(v.z, s4.z, u.z) + __builtin_fmaf(v.w, s4.w, u.w));
+                    for (int b = 0; b < 2; ++b) ex[b] = split_scaled(d + kDX2 + c * 2048 + (32 * b + m) * 32 + col, xh[b], xl[b]);
+                    const float* yp = d + kDY3 + c * 1024 + m * 32 + col;
+                    const int ey = split_scaled(yp, yh, yl);
+                    if (c == 0) {
+                        const float4_t a = *reinterpret_cast<const float4_t*>(yp), bq = *reinterpret_cast<const float4_t*>(yp + 4);
+                        bias[0] += ((a.x + a.y) + (a.z + a.w)) + ((bq.x + bq.y) + (bq.z + bq.w));
+                    }
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb) mfma3_unscaled(acc[mb][0], xh[mb], xl[mb], ex[mb], yh, yl, ey, hs);
+                }
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const float* y0 = d + kDY30 + m * 32 + 16 * st + 8 * hs;
+                const float4_t a = *reinterpret_cast<const float4_t*>(y0), bq = *reinterpret_cast<const float4_t*>(y0 + 4);
+                bias20 += ((a.x + a.y) + (a.z + a.w)) + ((bq.x + bq.y) + (bq.z + bq.w));
             }
         }
     }
-    partial[(size_t)split * kGFloats + out] = acc;
+    // this wave's sums -> LDS (matrix entries in (k, u) order; the per-unit sums of the two K halves are added by the lane pair)
+    float* rw = red[wave];
+    const int ncols = job == 0 ? 64 : 32;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            if (job == 1 && nb == 1) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rw[(32 * mb + (r & 3) + 8 * (r >> 2) + 4 * hs) * ncols + 32 * nb + m] = acc[mb][nb][r];
+        }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const float sb = xhalf_sum(bias[b]), sb0 = xhalf_sum(bias0[b]), sg = xhalf_sum(gw0[b]);
+        if (hs == 0) { rw[4096 + 32 * b + m] = sb; rw[4096 + 64 + 32 * b + m] = sb0; rw[4096 + 128 + 32 * b + m] = sg; }
+    }
+    const float s20 = xhalf_sum(bias20);
+    if (job == 1 && hs == 0) rw[4096 + 64 + m] = s20;     // (job 1: slot of bias0 block 0 carries Gb2 of dimension 0)
+    __syncthreads();
+    float* g = partial + (size_t)split * kGFloats;
+    const int n_mat = job == 0 ? 4096 : 2048;
+    for (int i = threadIdx.x; i < n_mat; i += 256) g[(job == 0 ? kGW1 : kGW2) + i] = ((red[0][i] + red[1][i]) + red[2][i]) + red[3][i];
+    if (threadIdx.x < 64) {
+        const int u = threadIdx.x;
+        auto sum4 = [&](int o) { return ((red[0][o] + red[1][o]) + red[2][o]) + red[3][o]; };
+        if (job == 0) {
+            g[kGb1 + u] = sum4(4096 + u);
+            g[kGb0 + u] = sum4(4096 + 64 + u);
+            g[kGW0 + u] = sum4(4096 + 128 + u);
+        } else if (u < 32) {
+            g[kGb21 + u] = sum4(4096 + u);
+            g[kGb20 + u] = sum4(4096 + 64 + u);
+        }
+    }
 }
 __global__ void k_egrad_reduce(const float* __restrict__ partial, int accumulate, float* __restrict__ gacc) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1494,8 +1562,7 @@ int launch_energy_vjp(const MfmaDev* mdev, const ModelDev& md, const float* tabI
             hipLaunchKernelGGL(k_ebwd<true>, dim3(blocks), dim3(kBwdWaves * 64), lds_bytes, s, *mdev, n, tabI4, tabP4, st_n, adjb, w_psi, w_lap, B, dump);
         else
             hipLaunchKernelGGL(k_ebwd<false>, dim3(blocks), dim3(kBwdWaves * 64), lds_bytes, s, *mdev, n, tabI4, tabP4, st_n, adjb, w_psi, w_lap, B, dump);
-        hipLaunchKernelGGL(k_ewgrad, dim3(kESplit, 6), dim3(64), 0, s, (const float*)dump, n_tiles, partial);
-        hipLaunchKernelGGL(k_ebias, dim3(kESplit), dim3(256), 0, s, (const float*)dump, n_tiles, partial);
+        hipLaunchKernelGGL(k_ewgrad, dim3(kESplit, 2), dim3(256), 0, s, (const float*)dump, n_tiles, partial);
         hipLaunchKernelGGL(k_egrad_reduce, dim3((kGFloats + 255) / 256), dim3(256), 0, s, (const float*)partial, accumulate, gacc + (size_t)n * kGFloats);
     }
     return check();
