@@ -5,7 +5,7 @@ import bench
 from waveflow_amd.utils import physics
 m, flat = bench.he_model("auto")
 protons = physics.system_catalogue[1]["He"][0].reshape(-1)
-x = m.sample(11, 1 << 17, exact=True)
+x = m.sample(11, int(os.environ.get("B", 1 << 17)), exact=True)
 for _ in range(6):
     m.vqmc_loss_grad(x, protons, -1.8)
 torch.cuda.synchronize()

@@ -1272,7 +1272,7 @@ __global__ __launch_bounds__(kBwdWaves * 64) void k_ebwd(const MfmaDev mm, int n
 // ---- weight-gradient products of one net from the tile dumps.  Gradient block of a net (floats, in the units of the MFMA image):
 //   GW0 [64] (d / d W0'[0][u]), Gb0 [64], GW1 [64][64] (k, u), Gb1 [64], GW2 [64][32] (k, row), Gb2 of dimension 1 [32], of dimension 0 [32]
 constexpr int kGW0 = 0, kGb0 = 64, kGW1 = 128, kGb1 = 4224, kGW2 = 4288, kGb21 = 6336, kGb20 = 6368, kGFloats = 6400;
-constexpr int kESplit = 128;   // partial sums along the tile axis (summed in split order: bitwise reproducible)
+constexpr int kESplit = 256;   // partial sums along the tile axis (summed in split order: bitwise reproducible); 2 x 256 workgroups: two per CU (128: 197 us, 256: 135 us, 512: 130 us + a longer reduction, per net and 2^17 walkers)
 // 8 fp32 values of one operand row / column and K half -> fp16 pairs scaled by one power of two per row / column (exact; the adjoints are
 // unbounded).  The scale must be common to the 16 k's of a K step: a lane holds 8 of them, its partner lane (other half) the other 8.
 __device__ __forceinline__ int split_scaled(const float* __restrict__ p, f16x8& hi, f16x8& lo) {
