@@ -791,10 +791,23 @@ __global__ __launch_bounds__(kFusedWaves * 64) void k_efused(const MfmaDev mm, c
 //   k_egrad_reduce, k_egrad_scatter   reduction over the splits; scales and folds back to the flat leaf order
 using JA = adj::Jt<float>;
 using TA = adj::T2t<float>;
-constexpr int kBwdWaves = 8;
-// dump block of one tile (floats): X1 [3][64][32], X2 [3][64][32], Y1 [2][64][32], Y2 [3][64][32], Y3 [3][32][32], Y30 [32][32], S [32]
-constexpr int kDX1 = 0, kDX2 = 6144, kDY1 = 12288, kDY2 = 16384, kDY3 = 22528, kDY30 = 25600, kDS = 26624, kDumpFloats = 26656;
-
+#ifndef WF_BWD_WAVES
+#define WF_BWD_WAVES 4
+#endif
+constexpr int kBwdWaves = WF_BWD_WAVES;
+// dump block of one tile (floats): X2 [3][64][32], Y2 [3][64][32], Y3 [3][32][32], Y30 [32][32], S [32], G [2][64] (the tile's sums for the input
+// layer: Gb0, GW0).  The first hidden layer's activations X1 are a function of S alone and are recomputed by k_ewgrad; the adjoints Y1 of the first
+// layer's pre-activations only enter through G.
+constexpr int kDX2 = 0, kDY2 = 6144, kDY3 = 12288, kDY30 = 15360, kDS = 16384, kDG = 16416, kDumpFloats = 16544;
+__device__ __forceinline__ float half32_sum(float v) {   // sum over the 32 lanes of this lane's half, in every lane of it
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+    const unsigned u = __float_as_uint(v);
+    const auto sw = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+}
 __device__ __forceinline__ JA ja_load(const float* __restrict__ st, int slot, int64_t B, int64_t w) {
     const float* p = st + (int64_t)slot * 4 * B + w;
     return JA{p[0], p[B], p[2 * B], p[3 * B]};
@@ -1022,6 +1035,47 @@ __device__ __forceinline__ void ob_product(const _Float16* obh, f32x16 (&w)[NCH]
     }
 }
 
+// forward of one conditioner from its input (u0, u1) to the second hidden layer's pre-activation triples z2 (two 32-unit blocks); HEAD: on to the head
+// triples o, with the second hidden layer's activations X2 written to the tile's dump
+template <bool HEAD>
+__device__ __forceinline__ void cond_fwd(const float* net, float u0v, float u1v, int lane, f32x16 (&z2a)[NCH], f32x16 (&z2b)[NCH], f32x16 (&o)[NCH], float* __restrict__ dmp) {
+    using O = NetOff<2, 1>;
+    const int j = lane & 31, h = lane >> 5;
+    const float in0[2] = {u0v, 1.0f}, in1[2] = {u1v, 0.0f};
+    f32x16 a0[NCH], a1[NCH];
+    init_acc(a0, net + O::b0 + (0 * 2 + h) * 16);
+    init_acc(a1, net + O::b0 + (1 * 2 + h) * 16);
+    const float w0 = net[O::W0 + 0 * 64 + lane], w1 = net[O::W0 + 1 * 64 + lane];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        a0[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, h ? in1[c] : in0[c], a0[c], 0, 0, 0);
+        a1[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, h ? in1[c] : in0[c], a1[c], 0, 0, 0);
+    }
+    act_block(a0);
+    act_block(a1);
+    Frag f[NCH][2];
+    int e[NCH];
+    to_frags(a0, a1, f, e);
+    const _Float16* W1h = reinterpret_cast<const _Float16*>(net + O::W1h);
+    const _Float16* W1l = reinterpret_cast<const _Float16*>(net + O::W1l);
+    init_acc(z2a, net + O::b1 + (0 + h) * 16);
+    init_acc(z2b, net + O::b1 + (2 + h) * 16);
+    dense64_block<NCH>(W1h, W1l, f, z2a, lane);
+    dense64_block<NCH>(W1h + 2048, W1l + 2048, f, z2b, lane);
+    unscale(z2a, e);
+    unscale(z2b, e);
+    if (HEAD) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) { a0[c] = z2a[c]; a1[c] = z2b[c]; }
+        act_block(a0);
+        act_block(a1);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) { dump_block(dmp + kDX2 + c * 2048, 0, a0[c], j, h); dump_block(dmp + kDX2 + c * 2048, 32, a1[c], j, h); }
+        to_frags(a0, a1, f, e);
+        cond_out<1>(net, f, e, 0, lane, o);
+    }
+}
+
 template <bool PRIOR>
 __global__ __launch_bounds__(kBwdWaves * 64) void k_ebwd(const MfmaDev mm, int net_index, const float* __restrict__ tabI, const float* __restrict__ tabP,
                                                           const float* __restrict__ st_in, float* __restrict__ adjb, const float* __restrict__ w_psi,
@@ -1067,43 +1121,12 @@ __global__ __launch_bounds__(kBwdWaves * 64) void k_ebwd(const MfmaDev mm, int n
         const int64_t wl = valid ? w : B - 1;
         float* dmp = dump + (size_t)tile * kDumpFloats;
         const JA u0 = ja_load(st_in, 0, B, wl), u1 = ja_load(st_in, 1, B, wl);
-        // ---- the net's forward, with what the reverse needs kept: z2 (second hidden layer's pre-activation triples), o (head triples)
-        f32x16 z2a[NCH], z2b[NCH], o[NCH];
+        // ---- the net's forward to the head triples o (the second hidden layer's activations go to the dump on the way).  The second hidden layer's
+        // pre-activations z2, which the reverse needs, are computed again behind the head: 96 registers less across the head algebra
+        f32x16 o[NCH];
         {
-            using O = NetOff<2, 1>;
-            const float in0[2] = {u0.v, 1.0f}, in1[2] = {u1.v, 0.0f};
-            f32x16 a0[NCH], a1[NCH];
-            init_acc(a0, net + O::b0 + (0 * 2 + h) * 16);
-            init_acc(a1, net + O::b0 + (1 * 2 + h) * 16);
-            const float w0 = net[O::W0 + 0 * 64 + lane], w1 = net[O::W0 + 1 * 64 + lane];
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                a0[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, h ? in1[c] : in0[c], a0[c], 0, 0, 0);
-                a1[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, h ? in1[c] : in0[c], a1[c], 0, 0, 0);
-            }
-            act_block(a0);
-            act_block(a1);
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) { dump_block(dmp + kDX1 + c * 2048, 0, a0[c], j, h); dump_block(dmp + kDX1 + c * 2048, 32, a1[c], j, h); }
-            Frag f[NCH][2];
-            int e[NCH];
-            to_frags(a0, a1, f, e);
-            const _Float16* W1h = reinterpret_cast<const _Float16*>(net + O::W1h);
-            const _Float16* W1l = reinterpret_cast<const _Float16*>(net + O::W1l);
-            init_acc(z2a, net + O::b1 + (0 + h) * 16);
-            init_acc(z2b, net + O::b1 + (2 + h) * 16);
-            dense64_block<NCH>(W1h, W1l, f, z2a, lane);
-            dense64_block<NCH>(W1h + 2048, W1l + 2048, f, z2b, lane);
-            unscale(z2a, e);
-            unscale(z2b, e);
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) { a0[c] = z2a[c]; a1[c] = z2b[c]; }
-            act_block(a0);
-            act_block(a1);
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) { dump_block(dmp + kDX2 + c * 2048, 0, a0[c], j, h); dump_block(dmp + kDX2 + c * 2048, 32, a1[c], j, h); }
-            to_frags(a0, a1, f, e);
-            cond_out<1>(net, f, e, 0, lane, o);
+            f32x16 z2a[NCH], z2b[NCH];
+            cond_fwd<true>(net, u0.v, u1.v, lane, z2a, z2b, o, dmp);
         }
         if (h == 0) dmp[kDS + j] = u0.v;
         // ---- head: forward sums, pullback to adjoint head triples ob (dimension 1) and ob0 (dimension 0, channel 0)
@@ -1211,6 +1234,12 @@ __global__ __launch_bounds__(kBwdWaves * 64) void k_ebwd(const MfmaDev mm, int n
         for (int c = 0; c < NCH; ++c) dump_block(dmp + kDY3 + c * 1024, 0, ob[c], j, h);
         dump_block(dmp + kDY30, 0, ob0, j, h);
         // ---- conditioner, reverse: hbar2 = W2' obar, zbar2 = act'(z2) hbar2, hbar1 = W1' zbar2, zbar1 = act'(z1) hbar1
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 z2a[NCH], z2b[NCH];
+        {
+            f32x16 o2[NCH];
+            cond_fwd<false>(net, u0.v, u1.v, lane, z2a, z2b, o2, dmp);
+        }
         f32x16 g0[NCH], g1[NCH];
         {
             Frag f[NCH][2];
@@ -1252,8 +1281,22 @@ __global__ __launch_bounds__(kBwdWaves * 64) void k_ebwd(const MfmaDev mm, int n
             act_block_bwd(a0, g0);
             act_block_bwd(a1, g1);
         }
+        // input layer: Gb0[u] = sum_w zbar1_0[u][w], GW0[u] = sum_w zbar1_0[u][w] s_w + zbar1_1[u][w] (seed of the conditioner's input: (s, 1, 0)), summed
+        // over the tile's walkers here (the lanes of a half); lane (j, h) keeps the sums of register j & 15 of block j >> 4
+        {
+            float sb = 0.0f, sw = 0.0f;
 #pragma unroll
-        for (int c = 0; c < 2; ++c) { dump_block(dmp + kDY1 + c * 2048, 0, g0[c], j, h); dump_block(dmp + kDY1 + c * 2048, 32, g1[c], j, h); }
+            for (int r = 0; r < 16; ++r) {
+                const float a0 = half32_sum(g0[0][r]), a1 = half32_sum(g1[0][r]);
+                const float b0 = half32_sum(__builtin_fmaf(g0[0][r], u0.v, g0[1][r])), b1 = half32_sum(__builtin_fmaf(g1[0][r], u0.v, g1[1][r]));
+                const bool mine = (j & 15) == r;
+                sb = mine ? (j < 16 ? a0 : a1) : sb;
+                sw = mine ? (j < 16 ? b0 : b1) : sw;
+            }
+            const int u = 32 * (j >> 4) + (j & 3) + 8 * ((j & 15) >> 2) + 4 * h;
+            dmp[kDG + u] = sb;
+            dmp[kDG + 64 + u] = sw;
+        }
         {
             const f32x16 wa = load16(TW0 + (0 * 2 + h) * 16), wb2 = load16(TW0 + (1 * 2 + h) * 16);
             float sbar = 0.0f;
@@ -1273,146 +1316,208 @@ __global__ __launch_bounds__(kBwdWaves * 64) void k_ebwd(const MfmaDev mm, int n
 //   GW0 [64] (d / d W0'[0][u]), Gb0 [64], GW1 [64][64] (k, u), Gb1 [64], GW2 [64][32] (k, row), Gb2 of dimension 1 [32], of dimension 0 [32]
 constexpr int kGW0 = 0, kGb0 = 64, kGW1 = 128, kGb1 = 4224, kGW2 = 4288, kGb21 = 6336, kGb20 = 6368, kGFloats = 6400;
 constexpr int kESplit = 256;   // partial sums along the tile axis (summed in split order: bitwise reproducible); 2 x 256 workgroups: two per CU (128: 197 us, 256: 135 us, 512: 130 us + a longer reduction, per net and 2^17 walkers)
-// 8 fp32 values of one operand row / column and K half -> fp16 pairs scaled by one power of two per row / column (exact; the adjoints are
-// unbounded).  The scale must be common to the 16 k's of a K step: a lane holds 8 of them, its partner lane (other half) the other 8.
-__device__ __forceinline__ int split_scaled(const float* __restrict__ p, f16x8& hi, f16x8& lo) {
-    const float4_t a = *reinterpret_cast<const float4_t*>(p), b = *reinterpret_cast<const float4_t*>(p + 4);
-    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-    float mx = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) mx = fmaxf(mx, fabsf(v[i]));
-    mx = xhalf_max(mx);
-    const int ex = mx > 0.0f ? __builtin_amdgcn_frexp_expf(mx) : 0;
-    const float sc = __builtin_amdgcn_ldexpf(1.0f, -ex);
-    float vs[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) vs[i] = v[i] * sc;
-    split8(vs, hi, lo);
-    return ex;
+// The four waves of a workgroup work on one tile at a time.  The tile's operand blocks come from HBM as one coalesced stream (every thread 16-byte
+// pieces, a tile ahead, in registers while the current tile is being multiplied) and are laid into LDS with a padded row (36 floats: the operand
+// reads below are 32-byte pieces of rows 144 bytes apart); each wave owns one block of the product, so nothing is reduced across waves but the
+// K halves of job 1.  Operands are scaled by one power of two per (operand, channel) and wave before the fp16 split (exact; the adjoints are unbounded).
+constexpr int kEwStride = 36;
+__device__ __forceinline__ float wave_max(float v) {   // v >= 0
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true)));
+    const unsigned u = __float_as_uint(v);
+    const auto sw = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return xhalf_max(fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])));
 }
-// acc += 2^(ex_row + ey_col) * (three split products): the row exponent of register r's row (acc_row(r, h)) lives in lane `row`
-__device__ __forceinline__ void mfma3_unscaled(f32x16& acc, const f16x8& xh, const f16x8& xl, int ex, const f16x8& yh, const f16x8& yl, int ey, int hs) {
-    f32x16 p = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+__device__ __forceinline__ int exponent_of(float amax) { return amax > 0.0f ? __builtin_amdgcn_frexp_expf(amax) : 0; }
+__device__ __forceinline__ float amax8(const float (&v)[8]) {
+    return fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))), fmaxf(fmaxf(fabsf(v[4]), fabsf(v[5])), fmaxf(fabsf(v[6]), fabsf(v[7]))));
+}
+__device__ __forceinline__ void split_times(const float (&v)[8], float sc, f16x8& hi, f16x8& lo) {
+    const float vs[8] = {v[0] * sc, v[1] * sc, v[2] * sc, v[3] * sc, v[4] * sc, v[5] * sc, v[6] * sc, v[7] * sc};
+    split8(vs, hi, lo);
+}
+__device__ __forceinline__ void mfma3(f32x16& p, const f16x8& xh, const f16x8& xl, const f16x8& yh, const f16x8& yl) {
     p = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, yh, p, 0, 0, 0);
     p = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, yl, p, 0, 0, 0);
     p = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, yh, p, 0, 0, 0);
+}
+__device__ __forceinline__ void lds_row8(const float* __restrict__ p, float (&v)[8]) {
+    const float4_t a = *reinterpret_cast<const float4_t*>(p), b = *reinterpret_cast<const float4_t*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+// NQ 16-byte pieces per thread of a contiguous run of rows (32 floats each) starting at float offset `first`
+template <int NQ>
+__device__ __forceinline__ void ew_fetch(const float* __restrict__ d, int first, float4_t (&q)[NQ]) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * hs;
-        acc[r] = __builtin_fmaf(p[r], __builtin_amdgcn_ldexpf(1.0f, __shfl(ex, row) + ey), acc[r]);
+    for (int k = 0; k < NQ; ++k) q[k] = *reinterpret_cast<const float4_t*>(d + first + 4 * (k * 256 + (int)threadIdx.x));
+}
+template <int NQ>
+__device__ __forceinline__ void ew_stage(float* __restrict__ img, int row0, const float4_t (&q)[NQ]) {
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+        const int idx4 = k * 256 + (int)threadIdx.x;
+        *reinterpret_cast<float4_t*>(img + (row0 + (idx4 >> 3)) * kEwStride + 4 * (idx4 & 7)) = q[k];
     }
 }
-// Workgroup = 4 waves on one (split, job); job 0: dW1 (64 x 64: four blocks) with Gb1, Gb0 and GW0; job 1: dW2 (64 x 32: two blocks) with both Gb2.
-// A wave takes every fourth tile of the split; every operand row is read once per tile and net; the four waves' sums meet in LDS in wave order.
-__global__ __launch_bounds__(256, 2) void k_ewgrad(const float* __restrict__ dump, int64_t n_tiles, float* __restrict__ partial) {
-    __shared__ float red[4][64 * 64 + 3 * 64];
-    const int job = blockIdx.y, split = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int m = lane & 31, hs = lane >> 5;
-    const f32x16 z16 = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    f32x16 acc[2][2] = {{z16, z16}, {z16, z16}};
-    float bias[2] = {0.0f, 0.0f}, bias0[2] = {0.0f, 0.0f}, gw0[2] = {0.0f, 0.0f}, bias20 = 0.0f;
-    const int64_t t0 = n_tiles * split / kESplit, t1 = n_tiles * (split + 1) / kESplit;
-    for (int64_t t = t0 + wave; t < t1; t += 4) {
+
+// job 0: dW1 (64 x 64; wave w: rows 32 (w >> 1).., columns 32 (w & 1)..) = X1 (x) Y2 with Gb1; Gb0 and GW0 are the tile sums k_ebwd left in the dump.
+// X1, the first hidden layer's activation triples, is recomputed from s (as k_ebwd: z = b0 + W0 s, z' = W0, z'' = 0); its scale per channel is a bound
+// from the block's largest |W0| (r < 1, |r'| <= ln2 / 4, |r''| <= 0.0463).
+__device__ __forceinline__ void ewgrad_job0(float* __restrict__ img, const float* __restrict__ dump, int64_t t0, int64_t t1, const float* __restrict__ net_img,
+                                            float* __restrict__ g) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 31, hs = lane >> 5, mb = wave >> 1, nb = wave & 1;
+    const float w0u = net_img[NetOff<2, 1>::W0 + mb * 64 + m];
+    // (b0 sits in accumulator layout: register (m & 3) + 4 (m >> 3) of half (m >> 2) & 1)
+    const float b0u = net_img[NetOff<2, 1>::b0 + (mb * 2 + ((m >> 2) & 1)) * 16 + (m & 3) + 4 * (m >> 3)];
+    const float wmax = wave_max(fabsf(w0u));
+    const int exc[NCH] = {0, exponent_of(0.1732868f * wmax), exponent_of(0.0462982f * wmax * wmax)};
+    f32x16 acc = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    float bias = 0.0f, gsum = 0.0f;
+    float4_t q[6], qs;
+    float gq = 0.0f;
+    auto fetch = [&](int64_t t) {
         const float* d = dump + (size_t)t * kDumpFloats;
-        if (job == 0) {
+        ew_fetch<6>(d, kDY2, q);
+        if (threadIdx.x < 8) qs = *reinterpret_cast<const float4_t*>(d + kDS + 4 * threadIdx.x);
+        if (mb == 1) gq = d[kDG + 64 * hs + 32 * nb + m];     // half 0: Gb0, half 1: GW0 of unit 32 nb + m
+    };
+    if (t0 < t1) fetch(t0);
+    for (int64_t t = t0; t < t1; ++t) {
+        __syncthreads();
+        ew_stage<6>(img, 0, q);
+        if (threadIdx.x < 8) *reinterpret_cast<float4_t*>(img + 192 * kEwStride + 4 * threadIdx.x) = qs;
+        gsum += gq;
+        __syncthreads();
+        if (t + 1 < t1) fetch(t + 1);
+        // this wave's Y rows (unit 32 nb + m, its K half), all channels and K steps
+        float yv[NCH][2][8];
+        int ey[NCH];
 #pragma unroll
-            for (int c = 0; c < NCH; ++c)
-#pragma unroll
-                for (int st = 0; st < 2; ++st) {
-                    const int col = 16 * st + 8 * hs;
-                    f16x8 xh[2], xl[2], yh[2], yl[2];
-                    int ex[2], ey[2];
-#pragma unroll
-                    for (int b = 0; b < 2; ++b) {
-                        ex[b] = split_scaled(d + kDX1 + c * 2048 + (32 * b + m) * 32 + col, xh[b], xl[b]);
-                        const float* yp = d + kDY2 + c * 2048 + (32 * b + m) * 32 + col;
-                        ey[b] = split_scaled(yp, yh[b], yl[b]);
-                        if (c == 0) {   // Gb1[u] = sum_w zbar2_0[u][w]
-                            const float4_t a = *reinterpret_cast<const float4_t*>(yp), bq = *reinterpret_cast<const float4_t*>(yp + 4);
-                            bias[b] += ((a.x + a.y) + (a.z + a.w)) + ((bq.x + bq.y) + (bq.z + bq.w));
-                        }
-                    }
-#pragma unroll
-                    for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-                        for (int nb = 0; nb < 2; ++nb) mfma3_unscaled(acc[mb][nb], xh[mb], xl[mb], ex[mb], yh[nb], yl[nb], ey[nb], hs);
-                }
-            // input layer: Gb0[u] = sum_w zbar1_0[u][w], GW0[u] = sum_w zbar1_0[u][w] s_w + zbar1_1[u][w]   (seed of the conditioner's input: (s, 1, 0))
+        for (int c = 0; c < NCH; ++c) {
+            float am = 0.0f;
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
-                const int col = 16 * st + 8 * hs;
-                const float4_t s0 = *reinterpret_cast<const float4_t*>(d + kDS + col), s1 = *reinterpret_cast<const float4_t*>(d + kDS + col + 4);
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const float* y0 = d + kDY1 + (32 * b + m) * 32 + col;
-                    const float4_t a = *reinterpret_cast<const float4_t*>(y0), bq = *reinterpret_cast<const float4_t*>(y0 + 4);
-                    const float4_t c4 = *reinterpret_cast<const float4_t*>(y0 + 2048), d4 = *reinterpret_cast<const float4_t*>(y0 + 2052);
-                    bias0[b] += ((a.x + a.y) + (a.z + a.w)) + ((bq.x + bq.y) + (bq.z + bq.w));
-                    gw0[b] += (__builtin_fmaf(a.x, s0.x, c4.x) + __builtin_fmaf(a.y, s0.y, c4.y)) + (__builtin_fmaf(a.z, s0.z, c4.z) + __builtin_fmaf(a.w, s0.w, c4.w)) +
-                              (__builtin_fmaf(bq.x, s1.x, d4.x) + __builtin_fmaf(bq.y, s1.y, d4.y)) + (__builtin_fmaf(bq.z, s1.z, d4.z) + __builtin_fmaf(bq.w, s1.w, d4.w));
-                }
+                lds_row8(img + (c * 64 + 32 * nb + m) * kEwStride + 16 * st + 8 * hs, yv[c][st]);
+                am = fmaxf(am, amax8(yv[c][st]));
             }
-        } else {
+            ey[c] = exponent_of(wave_max(am));
+        }
+        if (mb == 0) {   // Gb1[u] = sum_w zbar2_0[u][w]
 #pragma unroll
-            for (int c = 0; c < NCH; ++c)
+            for (int st = 0; st < 2; ++st) bias += ((yv[0][st][0] + yv[0][st][1]) + (yv[0][st][2] + yv[0][st][3])) + ((yv[0][st][4] + yv[0][st][5]) + (yv[0][st][6] + yv[0][st][7]));
+        }
+        f16x8 xh[NCH][2], xl[NCH][2];
 #pragma unroll
-                for (int st = 0; st < 2; ++st) {
-                    const int col = 16 * st + 8 * hs;
-                    f16x8 xh[2], xl[2], yh, yl;
-                    int ex[2];
+        for (int st = 0; st < 2; ++st) {
+            float sv[8], v0[8], v1[8], v2[8];
+            lds_row8(img + 192 * kEwStride + 16 * st + 8 * hs, sv);
 #pragma unroll
-                    for (int b = 0; b < 2; ++b) ex[b] = split_scaled(d + kDX2 + c * 2048 + (32 * b + m) * 32 + col, xh[b], xl[b]);
-                    const float* yp = d + kDY3 + c * 1024 + m * 32 + col;
-                    const int ey = split_scaled(yp, yh, yl);
-                    if (c == 0) {
-                        const float4_t a = *reinterpret_cast<const float4_t*>(yp), bq = *reinterpret_cast<const float4_t*>(yp + 4);
-                        bias[0] += ((a.x + a.y) + (a.z + a.w)) + ((bq.x + bq.y) + (bq.z + bq.w));
-                    }
+            for (int i = 0; i < 8; ++i) {
+                const float z = __builtin_fmaf(w0u, sv[i], b0u);
+                const float rr = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(z) + 1.0f);
+                const float r1 = -0.6931471805599453f * __builtin_fmaf(-rr, rr, rr);
+                const float k = __builtin_fmaf(1.3862943611198906f, rr, -0.6931471805599453f);
+                v0[i] = rr;
+                v1[i] = r1 * w0u;
+                v2[i] = r1 * ((k * w0u) * w0u);
+            }
+            split_times(v0, 1.0f, xh[0][st], xl[0][st]);
+            split_times(v1, __builtin_amdgcn_ldexpf(1.0f, -exc[1]), xh[1][st], xl[1][st]);
+            split_times(v2, __builtin_amdgcn_ldexpf(1.0f, -exc[2]), xh[2][st], xl[2][st]);
+        }
 #pragma unroll
-                    for (int mb = 0; mb < 2; ++mb) mfma3_unscaled(acc[mb][0], xh[mb], xl[mb], ex[mb], yh, yl, ey, hs);
-                }
+        for (int c = 0; c < NCH; ++c) {
+            f32x16 p = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            const float sy = __builtin_amdgcn_ldexpf(1.0f, -ey[c]), un = __builtin_amdgcn_ldexpf(1.0f, exc[c] + ey[c]);
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
-                const float* y0 = d + kDY30 + m * 32 + 16 * st + 8 * hs;
-                const float4_t a = *reinterpret_cast<const float4_t*>(y0), bq = *reinterpret_cast<const float4_t*>(y0 + 4);
-                bias20 += ((a.x + a.y) + (a.z + a.w)) + ((bq.x + bq.y) + (bq.z + bq.w));
+                f16x8 yh, yl;
+                split_times(yv[c][st], sy, yh, yl);
+                mfma3(p, xh[c][st], xl[c][st], yh, yl);
             }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = __builtin_fmaf(p[r], un, acc[r]);
         }
     }
-    // this wave's sums -> LDS (matrix entries in (k, u) order; the per-unit sums of the two K halves are added by the lane pair)
-    float* rw = red[wave];
-    const int ncols = job == 0 ? 64 : 32;
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-            if (job == 1 && nb == 1) continue;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) rw[(32 * mb + (r & 3) + 8 * (r >> 2) + 4 * hs) * ncols + 32 * nb + m] = acc[mb][nb][r];
-        }
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const float sb = xhalf_sum(bias[b]), sb0 = xhalf_sum(bias0[b]), sg = xhalf_sum(gw0[b]);
-        if (hs == 0) { rw[4096 + 32 * b + m] = sb; rw[4096 + 64 + 32 * b + m] = sb0; rw[4096 + 128 + 32 * b + m] = sg; }
+    for (int r = 0; r < 16; ++r) g[kGW1 + (32 * mb + (r & 3) + 8 * (r >> 2) + 4 * hs) * 64 + 32 * nb + m] = acc[r];
+    if (mb == 0) {
+        const float sb = xhalf_sum(bias);
+        if (hs == 0) g[kGb1 + 32 * nb + m] = sb;
+    } else {
+        g[(hs ? kGW0 : kGb0) + 32 * nb + m] = gsum;
     }
-    const float s20 = xhalf_sum(bias20);
-    if (job == 1 && hs == 0) rw[4096 + 64 + m] = s20;     // (job 1: slot of bias0 block 0 carries Gb2 of dimension 0)
+}
+
+// job 1: dW2 (64 x 32; wave w: rows 32 (w & 1).., K step w >> 1, the two K steps of a block meet in LDS at the end) = X2 (x) Y3 with both Gb2
+__device__ __forceinline__ void ewgrad_job1(float* __restrict__ img, const float* __restrict__ dump, int64_t t0, int64_t t1, float* __restrict__ g) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 31, hs = lane >> 5, mb = wave & 1, st = wave >> 1;
+    f32x16 acc = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    float bias = 0.0f;      // mb 0: Gb2 of dimension 1, mb 1: of dimension 0 (this wave's K step)
+    float4_t qx[6], qy[3], q0[1];
+    auto fetch = [&](int64_t t) {
+        const float* d = dump + (size_t)t * kDumpFloats;
+        ew_fetch<6>(d, kDX2, qx);
+        ew_fetch<3>(d, kDY3, qy);
+        ew_fetch<1>(d, kDY30, q0);
+    };
+    if (t0 < t1) fetch(t0);
+    for (int64_t t = t0; t < t1; ++t) {
+        __syncthreads();
+        ew_stage<6>(img, 0, qx);        // rows   0 .. 191: X2 [c][64]
+        ew_stage<3>(img, 192, qy);      // rows 192 .. 287: Y3 [c][32]
+        ew_stage<1>(img, 288, q0);      // rows 288 .. 319: Y30
+        __syncthreads();
+        if (t + 1 < t1) fetch(t + 1);
+        const int col = 16 * st + 8 * hs;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            float xv[8], yv[8];
+            lds_row8(img + (c * 64 + 32 * mb + m) * kEwStride + col, xv);
+            lds_row8(img + (192 + c * 32 + m) * kEwStride + col, yv);
+            const int ex = exponent_of(wave_max(amax8(xv))), ey = exponent_of(wave_max(amax8(yv)));
+            if (c == 0 && mb == 0) bias += ((yv[0] + yv[1]) + (yv[2] + yv[3])) + ((yv[4] + yv[5]) + (yv[6] + yv[7]));
+            f16x8 xh, xl, yh, yl;
+            split_times(xv, __builtin_amdgcn_ldexpf(1.0f, -ex), xh, xl);
+            split_times(yv, __builtin_amdgcn_ldexpf(1.0f, -ey), yh, yl);
+            f32x16 p = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            mfma3(p, xh, xl, yh, yl);
+            const float un = __builtin_amdgcn_ldexpf(1.0f, ex + ey);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = __builtin_fmaf(p[r], un, acc[r]);
+        }
+        if (mb == 1) {
+            float y0[8];
+            lds_row8(img + (288 + m) * kEwStride + col, y0);
+            bias += ((y0[0] + y0[1]) + (y0[2] + y0[3])) + ((y0[4] + y0[5]) + (y0[6] + y0[7]));
+        }
+    }
+    // K step 1 -> LDS, K step 0 adds it and writes
     __syncthreads();
-    float* g = partial + (size_t)split * kGFloats;
-    const int n_mat = job == 0 ? 4096 : 2048;
-    for (int i = threadIdx.x; i < n_mat; i += 256) g[(job == 0 ? kGW1 : kGW2) + i] = ((red[0][i] + red[1][i]) + red[2][i]) + red[3][i];
-    if (threadIdx.x < 64) {
-        const int u = threadIdx.x;
-        auto sum4 = [&](int o) { return ((red[0][o] + red[1][o]) + red[2][o]) + red[3][o]; };
-        if (job == 0) {
-            g[kGb1 + u] = sum4(4096 + u);
-            g[kGb0 + u] = sum4(4096 + 64 + u);
-            g[kGW0 + u] = sum4(4096 + 128 + u);
-        } else if (u < 32) {
-            g[kGb21 + u] = sum4(4096 + u);
-            g[kGb20 + u] = sum4(4096 + 64 + u);
-        }
+    const float sb = xhalf_sum(bias);
+    float* mine = img + mb * (16 * 64 + 32);
+    if (st == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mine[r * 64 + lane] = acc[r];
+        if (hs == 0) mine[16 * 64 + m] = sb;
     }
+    __syncthreads();
+    if (st == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[kGW2 + (32 * mb + (r & 3) + 8 * (r >> 2) + 4 * hs) * 32 + m] = acc[r] + mine[r * 64 + lane];
+        if (hs == 0) g[(mb ? kGb20 : kGb21) + m] = sb + mine[16 * 64 + m];
+    }
+}
+constexpr int kEwLdsFloats = 320 * kEwStride;
+__global__ __launch_bounds__(256, 2) void k_ewgrad(const float* __restrict__ dump, int64_t n_tiles, const float* __restrict__ net_img, float* __restrict__ partial) {
+    __shared__ __attribute__((aligned(16))) float img[kEwLdsFloats];
+    const int split = blockIdx.x;
+    const int64_t t0 = n_tiles * split / kESplit, t1 = n_tiles * (split + 1) / kESplit;
+    float* g = partial + (size_t)split * kGFloats;
+    if (blockIdx.y == 0) ewgrad_job0(img, dump, t0, t1, net_img, g);
+    else ewgrad_job1(img, dump, t0, t1, g);
 }
 __global__ void k_egrad_reduce(const float* __restrict__ partial, int accumulate, float* __restrict__ gacc) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1562,7 +1667,7 @@ int launch_energy_vjp(const MfmaDev* mdev, const ModelDev& md, const float* tabI
             hipLaunchKernelGGL(k_ebwd<true>, dim3(blocks), dim3(kBwdWaves * 64), lds_bytes, s, *mdev, n, tabI4, tabP4, st_n, adjb, w_psi, w_lap, B, dump);
         else
             hipLaunchKernelGGL(k_ebwd<false>, dim3(blocks), dim3(kBwdWaves * 64), lds_bytes, s, *mdev, n, tabI4, tabP4, st_n, adjb, w_psi, w_lap, B, dump);
-        hipLaunchKernelGGL(k_ewgrad, dim3(kESplit, 2), dim3(256), 0, s, (const float*)dump, n_tiles, partial);
+        hipLaunchKernelGGL(k_ewgrad, dim3(kESplit, 2), dim3(256), 0, s, (const float*)dump, n_tiles, mdev->image + (size_t)n * mdev->net_floats, partial);
         hipLaunchKernelGGL(k_egrad_reduce, dim3((kGFloats + 255) / 256), dim3(256), 0, s, (const float*)partial, accumulate, gacc + (size_t)n * kGFloats);
     }
     return check();
