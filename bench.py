@@ -38,6 +38,12 @@ PMC_TRAFFIC = {"bytes": (10706 + 4096) * 1024, "source": "profiles/r03_pmc_summa
 # (+ the 32x32 change of basis of the prior, forward and transposed, for 2 dimensions), FMA = 2 FLOP
 VQMC_BWD_FLOP_PER_WALKER = 2 * (4 * 2 * 64 * 64 * 4 + 2 * 2 * 32 * 32 * 4)
 VQMC_BWD_SHARE = 0.54   # of the loss + gradient time (profiles/r01h_loss_grad_kernel_stats.csv)
+# Batches >= 16 384 walkers of the two-particle family take the matrix-core gradient path.  Its dominant kernel is the per-net reverse
+# kernel k_ebwd<false> (three launches per call): 288 v_mfma_f32_32x32x16_f16 + 12 v_mfma_f32_32x32x2_f32 per 32-walker tile (disassembly of the
+# linked library), 46 % of the call (profiles/r03_grad_tile_kernel_stats.csv: 3 x 163.6 us of 1 064 us)
+GRAD_TILE_MFMA_FLOP_PER_WALKER_NET = (288 * 32768 + 12 * 4096) / 32
+GRAD_TILE_BWD_SHARE = 0.46
+GRAD_TILE_MIN = 16384
 
 
 def he_model(kernel):
@@ -87,7 +93,9 @@ def kernel_ms(model, x, n=50, warm=150):
 
 
 HPSI_KERNELS = "k_efused (one launch: box + 3 x (conditioner Taylor channels on the matrix cores + head) + prior + H psi)"
-GRAD_KERNELS = "k_wave_fwd<2,RF<2>> + k_energy_out + k_vqmc_seeds + k_wave_bwd<2,RF<2>> + k_wgrad<4> + k_wgrad_reduce + k_grad_gather"
+GRAD_KERNELS = ("k_efused<1> (forward, per-net input jets kept) + k_vqmc_seeds + 4 x (k_ebwd<PRIOR> reverse of one net on the matrix cores + k_ewgrad "
+                "weight-gradient products + k_egrad_reduce) + k_egrad_scatter")
+GRAD_KERNELS_WAVE = "k_wave_fwd<2,RF<2>> + k_energy_out + k_vqmc_seeds + k_wave_bwd<2,RF<2>> + k_wgrad<4> + k_wgrad_reduce + k_grad_gather"
 
 
 def event_ms(fn, n, warm):
@@ -538,6 +546,22 @@ def main_vqmc(args):
     t0 = time.perf_counter()
     tr.start_training(verbose=False)
     t_train = (time.perf_counter() - t0) / 4000
+    tile = B >= int(os.environ.get("WF_GRAD_TILE_MIN", GRAD_TILE_MIN)) > 0
+    if tile:
+        k_ms = GRAD_TILE_BWD_SHARE * step_ms / 3
+        ach = B * GRAD_TILE_MFMA_FLOP_PER_WALKER_NET / (k_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_F16_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F16_MATRIX_TFLOPS, "traffic": None,
+                "kernel": "k_ebwd<false>", "kernel_ms": k_ms,
+                "note": "executed matrix FLOP of one reverse launch (split-fp16 products, three Taylor channels) / its share of the call (46 %, three "
+                        "launches; profiles/r03_grad_tile_kernel_stats.csv); the kernel runs one wave per SIMD and is bound by vector issue and "
+                        "memory waits, not by the matrix pipe (profiles/r03_grad_tile_pmc.txt)"}
+    else:
+        ach = B * VQMC_BWD_FLOP_PER_WALKER / (VQMC_BWD_SHARE * step_ms * 1e-3) / 1e12
+        roof = {"bound": "valu", "achieved": ach, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MATRIX_TFLOPS, "traffic": None,
+                "kernel": "k_wave_bwd<2, RF<2>>", "kernel_ms": VQMC_BWD_SHARE * step_ms,
+                "note": "the sweeps are fp32 vector (VALU) work, which this contract's bound enum does not name: achieved = algorithmic "
+                        "FMA FLOP of the reverse sweep (one 4-channel sample per walker) / its share of the step (54 %, profiles/r01h_*); "
+                        "peak = the fp32 vector peak"}
     out = {
         "metric": "VQMC loss+gradient walkers/sec", "value": B / t_grad, "unit": "walkers/s", "n_gpus": 1, "steps": n, "warmup": 3,
         "ms_per_step": t_grad * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -547,12 +571,8 @@ def main_vqmc(args):
         "hpsi_2pow20": {"walkers_per_s": (1 << 20) / t_h20, "ms": t_h20 * 1e3, "kernels": HPSI_KERNELS,
                         "wave_kernel_walkers_per_s": (1 << 20) / t_h20_wave},
         "train_steps_per_s_batch128": 1.0 / t_train, "train_ms_per_step_batch128": t_train * 1e3,
-        "roofline": {"bound": "valu", "achieved": B * VQMC_BWD_FLOP_PER_WALKER / (VQMC_BWD_SHARE * step_ms * 1e-3) / 1e12, "peak": PEAK_F32_MATRIX_TFLOPS,
-                     "unit": "TFLOP/s", "frac": B * VQMC_BWD_FLOP_PER_WALKER / (VQMC_BWD_SHARE * step_ms * 1e-3) / 1e12 / PEAK_F32_MATRIX_TFLOPS,
-                     "traffic": None, "kernel": "k_wave_bwd<2, RF<2>>", "kernel_ms": VQMC_BWD_SHARE * step_ms,
-                     "note": "the sweeps are fp32 vector (VALU) work, which this contract's bound enum does not name: achieved = algorithmic "
-                             "FMA FLOP of the reverse sweep (one 4-channel sample per walker) / its share of the step (54 %, profiles/r01h_*); "
-                             "peak = the fp32 vector peak"},
+        "roofline": roof,
+        "kernels": GRAD_KERNELS if tile else GRAD_KERNELS_WAVE,
     }
     if not args.no_cpu_baseline:
         from oracle import energy_torch as et

@@ -783,11 +783,13 @@ __global__ __launch_bounds__(kFusedWaves * 64) void k_efused(const MfmaDev mm, c
 //   k_ebwd<PRIOR>       one launch per net, last net first: recomputes the net's forward from its input jets, pulls the adjoint of its output
 //                       jets back through the head algebra (wf_etile_adjoint.h) to adjoint head triples, through the conditioner with TRANSPOSED
 //                       operand images on the matrix cores (three channels, like the forward), writes the adjoint of the net's input jets for the
-//                       next launch and DUMPS, per 32-walker tile, the operands of the weight-gradient products: activations X1, X2 and adjoints
-//                       Y1, Y2, Y3 as [channel][unit][32 walkers] blocks (coalesced: a register of the accumulator layout is two 128-byte rows)
+//                       next launch and DUMPS, per 32-walker tile, the operands of the weight-gradient products that cannot be had cheaper: the second
+//                       hidden layer's activations X2 and the adjoints Y2, Y3 as [channel][unit][32 walkers] blocks (coalesced: a register of the
+//                       accumulator layout is two 128-byte rows), s, and the input layer's sums over the tile's walkers.
+//                       One wave per SIMD (512 registers): at two, 213 spilled registers kept 68 % of the wave cycles waiting on memory counters
 //   k_ewgrad            dW[k][u] = sum_walkers sum_channels X_c[k][w] Y_c[u][w]: the walker axis is the K of this product and the dumps hold it
-//                       contiguous, so both MFMA operands are plain 32-byte reads; split-fp16 products, per-split partial sums (fixed order)
-//                       (bias and input-layer sums ride along: the same reads)
+//                       contiguous; a workgroup's four waves share a tile (blocks streamed a tile ahead into LDS), each owns one block of the
+//                       product; the first hidden layer's activations X1 are recomputed from s; split-fp16 products, per-split partial sums (fixed order)
 //   k_egrad_reduce, k_egrad_scatter   reduction over the splits; scales and folds back to the flat leaf order
 using JA = adj::Jt<float>;
 using TA = adj::T2t<float>;
