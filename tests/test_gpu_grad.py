@@ -114,6 +114,72 @@ def test_gradients_on_the_matrix_cores_vs_oracle_and_wave_sweeps(golden, he_flat
     assert rel_l2(gt.cpu().numpy(), gw.cpu().numpy()) < 2e-3, rel_l2(gt.cpu().numpy(), gw.cpu().numpy())
 
 
+def _leaves(tree):
+    if isinstance(tree, (tuple, list)):
+        return [a for t in tree for a in _leaves(t)]
+    return [np.asarray(tree)]
+
+
+@pytest.mark.gpu
+def test_gradient_tile_path_other_models(monkeypatch):
+    """The matrix-core gradient path on models the He checkpoint does not exercise (derivative boundary constraints, one and two layers, other
+    boxes, degrees and knot counts), forced on 4 097 walkers against the reverse wave sweeps -- overall and LEAF BY LEAF (a wrong small leaf
+    would hide behind the large ones); models outside its family (two row blocks per dimension, a non-zero boundary value on the prior,
+    first-type box) keep the wave sweeps bit for bit."""
+    import torch
+    from waveflow_amd import checkpoint, flows, model_factory, wavefunctions
+    mt = model_factory.get_masked_transform
+    il, ir, pl, pr = {0: 0.0, 1: 0.0}, {0: 1.0, 1: 0.0}, {0: 0, 2: 0}, {0: 0, 1: 0}
+    cases = [
+        dict(L=3.0, n=2, k=6, kn=23, il=il, ir=ir, pl=pl, pr=pr, family=True),
+        dict(L=2.0, n=1, k=5, kn=16, il={0: 0.0}, ir={0: 1.0}, pl={0: 0}, pr={0: 0}, family=True),
+        dict(L=6.0, n=3, k=3, kn=10, il={0: 0.0}, ir={0: 1.0}, pl={0: 0}, pr={0: 0}, family=True),
+        dict(L=10.0, n=3, k=6, kn=33, il={0: 0.0}, ir={0: 1.0}, pl={0: 0}, pr={0: 0}, family=False),     # 39 / 38 bases: two row blocks
+        dict(L=3.0, n=1, k=5, kn=16, il={0: 0.0}, ir={0: 1.0}, pl={0: 0.3}, pr={0: 0}, family=False),     # boundary value 0.3 on the prior
+    ]
+    g = np.random.default_rng(17)
+    for c in cases:
+        init = wavefunctions.Waveflow(
+            flows.Serial(flows.BoxTransformLayer(c["L"]), *(flows.IMADE(mt(), c["k"], c["kn"], 0.05, 1e-6, c["il"], c["ir"]), flows.Reverse()) * c["n"]),
+            mt(allow_negative_params=True), c["k"], c["kn"], constraints_dict_left=c["pl"], constraints_dict_right=c["pr"],
+            constrained_dimension_indices_left=[0], set_nn_output_grad_to_zero=False)
+        params, psi, log_pdf, _ = init(4, 2)
+        m = psi.model
+        m.ensure_params(params)
+        x = torch.as_tensor(sorted_walkers(4097, 2, 0.95 * c["L"], 13)).cuda()
+        w1 = torch.as_tensor(g.normal(size=4097).astype(np.float32)).cuda()
+        w2 = torch.as_tensor((0.05 * g.normal(size=4097)).astype(np.float32)).cuda()
+        monkeypatch.setenv("WF_GRAD_TILE_MIN", "1")
+        tile = m.psi_vjp(x, w1, w2)
+        monkeypatch.setenv("WF_GRAD_TILE_MIN", "0")
+        wave = m.psi_vjp(x, w1, w2)
+        monkeypatch.delenv("WF_GRAD_TILE_MIN")
+        if not c["family"]:
+            assert torch.equal(tile, wave), c
+            continue
+        t, w = tile.cpu().numpy().astype(np.float64), wave.cpu().numpy().astype(np.float64)
+        assert np.isfinite(t).all() and not np.array_equal(t, w), c
+        assert rel_l2(t, w) < 2e-4, (c, rel_l2(t, w))
+        scale = np.linalg.norm(w) / np.sqrt(w.size)
+        for i, (lt, lw) in enumerate(zip(_leaves(checkpoint.unflatten_like(params, t)), _leaves(checkpoint.unflatten_like(params, w)))):
+            if lw.size == 0:
+                continue
+            # a leaf's error against its own size, with a floor of 1e-3 of the gradient's rms entry (leaves that are zero by the masks stay zero)
+            err = np.linalg.norm(lt - lw) / np.sqrt(lw.size)
+            assert err <= 1e-3 * np.linalg.norm(lw) / np.sqrt(lw.size) + 1e-3 * scale * 1e-2, (c, i, lw.shape, err, np.linalg.norm(lw) / np.sqrt(lw.size))
+            assert np.array_equal(lt == 0, lw == 0) or np.abs(lt[(lw == 0)]).max() <= 1e-5 * scale, (c, i)
+    init = model_factory.get_waveflow_model(2, n_flow_layers=1, box_size=2, xu_coord_type="first")
+    params, psi, log_pdf, _ = init(1, 2)
+    m = psi.model
+    m.ensure_params(params)
+    x = torch.as_tensor(sorted_walkers(512, 2, 1.9, 3)).cuda()
+    w = torch.ones(512, device="cuda")
+    monkeypatch.setenv("WF_GRAD_TILE_MIN", "1")
+    tile = m.psi_vjp(x, w, w * 0.1)
+    monkeypatch.setenv("WF_GRAD_TILE_MIN", "0")
+    assert torch.equal(tile, m.psi_vjp(x, w, w * 0.1))
+
+
 def test_psi_vjp_chunks_and_errors(he_flat):
     import torch
     from waveflow_amd import _lib

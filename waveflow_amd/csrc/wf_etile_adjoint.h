@@ -130,11 +130,19 @@ template <class S> WF_HD void r_triple(S r, S x1, S x2, S& v0, S& v1, S& v2) {
     v1 = d.r1 * x1;
     v2 = d.r1 * x2 + d.r2 * x1 * x1;
 }
+// pullback of r_triple.  With q = r (1 - r), A = -L (1 - 2 r): r' = -L q, r'' = A r', r''' = r' (A^2 - 2 L^2 q), so every adjoint carries the factor r'
+// (15 operations instead of the 23 of the literal form: the activation pullbacks are half of the reverse kernel's vector work)
 template <class S> WF_HD void r_triple_bwd(S r, S x1, S x2, S vb0, S vb1, S vb2, S& xb0, S& xb1, S& xb2) {
-    const RDeriv<S> d = r_derivs(r);
-    xb0 = vb0 * d.r1 + vb1 * d.r2 * x1 + vb2 * (d.r2 * x2 + d.r3 * x1 * x1);
-    xb1 = vb1 * d.r1 + vb2 * S(2) * d.r2 * x1;
-    xb2 = vb2 * d.r1;
+    const S L = S(0.6931471805599453);
+    const S q = r - r * r;
+    const S r1 = -L * q;
+    const S A = S(2) * L * r - L;
+    const S t = x1 * vb2;
+    const S u = x1 * vb1 + x2 * vb2;
+    const S B = A * A - S(2) * L * L * q;
+    xb2 = vb2 * r1;
+    xb1 = r1 * (vb1 + S(2) * (A * t));
+    xb0 = r1 * (vb0 + A * u + B * (x1 * t));
 }
 
 // ------------------------------------------------------------------------------------------------ flow head (made.py:66-81)
