@@ -245,6 +245,24 @@ def test_training_reduces_the_energy_and_writes_the_reference_artefacts(tmp_path
     assert checkpoint.load_reference_checkpoint(f"{sd}/checkpoints")[1] == 320
 
 
+def test_large_batch_training_steps_take_the_matrix_core_gradient(tmp_path, monkeypatch):
+    """From WF_GRAD_TILE_MIN walkers per step on, the captured training step refreshes every table and runs loss + gradient on the matrix cores
+    (vqmc.py: _train_graphed); same seeds with the path switched off give the same loss curve up to the fp32 differences of the two kernels."""
+    from waveflow_amd import vqmc
+    curves = []
+    for tm in ("16384", "0"):
+        monkeypatch.setenv("WF_GRAD_TILE_MIN", tm)
+        t = vqmc.ModelTrainer(system_name="He", learning_rate=1e-3, box_length=10, num_epochs=12, batch_size=16384, log_every=10 ** 9)
+        t.save_dir = str(tmp_path / f"He_tile_{tm}")
+        t.exact_sampler = True
+        params, loss = t.start_training(verbose=False)
+        curves.append(np.asarray(loss[1:], dtype=np.float64))
+    a, b = curves
+    assert len(a) == 12 and np.isfinite(a).all() and np.isfinite(b).all()
+    assert not np.array_equal(a, b)                       # two different kernels ...
+    np.testing.assert_allclose(a, b, rtol=2e-3)           # ... one training run (the walkers are the same: same sampler, same seeds)
+
+
 def test_training_with_more_than_32_bases(tmp_path):
     """trainer.num_knots = 33 (examples/run_vqmc.py:10 pokes this attribute): 39 / 38 bases per dimension.  The sweeps run in the
     64-row layout, in the fused (captured) step like the 32-row ones."""

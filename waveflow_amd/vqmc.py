@@ -361,7 +361,13 @@ class ModelTrainer:
         model = psi.model
         # (the steps leave out the tables only the large-batch evaluation kernel reads; every evaluation below goes through
         # ensure_params / set_params_device first, and the loop ends with a full refresh)
-        st = model.make_train_state(opt_state.x, opt_state.m, opt_state.v, start_epoch + 1, ring_len=128, defer_eval_tables=True)
+        # Large batches are the exception: from WF_GRAD_TILE_MIN walkers per step on (default 16 384) the loss + gradient of the two-particle family runs
+        # on the matrix cores (wf_kernels_etile.hip), which reads those tables -- the steps then refresh everything (tens of microseconds against
+        # milliseconds of step)
+        tile_min = int(os.environ.get("WF_GRAD_TILE_MIN", 16384))
+        per_step = int(local_batch) if group is not None else int(self.batch_size)
+        st = model.make_train_state(opt_state.x, opt_state.m, opt_state.v, start_epoch + 1, ring_len=128,
+                                    defer_eval_tables=not (tile_min > 0 and per_step >= tile_min))
         model.set_params_device(opt_state.x)
         seed = int(rng.integers(1 << 62))
         if group is None:
