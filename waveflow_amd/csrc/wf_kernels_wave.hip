@@ -999,14 +999,25 @@ __device__ __forceinline__ float lerp0(const float* __restrict__ tab, const Lerp
 // the spline at one mesh point), (2) the root follows from the line through its two mesh values, (3) it is rounded down to the
 // halving grid 2^-K.  (A halving loop in fp32 takes a wrong turn when |f(mid)| is below its rounding noise, so does this; both
 // stay within one grid step of the exact-arithmetic answer.)  c: this lane's weight (lanes of half `hd` hold the dimension).
+// LDS copy of every 32nd row of the order-0 I-spline table (the first round of the mesh search): 64 rows, padded so that the lanes' 16-byte reads of
+// their own rows spread over the banks.  The sampler is bound by L2 bandwidth on these rows (PMC: 1 350 L2 requests per walker, 10.7 TB/s).
+template <int NBK> constexpr int kCoarseStride = 32 * NBK + 4;
+template <int NBK>
+__device__ __forceinline__ void stage_coarse_rows(float* coarse, const float* __restrict__ tab0, int n_mesh) {
+    constexpr int W = 32 * NBK;
+    for (int i = threadIdx.x; i < 64 * W; i += blockDim.x) {
+        const int row = i / W, col = i % W;
+        coarse[row * kCoarseStride<NBK> + col] = tab0[(size_t)min(row * 32, n_mesh - 1) * W + col];
+    }
+    __syncthreads();
+}
 template <int NBK = 1>
 __device__ __forceinline__ float ispline_inverse(const float* __restrict__ tab0 /* [n_mesh][32 NBK], order 0 */, int n_mesh, int nb, float c,
-                                                 float y, float tol, int hd, float (*ov)[64], int lane) {
+                                                 float y, float tol, int hd, float (*ov)[64], int lane, const float* coarse) {
     constexpr int W = 32 * NBK;
     put(ov, lane, R1{c});
     const float* __restrict__ cw = &ov[0][NBK == 1 ? hd * 32 : 0];
-    auto spline_at = [&](int m) {   // sum_j c_j T[m][j], j ascending
-        const float4_t* __restrict__ row = reinterpret_cast<const float4_t*>(tab0 + (size_t)m * W);
+    auto spline_row = [&](const float4_t* __restrict__ row) {   // sum_j c_j row[j], j ascending
         float acc = 0.0f;
 #pragma unroll
         for (int q = 0; q < W / 4; ++q) {
@@ -1018,10 +1029,12 @@ __device__ __forceinline__ float ispline_inverse(const float* __restrict__ tab0 
         }
         return acc;
     };
-    // round 1: mesh points 0, 32, 64, ... ; round 2: the 32 points inside the interval found (weights beyond nb are zero)
+    auto spline_at = [&](int m) { return spline_row(reinterpret_cast<const float4_t*>(tab0 + (size_t)m * W)); };
+    // round 1: mesh points 0, 32, 64, ... (rows min(32 lane, last): the workgroup's LDS copy, kCoarseStride floats apart, when the caller staged one);
+    // round 2: the 32 points inside the interval found (weights beyond nb are zero)
     const int last = n_mesh - 1;
     int m1 = min(lane * 32, last);
-    float g1 = spline_at(m1);
+    float g1 = coarse ? spline_row(reinterpret_cast<const float4_t*>(coarse + lane * kCoarseStride<NBK>)) : spline_at(m1);
     // (first lane whose mesh value exceeds y: robust against a rounding-level non-monotonicity of the fp32 sums)
     int cnt = __ffsll((long long)~__ballot(g1 <= y && lane * 32 <= last)) - 1;
     if (cnt < 0) cnt = 64;
@@ -1066,7 +1079,7 @@ __device__ __forceinline__ float ispline_inverse(const float* __restrict__ tab0 
 
 template <int D, int NBK = 1>
 __device__ __forceinline__ void wave_serial_inverse(const ModelDev& md, const float* __restrict__ tabI, const float* __restrict__ gI, float (&cur)[D],
-                                                    float (*vec)[64], float (*ov)[64], int lane, int exact) {
+                                                    float (*vec)[64], float (*ov)[64], int lane, int exact, const float* coarse) {
     const int dl = NBK == 1 ? lane >> 5 : 0, j = NBK == 1 ? (lane & 31) : lane;
     const Tape no_tape{nullptr, 0};
     float nxt[D];
@@ -1103,7 +1116,7 @@ __device__ __forceinline__ void wave_serial_inverse(const ModelDev& md, const fl
                 }
                 const bool valid_d = (NBK == 1 ? 2 * p + dl : p) < D, valid = valid_d && j < nb;
                 const SigHead<R1> hdw = sigmoid_head<R1, NBK>(o, valid, valid_d, gI[j], md.i_reg, gate_i, R1{gq}, net.z[p * 64 + lane]);
-                cur[d] = ispline_inverse<NBK>(tabI, n_mesh, nb, hdw.c.c0, nxt[d], tol, hd, ov, lane);
+                cur[d] = ispline_inverse<NBK>(tabI, n_mesh, nb, hdw.c.c0, nxt[d], tol, hd, ov, lane, coarse);
             }
         } else {
 #pragma unroll
@@ -1138,8 +1151,12 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(WF_OCC_SAMP
     unsigned long long seed, const float* __restrict__ ug, int64_t B, float* __restrict__ xg, float* __restrict__ latent, int exact,
     const unsigned long long* __restrict__ seed_offset_dev) {
     __shared__ float lds[kWaves][2][1][64];
+    __shared__ __attribute__((aligned(16))) float coarse_s[64 * kCoarseStride<NBK>];
     if (seed_offset_dev) seed += *seed_offset_dev * 0x9E3779B97F4A7C15ull;   // a device counter advances the stream (captured steps)
     const ModelDev& md = *mdp;
+    const bool use_coarse = md.layer_kind == WF_LAYER_IMADE && md.n_layers > 0;
+    if (use_coarse) stage_coarse_rows<NBK>(coarse_s, tabI, md.isp.n_mesh);
+    const float* coarse = use_coarse ? coarse_s : nullptr;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float (*vec)[64] = lds[wv][0];
     float (*ov)[64] = lds[wv][1];
@@ -1214,25 +1231,29 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(WF_OCC_SAMP
                     put(ov, lane, R1{cj});
                     const float* __restrict__ cw = &ov[0][NBK == 1 ? hd * 32 : 0];
                     float xs = __builtin_nanf("");
-                    for (int round = 0; round < 1563; ++round) {
+                    for (int round = 0; round < 3126; ++round) {
+                        // (32 proposals per round on lanes 0..31: the first accepted one in sequence order does not depend on the round size, the
+                        // expected number of table rows read does -- 40 proposals instead of 67 at the reference bound's 5 % acceptance)
                         scalar::Philox prop(seed, (unsigned long long)b);
-                        prop.c0 = (unsigned)(round * 64 + lane);
+                        prop.c0 = (unsigned)(round * 32 + (lane & 31));
                         prop.c1 = (unsigned)(col + 1);          // the shared stream of this walker uses c1 == 0
                         const float xc = prop.uniform(), yc = prop.uniform() * ymax;
-                        const Lerp L = make_lerp(xc, n_mesh);
-                        const float4_t* __restrict__ rl = reinterpret_cast<const float4_t*>(tabP + (size_t)L.il * W);
-                        const float4_t* __restrict__ rr = reinterpret_cast<const float4_t*>(tabP + (size_t)L.ir * W);
                         float v = 0.0f;
+                        if (lane < 32) {
+                            const Lerp L = make_lerp(xc, n_mesh);
+                            const float4_t* __restrict__ rl = reinterpret_cast<const float4_t*>(tabP + (size_t)L.il * W);
+                            const float4_t* __restrict__ rr = reinterpret_cast<const float4_t*>(tabP + (size_t)L.ir * W);
 #pragma unroll
-                        for (int q = 0; q < W / 4; ++q) {
-                            const float4_t a4 = rl[q], b4 = rr[q], w4 = *reinterpret_cast<const float4_t*>(cw + 4 * q);
-                            v = __builtin_fmaf(w4.x, a4.x + ((b4.x - a4.x) * L.n) * L.dx, v);
-                            v = __builtin_fmaf(w4.y, a4.y + ((b4.y - a4.y) * L.n) * L.dx, v);
-                            v = __builtin_fmaf(w4.z, a4.z + ((b4.z - a4.z) * L.n) * L.dx, v);
-                            v = __builtin_fmaf(w4.w, a4.w + ((b4.w - a4.w) * L.n) * L.dx, v);
+                            for (int q = 0; q < W / 4; ++q) {
+                                const float4_t a4 = rl[q], b4 = rr[q], w4 = *reinterpret_cast<const float4_t*>(cw + 4 * q);
+                                v = __builtin_fmaf(w4.x, a4.x + ((b4.x - a4.x) * L.n) * L.dx, v);
+                                v = __builtin_fmaf(w4.y, a4.y + ((b4.y - a4.y) * L.n) * L.dx, v);
+                                v = __builtin_fmaf(w4.z, a4.z + ((b4.z - a4.z) * L.n) * L.dx, v);
+                                v = __builtin_fmaf(w4.w, a4.w + ((b4.w - a4.w) * L.n) * L.dx, v);
+                            }
+                            if (wavefn) v = v * v;
                         }
-                        if (wavefn) v = v * v;
-                        const unsigned long long hit = __ballot(yc < v);
+                        const unsigned long long hit = __ballot(lane < 32 && yc < v);
                         if (hit) {
                             xs = __shfl(xc, __ffsll((long long)hit) - 1);
                             break;
@@ -1248,7 +1269,7 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(WF_OCC_SAMP
                     if (lane == d) latent[b * D + d] = cur[d];
             }
         }
-        wave_serial_inverse<D, NBK>(md, tabI, gI, cur, vec, ov, lane, exact);
+        wave_serial_inverse<D, NBK>(md, tabI, gI, cur, vec, ov, lane, exact, coarse);
 #pragma unroll
         for (int d = 0; d < D; ++d)
             if (lane == d) xg[b * D + d] = cur[d];
