@@ -194,7 +194,11 @@ int wf_inverse_fwd(const wf_model* m, const float* u_dev, int64_t B, float* x_de
  * (distributions.py:104-108): column-by-column rejection sampling of the prior, then wf_inverse_fwd.  x_dev[B][D];
  * latent_dev[B][D] or NULL (`return_original_samples`).  Counter-based Philox4x32-10 keyed by (seed, walker index):
  * results are reproducible for a given seed but do not follow JAX's threefry stream (parity unpinned).  The rejection loop of a
- * column is bounded (~1e5 proposals, where the reference's while_loop is not): a walker that exhausts it is written as NaN. */
+ * column is bounded (~1e5 proposals, where the reference's while_loop is not): a walker that exhausts it is written as NaN.
+ * Three kernels share the work: one walker per wave (small and medium batches), one lane per walker (other large batches), and for
+ * batches >= 16384 of two-particle models with <= 32 bases the staged form (wf_kernels_etile.hip: conditioners on the matrix cores, the
+ * mesh searches one lane per walker; WF_SAMPLE_TILE_MIN moves the switch); the same holds for wf_inverse_fwd.  The kernels draw from the
+ * same law with their own proposal sequences, so the walkers of a seed change across the switch points. */
 int wf_sample(const wf_model* m, uint64_t seed, int64_t B, float* x_dev, float* latent_dev, int32_t exact, void* stream);
 
 /* H psi = -1/2 laplacian(psi) + V psi of the Waveflow wavefunction: physics.construct_hamiltonian_function (utils/physics.py:79-93)
@@ -242,8 +246,9 @@ int wf_vqmc_loss_grad(const wf_model* m, const float* x_dev, int64_t B, const fl
  *                        before wf_logpdf_fwd / wf_psi_fwd / wf_flow_fwd / wf_layer_fwd -- further training steps, wf_sample,
  *                        wf_hamiltonian_fwd and the gradient entry points need nothing
  * The model's weight images must hold params_dev on entry (wf_model_set_params_device); they hold the updated parameters on
- * exit.  Single process; batch <= 131072 (the wave sampler; beyond: WF_ERR_UNSUPPORTED, step from the host with wf_sample,
- * wf_vqmc_loss_grad, wf_adam_step).  Workspace: wf_vqmc_train_step_workspace_bytes. */
+ * exit.  Single process; batch <= 131072 where the step samples with the wave kernel (beyond: WF_ERR_UNSUPPORTED, step from the host
+ * with wf_sample, wf_vqmc_loss_grad, wf_adam_step), any batch where the staged large-batch sampler applies (see wf_sample; it and the
+ * matrix-core gradient path read the tables a deferred step leaves stale: use defer_eval_tables = 0 from 16384 walkers per step on).  Workspace: wf_vqmc_train_step_workspace_bytes. */
 typedef struct wf_train_state {
     float* params_dev;
     float* m_dev;

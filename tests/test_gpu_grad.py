@@ -261,6 +261,13 @@ def test_large_batch_training_steps_take_the_matrix_core_gradient(tmp_path, monk
     assert len(a) == 12 and np.isfinite(a).all() and np.isfinite(b).all()
     assert not np.array_equal(a, b)                       # two different kernels ...
     np.testing.assert_allclose(a, b, rtol=2e-3)           # ... one training run (the walkers are the same: same sampler, same seeds)
+    # the staged sampler lifts the step's limit of 2^17 walkers (the wave sampler's): 2^18 walkers per step
+    monkeypatch.delenv("WF_GRAD_TILE_MIN")
+    t = vqmc.ModelTrainer(system_name="He", learning_rate=1e-3, box_length=10, num_epochs=3, batch_size=1 << 18, log_every=10 ** 9)
+    t.save_dir = str(tmp_path / "He_2pow18")
+    t.exact_sampler = True
+    params, loss = t.start_training(verbose=False)
+    assert len(loss[1:]) == 3 and np.isfinite(np.asarray(loss[1:], dtype=np.float64)).all()
 
 
 def test_training_with_more_than_32_bases(tmp_path):

@@ -123,6 +123,7 @@ def test_wave_and_one_lane_samplers_draw_from_the_same_distribution(he_flat, mon
     params, psi, log_pdf, sample, om = he(he_flat)
     m = psi.model
     m.ensure_params(params)
+    monkeypatch.setenv("WF_SAMPLE_TILE_MIN", "0")                             # (not the staged sampler of large batches: its own test below)
     for exact in (True, False):
         monkeypatch.setenv("WF_WAVE_SAMPLE_MAX", "100000000")                 # one wave per walker
         xa, la = m.sample(7, 30000, return_latent=True, exact=exact)
@@ -191,3 +192,59 @@ def test_mean_type_box_inverse_beyond_two_particles(D, monkeypatch):
         assert np.median(np.abs(u2 - u)) < 3e-5 and np.abs(u2 - u).max() < 1e-2, (limit, np.abs(u2 - u).max())
     xs = m.sample(3, 4096, exact=True).cpu().numpy()
     assert np.all(np.diff(xs, axis=1) >= 0) and np.isfinite(psi(params, xs)).all()
+
+
+def test_staged_sampler_of_large_batches(he_flat, monkeypatch):
+    """From WF_SAMPLE_TILE_MIN walkers on (default 16 384) wf_sample / wf_inverse_fwd of the two-particle family run staged (wf_kernels_etile.hip:
+    conditioners on the matrix cores, one lane per walker for the mesh searches): the inverse against the oracle and against the one-walker-per-wave
+    kernel on the same latent points, the round trip through the forward pass, the draws against the wave kernel's (two-sample Kolmogorov-Smirnov),
+    several passes over the model's scratch (a walker's stream is keyed by its index in the batch), and the fall-back of other models."""
+    import torch
+    from scipy import stats
+    from waveflow_amd import model_factory
+    params, psi, log_pdf, sample, om = he(he_flat)
+    m = psi.model
+    m.ensure_params(params)
+    g = np.random.default_rng(3)
+    u = g.uniform(0.01, 0.99, size=(20001, 2)).astype(np.float32)
+    for exact in (True, False):
+        monkeypatch.setenv("WF_SAMPLE_TILE_MIN", "16384")
+        xs = m.inverse(u, exact=exact)
+        monkeypatch.setenv("WF_SAMPLE_TILE_MIN", "0")
+        xw = m.inverse(u, exact=exact)                       # one wave per walker
+        assert np.isfinite(xs).all() and not np.array_equal(xs, xw)
+        d = np.abs(xs - xw)
+        assert np.median(d) < 2e-6 and np.quantile(d, 0.999) < 4e-4 and d.max() < 2e-3, (exact, np.median(d), d.max())
+        xo = om.inverse(he_flat, u[:3000], exact=exact)
+        do = np.abs(xs[:3000] - xo)
+        assert np.median(do) < 1e-5 and (do > 2e-3).mean() < 5e-3, (exact, np.median(do), do.max())
+        if exact:
+            u2, _ = m.flow(xs)
+            assert np.median(np.abs(u2 - u)) < 2e-5 and np.abs(u2 - u).max() < 5e-3
+    # the draws: reproducible, the same law as the wave kernel's, x = inverse(latent)
+    monkeypatch.setenv("WF_SAMPLE_TILE_MIN", "16384")
+    xa, la = m.sample(11, 60000, return_latent=True, exact=True)
+    assert torch.equal(xa, m.sample(11, 60000, exact=True)) and not torch.equal(xa, m.sample(12, 60000, exact=True))
+    assert torch.isfinite(xa).all() and la.min().item() >= 0 and la.max().item() <= 1
+    ub, _ = m.flow(xa)
+    assert np.median(np.abs(ub.cpu().numpy() - la.cpu().numpy())) < 2e-5
+    monkeypatch.setenv("WF_SAMPLE_TILE_MIN", "0")
+    xb, lb = m.sample(13, 60000, return_latent=True, exact=True)
+    for c in range(2):
+        for a, b in ((xa, xb), (la, lb)):
+            p = stats.ks_2samp(a[:, c].cpu().numpy(), b[:, c].cpu().numpy()).pvalue
+            assert p > 1e-4, (c, p)
+    # more walkers than one pass of the scratch holds (2^18): the same walkers as a prefix of the larger batch drew
+    monkeypatch.setenv("WF_SAMPLE_TILE_MIN", "16384")
+    big = m.sample(21, (1 << 18) + 5000, exact=True)
+    small = m.sample(21, 40000, exact=True)
+    assert torch.equal(big[:40000], small) and torch.isfinite(big).all()
+    tail = m.sample(21, (1 << 18) + 5000, exact=True)[(1 << 18):]
+    assert torch.equal(tail, big[(1 << 18):]) and tail.std().item() > 0.5
+    # a model outside the family (first-type box) keeps the other kernels: the switch changes nothing
+    init = model_factory.get_waveflow_model(2, n_flow_layers=1, box_size=2, xu_coord_type="first")
+    p1, psi1, lp1, _ = init(1, 2)
+    lp1.model.ensure_params(p1)
+    a = lp1.model.sample(5, 20000, exact=True)
+    monkeypatch.setenv("WF_SAMPLE_TILE_MIN", "0")
+    assert torch.equal(a, lp1.model.sample(5, 20000, exact=True))

@@ -1557,6 +1557,248 @@ __global__ void k_egrad_scatter(const float* __restrict__ gacc, int n_nets, cons
     else { const int jb = i - kGb20; if (jb < q.n_out) flat[q.b2 + jb * 2 + 0] = q.c2 * g[i]; }
 }
 
+// ============================================================================ inverse / sampler of large batches (two-particle family)
+// Serial.inverse_fun / the Waveflow prior's sample_fun (made.py:85-100, bsplines_jax.py:144-171) for batches the one-walker-per-wave kernel
+// (wf_kernels_wave.hip: 6.8e7 walkers/s, a chain of dependent reads per walker) is too slow for.  Staged: the conditioner of a net runs on the
+// matrix cores for the whole batch (k_etile_cond: head outputs to HBM, 384 B per walker), everything else is one lane per walker (k_tsample):
+//   dimension 0 of a net does not depend on the walker: its spline is the composite table comp[net] (k_prepare_dim0), inverted by a binary
+//     search over the mesh; the prior's first column is drawn by rejection under the table's own maximum (tight: the lerp of P is piecewise
+//     linear, so P^2 peaks at a mesh point)
+//   dimension 1: coefficients c_j = g_j (v_j / S0 + reg) / Q from the head outputs (as k_etile_flow), the spline sum_j c_j I_j inverted by the
+//     same search with 32-term row sums; the prior's second column by rejection under the reference's bound max_i ((e @ b_to_ob)_i)^2
+//   the root of a search is rounded to the reference's halving grid exactly as wf_kernels_wave.hip: ispline_inverse does (largest grid point
+//     whose table-lerp value does not exceed y)
+// Streams: Philox4x32-10 keyed by (seed, walker), proposal n of column col uses counter (n, col + 1) -- as the wave sampler; the draws differ
+// from that kernel's in rounding-level cases only for column 1 (matrix-core conditioner) and by the tighter bound for column 0.
+struct Philox4 {   // (as scalar::Philox, wf_scalar_impl.h)
+    unsigned key0, key1, c0, c1, c2, c3;
+    unsigned out[4];
+    int have;
+    __device__ Philox4(unsigned long long seed, unsigned long long stream) : key0((unsigned)seed), key1((unsigned)(seed >> 32)), c0(0), c1(0), c2((unsigned)stream), c3((unsigned)(stream >> 32)), have(0) {}
+    __device__ void round(unsigned& a0, unsigned& a1, unsigned& a2, unsigned& a3, unsigned k0, unsigned k1) {
+        const unsigned long long p0 = 0xD2511F53ull * a0, p1 = 0xCD9E8D57ull * a2;
+        const unsigned h0 = (unsigned)(p0 >> 32), l0 = (unsigned)p0, h1 = (unsigned)(p1 >> 32), l1 = (unsigned)p1;
+        a0 = h1 ^ a1 ^ k0; a1 = l1; a2 = h0 ^ a3 ^ k1; a3 = l0;
+    }
+    __device__ void refill() {
+        unsigned a0 = c0, a1 = c1, a2 = c2, a3 = c3, k0 = key0, k1 = key1;
+#pragma unroll
+        for (int r = 0; r < 10; ++r) { round(a0, a1, a2, a3, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+        out[0] = a0; out[1] = a1; out[2] = a2; out[3] = a3;
+        if (++c0 == 0) ++c1;
+        have = 4;
+    }
+    __device__ float uniform() {
+        if (!have) refill();
+        return (float)(out[--have] >> 8) * (1.0f / 16777216.0f);
+    }
+};
+struct TsArgs {
+    const float4_t* comp;      // [n_nets][n_mesh] composite tables of dimension 0 (flow nets: Y; prior: P with sign and norm)
+    const float* tabI0;        // order-0 rows of the I-spline table [n_mesh][32]
+    const float* tabP0;        // order-0 rows of the prior's table [n_mesh][32]
+    const float* gI;           // [32] row factors of the flow heads (boundary map; 0 beyond the bases)
+    const float* b_to_ob;      // [32][32]
+    int n_mesh, nbI, nbP, n_layers;
+    float i_reg, tol, box_L;
+    unsigned long long seed;
+    const unsigned long long* seed_offset_dev;
+    int exact;
+    int64_t b0;                // index of the chunk's first walker in the batch (the key of a walker's stream is its index in the batch)
+};
+// largest mesh point m with F(m) <= y (0 if there is none), F monotone on the mesh; yl = F(m), yr = F(m + 1) (yr = yl at the last point)
+template <class F>
+__device__ __forceinline__ void mesh_search(F f, int last, float y, int& m, float& yl, float& yr) {
+    int lo = 0, hi = last;
+    float flo = f(0), fhi = f(last);
+    const bool beyond = fhi <= y;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        const float fm = f(mid);
+        if (fm <= y) { lo = mid; flo = fm; } else { hi = mid; fhi = fm; }
+    }
+    m = beyond ? last : lo;
+    yl = beyond ? fhi : flo;
+    yr = fhi;
+}
+// the root on the line through the two mesh values, rounded down to the halving grid 2^-K of helpers.binary_search; the table lerp itself decides
+// between the neighbouring grid points (wf_kernels_wave.hip: ispline_inverse)
+template <class FL>
+__device__ __forceinline__ float grid_root(FL flerp, int m, float yl, float yr, float y, int last, float tol) {
+    const float n = (float)last;
+    float xs = (float)m / n;
+    if (yr > yl) xs = xs + (y - yl) / ((yr - yl) * n);
+    int K = 0;
+    float w = 1.0f;
+    while (K < 64 && w * 0.5f > tol * 0.5f) { w *= 0.5f; ++K; }
+    const float scale = ldexpf(1.0f, K);
+    float q = floorf(xs * scale);
+    q = fminf(fmaxf(q, 0.0f), scale - 1.0f);
+    const float f_lo = flerp(q / scale) - y, f_hi = flerp(fminf(q + 1.0f, scale - 1.0f) / scale) - y;
+    if (f_hi <= 0.0f && q + 1.0f <= scale - 1.0f) q = q + 1.0f;
+    else if (f_lo > 0.0f && q >= 1.0f) q = q - 1.0f;
+    return q / scale;
+}
+__device__ __forceinline__ float comp_lerp_x(const float4_t* __restrict__ comp, float x, int n_mesh) {
+    const LerpN L = nlerp(x, n_mesh);
+    const float a = comp[L.il].x, b = comp[L.ir].x;
+    return __builtin_fmaf(b - a, L.t, a);
+}
+__device__ __forceinline__ float inv_comp(const float4_t* __restrict__ comp, int n_mesh, float y, float tol) {
+    int m;
+    float yl, yr;
+    mesh_search([&](int i) { return comp[i].x; }, n_mesh - 1, y, m, yl, yr);
+    return grid_root([&](float x) { return comp_lerp_x(comp, x, n_mesh); }, m, yl, yr, y, n_mesh - 1, tol);
+}
+__device__ __forceinline__ float rows_dot(const float* __restrict__ row, const float (&c)[32]) {   // sum_j c_j row[j], j ascending
+    const float4_t* r4 = reinterpret_cast<const float4_t*>(row);
+    float acc = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float4_t t = r4[q];
+        acc = __builtin_fmaf(c[4 * q], t.x, acc);
+        acc = __builtin_fmaf(c[4 * q + 1], t.y, acc);
+        acc = __builtin_fmaf(c[4 * q + 2], t.z, acc);
+        acc = __builtin_fmaf(c[4 * q + 3], t.w, acc);
+    }
+    return acc;
+}
+__device__ __forceinline__ float rows_lerp(const float* __restrict__ tab0, const float (&c)[32], float x, int n_mesh) {
+    const LerpN L = nlerp(x, n_mesh);
+    const float4_t* ra = reinterpret_cast<const float4_t*>(tab0 + (size_t)L.il * 32);
+    const float4_t* rb = reinterpret_cast<const float4_t*>(tab0 + (size_t)L.ir * 32);
+    float acc = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float4_t a = ra[q], b = rb[q];
+        acc = __builtin_fmaf(c[4 * q], __builtin_fmaf(b.x - a.x, L.t, a.x), acc);
+        acc = __builtin_fmaf(c[4 * q + 1], __builtin_fmaf(b.y - a.y, L.t, a.y), acc);
+        acc = __builtin_fmaf(c[4 * q + 2], __builtin_fmaf(b.z - a.z, L.t, a.z), acc);
+        acc = __builtin_fmaf(c[4 * q + 3], __builtin_fmaf(b.w - a.w, L.t, a.w), acc);
+    }
+    return acc;
+}
+__device__ __forceinline__ float inv_rows(const float* __restrict__ tab0, const float (&c)[32], int n_mesh, float y, float tol) {
+    int m;
+    float yl, yr;
+    mesh_search([&](int i) { return rows_dot(tab0 + (size_t)i * 32, c); }, n_mesh - 1, y, m, yl, yr);
+    return grid_root([&](float x) { return rows_lerp(tab0, c, x, n_mesh); }, m, yl, yr, y, n_mesh - 1, tol);
+}
+// channel 0 of the head outputs of walker b: oj[tile][row][channel][32 walkers]
+__device__ __forceinline__ float oj0(const float* __restrict__ oj, int64_t b, int row) { return oj[((b >> 5) * (32 * NCH) + row * NCH) * 32 + (b & 31)]; }
+
+// phase 0: prior column 0;  1: prior column 1, then the last layer's dimension 0;  2: dimension 1 of layer `layer`, then dimension 0 of the layer before it
+// (layer 0: the box reverse and the result);  3: entry of a plain inverse (latent given): the last layer's dimension 0.
+// Between the phases: cur0 = the inverted dimension 0, cur1 = the value waiting for dimension 1, cin = what the conditioner of the next launch sees
+// (exact: the inverted prefix; reference mode, made.py:88: the value being inverted).
+__global__ __launch_bounds__(256) void k_tsample(const TsArgs a, int phase, int layer, const float* __restrict__ oj, const float* __restrict__ ug, int64_t B,
+                                                 float* __restrict__ cur0, float* __restrict__ cur1, float* __restrict__ cin, float* __restrict__ lat,
+                                                 float* __restrict__ latent_out, float* __restrict__ xg) {
+    __shared__ float red[256];
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int n_mesh = a.n_mesh;
+    unsigned long long seed = a.seed;
+    if (a.seed_offset_dev) seed += *a.seed_offset_dev * 0x9E3779B97F4A7C15ull;
+    float ymax0 = 0.0f;
+    if (phase == 0) {   // the first column's bound: the largest P^2 on the mesh
+        const float4_t* cp = a.comp + (size_t)a.n_layers * n_mesh;
+        float mx = 0.0f;
+        for (int i = threadIdx.x; i < n_mesh; i += blockDim.x) { const float p = cp[i].x; mx = fmaxf(mx, p * p); }
+        red[threadIdx.x] = mx;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+            __syncthreads();
+        }
+        ymax0 = red[0];
+    }
+    if (b >= B) return;
+    // the next layer's dimension 0 from the pair (va, vb) that leaves a layer (or the prior): Reverse.inverse_fun, then the composite table
+    auto start_layer = [&](int l, float va, float vb) {
+        const float n0 = vb, n1 = va;
+        const float o0 = inv_comp(a.comp + (size_t)l * n_mesh, n_mesh, n0, a.tol);
+        cur0[b] = o0;
+        cur1[b] = n1;
+        cin[b] = a.exact ? o0 : n0;
+    };
+    if (phase == 0) {
+        const float4_t* cp = a.comp + (size_t)a.n_layers * n_mesh;
+        float xs = __builtin_nanf("");
+        for (int n = 0; n < 100000; ++n) {
+            Philox4 prop(seed, (unsigned long long)(a.b0 + b));
+            prop.c0 = (unsigned)n;
+            prop.c1 = 1u;
+            const float xc = prop.uniform(), yc = prop.uniform() * ymax0;
+            const float p = comp_lerp_x(cp, xc, n_mesh);
+            if (yc < p * p) { xs = xc; break; }
+        }
+        lat[b] = xs;
+        cin[b] = xs;
+        cin[4 * B + b] = 0.0f;
+        return;
+    }
+    if (phase == 3) {
+        cin[4 * B + b] = 0.0f;
+        start_layer(a.n_layers - 1, ug[b * 2], ug[b * 2 + 1]);
+        return;
+    }
+    if (phase == 1) {
+        // e = c / |c| with c = (o keep) @ ob_to_b from the conditioner launch; bound max_i ((e @ b_to_ob)_i)^2 (bsplines_jax.py:164-166)
+        float e[32];
+        float ss = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) { e[j] = j < a.nbP ? oj0(oj, b, j) : 0.0f; ss = __builtin_fmaf(e[j], e[j], ss); }
+        const float rn = 1.0f / sqrtf(ss);
+#pragma unroll
+        for (int j = 0; j < 32; ++j) e[j] = e[j] * rn;
+        float ymax = 0.0f;
+        for (int i = 0; i < a.nbP; ++i) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) acc = __builtin_fmaf(e[j], a.b_to_ob[j * 32 + i], acc);
+            ymax = fmaxf(ymax, acc * acc);
+        }
+        float xs = __builtin_nanf("");
+        for (int n = 0; n < 100000; ++n) {
+            Philox4 prop(seed, (unsigned long long)(a.b0 + b));
+            prop.c0 = (unsigned)n;
+            prop.c1 = 2u;
+            const float xc = prop.uniform(), yc = prop.uniform() * ymax;
+            const float v = rows_lerp(a.tabP0, e, xc, n_mesh);
+            if (yc < v * v) { xs = xc; break; }
+        }
+        const float l0 = lat[b];
+        if (latent_out) { latent_out[b * 2] = l0; latent_out[b * 2 + 1] = xs; }
+        start_layer(a.n_layers - 1, l0, xs);
+        return;
+    }
+    // phase 2: c_j = g_j (v_j / S0 + reg) / Q (calculate_bijection_params + reg, remove_bias, boundary map), v_j = 1 / (2^o_j + 1)
+    float c[32];
+    float S0 = 0.0f, Qv = 0.0f, G = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const float g = a.gI[j];
+        const float v = j < a.nbI ? r_of(oj0(oj, b, j)) : 0.0f;
+        c[j] = v;
+        S0 += v;
+        Qv = __builtin_fmaf(v, g, Qv);
+        G += j < a.nbI ? g : 0.0f;
+    }
+    const float rS = 1.0f / S0, rQ = 1.0f / __builtin_fmaf(Qv, rS, a.i_reg * G);
+#pragma unroll
+    for (int j = 0; j < 32; ++j) c[j] = j < a.nbI ? (a.gI[j] * __builtin_fmaf(c[j], rS, a.i_reg)) * rQ : 0.0f;
+    const float o0 = cur0[b];
+    const float o1 = inv_rows(a.tabI0, c, n_mesh, cur1[b], a.tol);
+    if (layer > 0) {
+        start_layer(layer - 1, o0, o1);
+        return;
+    }
+    // BoxTransformLayer.reverse_fun_mean (made.py:186-197), two particles
+    const float mean = 0.5f * o0, pm = o1 * (1.0f - o0) - (0.5f - mean);
+    xg[b * 2] = ((0.0f - mean) + pm) * 2.0f * a.box_L;
+    xg[b * 2 + 1] = ((o0 - mean) + pm) * 2.0f * a.box_L;
+}
+
 int check() {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -1686,6 +1928,64 @@ int launch_energy_vjp_finish(const float* gacc, int n_nets, const int* offs /* [
     }
     hipLaunchKernelGGL(k_fill_zero, dim3((unsigned)((n_params + 255) / 256)), dim3(256), 0, s, flat, n_params);
     hipLaunchKernelGGL(k_egrad_scatter, dim3((kGFloats + 255) / 256, n_nets), dim3(256), 0, s, gacc, n_nets, o, flat);
+    return check();
+}
+
+// ---- host side of the staged inverse / sampler
+bool tile_sample_capable(const MfmaDev* mdev) {
+    return mdev->D == 2 && mdev->nbk == 1 && mdev->n_layers > 0 && mdev->n_layers < 8 && !mdev->p_bias && !mdev->i_gate && !mdev->p_gate && mdev->comp != nullptr;
+}
+// floats of workspace: conditioner input (5 B: the slot of the second input sits 4 B behind the first), cur0, cur1, the latent pair, the prior's sign sums,
+// the head outputs of whole tiles
+int64_t tile_sample_floats(int64_t B) { return B * 10 + ((B + 31) / 32) * 32 * (32 * NCH) + 64; }
+
+// draw == 0: x = inverse(u);  draw == 1: latent ~ prior (reported in `latent` if given), x = inverse(latent)
+int launch_tile_sample(const MfmaDev* mdev, const ModelDev& md, const float* tabI0, const float* tabP0, const float* fk_nat, int draw, unsigned long long seed,
+                       const float* u, int64_t B, float* x, float* latent, int exact, const unsigned long long* seed_offset_dev, int64_t b0, float* ws, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (B == 0) return WF_OK;
+    float* cin = ws;                 // [5][B]
+    float* cur0 = cin + 5 * B;
+    float* cur1 = cur0 + B;
+    float* lat = cur1 + B;           // [B] (column 0 between the two prior phases)
+    float* s1 = lat + 2 * B;
+    float* oj = ws + (((size_t)10 * B + 63) / 64) * 64;
+    TsArgs a{};
+    a.comp = mdev->comp;
+    a.tabI0 = tabI0;
+    a.tabP0 = tabP0;
+    a.gI = fk_nat;
+    a.b_to_ob = md.b_to_ob;
+    a.n_mesh = mdev->n_mesh;
+    a.nbI = md.isp.nb;
+    a.nbP = md.psp.nb;
+    a.n_layers = md.n_layers;
+    a.i_reg = md.i_reg;
+    a.tol = md.reverse_tol;
+    a.box_L = md.box_L;
+    a.seed = seed;
+    a.seed_offset_dev = seed_offset_dev;
+    a.exact = exact;
+    a.b0 = b0;
+    const unsigned lane_blocks = (unsigned)((B + 255) / 256);
+    const int lds_bytes = (mdev->const_floats + mdev->net_floats) * (int)sizeof(float);
+    static DynLdsSlots cfg_flow{}, cfg_prior{};
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(k_etile_cond<false>), lds_bytes, &cfg_flow)) return rc;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(k_etile_cond<true>), lds_bytes, &cfg_prior)) return rc;
+    const int64_t n_tiles = (B + 31) / 32;
+    const unsigned cond_blocks = (unsigned)std::min<int64_t>((n_tiles + kCondWaves - 1) / kCondWaves, 256 * 4);
+    const int L = md.n_layers;
+    if (draw) {
+        hipLaunchKernelGGL(k_tsample, dim3(lane_blocks), dim3(256), 0, s, a, 0, 0, (const float*)oj, u, B, cur0, cur1, cin, lat, latent, x);
+        hipLaunchKernelGGL(k_etile_cond<true>, dim3(cond_blocks), dim3(kCondWaves * 64), lds_bytes, s, *mdev, L, (const float*)cin, B, oj, s1);
+        hipLaunchKernelGGL(k_tsample, dim3(lane_blocks), dim3(256), 0, s, a, 1, 0, (const float*)oj, u, B, cur0, cur1, cin, lat, latent, x);
+    } else {
+        hipLaunchKernelGGL(k_tsample, dim3(lane_blocks), dim3(256), 0, s, a, 3, 0, (const float*)oj, u, B, cur0, cur1, cin, lat, latent, x);
+    }
+    for (int l = L - 1; l >= 0; --l) {
+        hipLaunchKernelGGL(k_etile_cond<false>, dim3(cond_blocks), dim3(kCondWaves * 64), lds_bytes, s, *mdev, l, (const float*)cin, B, oj, s1);
+        hipLaunchKernelGGL(k_tsample, dim3(lane_blocks), dim3(256), 0, s, a, 2, l, (const float*)oj, u, B, cur0, cur1, cin, lat, latent, x);
+    }
     return check();
 }
 

@@ -1425,6 +1425,33 @@ static int64_t wave_sample_max() {   // tuning knob (read at every call): WF_WAV
     return e ? atoll(e) : kWaveSampleMax;
 }
 
+// Large batches of the two-particle family (the family of the matrix-core local energy, <= 32 bases): the staged inverse / sampler of
+// wf_kernels_etile.hip (conditioners on the matrix cores, one lane per walker for the searches).  WF_SAMPLE_TILE_MIN (read per call) moves the switch
+// point; 0 disables the path.  It reads the MFMA image and the composite dimension-0 tables: not while they are stale (deferred training steps).
+static constexpr int64_t kTileSampleMin = 16384;
+static constexpr int64_t kTileSampleChunk = 1 << 18;   // walkers per pass of a call without a caller's workspace (the model's scratch: 111 MB)
+static bool tile_sample_ok(const wf_model* m, int64_t B) {
+    const char* e = getenv("WF_SAMPLE_TILE_MIN");
+    const int64_t mn = e ? atoll(e) : kTileSampleMin;
+    const wf_model_desc& d = m->desc;
+    return mn > 0 && B >= mn && d.n_dim == 2 && m->nbp == 32 && m->mfma_ok && d.box_kind == WF_BOX_MEAN && d.layer_kind == WF_LAYER_IMADE && d.n_flow_layers > 0 &&
+           d.prior_kind == WF_PRIOR_WAVEFLOW && !m->eval_tables_stale && m->d_tabI4 && m->d_tabP3 && m->dev.b_to_ob && m->d_grad_fk && tile_sample_capable(&m->mdev);
+}
+// in passes of what the workspace holds; a walker's stream is keyed by its index in the batch, whatever the passes
+static int run_tile_sample(const wf_model* m, int draw, uint64_t seed, const float* u_dev, int64_t B, float* x_dev, float* latent_dev, int exact,
+                           const unsigned long long* counter_dev, float* ws, int64_t ws_floats, void* stream) {
+    int64_t chunk = B;
+    while (chunk > 32 && tile_sample_floats(chunk) > ws_floats) chunk = ((chunk / 2) + 31) / 32 * 32;
+    if (tile_sample_floats(chunk) > ws_floats) return WF_ERR_INVALID;
+    for (int64_t c0 = 0; c0 < B; c0 += chunk) {
+        const int64_t bc = std::min(chunk, B - c0);
+        int rc = launch_tile_sample(&m->mdev, m->dev, m->d_tabI4, m->d_tabP3, m->d_grad_fk, draw, (unsigned long long)seed, u_dev ? u_dev + c0 * 2 : nullptr, bc,
+                                    x_dev + c0 * 2, latent_dev ? latent_dev + c0 * 2 : nullptr, exact, counter_dev, c0, ws, stream);
+        if (rc) return rc;
+    }
+    return WF_OK;
+}
+
 int wf_inverse_fwd(const wf_model* m, const float* u_dev, int64_t B, float* x_dev, int32_t exact, void* stream) {
     int rc = check_fwd(m, u_dev, B, x_dev);
     if (rc) return rc;
@@ -1434,6 +1461,12 @@ int wf_inverse_fwd(const wf_model* m, const float* u_dev, int64_t B, float* x_de
         rc = ensure_scratch(m, B);
         if (rc) return rc;
         return launch_nsc_model(m->nsc, 3, u_dev, B, m->d_scratch, x_dev, stream);
+    }
+    if (tile_sample_ok(m, B)) {
+        const int64_t fl = tile_sample_floats(std::min(B, kTileSampleChunk));
+        rc = ensure_scratch(m, fl);
+        if (rc) return rc;
+        return run_tile_sample(m, 0, 0, u_dev, B, x_dev, nullptr, exact, nullptr, m->d_scratch, fl, stream);
     }
     if (m->wave_ok && B <= wave_sample_max())
         return launch_wave_sample(m->dev, m->d_dev, m->d_tabI4, m->d_tabP3, m->d_grad_fk, 0, 0ull, u_dev, B, x_dev, nullptr, exact, nullptr, stream);
@@ -1452,6 +1485,12 @@ int wf_sample(const wf_model* m, uint64_t seed, int64_t B, float* x_dev, float* 
         rc = launch_nsc_latent(m->desc.prior_kind, m->desc.n_dim, (unsigned long long)seed, B, z, stream);
         if (rc) return rc;
         return launch_nsc_model(m->nsc, 3, z, B, m->d_scratch, x_dev, stream);
+    }
+    if (tile_sample_ok(m, B)) {
+        const int64_t fl = tile_sample_floats(std::min(B, kTileSampleChunk));
+        rc = ensure_scratch(m, fl);
+        if (rc) return rc;
+        return run_tile_sample(m, 1, seed, nullptr, B, x_dev, latent_dev, exact, nullptr, m->d_scratch, fl, stream);
     }
     if (m->wave_ok && B <= wave_sample_max())
         return launch_wave_sample(m->dev, m->d_dev, m->d_tabI4, m->d_tabP3, m->d_grad_fk, 1, (unsigned long long)seed, nullptr, B, x_dev, latent_dev,
@@ -1710,9 +1749,10 @@ static int adam_from_sweep(wf_model* m, const wf_train_state* st, const float* g
 
 int64_t wf_vqmc_train_step_workspace_bytes(const wf_model* m, int64_t batch) {
     if (!m || batch < 1) return WF_ERR_INVALID;
-    if (!m->d_grad_map || !m->grad_psi_ok || !m->wave_ok || batch > kWaveSampleMax) return WF_ERR_UNSUPPORTED;
+    if (!m->d_grad_map || !m->grad_psi_ok || !m->wave_ok || (batch > kWaveSampleMax && !tile_sample_ok(m, batch))) return WF_ERR_UNSUPPORTED;
+    // (the staged sampler of large batches works in the gradient's workspace before the gradient needs it)
     return align256(batch * m->desc.n_dim * 4) + align256(batch * 4) + align256(m->n_params * 4) + 256 + align256(block_sums_ws_bytes(batch)) +
-           vjp_ws_bytes(m, batch, true);
+           std::max<int64_t>(vjp_ws_bytes(m, batch, true), tile_sample_ok(m, batch) ? align256(tile_sample_floats(std::min(batch, kTileSampleChunk)) * 4) : 0);
 }
 
 int wf_vqmc_train_step(wf_model* m, const wf_train_state* st, uint64_t seed, int64_t batch, const float* protons_host, int32_t n_protons,
@@ -1721,7 +1761,7 @@ int wf_vqmc_train_step(wf_model* m, const wf_train_state* st, uint64_t seed, int
     if (!m || !st || batch < 1 || n_protons < 0 || n_protons > 8 || (n_protons > 0 && !protons_host)) return WF_ERR_INVALID;
     if (!st->params_dev || !st->m_dev || !st->v_dev || !st->counter_dev || !st->running_average_dev || !st->loss_ring_dev || st->ring_len < 1)
         return WF_ERR_INVALID;
-    if (!m->d_grad_map || !m->grad_psi_ok || !m->wave_ok || batch > kWaveSampleMax) return WF_ERR_UNSUPPORTED;
+    if (!m->d_grad_map || !m->grad_psi_ok || !m->wave_ok || (batch > kWaveSampleMax && !tile_sample_ok(m, batch))) return WF_ERR_UNSUPPORTED;
     if (!m->params_set || !workspace_dev || workspace_bytes < wf_vqmc_train_step_workspace_bytes(m, batch)) return WF_ERR_INVALID;
     DeviceGuard g(m->device);
     const int D = m->desc.n_dim;
@@ -1737,8 +1777,10 @@ int wf_vqmc_train_step(wf_model* m, const wf_train_state* st, uint64_t seed, int
     for (int i = 0; i < n_protons; ++i) pr.pos[i] = protons_host[i];
     const unsigned long long* counter = (const unsigned long long*)st->counter_dev;
     // walkers ~ the sampler, stream advanced by the device counter
-    int rc = launch_wave_sample(m->dev, m->d_dev, m->d_tabI4, m->d_tabP3, m->d_grad_fk, 1, (unsigned long long)seed, nullptr, batch, x, nullptr,
-                                exact_sampler, counter, stream);
+    int rc = tile_sample_ok(m, batch)
+                 ? run_tile_sample(m, 1, seed, nullptr, batch, x, nullptr, exact_sampler, counter, (float*)p, vjp_bytes / 4, stream)
+                 : launch_wave_sample(m->dev, m->d_dev, m->d_tabI4, m->d_tabP3, m->d_grad_fk, 1, (unsigned long long)seed, nullptr, batch, x, nullptr,
+                                      exact_sampler, counter, stream);
     if (rc) return rc;
     // mean local energy and its gradient under the custom tangent rule, running average from the device scalar
     int split = 0;   // (gated heads: no deferred gather -- the flat gradient gets its zero_params entries, Adam reads it)
@@ -1759,7 +1801,7 @@ int wf_vqmc_train_step_local(wf_model* m, const wf_train_state* st, uint64_t see
                              void* stream) {
     if (!m || !st || !reduce_dev || batch_local < 1 || n_protons < 0 || n_protons > 8 || (n_protons > 0 && !protons_host)) return WF_ERR_INVALID;
     if (!st->counter_dev || !st->running_average_dev) return WF_ERR_INVALID;
-    if (!m->d_grad_map || !m->grad_psi_ok || !m->wave_ok || batch_local > kWaveSampleMax) return WF_ERR_UNSUPPORTED;
+    if (!m->d_grad_map || !m->grad_psi_ok || !m->wave_ok || (batch_local > kWaveSampleMax && !tile_sample_ok(m, batch_local))) return WF_ERR_UNSUPPORTED;
     if (!m->params_set || !workspace_dev || workspace_bytes < wf_vqmc_train_step_workspace_bytes(m, batch_local)) return WF_ERR_INVALID;
     DeviceGuard g(m->device);
     const int D = m->desc.n_dim;
@@ -1773,8 +1815,11 @@ int wf_vqmc_train_step_local(wf_model* m, const wf_train_state* st, uint64_t see
     Protons pr{};
     pr.n = n_protons;
     for (int i = 0; i < n_protons; ++i) pr.pos[i] = protons_host[i];
-    int rc = launch_wave_sample(m->dev, m->d_dev, m->d_tabI4, m->d_tabP3, m->d_grad_fk, 1, (unsigned long long)seed, nullptr, batch_local, x, nullptr,
-                                exact_sampler, (const unsigned long long*)st->counter_dev, stream);
+    int rc = tile_sample_ok(m, batch_local)
+                 ? run_tile_sample(m, 1, seed, nullptr, batch_local, x, nullptr, exact_sampler, (const unsigned long long*)st->counter_dev, (float*)p,
+                                   vjp_bytes / 4, stream)
+                 : launch_wave_sample(m->dev, m->d_dev, m->d_tabI4, m->d_tabP3, m->d_grad_fk, 1, (unsigned long long)seed, nullptr, batch_local, x,
+                                      nullptr, exact_sampler, (const unsigned long long*)st->counter_dev, stream);
     if (rc) return rc;
     int split = 0;
     rc = run_vjp_chunks(m, 2, true, x, batch_local, nullptr, nullptr, &pr, 0.0f, inv_global_batch, e_loc, grad, p, vjp_bytes, stream,

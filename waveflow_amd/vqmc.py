@@ -315,8 +315,8 @@ class ModelTrainer:
                 json.dump(system_dict, fout_sys, indent=4)
         if verbose:
             print("Start training...")
-        # the whole step as one captured launch sequence, where the library has it (the wave sampler: <= 131072 walkers per
-        # step; models the sweeps cover); otherwise the host-stepped loop below (sampler, loss + gradient, Adam: three library calls per step)
+        # the whole step as one captured launch sequence, where the library has it (models the sweeps cover; the wave sampler: <= 131072 walkers
+        # per step, no such limit where the staged large-batch sampler applies); otherwise the host-stepped loop below (sampler, loss + gradient, Adam: three library calls per step)
         # Sharded over several processes: the same sequence in two halves around the step's one all-reduce.
         fused = self.use_graph and local_batch >= 1
         if fused:
@@ -365,9 +365,10 @@ class ModelTrainer:
         # on the matrix cores (wf_kernels_etile.hip), which reads those tables -- the steps then refresh everything (tens of microseconds against
         # milliseconds of step)
         tile_min = int(os.environ.get("WF_GRAD_TILE_MIN", 16384))
+        sample_min = int(os.environ.get("WF_SAMPLE_TILE_MIN", 16384))   # (the staged sampler of large batches reads them too)
         per_step = int(local_batch) if group is not None else int(self.batch_size)
-        st = model.make_train_state(opt_state.x, opt_state.m, opt_state.v, start_epoch + 1, ring_len=128,
-                                    defer_eval_tables=not (tile_min > 0 and per_step >= tile_min))
+        large = (tile_min > 0 and per_step >= tile_min) or (sample_min > 0 and per_step >= sample_min)
+        st = model.make_train_state(opt_state.x, opt_state.m, opt_state.v, start_epoch + 1, ring_len=128, defer_eval_tables=not large)
         model.set_params_device(opt_state.x)
         seed = int(rng.integers(1 << 62))
         if group is None:
