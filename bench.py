@@ -95,6 +95,7 @@ def kernel_ms(model, x, n=50, warm=150):
 HPSI_KERNELS = "k_efused (one launch: box + 3 x (conditioner Taylor channels on the matrix cores + head) + prior + H psi)"
 GRAD_KERNELS = ("k_efused<1> (forward, per-net input jets kept) + k_vqmc_seeds + 4 x (k_ebwd<PRIOR> reverse of one net on the matrix cores + k_ewgrad "
                 "weight-gradient products + k_egrad_reduce) + k_egrad_scatter")
+SAMPLE_KERNELS = "k_tsample (one lane per walker: rejection draws, mesh searches) + 4 x k_etile_cond (conditioner of a net on the matrix cores)"
 GRAD_KERNELS_WAVE = "k_wave_fwd<2,RF<2>> + k_energy_out + k_vqmc_seeds + k_wave_bwd<2,RF<2>> + k_wgrad<4> + k_wgrad_reduce + k_grad_gather"
 
 
@@ -162,10 +163,29 @@ def vqmc_legs(model, n_h=20, n_g=10):
     m33 = seeded_model(2, 33, "auto")   # BASELINE's "32-bin" variant: two 32-row blocks per dimension (k_efused<2>)
     ms_h33 = event_ms(lambda: m33.hamiltonian(xb, protons), 10, 5)
     del m33
-    return {"hpsi_2pow20": {"kernels": HPSI_KERNELS, "ms": ms_h, "walkers": 1 << 20, "walkers_per_s": (1 << 20) / (ms_h * 1e-3)},
+    # the sampler (walkers ~ |psi|^2: prior columns by rejection, inverse flow) through the staged large-batch form
+    seeds = iter(range(100, 200))
+    ms_s = event_ms(lambda: model.sample(next(seeds), 1 << 17, exact=True), 10, 3)
+    # whole training steps of 2^17 walkers (sample -> loss + gradient -> Adam -> image refresh; one hipGraph replay each): 260 steps minus 60 steps
+    import time as _time
+    from waveflow_amd import vqmc
+
+    def train_seconds(n_steps):
+        tr = vqmc.ModelTrainer(system_name="He", learning_rate=1e-4, box_length=10, num_epochs=n_steps, batch_size=1 << 17, log_every=10 ** 9)
+        tr.save_dir = os.path.join("/tmp", "wf_bench_step_2pow17")
+        tr.exact_sampler = True
+        t0 = _time.perf_counter()
+        tr.start_training(verbose=False)
+        return _time.perf_counter() - t0
+    ms_step = (train_seconds(260) - train_seconds(60)) / 200 * 1e3
+    return {"sample_2pow17": {"kernels": SAMPLE_KERNELS, "ms": ms_s, "walkers": 1 << 17, "walkers_per_s": (1 << 17) / (ms_s * 1e-3)},
+            "train_step_2pow17": {"ms": ms_step, "walkers": 1 << 17, "walkers_per_s": (1 << 17) / (ms_step * 1e-3),
+                                  "what": "vqmc.ModelTrainer, He, batch 2^17: sampler + loss + gradient + Adam + image refresh per step, hipGraph replay "
+                                          "(wall time of 260 steps minus 60 steps)"},
+            **{"hpsi_2pow20": {"kernels": HPSI_KERNELS, "ms": ms_h, "walkers": 1 << 20, "walkers_per_s": (1 << 20) / (ms_h * 1e-3)},
             "hpsi_33knot_2pow20": {"kernels": "k_efused<2>", "ms": ms_h33, "walkers": 1 << 20, "walkers_per_s": (1 << 20) / (ms_h33 * 1e-3)},
             "loss_grad_2pow17": {"kernels": GRAD_KERNELS, "ms": ms_g, "walkers": 1 << 17,
-                                 "walkers_per_s": (1 << 17) / (ms_g * 1e-3)}}
+                                 "walkers_per_s": (1 << 17) / (ms_g * 1e-3)}}}
 
 
 def extra_legs(model, flat):
