@@ -1599,7 +1599,7 @@ struct TsArgs {
     const float* tabP0;        // order-0 rows of the prior's table [n_mesh][32]
     const float* gI;           // [32] row factors of the flow heads (boundary map; 0 beyond the bases)
     const float* b_to_ob;      // [32][32]
-    int n_mesh, nbI, nbP, n_layers;
+    int n_mesh, nbI, nbP, n_layers, degP;
     float i_reg, tol, box_L;
     unsigned long long seed;
     const unsigned long long* seed_offset_dev;
@@ -1751,24 +1751,58 @@ __global__ __launch_bounds__(256) void k_tsample(const TsArgs a, int phase, int 
         const float rn = 1.0f / sqrtf(ss);
 #pragma unroll
         for (int j = 0; j < 32; ++j) e[j] = e[j] * rn;
-        float ymax = 0.0f;
-        for (int i = 0; i < a.nbP; ++i) {
+        // q = e @ b_to_ob are the coefficients of this column's factor f = sum_i q_i b_i in the plain B-splines (non-negative, summing to one), so
+        // |f| <= max_i |q_i| (the reference's bound, bsplines_jax.py:164-166) and, on the knot interval s where only b_s .. b_{s + k} live,
+        // |f| <= M_s = max(|q_s| .. |q_{s + k}|).  Proposals are drawn from the piecewise-constant envelope M_s^2 (one uniform picks the interval and the
+        // point in it) and accepted against M_s^2: the same law as the reference's uniform proposals under the global bound, at 5 - 8 x its acceptance rate.
+        float aq[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
             float acc = 0.0f;
 #pragma unroll
             for (int j = 0; j < 32; ++j) acc = __builtin_fmaf(e[j], a.b_to_ob[j * 32 + i], acc);
-            ymax = fmaxf(ymax, acc * acc);
+            aq[i] = i < a.nbP ? acc * acc : 0.0f;
         }
+        const int n_int = a.nbP - a.degP;       // knot intervals of equal width on [0, 1] (knots: linspace, the end knots (k + 1)-fold)
+        float msq[32], tot = 0.0f;
+#pragma unroll
+        for (int sI = 0; sI < 32; ++sI) {
+            float mx = 0.0f;
+#pragma unroll
+            for (int d = 0; d <= 8; ++d)
+                if (sI + d < 32 && d <= a.degP) mx = fmaxf(mx, aq[sI + d]);
+            msq[sI] = sI < n_int ? mx : 0.0f;
+            tot += msq[sI];
+        }
+        const float wI = 1.0f / (float)n_int;
+        int n_prop = 0;
         float xs = __builtin_nanf("");
         for (int n = 0; n < 100000; ++n) {
             Philox4 prop(seed, (unsigned long long)(a.b0 + b));
             prop.c0 = (unsigned)n;
             prop.c1 = 2u;
-            const float xc = prop.uniform(), yc = prop.uniform() * ymax;
+            const float t = prop.uniform() * tot, u2 = prop.uniform();
+            float run = 0.0f, base = 0.0f, msel = msq[0];
+            int ssel = 0;
+#pragma unroll
+            for (int sI = 0; sI < 32; ++sI) {   // (the last interval with a positive bound catches t == tot)
+                const bool hit = t >= run && msq[sI] > 0.0f;
+                ssel = hit ? sI : ssel;
+                base = hit ? run : base;
+                msel = hit ? msq[sI] : msel;
+                run += msq[sI];
+            }
+            const float xc = fminf(((float)ssel + fminf((t - base) / msel, 1.0f)) * wI, 0.99999994f);
             const float v = rows_lerp(a.tabP0, e, xc, n_mesh);
-            if (yc < v * v) { xs = xc; break; }
+            n_prop = n + 1;
+            if (u2 * msel < v * v) { xs = xc; break; }
         }
         const float l0 = lat[b];
+#ifdef WF_TS_COUNT   // diagnostics build: the number of proposals of column 1 instead of its draw in the reported latent
+        if (latent_out) { latent_out[b * 2] = l0; latent_out[b * 2 + 1] = (float)n_prop; }
+#else
         if (latent_out) { latent_out[b * 2] = l0; latent_out[b * 2 + 1] = xs; }
+#endif
         start_layer(a.n_layers - 1, l0, xs);
         return;
     }
@@ -1959,6 +1993,7 @@ int launch_tile_sample(const MfmaDev* mdev, const ModelDev& md, const float* tab
     a.n_mesh = mdev->n_mesh;
     a.nbI = md.isp.nb;
     a.nbP = md.psp.nb;
+    a.degP = md.psp.degree;
     a.n_layers = md.n_layers;
     a.i_reg = md.i_reg;
     a.tol = md.reverse_tol;
