@@ -1565,11 +1565,13 @@ __global__ void k_egrad_scatter(const float* __restrict__ gacc, int n_nets, cons
 //     search over the mesh; the prior's first column is drawn by rejection under the table's own maximum (tight: the lerp of P is piecewise
 //     linear, so P^2 peaks at a mesh point)
 //   dimension 1: coefficients c_j = g_j (v_j / S0 + reg) / Q from the head outputs (as k_etile_flow), the spline sum_j c_j I_j inverted by the
-//     same search with 32-term row sums; the prior's second column by rejection under the reference's bound max_i ((e @ b_to_ob)_i)^2
+//     same search with 32-term row sums; the prior's second column by rejection from a piecewise-constant envelope over the knot intervals
+//     (the largest of the k + 1 B-spline coefficients alive on an interval: k_tsample, phase 1) -- the reference proposes uniformly under the
+//     global bound max_i ((e @ b_to_ob)_i)^2: the same law at 2.5 x the acceptance rate
 //   the root of a search is rounded to the reference's halving grid exactly as wf_kernels_wave.hip: ispline_inverse does (largest grid point
 //     whose table-lerp value does not exceed y)
 // Streams: Philox4x32-10 keyed by (seed, walker), proposal n of column col uses counter (n, col + 1) -- as the wave sampler; the draws differ
-// from that kernel's in rounding-level cases only for column 1 (matrix-core conditioner) and by the tighter bound for column 0.
+// from that kernel's (other proposal sequences), their law does not.
 struct Philox4 {   // (as scalar::Philox, wf_scalar_impl.h)
     unsigned key0, key1, c0, c1, c2, c3;
     unsigned out[4];
