@@ -18,7 +18,7 @@ for exact in (False, True):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 5
         print(f"sample exact={exact} n={n}: {dt * 1e3:.3f} ms = {n / dt:.3e} walkers/s", flush=True)
-for tm in ("16384", "0"):
+for tm in (("16384", "0") if B <= (1 << 17) else ("16384",)):
     os.environ["WF_GRAD_TILE_MIN"] = tm
     tr = vqmc.ModelTrainer(system_name="He", learning_rate=1e-4, box_length=10, num_epochs=int(os.environ.get("EPOCHS", 60)), batch_size=B, log_every=10 ** 9)
     tr.save_dir = "/tmp/wf_step_prof"
