@@ -1693,10 +1693,12 @@ __device__ __forceinline__ float oj0(const float* __restrict__ oj, int64_t b, in
 // (layer 0: the box reverse and the result);  3: entry of a plain inverse (latent given): the last layer's dimension 0.
 // Between the phases: cur0 = the inverted dimension 0, cur1 = the value waiting for dimension 1, cin = what the conditioner of the next launch sees
 // (exact: the inverted prefix; reference mode, made.py:88: the value being inverted).
-__global__ __launch_bounds__(256) void k_tsample(const TsArgs a, int phase, int layer, const float* __restrict__ oj, const float* __restrict__ ug, int64_t B,
+template <int PHASE>
+__global__ __launch_bounds__(256, 2) void k_tsample(const TsArgs a, int layer, const float* __restrict__ oj, const float* __restrict__ ug, int64_t B,
                                                  float* __restrict__ cur0, float* __restrict__ cur1, float* __restrict__ cin, float* __restrict__ lat,
                                                  float* __restrict__ latent_out, float* __restrict__ xg) {
     __shared__ float red[256];
+    constexpr int phase = PHASE;
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int n_mesh = a.n_mesh;
     unsigned long long seed = a.seed;
@@ -1777,27 +1779,74 @@ __global__ __launch_bounds__(256) void k_tsample(const TsArgs a, int phase, int 
             tot += msq[sI];
         }
         const float wI = 1.0f / (float)n_int;
-        int n_prop = 0;
-        float xs = __builtin_nanf("");
-        for (int n = 0; n < 100000; ++n) {
-            Philox4 prop(seed, (unsigned long long)(a.b0 + b));
+        // one proposal (number n of walker wb's sequence) against the envelope (mq, mtot) of the factor with coefficients ec
+        auto propose = [&](unsigned long long wb, int n, const float (&ec)[32], const float (&mq)[32], float mtot, float& xc) {
+            Philox4 prop(seed, wb);
             prop.c0 = (unsigned)n;
             prop.c1 = 2u;
-            const float t = prop.uniform() * tot, u2 = prop.uniform();
-            float run = 0.0f, base = 0.0f, msel = msq[0];
+            const float t = prop.uniform() * mtot, u2 = prop.uniform();
+            float run = 0.0f, base = 0.0f, msel = mq[0];
             int ssel = 0;
 #pragma unroll
-            for (int sI = 0; sI < 32; ++sI) {   // (the last interval with a positive bound catches t == tot)
-                const bool hit = t >= run && msq[sI] > 0.0f;
+            for (int sI = 0; sI < 32; ++sI) {   // (the last interval with a positive bound catches t == mtot)
+                const bool hit = t >= run && mq[sI] > 0.0f;
                 ssel = hit ? sI : ssel;
                 base = hit ? run : base;
-                msel = hit ? msq[sI] : msel;
-                run += msq[sI];
+                msel = hit ? mq[sI] : msel;
+                run += mq[sI];
             }
-            const float xc = fminf(((float)ssel + fminf((t - base) / msel, 1.0f)) * wI, 0.99999994f);
-            const float v = rows_lerp(a.tabP0, e, xc, n_mesh);
+            xc = fminf(((float)ssel + fminf((t - base) / msel, 1.0f)) * wI, 0.99999994f);
+            const float v = rows_lerp(a.tabP0, ec, xc, n_mesh);
+            return u2 * msel < v * v;
+        };
+        // Stage A: every lane proposes for its own walker, kTsOwn times at most (88 % of the walkers are done by then).  Stage B: the wave's remaining
+        // walkers get eight lanes each, eight consecutive proposals of a walker's sequence per round, the first accepted one in sequence order taken --
+        // the same draws as one lane proposing on alone, without the wave waiting 80 rounds for its unluckiest lane.
+        constexpr int kTsOwn = 16;
+        int n_prop = 0;
+        float xs = __builtin_nanf("");
+        bool done = false;
+        const unsigned long long wb_own = (unsigned long long)(a.b0 + b);
+        for (int n = 0; n < kTsOwn; ++n) {
+            float xc;
             n_prop = n + 1;
-            if (u2 * msel < v * v) { xs = xc; break; }
+            if (propose(wb_own, n, e, msq, tot, xc)) { xs = xc; done = true; break; }
+        }
+        {
+            const int lane = threadIdx.x & 63, g = lane >> 3, r = lane & 7;
+            unsigned long long rem = __ballot(!done);
+            for (int pass = 0; pass < 64 && rem; ++pass) {
+                // group g serves the g-th walker of `rem`
+                unsigned long long mm = rem;
+                for (int i = 0; i < g; ++i) mm &= mm - 1;
+                const bool has = mm != 0;
+                const int src = has ? __ffsll((long long)mm) - 1 : lane;
+                float ew[32], mw[32];
+#pragma unroll
+                for (int j = 0; j < 32; ++j) { ew[j] = __shfl(e[j], src); mw[j] = __shfl(msq[j], src); }
+                const float totw = __shfl(tot, src);
+                const unsigned wlo = __shfl((unsigned)(wb_own & 0xFFFFFFFFull), src), whi = __shfl((unsigned)(wb_own >> 32), src);
+                const unsigned long long wbw = ((unsigned long long)whi << 32) | wlo;
+                float xw = __builtin_nanf("");
+                bool found = !has;
+                int rounds = 0;
+                for (int round = 0; round < (100000 - kTsOwn) / 8; ++round) {
+                    float xc = 0.0f;
+                    const bool acc = !found && propose(wbw, kTsOwn + round * 8 + r, ew, mw, totw, xc);
+                    const unsigned long long hits = __ballot(acc);
+                    const unsigned gh = (unsigned)(hits >> (8 * g)) & 0xFFu;
+                    const float xfirst = __shfl(xc, 8 * g + (gh ? __ffs((int)gh) - 1 : 0));
+                    if (!found) rounds = round + 1;
+                    if (!found && gh) { xw = xfirst; found = true; }
+                    if (__ballot(!found) == 0ull) break;
+                }
+                // the walkers served in this pass take their draws from the first lane of their group
+                const int rank = __popcll(rem & ((1ull << lane) - 1ull));
+                const float xmine = __shfl(xw, 8 * (rank & 7));
+                const int rmine = __shfl(rounds, 8 * (rank & 7));
+                if (!done && rank < 8) { xs = xmine; done = true; n_prop = kTsOwn + 8 * rmine; }
+                rem = __ballot(!done);
+            }
         }
         const float l0 = lat[b];
 #ifdef WF_TS_COUNT   // diagnostics build: the number of proposals of column 1 instead of its draw in the reported latent
@@ -2013,15 +2062,15 @@ int launch_tile_sample(const MfmaDev* mdev, const ModelDev& md, const float* tab
     const unsigned cond_blocks = (unsigned)std::min<int64_t>((n_tiles + kCondWaves - 1) / kCondWaves, 256 * 4);
     const int L = md.n_layers;
     if (draw) {
-        hipLaunchKernelGGL(k_tsample, dim3(lane_blocks), dim3(256), 0, s, a, 0, 0, (const float*)oj, u, B, cur0, cur1, cin, lat, latent, x);
+        hipLaunchKernelGGL(k_tsample<0>, dim3(lane_blocks), dim3(256), 0, s, a, 0, (const float*)oj, u, B, cur0, cur1, cin, lat, latent, x);
         hipLaunchKernelGGL(k_etile_cond<true>, dim3(cond_blocks), dim3(kCondWaves * 64), lds_bytes, s, *mdev, L, (const float*)cin, B, oj, s1);
-        hipLaunchKernelGGL(k_tsample, dim3(lane_blocks), dim3(256), 0, s, a, 1, 0, (const float*)oj, u, B, cur0, cur1, cin, lat, latent, x);
+        hipLaunchKernelGGL(k_tsample<1>, dim3(lane_blocks), dim3(256), 0, s, a, 0, (const float*)oj, u, B, cur0, cur1, cin, lat, latent, x);
     } else {
-        hipLaunchKernelGGL(k_tsample, dim3(lane_blocks), dim3(256), 0, s, a, 3, 0, (const float*)oj, u, B, cur0, cur1, cin, lat, latent, x);
+        hipLaunchKernelGGL(k_tsample<3>, dim3(lane_blocks), dim3(256), 0, s, a, 0, (const float*)oj, u, B, cur0, cur1, cin, lat, latent, x);
     }
     for (int l = L - 1; l >= 0; --l) {
         hipLaunchKernelGGL(k_etile_cond<false>, dim3(cond_blocks), dim3(kCondWaves * 64), lds_bytes, s, *mdev, l, (const float*)cin, B, oj, s1);
-        hipLaunchKernelGGL(k_tsample, dim3(lane_blocks), dim3(256), 0, s, a, 2, l, (const float*)oj, u, B, cur0, cur1, cin, lat, latent, x);
+        hipLaunchKernelGGL(k_tsample<2>, dim3(lane_blocks), dim3(256), 0, s, a, l, (const float*)oj, u, B, cur0, cur1, cin, lat, latent, x);
     }
     return check();
 }
