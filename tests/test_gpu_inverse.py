@@ -237,8 +237,10 @@ def test_staged_sampler_of_large_batches(he_flat, monkeypatch):
     # more walkers than one pass of the scratch holds (2^18): the same walkers as a prefix of the larger batch drew
     monkeypatch.setenv("WF_SAMPLE_TILE_MIN", "16384")
     big = m.sample(21, (1 << 18) + 5000, exact=True)
-    small = m.sample(21, 40000, exact=True)
-    assert torch.equal(big[:40000], small) and torch.isfinite(big).all()
+    # (40 010 walkers end in a partial wave, whose lanes each finish their own rejection loop; in the larger batch the same walkers sit in a full
+    # wave, where the unfinished ones are served by groups of eight lanes: the same draws either way)
+    small = m.sample(21, 40010, exact=True)
+    assert torch.equal(big[:40010], small) and torch.isfinite(big).all()
     tail = m.sample(21, (1 << 18) + 5000, exact=True)[(1 << 18):]
     assert torch.equal(tail, big[(1 << 18):]) and tail.std().item() > 0.5
     # a model outside the family (first-type box) keeps the other kernels: the switch changes nothing

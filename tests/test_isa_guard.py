@@ -25,3 +25,13 @@ def test_the_scanner_sees_packed_fp32_code_where_it_exists(monkeypatch):
 
 def test_mfma_translation_units_are_built_with_the_rule():
     assert "-fno-slp-vectorize" in wf_build.MFMA_FLAGS and "-packed-fp32-ops" in wf_build.MFMA_FLAGS
+
+
+def test_every_translation_unit_is_built_with_preallocated_sgpr_spill_vgprs():
+    """DESIGN.md section 9 (round 3): SGPRs spilled into lazily allocated VGPR lanes lost values at random in k_sample<2, 64>; the flag that ends it
+    belongs to the flags of every translation unit, and the recorded flags of the built objects say so."""
+    import os
+    flags = wf_build.FLAGS
+    assert "-amdgpu-prealloc-sgpr-spill-vgprs" in flags and flags[flags.index("-amdgpu-prealloc-sgpr-spill-vgprs") - 1] == "-mllvm"
+    wf_build.build()
+    assert os.path.exists(wf_build.STAMP) and "-amdgpu-prealloc-sgpr-spill-vgprs" in open(wf_build.STAMP).read()

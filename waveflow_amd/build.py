@@ -15,6 +15,11 @@ SOURCES = ["wf_tables.cpp", "wf_model.cpp", "wf_kernels_scalar.hip", "wf_scalar_
 # -ffp-contract=off: the index arithmetic and the table lerp keep the reference's separate
 # multiply / add roundings; dot products that may fuse say so with explicit fmaf / MFMA.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+# SGPRs that do not fit are spilled into the lanes of VGPRs (v_writelane_b32 / v_readlane_b32).  With the compiler's default, lazily allocated spill
+# VGPRs the one-lane-per-walker sampler of 33 .. 64 bases (k_sample<2, 64>: 427 such spills, a divergent rejection loop) lost values at random --
+# NaN draws for 2 - 40 % of the walkers, other ones from run to run, the code object byte-identical to a build that had worked.
+# Pre-allocated spill VGPRs end it; every translation unit is built this way (scratch/sgpr_spill_scan.py lists the kernels that spill).
+FLAGS += ["-mllvm", "-amdgpu-prealloc-sgpr-spill-vgprs"]
 FLAGS += os.environ.get("WF_CXXFLAGS", "").split()  # experiment switches (-DWF_...)
 # No packed-FP32 VALU code (v_pk_fma_f32 ...) in the translation units of the MFMA kernels: wf_mfma_impl.h, DESIGN.md §9.  The SLP
 # vectorizer is one source of it, instruction selection of two-element float vectors another (the box transform's differences came out as

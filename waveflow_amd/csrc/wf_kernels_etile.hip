@@ -1812,7 +1812,14 @@ __global__ __launch_bounds__(256, 2) void k_tsample(const TsArgs a, int layer, c
             n_prop = n + 1;
             if (propose(wb_own, n, e, msq, tot, xc)) { xs = xc; done = true; break; }
         }
-        {
+        if (__ballot(true) != ~0ull) {
+            // the batch's last, partial wave: lanes are missing from the groups, every walker keeps its own lane
+            for (int n = kTsOwn; n < 100000 && !done; ++n) {
+                float xc;
+                n_prop = n + 1;
+                if (propose(wb_own, n, e, msq, tot, xc)) { xs = xc; done = true; }
+            }
+        } else {
             const int lane = threadIdx.x & 63, g = lane >> 3, r = lane & 7;
             unsigned long long rem = __ballot(!done);
             for (int pass = 0; pass < 64 && rem; ++pass) {
