@@ -154,7 +154,7 @@ bool energy_tile_fused(const MfmaDev* mdev);
 // parameter gradients of psi and its Laplacian on the matrix cores (two-particle family, <= 32 bases; wf_kernels_etile.hip: k_ebwd, k_ewgrad)
 bool energy_vjp_capable(const MfmaDev* mdev);
 int64_t energy_vjp_floats_per_walker(int n_nets);
-int64_t energy_vjp_fixed_floats();
+int64_t energy_vjp_fixed_floats(int n_nets);
 int energy_vjp_gacc_floats(int n_nets);
 int launch_energy_vjp(const MfmaDev* mdev, const ModelDev& md, const float* tabI4, const float* tabP4, const float* x, int64_t B, int mode, const float* w_psi,
                       const float* w_lap, const Protons& pr, float running_avg, const float* running_avg_dev, float inv_count, float* e_loc, float* ws,

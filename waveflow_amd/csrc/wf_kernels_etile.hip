@@ -1521,12 +1521,15 @@ __global__ __launch_bounds__(256, 2) void k_ewgrad(const float* __restrict__ dum
     if (blockIdx.y == 0) ewgrad_job0(img, dump, t0, t1, net_img, g);
     else ewgrad_job1(img, dump, t0, t1, g);
 }
+// (one launch for the nets of a chunk: blockIdx.y = net; partial [n_nets][kESplit][kGFloats], gacc [n_nets][kGFloats])
 __global__ void k_egrad_reduce(const float* __restrict__ partial, int accumulate, float* __restrict__ gacc) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= kGFloats) return;
-    float sacc = accumulate ? gacc[i] : 0.0f;
-    for (int p = 0; p < kESplit; ++p) sacc += partial[(size_t)p * kGFloats + i];
-    gacc[i] = sacc;
+    const float* pn = partial + (size_t)blockIdx.y * kESplit * kGFloats;
+    float* gn = gacc + (size_t)blockIdx.y * kGFloats;
+    float sacc = accumulate ? gn[i] : 0.0f;
+    for (int p = 0; p < kESplit; ++p) sacc += pn[(size_t)p * kGFloats + i];
+    gn[i] = sacc;
 }
 struct ENetOff {
     int W0, b0, W1, b1, W2, b2, NO, n_out;
@@ -1963,7 +1966,7 @@ int launch_energy_tile(const MfmaDev* mdev, const ModelDev& md, const float* tab
 bool energy_vjp_capable(const MfmaDev* mdev) { return mdev->timg_off >= 0 && mdev->nbk == 1 && energy_tile_fused(mdev) && !mdev->p_bias && !mdev->i_gate && !mdev->p_gate; }
 // floats of workspace per walker of a chunk (whole tiles), + the fixed part
 int64_t energy_vjp_floats_per_walker(int n_nets) { return (int64_t)n_nets * 12 + 12 + 4 + kDumpFloats / 32; }
-int64_t energy_vjp_fixed_floats() { return (int64_t)kESplit * kGFloats + kDumpFloats + 128; }
+int64_t energy_vjp_fixed_floats(int n_nets) { return (int64_t)n_nets * kESplit * kGFloats + kDumpFloats + 128; }
 int energy_vjp_gacc_floats(int n_nets) { return n_nets * kGFloats; }
 
 // One chunk of walkers (B a multiple of 32 except for the last chunk of a batch): forward with the per-net input jets, seeds (mode 2: from H psi of
@@ -2003,9 +2006,10 @@ int launch_energy_vjp(const MfmaDev* mdev, const ModelDev& md, const float* tabI
             hipLaunchKernelGGL(k_ebwd<true>, dim3(blocks), dim3(kBwdWaves * 64), lds_bytes, s, *mdev, n, tabI4, tabP4, st_n, adjb, w_psi, w_lap, B, dump);
         else
             hipLaunchKernelGGL(k_ebwd<false>, dim3(blocks), dim3(kBwdWaves * 64), lds_bytes, s, *mdev, n, tabI4, tabP4, st_n, adjb, w_psi, w_lap, B, dump);
-        hipLaunchKernelGGL(k_ewgrad, dim3(kESplit, 2), dim3(256), 0, s, (const float*)dump, n_tiles, mdev->image + (size_t)n * mdev->net_floats, partial);
-        hipLaunchKernelGGL(k_egrad_reduce, dim3((kGFloats + 255) / 256), dim3(256), 0, s, (const float*)partial, accumulate, gacc + (size_t)n * kGFloats);
+        hipLaunchKernelGGL(k_ewgrad, dim3(kESplit, 2), dim3(256), 0, s, (const float*)dump, n_tiles, mdev->image + (size_t)n * mdev->net_floats,
+                           partial + (size_t)n * kESplit * kGFloats);
     }
+    hipLaunchKernelGGL(k_egrad_reduce, dim3((kGFloats + 255) / 256, n_nets), dim3(256), 0, s, (const float*)partial, accumulate, gacc);
     return check();
 }
 

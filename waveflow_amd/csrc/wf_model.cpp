@@ -1617,7 +1617,7 @@ static int run_vjp_chunks(const wf_model* m, int mode, bool second_order, const 
         const wf_model_desc& d = m->desc;
         const bool family = D == 2 && m->nbp == 32 && m->mfma_ok && d.box_kind == WF_BOX_MEAN && d.layer_kind == WF_LAYER_IMADE && d.n_flow_layers > 0 &&
                             d.prior_kind == WF_PRIOR_WAVEFLOW && m->d_tabI4c && m->d_tabP4c && !m->eval_tables_stale && energy_vjp_capable(&m->mdev);
-        const int64_t per = energy_vjp_floats_per_walker(n_nets) * (int64_t)sizeof(float), fixed = energy_vjp_fixed_floats() * (int64_t)sizeof(float);
+        const int64_t per = energy_vjp_floats_per_walker(n_nets) * (int64_t)sizeof(float), fixed = energy_vjp_fixed_floats(n_nets) * (int64_t)sizeof(float);
         const int64_t tchunk = workspace_bytes > fixed ? ((workspace_bytes - fixed) / per) / 32 * 32 : 0;
         if (family && tile_min > 0 && B >= tile_min && tchunk >= 32) {
             Protons none{};
