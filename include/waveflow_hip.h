@@ -196,7 +196,7 @@ int wf_inverse_fwd(const wf_model* m, const float* u_dev, int64_t B, float* x_de
  * results are reproducible for a given seed but do not follow JAX's threefry stream (parity unpinned).  The rejection loop of a
  * column is bounded (~1e5 proposals, where the reference's while_loop is not): a walker that exhausts it is written as NaN.
  * Three kernels share the work: one walker per wave (small and medium batches), one lane per walker (other large batches), and for
- * batches >= 16384 of two-particle models with <= 32 bases the staged form (wf_kernels_etile.hip: conditioners on the matrix cores, the
+ * batches >= 16384 of two-particle models with <= 64 bases the staged form (wf_kernels_etile.hip: conditioners on the matrix cores, the
  * mesh searches one lane per walker; WF_SAMPLE_TILE_MIN moves the switch); the same holds for wf_inverse_fwd.  The kernels draw from the
  * same law with their own proposal sequences, so the walkers of a seed change across the switch points. */
 int wf_sample(const wf_model* m, uint64_t seed, int64_t B, float* x_dev, float* latent_dev, int32_t exact, void* stream);

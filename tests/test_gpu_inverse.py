@@ -250,3 +250,42 @@ def test_staged_sampler_of_large_batches(he_flat, monkeypatch):
     a = lp1.model.sample(5, 20000, exact=True)
     monkeypatch.setenv("WF_SAMPLE_TILE_MIN", "0")
     assert torch.equal(a, lp1.model.sample(5, 20000, exact=True))
+
+
+def test_staged_sampler_with_two_row_blocks(monkeypatch):
+    """The staged large-batch sampler on 33 knots at k = 6 (39 / 38 bases: two 32-row blocks per dimension, BASELINE's "32-bin" variant): inverse
+    against the one-walker-per-wave kernel on the same latent points, round trip through the forward pass, draws against the wave kernel's."""
+    import torch
+    from scipy import stats
+    from waveflow_amd import model_factory
+    init_fun = model_factory.get_waveflow_model(2, base_spline_degree=6, i_spline_degree=6, n_prior_internal_knots=33,
+                                                n_i_internal_knots=33, i_spline_reg=0.05, i_spline_reverse_fun_tol=1e-6,
+                                                n_flow_layers=2, box_size=10, xu_coord_type="mean")
+    params, psi, log_pdf, sample = init_fun(3, 2)
+    m = psi.model
+    m.ensure_params(params)
+    assert (m.i_nb, m.p_nb) == (39, 38)
+    u = np.random.default_rng(5).uniform(0.01, 0.99, size=(20001, 2)).astype(np.float32)
+    for exact in (True, False):
+        monkeypatch.setenv("WF_SAMPLE_TILE_MIN", "16384")
+        xs = m.inverse(u, exact=exact)
+        monkeypatch.setenv("WF_SAMPLE_TILE_MIN", "0")
+        monkeypatch.setenv("WF_WAVE_SAMPLE_MAX", "100000000")
+        xw = m.inverse(u, exact=exact)
+        assert np.isfinite(xs).all() and not np.array_equal(xs, xw)
+        d = np.abs(xs - xw)
+        assert np.median(d) < 2e-6 and np.quantile(d, 0.999) < 4e-4 and d.max() < 2e-3, (exact, np.median(d), d.max())
+        if exact:
+            u2, _ = m.flow(xs)
+            assert np.median(np.abs(u2 - u)) < 2e-5 and np.abs(u2 - u).max() < 5e-3
+    monkeypatch.setenv("WF_SAMPLE_TILE_MIN", "16384")
+    xa, la = m.sample(11, 60001, return_latent=True, exact=True)
+    assert torch.equal(xa, m.sample(11, 60001, exact=True)) and torch.isfinite(xa).all() and torch.isfinite(la).all()
+    ub, _ = m.flow(xa)
+    assert np.median(np.abs(ub.cpu().numpy() - la.cpu().numpy())) < 2e-5
+    monkeypatch.setenv("WF_SAMPLE_TILE_MIN", "0")
+    xb, lb = m.sample(13, 60000, return_latent=True, exact=True)
+    for c in range(2):
+        for a, b in ((xa, xb), (la, lb)):
+            p = stats.ks_2samp(a[:, c].cpu().numpy(), b[:, c].cpu().numpy()).pvalue
+            assert p > 1e-4, (c, p)

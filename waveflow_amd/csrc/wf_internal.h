@@ -192,7 +192,7 @@ int launch_wave_energy(const ModelDev& md, const ModelDev* md_dev, const float* 
                        int64_t B, const Protons& pr, float* hpsi, float* psi, float* lap, float* tail_ws, void* stream);
 // staged inverse / sampler of large two-particle batches (wf_kernels_etile.hip: conditioners on the matrix cores, one lane per walker elsewhere)
 bool tile_sample_capable(const MfmaDev* mdev);
-int64_t tile_sample_floats(int64_t B);
+int64_t tile_sample_floats(int64_t B, int nbk);
 int launch_tile_sample(const MfmaDev* mdev, const ModelDev& md, const float* tabI0, const float* tabP0, const float* fk_nat, int draw, unsigned long long seed,
                        const float* u, int64_t B, float* x, float* latent, int exact, const unsigned long long* seed_offset_dev, int64_t b0, float* ws, void* stream);
 int launch_wave_sample(const ModelDev& md, const ModelDev* md_dev, const float* tabI4, const float* tabP4, const float* fk_nat, int draw,

@@ -283,24 +283,28 @@ __device__ __forceinline__ void prior_c_block(const _Float16* obh, const Frag (&
     }
 }
 // the whole conditioner for <= 32 bases (the launch-per-net path): head triples (PRIOR: of c) in a0, the sum of the raw outputs in s1
-template <bool PRIOR>
-__device__ __forceinline__ void cond_net(const float* net, const float* fkP, const _Float16* obh, float u0v, float u1v, int lane, f32x16 (&a0)[NCH], float& s1) {
+template <bool PRIOR, int NBK = 1>
+__device__ __forceinline__ void cond_net(const float* net, const float* fkP, const _Float16* obh, float u0v, float u1v, int lane, f32x16 (&a0)[NBK][NCH], float& s1) {
     Frag f[NCH][2];
     int e[NCH];
-    cond_hidden<1>(net, u0v, u1v, lane, f, e);
+    cond_hidden<NBK>(net, u0v, u1v, lane, f, e);
     if (!PRIOR) {
-        cond_out<1>(net, f, e, 0, lane, a0);
+#pragma unroll
+        for (int kb = 0; kb < NBK; ++kb) cond_out<NBK>(net, f, e, kb, lane, a0[kb]);
     } else {
-        f32x16 o[1][NCH];
-        cond_out<1>(net, f, e, 0, lane, o[0]);
-        Frag of[1][NCH];
+        f32x16 o[NBK][NCH];
+#pragma unroll
+        for (int kb = 0; kb < NBK; ++kb) cond_out<NBK>(net, f, e, kb, lane, o[kb]);
+        Frag of[NBK][NCH];
         int eo[NCH];
-        prior_frags<1>(o, fkP, lane, of, eo, s1);
-        prior_c_block<1>(obh, of, eo, 0, lane, a0);
+        prior_frags<NBK>(o, fkP, lane, of, eo, s1);
+#pragma unroll
+        for (int kb = 0; kb < NBK; ++kb) prior_c_block<NBK>(obh, of, eo, kb, lane, a0[kb]);
     }
 }
 
-template <bool PRIOR>
+// NBK row blocks per dimension: the head outputs go out as oj[tile][row 0 .. 32 NBK)[channel][32 walkers] (NBK = 2: the staged sampler of 33 .. 64 bases)
+template <bool PRIOR, int NBK = 1>
 __global__ __launch_bounds__(kCondWaves * 64, WF_ETILE_OCC) void k_etile_cond(const MfmaDev mm, int net_index, const float* __restrict__ st, int64_t B,
                                                                 float* __restrict__ oj, float* __restrict__ s1buf) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -311,8 +315,8 @@ __global__ __launch_bounds__(kCondWaves * 64, WF_ETILE_OCC) void k_etile_cond(co
     stage_floats<kThreads>(mm.image + (size_t)net_index * mm.net_floats, lds + mm.const_floats, mm.net_floats);
     __syncthreads();
     const float* net = lds + mm.const_floats;
-    const float* fkP = lds + 32;
-    const _Float16* obh = reinterpret_cast<const _Float16*>(lds + 64);
+    const float* fkP = lds + 32 * NBK;
+    const _Float16* obh = reinterpret_cast<const _Float16*>(lds + 64 * NBK);
     const int lane = threadIdx.x & 63;
     const int j = lane & 31, h = lane >> 5;
     const int64_t n_tiles = (B + 31) >> 5;
@@ -328,22 +332,24 @@ __global__ __launch_bounds__(kCondWaves * 64, WF_ETILE_OCC) void k_etile_cond(co
         const bool valid = w < B;
         const int64_t wl = valid ? w : B - 1;
         const float u0v = st[wl], u1v = st[(int64_t)4 * B + wl];
-        f32x16 a0[NCH];
+        f32x16 a0[NBK][NCH];
         float s1 = 0.0f;
-        cond_net<PRIOR>(net, fkP, obh, u0v, u1v, lane, a0, s1);
+        cond_net<PRIOR, NBK>(net, fkP, obh, u0v, u1v, lane, a0, s1);
         if (PRIOR && valid && h == 0) s1buf[w] = s1;
-        // ---- store: oj[tile][row][c][32 walkers] (one contiguous 12 KB block per tile), row = accumulator row of register r in lane half h
+        // ---- store: oj[tile][row][c][32 walkers] (one contiguous block per tile), row = accumulator row of register r in lane half h of block kb
 #ifdef WF_ABL_OJ   // ablation build (timing only): the head triples are computed, not stored
-        if (valid && a0[0][0] == 12345.678f) {
+        if (valid && a0[0][0][0] == 12345.678f) {
 #else
         if (valid) {
 #endif
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            for (int kb = 0; kb < NBK; ++kb)
 #pragma unroll
-                for (int c = 0; c < NCH; ++c) oj[(tile * (32 * NCH) + row * NCH + c) * 32 + j] = a0[c][r];
-            }
+                for (int r = 0; r < 16; ++r) {
+                    const int row = 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * h;
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) oj[(tile * (32 * NBK * NCH) + row * NCH + c) * 32 + j] = a0[kb][c][r];
+                }
         }
     }
 }
@@ -1655,11 +1661,12 @@ __device__ __forceinline__ float inv_comp(const float4_t* __restrict__ comp, int
     mesh_search([&](int i) { return comp[i].x; }, n_mesh - 1, y, m, yl, yr);
     return grid_root([&](float x) { return comp_lerp_x(comp, x, n_mesh); }, m, yl, yr, y, n_mesh - 1, tol);
 }
-__device__ __forceinline__ float rows_dot(const float* __restrict__ row, const float (&c)[32]) {   // sum_j c_j row[j], j ascending
+template <int NB>
+__device__ __forceinline__ float rows_dot(const float* __restrict__ row, const float (&c)[NB]) {   // sum_j c_j row[j], j ascending
     const float4_t* r4 = reinterpret_cast<const float4_t*>(row);
     float acc = 0.0f;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < NB / 4; ++q) {
         const float4_t t = r4[q];
         acc = __builtin_fmaf(c[4 * q], t.x, acc);
         acc = __builtin_fmaf(c[4 * q + 1], t.y, acc);
@@ -1668,13 +1675,14 @@ __device__ __forceinline__ float rows_dot(const float* __restrict__ row, const f
     }
     return acc;
 }
-__device__ __forceinline__ float rows_lerp(const float* __restrict__ tab0, const float (&c)[32], float x, int n_mesh) {
+template <int NB>
+__device__ __forceinline__ float rows_lerp(const float* __restrict__ tab0, const float (&c)[NB], float x, int n_mesh) {
     const LerpN L = nlerp(x, n_mesh);
-    const float4_t* ra = reinterpret_cast<const float4_t*>(tab0 + (size_t)L.il * 32);
-    const float4_t* rb = reinterpret_cast<const float4_t*>(tab0 + (size_t)L.ir * 32);
+    const float4_t* ra = reinterpret_cast<const float4_t*>(tab0 + (size_t)L.il * NB);
+    const float4_t* rb = reinterpret_cast<const float4_t*>(tab0 + (size_t)L.ir * NB);
     float acc = 0.0f;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < NB / 4; ++q) {
         const float4_t a = ra[q], b = rb[q];
         acc = __builtin_fmaf(c[4 * q], __builtin_fmaf(b.x - a.x, L.t, a.x), acc);
         acc = __builtin_fmaf(c[4 * q + 1], __builtin_fmaf(b.y - a.y, L.t, a.y), acc);
@@ -1683,20 +1691,23 @@ __device__ __forceinline__ float rows_lerp(const float* __restrict__ tab0, const
     }
     return acc;
 }
-__device__ __forceinline__ float inv_rows(const float* __restrict__ tab0, const float (&c)[32], int n_mesh, float y, float tol) {
+template <int NB>
+__device__ __forceinline__ float inv_rows(const float* __restrict__ tab0, const float (&c)[NB], int n_mesh, float y, float tol) {
     int m;
     float yl, yr;
-    mesh_search([&](int i) { return rows_dot(tab0 + (size_t)i * 32, c); }, n_mesh - 1, y, m, yl, yr);
-    return grid_root([&](float x) { return rows_lerp(tab0, c, x, n_mesh); }, m, yl, yr, y, n_mesh - 1, tol);
+    mesh_search([&](int i) { return rows_dot<NB>(tab0 + (size_t)i * NB, c); }, n_mesh - 1, y, m, yl, yr);
+    return grid_root([&](float x) { return rows_lerp<NB>(tab0, c, x, n_mesh); }, m, yl, yr, y, n_mesh - 1, tol);
 }
-// channel 0 of the head outputs of walker b: oj[tile][row][channel][32 walkers]
-__device__ __forceinline__ float oj0(const float* __restrict__ oj, int64_t b, int row) { return oj[((b >> 5) * (32 * NCH) + row * NCH) * 32 + (b & 31)]; }
+// channel 0 of the head outputs of walker b: oj[tile][row 0 .. NB)[channel][32 walkers]
+template <int NB>
+__device__ __forceinline__ float oj0(const float* __restrict__ oj, int64_t b, int row) { return oj[((b >> 5) * (NB * NCH) + row * NCH) * 32 + (b & 31)]; }
 
 // phase 0: prior column 0;  1: prior column 1, then the last layer's dimension 0;  2: dimension 1 of layer `layer`, then dimension 0 of the layer before it
 // (layer 0: the box reverse and the result);  3: entry of a plain inverse (latent given): the last layer's dimension 0.
 // Between the phases: cur0 = the inverted dimension 0, cur1 = the value waiting for dimension 1, cin = what the conditioner of the next launch sees
 // (exact: the inverted prefix; reference mode, made.py:88: the value being inverted).
-template <int PHASE>
+// NB: padded bases per dimension (32, or 64: two row blocks -- there the rejection loop of the second column stays on the walker's own lane)
+template <int PHASE, int NB>
 __global__ __launch_bounds__(256, 2) void k_tsample(const TsArgs a, int layer, const float* __restrict__ oj, const float* __restrict__ ug, int64_t B,
                                                  float* __restrict__ cur0, float* __restrict__ cur1, float* __restrict__ cin, float* __restrict__ lat,
                                                  float* __restrict__ latent_out, float* __restrict__ xg) {
@@ -1751,39 +1762,39 @@ __global__ __launch_bounds__(256, 2) void k_tsample(const TsArgs a, int layer, c
     }
     if (phase == 1) {
         // e = c / |c| with c = (o keep) @ ob_to_b from the conditioner launch; bound max_i ((e @ b_to_ob)_i)^2 (bsplines_jax.py:164-166)
-        float e[32];
+        float e[NB];
         float ss = 0.0f;
 #pragma unroll
-        for (int j = 0; j < 32; ++j) { e[j] = j < a.nbP ? oj0(oj, b, j) : 0.0f; ss = __builtin_fmaf(e[j], e[j], ss); }
+        for (int j = 0; j < NB; ++j) { e[j] = j < a.nbP ? oj0<NB>(oj, b, j) : 0.0f; ss = __builtin_fmaf(e[j], e[j], ss); }
         const float rn = 1.0f / sqrtf(ss);
 #pragma unroll
-        for (int j = 0; j < 32; ++j) e[j] = e[j] * rn;
+        for (int j = 0; j < NB; ++j) e[j] = e[j] * rn;
         // q = e @ b_to_ob are the coefficients of this column's factor f = sum_i q_i b_i in the plain B-splines (non-negative, summing to one), so
         // |f| <= max_i |q_i| (the reference's bound, bsplines_jax.py:164-166) and, on the knot interval s where only b_s .. b_{s + k} live,
         // |f| <= M_s = max(|q_s| .. |q_{s + k}|).  Proposals are drawn from the piecewise-constant envelope M_s^2 (one uniform picks the interval and the
         // point in it) and accepted against M_s^2: the same law as the reference's uniform proposals under the global bound, at 5 - 8 x its acceptance rate.
-        float aq[32];
+        float aq[NB];
 #pragma unroll
-        for (int i = 0; i < 32; ++i) {
+        for (int i = 0; i < NB; ++i) {
             float acc = 0.0f;
 #pragma unroll
-            for (int j = 0; j < 32; ++j) acc = __builtin_fmaf(e[j], a.b_to_ob[j * 32 + i], acc);
+            for (int j = 0; j < NB; ++j) acc = __builtin_fmaf(e[j], a.b_to_ob[j * NB + i], acc);
             aq[i] = i < a.nbP ? acc * acc : 0.0f;
         }
         const int n_int = a.nbP - a.degP;       // knot intervals of equal width on [0, 1] (knots: linspace, the end knots (k + 1)-fold)
-        float msq[32], tot = 0.0f;
+        float msq[NB], tot = 0.0f;
 #pragma unroll
-        for (int sI = 0; sI < 32; ++sI) {
+        for (int sI = 0; sI < NB; ++sI) {
             float mx = 0.0f;
 #pragma unroll
             for (int d = 0; d <= 8; ++d)
-                if (sI + d < 32 && d <= a.degP) mx = fmaxf(mx, aq[sI + d]);
+                if (sI + d < NB && d <= a.degP) mx = fmaxf(mx, aq[sI + d]);
             msq[sI] = sI < n_int ? mx : 0.0f;
             tot += msq[sI];
         }
         const float wI = 1.0f / (float)n_int;
         // one proposal (number n of walker wb's sequence) against the envelope (mq, mtot) of the factor with coefficients ec
-        auto propose = [&](unsigned long long wb, int n, const float (&ec)[32], const float (&mq)[32], float mtot, float& xc) {
+        auto propose = [&](unsigned long long wb, int n, const float (&ec)[NB], const float (&mq)[NB], float mtot, float& xc) {
             Philox4 prop(seed, wb);
             prop.c0 = (unsigned)n;
             prop.c1 = 2u;
@@ -1791,7 +1802,7 @@ __global__ __launch_bounds__(256, 2) void k_tsample(const TsArgs a, int layer, c
             float run = 0.0f, base = 0.0f, msel = mq[0];
             int ssel = 0;
 #pragma unroll
-            for (int sI = 0; sI < 32; ++sI) {   // (the last interval with a positive bound catches t == mtot)
+            for (int sI = 0; sI < NB; ++sI) {   // (the last interval with a positive bound catches t == mtot)
                 const bool hit = t >= run && mq[sI] > 0.0f;
                 ssel = hit ? sI : ssel;
                 base = hit ? run : base;
@@ -1799,7 +1810,7 @@ __global__ __launch_bounds__(256, 2) void k_tsample(const TsArgs a, int layer, c
                 run += mq[sI];
             }
             xc = fminf(((float)ssel + fminf((t - base) / msel, 1.0f)) * wI, 0.99999994f);
-            const float v = rows_lerp(a.tabP0, ec, xc, n_mesh);
+            const float v = rows_lerp<NB>(a.tabP0, ec, xc, n_mesh);
             return u2 * msel < v * v;
         };
         // Stage A: every lane proposes for its own walker, kTsOwn times at most (88 % of the walkers are done by then).  Stage B: the wave's remaining
@@ -1815,8 +1826,9 @@ __global__ __launch_bounds__(256, 2) void k_tsample(const TsArgs a, int layer, c
             n_prop = n + 1;
             if (propose(wb_own, n, e, msq, tot, xc)) { xs = xc; done = true; break; }
         }
-        if (__ballot(true) != ~0ull) {
-            // the batch's last, partial wave: lanes are missing from the groups, every walker keeps its own lane
+        if (NB > 32 || __ballot(true) != ~0ull) {
+            // the batch's last, partial wave: lanes are missing from the groups, every walker keeps its own lane (and with two row blocks the
+            // coefficients of a walker are too many to hand to other lanes)
             for (int n = kTsOwn; n < 100000 && !done; ++n) {
                 float xc;
                 n_prop = n + 1;
@@ -1831,9 +1843,9 @@ __global__ __launch_bounds__(256, 2) void k_tsample(const TsArgs a, int layer, c
                 for (int i = 0; i < g; ++i) mm &= mm - 1;
                 const bool has = mm != 0;
                 const int src = has ? __ffsll((long long)mm) - 1 : lane;
-                float ew[32], mw[32];
+                float ew[NB], mw[NB];
 #pragma unroll
-                for (int j = 0; j < 32; ++j) { ew[j] = __shfl(e[j], src); mw[j] = __shfl(msq[j], src); }
+                for (int j = 0; j < NB; ++j) { ew[j] = __shfl(e[j], src); mw[j] = __shfl(msq[j], src); }
                 const float totw = __shfl(tot, src);
                 const unsigned wlo = __shfl((unsigned)(wb_own & 0xFFFFFFFFull), src), whi = __shfl((unsigned)(wb_own >> 32), src);
                 const unsigned long long wbw = ((unsigned long long)whi << 32) | wlo;
@@ -1868,12 +1880,12 @@ __global__ __launch_bounds__(256, 2) void k_tsample(const TsArgs a, int layer, c
         return;
     }
     // phase 2: c_j = g_j (v_j / S0 + reg) / Q (calculate_bijection_params + reg, remove_bias, boundary map), v_j = 1 / (2^o_j + 1)
-    float c[32];
+    float c[NB];
     float S0 = 0.0f, Qv = 0.0f, G = 0.0f;
 #pragma unroll
-    for (int j = 0; j < 32; ++j) {
+    for (int j = 0; j < NB; ++j) {
         const float g = a.gI[j];
-        const float v = j < a.nbI ? r_of(oj0(oj, b, j)) : 0.0f;
+        const float v = j < a.nbI ? r_of(oj0<NB>(oj, b, j)) : 0.0f;
         c[j] = v;
         S0 += v;
         Qv = __builtin_fmaf(v, g, Qv);
@@ -1881,9 +1893,9 @@ __global__ __launch_bounds__(256, 2) void k_tsample(const TsArgs a, int layer, c
     }
     const float rS = 1.0f / S0, rQ = 1.0f / __builtin_fmaf(Qv, rS, a.i_reg * G);
 #pragma unroll
-    for (int j = 0; j < 32; ++j) c[j] = j < a.nbI ? (a.gI[j] * __builtin_fmaf(c[j], rS, a.i_reg)) * rQ : 0.0f;
+    for (int j = 0; j < NB; ++j) c[j] = j < a.nbI ? (a.gI[j] * __builtin_fmaf(c[j], rS, a.i_reg)) * rQ : 0.0f;
     const float o0 = cur0[b];
-    const float o1 = inv_rows(a.tabI0, c, n_mesh, cur1[b], a.tol);
+    const float o1 = inv_rows<NB>(a.tabI0, c, n_mesh, cur1[b], a.tol);
     if (layer > 0) {
         start_layer(layer - 1, o0, o1);
         return;
@@ -2029,23 +2041,50 @@ int launch_energy_vjp_finish(const float* gacc, int n_nets, const int* offs /* [
 
 // ---- host side of the staged inverse / sampler
 bool tile_sample_capable(const MfmaDev* mdev) {
-    return mdev->D == 2 && mdev->nbk == 1 && mdev->n_layers > 0 && mdev->n_layers < 8 && !mdev->p_bias && !mdev->i_gate && !mdev->p_gate && mdev->comp != nullptr;
+    return mdev->D == 2 && (mdev->nbk == 1 || mdev->nbk == 2) && mdev->n_layers > 0 && mdev->n_layers < 8 && !mdev->p_bias && !mdev->i_gate && !mdev->p_gate &&
+           mdev->comp != nullptr && (mdev->const_floats + mdev->net_floats) * 4 <= 160 * 1024 - 64;
 }
 // floats of workspace: conditioner input (5 B: the slot of the second input sits 4 B behind the first), cur0, cur1, the latent pair, the prior's sign sums,
-// the head outputs of whole tiles
-int64_t tile_sample_floats(int64_t B) { return B * 10 + ((B + 31) / 32) * 32 * (32 * NCH) + 64; }
+// the head outputs of whole tiles (32 nbk rows x 3 channels)
+int64_t tile_sample_floats(int64_t B, int nbk) { return B * 10 + ((B + 31) / 32) * 32 * (32 * nbk * NCH) + 64; }
 
-// draw == 0: x = inverse(u);  draw == 1: latent ~ prior (reported in `latent` if given), x = inverse(latent)
-int launch_tile_sample(const MfmaDev* mdev, const ModelDev& md, const float* tabI0, const float* tabP0, const float* fk_nat, int draw, unsigned long long seed,
-                       const float* u, int64_t B, float* x, float* latent, int exact, const unsigned long long* seed_offset_dev, int64_t b0, float* ws, void* stream) {
-    hipStream_t s = (hipStream_t)stream;
-    if (B == 0) return WF_OK;
+namespace {
+template <int NBK>
+int launch_tile_sample_t(const MfmaDev* mdev, const ModelDev& md, const TsArgs& a, int draw, const float* u, int64_t B, float* x, float* latent, float* ws, hipStream_t s) {
+    constexpr int NB = 32 * NBK;
     float* cin = ws;                 // [5][B]
     float* cur0 = cin + 5 * B;
     float* cur1 = cur0 + B;
     float* lat = cur1 + B;           // [B] (column 0 between the two prior phases)
     float* s1 = lat + 2 * B;
     float* oj = ws + (((size_t)10 * B + 63) / 64) * 64;
+    const unsigned lane_blocks = (unsigned)((B + 255) / 256);
+    const int lds_bytes = (mdev->const_floats + mdev->net_floats) * (int)sizeof(float);
+    static DynLdsSlots cfg_flow{}, cfg_prior{};
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(k_etile_cond<false, NBK>), lds_bytes, &cfg_flow)) return rc;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(k_etile_cond<true, NBK>), lds_bytes, &cfg_prior)) return rc;
+    const int64_t n_tiles = (B + 31) / 32;
+    const unsigned cond_blocks = (unsigned)std::min<int64_t>((n_tiles + kCondWaves - 1) / kCondWaves, 256 * 4);
+    const int L = md.n_layers;
+    if (draw) {
+        hipLaunchKernelGGL((k_tsample<0, NB>), dim3(lane_blocks), dim3(256), 0, s, a, 0, (const float*)oj, u, B, cur0, cur1, cin, lat, latent, x);
+        hipLaunchKernelGGL((k_etile_cond<true, NBK>), dim3(cond_blocks), dim3(kCondWaves * 64), lds_bytes, s, *mdev, L, (const float*)cin, B, oj, s1);
+        hipLaunchKernelGGL((k_tsample<1, NB>), dim3(lane_blocks), dim3(256), 0, s, a, 0, (const float*)oj, u, B, cur0, cur1, cin, lat, latent, x);
+    } else {
+        hipLaunchKernelGGL((k_tsample<3, NB>), dim3(lane_blocks), dim3(256), 0, s, a, 0, (const float*)oj, u, B, cur0, cur1, cin, lat, latent, x);
+    }
+    for (int l = L - 1; l >= 0; --l) {
+        hipLaunchKernelGGL((k_etile_cond<false, NBK>), dim3(cond_blocks), dim3(kCondWaves * 64), lds_bytes, s, *mdev, l, (const float*)cin, B, oj, s1);
+        hipLaunchKernelGGL((k_tsample<2, NB>), dim3(lane_blocks), dim3(256), 0, s, a, l, (const float*)oj, u, B, cur0, cur1, cin, lat, latent, x);
+    }
+    return check();
+}
+}  // namespace
+
+// draw == 0: x = inverse(u);  draw == 1: latent ~ prior (reported in `latent` if given), x = inverse(latent)
+int launch_tile_sample(const MfmaDev* mdev, const ModelDev& md, const float* tabI0, const float* tabP0, const float* fk_nat, int draw, unsigned long long seed,
+                       const float* u, int64_t B, float* x, float* latent, int exact, const unsigned long long* seed_offset_dev, int64_t b0, float* ws, void* stream) {
+    if (B == 0) return WF_OK;
     TsArgs a{};
     a.comp = mdev->comp;
     a.tabI0 = tabI0;
@@ -2064,26 +2103,8 @@ int launch_tile_sample(const MfmaDev* mdev, const ModelDev& md, const float* tab
     a.seed_offset_dev = seed_offset_dev;
     a.exact = exact;
     a.b0 = b0;
-    const unsigned lane_blocks = (unsigned)((B + 255) / 256);
-    const int lds_bytes = (mdev->const_floats + mdev->net_floats) * (int)sizeof(float);
-    static DynLdsSlots cfg_flow{}, cfg_prior{};
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(k_etile_cond<false>), lds_bytes, &cfg_flow)) return rc;
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(k_etile_cond<true>), lds_bytes, &cfg_prior)) return rc;
-    const int64_t n_tiles = (B + 31) / 32;
-    const unsigned cond_blocks = (unsigned)std::min<int64_t>((n_tiles + kCondWaves - 1) / kCondWaves, 256 * 4);
-    const int L = md.n_layers;
-    if (draw) {
-        hipLaunchKernelGGL(k_tsample<0>, dim3(lane_blocks), dim3(256), 0, s, a, 0, (const float*)oj, u, B, cur0, cur1, cin, lat, latent, x);
-        hipLaunchKernelGGL(k_etile_cond<true>, dim3(cond_blocks), dim3(kCondWaves * 64), lds_bytes, s, *mdev, L, (const float*)cin, B, oj, s1);
-        hipLaunchKernelGGL(k_tsample<1>, dim3(lane_blocks), dim3(256), 0, s, a, 0, (const float*)oj, u, B, cur0, cur1, cin, lat, latent, x);
-    } else {
-        hipLaunchKernelGGL(k_tsample<3>, dim3(lane_blocks), dim3(256), 0, s, a, 0, (const float*)oj, u, B, cur0, cur1, cin, lat, latent, x);
-    }
-    for (int l = L - 1; l >= 0; --l) {
-        hipLaunchKernelGGL(k_etile_cond<false>, dim3(cond_blocks), dim3(kCondWaves * 64), lds_bytes, s, *mdev, l, (const float*)cin, B, oj, s1);
-        hipLaunchKernelGGL(k_tsample<2>, dim3(lane_blocks), dim3(256), 0, s, a, l, (const float*)oj, u, B, cur0, cur1, cin, lat, latent, x);
-    }
-    return check();
+    return mdev->nbk == 1 ? launch_tile_sample_t<1>(mdev, md, a, draw, u, B, x, latent, ws, (hipStream_t)stream)
+                          : launch_tile_sample_t<2>(mdev, md, a, draw, u, B, x, latent, ws, (hipStream_t)stream);
 }
 
 }  // namespace wf

@@ -1434,15 +1434,15 @@ static bool tile_sample_ok(const wf_model* m, int64_t B) {
     const char* e = getenv("WF_SAMPLE_TILE_MIN");
     const int64_t mn = e ? atoll(e) : kTileSampleMin;
     const wf_model_desc& d = m->desc;
-    return mn > 0 && B >= mn && d.n_dim == 2 && m->nbp == 32 && m->mfma_ok && d.box_kind == WF_BOX_MEAN && d.layer_kind == WF_LAYER_IMADE && d.n_flow_layers > 0 &&
+    return mn > 0 && B >= mn && d.n_dim == 2 && m->nbp == 32 * m->mdev.nbk && m->mfma_ok && d.box_kind == WF_BOX_MEAN && d.layer_kind == WF_LAYER_IMADE && d.n_flow_layers > 0 &&
            d.prior_kind == WF_PRIOR_WAVEFLOW && !m->eval_tables_stale && m->d_tabI4 && m->d_tabP3 && m->dev.b_to_ob && m->d_grad_fk && tile_sample_capable(&m->mdev);
 }
 // in passes of what the workspace holds; a walker's stream is keyed by its index in the batch, whatever the passes
 static int run_tile_sample(const wf_model* m, int draw, uint64_t seed, const float* u_dev, int64_t B, float* x_dev, float* latent_dev, int exact,
                            const unsigned long long* counter_dev, float* ws, int64_t ws_floats, void* stream) {
     int64_t chunk = B;
-    while (chunk > 32 && tile_sample_floats(chunk) > ws_floats) chunk = ((chunk / 2) + 31) / 32 * 32;
-    if (tile_sample_floats(chunk) > ws_floats) return WF_ERR_INVALID;
+    while (chunk > 32 && tile_sample_floats(chunk, m->mdev.nbk) > ws_floats) chunk = ((chunk / 2) + 31) / 32 * 32;
+    if (tile_sample_floats(chunk, m->mdev.nbk) > ws_floats) return WF_ERR_INVALID;
     for (int64_t c0 = 0; c0 < B; c0 += chunk) {
         const int64_t bc = std::min(chunk, B - c0);
         int rc = launch_tile_sample(&m->mdev, m->dev, m->d_tabI4, m->d_tabP3, m->d_grad_fk, draw, (unsigned long long)seed, u_dev ? u_dev + c0 * 2 : nullptr, bc,
@@ -1463,7 +1463,7 @@ int wf_inverse_fwd(const wf_model* m, const float* u_dev, int64_t B, float* x_de
         return launch_nsc_model(m->nsc, 3, u_dev, B, m->d_scratch, x_dev, stream);
     }
     if (tile_sample_ok(m, B)) {
-        const int64_t fl = tile_sample_floats(std::min(B, kTileSampleChunk));
+        const int64_t fl = tile_sample_floats(std::min(B, kTileSampleChunk), m->mdev.nbk);
         rc = ensure_scratch(m, fl);
         if (rc) return rc;
         return run_tile_sample(m, 0, 0, u_dev, B, x_dev, nullptr, exact, nullptr, m->d_scratch, fl, stream);
@@ -1487,7 +1487,7 @@ int wf_sample(const wf_model* m, uint64_t seed, int64_t B, float* x_dev, float* 
         return launch_nsc_model(m->nsc, 3, z, B, m->d_scratch, x_dev, stream);
     }
     if (tile_sample_ok(m, B)) {
-        const int64_t fl = tile_sample_floats(std::min(B, kTileSampleChunk));
+        const int64_t fl = tile_sample_floats(std::min(B, kTileSampleChunk), m->mdev.nbk);
         rc = ensure_scratch(m, fl);
         if (rc) return rc;
         return run_tile_sample(m, 1, seed, nullptr, B, x_dev, latent_dev, exact, nullptr, m->d_scratch, fl, stream);
@@ -1752,7 +1752,7 @@ int64_t wf_vqmc_train_step_workspace_bytes(const wf_model* m, int64_t batch) {
     if (!m->d_grad_map || !m->grad_psi_ok || !m->wave_ok || (batch > kWaveSampleMax && !tile_sample_ok(m, batch))) return WF_ERR_UNSUPPORTED;
     // (the staged sampler of large batches works in the gradient's workspace before the gradient needs it)
     return align256(batch * m->desc.n_dim * 4) + align256(batch * 4) + align256(m->n_params * 4) + 256 + align256(block_sums_ws_bytes(batch)) +
-           std::max<int64_t>(vjp_ws_bytes(m, batch, true), tile_sample_ok(m, batch) ? align256(tile_sample_floats(std::min(batch, kTileSampleChunk)) * 4) : 0);
+           std::max<int64_t>(vjp_ws_bytes(m, batch, true), tile_sample_ok(m, batch) ? align256(tile_sample_floats(std::min(batch, kTileSampleChunk), m->mdev.nbk) * 4) : 0);
 }
 
 int wf_vqmc_train_step(wf_model* m, const wf_train_state* st, uint64_t seed, int64_t batch, const float* protons_host, int32_t n_protons,
