@@ -289,3 +289,44 @@ def test_staged_sampler_with_two_row_blocks(monkeypatch):
         for a, b in ((xa, xb), (la, lb)):
             p = stats.ks_2samp(a[:, c].cpu().numpy(), b[:, c].cpu().numpy()).pvalue
             assert p > 1e-4, (c, p)
+
+
+def test_staged_sampler_other_models(monkeypatch):
+    """The staged sampler on models with derivative boundary constraints on the layers and the prior, one and two layers, other boxes, degrees and
+    knot counts: inverse against the one-walker-per-wave kernel, round trip, draws against the wave kernel's."""
+    import torch
+    from scipy import stats
+    from waveflow_amd import flows, model_factory, wavefunctions
+    mt = model_factory.get_masked_transform
+    il, ir, pl, pr = {0: 0.0, 1: 0.0}, {0: 1.0, 1: 0.0}, {0: 0, 2: 0}, {0: 0, 1: 0}
+    cases = [
+        dict(L=3.0, n=2, k=6, kn=23, il=il, ir=ir, pl=pl, pr=pr),
+        dict(L=2.0, n=1, k=5, kn=16, il={0: 0.0}, ir={0: 1.0}, pl={0: 0}, pr={0: 0}),
+        dict(L=6.0, n=3, k=3, kn=10, il={0: 0.0}, ir={0: 1.0}, pl={0: 0}, pr={0: 0}),
+    ]
+    g = np.random.default_rng(9)
+    for c in cases:
+        init = wavefunctions.Waveflow(
+            flows.Serial(flows.BoxTransformLayer(c["L"]), *(flows.IMADE(mt(), c["k"], c["kn"], 0.05, 1e-6, c["il"], c["ir"]), flows.Reverse()) * c["n"]),
+            mt(allow_negative_params=True), c["k"], c["kn"], constraints_dict_left=c["pl"], constraints_dict_right=c["pr"],
+            constrained_dimension_indices_left=[0], set_nn_output_grad_to_zero=False)
+        params, psi, log_pdf, _ = init(4, 2)
+        m = psi.model
+        m.ensure_params(params)
+        u = g.uniform(0.01, 0.99, size=(17000, 2)).astype(np.float32)
+        monkeypatch.setenv("WF_SAMPLE_TILE_MIN", "16384")
+        xs = m.inverse(u, exact=True)
+        xa, la = m.sample(3, 30000, return_latent=True, exact=True)
+        monkeypatch.setenv("WF_SAMPLE_TILE_MIN", "0")
+        xw = m.inverse(u, exact=True)
+        xb, lb = m.sample(4, 30000, return_latent=True, exact=True)
+        assert np.isfinite(xs).all() and not np.array_equal(xs, xw), c
+        d = np.abs(xs - xw) / c["L"]
+        assert np.median(d) < 1e-6 and np.quantile(d, 0.999) < 1e-4 and d.max() < 1e-3, (c, np.median(d), d.max())
+        u2, _ = m.flow(xs)
+        assert np.median(np.abs(u2 - u)) < 2e-5, c
+        assert torch.isfinite(xa).all() and torch.isfinite(la).all(), c
+        for col in range(2):
+            for a, b in ((xa, xb), (la, lb)):
+                p = stats.ks_2samp(a[:, col].cpu().numpy(), b[:, col].cpu().numpy()).pvalue
+                assert p > 1e-4, (c, col, p)
