@@ -1,24 +1,26 @@
-import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch, ctypes
-from waveflow_amd import checkpoint, model_factory, _lib
-flat = np.load('tests/golden/he_checkpoint.npz')['flat']
-init_fun = model_factory.get_waveflow_model(2, base_spline_degree=6, i_spline_degree=6, n_prior_internal_knots=23, n_i_internal_knots=23, i_spline_reg=0.05, n_flow_layers=3, box_size=10)
-params, psi, log_pdf, sample = init_fun(0, 2)
-m = log_pdf.model; m.set_params(flat)
-L = _lib.lib()
-g = np.random.default_rng(0)
-for B in (256, 1024, 2048, 4096, 8192, 16384, 32768):
-    x = torch.as_tensor(np.sort(g.uniform(-10, 10, size=(B, 2)), -1).astype(np.float32)).cuda()
-    out = torch.empty(B, device='cuda')
-    res = []
-    for k in ("wave", "mfma"):
-        m.set_kernel(k)
-        sp = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        f = lambda: L.wf_logpdf_fwd(m._h, ctypes.c_void_p(x.data_ptr()), B, ctypes.c_void_p(out.data_ptr()), None, None, sp)
-        for _ in range(20): f()
-        torch.cuda.synchronize(); t = time.perf_counter()
-        n = 200
-        for _ in range(n): f()
-        torch.cuda.synchronize(); res.append((time.perf_counter() - t) / n * 1e6)
-    print(f"B={B}: wave {res[0]:.1f} us  mfma {res[1]:.1f} us")
+"""Where do the matrix-core paths overtake the one-walker-per-wave kernels?  sample / loss + gradient / H psi of the He model at small batches, both ways."""
+import os, sys, time, torch
+sys.path.insert(0, os.getcwd())
+import bench
+from waveflow_amd.utils import physics
+m, flat = bench.he_model("auto")
+protons = physics.system_catalogue[1]["He"][0].reshape(-1)
+def t(fn, n=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
+print("%8s | %-23s | %-23s | %-23s" % ("walkers", "sample ms  tile / wave", "loss+grad ms tile / wave", "H psi ms   tile / wave"))
+for B in (1024, 2048, 4096, 8192, 16384, 32768):
+    x = m.sample(3, B, exact=True)
+    row = []
+    for env in ("WF_SAMPLE_TILE_MIN", "WF_GRAD_TILE_MIN", "WF_ENERGY_TILE_MIN"):
+        pair = []
+        for v in ("1", "0"):
+            os.environ[env] = v
+            if env == "WF_SAMPLE_TILE_MIN": pair.append(t(lambda: m.sample(5, B, exact=True)))
+            elif env == "WF_GRAD_TILE_MIN": pair.append(t(lambda: m.vqmc_loss_grad(x, protons, -1.8)))
+            else: pair.append(t(lambda: m.hamiltonian(x, protons)))
+        del os.environ[env]
+        row.append("%9.3f / %9.3f" % tuple(pair))
+    print("%8d | %-23s | %-23s | %-23s" % (B, *row), flush=True)
