@@ -9,7 +9,7 @@ import csv, sys
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
 names = [(r["Kernel_Name"], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, int(r["Start_Timestamp"])) for r in rows]
 # the last sample() call: find the last run of 9 launches starting with k_tsample, cond<true>
-idx = [i for i, (n, d, s) in enumerate(names) if "k_etile_cond<true>" in n]
+idx = [i for i, (n, d, s) in enumerate(names) if "k_etile_cond<true" in n]
 i0 = idx[-1] - 1
 t0 = names[i0][2]
 for n, d, s in names[i0:i0 + 9]:
