@@ -844,9 +844,21 @@ def test_wavefunction_with_a_nonzero_boundary_value_on_the_prior(D):
     ho, _, lo = et.hamiltonian(mo, flat, x.astype(np.float64), [0.0] * D)
     np.testing.assert_allclose(lap, lo, rtol=0, atol=3e-3 * np.abs(lo).max())
     np.testing.assert_allclose(hp, ho, rtol=0, atol=3e-3 * np.abs(ho).max())
-    # 20 000 walkers: H psi stays on the wave sweeps (the matrix-core tile path leaves this family out), finite and consistent with psi
-    hb, pb, _ = m.hamiltonian(xb, [0.0] * D, return_psi=True, return_laplacian=True)
-    assert np.isfinite(np.asarray(hb)).all() and np.abs(np.asarray(pb) - p_w).max() <= 5e-5 * np.abs(p_w).max()
+    # 20 000 walkers: with two particles H psi goes through the one-kernel matrix-core form, which carries the term channel by channel
+    # (c += (sum o) (b @ ob_to_b) for the value and both derivative channels); for D = 3 it stays on the wave sweeps.  Against the wave sweeps:
+    hb, pb, lb = (np.asarray(t) for t in m.hamiltonian(xb, [0.0] * D, return_psi=True, return_laplacian=True))
+    assert np.isfinite(hb).all() and np.abs(pb - p_w).max() <= 5e-5 * np.abs(p_w).max()
+    import os
+    os.environ["WF_ENERGY_TILE_MIN"] = "0"
+    try:
+        hw, pw2, lw = (np.asarray(t) for t in m.hamiltonian(xb, [0.0] * D, return_psi=True, return_laplacian=True))
+    finally:
+        del os.environ["WF_ENERGY_TILE_MIN"]
+    if D == 2:
+        assert not np.array_equal(hb, hw)                       # two different kernels
+    for a_, b_ in ((pb, pw2), (lb, lw), (hb, hw)):
+        d_ = np.abs(a_ - b_)
+        assert d_.max() <= 5e-4 * np.abs(b_).max() and np.median(d_) <= 1e-6 * np.abs(b_).max(), (d_.max() / np.abs(b_).max(), np.median(d_) / np.abs(b_).max())
     g = np.random.default_rng(2)
     w1, w2 = g.normal(size=len(x)).astype(np.float32), g.normal(size=len(x)).astype(np.float32)
     got = m.psi_vjp(x, w1, 0.1 * w2).cpu().numpy().astype(np.float64)

@@ -227,10 +227,20 @@ __device__ __forceinline__ void cond_out(const float* net, const Frag (&f)[NCH][
 // the prior head behind cond_out: of[ki][c] = fragments of w = o * keep (every (walker, channel) column of the 32 * NBK rows scaled by one power of
 // two: the head is unbounded), eo[c] the exponents, s1 = sum of the raw outputs (model_factory.py:69: its sign, as in k_mfma)
 template <int NBK>
-__device__ __forceinline__ void prior_frags(f32x16 (&o)[NBK][NCH], const float* fkP, int lane, Frag (&of)[NBK][NCH], int (&eo)[NCH], float& s1) {
+__device__ __forceinline__ void prior_frags(f32x16 (&o)[NBK][NCH], const float* fkP, int lane, Frag (&of)[NBK][NCH], int (&eo)[NCH], float& s1,
+                                            float* sder = nullptr /* [2]: the sums of the derivative channels (a boundary map with a constant term needs them) */) {
     const int h = lane >> 5;
     s1 = 0.0f;
     float amax[NCH] = {0.0f, 0.0f, 0.0f};
+    if (sder) {
+        float d1 = 0.0f, d2 = 0.0f;
+#pragma unroll
+        for (int kb = 0; kb < NBK; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { d1 += o[kb][1][r]; d2 += o[kb][2][r]; }
+        sder[0] = xhalf_sum(d1);
+        sder[1] = xhalf_sum(d2);
+    }
 #pragma unroll
     for (int kb = 0; kb < NBK; ++kb) {
         const f32x16 keep = load16(fkP + (kb * 2 + h) * 16);
@@ -636,7 +646,9 @@ __device__ __forceinline__ void prior_rows(PriorSums& a, const f32x16 (&c)[NCH],
     }
 }
 
-template <int NBK>
+// PBIAS: the B prior's boundary map has a constant term (a constraint with a non-zero value): its own instantiation, so that the derivative channels'
+// sums do not lengthen live ranges in the common one
+template <int NBK, bool PBIAS = false>
 __global__ __launch_bounds__(kFusedWaves * 64) void k_efused(const MfmaDev mm, const float* __restrict__ tabI, const float* __restrict__ tabP,
                                                              const float* __restrict__ xg, int64_t B, const Protons pr, float* __restrict__ hpsi,
                                                              float* __restrict__ psi_out, float* __restrict__ lap_out, float* __restrict__ st_out) {
@@ -656,6 +668,7 @@ __global__ __launch_bounds__(kFusedWaves * 64) void k_efused(const MfmaDev mm, c
     const float* fkI = lds;
     const float* fkP = lds + 32 * NBK;
     const _Float16* obh = reinterpret_cast<const _Float16*>(lds + 64 * NBK);
+    const float* cbP = lds + 64 * NBK + NBK * NBK * 1024 + 64 * NBK;   // [NBK][2][16] constant term of the B prior's boundary map times ob_to_b (mm.p_bias; wf_model.cpp)
     const int lane = threadIdx.x & 63;
     const int j = lane & 31, h = lane >> 5;
     const int n_mesh = mm.n_mesh;
@@ -724,7 +737,7 @@ __global__ __launch_bounds__(kFusedWaves * 64) void k_efused(const MfmaDev mm, c
                 st_store(st_out + (size_t)mm.n_layers * 12 * B, 1, B, w, u1);
                 st_store(st_out + (size_t)mm.n_layers * 12 * B, 2, B, w, ld);
             }
-            float s1 = 0.0f;
+            float s1 = 0.0f, sder[2] = {0.0f, 0.0f};
             Frag of[NBK][NCH];
             int eo[NCH];
             {
@@ -734,7 +747,7 @@ __global__ __launch_bounds__(kFusedWaves * 64) void k_efused(const MfmaDev mm, c
                 f32x16 o[NBK][NCH];
 #pragma unroll
                 for (int kb = 0; kb < NBK; ++kb) cond_out<NBK>(net, f, e, kb, lane, o[kb]);
-                prior_frags<NBK>(o, fkP, lane, of, eo, s1);
+                prior_frags<NBK>(o, fkP, lane, of, eo, s1, PBIAS ? sder : nullptr);
             }
             const J uc0 = (u0.v < 0.0f) ? jc(0.0f) : (u0.v > 1.0f ? jc(1.0f) : u0);   // the spline sees the clipped coordinate (:45)
             const J uc1 = (u1.v < 0.0f) ? jc(0.0f) : (u1.v > 1.0f ? jc(1.0f) : u1);
@@ -751,6 +764,15 @@ __global__ __launch_bounds__(kFusedWaves * 64) void k_efused(const MfmaDev mm, c
             for (int ko = 0; ko < NBK; ++ko) {
                 f32x16 cblk[NCH];
                 prior_c_block<NBK>(obh, of, eo, ko, lane, cblk);
+                if (PBIAS) {   // a boundary constraint with a non-zero value (bsplines_jax.py:173-199): c += (sum o) * (b @ ob_to_b), channel by channel
+                    const f32x16 cb = load16(cbP + (ko * 2 + h) * 16);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        cblk[0][r] = __builtin_fmaf(s1, cb[r], cblk[0][r]);
+                        cblk[1][r] = __builtin_fmaf(sder[0], cb[r], cblk[1][r]);
+                        cblk[2][r] = __builtin_fmaf(sder[1], cb[r], cblk[2][r]);
+                    }
+                }
                 prior_rows(a, cblk, tabP, kMeshStride, bnd_s + 16 * NBK, L, ko, h);
             }
 #pragma unroll
@@ -1939,15 +1961,18 @@ int launch_energy_tile(const MfmaDev* mdev, const ModelDev& md, const float* tab
             const int lds_all = (mdev->const_floats + mdev->net_floats * mdev->n_nets) * (int)sizeof(float);
             const int64_t n_tiles = (B + 31) / 32;
             const unsigned blocks = (unsigned)std::min<int64_t>((n_tiles + kFusedWaves - 1) / kFusedWaves, 256);
+#define WF_EFUSED(NBK_, PB_)                                                                                                                   \
+    {                                                                                                                                          \
+        static DynLdsSlots cfg{};                                                                                                              \
+        if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(k_efused<NBK_, PB_>), lds_all, &cfg)) return rc;                          \
+        hipLaunchKernelGGL((k_efused<NBK_, PB_>), dim3(blocks), dim3(kFusedWaves * 64), lds_all, s, *mdev, tabI4, tabP4, x, B, pr, hpsi, psi, lap, st_out); \
+    }
             if (mdev->nbk == 1) {
-                static DynLdsSlots cfg1{};
-                if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(k_efused<1>), lds_all, &cfg1)) return rc;
-                hipLaunchKernelGGL(k_efused<1>, dim3(blocks), dim3(kFusedWaves * 64), lds_all, s, *mdev, tabI4, tabP4, x, B, pr, hpsi, psi, lap, st_out);
+                if (mdev->p_bias) WF_EFUSED(1, true) else WF_EFUSED(1, false)
             } else {
-                static DynLdsSlots cfg2{};
-                if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(k_efused<2>), lds_all, &cfg2)) return rc;
-                hipLaunchKernelGGL(k_efused<2>, dim3(blocks), dim3(kFusedWaves * 64), lds_all, s, *mdev, tabI4, tabP4, x, B, pr, hpsi, psi, lap, st_out);
+                if (mdev->p_bias) WF_EFUSED(2, true) else WF_EFUSED(2, false)
             }
+#undef WF_EFUSED
             return check();
         }
     }

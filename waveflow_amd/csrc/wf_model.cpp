@@ -1538,7 +1538,7 @@ int wf_hamiltonian_fwd(const wf_model* m, const float* x_dev, int64_t B, const f
         const wf_model_desc& d = m->desc;
         // (<= 32 bases: the one-kernel form or, if the nets do not fit LDS together, the launch-per-net form; 33 .. 64 bases: the one-kernel form only)
         const bool family = D == 2 && (m->nbp == 32 || (m->nbp == 64 && m->mfma_ok && energy_tile_fused(&m->mdev))) && m->mfma_ok && d.box_kind == WF_BOX_MEAN && d.layer_kind == WF_LAYER_IMADE &&
-                            d.n_flow_layers > 0 && !m->dev.i_gate && !m->dev.p_gate && m->d_tabI4c && m->d_tabP4c && !m->mdev.p_bias && !getenv("WF_ENERGY_R3");
+                            d.n_flow_layers > 0 && !m->dev.i_gate && !m->dev.p_gate && m->d_tabI4c && m->d_tabP4c && (!m->mdev.p_bias || energy_tile_fused(&m->mdev)) && !getenv("WF_ENERGY_R3");   // (a constant term of the prior's boundary map: the one-kernel form only)
         if (family && tile_min > 0 && B >= tile_min && !m->eval_tables_stale) {
             // the conditioner and the head kernels exchange 384 B per walker and net through the scratch buffer: chunks that keep it
             // (and its re-use by the next net and the next chunk) inside the 256 MB memory-side cache instead of HBM
