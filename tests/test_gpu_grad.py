@@ -883,6 +883,17 @@ def test_wavefunction_with_a_nonzero_boundary_value_on_the_prior(D):
             del os.environ["WF_WAVE_SAMPLE_MAX"]
         for c in range(2):
             assert stats.ks_2samp(lat[:, c].cpu().numpy(), lat2[:, c].cpu().numpy()).pvalue > 1e-4
+        # the staged large-batch sampler (forced onto this batch): the conditioner launch adds the term to the head's value channel
+        os.environ["WF_SAMPLE_TILE_MIN"] = "1"
+        try:
+            xs3, lat3 = m.sample(5, 4000, return_latent=True, exact=True)
+        finally:
+            del os.environ["WF_SAMPLE_TILE_MIN"]
+        _, u3 = log_pdf(params, xs3.cpu().numpy(), return_sample=True)
+        d3 = np.abs(np.asarray(u3) - lat3.cpu().numpy()).max(1)
+        assert np.median(d3) < 1e-4 and np.quantile(d3, 0.99) < 5e-3, (np.median(d3), np.quantile(d3, 0.99))
+        for c in range(2):
+            assert stats.ks_2samp(lat[:, c].cpu().numpy(), lat3[:, c].cpu().numpy()).pvalue > 1e-4
 
 
 @pytest.mark.parametrize("D,knots", [(2, 23), (3, 23), (2, 33), (4, 23)])

@@ -293,8 +293,11 @@ __device__ __forceinline__ void prior_c_block(const _Float16* obh, const Frag (&
     }
 }
 // the whole conditioner for <= 32 bases (the launch-per-net path): head triples (PRIOR: of c) in a0, the sum of the raw outputs in s1
+// cbP: the constant term of the B prior's boundary map times ob_to_b ([NBK][2][16], accumulator layout) or null; it is added to the VALUE channel only --
+// the staged sampler, which reads nothing else, is the one caller with such models (the launch-per-net energy path leaves them to k_efused)
 template <bool PRIOR, int NBK = 1>
-__device__ __forceinline__ void cond_net(const float* net, const float* fkP, const _Float16* obh, float u0v, float u1v, int lane, f32x16 (&a0)[NBK][NCH], float& s1) {
+__device__ __forceinline__ void cond_net(const float* net, const float* fkP, const _Float16* obh, float u0v, float u1v, int lane, f32x16 (&a0)[NBK][NCH], float& s1,
+                                         const float* cbP = nullptr) {
     Frag f[NCH][2];
     int e[NCH];
     cond_hidden<NBK>(net, u0v, u1v, lane, f, e);
@@ -309,7 +312,14 @@ __device__ __forceinline__ void cond_net(const float* net, const float* fkP, con
         int eo[NCH];
         prior_frags<NBK>(o, fkP, lane, of, eo, s1);
 #pragma unroll
-        for (int kb = 0; kb < NBK; ++kb) prior_c_block<NBK>(obh, of, eo, kb, lane, a0[kb]);
+        for (int kb = 0; kb < NBK; ++kb) {
+            prior_c_block<NBK>(obh, of, eo, kb, lane, a0[kb]);
+            if (cbP) {
+                const f32x16 cb = load16(cbP + (kb * 2 + (lane >> 5)) * 16);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a0[kb][0][r] = __builtin_fmaf(s1, cb[r], a0[kb][0][r]);
+            }
+        }
     }
 }
 
@@ -344,7 +354,7 @@ __global__ __launch_bounds__(kCondWaves * 64, WF_ETILE_OCC) void k_etile_cond(co
         const float u0v = st[wl], u1v = st[(int64_t)4 * B + wl];
         f32x16 a0[NBK][NCH];
         float s1 = 0.0f;
-        cond_net<PRIOR, NBK>(net, fkP, obh, u0v, u1v, lane, a0, s1);
+        cond_net<PRIOR, NBK>(net, fkP, obh, u0v, u1v, lane, a0, s1, (PRIOR && mm.p_bias) ? lds + 64 * NBK + NBK * NBK * 1024 + 64 * NBK : nullptr);
         if (PRIOR && valid && h == 0) s1buf[w] = s1;
         // ---- store: oj[tile][row][c][32 walkers] (one contiguous block per tile), row = accumulator row of register r in lane half h of block kb
 #ifdef WF_ABL_OJ   // ablation build (timing only): the head triples are computed, not stored
@@ -2066,7 +2076,7 @@ int launch_energy_vjp_finish(const float* gacc, int n_nets, const int* offs /* [
 
 // ---- host side of the staged inverse / sampler
 bool tile_sample_capable(const MfmaDev* mdev) {
-    return mdev->D == 2 && (mdev->nbk == 1 || mdev->nbk == 2) && mdev->n_layers > 0 && mdev->n_layers < 8 && !mdev->p_bias && !mdev->i_gate && !mdev->p_gate &&
+    return mdev->D == 2 && (mdev->nbk == 1 || mdev->nbk == 2) && mdev->n_layers > 0 && mdev->n_layers < 8 && !mdev->i_gate && !mdev->p_gate &&
            mdev->comp != nullptr && (mdev->const_floats + mdev->net_floats) * 4 <= 160 * 1024 - 64;
 }
 // floats of workspace: conditioner input (5 B: the slot of the second input sits 4 B behind the first), cur0, cur1, the latent pair, the prior's sign sums,
