@@ -205,11 +205,12 @@ int wf_sample(const wf_model* m, uint64_t seed, int64_t B, float* x_dev, float* 
  * with physics.laplacian (:50-52, trace of jax.hessian -- the table lerp differentiates to the next cached derivative table,
  * isplines_jax.py:60-66) and the one-dimensional soft-Coulomb physics.get_potential (:60-76) for `n_protons` <= 8 protons at
  * `protons_host`.  hpsi_dev[B]; psi_dev[B] and laplacian_dev[B] may be NULL.  The local energy of vqmc.loss_fn_efficient
- * (vqmc.py:193-200) is hpsi / (psi + 1e-8).  Batches of >= 16384 walkers of two-particle models (<= 32 bases, mean-type box, ungated) run on the
- * matrix cores in passes of 2^19 walkers (wf_kernels_etile.hip; WF_ENERGY_TILE_MIN moves the switch, WF_ENERGY_TILE_CHUNK the pass size),
+ * (vqmc.py:193-200) is hpsi / (psi + 1e-8).  Batches of >= 16384 walkers of two-particle models (<= 64 bases, mean-type box, ungated) run on the
+ * matrix cores -- one kernel for the whole of H psi where the nets fit LDS together (the shipped shapes), else launch by launch in passes of 2^19
+ * walkers (wf_kernels_etile.hip; WF_ENERGY_TILE_MIN moves the switch, WF_ENERGY_TILE_CHUNK the pass size) --,
  * everything else on the wave-cooperative kernel: same function.
- * Coverage: WF_PRIOR_WAVEFLOW models with IMADE layers, boundary constraints the spline tables carry (prior: every value 0; I layers: any
- * value, the coefficients being normalised), gated heads included;
+ * Coverage: WF_PRIOR_WAVEFLOW models with IMADE layers, boundary constraints the spline tables carry (any value on the I layers and, since
+ * round 3, on the B-spline prior), gated heads included;
  * D = 2..8 with <= 32 bases per dimension, D = 2..4 with 33..64. */
 int wf_hamiltonian_fwd(const wf_model* m, const float* x_dev, int64_t B, const float* protons_host, int32_t n_protons,
                        float* hpsi_dev, float* psi_dev, float* laplacian_dev, void* stream);
@@ -286,7 +287,7 @@ int wf_mle_train_step(wf_model* m, const wf_train_state* st, const float* x_dev,
                       void* workspace_dev, int64_t workspace_bytes, void* stream);
 
 /* Parameter gradient of the log-density: grad_dev[p] = sum_b w_dev[b] * d log_pdf_b / d theta_p for every model wf_logpdf_fwd
- * evaluates with boundary constraints the spline tables carry (B-spline prior: every value 0; I / M splines: any value), gated heads included, and <= 32 bases per dimension (or <= 64 for D <= 4) (IMADE or MADE layers; Waveflow, M-spline, Normal or Uniform
+ * evaluates with boundary constraints the spline tables carry (any value), gated heads included, and <= 32 bases per dimension (or <= 64 for D <= 4) (IMADE or MADE layers; Waveflow, M-spline, Normal or Uniform
  * prior).  With w = -1/B this is the gradient of benchmark_tests.loss (benchmark_tests.py:84-87, 98-101); with per-walker
  * weights it is the jacrev(log_pdf) contraction of vqmc.train_step (vqmc.py:175-180). */
 int64_t wf_logpdf_vjp_workspace_bytes(const wf_model* m, int64_t B);
