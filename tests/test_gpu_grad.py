@@ -85,6 +85,10 @@ def test_gradients_on_the_matrix_cores_vs_oracle_and_wave_sweeps(golden, he_flat
     got = m.psi_vjp(x, w1, w2).cpu().numpy().astype(np.float64)
     want = et.psi_vjp(et.he_model(torch.float64), he_flat, x.astype(np.float64), w1, w2)
     assert rel_l2(got, want) < 5e-3, rel_l2(got, want)
+    monkeypatch.setenv("WF_GRAD_TILE_MIN", "0")
+    got_w = m.psi_vjp(x, w1, w2).cpu().numpy().astype(np.float64)
+    monkeypatch.setenv("WF_GRAD_TILE_MIN", "1")
+    assert not np.array_equal(got, got_w) and rel_l2(got, got_w) < 5e-4      # (the forced small batch did take the matrix-core path: another kernel's bits)
     # a large ragged batch: against the wave sweeps (fp32 both: 1.6e-5 measured), bit-reproducible, and in several chunks
     xb = torch.as_tensor(sorted_walkers(50001, 2, 9.5, 7)).cuda()
     wb1 = torch.as_tensor(g.normal(size=50001).astype(np.float32)).cuda()
@@ -124,7 +128,7 @@ def _leaves(tree):
 def test_gradient_tile_path_other_models(monkeypatch):
     """The matrix-core gradient path on models the He checkpoint does not exercise (derivative boundary constraints, one and two layers, other
     boxes, degrees and knot counts), forced on 4 097 walkers against the reverse wave sweeps -- overall and LEAF BY LEAF (a wrong small leaf
-    would hide behind the large ones); models outside its family (two row blocks per dimension, a non-zero boundary value on the prior,
+    would hide behind the large ones), a non-zero boundary value on the prior included; models outside its family (two row blocks per dimension,
     first-type box) keep the wave sweeps bit for bit."""
     import torch
     from waveflow_amd import checkpoint, flows, model_factory, wavefunctions
@@ -135,7 +139,7 @@ def test_gradient_tile_path_other_models(monkeypatch):
         dict(L=2.0, n=1, k=5, kn=16, il={0: 0.0}, ir={0: 1.0}, pl={0: 0}, pr={0: 0}, family=True),
         dict(L=6.0, n=3, k=3, kn=10, il={0: 0.0}, ir={0: 1.0}, pl={0: 0}, pr={0: 0}, family=True),
         dict(L=10.0, n=3, k=6, kn=33, il={0: 0.0}, ir={0: 1.0}, pl={0: 0}, pr={0: 0}, family=False),     # 39 / 38 bases: two row blocks
-        dict(L=3.0, n=1, k=5, kn=16, il={0: 0.0}, ir={0: 1.0}, pl={0: 0.3}, pr={0: 0}, family=False),     # boundary value 0.3 on the prior
+        dict(L=3.0, n=1, k=5, kn=16, il={0: 0.0}, ir={0: 1.0}, pl={0: 0.3}, pr={0: 0}, family=True),      # boundary value 0.3 on the prior (constant term)
     ]
     g = np.random.default_rng(17)
     for c in cases:
@@ -864,6 +868,17 @@ def test_wavefunction_with_a_nonzero_boundary_value_on_the_prior(D):
     got = m.psi_vjp(x, w1, 0.1 * w2).cpu().numpy().astype(np.float64)
     want = et.psi_vjp(mo, flat, x.astype(np.float64), w1, 0.1 * w2)
     assert rel_l2(got, want) < 5e-3, rel_l2(got, want)
+    if D == 2:
+        # the matrix-core gradient path (forced onto this batch) carries the term too: the prior's reverse kernel adds (sum o) (b @ ob_to_b) to the three
+        # channels of c and gives every raw output the adjoint of its channel's sum
+        import os
+        os.environ["WF_GRAD_TILE_MIN"] = "1"
+        try:
+            got_t = m.psi_vjp(x, w1, 0.1 * w2).cpu().numpy().astype(np.float64)
+        finally:
+            del os.environ["WF_GRAD_TILE_MIN"]
+        assert not np.array_equal(got_t, got)
+        assert rel_l2(got_t, want) < 5e-3 and rel_l2(got_t, got) < 5e-4, (rel_l2(got_t, want), rel_l2(got_t, got))
     got = m.logpdf_vjp(x, w1).cpu().numpy().astype(np.float64)
     want = et.logpdf_vjp(mo, flat, x.astype(np.float64), w1)
     assert rel_l2(got, want) < 2e-3, rel_l2(got, want)

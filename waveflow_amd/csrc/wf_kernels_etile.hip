@@ -1228,6 +1228,22 @@ __global__ __launch_bounds__(kBwdWaves * 64) void k_ebwd(const MfmaDev mm, int n
                 for (int r = 0; r < 16; ++r) { wv[c][r] = o[c][r] * keep[r]; w0v[c][r] = c == 0 ? b20[r] * keep[r] : 0.0f; }
             ob_product(obh, wv, lane, c1);
             ob_product(obh, w0v, lane, c0);
+            // a boundary constraint with a non-zero value on the prior (mm.p_bias): c += (sum o) * (b @ ob_to_b), channel by channel (as k_efused<.., true>)
+            const f32x16 cbv = mm.p_bias ? load16(lds + 64 + 1024 + 64 + h * 16) : f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            if (mm.p_bias) {
+                float sd1 = 0.0f, sd2 = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { sd1 += o[1][r]; sd2 += o[2][r]; }
+                sd1 = xhalf_sum(sd1);
+                sd2 = xhalf_sum(sd2);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    c1[0][r] = __builtin_fmaf(s1, cbv[r], c1[0][r]);
+                    c1[1][r] = __builtin_fmaf(sd1, cbv[r], c1[1][r]);
+                    c1[2][r] = __builtin_fmaf(sd2, cbv[r], c1[2][r]);
+                    c0[0][r] = __builtin_fmaf(s0, cbv[r], c0[0][r]);
+                }
+            }
             const float sg1 = s1 < 0.0f ? -1.0f : 1.0f, sg0 = s0 < 0.0f ? -1.0f : 1.0f;
             const bool in0 = u0.v >= 0.0f && u0.v <= 1.0f, in1 = u1.v >= 0.0f && u1.v <= 1.0f;
             const JA uc0 = in0 ? u0 : JA{u0.v < 0.0f ? 0.0f : 1.0f, 0.0f, 0.0f, 0.0f}, uc1 = in1 ? u1 : JA{u1.v < 0.0f ? 0.0f : 1.0f, 0.0f, 0.0f, 0.0f};
@@ -1262,13 +1278,28 @@ __global__ __launch_bounds__(kBwdWaves * 64) void k_ebwd(const MfmaDev mm, int n
             prior_rows_bwd<false>(ab1, c1, tabP, bnd_s + 16, L1, h, cb);
             ob_product(obT, cb, lane, wb);
 #pragma unroll
-            for (int c = 0; c < NCH; ++c)
+            for (int c = 0; c < NCH; ++c) {
+                float sbar = 0.0f;     // adjoint of the channel's sum of raw outputs (the constant term reaches every one of them)
+                if (mm.p_bias) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) ob[c][r] = wb[c][r] * keep[r];
+                    for (int r = 0; r < 16; ++r) sbar = __builtin_fmaf(cb[c][r], cbv[r], sbar);
+                    sbar = xhalf_sum(sbar);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ob[c][r] = __builtin_fmaf(wb[c][r], keep[r], sbar);
+            }
             prior_rows_bwd<true>(ab0, c0, tabP, bnd_s + 16, L0, h, cb);
             ob_product(obT, cb, lane, wb);
+            {
+                float sbar = 0.0f;
+                if (mm.p_bias) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) ob0[r] = wb[0][r] * keep[r];
+                    for (int r = 0; r < 16; ++r) sbar = __builtin_fmaf(cb[0][r], cbv[r], sbar);
+                    sbar = xhalf_sum(sbar);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ob0[r] = __builtin_fmaf(wb[0][r], keep[r], sbar);
+            }
         }
 #pragma unroll
         for (int c = 0; c < NCH; ++c) dump_block(dmp + kDY3 + c * 1024, 0, ob[c], j, h);
@@ -2010,7 +2041,7 @@ int launch_energy_tile(const MfmaDev* mdev, const ModelDev& md, const float* tab
 
 
 // ---- host side of the matrix-core gradient path
-bool energy_vjp_capable(const MfmaDev* mdev) { return mdev->timg_off >= 0 && mdev->nbk == 1 && energy_tile_fused(mdev) && !mdev->p_bias && !mdev->i_gate && !mdev->p_gate; }
+bool energy_vjp_capable(const MfmaDev* mdev) { return mdev->timg_off >= 0 && mdev->nbk == 1 && energy_tile_fused(mdev) && !mdev->i_gate && !mdev->p_gate; }
 // floats of workspace per walker of a chunk (whole tiles), + the fixed part
 int64_t energy_vjp_floats_per_walker(int n_nets) { return (int64_t)n_nets * 12 + 12 + 4 + kDumpFloats / 32; }
 int64_t energy_vjp_fixed_floats(int n_nets) { return (int64_t)n_nets * kESplit * kGFloats + kDumpFloats + 128; }

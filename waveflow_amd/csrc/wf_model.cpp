@@ -1581,7 +1581,12 @@ static int64_t vjp_ws_bytes(const wf_model* m, int64_t B, bool second_order) {
     if (!m || B < 0) return WF_ERR_INVALID;
     if (!m->d_grad_map || (second_order && !m->grad_psi_ok)) return WF_ERR_UNSUPPORTED;
     const int64_t chunk = std::min<int64_t>(std::max<int64_t>(B, 1), 32768);
-    return chunk * vjp_bytes_per_walker(m, second_order);
+    int64_t bytes = chunk * vjp_bytes_per_walker(m, second_order);
+    if (second_order && m->d_egacc) {   // the matrix-core gradient path has a fixed part (the partial gradient blocks of every net): room for it at any batch size
+        const int n_nets = (int)m->nets.size();
+        bytes = std::max<int64_t>(bytes, (energy_vjp_fixed_floats(n_nets) + ((chunk + 31) / 32 * 32) * energy_vjp_floats_per_walker(n_nets)) * (int64_t)sizeof(float));
+    }
+    return bytes;
 }
 
 // mode 0: log_pdf, w1 only;  mode 1: psi (w1) and, with second_order, its Laplacian (w2);
