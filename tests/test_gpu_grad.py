@@ -196,7 +196,8 @@ def test_psi_vjp_chunks_and_errors(he_flat):
     full = m.psi_vjp(x, w, w * 0.1)
     assert torch.equal(full, m.psi_vjp(x, w, w * 0.1))      # fixed-order reductions: bitwise reproducible
     # a workspace that only holds 128 samples forces 16 chunks: same gradient up to the grouping of the sums
-    per = L.wf_psi_vjp_workspace_bytes(m._h, 1) // 64
+    # (bytes per walker of the wave sweeps from a large batch: small ones are padded to the fixed part of the matrix-core path)
+    per = L.wf_psi_vjp_workspace_bytes(m._h, 32768) // 32768 // 64
     ws = torch.empty(per * 128, device="cuda", dtype=torch.uint8)
     grad = torch.empty(m.n_params, device="cuda")
     w2 = (w * 0.1).contiguous()
