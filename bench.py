@@ -30,10 +30,32 @@ PEAK_HBM_GBS = 8000.0
 # ob_to_b product of the prior = 150 of 32768 FLOP, plus 8 v_mfma_f32_32x32x2_f32 of 4096 FLOP (input layer, 2 per net).
 MFMA_F16_PER_TILE, MFMA_F32_PER_TILE = 150, 8
 MFMA_FLOP_PER_EVAL = (MFMA_F16_PER_TILE * 32768 + MFMA_F32_PER_TILE * 4096) / 32
-# HBM bytes of one 2^20-walker log_pdf launch from the PMC passes of this command (separate rocprofv3 --pmc runs, scratch/pmc.sh):
-# FETCH_SIZE 10706 KB + WRITE_SIZE 4096 KB.  The walker read is 8 B per lane, not the 16 B-per-lane stream the guide's x2 FETCH_SIZE
-# correction is calibrated on (the sum already equals the 12.6 MB of algorithmic bytes), so no correction is applied.
-PMC_TRAFFIC = {"bytes": (10706 + 4096) * 1024, "source": "profiles/r03_pmc_summary.txt"}
+# HBM bytes of one 2^20-walker log_pdf launch: FETCH_SIZE + WRITE_SIZE (KB) of the headline kernel, READ AT RUN TIME from the committed
+# summary of the separate rocprofv3 --pmc passes of this command (scratch/pmc.sh -> scratch/pmc_summary.py).  The walker read is 8 B per
+# lane, not the 16 B-per-lane stream the guide's x2 FETCH_SIZE correction is calibrated on (the sum equals the 12.6 MB of algorithmic
+# bytes within 20 %), so no correction is applied.
+PMC_SUMMARIES = ("profiles/r04_pmc_summary.txt", "profiles/r03_pmc_summary.txt")
+
+
+def pmc_traffic(kernel_substring="k_mfma<2, 1, 16, 1, false, true>"):
+    """-> {"bytes", "source"} from the newest committed PMC summary that has the kernel, or None."""
+    for rel in PMC_SUMMARIES:
+        path = os.path.join(ROOT, rel)
+        if not os.path.exists(path):
+            continue
+        cur, vals = None, {}
+        for line in open(path):
+            if line.startswith("=="):
+                cur = line
+                continue
+            if cur and kernel_substring in cur:
+                f = line.split()
+                if len(f) >= 2 and f[0] in ("FETCH_SIZE", "WRITE_SIZE"):
+                    vals[f[0]] = float(f[1])
+        if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+            return {"bytes": int((vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), "source": rel,
+                    "fetch_kb": vals["FETCH_SIZE"], "write_kb": vals["WRITE_SIZE"]}
+    return None
 # reverse sweep of one walker, He, in the (value, gradient, Laplacian) algebra RF<2> = 4 channels: per net 2 dense 64x64 products
 # (+ the 32x32 change of basis of the prior, forward and transposed, for 2 dimensions), FMA = 2 FLOP
 VQMC_BWD_FLOP_PER_WALKER = 2 * (4 * 2 * 64 * 64 * 4 + 2 * 2 * 32 * 32 * 4)
@@ -44,6 +66,19 @@ VQMC_BWD_SHARE = 0.54   # of the loss + gradient time (profiles/r01h_loss_grad_k
 GRAD_TILE_MFMA_FLOP_PER_WALKER_NET = (288 * 32768 + 12 * 4096) / 32
 GRAD_TILE_BWD_SHARE = 0.46
 GRAD_TILE_MIN = 16384
+# Executed matrix-core work of the other two log_pdf shapes (static MFMA counts of the linked kernels x their trip counts, scratch/isa/isa_stats.py):
+# 33-knot He (k_mfma<2,2,12,1>: two output blocks per net, 2 x 2 blocks of the prior's change of basis): per tile and flow net 24 + 24, prior net
+# 24 + 24 + 24 = 48 * 3 + 72 = 216 f16 + 8 f32;  8-electron chain (k_mfma<8,1,8,1>: 7 output blocks per net): per net 24 + 7 * 12 = 108, + 7 * 6
+# for the prior = 4 * 108 + 42 = 474 f16, + 4 * 8 f32 (K = 8 input layer: 4 steps x 2 blocks)
+MFMA_PER_TILE = {"33knot": (216, 8), "c4": (474, 32)}
+
+
+def mfma_roofline(key, n_walkers, ms, kernel):
+    f16, f32 = MFMA_PER_TILE[key]
+    flop_per_eval = (f16 * 32768 + f32 * 4096) / 32
+    ach = n_walkers / (ms * 1e-3) * flop_per_eval / 1e12
+    return {"bound": "mfma", "achieved": ach, "peak": PEAK_F16_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F16_MATRIX_TFLOPS, "traffic": None,
+            "kernel": kernel, "kernel_ms": ms, "executed_mfma_flop_per_eval": flop_per_eval}
 
 
 def he_model(kernel):
@@ -197,7 +232,8 @@ def extra_legs(model, flat):
     x = sorted_uniform(1 << 20, 2, 1234).cuda()
     ms = kernel_ms(m33, x)
     out["variant_33knot"] = {"evals_per_s": (1 << 20) / (ms * 1e-3), "kernel_ms": ms, "kernel": "k_mfma<2,2,12,1>",
-                             "workload": "He, 33 knots (32 intervals), 2^20 walkers, seeded parameters"}
+                             "workload": "He, 33 knots (32 intervals), 2^20 walkers, seeded parameters",
+                             "roofline": mfma_roofline("33knot", 1 << 20, ms, "k_mfma<2,2,12,1>")}
     del m33
     # C2: the reference's batch size, one call (shipped checkpoint); AUTO routes it to the wave kernel
     model.set_kernel("auto")
@@ -207,7 +243,8 @@ def extra_legs(model, flat):
     m8 = seeded_model(8, 23, "mfma")
     x8 = sorted_uniform(1 << 18, 8, 1234).cuda()
     ms8 = kernel_ms(m8, x8, n=10, warm=3)
-    out["c4_d8_2pow18"] = {"evals_per_s": (1 << 18) / (ms8 * 1e-3), "kernel_ms": ms8, "kernel": "k_mfma<8,1,8,1>"}
+    out["c4_d8_2pow18"] = {"evals_per_s": (1 << 18) / (ms8 * 1e-3), "kernel_ms": ms8, "kernel": "k_mfma<8,1,8,1>",
+                           "roofline": mfma_roofline("c4", 1 << 18, ms8, "k_mfma<8,1,8,1>")}
     del m8
     torch.cuda.synchronize()
     # the secondary paths, so that the driver's record carries them (each reproducible from a file under profiles/)
@@ -276,6 +313,34 @@ def cpu_baseline(flat, x_host, budget_s=10.0):
                       f"OpenMP over walkers on {cores} threads, {passes} passes of {dt:.1f} s"}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) under torch.distributed.run as a CHILD process -- this process
+    has not touched the GPU and never does --, relay rank 0's JSON line to stdout, everything else to stderr, exit with the child's code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True)
+    lines = 0
+    for line in proc.stdout:
+        if line.startswith('{"metric"'):
+            sys.stdout.write(line)
+            sys.stdout.flush()
+            lines += 1
+        else:
+            sys.stderr.write(line)
+    rc = proc.wait()
+    if rc == 0 and lines != 1:
+        sys.stderr.write(f"bench.py: expected one JSON line from rank 0, saw {lines}\n")
+        rc = 1
+    sys.exit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -292,6 +357,8 @@ def main():
                     help="he_logpdf: the BASELINE metric (default).  rqs: the RQS bijector kernel alone (SURVEY row a12), an "
                          "HBM-bound elementwise op: 2 dims x `--batch` walkers, 32 bins")
     args = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return self_launch(args.gpus)       # before anything touches the GPU: the ranks are fresh child processes
     if args.workload == "rqs":
         return main_rqs(args)
     if args.workload == "vqmc":
@@ -305,8 +372,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: one rank per GPU (launch with --nproc-per-node {args.gpus}, or without a "
+                         f"launcher: bench.py starts its own ranks)")
     if os.environ.get("WF_BENCH_SHARE_GPU0") == "1":   # test hook: several ranks on one GPU (with WF_BENCH_BACKEND=gloo)
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -343,7 +411,7 @@ def main():
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
-    def step(i=None):
+    def step(i=None, collective=True):
         if i is not None:
             ev0[i].record(stream)
         _lib.check(L.wf_logpdf_fwd(model._h, P(x), B, P(lp), None, None, sp), "wf_logpdf_fwd")
@@ -352,7 +420,7 @@ def main():
         sums = sums_all[n_done[0] % sums_all.shape[0]]
         n_done[0] += 1
         _lib.check(L.wf_block_sums(P(lp), B, P(sums), P(ws), ws.numel(), sp), "wf_block_sums")
-        if use_dist:   # one RCCL all-reduce of 3 doubles per step, asynchronous: completed in fence(), inside the timed region
+        if use_dist and collective:   # one RCCL all-reduce of 3 doubles per step, asynchronous: completed in fence(), inside the timed region
             pending.append(dist.all_reduce(sums, op=dist.ReduceOp.SUM, async_op=True))
             if len(pending) > 32:      # bound the number of outstanding collectives: a stream-side wait on one that finished long ago
                 pending.pop(0).wait()
@@ -384,12 +452,21 @@ def main():
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
     last = sums_all[(n_done[0] - 1) % sums_all.shape[0]]
     mean_logp = float((last[0] / last[2]).item())
-    kern_ms_ranks = [kern_ms]
+    kern_ms_ranks, solo_rates = [kern_ms], None
     if use_dist:   # every rank's own kernel time, so that an N > 1 record can be checked against the N = 1 one
-        kt = torch.tensor([kern_ms], device=dev, dtype=torch.float64)
+        # ... and its N = 1-style rate: the same K steps (kernel + block sums) WITHOUT the collective, all ranks at once (what a rank of a
+        # node under the same load does alone): scaling_efficiency = value / sum of these.  After the timed region, never part of `value`.
+        fence()
+        ts = time.perf_counter()
+        for _ in range(args.steps):
+            step(collective=False)
+        torch.cuda.synchronize(dev)
+        solo = B * args.steps / (time.perf_counter() - ts)
+        kt = torch.tensor([kern_ms, solo], device=dev, dtype=torch.float64)
         gathered = [torch.zeros_like(kt) for _ in range(dist.get_world_size())]
         dist.all_gather(gathered, kt)
-        kern_ms_ranks = [float(g.item()) for g in gathered]
+        kern_ms_ranks = [float(g[0].item()) for g in gathered]
+        solo_rates = [float(g[1].item()) for g in gathered]
     # AFTER the timed region (never part of `value`): the same launch once the device has reached its sustained clocks -- from an idle GPU
     # the first ~60 back-to-back launches take 0.29 - 0.32 ms, from ~200 on 15 % less (scratch/time_warm.py)
     sustained = None
@@ -404,6 +481,8 @@ def main():
         waves = os.environ.get("WF_MFMA_WAVES", "16")
         tiles = os.environ.get("WF_MFMA_TILES", "1")
         mfma_tflops = k_evals_s * MFMA_FLOP_PER_EVAL / 1e12
+        # PMC bytes of the committed summary: for the 2^20-walker launch of the default workgroup shape only
+        traffic = pmc_traffic() if (B == (1 << 20) and args.kernel in ("auto", "mfma") and waves == "16" and tiles == "1") else None
         out = {
             "metric": "flow log-prob evals/sec", "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -416,8 +495,8 @@ def main():
             # MFMA peak of the guide.  The algorithmic fp32 figures of SURVEY 8d are the labelled extras.
             "roofline": {"bound": "mfma", "achieved": mfma_tflops, "peak": PEAK_F16_MATRIX_TFLOPS, "unit": "TFLOP/s",
                          "frac": mfma_tflops / PEAK_F16_MATRIX_TFLOPS,
-                         "traffic": PMC_TRAFFIC["bytes"] if (B == (1 << 20) and args.kernel in ("auto", "mfma")) else None,
-                         "traffic_source": PMC_TRAFFIC["source"] if (B == (1 << 20) and args.kernel in ("auto", "mfma")) else None,
+                         "traffic": traffic["bytes"] if traffic else None,
+                         "traffic_source": traffic["source"] if traffic else None,
                          "kernel": {"scalar": "k_eval<2,32>", "wave": "k_wave_fwd<2,R1>"}.get(args.kernel, f"k_mfma<2,1,{waves},{tiles}>"),
                          "kernel_ms": kern_ms, "executed_mfma_flop_per_eval": MFMA_FLOP_PER_EVAL,
                          "algorithmic_flop_per_eval": FLOP_PER_EVAL, "algorithmic_tflops": k_evals_s * FLOP_PER_EVAL / 1e12,
@@ -436,6 +515,10 @@ def main():
             out["rccl_ranks"] = dist.get_world_size()
             out["dist_backend"] = dist.get_backend()
             out["kernel_ms_per_rank"] = kern_ms_ranks
+            out["per_rank_solo_evals_per_s"] = solo_rates
+            out["scaling_efficiency"] = value / sum(solo_rates)
+            out["roofline_per_rank"] = [{"kernel_ms": k, "achieved": B / (k * 1e-3) * MFMA_FLOP_PER_EVAL / 1e12, "unit": "TFLOP/s",
+                                         "frac": B / (k * 1e-3) * MFMA_FLOP_PER_EVAL / 1e12 / PEAK_F16_MATRIX_TFLOPS} for k in kern_ms_ranks]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(flat, x_host.numpy())
             if not args.no_extras:

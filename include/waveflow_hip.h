@@ -17,12 +17,23 @@
  *     (NULL = the default stream); launches are asynchronous on that stream;
  *   - the library owns wf_model (wf_model_create / wf_model_destroy).  The
  *     large-batch forward entry points (wf_logpdf_fwd / wf_psi_fwd / wf_flow_fwd
- *     / wf_layer_fwd above 6144 rows, wf_inverse_fwd, wf_sample) only read the
- *     model: concurrent launches on different streams are safe.  The small-batch
- *     forward path, wf_hamiltonian_fwd and the gradient / training entry points
- *     use per-model scratch: issue those for one model on one stream at a time
- *     (or serialise them with events).  wf_model_set_params(_device) must not run
- *     concurrently with launches that use the model;
+ *     / wf_layer_fwd above 6144 rows) only read the model: concurrent launches
+ *     on different streams are safe.  The small-batch forward path,
+ *     wf_inverse_fwd and wf_sample (from 16 384 rows on they stage conditioner
+ *     outputs in the model's scratch buffer, which may be re-allocated -- with a
+ *     device synchronisation -- when a call needs more than any before: not inside
+ *     a stream capture unless a call of that size has run before),
+ *     wf_hamiltonian_fwd and the gradient / training entry points use per-model
+ *     scratch: issue those for one model on one stream at a time (or serialise
+ *     them with events).  wf_model_set_params(_device) must not run concurrently
+ *     with launches that use the model;
+ *   - fp16 range: the matrix-core kernels read the weights behind a tanh as fp16
+ *     pairs of scale * W (|scale| <= 5.8).  A parameter vector with such a product
+ *     at or beyond 65 520 is detected at upload: while it is loaded WF_KERNEL_AUTO
+ *     takes the fp32 kernels (scalar / wave sweeps), WF_KERNEL_MFMA returns
+ *     WF_ERR_UNSUPPORTED, and a matrix-core kernel that runs anyway (a replayed
+ *     hipGraph captured with other parameters) writes NaN, never a finite wrong
+ *     value;
  *   - there is no CPU fallback: on a machine without a gfx950 device every
  *     device entry point returns WF_ERR_NO_DEVICE.
  */
@@ -175,6 +186,18 @@ int wf_logpdf_fwd(const wf_model* m, const float* x_dev, int64_t B, float* logp_
 int wf_psi_fwd(const wf_model* m, const float* x_dev, int64_t B, float* psi_dev, float* u_dev,
                int32_t* bin_idx_dev, void* stream);
 
+/* The antisymmetrised wavefunction of walkers in ANY particle order: psi(params, sort(x)) * (-1)^inversions(x) -- what the
+ * reference's callers compute on the host around psi (utils/helpers.py:55-58: `inversion_count = get_num_inversion_count(c);
+ * z = psi(params, np.sort(c, -1)) * (-1) ** inversion_count`; utils/coordinates.py:41-51; tests/test_waveflow.py:39-43).  Each
+ * row is sorted ascending on the device (the matrix-core kernel: in registers, a network of adjacent exchanges whose count is
+ * the inversion count, ties exchanging nothing -- `c[i] > c[j]` strictly, as the reference counts) and psi gets the sign.
+ *   inversions_dev [B] int32 or NULL: get_num_inversion_count of every row
+ * wf_logpdf_unsorted_fwd: log_pdf(params, sort(x)), the density of the unordered configuration's ordered image (no sign).
+ * wf_inversion_count: coordinates.get_num_inversion_count alone, no model. */
+int wf_psi_antisym_fwd(const wf_model* m, const float* x_dev, int64_t B, float* psi_dev, int32_t* inversions_dev, void* stream);
+int wf_logpdf_unsorted_fwd(const wf_model* m, const float* x_dev, int64_t B, float* logp_dev, void* stream);
+int wf_inversion_count(const float* x_dev, int64_t B, int32_t n_dim, int32_t* count_dev, void* stream);
+
 /* Serial(...).direct_fun (bijections.py:452-460): u[B][D], logdet[B] of the whole bijector stack. */
 int wf_flow_fwd(const wf_model* m, const float* x_dev, int64_t B, float* u_dev, float* logdet_dev, void* stream);
 
@@ -249,7 +272,9 @@ int wf_vqmc_loss_grad(const wf_model* m, const float* x_dev, int64_t B, const fl
  * The model's weight images must hold params_dev on entry (wf_model_set_params_device); they hold the updated parameters on
  * exit.  Single process; batch <= 131072 where the step samples with the wave kernel (beyond: WF_ERR_UNSUPPORTED, step from the host
  * with wf_sample, wf_vqmc_loss_grad, wf_adam_step), any batch where the staged large-batch sampler applies (see wf_sample; it and the
- * matrix-core gradient path read the tables a deferred step leaves stale: use defer_eval_tables = 0 from 16384 walkers per step on).  Workspace: wf_vqmc_train_step_workspace_bytes. */
+ * matrix-core gradient path read the tables a deferred step leaves stale: from 16384 walkers per step on -- wherever one of them applies at the
+ * step's batch size -- the step refreshes every table whatever defer_eval_tables says, so that a hipGraph of it replays on fresh tables).
+ * Workspace: wf_vqmc_train_step_workspace_bytes (by capability at that batch size, independent of transient state). */
 typedef struct wf_train_state {
     float* params_dev;
     float* m_dev;

@@ -1238,3 +1238,41 @@ def test_deferred_evaluation_tables_contract(he_flat):
         assert torch.isfinite(a).all() and float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()), (k, float((a - b).abs().max()), float(b.abs().max()))
     # (two fp32 kernels, each within 2.5e-5 of max|psi| of the reference's golden grid: their difference is bounded by the sum)
     np.testing.assert_allclose(out[True][3][:2000].cpu().numpy(), out[True][1].cpu().numpy(), rtol=0, atol=4e-5 * float(out[True][1].abs().max()))
+
+
+@pytest.mark.gpu
+def test_captured_large_batch_step_with_deferred_tables_replays_on_fresh_tables(he_flat):
+    """a hipGraph of wf_vqmc_train_step captured with defer_eval_tables = 1 at a batch size of the matrix-core sampler /
+    gradient (>= 16 384 walkers) bakes k_tsample / k_efused / k_ebwd in; a deferred refresh would leave every replay after the first on the
+    MFMA image and the composite tables of older parameters.  The step now refreshes everything whenever such a path applies at its batch
+    size, whatever the flag says: three replays of the captured deferred step equal three eager steps without deferral, bit for bit."""
+    import torch
+    from waveflow_amd.utils import physics
+    params, psi, log_pdf, sample = he(he_flat)
+    m = psi.model
+    protons = physics.system_catalogue[1]["He"][0].reshape(-1)
+    B, out = 16384, {}
+    for mode in ("eager", "graph"):
+        flat = torch.as_tensor(he_flat).cuda().clone()
+        st = m.make_train_state(flat, torch.zeros_like(flat), torch.zeros_like(flat), 1, ring_len=8, defer_eval_tables=(mode == "graph"))
+        m.set_params_device(flat)
+        m.train_step(st, 5, B, protons, 1e-3, exact_sampler=True)       # (also sizes the workspace and the scratch outside the capture)
+        if mode == "eager":
+            for _ in range(3):
+                m.train_step(st, 5, B, protons, 1e-3, exact_sampler=True)
+        else:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                side.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side):
+                    m.train_step(st, 5, B, protons, 1e-3, exact_sampler=True)
+            torch.cuda.current_stream().wait_stream(side)
+            # (the capture itself executes nothing: three replays = steps 2 .. 4)
+            for _ in range(3):
+                graph.replay()
+        torch.cuda.synchronize()
+        out[mode] = (flat.clone(), st["ring"].clone())
+    assert torch.isfinite(out["graph"][0]).all()
+    assert torch.equal(out["eager"][0], out["graph"][0]) and torch.equal(out["eager"][1], out["graph"][1])

@@ -330,3 +330,34 @@ def test_staged_sampler_other_models(monkeypatch):
             for a, b in ((xa, xb), (la, lb)):
                 p = stats.ks_2samp(a[:, col].cpu().numpy(), b[:, col].cpu().numpy()).pvalue
                 assert p > 1e-4, (c, col, p)
+
+
+def test_staged_sampler_leaves_high_prior_degrees_to_the_wave_sampler(monkeypatch):
+    """k_tsample's piecewise-constant envelope of the second prior column takes the maximum over at most 9 coefficients per
+    knot interval; a prior of degree > 8 has more live B-splines per interval, so those models keep the wave sampler (whose bound is the
+    global one) at every batch size: same seed, same draws with the staged path switched on and off -- and the draws follow the oracle's
+    column density."""
+    import torch
+    from scipy import stats
+    from waveflow_amd import flatten_params, flows, model_factory, wavefunctions
+    mt = model_factory.get_masked_transform
+    init = wavefunctions.Waveflow(
+        flows.Serial(flows.BoxTransformLayer(3.0), flows.IMADE(mt(), 5, 16, 0.05, 1e-6, {0: 0.0}, {0: 1.0}), flows.Reverse()),
+        mt(allow_negative_params=True), 9, 14, constraints_dict_left={0: 0}, constraints_dict_right={0: 0},
+        constrained_dimension_indices_left=[0], set_nn_output_grad_to_zero=False)
+    params, psi, log_pdf, _ = init(6, 2)
+    m = psi.model
+    m.ensure_params(params)
+    monkeypatch.setenv("WF_SAMPLE_TILE_MIN", "16384")
+    xa, la = m.sample(3, 20000, return_latent=True, exact=True)
+    monkeypatch.setenv("WF_SAMPLE_TILE_MIN", "0")
+    xb, lb = m.sample(3, 20000, return_latent=True, exact=True)
+    assert torch.isfinite(xa).all() and torch.equal(xa, xb) and torch.equal(la, lb)
+    # first latent column against the oracle's density of that column (bsplines_jax.py:144-171)
+    om = oracle.Model(D=2, n_layers=1, box="mean", box_L=3.0, i_k=5, i_knots=16, i_reg=0.05, prior="waveflow", p_k=9, p_knots=14, constr_left=(0,))
+    flat = flatten_params(params)
+    grid = np.linspace(0.0, 1.0, 4001).astype(np.float32)
+    dens, _ = om.prior_column_density(flat, np.zeros(2, np.float32), 0, grid)
+    cdf = np.cumsum(dens.astype(np.float64)); cdf /= cdf[-1]
+    p = stats.kstest(la[:, 0].cpu().numpy().astype(np.float64), lambda t: np.interp(t, grid, cdf)).pvalue
+    assert p > 1e-4, p

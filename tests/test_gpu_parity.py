@@ -76,7 +76,7 @@ def as_accurate_as_fp32_reference(gpu, oracle32, truth, rtol=RTOL, atol=ATOL, wh
 COND_MIN, LOGP_MIN = 0.05, 1.0
 
 
-def strict_on_well_conditioned_subset(gpu, oracle32, truth, cond, what=""):
+def strict_on_well_conditioned_subset(gpu, oracle32, truth, cond, what="", direct_margin=0.01):
     gpu, oracle32, truth = (np.asarray(v, np.float64) for v in (gpu, oracle32, truth))
     sub = (np.asarray(cond) > COND_MIN) & (np.abs(truth) > LOGP_MIN)
     if sub.sum() < 20:
@@ -86,13 +86,17 @@ def strict_on_well_conditioned_subset(gpu, oracle32, truth, cond, what=""):
     rel = 1e-5 * np.abs(truth)[sub]
     r_g, r_o = (e_g <= rel).mean(), (e_o <= rel).mean()
     direct = (np.abs(gpu - oracle32)[sub] <= 1e-5 * np.abs(oracle32)[sub]).mean()
+    direct_exact = (np.abs(truth - oracle32)[sub] <= 1e-5 * np.abs(oracle32)[sub]).mean()
     print(f"[strict {what}] {sub.sum()} of {sub.size} walkers well conditioned: pass 1e-5 rel vs fp64: HIP {r_g:.4f} fp32-oracle {r_o:.4f}; "
-          f"max |err| HIP {e_g.max():.2e} oracle {e_o.max():.2e}; direct HIP vs oracle32 within 1e-5 rel: {direct:.4f}")
+          f"max |err| HIP {e_g.max():.2e} oracle {e_o.max():.2e}; direct HIP vs oracle32 within 1e-5 rel: {direct:.4f} (exact arithmetic in place of HIP: {direct_exact:.4f})")
     assert r_g >= r_o - 0.005 - 3 * np.sqrt(r_o * (1 - r_o) / sub.sum()), (r_g, r_o)   # (3 sigma of a rate over sub.sum() walkers)
-    # the DIRECT statement of the north star on this subset, HIP against the fp32 oracle itself: two fp32 evaluations that each pass
-    # 1e-5 relative against exact arithmetic at rate r_o differ from EACH OTHER by more than that a little more often (measured at
-    # 2^20 walkers, r_o = 0.962: scalar kernel 0.980, MFMA kernel 0.940, wave kernel 0.95) -- floor: r_o - 0.06 (- 3 sigma)
-    assert direct >= r_o - 0.06 - 3 * np.sqrt(r_o * (1 - r_o) / sub.sum()), (direct, r_o)
+    # The DIRECT statement of the north star on this subset, HIP against the fp32 oracle itself.  The oracle carries its own fp32 roundings:
+    # EXACT arithmetic in place of the HIP result agrees with it to 1e-5 relative at rate direct_exact (0.962 at 2^20 walkers) -- the
+    # ceiling for every evaluation whose roundings are independent of the oracle's; only a kernel that repeats the oracle's operation order
+    # (the scalar kernel: 0.980) scores above it, by sharing its errors.  Round 4: the floor is that ceiling - 1 %
+    # (- 3 sigma) for every kernel -- the kernel itself may not be a measurable source of disagreement -- instead of r_o - 6 %.  The
+    # matrix-core kernel stood at 0.940 before its first hidden layer handed r - 1/2 to the second (wf_mfma_impl.h: hidden_layers).
+    assert direct >= direct_exact - direct_margin - 3 * np.sqrt(direct_exact * (1 - direct_exact) / sub.sum()), (direct, direct_exact)
     assert np.quantile(e_g, 0.99) <= 1.1 * max(np.quantile(e_o, 0.99), np.quantile(rel, 0.99)), (np.quantile(e_g, 0.99), np.quantile(e_o, 0.99))
     assert e_g.max() <= 2 * max(e_o.max(), rel.max()), (e_g.max(), e_o.max())
 
@@ -329,7 +333,7 @@ def test_general_boundary_constraint_dicts(kernel, D, knots):
     # oracle's 283 - 321 with {0: 0} dicts, 582 - 714 vs 308 - 432 with these; scalar and wave kernels match the oracle's counts): its
     # operands are fp16 pairs (22 significant bits, not 24) and its activations are exact to 2^-24 absolute rather than relative.
     # The shipped configurations pass the unrelaxed criteria (C1 - C4 tests above); here the MFMA kernel gets count <= 2x, tail <= 3x.
-    slack = dict(tail=3.0, count=2.0) if kernel == "mfma" else {}
+    slack = {}   # (rounds 2 - 3 allowed the matrix-core kernel tail = 3, count = 2 here; round 4: none)
     as_accurate_as_fp32_reference(log_pdf(params, x), om.log_pdf(flat, x), om.log_pdf(flat, x, f64=True), **slack)
     pso, pst = om.psi(flat, x), om.psi(flat, x, f64=True)
     as_accurate_as_fp32_reference(psi(params, x), pso, pst, atol=1e-6 * np.abs(pst).max(), **slack)
@@ -572,7 +576,9 @@ def test_strict_on_the_well_conditioned_subset(golden, he_flat, kernel, config):
     lp = log_pdf(params, x)
     lp32, _, _ = om.log_pdf_cond(flat, x, threads=thr)
     lp64, cond, _ = om.log_pdf_cond(flat, x, threads=thr, f64=True)
-    strict_on_well_conditioned_subset(lp, lp32, lp64, cond, what=f"{config} {kernel}")
+    # (the wave kernel's fp32 roundings are as large as the oracle's and independent of them: two such evaluations disagree more often than
+    # either disagrees with exact arithmetic; the matrix-core and the scalar kernel are held to exact arithmetic's own rate - 1 %)
+    strict_on_well_conditioned_subset(lp, lp32, lp64, cond, what=f"{config} {kernel}", direct_margin=0.04 if kernel == "wave" else 0.01)
     as_accurate_as_fp32_reference(lp, lp32, lp64, what=f"{config} {kernel}")
 
 
@@ -755,29 +761,34 @@ def test_small_batch_calls_are_graph_capturable(he_flat):
 
 
 def test_bench_two_rank_path_on_a_shared_gpu():
-    """bench.py --gpus 2 under torch.distributed.run (test hook: both ranks on cuda:0, gloo): one JSON line from rank 0 with the
-    whole-job aggregate, the per-step all-reduce completed inside the timed region."""
+    """`python bench.py --gpus 2` with NO launcher: bench.py starts its own two ranks (a child torch.distributed.run; test hook: both ranks
+    on cuda:0, gloo) and relays one JSON line from rank 0 with the whole-job aggregate, the per-step all-reduce completed inside the timed
+    region, and the per-rank keys of an N > 1 record.  A WORLD_SIZE that contradicts --gpus is refused."""
     import json
     import os
-    import socket
     import subprocess
     import sys
     from conftest import ROOT
-    sock = socket.socket()
-    sock.bind(("127.0.0.1", 0))
-    port = sock.getsockname()[1]
-    sock.close()
-    env = dict(os.environ, WF_BENCH_SHARE_GPU0="1", WF_BENCH_BACKEND="gloo")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2", "--batch", "65536"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(WF_BENCH_SHARE_GPU0="1", WF_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2", "--batch", "65536"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
+    assert len(lines) == 1 and r.stdout.strip() == lines[0]      # stdout carries the JSON line and nothing else
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 8 and d["scaling"] == "weak" and d["metric"] == "flow log-prob evals/sec"
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["steps"] == 8 and d["scaling"] == "weak" and d["metric"] == "flow log-prob evals/sec"
     assert abs(d["value"] - 2 * 65536 * 8 / (d["ms_per_step"] * 8e-3)) < 1e-6 * d["value"]
     assert "cpu_baseline" not in d and d["roofline"]["bound"] == "mfma"
+    assert len(d["kernel_ms_per_rank"]) == 2 and len(d["per_rank_solo_evals_per_s"]) == 2 and len(d["roofline_per_rank"]) == 2
+    assert abs(d["scaling_efficiency"] - d["value"] / sum(d["per_rank_solo_evals_per_s"])) < 1e-9
+    assert 0.2 < d["scaling_efficiency"] < 1.5      # two ranks SHARE one GPU here: the hook tests the plumbing, not the scaling
+    # the same batch on both ranks' shards: the all-reduced mean of the last step is the mean over both shards (vqmc.py:196)
+    assert np.isfinite(d["config"]["mean_logp"])
+    # --gpus 1 inside a two-rank world: refused
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--no-extras", "--no-cpu-baseline"],
+                         env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert bad.returncode != 0 and "WORLD_SIZE=2" in (bad.stdout + bad.stderr)
 
 
 @pytest.mark.parametrize("kernel", KERNELS)
@@ -797,7 +808,7 @@ def test_gated_conditioner_heads(kernel):
     g = np.random.default_rng(21)
     x = g.random((20000, 2)).astype(np.float32)
     flat = flatten_params(params)
-    slack = dict(tail=3.0, count=2.0) if kernel == "mfma" else {}
+    slack = {}   # (rounds 2 - 3: tail = 3, count = 2 for the matrix-core kernel; round 4: none)
     as_accurate_as_fp32_reference(log_pdf(params, x), om.log_pdf(flat, x), om.log_pdf(flat, x, f64=True), what="gated get_model", **slack)
     # the gate is not a no-op: the ungated evaluation of the same parameters differs
     om0 = oracle.Model(D=2, n_layers=2, i_k=5, i_knots=15, i_reg=0.05, i_left=il, i_right=ir, prior="mflow", p_k=5, p_knots=15, p_left=pl, p_right={})
@@ -849,3 +860,118 @@ def test_gated_conditioner_heads(kernel):
     assert np.isfinite(m.logpdf_vjp(x[:16], np.ones(16, np.float32)).cpu().numpy()).all()
     L = _lib.lib()
     assert L.wf_vqmc_train_step_workspace_bytes(m._h, 128) > 0 and L.wf_mle_train_step_workspace_bytes(m._h, 128) > 0
+
+
+def test_fp16_range_guard_routes_around_the_matrix_cores(he_flat, monkeypatch):
+    """k_pack casts scale * W (|scale| up to 5.8) to fp16 for the matrix-core operand images; one weight of 3e4 makes that
+    +-inf in every MFMA image.  The upload detects it (k_fold_bias): `auto` then takes the fp32 kernels -- bit-identical to an explicit request
+    for them --, an explicit request for the MFMA kernel is WF_ERR_UNSUPPORTED, the large-batch H psi / sampler keep the wave kernels, and the
+    next in-range upload switches everything back."""
+    import torch
+    from waveflow_amd import _lib
+    from waveflow_amd.utils import physics
+    params, psi, log_pdf, _ = he_models(he_flat, "auto")
+    m = psi.model
+    protons = physics.system_catalogue[1]["He"][0].reshape(-1)
+    x = torch.as_tensor(sorted_walkers(20000, 2, 9.5, 31)).cuda()
+    m.set_params(he_flat)
+    m.set_kernel("mfma")
+    good = m.log_pdf(x)
+    bad_flat = he_flat.copy()
+    D, H = 2, 64
+    w1_off = D * H + H                                  # W1 of the first flow net
+    bad_flat[w1_off + 5 * H + 7] = 3.0e4                # |(-2 * 2 log2 e) * 3e4| = 1.7e5 > 65 504
+    m.set_kernel("auto")
+    m.set_params(bad_flat)
+    a = m.log_pdf(x)
+    assert torch.isfinite(a).all()
+    m.set_kernel("scalar")
+    assert torch.equal(a, m.log_pdf(x))
+    m.set_kernel("mfma")                                # (accepted: the model has the kernel) ...
+    with pytest.raises(_lib.WfError) as e:
+        m.log_pdf(x)                                    # ... but not with these parameters
+    assert e.value.status == _lib.ERR_UNSUPPORTED
+    m.set_kernel("auto")
+    h_auto = m.hamiltonian(x, protons)
+    monkeypatch.setenv("WF_ENERGY_TILE_MIN", "0")
+    assert torch.equal(h_auto, m.hamiltonian(x, protons)) and torch.isfinite(h_auto).all()
+    monkeypatch.delenv("WF_ENERGY_TILE_MIN")
+    s_auto = m.sample(3, 20000, exact=True)
+    monkeypatch.setenv("WF_SAMPLE_TILE_MIN", "0")
+    assert torch.equal(s_auto, m.sample(3, 20000, exact=True)) and torch.isfinite(s_auto).all()
+    monkeypatch.delenv("WF_SAMPLE_TILE_MIN")
+    # the same through the asynchronous upload (the flag travels behind the pack kernels; the next call waits for it)
+    m.set_params(he_flat)
+    m.set_params_device(torch.as_tensor(bad_flat).cuda())
+    m.set_kernel("mfma")
+    with pytest.raises(_lib.WfError):
+        m.log_pdf(x)
+    # back in range: the MFMA kernel again, same bits as before
+    m.set_params(he_flat)
+    assert torch.equal(good, m.log_pdf(x))
+    m.set_kernel("auto")
+
+
+def test_c4_antisymmetrised_psi_of_unsorted_walkers_on_the_device():
+    """BASELINE configs[3] as it is worded ("square-flow antisymmetrised psi", helpers.py:55-58, coordinates.py:41-51): 2^18 UNSORTED walkers of the
+    8-electron chain -> psi(sort(x)) * (-1)^inversions(x) in one launch (k_mfma sorts each row in registers and signs its output).  Against the
+    same kernel on host-sorted rows with the host's inversion parity: bit for bit, sign included; the inversion counts equal the host's pair
+    count; a sample against the C oracle with the usual yardstick; the wave and the scalar kernel (sorted rows through the scratch) agree in
+    sign bit for bit and in value as usual; ties exchange nothing."""
+    torch = _torch()
+    from waveflow_amd import flatten_params, model_factory
+    from waveflow_amd.utils.coordinates import get_num_inversion_count
+    init_fun = model_factory.get_waveflow_model(8, base_spline_degree=6, i_spline_degree=6, n_prior_internal_knots=23,
+                                                n_i_internal_knots=23, i_spline_reg=0.05, n_flow_layers=3, box_size=10.0)
+    params, psi, log_pdf, _ = init_fun(42, 8)
+    m = psi.model
+    m.ensure_params(params)
+    m.set_kernel("mfma")
+    B = 1 << 18
+    g = np.random.default_rng(4321)
+    xn = g.uniform(-10.0, 10.0, size=(B, 8)).astype(np.float32)
+    xn[5, 3] = xn[5, 6]                                           # a tie: counted by `>`, exchanged by nothing
+    xn[7] = np.sort(xn[7])[::-1]                                  # the reversed row: 28 inversions
+    x = torch.from_numpy(xn).cuda()
+    inv_host = get_num_inversion_count(xn)
+    assert inv_host[7] == 28 and inv_host.min() >= 0 and (inv_host & 1).mean() > 0.4
+    ps, inv = m.psi_antisym(x, return_inversions=True)
+    assert np.array_equal(inv.cpu().numpy(), inv_host)
+    assert np.array_equal(get_num_inversion_count(x).cpu().numpy(), inv_host)      # the device count alone (wf_inversion_count)
+    xs = torch.from_numpy(np.sort(xn, axis=-1)).cuda()
+    ref = m.psi(xs) * torch.from_numpy(((-1.0) ** inv_host).astype(np.float32)).cuda()
+    assert torch.isfinite(ps).all() and torch.equal(ps, ref)
+    assert torch.equal(m.log_pdf_unsorted(x), m.log_pdf(xs))
+    sel = np.arange(0, B, 64)
+    om = oracle.Model(D=8, n_layers=3, box="mean", box_L=10.0, i_k=6, i_knots=23, i_reg=0.05, i_left={0: 0}, i_right={0: 1},
+                      prior="waveflow", p_k=6, p_knots=23, p_left={0: 0}, p_right={0: 0}, constr_left=tuple(range(7)))
+    flat = flatten_params(params)
+    sgn = (-1.0) ** inv_host[sel]
+    o32 = om.psi(flat, np.sort(xn[sel], axis=-1), threads=8) * sgn
+    o64 = om.psi(flat, np.sort(xn[sel], axis=-1), threads=8, f64=True) * sgn
+    got = ps[torch.from_numpy(sel).cuda()].cpu().numpy()
+    nz = np.abs(o64) > 1e-6 * np.abs(o64).max()
+    assert np.array_equal(np.sign(got[nz]), np.sign(o64[nz]))      # the sign, bit for bit
+    as_accurate_as_fp32_reference(got, o32, o64, atol=1e-6 * np.abs(o64).max(), what="C4 antisymmetrised psi, 2^18 unsorted walkers (sample)")
+    # the kernels that read sorted rows from the scratch: same sign, values as close as two kernels are
+    small = x[:3000]
+    for kernel in ("wave", "scalar"):
+        m.set_kernel(kernel)
+        a = m.psi_antisym(small)
+        b = ps[:3000]
+        big = b.abs() > 1e-6 * b.abs().max()
+        assert torch.equal(torch.sign(a[big]), torch.sign(b[big])), kernel
+        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()), kernel
+        assert torch.equal(m.log_pdf_unsorted(small), m.log_pdf(xs[:3000])), kernel
+    m.set_kernel("auto")
+
+
+def test_antisymmetrised_psi_of_the_he_grid_on_the_device(he_flat, golden):
+    """The reference's own use of the sign (helpers.py:52-59): psi on the 100 x 100 grid of UNSORTED coordinate pairs, sorted and signed on the
+    device, against the shipped output file -- the same bound as the host-sorted comparison."""
+    params, psi, log_pdf, om = he_models(he_flat, "mfma")
+    psi.model.ensure_params(params)
+    coords, srt, sign = he_grid()
+    z = psi.model.psi_antisym(coords.astype(np.float32))
+    assert np.abs(z - golden["he_golden"]["psi_grid"]).max() < 2.5e-5
+    assert np.array_equal(z, psi(params, srt.astype(np.float32)) * sign.astype(np.float32))     # the host-sorted route, bit for bit

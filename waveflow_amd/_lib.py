@@ -18,6 +18,7 @@ BOX_NONE, BOX_MEAN, BOX_FIRST = 0, 1, 2
 PRIOR_WAVEFLOW, PRIOR_MFLOW, PRIOR_UNIFORM, PRIOR_NORMAL = 0, 1, 2, 3
 KERNEL_AUTO, KERNEL_SCALAR, KERNEL_MFMA, KERNEL_WAVE = 0, 1, 2, 3
 ERR_NO_DEVICE = -4
+ERR_UNSUPPORTED = -2
 
 
 class WfError(RuntimeError):
@@ -70,7 +71,7 @@ EXPORTS = ["wf_abi_version", "wf_strerror", "wf_last_hip_error", "wf_last_hip_er
            "wf_psi_vjp", "wf_psi_vjp_workspace_bytes", "wf_vqmc_seeds",
            "wf_logpdf_vjp", "wf_logpdf_vjp_workspace_bytes", "wf_vqmc_loss_grad", "wf_model_set_params_device", "wf_adam_step",
            "wf_vqmc_train_step", "wf_vqmc_train_step_workspace_bytes", "wf_nsc_fwd", "wf_nsc_workspace_bytes", "wf_logpdf_loss_grad", "wf_mle_train_step", "wf_mle_train_step_workspace_bytes", "wf_vqmc_train_step_local",
-           "wf_vqmc_train_step_apply"]
+           "wf_vqmc_train_step_apply", "wf_psi_antisym_fwd", "wf_logpdf_unsorted_fwd", "wf_inversion_count"]
 
 _lib = None
 
@@ -116,6 +117,12 @@ def lib():
         f.argtypes = [vp, vp, i64, vp, vp, vp, vp]
     L.wf_flow_fwd.restype = i32
     L.wf_flow_fwd.argtypes = [vp, vp, i64, vp, vp, vp]
+    L.wf_psi_antisym_fwd.restype = i32
+    L.wf_psi_antisym_fwd.argtypes = [vp, vp, i64, vp, vp, vp]
+    L.wf_logpdf_unsorted_fwd.restype = i32
+    L.wf_logpdf_unsorted_fwd.argtypes = [vp, vp, i64, vp, vp]
+    L.wf_inversion_count.restype = i32
+    L.wf_inversion_count.argtypes = [vp, i64, i32, vp, vp]
     L.wf_layer_fwd.restype = i32
     L.wf_layer_fwd.argtypes = [vp, i32, vp, i64, vp, vp, vp, vp]
     L.wf_inverse_fwd.restype = i32

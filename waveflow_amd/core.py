@@ -172,6 +172,24 @@ class DeviceModel:
     def psi(self, x, return_sample=False, return_bin_idx=False):
         return self._eval(_lib.lib().wf_psi_fwd, x, return_sample, return_bin_idx)
 
+    def psi_antisym(self, x, return_inversions=False):
+        """psi(sort(x)) * (-1)^inversions(x) for walkers in any particle order (helpers.py:55-58, coordinates.py:41-51): sort and sign on the device."""
+        torch = _torch()
+        t, back = self._to_dev(x)
+        B = t.shape[0]
+        out = self._new((B,))
+        inv = self._new((B,), torch.int32) if return_inversions else None
+        _lib.check(_lib.lib().wf_psi_antisym_fwd(self._h, self._p(t), B, self._p(out), self._p(inv), self._stream()), "wf_psi_antisym_fwd")
+        return (back(out), back(inv)) if return_inversions else back(out)
+
+    def log_pdf_unsorted(self, x):
+        """log_pdf(sort(x)): rows in any particle order, sorted on the device."""
+        t, back = self._to_dev(x)
+        B = t.shape[0]
+        out = self._new((B,))
+        _lib.check(_lib.lib().wf_logpdf_unsorted_fwd(self._h, self._p(t), B, self._p(out), self._stream()), "wf_logpdf_unsorted_fwd")
+        return back(out)
+
     def flow(self, x):
         t, back = self._to_dev(x)
         B = t.shape[0]

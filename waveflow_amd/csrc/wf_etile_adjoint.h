@@ -13,7 +13,7 @@
 // pullback against central differences).
 #pragma once
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define WF_HD __host__ __device__ __forceinline__
 #else
 #define WF_HD inline

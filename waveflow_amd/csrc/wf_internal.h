@@ -121,6 +121,7 @@ struct MfmaDev {
     int i_gate, p_gate;        // gated heads (wf_model_desc.i_gate / p_gate): zero_params blocks of the net images are live
     int timg_off, tnet_floats, tconst_off;   // transposed operand images of the gradient path behind the constants block (float offsets in `image`; -1: not built)
     int p_bias;                // the B prior's boundary map has a constant term: cbP[nbk][2][16] (accumulator layout) sits at the end of the constants block
+    const int* f16_ovf;        // [n_nets] 1 = a packed weight of that net is outside the fp16 range (k_fold_bias, rewritten at every upload): outputs are poisoned with NaN
 };
 
 constexpr int kStagedGroups = 4;   // staged mode: a wave's tile groups whose state waits in LDS between two nets (LDS: waves x groups x T x (D + 1) x 128 B)
@@ -131,7 +132,7 @@ int launch_mfma(int D, int nbk, const MfmaDev* mdev, int lds_bytes, int mode, co
 bool mfma_shape_built(int D, int nbk);
 int mfma_extra_lds_floats(int n_nets);
 int dim0_coef_floats(int n_nets);
-int launch_fold_bias(float* image_dev, int n_nets, int net_floats, int D, int nbk, void* stream);
+int launch_fold_bias(float* image_dev, int n_nets, int net_floats, int D, int nbk, int* ovf_dev, void* stream);
 int launch_prepare_dim0(const ModelDev* md_dev, int n_nets, int n_mesh, const float* fk_nat_dev, float F_I, float F_P, const float* tab_i_dev,
                         const float* tab_p_dev, void* comp_dev,
                         void* stream);
@@ -251,6 +252,10 @@ int launch_nsc(const float* x, int64_t B, int dim, int K, float tail, int hidden
 int launch_block_sums(const float* v, int64_t B, double* out, void* ws, int64_t ws_bytes, void* stream, double* ring = nullptr, int ring_len = 0,
                       unsigned long long* counter = nullptr);
 int64_t block_sums_ws_bytes(int64_t B);
+// walkers in any order: rows sorted ascending (xs may be null) and / or their inversion counts (inv may be null); psi *= (-1)^inv
+constexpr int kModePresort = 4;   // bit of launch_mfma's mode: sort each row in registers, psi gets (-1)^inversions (wf_mfma_impl.h)
+int launch_sort_rows(const float* x, int64_t B, int D, float* xs, int32_t* inv, void* stream);
+int launch_apply_sign(float* v, const int32_t* inv, int64_t B, void* stream);
 
 void set_hip_error(int e);
 

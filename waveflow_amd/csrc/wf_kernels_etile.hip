@@ -684,6 +684,9 @@ __global__ __launch_bounds__(kFusedWaves * 64) void k_efused(const MfmaDev mm, c
     const int n_mesh = mm.n_mesh;
     const int64_t n_tiles = (B + 31) >> 5;
     const int64_t my_tiles = n_tiles > (int64_t)blockIdx.x ? (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    int f16_bad = 0;
+    if (mm.f16_ovf)
+        for (int n = 0; n < mm.n_nets; ++n) f16_bad |= mm.f16_ovf[n];
     for (;;) {
         int q_ = 0;
         if (lane == 0) q_ = __hip_atomic_fetch_add(&next_tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -808,9 +811,10 @@ __global__ __launch_bounds__(kFusedWaves * 64) void k_efused(const MfmaDev mm, c
                 const float r = x1v - x0v;
                 V += 1.0f / sqrtf(1.0f + r * r);
             }
-            hpsi[w] = -0.5f * lap + V * psi.v;
-            if (psi_out) psi_out[w] = psi.v;
-            if (lap_out) lap_out[w] = lap;
+            // a packed weight outside the fp16 range (k_fold_bias): NaN instead of whatever inf operands made of the walker
+            hpsi[w] = f16_bad ? __builtin_nanf("") : -0.5f * lap + V * psi.v;
+            if (psi_out) psi_out[w] = f16_bad ? __builtin_nanf("") : psi.v;
+            if (lap_out) lap_out[w] = f16_bad ? __builtin_nanf("") : lap;
         }
     }
 }

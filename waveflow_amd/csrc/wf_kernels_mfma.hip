@@ -177,13 +177,17 @@ __global__ void k_pair_dim0(const f32x4* __restrict__ comp, int n_nets, int nm, 
 // b' = b + sum_k W_k for the layers whose input is a tanh (see act_split_block): the packed weights already hold -2 c W as fp16
 // pairs in MFMA A-operand order, so the column sum is -0.5 * sum over the 64 k's of (hi + lo).  One thread per bias entry, fixed
 // summation order (deterministic); runs after k_pack at every parameter upload.  Padding rows have zero weights: unchanged.
-__global__ void k_fold_bias(float* __restrict__ image, int net_floats, int D, int nbk) {
+// ovf[net] (may be null) = 1 when a packed weight of the net left the fp16 range (|scale * W| >= 65 520: its hi half is +-inf), else 0 -- rewritten at
+// every upload.  The matrix-core kernels would turn such a weight into inf / NaN for every walker; wf_model.cpp routes around them while it is set
+// (include/waveflow_hip.h: "fp16 range") and k_mfma / k_efused poison their outputs with NaN if they are launched anyway (a captured graph).
+__global__ void k_fold_bias(float* __restrict__ image, int net_floats, int D, int nbk, int* __restrict__ ovf) {
     const int S0 = (D + 1) / 2;
     const int W1h = 128 * S0 + 64, b1 = W1h + 4096, W2h = b1 + 64;
     const int n_out_blocks = (D - 1) * nbk;
     const int b2 = W2h + n_out_blocks * 2048;
     float* net = image + (size_t)blockIdx.x * net_floats;
     const int n_entries = 64 + n_out_blocks * 32;
+    int bad = 0;
     for (int e = threadIdx.x; e < n_entries; e += blockDim.x) {
         const _Float16* halves;
         int n_pairs, blk, bias_at;
@@ -206,10 +210,14 @@ __global__ void k_fold_bias(float* __restrict__ image, int net_floats, int D, in
             for (int hh = 0; hh < 2; ++hh)
                 for (int j = 0; j < 8; ++j) {
                     const int idx = ((blk * 4 + ts) * 64 + row + 32 * hh) * 8 + j;
-                    sum += (float)halves[idx] + (float)halves[n_pairs + idx];
+                    const float hi = (float)halves[idx];
+                    bad |= !(fabsf(hi) <= 65504.0f);   // +-inf (or NaN from a NaN parameter)
+                    sum += hi + (float)halves[n_pairs + idx];
                 }
         net[bias_at] += -0.5f * sum;
     }
+    bad = __syncthreads_or(bad);
+    if (ovf && threadIdx.x == 0) ovf[blockIdx.x] = bad ? 1 : 0;
 }
 
 int waves_per_group(int tiles, int nbk) {
@@ -242,9 +250,9 @@ bool mfma_div_ok(int n_mesh) {
 }
 int dim0_coef_floats(int n_nets) { return n_nets * kCoefStride; }
 
-int launch_fold_bias(float* image_dev, int n_nets, int net_floats, int D, int nbk, void* stream) {
+int launch_fold_bias(float* image_dev, int n_nets, int net_floats, int D, int nbk, int* ovf_dev, void* stream) {
     if (n_nets <= 0 || !image_dev) return WF_OK;
-    hipLaunchKernelGGL(k_fold_bias, dim3(n_nets), dim3(128), 0, (hipStream_t)stream, image_dev, net_floats, D, nbk);
+    hipLaunchKernelGGL(k_fold_bias, dim3(n_nets), dim3(128), 0, (hipStream_t)stream, image_dev, net_floats, D, nbk, ovf_dev);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_hip_error((int)e);

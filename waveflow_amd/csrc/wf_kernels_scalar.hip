@@ -178,6 +178,40 @@ int launch_scalar_sample(const ModelDev& md, const ModelDev* md_dev, unsigned lo
     return finish_launch();
 }
 
+// ---- walkers in any order (helpers.py:55-58, coordinates.py:41-51): per row the ascending sort and the inversion count.  The MFMA kernel does
+// both in registers (mode bit kModePresort); the other kernels get sorted rows from here and psi its sign afterwards.
+__global__ void k_sort_rows(const float* __restrict__ x, int64_t B, int D, float* __restrict__ xs, int32_t* __restrict__ inv) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float r[WF_MAX_DIM];
+    for (int d = 0; d < D; ++d) r[d] = x[b * D + d];
+    int n = 0;
+    for (int pass = 0; pass < D; ++pass)          // odd-even transposition: adjacent exchanges only, #exchanges == #inversions (ties: none)
+        for (int i = pass & 1; i + 1 < D; i += 2)
+            if (r[i] > r[i + 1]) {
+                const float t = r[i]; r[i] = r[i + 1]; r[i + 1] = t;
+                ++n;
+            }
+    if (xs)
+        for (int d = 0; d < D; ++d) xs[b * D + d] = r[d];
+    if (inv) inv[b] = n;
+}
+__global__ void k_apply_sign(float* __restrict__ v, const int32_t* __restrict__ inv, int64_t B) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B && (inv[b] & 1)) v[b] = -v[b];
+}
+
+int launch_sort_rows(const float* x, int64_t B, int D, float* xs, int32_t* inv, void* stream) {
+    if (B <= 0) return WF_OK;
+    hipLaunchKernelGGL(k_sort_rows, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, B, D, xs, inv);
+    return finish_launch();
+}
+int launch_apply_sign(float* v, const int32_t* inv, int64_t B, void* stream) {
+    if (B <= 0) return WF_OK;
+    hipLaunchKernelGGL(k_apply_sign, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, v, inv, B);
+    return finish_launch();
+}
+
 int64_t block_sums_ws_bytes(int64_t) { return (int64_t)kSumMaxBlocks * 2 * sizeof(double); }
 
 // ring != NULL: the kernel that ends up with the sums also pushes them to the loss ring and advances the step counter

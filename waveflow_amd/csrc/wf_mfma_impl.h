@@ -219,7 +219,8 @@ __device__ __forceinline__ void dense64_block(const _Float16* Wh, const _Float16
 }
 // the activation of registers 8s .. 8s+7 of a block (one K = 16 fragment) of every tile: the unit of work that is placed between
 // the K steps of an MFMA chain that does not depend on it (hidden_layers, out_block_first)
-template <int T>
+// CENTER: r - 1/2 instead of r (= -tanh / 2: the layer behind takes the UNFOLDED bias NetOff::b1c, see hidden_layers)
+template <int T, bool CENTER = false>
 __device__ __forceinline__ void act8(const f32x16 (&x)[T], int s, Frag (&f)[T][2], int ob) {
 #pragma unroll
     for (int t = 0; t < T; ++t) {
@@ -230,12 +231,20 @@ __device__ __forceinline__ void act8(const f32x16 (&x)[T], int s, Frag (&f)[T][2
 #else
         float r[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) r[j] = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x[t][8 * s + j]) + 1.0f);
+        for (int j = 0; j < 8; ++j) {
+            r[j] = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x[t][8 * s + j]) + 1.0f);
+            if (CENTER) r[j] = r[j] - 0.5f;
+        }
         split8(r, f[t][ob].hi[s], f[t][ob].lo[s]);
 #endif
     }
 }
 
+#ifdef WF_NO_CENTER   // A/B build: the flow nets' first hidden layer in the folded form of rounds 2 - 3
+constexpr bool kCenter = false;
+#else
+constexpr bool kCenter = true;
+#endif
 // float offsets inside a net image (wf_model.cpp: build_mfma_image); NBK = 32-row blocks per dimension (1 or 2)
 template <int D, int NBK>
 struct NetOff {
@@ -249,7 +258,8 @@ struct NetOff {
     static constexpr int W2l = W2h + (D - 1) * NBK * 1024;
     static constexpr int b2 = W2l + (D - 1) * NBK * 1024;
     static constexpr int z = b2 + 32 * D * NBK;     // zero_params of a gated head [D][NBK][2][16] (zeros otherwise)
-    static constexpr int total = z + 32 * D * NBK;
+    static constexpr int b1c = z + 32 * D * NBK;    // the second hidden layer's bias WITHOUT the column sums of k_fold_bias [2][2][16] (centred activations)
+    static constexpr int total = b1c + 64;
 };
 
 // Hidden layers of one conditioner net for the wave's T tiles of 32 walkers.  Written in the order the instructions should issue:
@@ -258,7 +268,15 @@ struct NetOff {
 //   chain(layer 2, block 1)                              ||  activation of layer-2 block 0
 // Result: h2[t][0] complete, pend[t] = pre-activations of layer-2 block 1 (their activation goes under the first K steps of the
 // output chain: out_block_first).
-template <int D, int NBK, int T>
+// CENTER (the flow nets; round 4): the first hidden layer hands r - 1/2 = -tanh/2 to the second one, whose bias is then the plain c b1
+// (NetOff::b1c) instead of c (b1 + sum_k W1_k).  With r itself the products (-2 c W1_k) r_k are of the size of the weights while their sum,
+// after the constant cancels, is of the size of sum_k W1_k tanh_k: the 2^-22 relative representation error of the fp16 pairs and the
+// accumulator's roundings at the constant's magnitude then show in the pre-activations of the second hidden layer -- the one site that moved
+// the kernel's agreement with the fp32 reference (scratch/r04_parity_attribution.py, profiles/r04_parity_attribution.txt: 1.8 % of the
+// well-conditioned walkers moved by more than 1e-5 relative through this product alone, a fourth product lo * lo changes nothing, the centred
+// form 0.25 - 0.7 %).  One v_add_f32 per value of the first hidden layer; the output layer and the prior net keep the folded form (their
+// sites move no walker).
+template <int D, int NBK, int T, bool CENTER = false>
 __device__ __forceinline__ void hidden_layers(const float* net, const float (&in)[T][D], int lane, Frag (&h2)[T][2], f32x16 (&pend)[T]) {
     using O = NetOff<D, NBK>;
     const int h = lane >> 5;
@@ -280,27 +298,28 @@ __device__ __forceinline__ void hidden_layers(const float* net, const float (&in
             }
         }
     }
-    act8<T>(a[0], 0, h1, 0);
-    act8<T>(a[0], 1, h1, 0);
+    act8<T, CENTER>(a[0], 0, h1, 0);
+    act8<T, CENTER>(a[0], 1, h1, 0);
     const _Float16* W1h = reinterpret_cast<const _Float16*>(net + O::W1h);
     const _Float16* W1l = reinterpret_cast<const _Float16*>(net + O::W1l);
+    constexpr int kB1 = CENTER ? O::b1c : O::b1;
     f32x16 c0[T];
     {
-        const f32x16 bias = load16(net + O::b1 + h * 16);
+        const f32x16 bias = load16(net + kB1 + h * 16);
 #pragma unroll
         for (int t = 0; t < T; ++t) c0[t] = bias;
     }
     WF_PIN();
     mfma_step<T>(W1h, W1l, 0, 0, h1, c0, lane);
-    act8<T>(a[1], 0, h1, 1);
+    act8<T, CENTER>(a[1], 0, h1, 1);
     WF_PIN();
     mfma_step<T>(W1h, W1l, 0, 1, h1, c0, lane);
-    act8<T>(a[1], 1, h1, 1);
+    act8<T, CENTER>(a[1], 1, h1, 1);
     WF_PIN();
     mfma_step<T>(W1h, W1l, 1, 0, h1, c0, lane);
     mfma_step<T>(W1h, W1l, 1, 1, h1, c0, lane);
     {
-        const f32x16 bias = load16(net + O::b1 + (2 + h) * 16);
+        const f32x16 bias = load16(net + kB1 + (2 + h) * 16);
 #pragma unroll
         for (int t = 0; t < T; ++t) pend[t] = bias;
     }
@@ -552,8 +571,14 @@ __device__ __forceinline__ void stage_floats(const float* __restrict__ src, floa
 // SPEC: the headline family (mean-type box, IMADE layers, Waveflow prior, every net resident in LDS, division-free x_l / n) with the
 // model switches as compile-time constants: the tile loop becomes one straight-line block per net.
 template <int D, int NBK, int kWaves, int T, bool IDX, bool SPEC>
-__global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode, const float* __restrict__ xg, int64_t B,
+__global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode_in, const float* __restrict__ xg, int64_t B,
                                                       float* __restrict__ out, float* __restrict__ u_out, int32_t* __restrict__ idx_out) {
+    // mode_in & 3: 0 log_pdf, 1 psi, 2 flow only.  mode_in & 4 (kModePresort): the walkers arrive in ANY order -- every row is sorted in
+    // registers (odd-even transposition network: adjacent exchanges only, so the number of exchanges IS the inversion count, ties included)
+    // and psi gets the sign (-1)^inversions: the antisymmetrised wavefunction psi(sort(x)) * (-1)^inv of helpers.py:55-58 /
+    // coordinates.py:41-51 without a host loop or a second pass over the walkers.
+    const int mode = mode_in & 3;
+    const bool presort = (mode_in & 4) != 0;
     // mm is passed BY VALUE: it lives in the kernarg segment, so its fields are scalar loads and the table pointers
     // are known to be global (with a pointer-to-struct argument hipcc emitted flat_load for every table access).
     // LDS: [constants][net slot(s)].  Resident mode: every net has its own slot, staged once.  Staged mode (the nets do
@@ -604,6 +629,9 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
     // per SIMD slot keeps them out of phase (there is no barrier after this point in resident mode).
     for (int q = 0; q < ((wave >> 2) & 3); ++q) __builtin_amdgcn_s_sleep(WF_STAGGER);
 #endif
+    int f16_bad = 0;   // wave-uniform: scalar loads
+    if (mm.f16_ovf)
+        for (int n = 0; n < mm.n_nets; ++n) f16_bad |= mm.f16_ovf[n];
     // this workgroup's chunks: blockIdx.x, blockIdx.x + gridDim.x, ...; a slot = (chunk, wave position) = T tiles
     const int64_t my_chunks = n_chunks > (int64_t)blockIdx.x ? (n_chunks - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
     const int my_slots = (int)(my_chunks * kWaves);
@@ -625,6 +653,17 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
             const int64_t wl = valid[t] ? w[t] : B - 1;
 #pragma unroll
             for (int d = 0; d < D; ++d) cur[t][d] = xg[wl * D + d];
+            if (presort) {
+#pragma unroll
+                for (int r = 0; r < D; ++r)
+#pragma unroll
+                    for (int i = r & 1; i + 1 < D; i += 2) {
+                        const float a = cur[t][i], b = cur[t][i + 1];
+                        const bool sw = a > b;
+                        cur[t][i] = sw ? b : a;
+                        cur[t][i + 1] = sw ? a : b;
+                    }
+            }
         }
         // ---- BoxTransformLayer (made.py:118-137, 156-183); IEEE divisions: layer-0 bin indices must be exact
 #pragma unroll
@@ -670,7 +709,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
             Frag h2[T][2];
             f32x16 pend[T];
             STAMP(0);
-            hidden_layers<D, NBK, T>(net, cur, lane, h2, pend);
+            hidden_layers<D, NBK, T, kCenter>(net, cur, lane, h2, pend);
             STAMP(1);
             if (layer_kind == WF_LAYER_IMADE) {
                 // dimension 0: walker-independent weights -> composite table (k_prepare_dim0)
@@ -939,6 +978,18 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
 #pragma unroll
         for (int t = 0; t < T; ++t)
             if (valid[t] && h == 0) {
+                if (f16_bad) result[t] = __builtin_nanf("");   // a packed weight outside the fp16 range (k_fold_bias): NaN, not what inf operands made of it
+                if (presort && mode == 1) {   // (-1)^inversions of the walker as it arrived (coordinates.py:41-51): the row is read again, nothing rides through the nets
+                    int inv = 0;
+                    float xr[D];
+#pragma unroll
+                    for (int d = 0; d < D; ++d) xr[d] = xg[w[t] * D + d];
+#pragma unroll
+                    for (int i = 0; i < D; ++i)
+#pragma unroll
+                        for (int k = i + 1; k < D; ++k) inv += xr[i] > xr[k] ? 1 : 0;
+                    if (inv & 1) result[t] = -result[t];
+                }
                 out[w[t]] = result[t];
                 if (u_out) {
 #pragma unroll

@@ -88,6 +88,14 @@ struct wf_model {
     // biases and the composite dimension-0 tables are those of older parameters.  Cleared by the next full refresh; while it is set,
     // wf_hamiltonian_fwd stays on the wave sweeps (which read neither) -- include/waveflow_hip.h promises it needs no refresh.
     bool eval_tables_stale = false;
+    // fp16 range of the matrix-core operand images: k_fold_bias leaves one flag per net in d_f16_ovf at every upload; the host copy arrives through
+    // pinned memory behind ovf_event (f16_overflow() below waits for it when an entry point needs the answer before the upload has finished).
+    int* d_f16_ovf = nullptr;
+    int* h_f16_ovf = nullptr;
+    hipEvent_t ovf_event = nullptr;
+    bool ovf_pending = false;
+    bool f16_overflow = false;
+    bool local_step_tile = false;    // the last wf_vqmc_train_step_local ran at a batch size of the matrix-core sampler / gradient: _apply refreshes every table
     wf::ModelDev dev{};
     std::vector<void*> allocs;
     // device images
@@ -718,7 +726,7 @@ static inline int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h;
 
 static int mfma_net_floats(int D, int nbk) {
     const int S0 = (D + 1) / 2;
-    return 128 * S0 + 64 + 4096 + 64 + (D - 1) * nbk * 2048 + 32 * D * nbk + 32 * D * nbk;   // ..., biases, zero_params
+    return 128 * S0 + 64 + 4096 + 64 + (D - 1) * nbk * 2048 + 32 * D * nbk + 32 * D * nbk + 64;   // ..., biases, zero_params, unfolded b1 (NetOff::b1c)
 }
 
 // per-row factor: remove_bias scaling (isplines_jax.py:196-202 / msplines_jax.py:186-192) times the
@@ -870,6 +878,11 @@ static void describe_mfma_image(const wf_model* m, int n, uint32_t base, std::ve
                     if (sig) w.f32_abs(src);
                     else w.f32(src);
                 }
+    // NetOff::b1c: the second hidden layer's bias as c1 * b1, which k_fold_bias leaves alone -- for the centred first-layer activations
+    // (r - 1/2) of k_mfma's flow nets (wf_mfma_impl.h: hidden_layers<..., CENTER>)
+    for (int ob = 0; ob < 2; ++ob)
+        for (int h = 0; h < 2; ++h)
+            for (int r = 0; r < 16; ++r) w.f32(q.b1 + 32 * ob + acc_row(r, h), c1);
 }
 
 // Decides whether the MFMA kernel covers this model and builds its parameter-independent parts.
@@ -1033,6 +1046,15 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
         m->d_comp = comp;
         md.comp = reinterpret_cast<const float4_t*>(comp);
         md.comp2 = reinterpret_cast<const float4_t*>(comp + comp_floats + ((coef_floats + 3) & ~(size_t)3));
+    }
+    {   // fp16-range flags of the operand images (one per net), their pinned host copy and the event that says it has arrived
+        rc = dev_alloc(m, &m->d_f16_ovf, (size_t)kMaxNets);
+        if (rc) return rc;
+        WF_HIP(hipMemset(m->d_f16_ovf, 0, kMaxNets * sizeof(int)));
+        WF_HIP(hipHostMalloc(reinterpret_cast<void**>(&m->h_f16_ovf), kMaxNets * sizeof(int), hipHostMallocDefault));
+        memset(m->h_f16_ovf, 0, kMaxNets * sizeof(int));
+        WF_HIP(hipEventCreateWithFlags(&m->ovf_event, hipEventDisableTiming));
+        md.f16_ovf = m->d_f16_ovf;
     }
     m->mfma_floats = total;
     m->mfma_ok = true;
@@ -1270,6 +1292,8 @@ void wf_model_destroy(wf_model* m) {
     if (!m) return;
     DeviceGuard g(m->device);
     for (void* p : m->allocs) (void)hipFree(p);
+    if (m->ovf_event) (void)hipEventDestroy(m->ovf_event);
+    if (m->h_f16_ovf) (void)hipHostFree(m->h_f16_ovf);
     delete m;
 }
 
@@ -1302,8 +1326,16 @@ static int apply_params(wf_model* m, const float* flat_dev, void* stream, bool e
     }
     if (m->mfma_ok && eval_tables) {
         // biases of the layers behind a tanh: + column sums of their weights (the kernel's activations are r, tanh = 1 - 2r)
-        int rc0 = launch_fold_bias(m->d_mfma, (int)m->nets.size(), m->mdev.net_floats, m->desc.n_dim, m->mdev.nbk, stream);
+        int rc0 = launch_fold_bias(m->d_mfma, (int)m->nets.size(), m->mdev.net_floats, m->desc.n_dim, m->mdev.nbk, m->d_f16_ovf, stream);
         if (rc0) return rc0;
+        // the flags follow the images to the host (not while the stream is being captured: a replayed step keeps the answer of its capture
+        // and the kernels' own NaN poisoning is what shows)
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) {
+            WF_HIP(hipMemcpyAsync(m->h_f16_ovf, m->d_f16_ovf, m->nets.size() * sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+            WF_HIP(hipEventRecord(m->ovf_event, (hipStream_t)stream));
+            m->ovf_pending = true;
+        }
         // composite tables of output dimension 0 (reads the plain image filled above)
         int rc = launch_prepare_dim0(m->d_dev, (int)m->nets.size(), m->desc.n_mesh, m->d_fk_nat, m->mdev.F_I, m->mdev.F_P, m->d_tabI4, m->d_tabP3, m->d_comp, stream);
         if (rc) return rc;
@@ -1339,6 +1371,23 @@ int wf_adam_step(float* params_dev, const float* grad_dev, float* m_dev, float* 
     return launch_adam(params_dev, grad_dev, m_dev, v_dev, n, step, step_size, b1, b2, eps, nullptr, stream);
 }
 
+// Is a packed weight of the current parameters outside the fp16 range?  Then every path that feeds fp16 operand images to the matrix cores
+// (k_mfma, the tile kernels of wf_kernels_etile.hip) is off: `auto` takes the fp32 scalar / wave kernels, an explicit request for the MFMA
+// kernel returns WF_ERR_UNSUPPORTED.  Waits for the upload's flag copy if it is still in flight (a host wait of the pack kernels, ~50 us,
+// only in the call that follows an asynchronous upload).
+static bool f16_overflow(const wf_model* cm) {
+    wf_model* m = const_cast<wf_model*>(cm);
+    if (!m->mfma_ok) return false;
+    if (m->ovf_pending) {
+        if (hipEventSynchronize(m->ovf_event) != hipSuccess) return true;
+        m->ovf_pending = false;
+        bool any = false;
+        for (size_t n = 0; n < m->nets.size(); ++n) any |= m->h_f16_ovf[n] != 0;
+        m->f16_overflow = any;
+    }
+    return m->f16_overflow;
+}
+
 static int check_fwd(const wf_model* m, const void* x, int64_t B, const void* out) {
     if (!m || B < 0) return WF_ERR_INVALID;
     if (B > 0 && (!x || !out)) return WF_ERR_INVALID;
@@ -1347,13 +1396,26 @@ static int check_fwd(const wf_model* m, const void* x, int64_t B, const void* ou
 }
 
 
-static int dispatch(const wf_model* m, int mode, const float* x, int64_t B, float* out, float* u, int32_t* idx, void* stream) {
+// presort: the rows of x arrive in any order -- evaluate on the ascending sort of each row, psi (mode 1) times (-1)^inversions (helpers.py:55-58).
+// The MFMA kernel sorts in registers; the wave and the scalar kernel read sorted rows from the model's scratch (one small launch in front,
+// the sign behind).
+static int dispatch(const wf_model* m, int mode, const float* x, int64_t B, float* out, float* u, int32_t* idx, void* stream, bool presort = false) {
     DeviceGuard g(m->device);
     if (B == 0) return WF_OK;
     if (m->is_nsc) {
-        if (mode == 1 || idx) return WF_ERR_UNSUPPORTED;
+        if (mode == 1 || idx || presort) return WF_ERR_UNSUPPORTED;
         return launch_nsc_model(m->nsc, mode, x, B, out, u, stream);
     }
+    const int Dm = m->desc.n_dim;
+    // sorted rows + inversion counts for the kernels that do not sort themselves: behind the first `front` floats of the scratch
+    auto presorted = [&](int64_t front, const float** xs, int32_t** inv) -> int {
+        int rc = ensure_scratch(m, front + B * (Dm + 1));
+        if (rc) return rc;
+        float* s = m->d_scratch + front;
+        *inv = reinterpret_cast<int32_t*>(s + B * Dm);
+        *xs = s;
+        return launch_sort_rows(x, B, Dm, s, *inv, stream);
+    };
     // Small batches: one wave per walker (wf_kernels_wave.hip) takes 14 us for up to ~1000 walkers where the MFMA kernel,
     // which first stages its weight images into LDS, takes 38-42 us whatever the batch; from ~7000 walkers on the MFMA
     // kernel's throughput wins (4096: 30 vs 42 us, 8192: 46 vs 42 us).  The wave kernel does
@@ -1364,22 +1426,39 @@ static int dispatch(const wf_model* m, int mode, const float* x, int64_t B, floa
     if (use_wave) {
         const int D = m->desc.n_dim;
         const int64_t chunk = std::min<int64_t>(B, (int64_t)1 << 20);
-        int rc = ensure_scratch(m, chunk * wave_tail_floats(D, 0));
+        int rc = ensure_scratch(m, chunk * wave_tail_floats(D, 0) + (presort ? B * (D + 1) : 0));
         if (rc) return rc;
+        int32_t* inv = nullptr;
+        if (presort) {
+            rc = presorted(chunk * wave_tail_floats(D, 0), &x, &inv);
+            if (rc) return rc;
+        }
         for (int64_t c0 = 0; c0 < B; c0 += chunk) {
             const int64_t bc = std::min(chunk, B - c0);
             rc = launch_wave_eval(m->dev, m->d_dev, m->d_tabI4, m->d_tabP3, m->d_grad_fk, mode, x + c0 * D, bc, out + c0, u ? u + c0 * D : nullptr,
                                   m->d_scratch, stream);
             if (rc) return rc;
         }
-        return WF_OK;
+        return (presort && mode == 1) ? launch_apply_sign(out, inv, B, stream) : WF_OK;
     }
-    const bool use_mfma = m->mfma_ok && m->kernel_kind != WF_KERNEL_SCALAR;
+    bool use_mfma = m->mfma_ok && m->kernel_kind != WF_KERNEL_SCALAR;
+    if (use_mfma && f16_overflow(m)) {   // a weight outside the fp16 range: the fp32 kernels only
+        if (m->kernel_kind == WF_KERNEL_MFMA) return WF_ERR_UNSUPPORTED;
+        use_mfma = false;
+    }
 #if defined(WF_DEBUG) || defined(WF_STAMP)
     if (use_mfma && getenv("WF_DBG_PTR")) const_cast<wf_model*>(m)->mdev.dbg = (float*)strtoull(getenv("WF_DBG_PTR"), nullptr, 0);
 #endif
-    if (use_mfma) return launch_mfma(m->dev.D, m->mdev.nbk, &m->mdev, (int)(m->mfma_lds_floats * sizeof(float)), mode, x, B, out, u, idx, stream);
-    return launch_scalar(m->dev, m->d_dev, mode, x, B, out, u, idx, stream);
+    if (use_mfma)
+        return launch_mfma(m->dev.D, m->mdev.nbk, &m->mdev, (int)(m->mfma_lds_floats * sizeof(float)), mode | (presort ? kModePresort : 0), x, B, out, u, idx, stream);
+    int32_t* inv = nullptr;
+    if (presort) {
+        int rc = presorted(0, &x, &inv);
+        if (rc) return rc;
+    }
+    int rc = launch_scalar(m->dev, m->d_dev, mode, x, B, out, u, idx, stream);
+    if (rc || !(presort && mode == 1)) return rc;
+    return launch_apply_sign(out, inv, B, stream);
 }
 
 int wf_logpdf_fwd(const wf_model* m, const float* x_dev, int64_t B, float* logp_dev, float* u_dev, int32_t* bin_idx_dev,
@@ -1395,6 +1474,28 @@ int wf_psi_fwd(const wf_model* m, const float* x_dev, int64_t B, float* psi_dev,
     if (rc) return rc;
     if (m->desc.prior_kind != WF_PRIOR_WAVEFLOW) return WF_ERR_INVALID;
     return dispatch(m, 1, x_dev, B, psi_dev, u_dev, bin_idx_dev, stream);
+}
+
+int wf_psi_antisym_fwd(const wf_model* m, const float* x_dev, int64_t B, float* psi_dev, int32_t* inversions_dev, void* stream) {
+    int rc = check_fwd(m, x_dev, B, psi_dev);
+    if (rc) return rc;
+    if (m->desc.prior_kind != WF_PRIOR_WAVEFLOW) return WF_ERR_INVALID;
+    rc = dispatch(m, 1, x_dev, B, psi_dev, nullptr, nullptr, stream, true);
+    if (rc || !inversions_dev || B == 0) return rc;
+    DeviceGuard g(m->device);
+    return launch_sort_rows(x_dev, B, m->desc.n_dim, nullptr, inversions_dev, stream);
+}
+
+int wf_logpdf_unsorted_fwd(const wf_model* m, const float* x_dev, int64_t B, float* logp_dev, void* stream) {
+    int rc = check_fwd(m, x_dev, B, logp_dev);
+    if (rc) return rc;
+    return dispatch(m, 0, x_dev, B, logp_dev, nullptr, nullptr, stream, true);
+}
+
+int wf_inversion_count(const float* x_dev, int64_t B, int32_t n_dim, int32_t* count_dev, void* stream) {
+    if (B < 0 || n_dim < 1 || n_dim > WF_MAX_DIM || (B > 0 && (!x_dev || !count_dev))) return WF_ERR_INVALID;
+    if (wf_device_count() <= 0) return WF_ERR_NO_DEVICE;
+    return launch_sort_rows(x_dev, B, n_dim, nullptr, count_dev, stream);
 }
 
 int wf_flow_fwd(const wf_model* m, const float* x_dev, int64_t B, float* u_dev, float* logdet_dev, void* stream) {
@@ -1430,13 +1531,19 @@ static int64_t wave_sample_max() {   // tuning knob (read at every call): WF_WAV
 // point; 0 disables the path.  It reads the MFMA image and the composite dimension-0 tables: not while they are stale (deferred training steps).
 static constexpr int64_t kTileSampleMin = 16384;
 static constexpr int64_t kTileSampleChunk = 1 << 18;   // walkers per pass of a call without a caller's workspace (the model's scratch: 111 MB)
-static bool tile_sample_ok(const wf_model* m, int64_t B) {
+// capability at this batch size (the model, the knob): what workspace queries and the training steps' refresh decisions go by -- independent of
+// transient state
+static bool tile_sample_capable_at(const wf_model* m, int64_t B) {
     const char* e = getenv("WF_SAMPLE_TILE_MIN");
     const int64_t mn = e ? atoll(e) : kTileSampleMin;
     const wf_model_desc& d = m->desc;
+    // (the piecewise-constant envelope of k_tsample's second prior column takes the maximum over at most 9 coefficients per knot interval:
+    // prior degrees above 8 keep the wave / one-lane samplers, whose bound is the global one)
     return mn > 0 && B >= mn && d.n_dim == 2 && m->nbp == 32 * m->mdev.nbk && m->mfma_ok && d.box_kind == WF_BOX_MEAN && d.layer_kind == WF_LAYER_IMADE && d.n_flow_layers > 0 &&
-           d.prior_kind == WF_PRIOR_WAVEFLOW && !m->eval_tables_stale && m->d_tabI4 && m->d_tabP3 && m->dev.b_to_ob && m->d_grad_fk && tile_sample_capable(&m->mdev);
+           d.prior_kind == WF_PRIOR_WAVEFLOW && d.p_degree <= 8 && m->d_tabI4 && m->d_tabP3 && m->dev.b_to_ob && m->d_grad_fk && tile_sample_capable(&m->mdev);
 }
+// ... and right now: the MFMA image and the composite tables are fresh, every packed weight inside the fp16 range
+static bool tile_sample_ok(const wf_model* m, int64_t B) { return tile_sample_capable_at(m, B) && !m->eval_tables_stale && !f16_overflow(m); }
 // in passes of what the workspace holds; a walker's stream is keyed by its index in the batch, whatever the passes
 static int run_tile_sample(const wf_model* m, int draw, uint64_t seed, const float* u_dev, int64_t B, float* x_dev, float* latent_dev, int exact,
                            const unsigned long long* counter_dev, float* ws, int64_t ws_floats, void* stream) {
@@ -1539,7 +1646,7 @@ int wf_hamiltonian_fwd(const wf_model* m, const float* x_dev, int64_t B, const f
         // (<= 32 bases: the one-kernel form or, if the nets do not fit LDS together, the launch-per-net form; 33 .. 64 bases: the one-kernel form only)
         const bool family = D == 2 && (m->nbp == 32 || (m->nbp == 64 && m->mfma_ok && energy_tile_fused(&m->mdev))) && m->mfma_ok && d.box_kind == WF_BOX_MEAN && d.layer_kind == WF_LAYER_IMADE &&
                             d.n_flow_layers > 0 && !m->dev.i_gate && !m->dev.p_gate && m->d_tabI4c && m->d_tabP4c && (!m->mdev.p_bias || energy_tile_fused(&m->mdev)) && !getenv("WF_ENERGY_R3");   // (a constant term of the prior's boundary map: the one-kernel form only)
-        if (family && tile_min > 0 && B >= tile_min && !m->eval_tables_stale) {
+        if (family && tile_min > 0 && B >= tile_min && !m->eval_tables_stale && !f16_overflow(m)) {
             // the conditioner and the head kernels exchange 384 B per walker and net through the scratch buffer: chunks that keep it
             // (and its re-use by the next net and the next chunk) inside the 256 MB memory-side cache instead of HBM
             if (energy_tile_fused(&m->mdev))   // every net resident in LDS: one launch for the whole batch, no exchange buffer (k_efused)
@@ -1577,12 +1684,23 @@ static int64_t vjp_bytes_per_walker(const wf_model* m, bool second_order) {
     return (samples * ((int64_t)m->nets.size() * grad_ws_rows(D, m->nbp) * nc + zrows) + wave_tail_floats(D, kind) + 4) * (int64_t)sizeof(float);
 }
 
+// the matrix-core gradient path (wf_kernels_etile.hip) applies to this model at this batch size: capability + the knob WF_GRAD_TILE_MIN (read per call),
+// independent of transient state (stale evaluation tables, fp16 range of the current parameters)
+static bool grad_tile_capable_at(const wf_model* m, int64_t B) {
+    if (!m->d_egacc) return false;
+    const char* e = getenv("WF_GRAD_TILE_MIN");
+    const int64_t tile_min = e ? atoll(e) : kGradTileMin;
+    const wf_model_desc& d = m->desc;
+    return tile_min > 0 && B >= tile_min && d.n_dim == 2 && m->nbp == 32 && m->mfma_ok && d.box_kind == WF_BOX_MEAN && d.layer_kind == WF_LAYER_IMADE && d.n_flow_layers > 0 &&
+           d.prior_kind == WF_PRIOR_WAVEFLOW && m->d_tabI4c && m->d_tabP4c && energy_vjp_capable(&m->mdev);
+}
+
 static int64_t vjp_ws_bytes(const wf_model* m, int64_t B, bool second_order) {
     if (!m || B < 0) return WF_ERR_INVALID;
     if (!m->d_grad_map || (second_order && !m->grad_psi_ok)) return WF_ERR_UNSUPPORTED;
     const int64_t chunk = std::min<int64_t>(std::max<int64_t>(B, 1), 32768);
     int64_t bytes = chunk * vjp_bytes_per_walker(m, second_order);
-    if (second_order && m->d_egacc) {   // the matrix-core gradient path has a fixed part (the partial gradient blocks of every net): room for it at any batch size
+    if (second_order && grad_tile_capable_at(m, B)) {   // the matrix-core gradient path has a fixed part (the partial gradient blocks of every net): only where the path applies (a smaller WF_GRAD_TILE_MIN at query time moves it)
         const int n_nets = (int)m->nets.size();
         bytes = std::max<int64_t>(bytes, (energy_vjp_fixed_floats(n_nets) + ((chunk + 31) / 32 * 32) * energy_vjp_floats_per_walker(n_nets)) * (int64_t)sizeof(float));
     }
@@ -1617,11 +1735,8 @@ static int run_vjp_chunks(const wf_model* m, int mode, bool second_order, const 
     // matrix cores (wf_kernels_etile.hip: k_efused with the per-net input jets, k_ebwd per net, k_ewgrad).  WF_GRAD_TILE_MIN (read per call) moves the
     // switch point; 0 disables the path.
     if ((mode == 1 || mode == 2) && second_order && m->d_egacc) {
-        const char* e = getenv("WF_GRAD_TILE_MIN");
-        const int64_t tile_min = e ? atoll(e) : kGradTileMin;
-        const wf_model_desc& d = m->desc;
-        const bool family = D == 2 && m->nbp == 32 && m->mfma_ok && d.box_kind == WF_BOX_MEAN && d.layer_kind == WF_LAYER_IMADE && d.n_flow_layers > 0 &&
-                            d.prior_kind == WF_PRIOR_WAVEFLOW && m->d_tabI4c && m->d_tabP4c && !m->eval_tables_stale && energy_vjp_capable(&m->mdev);
+        const int64_t tile_min = 1;
+        const bool family = grad_tile_capable_at(m, B) && !m->eval_tables_stale && !f16_overflow(m);
         const int64_t per = energy_vjp_floats_per_walker(n_nets) * (int64_t)sizeof(float), fixed = energy_vjp_fixed_floats(n_nets) * (int64_t)sizeof(float);
         const int64_t tchunk = workspace_bytes > fixed ? ((workspace_bytes - fixed) / per) / 32 * 32 : 0;
         if (family && tile_min > 0 && B >= tile_min && tchunk >= 32) {
@@ -1754,10 +1869,11 @@ static int adam_from_sweep(wf_model* m, const wf_train_state* st, const float* g
 
 int64_t wf_vqmc_train_step_workspace_bytes(const wf_model* m, int64_t batch) {
     if (!m || batch < 1) return WF_ERR_INVALID;
-    if (!m->d_grad_map || !m->grad_psi_ok || !m->wave_ok || (batch > kWaveSampleMax && !tile_sample_ok(m, batch))) return WF_ERR_UNSUPPORTED;
+    // (capability, not the current state: a size queried while the evaluation tables are stale holds after the next full refresh as well)
+    if (!m->d_grad_map || !m->grad_psi_ok || !m->wave_ok || (batch > kWaveSampleMax && !tile_sample_capable_at(m, batch))) return WF_ERR_UNSUPPORTED;
     // (the staged sampler of large batches works in the gradient's workspace before the gradient needs it)
     return align256(batch * m->desc.n_dim * 4) + align256(batch * 4) + align256(m->n_params * 4) + 256 + align256(block_sums_ws_bytes(batch)) +
-           std::max<int64_t>(vjp_ws_bytes(m, batch, true), tile_sample_ok(m, batch) ? align256(tile_sample_floats(std::min(batch, kTileSampleChunk), m->mdev.nbk) * 4) : 0);
+           std::max<int64_t>(vjp_ws_bytes(m, batch, true), tile_sample_capable_at(m, batch) ? align256(tile_sample_floats(std::min(batch, kTileSampleChunk), m->mdev.nbk) * 4) : 0);
 }
 
 int wf_vqmc_train_step(wf_model* m, const wf_train_state* st, uint64_t seed, int64_t batch, const float* protons_host, int32_t n_protons,
@@ -1794,7 +1910,11 @@ int wf_vqmc_train_step(wf_model* m, const wf_train_state* st, uint64_t seed, int
     if (rc) return rc;
     rc = adam_from_sweep(m, st, grad, split, step_size, b1, b2, eps, stream);
     if (rc) return rc;
-    rc = apply_params(m, st->params_dev, stream, !st->defer_eval_tables);
+    // A step whose batch size puts it on the matrix-core sampler / gradient reads the MFMA image and the composite tables: it refreshes them
+    // whatever defer_eval_tables says -- a hipGraph of this step replays the kernels chosen at capture, and a deferred refresh would leave
+    // them on stale tables from the second replay on (the selection above does not depend on the deferral either: with stale tables at
+    // call time the step takes the wave sweeps, which are valid in every replay).
+    rc = apply_params(m, st->params_dev, stream, !st->defer_eval_tables || tile_sample_capable_at(m, batch) || grad_tile_capable_at(m, batch));
     if (rc) return rc;
     // batch sums of the local energies -> loss ring, step counter + 1 (after Adam, which reads the counter as its step index)
     return launch_block_sums(e_loc, batch, sums, sums_ws, block_sums_ws_bytes(batch), stream, st->loss_ring_dev, st->ring_len,
@@ -1833,6 +1953,7 @@ int wf_vqmc_train_step_local(wf_model* m, const wf_train_state* st, uint64_t see
     const int64_t n_img = plain_fwd_floats(D, m->nbp) * (int64_t)m->nets.size();
     rc = launch_pack_reduce_buffer(m->d_grad_partial, split, n_img, m->d_grad_map, grad, m->n_params, reduce_dev, stream);
     if (rc) return rc;
+    m->local_step_tile = tile_sample_capable_at(m, batch_local) || grad_tile_capable_at(m, batch_local);   // -> wf_vqmc_train_step_apply refreshes everything
     return launch_block_sums(e_loc, batch_local, reduce_dev + m->n_params, sums_ws, block_sums_ws_bytes(batch_local), stream);
 }
 
@@ -1845,7 +1966,7 @@ int wf_vqmc_train_step_apply(wf_model* m, const wf_train_state* st, const double
     int rc = launch_adam_reduced(st->params_dev, reduce_dev, st->m_dev, st->v_dev, m->n_params, step_size, b1, b2, eps,
                                  (const unsigned long long*)st->counter_dev, stream);
     if (rc) return rc;
-    rc = apply_params(m, st->params_dev, stream, !st->defer_eval_tables);
+    rc = apply_params(m, st->params_dev, stream, !st->defer_eval_tables || m->local_step_tile);   // (see wf_vqmc_train_step)
     if (rc) return rc;
     return launch_ring_push(reduce_dev + m->n_params, st->loss_ring_dev, st->ring_len, (unsigned long long*)st->counter_dev, stream);
 }

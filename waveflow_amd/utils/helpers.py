@@ -38,8 +38,13 @@ def _to_numpy_tree(t):
 
 
 def _signed_psi(psi, params, coordinates):
-    """psi(sorted coordinates) * (-1)^inversions (helpers.py:55-58)"""
+    """psi(sorted coordinates) * (-1)^inversions (helpers.py:55-58).  A closure of this package sorts and signs on the device
+    (wf_psi_antisym_fwd); any other psi gets the reference's host sequence."""
     coordinates = np.asarray(coordinates, dtype=np.float32)
+    model = getattr(psi, "model", None)
+    if model is not None and hasattr(model, "psi_antisym"):
+        model.ensure_params(params)
+        return np.asarray(_np(model.psi_antisym(coordinates)), dtype=np.float32)
     inv = get_num_inversion_count(coordinates)
     z = _np(psi(params, np.sort(coordinates, axis=-1)))
     return (z * ((-1.0) ** inv)).astype(np.float32)
