@@ -825,24 +825,90 @@ __global__ __launch_bounds__(kFusedWaves * 64) void k_efused(const MfmaDev mm, c
 //   k_ebwd<PRIOR>       one launch per net, last net first: recomputes the net's forward from its input jets, pulls the adjoint of its output
 //                       jets back through the head algebra (wf_etile_adjoint.h) to adjoint head triples, through the conditioner with TRANSPOSED
 //                       operand images on the matrix cores (three channels, like the forward), writes the adjoint of the net's input jets for the
-//                       next launch and DUMPS, per 32-walker tile, the operands of the weight-gradient products that cannot be had cheaper: the second
-//                       hidden layer's activations X2 and the adjoints Y2, Y3 as [channel][unit][32 walkers] blocks (coalesced: a register of the
-//                       accumulator layout is two 128-byte rows), s, and the input layer's sums over the tile's walkers.
-//                       One wave per SIMD (512 registers): at two, 213 spilled registers kept 68 % of the wave cycles waiting on memory counters
-//   k_ewgrad            dW[k][u] = sum_walkers sum_channels X_c[k][w] Y_c[u][w]: the walker axis is the K of this product and the dumps hold it
-//                       contiguous; a workgroup's four waves share a tile (blocks streamed a tile ahead into LDS), each owns one block of the
-//                       product; the first hidden layer's activations X1 are recomputed from s; split-fp16 products, per-split partial sums (fixed order)
-//   k_egrad_reduce, k_egrad_scatter   reduction over the splits; scales and folds back to the flat leaf order
+//                       next launch -- and, since round 4, forms the weight-gradient products dW[k][u] = sum_walkers sum_channels X_c[k][w] Y_c[u][w]
+//                       itself.  The walker axis is the K of that product, while every tensor of the sweep has the walker on the LANE (accumulator
+//                       layout): the operands are transposed ON THE MATRIX CORES -- an fp16 fragment times a 0/1 permutation operand is an exact
+//                       transposition, one v_mfma per K step (tr_frag) -- and the six 32 x 32 blocks of (dW1, dW2) accumulate in LDS, one private set
+//                       per wave (24 KB; the four sets + the operand images fill the 160 KB), summed over the workgroup's waves in wave order at the
+//                       end: one 25.6 KB block of partial sums per workgroup.  Tiles are dealt to the waves statically, so the sums -- and whole
+//                       training runs -- stay bitwise reproducible.  Rounds 2 - 3 dumped the operands per tile (66 KB: 270 MB per net and 2^17
+//                       walkers) for a second kernel (k_ewgrad) that read them back: ~2 GB of HBM traffic per call against ~27 MB algorithmic.
+//                       One wave per SIMD (512 registers).
+//   k_egrad_reduce, k_egrad_scatter   reduction over the workgroups' blocks (fixed order); scales and folds back to the flat leaf order
+__device__ __forceinline__ float wave_max(float v) {   // v >= 0
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true)));
+    const unsigned u = __float_as_uint(v);
+    const auto sw = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return xhalf_max(fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])));
+}
+__device__ __forceinline__ int exponent_of(float amax) { return amax > 0.0f ? __builtin_amdgcn_frexp_expf(amax) : 0; }
 using JA = adj::Jt<float>;
 using TA = adj::T2t<float>;
 #ifndef WF_BWD_WAVES
 #define WF_BWD_WAVES 4
 #endif
 constexpr int kBwdWaves = WF_BWD_WAVES;
-// dump block of one tile (floats): X2 [3][64][32], Y2 [3][64][32], Y3 [3][32][32], Y30 [32][32], S [32], G [2][64] (the tile's sums for the input
-// layer: Gb0, GW0).  The first hidden layer's activations X1 are a function of S alone and are recomputed by k_ewgrad; the adjoints Y1 of the first
-// layer's pre-activations only enter through G.
-constexpr int kDX2 = 0, kDY2 = 6144, kDY3 = 12288, kDY30 = 15360, kDS = 16384, kDG = 16416, kDumpFloats = 16544;
+// Gradient block of a net (floats, in the units of the MFMA image):
+//   GW0 [64] (d / d W0'[0][u]), Gb0 [64], GW1 [64][64] (k, u), Gb1 [64], GW2 [64][32] (k, row), Gb2 of dimension 1 [32], of dimension 0 [32]
+constexpr int kGW0 = 0, kGb0 = 64, kGW1 = 128, kGb1 = 4224, kGW2 = 4288, kGb21 = 6336, kGb20 = 6368, kGFloats = 6400;
+constexpr int kESplit = 256;        // partial blocks per net: one per workgroup of k_ebwd (grid <= 256), summed in block order by k_egrad_reduce
+// LDS accumulators of one wave: blocks 0..3 = dW1 (k block mb = b >> 1, u block nb = b & 1), 4..5 = dW2 (k block b - 4), each [4 q][64 lanes][4]
+// (register 4 q + e of the lane: one conflict-free ds_read_b128 per q)
+constexpr int kAccBlocks = 6, kAccFloats = kAccBlocks * 1024;
+__device__ __forceinline__ int acc_rho(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }   // row of register r in lane half h (accumulator layout)
+__device__ __forceinline__ f32x16 acc_load(const float* aw, int b, int lane) {
+    f32x16 a;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(aw + ((b * 4 + q) * 64 + lane) * 4);
+        a[4 * q] = v[0]; a[4 * q + 1] = v[1]; a[4 * q + 2] = v[2]; a[4 * q + 3] = v[3];
+    }
+    return a;
+}
+__device__ __forceinline__ void acc_store(float* aw, int b, int lane, const f32x16& a) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(aw + ((b * 4 + q) * 64 + lane) * 4) = f32x4{a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
+}
+// B operand of the transposition product: P[K = (s, khalf, i)][n] = 1 where the K slot holds row n (K slot (s, h, i) of a fragment = register 8 s + i of half h)
+__device__ __forceinline__ void make_perm(int lane, f16x8 (&pm)[2]) {
+    const int n = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pm[s][i] = acc_rho(8 * s + i, h) == n ? (_Float16)1.0f : (_Float16)0.0f;
+}
+__device__ __forceinline__ f16x8 cvt8(const f32x16& d, int s) {
+    using f32x2 = __attribute__((ext_vector_type(2))) float;
+    f16x8 o;
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+        const f16x2 pr = __builtin_convertvector((f32x2){d[8 * s + i], d[8 * s + i + 1]}, f16x2);
+        o[i] = pr[0]; o[i + 1] = pr[1];
+    }
+    return o;
+}
+// One 32-row block X (accumulator layout: lane = walker, registers = rows) given as fp16 fragments (hi, lo) -> X^T as fp16 fragments with the ROW on the
+// lane and the walkers in the registers (walker acc_rho(r, half) in register r): D[walker][row] = sum_K frag[walker][K] P[K][row] has one non-zero term
+// per entry, so hi and lo come through exactly.  rowsum (may be null): += the sum over the lane's 16 walkers of hi + lo (both halves: xhalf at the end).
+__device__ __forceinline__ void tr_frag(const Frag& f, const f16x8 (&pm)[2], Frag& t, float* rowsum = nullptr) {
+    f32x16 dh = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, dl = dh;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        dh = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.hi[s], pm[s], dh, 0, 0, 0);
+        dl = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.lo[s], pm[s], dl, 0, 0, 0);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) { t.hi[s] = cvt8(dh, s); t.lo[s] = cvt8(dl, s); }
+    if (rowsum) {
+        float a = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a += dh[r] + dl[r];
+        *rowsum += a;
+    }
+}
 __device__ __forceinline__ float half32_sum(float v) {   // sum over the 32 lanes of this lane's half, in every lane of it
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
@@ -861,19 +927,18 @@ __device__ __forceinline__ void ja_store(float* __restrict__ st, int slot, int64
     p[0] = x.v; p[B] = x.a; p[2 * B] = x.b; p[3 * B] = x.h;
 }
 __device__ __forceinline__ float r_of(float x) { return __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x) + 1.0f); }
-// register r of lane (walker j, half h) of a 32-unit block -> dump[(unit0 + row) * 32 + j]
-__device__ __forceinline__ void dump_block(float* __restrict__ d, int unit0, const f32x16& v, int j, int h) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) d[(unit0 + (r & 3) + 8 * (r >> 2) + 4 * h) * 32 + j] = v[r];
-}
-// one 32-row block of triples -> fragments of K = 32 (two K steps), derivative channels scaled (as to_frags, one block)
+// one 32-row block of triples -> fragments of K = 32 (two K steps), every channel scaled (as to_frags, one block).  UNI: one power of two per
+// (TILE, channel) instead of per (walker, channel) -- the wave's largest.  The adjoint tensors of the reverse kernel take it: what they feed are sums
+// over walkers (the weight gradients; the input adjoints, which the next net's reverse again only sums), so a walker far below the tile's largest
+// loses bits that do not show in any sum, and the same fragments serve as operands of the products over the walker axis, which need one scale per tile.
+template <bool UNI = false>
 __device__ __forceinline__ void to_frags1(const f32x16 (&blk)[NCH], Frag (&f)[NCH][2], int (&e)[NCH]) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         float amax = 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) amax = fmaxf(amax, fabsf(blk[c][r]));
-        e[c] = col_exponent(amax);
+        e[c] = UNI ? exponent_of(wave_max(amax)) : col_exponent(amax);
         const float sc = __builtin_amdgcn_ldexpf(1.0f, -e[c]);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -884,14 +949,15 @@ __device__ __forceinline__ void to_frags1(const f32x16 (&blk)[NCH], Frag (&f)[NC
         }
     }
 }
-// two blocks, every channel scaled (adjoints are unbounded in every channel)
+// two blocks, every channel scaled (adjoints are unbounded in every channel); UNI as above
+template <bool UNI = false>
 __device__ __forceinline__ void to_frags_all(const f32x16 (&blk0)[NCH], const f32x16 (&blk1)[NCH], Frag (&f)[NCH][2], int (&e)[NCH]) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         float amax = 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) amax = fmaxf(amax, fmaxf(fabsf(blk0[c][r]), fabsf(blk1[c][r])));
-        e[c] = col_exponent(amax);
+        e[c] = UNI ? exponent_of(wave_max(amax)) : col_exponent(amax);
         const float sc = __builtin_amdgcn_ldexpf(1.0f, -e[c]);
 #pragma unroll
         for (int ob = 0; ob < 2; ++ob)
@@ -1079,12 +1145,14 @@ __device__ __forceinline__ void ob_product(const _Float16* obh, f32x16 (&w)[NCH]
     }
 }
 
-// forward of one conditioner from its input (u0, u1) to the second hidden layer's pre-activation triples z2 (two 32-unit blocks); HEAD: on to the head
-// triples o, with the second hidden layer's activations X2 written to the tile's dump
+// forward of one conditioner from its input (u0, u1) to the second hidden layer's pre-activation triples z2 (two 32-unit blocks).  HEAD: on to the head
+// triples o.
 template <bool HEAD>
-__device__ __forceinline__ void cond_fwd(const float* net, float u0v, float u1v, int lane, f32x16 (&z2a)[NCH], f32x16 (&z2b)[NCH], f32x16 (&o)[NCH], float* __restrict__ dmp) {
+__device__ __forceinline__ void cond_fwd(const float* net, float u0v, float u1v, int lane, f32x16 (&z2a)[NCH], f32x16 (&z2b)[NCH], f32x16 (&o)[NCH]) {
+    Frag f2[NCH][2];
+    int e2[NCH];
     using O = NetOff<2, 1>;
-    const int j = lane & 31, h = lane >> 5;
+    const int h = lane >> 5;
     const float in0[2] = {u0v, 1.0f}, in1[2] = {u1v, 0.0f};
     f32x16 a0[NCH], a1[NCH];
     init_acc(a0, net + O::b0 + (0 * 2 + h) * 16);
@@ -1097,38 +1165,75 @@ __device__ __forceinline__ void cond_fwd(const float* net, float u0v, float u1v,
     }
     act_block(a0);
     act_block(a1);
-    Frag f[NCH][2];
-    int e[NCH];
-    to_frags(a0, a1, f, e);
+    to_frags(a0, a1, f2, e2);
     const _Float16* W1h = reinterpret_cast<const _Float16*>(net + O::W1h);
     const _Float16* W1l = reinterpret_cast<const _Float16*>(net + O::W1l);
     init_acc(z2a, net + O::b1 + (0 + h) * 16);
     init_acc(z2b, net + O::b1 + (2 + h) * 16);
-    dense64_block<NCH>(W1h, W1l, f, z2a, lane);
-    dense64_block<NCH>(W1h + 2048, W1l + 2048, f, z2b, lane);
-    unscale(z2a, e);
-    unscale(z2b, e);
+    dense64_block<NCH>(W1h, W1l, f2, z2a, lane);
+    dense64_block<NCH>(W1h + 2048, W1l + 2048, f2, z2b, lane);
+    unscale(z2a, e2);
+    unscale(z2b, e2);
     if (HEAD) {
 #pragma unroll
         for (int c = 0; c < NCH; ++c) { a0[c] = z2a[c]; a1[c] = z2b[c]; }
         act_block(a0);
         act_block(a1);
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) { dump_block(dmp + kDX2 + c * 2048, 0, a0[c], j, h); dump_block(dmp + kDX2 + c * 2048, 32, a1[c], j, h); }
-        to_frags(a0, a1, f, e);
-        cond_out<1>(net, f, e, 0, lane, o);
+        to_frags(a0, a1, f2, e2);
+        cond_out<1>(net, f2, e2, 0, lane, o);
     }
+}
+// X operand of a product over the walker axis: one 32-unit block of ACTIVATION jets (channel 0 = r in (0, 1)) -> fragments scaled by 2^-ex[c], one power
+// of two per (tile, channel).  ey[c]: the exponents of the other operand's channels.  All three channels' products are to land in ONE accumulator
+// chain, so the channels share the product's exponent E = max_c (natural exponent of X_c + ey[c]) and X_c is scaled by 2^-(E - ey[c]) -- at most its
+// natural scale; a channel whose product lies below the largest one's loses bits that the sum does not see.  Returns E.
+__device__ __forceinline__ int block_frags_x(const f32x16 (&blk)[NCH], const int (&ey)[NCH], Frag (&f)[NCH]) {
+    int en[NCH];
+    en[0] = 0;
+#pragma unroll
+    for (int c = 1; c < NCH; ++c) {
+        float amax = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) amax = fmaxf(amax, fabsf(blk[c][r]));
+        en[c] = exponent_of(wave_max(amax));
+    }
+    const int E = max(en[0] + ey[0], max(en[1] + ey[1], en[2] + ey[2]));
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const float sc = __builtin_amdgcn_ldexpf(1.0f, ey[c] - E);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float r8[8];
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) r8[jj] = blk[c][8 * s + jj] * sc;
+            split8(r8, f[c].hi[s], f[c].lo[s]);
+        }
+    }
+    return E;
+}
+__device__ __forceinline__ void mfma3(f32x16& p, const f16x8& xh, const f16x8& xl, const f16x8& yh, const f16x8& yl) {
+    p = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, yh, p, 0, 0, 0);
+    p = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, yl, p, 0, 0, 0);
+    p = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, yh, p, 0, 0, 0);
+}
+// one channel's product block over the 32 walkers of the tile: p += A (x) B (both K steps, three split products each)
+__device__ __forceinline__ void wgrad_block(f32x16& p, const Frag& xt, const Frag& yt) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) mfma3(p, xt.hi[s], xt.lo[s], yt.hi[s], yt.lo[s]);
+}
+__device__ __forceinline__ void acc_fma(f32x16& acc, const f32x16& p, float un) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = __builtin_fmaf(p[r], un, acc[r]);
 }
 
 template <bool PRIOR>
 __global__ __launch_bounds__(kBwdWaves * 64) void k_ebwd(const MfmaDev mm, int net_index, const float* __restrict__ tabI, const float* __restrict__ tabP,
                                                           const float* __restrict__ st_in, float* __restrict__ adjb, const float* __restrict__ w_psi,
-                                                          const float* __restrict__ w_lap, int64_t B, float* __restrict__ dump) {
+                                                          const float* __restrict__ w_lap, int64_t B, float* __restrict__ partial) {
+    // partial: [gridDim.x][kGFloats] -- this workgroup's block of the net's gradient (image units), written once at the end
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    __shared__ int next_tile;
     __shared__ int bnd_s[32];
     constexpr int kThreads = kBwdWaves * 64;
-    if (threadIdx.x == 0) next_tile = 0;
     if (threadIdx.x < 16) bnd_s[threadIdx.x] = reinterpret_cast<const int*>(tabI + (size_t)mm.n_mesh * 128)[threadIdx.x];
     else if (threadIdx.x < 32) bnd_s[threadIdx.x] = reinterpret_cast<const int*>(tabP + (size_t)mm.n_mesh * 128)[threadIdx.x - 16];
     float* net_l = lds + mm.const_floats;
@@ -1138,7 +1243,16 @@ __global__ __launch_bounds__(kBwdWaves * 64) void k_ebwd(const MfmaDev mm, int n
     stage_floats<kThreads>(mm.image + (size_t)net_index * mm.net_floats, net_l, mm.net_floats);
     stage_floats<kThreads>(mm.image + mm.timg_off + (size_t)net_index * mm.tnet_floats, tnet_l, mm.tnet_floats);
     stage_floats<kThreads>(mm.image + mm.tconst_off, tcon_l, 1024);
+    // the waves' private accumulators of (dW1, dW2) behind the images
+    float* acc_all = tcon_l + 1024;
+    for (int i = threadIdx.x; i < kBwdWaves * kAccFloats; i += kThreads) acc_all[i] = 0.0f;
     __syncthreads();
+    float* accw = acc_all + (threadIdx.x >> 6) * kAccFloats;
+    // bias / input-layer sums of this lane over its wave's tiles: Gb1 and Gb2 (dimension 1) of unit / row (lane & 31) of its u block (transposed operands:
+    // partial over the lane half's 16 walkers), Gb2 of dimension 0, Gb0, GW0 in the lane assignment of the DPP sums below
+    float gb1[2] = {0.0f, 0.0f}, gb21 = 0.0f, gb20 = 0.0f, gb0s = 0.0f, gw0s = 0.0f;
+    f16x8 pm[2];
+    make_perm(threadIdx.x & 63, pm);
     const float* net = net_l;
     const float* fkI = lds;
     const float* fkP = lds + 32;
@@ -1153,26 +1267,21 @@ __global__ __launch_bounds__(kBwdWaves * 64) void k_ebwd(const MfmaDev mm, int n
     const int j = lane & 31, h = lane >> 5;
     const int n_mesh = mm.n_mesh;
     const int64_t n_tiles = (B + 31) >> 5;
-    const int64_t my_tiles = n_tiles > (int64_t)blockIdx.x ? (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
-    for (;;) {
-        int q_ = 0;
-        if (lane == 0) q_ = __hip_atomic_fetch_add(&next_tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        q_ = __builtin_amdgcn_readfirstlane(q_);
-        if (q_ >= my_tiles) break;
-        const int64_t tile = (int64_t)blockIdx.x + (int64_t)q_ * gridDim.x;
+    // tiles are dealt statically (tile = block + (round * waves + wave) * grid): which wave sums which tiles -- and so every bit of the gradient --
+    // does not depend on timing (one wave per SIMD: no issue arbitration to balance, unlike k_mfma's tile counter)
+    for (int64_t tile = (int64_t)blockIdx.x + (int64_t)(threadIdx.x >> 6) * gridDim.x; tile < n_tiles; tile += (int64_t)kBwdWaves * gridDim.x) {
         const int64_t w = tile * 32 + j;
         const bool valid = w < B;
         const int64_t wl = valid ? w : B - 1;
-        float* dmp = dump + (size_t)tile * kDumpFloats;
+        // (padding lanes of the last tile repeat walker B - 1 with zero adjoints: their columns add nothing to the sums over walkers)
         const JA u0 = ja_load(st_in, 0, B, wl), u1 = ja_load(st_in, 1, B, wl);
         // ---- the net's forward to the head triples o (the second hidden layer's activations go to the dump on the way).  The second hidden layer's
         // pre-activations z2, which the reverse needs, are computed again behind the head: 96 registers less across the head algebra
         f32x16 o[NCH];
         {
             f32x16 z2a[NCH], z2b[NCH];
-            cond_fwd<true>(net, u0.v, u1.v, lane, z2a, z2b, o, dmp);
+            cond_fwd<true>(net, u0.v, u1.v, lane, z2a, z2b, o);
         }
-        if (h == 0) dmp[kDS + j] = u0.v;
         // ---- head: forward sums, pullback to adjoint head triples ob (dimension 1) and ob0 (dimension 0, channel 0)
         f32x16 ob[NCH], ob0;
         JA u0b = adj::jzero<float>(), u1b = adj::jzero<float>(), ldb = adj::jzero<float>();
@@ -1305,21 +1414,58 @@ __global__ __launch_bounds__(kBwdWaves * 64) void k_ebwd(const MfmaDev mm, int n
                 for (int r = 0; r < 16; ++r) ob0[r] = __builtin_fmaf(wb[0][r], keep[r], sbar);
             }
         }
+        // Gb2 of dimension 0: sum over the tile's walkers of obar0 (16 registers per half: DPP sums; lane (j, h) keeps register j & 15 where j < 16)
+        {
+            float sb = 0.0f;
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) dump_block(dmp + kDY3 + c * 1024, 0, ob[c], j, h);
-        dump_block(dmp + kDY30, 0, ob0, j, h);
+            for (int r = 0; r < 16; ++r) {
+                const float a = half32_sum(ob0[r]);
+                sb = (j & 15) == r ? a : sb;
+            }
+            gb20 += sb;
+        }
         // ---- conditioner, reverse: hbar2 = W2' obar, zbar2 = act'(z2) hbar2, hbar1 = W1' zbar2, zbar1 = act'(z1) hbar1
         __builtin_amdgcn_sched_barrier(0);
         f32x16 z2a[NCH], z2b[NCH];
+        Frag f[NCH][2];       // fragments of the tensor the next product contracts: obar, then zbar2
+        int e[NCH];
+        to_frags1<true>(ob, f, e);
         {
             f32x16 o2[NCH];
-            cond_fwd<false>(net, u0.v, u1.v, lane, z2a, z2b, o2, dmp);
+            cond_fwd<false>(net, u0.v, u1.v, lane, z2a, z2b, o2);
+        }
+        // dW2[k][row] = sum_c sum_w X2_c[k][w] obar_c[row][w]: X2 = act(z2), block by block (32 units: 48 registers of fragments at a time); both operands
+        // transposed on the matrix cores; the two 32 x 32 blocks of the product accumulate in this wave's LDS blocks 4, 5.  Gb2 rides on obar's transposes.
+        {
+            Frag yt[NCH];      // obar^T, once for both k blocks
+            {
+                float rs = 0.0f;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) tr_frag(f[c][0], pm, yt[c], c == 0 ? &rs : nullptr);
+                gb21 = __builtin_fmaf(rs, __builtin_amdgcn_ldexpf(1.0f, e[0]), gb21);
+            }
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                f32x16 t[NCH];
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) t[c] = mb ? z2b[c] : z2a[c];
+                act_block(t);
+                Frag fx[NCH];
+                const int E = block_frags_x(t, e, fx);
+                f32x16 p = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    Frag xt;
+                    tr_frag(fx[c], pm, xt);
+                    wgrad_block(p, xt, yt[c]);
+                }
+                f32x16 a = acc_load(accw, 4 + mb, lane);
+                acc_fma(a, p, __builtin_amdgcn_ldexpf(1.0f, E));
+                acc_store(accw, 4 + mb, lane, a);
+            }
         }
         f32x16 g0[NCH], g1[NCH];
         {
-            Frag f[NCH][2];
-            int e[NCH];
-            to_frags1(ob, f, e);
 #pragma unroll
             for (int c = 0; c < NCH; ++c) { g0[c] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; g1[c] = g0[c]; }
 #pragma unroll
@@ -1331,9 +1477,45 @@ __global__ __launch_bounds__(kBwdWaves * 64) void k_ebwd(const MfmaDev mm, int n
             unscale_all(g1, e);
             act_block_bwd(z2a, g0);
             act_block_bwd(z2b, g1);
+            to_frags_all<true>(g0, g1, f, e);
+            // dW1[k][u] = sum_c sum_w X1_c[k][w] zbar2_c[u][w] while the fragments of zbar2 (f, exponents e) are at hand and before the product that
+            // consumes them: X1, the first hidden layer's activation triples, is recomputed block by block from (s, 1, 0) (two f32 MFMAs and 16
+            // activations per lane and block).  LDS blocks 0 .. 3 = (k block mb, u block nb); Gb1 rides on the transposes of zbar2.
+            {
+                using O = NetOff<2, 1>;
+                const float in0[2] = {u0.v, 1.0f}, in1[2] = {u1.v, 0.0f};
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) { dump_block(dmp + kDY2 + c * 2048, 0, g0[c], j, h); dump_block(dmp + kDY2 + c * 2048, 32, g1[c], j, h); }
-            to_frags_all(g0, g1, f, e);
+                for (int mb = 0; mb < 2; ++mb) {
+                    f32x16 t[NCH];
+                    init_acc(t, net + O::b0 + (mb * 2 + h) * 16);
+                    const float w0 = net[O::W0 + mb * 64 + lane];
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) t[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, h ? in1[c] : in0[c], t[c], 0, 0, 0);
+                    act_block(t);
+                    Frag fx[NCH];
+                    const int E = block_frags_x(t, e, fx);
+                    Frag xt[NCH];
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) tr_frag(fx[c], pm, xt[c]);
+                    const float un = __builtin_amdgcn_ldexpf(1.0f, E);
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) {
+                        f32x16 p = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                        for (int c = 0; c < NCH; ++c) {
+                            Frag yt;
+                            float rs = 0.0f;
+                            const bool bias = c == 0 && mb == 0;
+                            tr_frag(f[c][nb], pm, yt, bias ? &rs : nullptr);
+                            wgrad_block(p, xt[c], yt);
+                            if (bias) gb1[nb] = __builtin_fmaf(rs, __builtin_amdgcn_ldexpf(1.0f, e[0]), gb1[nb]);
+                        }
+                        f32x16 c0 = acc_load(accw, 2 * mb + nb, lane);
+                        acc_fma(c0, p, un);
+                        acc_store(accw, 2 * mb + nb, lane, c0);
+                    }
+                }
+            }
 #pragma unroll
             for (int c = 0; c < NCH; ++c) { g0[c] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; g1[c] = g0[c]; }
             dense64_block<NCH>(TW1h, TW1l, f, g0, lane);
@@ -1368,9 +1550,8 @@ __global__ __launch_bounds__(kBwdWaves * 64) void k_ebwd(const MfmaDev mm, int n
                 sb = mine ? (j < 16 ? a0 : a1) : sb;
                 sw = mine ? (j < 16 ? b0 : b1) : sw;
             }
-            const int u = 32 * (j >> 4) + (j & 3) + 8 * ((j & 15) >> 2) + 4 * h;
-            dmp[kDG + u] = sb;
-            dmp[kDG + 64 + u] = sw;
+            gb0s += sb;
+            gw0s += sw;
         }
         {
             const f32x16 wa = load16(TW0 + (0 * 2 + h) * 16), wb2 = load16(TW0 + (1 * 2 + h) * 16);
@@ -1385,223 +1566,63 @@ __global__ __launch_bounds__(kBwdWaves * 64) void k_ebwd(const MfmaDev mm, int n
             ja_store(adjb, 2, B, w, ldb);
         }
     }
-}
-
-// ---- weight-gradient products of one net from the tile dumps.  Gradient block of a net (floats, in the units of the MFMA image):
-//   GW0 [64] (d / d W0'[0][u]), Gb0 [64], GW1 [64][64] (k, u), Gb1 [64], GW2 [64][32] (k, row), Gb2 of dimension 1 [32], of dimension 0 [32]
-constexpr int kGW0 = 0, kGb0 = 64, kGW1 = 128, kGb1 = 4224, kGW2 = 4288, kGb21 = 6336, kGb20 = 6368, kGFloats = 6400;
-constexpr int kESplit = 256;   // partial sums along the tile axis (summed in split order: bitwise reproducible); 2 x 256 workgroups: two per CU (128: 197 us, 256: 135 us, 512: 130 us + a longer reduction, per net and 2^17 walkers)
-// The four waves of a workgroup work on one tile at a time.  The tile's operand blocks come from HBM as one coalesced stream (every thread 16-byte
-// pieces, a tile ahead, in registers while the current tile is being multiplied) and are laid into LDS with a padded row (36 floats: the operand
-// reads below are 32-byte pieces of rows 144 bytes apart); each wave owns one block of the product, so nothing is reduced across waves but the
-// K halves of job 1.  Operands are scaled by one power of two per (operand, channel) and wave before the fp16 split (exact; the adjoints are unbounded).
-constexpr int kEwStride = 36;
-__device__ __forceinline__ float wave_max(float v) {   // v >= 0
-    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)));
-    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)));
-    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)));
-    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true)));
-    const unsigned u = __float_as_uint(v);
-    const auto sw = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    return xhalf_max(fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])));
-}
-__device__ __forceinline__ int exponent_of(float amax) { return amax > 0.0f ? __builtin_amdgcn_frexp_expf(amax) : 0; }
-__device__ __forceinline__ float amax8(const float (&v)[8]) {
-    return fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))), fmaxf(fmaxf(fabsf(v[4]), fabsf(v[5])), fmaxf(fabsf(v[6]), fabsf(v[7]))));
-}
-__device__ __forceinline__ void split_times(const float (&v)[8], float sc, f16x8& hi, f16x8& lo) {
-    const float vs[8] = {v[0] * sc, v[1] * sc, v[2] * sc, v[3] * sc, v[4] * sc, v[5] * sc, v[6] * sc, v[7] * sc};
-    split8(vs, hi, lo);
-}
-__device__ __forceinline__ void mfma3(f32x16& p, const f16x8& xh, const f16x8& xl, const f16x8& yh, const f16x8& yl) {
-    p = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, yh, p, 0, 0, 0);
-    p = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, yl, p, 0, 0, 0);
-    p = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, yh, p, 0, 0, 0);
-}
-__device__ __forceinline__ void lds_row8(const float* __restrict__ p, float (&v)[8]) {
-    const float4_t a = *reinterpret_cast<const float4_t*>(p), b = *reinterpret_cast<const float4_t*>(p + 4);
-    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-}
-// NQ 16-byte pieces per thread of a contiguous run of rows (32 floats each) starting at float offset `first`
-template <int NQ>
-__device__ __forceinline__ void ew_fetch(const float* __restrict__ d, int first, float4_t (&q)[NQ]) {
-#pragma unroll
-    for (int k = 0; k < NQ; ++k) q[k] = *reinterpret_cast<const float4_t*>(d + first + 4 * (k * 256 + (int)threadIdx.x));
-}
-template <int NQ>
-__device__ __forceinline__ void ew_stage(float* __restrict__ img, int row0, const float4_t (&q)[NQ]) {
-#pragma unroll
-    for (int k = 0; k < NQ; ++k) {
-        const int idx4 = k * 256 + (int)threadIdx.x;
-        *reinterpret_cast<float4_t*>(img + (row0 + (idx4 >> 3)) * kEwStride + 4 * (idx4 & 7)) = q[k];
-    }
-}
-
-// job 0: dW1 (64 x 64; wave w: rows 32 (w >> 1).., columns 32 (w & 1)..) = X1 (x) Y2 with Gb1; Gb0 and GW0 are the tile sums k_ebwd left in the dump.
-// X1, the first hidden layer's activation triples, is recomputed from s (as k_ebwd: z = b0 + W0 s, z' = W0, z'' = 0); its scale per channel is a bound
-// from the block's largest |W0| (r < 1, |r'| <= ln2 / 4, |r''| <= 0.0463).
-__device__ __forceinline__ void ewgrad_job0(float* __restrict__ img, const float* __restrict__ dump, int64_t t0, int64_t t1, const float* __restrict__ net_img,
-                                            float* __restrict__ g) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 31, hs = lane >> 5, mb = wave >> 1, nb = wave & 1;
-    const float w0u = net_img[NetOff<2, 1>::W0 + mb * 64 + m];
-    // (b0 sits in accumulator layout: register (m & 3) + 4 (m >> 3) of half (m >> 2) & 1)
-    const float b0u = net_img[NetOff<2, 1>::b0 + (mb * 2 + ((m >> 2) & 1)) * 16 + (m & 3) + 4 * (m >> 3)];
-    const float wmax = wave_max(fabsf(w0u));
-    const int exc[NCH] = {0, exponent_of(0.1732868f * wmax), exponent_of(0.0462982f * wmax * wmax)};
-    f32x16 acc = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    float bias = 0.0f, gsum = 0.0f;
-    float4_t q[6], qs;
-    float gq = 0.0f;
-    auto fetch = [&](int64_t t) {
-        const float* d = dump + (size_t)t * kDumpFloats;
-        ew_fetch<6>(d, kDY2, q);
-        if (threadIdx.x < 8) qs = *reinterpret_cast<const float4_t*>(d + kDS + 4 * threadIdx.x);
-        if (mb == 1) gq = d[kDG + 64 * hs + 32 * nb + m];     // half 0: Gb0, half 1: GW0 of unit 32 nb + m
-    };
-    if (t0 < t1) fetch(t0);
-    for (int64_t t = t0; t < t1; ++t) {
-        __syncthreads();
-        ew_stage<6>(img, 0, q);
-        if (threadIdx.x < 8) *reinterpret_cast<float4_t*>(img + 192 * kEwStride + 4 * threadIdx.x) = qs;
-        gsum += gq;
-        __syncthreads();
-        if (t + 1 < t1) fetch(t + 1);
-        // this wave's Y rows (unit 32 nb + m, its K half), all channels and K steps
-        float yv[NCH][2][8];
-        int ey[NCH];
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            float am = 0.0f;
-#pragma unroll
-            for (int st = 0; st < 2; ++st) {
-                lds_row8(img + (c * 64 + 32 * nb + m) * kEwStride + 16 * st + 8 * hs, yv[c][st]);
-                am = fmaxf(am, amax8(yv[c][st]));
-            }
-            ey[c] = exponent_of(wave_max(am));
-        }
-        if (mb == 0) {   // Gb1[u] = sum_w zbar2_0[u][w]
-#pragma unroll
-            for (int st = 0; st < 2; ++st) bias += ((yv[0][st][0] + yv[0][st][1]) + (yv[0][st][2] + yv[0][st][3])) + ((yv[0][st][4] + yv[0][st][5]) + (yv[0][st][6] + yv[0][st][7]));
-        }
-        f16x8 xh[NCH][2], xl[NCH][2];
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            float sv[8], v0[8], v1[8], v2[8];
-            lds_row8(img + 192 * kEwStride + 16 * st + 8 * hs, sv);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float z = __builtin_fmaf(w0u, sv[i], b0u);
-                const float rr = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(z) + 1.0f);
-                const float r1 = -0.6931471805599453f * __builtin_fmaf(-rr, rr, rr);
-                const float k = __builtin_fmaf(1.3862943611198906f, rr, -0.6931471805599453f);
-                v0[i] = rr;
-                v1[i] = r1 * w0u;
-                v2[i] = r1 * ((k * w0u) * w0u);
-            }
-            split_times(v0, 1.0f, xh[0][st], xl[0][st]);
-            split_times(v1, __builtin_amdgcn_ldexpf(1.0f, -exc[1]), xh[1][st], xl[1][st]);
-            split_times(v2, __builtin_amdgcn_ldexpf(1.0f, -exc[2]), xh[2][st], xl[2][st]);
-        }
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            f32x16 p = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            const float sy = __builtin_amdgcn_ldexpf(1.0f, -ey[c]), un = __builtin_amdgcn_ldexpf(1.0f, exc[c] + ey[c]);
-#pragma unroll
-            for (int st = 0; st < 2; ++st) {
-                f16x8 yh, yl;
-                split_times(yv[c][st], sy, yh, yl);
-                mfma3(p, xh[c][st], xl[c][st], yh, yl);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = __builtin_fmaf(p[r], un, acc[r]);
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) g[kGW1 + (32 * mb + (r & 3) + 8 * (r >> 2) + 4 * hs) * 64 + 32 * nb + m] = acc[r];
-    if (mb == 0) {
-        const float sb = xhalf_sum(bias);
-        if (hs == 0) g[kGb1 + 32 * nb + m] = sb;
-    } else {
-        g[(hs ? kGW0 : kGb0) + 32 * nb + m] = gsum;
-    }
-}
-
-// job 1: dW2 (64 x 32; wave w: rows 32 (w & 1).., K step w >> 1, the two K steps of a block meet in LDS at the end) = X2 (x) Y3 with both Gb2
-__device__ __forceinline__ void ewgrad_job1(float* __restrict__ img, const float* __restrict__ dump, int64_t t0, int64_t t1, float* __restrict__ g) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 31, hs = lane >> 5, mb = wave & 1, st = wave >> 1;
-    f32x16 acc = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    float bias = 0.0f;      // mb 0: Gb2 of dimension 1, mb 1: of dimension 0 (this wave's K step)
-    float4_t qx[6], qy[3], q0[1];
-    auto fetch = [&](int64_t t) {
-        const float* d = dump + (size_t)t * kDumpFloats;
-        ew_fetch<6>(d, kDX2, qx);
-        ew_fetch<3>(d, kDY3, qy);
-        ew_fetch<1>(d, kDY30, q0);
-    };
-    if (t0 < t1) fetch(t0);
-    for (int64_t t = t0; t < t1; ++t) {
-        __syncthreads();
-        ew_stage<6>(img, 0, qx);        // rows   0 .. 191: X2 [c][64]
-        ew_stage<3>(img, 192, qy);      // rows 192 .. 287: Y3 [c][32]
-        ew_stage<1>(img, 288, q0);      // rows 288 .. 319: Y30
-        __syncthreads();
-        if (t + 1 < t1) fetch(t + 1);
-        const int col = 16 * st + 8 * hs;
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            float xv[8], yv[8];
-            lds_row8(img + (c * 64 + 32 * mb + m) * kEwStride + col, xv);
-            lds_row8(img + (192 + c * 32 + m) * kEwStride + col, yv);
-            const int ex = exponent_of(wave_max(amax8(xv))), ey = exponent_of(wave_max(amax8(yv)));
-            if (c == 0 && mb == 0) bias += ((yv[0] + yv[1]) + (yv[2] + yv[3])) + ((yv[4] + yv[5]) + (yv[6] + yv[7]));
-            f16x8 xh, xl, yh, yl;
-            split_times(xv, __builtin_amdgcn_ldexpf(1.0f, -ex), xh, xl);
-            split_times(yv, __builtin_amdgcn_ldexpf(1.0f, -ey), yh, yl);
-            f32x16 p = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            mfma3(p, xh, xl, yh, yl);
-            const float un = __builtin_amdgcn_ldexpf(1.0f, ex + ey);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = __builtin_fmaf(p[r], un, acc[r]);
-        }
-        if (mb == 1) {
-            float y0[8];
-            lds_row8(img + (288 + m) * kEwStride + col, y0);
-            bias += ((y0[0] + y0[1]) + (y0[2] + y0[3])) + ((y0[4] + y0[5]) + (y0[6] + y0[7]));
-        }
-    }
-    // K step 1 -> LDS, K step 0 adds it and writes
-    __syncthreads();
-    const float sb = xhalf_sum(bias);
-    float* mine = img + mb * (16 * 64 + 32);
-    if (st == 1) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mine[r * 64 + lane] = acc[r];
-        if (hs == 0) mine[16 * 64 + m] = sb;
+    // ---- the waves' sums -> this workgroup's block of the net's gradient, waves added in wave order
+    __syncthreads();                       // every wave is done with its tiles: the operand images are dead, the accumulators complete
+    float* red = lds;                      // [wave][6 kinds][64 lanes] over the image area
+    {
+        float* mine = red + (threadIdx.x >> 6) * 6 * 64 + lane;
+        mine[0] = gb1[0]; mine[64] = gb1[1]; mine[128] = gb21; mine[192] = gb20; mine[256] = gb0s; mine[320] = gw0s;
     }
     __syncthreads();
-    if (st == 0) {
+    float* g = partial + (size_t)blockIdx.x * kGFloats;
+    auto wsum = [&](int kind, int ln) {    // sum over the waves of a lane's value
+        float a = 0.0f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) g[kGW2 + (32 * mb + (r & 3) + 8 * (r >> 2) + 4 * hs) * 32 + m] = acc[r] + mine[r * 64 + lane];
-        if (hs == 0) g[(mb ? kGb20 : kGb21) + m] = sb + mine[16 * 64 + m];
+        for (int wv = 0; wv < kBwdWaves; ++wv) a += red[(wv * 6 + kind) * 64 + ln];
+        return a;
+    };
+    for (int i = threadIdx.x; i < kAccFloats; i += kThreads) {
+        float a = 0.0f;
+#pragma unroll
+        for (int wv = 0; wv < kBwdWaves; ++wv) a += acc_all[wv * kAccFloats + i];
+        const int b = i >> 10, q = (i >> 8) & 3, ln = (i >> 2) & 63, r = 4 * q + (i & 3);
+        const int row = acc_rho(r, ln >> 5), n = ln & 31;
+        if (b < 4) g[kGW1 + (32 * (b >> 1) + row) * 64 + 32 * (b & 1) + n] = a;
+        else g[kGW2 + (32 * (b - 4) + row) * 32 + n] = a;
+    }
+    if (threadIdx.x < 64) {                // Gb1[u]: u block = thread >> 5; the two lane halves hold the two halves of the tile's walkers
+        const int nb = threadIdx.x >> 5, n = threadIdx.x & 31;
+        g[kGb1 + threadIdx.x] = wsum(nb, n) + wsum(nb, n + 32);
+    } else if (threadIdx.x < 96) {
+        const int n = threadIdx.x - 64;
+        g[kGb21 + n] = wsum(2, n) + wsum(2, n + 32);
+    } else if (threadIdx.x < 128) {        // Gb2 of dimension 0: lane (j < 16, h) keeps register j of half h
+        const int t = threadIdx.x - 96, jj = t & 15, hh = t >> 4;
+        g[kGb20 + acc_rho(jj, hh)] = wsum(3, jj + 32 * hh);
+    } else if (threadIdx.x < 192) {        // Gb0 / GW0: lane (j, h) keeps register j & 15 of block j >> 4
+        const int ln = threadIdx.x - 128, jj = ln & 31, hh = ln >> 5;
+        const int u = 32 * (jj >> 4) + acc_rho(jj & 15, hh);
+        g[kGb0 + u] = wsum(4, ln);
+        g[kGW0 + u] = wsum(5, ln);
     }
 }
-constexpr int kEwLdsFloats = 320 * kEwStride;
-__global__ __launch_bounds__(256, 2) void k_ewgrad(const float* __restrict__ dump, int64_t n_tiles, const float* __restrict__ net_img, float* __restrict__ partial) {
-    __shared__ __attribute__((aligned(16))) float img[kEwLdsFloats];
-    const int split = blockIdx.x;
-    const int64_t t0 = n_tiles * split / kESplit, t1 = n_tiles * (split + 1) / kESplit;
-    float* g = partial + (size_t)split * kGFloats;
-    if (blockIdx.y == 0) ewgrad_job0(img, dump, t0, t1, net_img, g);
-    else ewgrad_job1(img, dump, t0, t1, g);
-}
-// (one launch for the nets of a chunk: blockIdx.y = net; partial [n_nets][kESplit][kGFloats], gacc [n_nets][kGFloats])
-__global__ void k_egrad_reduce(const float* __restrict__ partial, int accumulate, float* __restrict__ gacc) {
+
+// (one launch for the nets of a chunk: blockIdx.y = net; partial [n_nets][kESplit][kGFloats] of which the first n_part blocks are live, gacc [n_nets][kGFloats])
+__global__ void k_egrad_reduce(const float* __restrict__ partial, int n_part, int accumulate, float* __restrict__ gacc) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= kGFloats) return;
     const float* pn = partial + (size_t)blockIdx.y * kESplit * kGFloats;
     float* gn = gacc + (size_t)blockIdx.y * kGFloats;
     float sacc = accumulate ? gn[i] : 0.0f;
-    for (int p = 0; p < kESplit; ++p) sacc += pn[(size_t)p * kGFloats + i];
+    int p = 0;
+    for (; p + 8 <= n_part; p += 8) {   // eight loads in flight, added in block order (a runtime trip count alone left one dependent load per ~230 ns: 60 us)
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = pn[(size_t)(p + k) * kGFloats + i];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sacc += v[k];
+    }
+    for (; p < n_part; ++p) sacc += pn[(size_t)p * kGFloats + i];
     gn[i] = sacc;
 }
 struct ENetOff {
@@ -2045,10 +2066,14 @@ int launch_energy_tile(const MfmaDev* mdev, const ModelDev& md, const float* tab
 
 
 // ---- host side of the matrix-core gradient path
-bool energy_vjp_capable(const MfmaDev* mdev) { return mdev->timg_off >= 0 && mdev->nbk == 1 && energy_tile_fused(mdev) && !mdev->i_gate && !mdev->p_gate; }
+bool energy_vjp_capable(const MfmaDev* mdev) {
+    // (the reverse kernel's LDS: constants, one net's forward and transposed images, the transposed ob_to_b, the four waves' accumulators of (dW1, dW2))
+    const int64_t lds = ((int64_t)mdev->const_floats + mdev->net_floats + mdev->tnet_floats + 1024 + kBwdWaves * kAccFloats) * (int64_t)sizeof(float);
+    return mdev->timg_off >= 0 && mdev->nbk == 1 && energy_tile_fused(mdev) && !mdev->i_gate && !mdev->p_gate && lds <= 160 * 1024 - 512;
+}
 // floats of workspace per walker of a chunk (whole tiles), + the fixed part
-int64_t energy_vjp_floats_per_walker(int n_nets) { return (int64_t)n_nets * 12 + 12 + 4 + kDumpFloats / 32; }
-int64_t energy_vjp_fixed_floats(int n_nets) { return (int64_t)n_nets * kESplit * kGFloats + kDumpFloats + 128; }
+int64_t energy_vjp_floats_per_walker(int n_nets) { return (int64_t)n_nets * 12 + 12 + 4; }   // per-net input jets, adjoint jets, H psi / psi / seeds
+int64_t energy_vjp_fixed_floats(int n_nets) { return (int64_t)n_nets * kESplit * kGFloats + 128; }   // the workgroups' gradient blocks
 int energy_vjp_gacc_floats(int n_nets) { return n_nets * kGFloats; }
 
 // One chunk of walkers (B a multiple of 32 except for the last chunk of a batch): forward with the per-net input jets, seeds (mode 2: from H psi of
@@ -2067,8 +2092,7 @@ int launch_energy_vjp(const MfmaDev* mdev, const ModelDev& md, const float* tabI
     float* psi = hpsi + B;
     float* wp = psi + B;
     float* wl = wp + B;
-    float* dump = ws + (((size_t)(n_nets * 12 + 12 + 4) * B + 63) / 64) * 64;   // (64-float alignment: the dump rows are read as 16-byte groups)
-    float* partial = dump + (size_t)n_tiles * kDumpFloats;
+    float* partial = ws + (((size_t)(n_nets * 12 + 12 + 4) * B + 63) / 64) * 64;   // [n_nets][kESplit][kGFloats]
     int rc = launch_energy_tile(mdev, md, tabI4, tabP4, nullptr, x, B, pr, hpsi, psi, nullptr, nullptr, stream, st);
     if (rc) return rc;
     if (mode == 2) {
@@ -2077,7 +2101,7 @@ int launch_energy_vjp(const MfmaDev* mdev, const ModelDev& md, const float* tabI
         w_psi = wp;
         w_lap = wl;
     }
-    const int lds_bytes = (mdev->const_floats + mdev->net_floats + mdev->tnet_floats + 1024) * (int)sizeof(float);
+    const int lds_bytes = (mdev->const_floats + mdev->net_floats + mdev->tnet_floats + 1024 + kBwdWaves * kAccFloats) * (int)sizeof(float);
     static DynLdsSlots cfg_p{}, cfg_f{};
     if (int r2 = ensure_dynamic_lds(reinterpret_cast<const void*>(k_ebwd<true>), lds_bytes, &cfg_p)) return r2;
     if (int r2 = ensure_dynamic_lds(reinterpret_cast<const void*>(k_ebwd<false>), lds_bytes, &cfg_f)) return r2;
@@ -2085,13 +2109,13 @@ int launch_energy_vjp(const MfmaDev* mdev, const ModelDev& md, const float* tabI
     for (int n = n_nets - 1; n >= 0; --n) {
         const float* st_n = st + (size_t)n * 12 * B;
         if (n == n_nets - 1)
-            hipLaunchKernelGGL(k_ebwd<true>, dim3(blocks), dim3(kBwdWaves * 64), lds_bytes, s, *mdev, n, tabI4, tabP4, st_n, adjb, w_psi, w_lap, B, dump);
+            hipLaunchKernelGGL(k_ebwd<true>, dim3(blocks), dim3(kBwdWaves * 64), lds_bytes, s, *mdev, n, tabI4, tabP4, st_n, adjb, w_psi, w_lap, B,
+                               partial + (size_t)n * kESplit * kGFloats);
         else
-            hipLaunchKernelGGL(k_ebwd<false>, dim3(blocks), dim3(kBwdWaves * 64), lds_bytes, s, *mdev, n, tabI4, tabP4, st_n, adjb, w_psi, w_lap, B, dump);
-        hipLaunchKernelGGL(k_ewgrad, dim3(kESplit, 2), dim3(256), 0, s, (const float*)dump, n_tiles, mdev->image + (size_t)n * mdev->net_floats,
-                           partial + (size_t)n * kESplit * kGFloats);
+            hipLaunchKernelGGL(k_ebwd<false>, dim3(blocks), dim3(kBwdWaves * 64), lds_bytes, s, *mdev, n, tabI4, tabP4, st_n, adjb, w_psi, w_lap, B,
+                               partial + (size_t)n * kESplit * kGFloats);
     }
-    hipLaunchKernelGGL(k_egrad_reduce, dim3((kGFloats + 255) / 256, n_nets), dim3(256), 0, s, (const float*)partial, accumulate, gacc);
+    hipLaunchKernelGGL(k_egrad_reduce, dim3((kGFloats + 255) / 256, n_nets), dim3(256), 0, s, (const float*)partial, (int)blocks, accumulate, gacc);
     return check();
 }
 

@@ -30,13 +30,47 @@ using i32x2 = __attribute__((ext_vector_type(2))) int;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 
+// Experiment builds (scratch/r04_parity_variants.py; timing is irrelevant there): one class of hardware approximations at a time replaced by fp64
+// arithmetic, to attribute the kernel's deviation from the reference -- WF_X_ACT: hidden activations, WF_X_SIG: sigmoid heads, WF_X_LOG: logarithms,
+// WF_X_RCP: reciprocals / reciprocal square roots of the heads.
+__device__ __forceinline__ float x_rinv(float xs) {   // 1 / (2^xs + 1)
+#if defined(WF_X_ACT) || defined(WF_X_SIG)
+    return (float)(1.0 / (exp2((double)xs) + 1.0));
+#else
+    return __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(xs) + 1.0f);
+#endif
+}
+__device__ __forceinline__ float x_rcp(float v) {
+#ifdef WF_X_RCP
+    return (float)(1.0 / (double)v);
+#else
+    return __builtin_amdgcn_rcpf(v);
+#endif
+}
+__device__ __forceinline__ float x_rsq(float v) {
+#ifdef WF_X_RCP
+    return (float)(1.0 / sqrt((double)v));
+#else
+    return __builtin_amdgcn_rsqf(v);
+#endif
+}
 __device__ __forceinline__ float act_tanh(float xs) {  // xs = 2*log2(e)*x (scale folded into the weights)
     return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(xs) + 1.0f), 1.0f);
 }
 __device__ __forceinline__ float act_sigmoid(float xs) {  // xs = -log2(e)*x
+#ifdef WF_X_SIG
+    return x_rinv(xs);
+#else
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(xs));
+#endif
 }
-__device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+__device__ __forceinline__ float fast_log(float x) {
+#ifdef WF_X_LOG
+    return (float)log((double)x);
+#else
+    return __builtin_amdgcn_logf(x) * 0.6931471805599453f;
+#endif
+}
 
 // sum of the two lane halves (lane l and l^32), result in every lane
 __device__ __forceinline__ float xhalf_sum(float v) {
@@ -232,18 +266,26 @@ __device__ __forceinline__ void act8(const f32x16 (&x)[T], int s, Frag (&f)[T][2
         float r[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
+#ifdef WF_X_ACT
+            r[j] = CENTER ? (float)(1.0 / (exp2((double)x[t][8 * s + j]) + 1.0) - 0.5) : x_rinv(x[t][8 * s + j]);
+#else
             r[j] = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x[t][8 * s + j]) + 1.0f);
             if (CENTER) r[j] = r[j] - 0.5f;
+#endif
         }
         split8(r, f[t][ob].hi[s], f[t][ob].lo[s]);
 #endif
     }
 }
 
-#ifdef WF_NO_CENTER   // A/B build: the flow nets' first hidden layer in the folded form of rounds 2 - 3
-constexpr bool kCenter = false;
-#else
+// WF_CENTER (experiment build, round 4): the flow nets' first hidden layer hands r - 1/2 to the second one (hidden_layers<..., CENTER>).  The CPU
+// emulation of the kernel's matrix arithmetic (scratch/r04_parity_attribution.py) named that product as the one that moves walkers; on the GPU the
+// centred form changed nothing that can be measured (direct agreement with the fp32 oracle on C3's well-conditioned subset 0.935 against 0.940,
+// profiles/r04_parity_variants_gpu.txt) at + 0.6 % time: not adopted, the switch and the unfolded bias (NetOff::b1c) stay for the record.
+#ifdef WF_CENTER
 constexpr bool kCenter = true;
+#else
+constexpr bool kCenter = false;
 #endif
 // float offsets inside a net image (wf_model.cpp: build_mfma_image); NBK = 32-row blocks per dimension (1 or 2)
 template <int D, int NBK>
@@ -268,14 +310,11 @@ struct NetOff {
 //   chain(layer 2, block 1)                              ||  activation of layer-2 block 0
 // Result: h2[t][0] complete, pend[t] = pre-activations of layer-2 block 1 (their activation goes under the first K steps of the
 // output chain: out_block_first).
-// CENTER (the flow nets; round 4): the first hidden layer hands r - 1/2 = -tanh/2 to the second one, whose bias is then the plain c b1
-// (NetOff::b1c) instead of c (b1 + sum_k W1_k).  With r itself the products (-2 c W1_k) r_k are of the size of the weights while their sum,
-// after the constant cancels, is of the size of sum_k W1_k tanh_k: the 2^-22 relative representation error of the fp16 pairs and the
-// accumulator's roundings at the constant's magnitude then show in the pre-activations of the second hidden layer -- the one site that moved
-// the kernel's agreement with the fp32 reference (scratch/r04_parity_attribution.py, profiles/r04_parity_attribution.txt: 1.8 % of the
-// well-conditioned walkers moved by more than 1e-5 relative through this product alone, a fourth product lo * lo changes nothing, the centred
-// form 0.25 - 0.7 %).  One v_add_f32 per value of the first hidden layer; the output layer and the prior net keep the folded form (their
-// sites move no walker).
+// CENTER (experiment, -DWF_CENTER; see kCenter): the first hidden layer hands r - 1/2 = -tanh/2 to the second one, whose bias is then the plain
+// c b1 (NetOff::b1c) instead of c (b1 + sum_k W1_k).  With r itself the products (-2 c W1_k) r_k are of the size of the weights while their sum,
+// after the constant cancels, is of the size of sum_k W1_k tanh_k; in a CPU emulation of the matrix arithmetic alone that showed (1.8 % of the
+// well-conditioned walkers moved by more than 1e-5 relative through this product, a fourth product lo * lo changing nothing, the centred form
+// 0.25 - 0.7 %: profiles/r04_parity_attribution_cpu.txt); in the real kernel it is below the fp32 roundings of everything else.
 template <int D, int NBK, int T, bool CENTER = false>
 __device__ __forceinline__ void hidden_layers(const float* net, const float (&in)[T][D], int lane, Frag (&h2)[T][2], f32x16 (&pend)[T]) {
     using O = NetOff<D, NBK>;
@@ -750,7 +789,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
                         float S1, Sf;
                         sigmoid_block<NBK>(v[t], fkI, h, S1, Sf, gate_i, gl[t], net + NetOff<D, NBK>::z + d * NBK * 32);
                         const float rs = mm.i_reg * S1;
-                        const float rS = __builtin_amdgcn_rcpf(__builtin_fmaf(rs, mm.F_I, Sf));
+                        const float rS = x_rcp(__builtin_fmaf(rs, mm.F_I, Sf));
                         const Lerp Lp = make_lerp(cur[t][d], mm.n_mesh, rn_mesh, exact_div);
                         if (IDX && idx[t]) { idx[t][(l * D + d) * 2] = Lp.xl; idx[t][(l * D + d) * 2 + 1] = Lp.xr; }
                         float ld;
@@ -909,7 +948,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
 #pragma unroll
                                 for (int r = 0; r < 16; ++r) n2 = __builtin_fmaf(c[ko][r], c[ko][r], n2);
                             }
-                            const float rnorm = __builtin_amdgcn_rsqf(xhalf_sum(n2));
+                            const float rnorm = x_rsq(xhalf_sum(n2));
                             const float v0 = rows_dot<NBK>(c, mm.tabP, Lp[t], h, bndP) * rnorm;
                             val[t] = (s1 < 0.0f && !mm.prior_quotient) ? -v0 : v0;
                         }

@@ -1413,8 +1413,9 @@ static int dispatch(const wf_model* m, int mode, const float* x, int64_t B, floa
         if (rc) return rc;
         float* s = m->d_scratch + front;
         *inv = reinterpret_cast<int32_t*>(s + B * Dm);
+        rc = launch_sort_rows(*xs, B, Dm, s, *inv, stream);   // (*xs: the caller's rows -- replaced by the sorted copy only now)
         *xs = s;
-        return launch_sort_rows(x, B, Dm, s, *inv, stream);
+        return rc;
     };
     // Small batches: one wave per walker (wf_kernels_wave.hip) takes 14 us for up to ~1000 walkers where the MFMA kernel,
     // which first stages its weight images into LDS, takes 38-42 us whatever the batch; from ~7000 walkers on the MFMA
