@@ -61,10 +61,12 @@ def pmc_traffic(kernel_substring="k_mfma<2, 1, 16, 1, false, true>"):
 VQMC_BWD_FLOP_PER_WALKER = 2 * (4 * 2 * 64 * 64 * 4 + 2 * 2 * 32 * 32 * 4)
 VQMC_BWD_SHARE = 0.54   # of the loss + gradient time (profiles/r01h_loss_grad_kernel_stats.csv)
 # Batches >= 16 384 walkers of the two-particle family take the matrix-core gradient path.  Its dominant kernel is the per-net reverse
-# kernel k_ebwd<false> (three launches per call): 288 v_mfma_f32_32x32x16_f16 + 12 v_mfma_f32_32x32x2_f32 per 32-walker tile (disassembly of the
-# linked library), 46 % of the call (profiles/r03_grad_tile_kernel_stats.csv: 3 x 163.6 us of 1 064 us)
-GRAD_TILE_MFMA_FLOP_PER_WALKER_NET = (288 * 32768 + 12 * 4096) / 32
-GRAD_TILE_BWD_SHARE = 0.46
+# kernel k_ebwd<false> (three launches per call): 480 v_mfma_f32_32x32x16_f16 (288 of the sweep itself, 192 of the transposes and weight-gradient
+# products it has formed itself since round 4) + 16 v_mfma_f32_32x32x2_f32 per 32-walker tile (disassembly of the linked library).  Its time is not
+# measured by this line (the C call is one unit): DERIVED from its share of the call in the committed rocprofv3 run, 3 x 201.0 us of 947 us
+# (profiles/r04_grad_tile_kernel_stats.csv, r04_grad_tile_check.txt).
+GRAD_TILE_MFMA_FLOP_PER_WALKER_NET = (480 * 32768 + 16 * 4096) / 32
+GRAD_TILE_BWD_SHARE = 0.637
 GRAD_TILE_MIN = 16384
 # Executed matrix-core work of the other two log_pdf shapes (static MFMA counts of the linked kernels x their trip counts, scratch/isa/isa_stats.py):
 # 33-knot He (k_mfma<2,2,12,1>: two output blocks per net, 2 x 2 blocks of the prior's change of basis): per tile and flow net 24 + 24, prior net
@@ -128,8 +130,8 @@ def kernel_ms(model, x, n=50, warm=150):
 
 
 HPSI_KERNELS = "k_efused (one launch: box + 3 x (conditioner Taylor channels on the matrix cores + head) + prior + H psi)"
-GRAD_KERNELS = ("k_efused<1> (forward, per-net input jets kept) + k_vqmc_seeds + 4 x (k_ebwd<PRIOR> reverse of one net on the matrix cores + k_ewgrad "
-                "weight-gradient products + k_egrad_reduce) + k_egrad_scatter")
+GRAD_KERNELS = ("k_efused<1> (forward, per-net input jets kept) + k_vqmc_seeds + 4 x k_ebwd<PRIOR> (reverse of one net on the matrix cores, weight-gradient "
+                "products included) + k_egrad_reduce + k_egrad_scatter")
 SAMPLE_KERNELS = "k_tsample (one lane per walker: rejection draws, mesh searches) + 4 x k_etile_cond (conditioner of a net on the matrix cores)"
 GRAD_KERNELS_WAVE = "k_wave_fwd<2,RF<2>> + k_energy_out + k_vqmc_seeds + k_wave_bwd<2,RF<2>> + k_wgrad<4> + k_wgrad_reduce + k_grad_gather"
 
@@ -239,11 +241,16 @@ def extra_legs(model, flat):
     model.set_kernel("auto")
     x256 = sorted_uniform(256, 2, 99).cuda()
     out["c2_batch256_us"] = kernel_ms(model, x256, n=200, warm=20) * 1e3
-    # C4: 8-electron chain, 2^18 walkers, seeded parameters
+    # C4 as BASELINE words it ("square-flow antisymmetrised psi", helpers.py:55-58): 8-electron chain, 2^18 UNSORTED walkers, seeded parameters --
+    # wf_psi_antisym_fwd sorts each row and signs psi inside k_mfma; beside it log_pdf of the same walkers sorted on the host (rounds 2 - 3's leg)
     m8 = seeded_model(8, 23, "mfma")
-    x8 = sorted_uniform(1 << 18, 8, 1234).cuda()
-    ms8 = kernel_ms(m8, x8, n=10, warm=3)
-    out["c4_d8_2pow18"] = {"evals_per_s": (1 << 18) / (ms8 * 1e-3), "kernel_ms": ms8, "kernel": "k_mfma<8,1,8,1>",
+    g8 = torch.Generator().manual_seed(1234)
+    x8u = ((torch.rand(1 << 18, 8, generator=g8) * 2 - 1) * 10.0).cuda().contiguous()
+    ms8 = event_ms(lambda: m8.psi_antisym(x8u), 10, 3)
+    x8 = torch.sort(x8u, dim=-1).values.contiguous()
+    ms8s = kernel_ms(m8, x8, n=10, warm=3)
+    out["c4_d8_2pow18"] = {"evals_per_s": (1 << 18) / (ms8 * 1e-3), "kernel_ms": ms8, "kernel": "k_mfma<8,1,8,1>", "entry": "wf_psi_antisym_fwd (unsorted walkers)",
+                           "logpdf_of_sorted_walkers_kernel_ms": ms8s,
                            "roofline": mfma_roofline("c4", 1 << 18, ms8, "k_mfma<8,1,8,1>")}
     del m8
     torch.cuda.synchronize()
@@ -394,40 +401,54 @@ def main():
     B = args.batch
     x_host = walkers(B, 1234 + rank)
     x = x_host.to(dev)
-    lp = torch.empty(B, device=dev, dtype=torch.float32)
+    # two log_pdf buffers: the fp64 block sums of step i (and its all-reduce) run on a second stream while the kernel of step i + 1 fills the other one
+    lp = [torch.empty(B, device=dev, dtype=torch.float32) for _ in range(2)]
 
     from waveflow_amd import _lib
     import ctypes
     L = _lib.lib()
-    ws = torch.empty(int(L.wf_block_sums_workspace_bytes(B)), device=dev, dtype=torch.uint8)
+    ws = [torch.empty(int(L.wf_block_sums_workspace_bytes(B)), device=dev, dtype=torch.uint8) for _ in range(2)]
     # one [sum, sum^2, n] triple per step: the all-reduce of step i runs on RCCL's stream while step i+1 computes
     sums_all = torch.zeros(args.steps + args.warmup + 2, 3, device=dev, dtype=torch.float64)
     pending = []
     n_done = [0]
     stream = torch.cuda.current_stream(dev)
-    sp = ctypes.c_void_p(stream.cuda_stream)
+    side = torch.cuda.Stream(device=dev)
+    sp, sp2 = ctypes.c_void_p(stream.cuda_stream), ctypes.c_void_p(side.cuda_stream)
     P = lambda t: ctypes.c_void_p(t.data_ptr())
+    filled = [torch.cuda.Event() for _ in range(2)]     # log_pdf of the buffer written (launch stream)
+    summed = [torch.cuda.Event() for _ in range(2)]     # its block sums done (side stream): the buffer may be overwritten
+    for e in summed:
+        e.record(side)
 
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
     def step(i=None, collective=True):
+        k = n_done[0] & 1
+        stream.wait_event(summed[k])
         if i is not None:
             ev0[i].record(stream)
-        _lib.check(L.wf_logpdf_fwd(model._h, P(x), B, P(lp), None, None, sp), "wf_logpdf_fwd")
+        _lib.check(L.wf_logpdf_fwd(model._h, P(x), B, P(lp[k]), None, None, sp), "wf_logpdf_fwd")
         if i is not None:
             ev1[i].record(stream)
+        filled[k].record(stream)
         sums = sums_all[n_done[0] % sums_all.shape[0]]
         n_done[0] += 1
-        _lib.check(L.wf_block_sums(P(lp), B, P(sums), P(ws), ws.numel(), sp), "wf_block_sums")
+        side.wait_event(filled[k])
+        _lib.check(L.wf_block_sums(P(lp[k]), B, P(sums), P(ws[k]), ws[k].numel(), sp2), "wf_block_sums")
+        summed[k].record(side)
         if use_dist and collective:   # one RCCL all-reduce of 3 doubles per step, asynchronous: completed in fence(), inside the timed region
-            pending.append(dist.all_reduce(sums, op=dist.ReduceOp.SUM, async_op=True))
+            with torch.cuda.stream(side):
+                pending.append(dist.all_reduce(sums, op=dist.ReduceOp.SUM, async_op=True))
             if len(pending) > 32:      # bound the number of outstanding collectives: a stream-side wait on one that finished long ago
-                pending.pop(0).wait()
+                with torch.cuda.stream(side):
+                    pending.pop(0).wait()
 
     def fence():
-        for w in pending:
-            w.wait()
+        with torch.cuda.stream(side):
+            for w in pending:
+                w.wait()
         pending.clear()
         torch.cuda.synchronize(dev)
         if use_dist:
@@ -488,7 +509,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "1D He-like 2e- box L=10 (shipped He checkpoint: 3 IMADE layers k=6/23 knots + B-spline prior), "
-                                   f"log_pdf over {B} sorted U(-L,L)^2 walkers per GPU, + fp64 block sums"
+                                   f"log_pdf over {B} sorted U(-L,L)^2 walkers per GPU, + fp64 block sums (on a second stream: they overlap the next step's kernel; "
+                                   "everything completes inside the timed region)"
                                    + (" + 1 RCCL all-reduce of 3 doubles per step (overlapped with the next step's kernel)" if world > 1 else ""),
                        "walkers_per_gpu": B, "kernel": args.kernel, "mean_logp": mean_logp},
             # bound = the matrix cores: achieved = EXECUTED f16 / f32 MFMA FLOP per second of the dominant kernel, peak = the dense f16
@@ -541,6 +563,7 @@ def main_rqs(args):
         "warmup": args.warmup, "ms_per_step": leg["kernel_ms"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic", "wall_s": dt,
         "config": {"workload": f"unconstrained RQS forward (neural_splines.py:16-71), K=32 bins, {N} elements (2 dims x {args.batch} walkers)"},
+        "value_is": "elements / mean HIP-event kernel time (rounds 1 - 2 of this line reported elements / wall time of the loop: ~5 % lower)",
         "roofline": {"bound": "hbm", "achieved": leg["gb_per_s"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": leg["frac_of_hbm_peak"], "traffic": None,
                      "kernel": "k_rqs_reg<32>", "kernel_ms": leg["kernel_ms"], "bytes_per_eval": leg["bytes_per_element"]}}), flush=True)
 
@@ -655,9 +678,10 @@ def main_vqmc(args):
         ach = B * GRAD_TILE_MFMA_FLOP_PER_WALKER_NET / (k_ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_F16_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F16_MATRIX_TFLOPS, "traffic": None,
                 "kernel": "k_ebwd<false>", "kernel_ms": k_ms,
-                "note": "executed matrix FLOP of one reverse launch (split-fp16 products, three Taylor channels) / its share of the call (46 %, three "
-                        "launches; profiles/r03_grad_tile_kernel_stats.csv); the kernel runs one wave per SIMD and is bound by vector issue and "
-                        "memory waits, not by the matrix pipe (profiles/r03_grad_tile_pmc.txt)"}
+                "kernel_ms_is": "derived: share of the call in profiles/r04_grad_tile_kernel_stats.csv x the call's event time / 3 launches",
+                "note": "executed matrix FLOP of one reverse launch (split-fp16 products, three Taylor channels, the transposes and weight-gradient "
+                        "products) / its share of the call (63.7 %, three launches); the kernel runs one wave per SIMD and is bound by vector issue "
+                        "and register spills, not by the matrix pipe (profiles/r04_grad_tile_pmc.txt)"}
     else:
         ach = B * VQMC_BWD_FLOP_PER_WALKER / (VQMC_BWD_SHARE * step_ms * 1e-3) / 1e12
         roof = {"bound": "valu", "achieved": ach, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MATRIX_TFLOPS, "traffic": None,

@@ -23,7 +23,8 @@ def rel_l2(a, b):
 # Bounds of the gradient comparisons against the fp64 torch oracle (reverse mode through the Hessian trace): 3 x the value measured on an MI355X in
 # round 4 (profiles/r04_grad_rel_l2_measured.txt; rounds 1 - 3 had 5e-3 everywhere, 40 - 300 x the measured values: a wrong small leaf could hide).
 # The key is the line of the assertion in round 3's file, kept as a stable name.
-BOUND = {"L59": 5e-3, "L82": 5e-3, "L87": 5e-3, "L314": 5e-3, "L803": 5e-3, "L871": 5e-3, "L963": 5e-3}
+# measured: L59 1.19e-4 (loss_fn_efficient's gradient: the seeds carry E_L - <E_L>), L82 1.53e-5, L87 1.72e-5, L314 2.02e-5, L803 2.8e-6, L871 3.9e-6, L963 <= 4.9e-6
+BOUND = {"L59": 4e-4, "L82": 5e-5, "L87": 6e-5, "L314": 7e-5, "L803": 1e-5, "L871": 1.2e-5, "L963": 1.5e-5}
 
 
 def rel_ok(got, want, bound, what):

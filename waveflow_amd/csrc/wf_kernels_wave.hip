@@ -1222,11 +1222,11 @@ __global__ __launch_bounds__(kWB) __attribute__((amdgpu_waves_per_eu(WF_OCC_SAMP
                         cj = hdw.c.c0;
                         ymax = col_max(valid ? cj : 0.0f) * (float)(nb + md.psp.degree);   // msplines_jax.py:147-150
                     }
-                    // Rejection sampling, 64 proposals per round: lane t holds proposal number 64 * round + t of the sequence, the
+                    // Rejection sampling, 32 proposals per round (lanes 0..31): lane t holds proposal number 32 * round + t of the sequence, the
                     // first accepted one in sequence order is taken (same distribution as proposing one by one; the acceptance
                     // rate of the reference's bound is 4-6 %, i.e. ~20 sequential table reads per column otherwise).  Each lane
                     // evaluates the whole spline at its own point: the column's coefficients come from LDS, two table rows per lane.
-                    // Bounded (1563 rounds ~ 1e5 proposals): a pathological density cannot hang the GPU; a walker that exhausts
+                    // Bounded (3126 rounds ~ 1e5 proposals): a pathological density cannot hang the GPU; a walker that exhausts
                     // the bound comes out as NaN (its later columns, its x and every batch sum over it), not as a plausible 0.5.
                     put(ov, lane, R1{cj});
                     const float* __restrict__ cw = &ov[0][NBK == 1 ? hd * 32 : 0];
