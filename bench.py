@@ -252,7 +252,22 @@ def extra_legs(model, flat):
     out["c4_d8_2pow18"] = {"evals_per_s": (1 << 18) / (ms8 * 1e-3), "kernel_ms": ms8, "kernel": "k_mfma<8,1,8,1>", "entry": "wf_psi_antisym_fwd (unsorted walkers)",
                            "logpdf_of_sorted_walkers_kernel_ms": ms8s,
                            "roofline": mfma_roofline("c4", 1 << 18, ms8, "k_mfma<8,1,8,1>")}
+    # H psi beyond two particles (SURVEY 8f rank 1 for C4's model and a 4-electron chain; proton positions: an even chain inside the box): the
+    # directional matrix-core path of wf_kernels_etile_dir.hip, and the wave kernel it replaces at these sizes beside it (WF_ENERGY_TILE_MIN=0)
+    def hpsi_leg(model_d, xs, D):
+        pr_d = np.linspace(-7.0, 7.0, D).astype(np.float32)
+        ms_t = event_ms(lambda: model_d.hamiltonian(xs, pr_d), 5, 2)
+        os.environ["WF_ENERGY_TILE_MIN"] = "0"
+        ms_w = event_ms(lambda: model_d.hamiltonian(xs, pr_d), 2, 1)
+        del os.environ["WF_ENERGY_TILE_MIN"]
+        return {"kernels": f"k_edir_box<{D}> + {model_d.n_layers} x k_edir<{D}, false> + k_edir<{D}, true> (one coordinate direction at a time, Taylor triples on the matrix cores)",
+                "ms": ms_t, "walkers": int(xs.shape[0]), "walkers_per_s": xs.shape[0] / (ms_t * 1e-3), "wave_kernel_ms": ms_w,
+                "wave_kernel_walkers_per_s": xs.shape[0] / (ms_w * 1e-3)}
+    out["hpsi_c4_2pow18"] = hpsi_leg(m8, x8, 8)
     del m8
+    m4 = seeded_model(4, 23, "auto")
+    out["hpsi_d4_2pow18"] = hpsi_leg(m4, sorted_uniform(1 << 18, 4, 1234).cuda(), 4)
+    del m4
     torch.cuda.synchronize()
     # the secondary paths, so that the driver's record carries them (each reproducible from a file under profiles/)
     model.set_kernel("auto")
@@ -401,54 +416,43 @@ def main():
     B = args.batch
     x_host = walkers(B, 1234 + rank)
     x = x_host.to(dev)
-    # two log_pdf buffers: the fp64 block sums of step i (and its all-reduce) run on a second stream while the kernel of step i + 1 fills the other one
-    lp = [torch.empty(B, device=dev, dtype=torch.float32) for _ in range(2)]
+    lp = torch.empty(B, device=dev, dtype=torch.float32)
 
     from waveflow_amd import _lib
     import ctypes
     L = _lib.lib()
-    ws = [torch.empty(int(L.wf_block_sums_workspace_bytes(B)), device=dev, dtype=torch.uint8) for _ in range(2)]
+    ws = torch.empty(int(L.wf_block_sums_workspace_bytes(B)), device=dev, dtype=torch.uint8)
     # one [sum, sum^2, n] triple per step: the all-reduce of step i runs on RCCL's stream while step i+1 computes
     sums_all = torch.zeros(args.steps + args.warmup + 2, 3, device=dev, dtype=torch.float64)
     pending = []
     n_done = [0]
     stream = torch.cuda.current_stream(dev)
-    side = torch.cuda.Stream(device=dev)
-    sp, sp2 = ctypes.c_void_p(stream.cuda_stream), ctypes.c_void_p(side.cuda_stream)
+    sp = ctypes.c_void_p(stream.cuda_stream)
     P = lambda t: ctypes.c_void_p(t.data_ptr())
-    filled = [torch.cuda.Event() for _ in range(2)]     # log_pdf of the buffer written (launch stream)
-    summed = [torch.cuda.Event() for _ in range(2)]     # its block sums done (side stream): the buffer may be overwritten
-    for e in summed:
-        e.record(side)
 
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
+    # (Round 4 tried the block sums of step i on a second stream under the kernel of step i + 1: the persistent workgroups of k_mfma leave the sums'
+    # blocks no room before they drain -- the sums' launches took 35 - 160 us each and the step time did not move, 0.3055 against 0.3011 ms:
+    # profiles/r04_two_stream_attempt_kernel_stats.csv.  One stream.)
     def step(i=None, collective=True):
-        k = n_done[0] & 1
-        stream.wait_event(summed[k])
         if i is not None:
             ev0[i].record(stream)
-        _lib.check(L.wf_logpdf_fwd(model._h, P(x), B, P(lp[k]), None, None, sp), "wf_logpdf_fwd")
+        _lib.check(L.wf_logpdf_fwd(model._h, P(x), B, P(lp), None, None, sp), "wf_logpdf_fwd")
         if i is not None:
             ev1[i].record(stream)
-        filled[k].record(stream)
         sums = sums_all[n_done[0] % sums_all.shape[0]]
         n_done[0] += 1
-        side.wait_event(filled[k])
-        _lib.check(L.wf_block_sums(P(lp[k]), B, P(sums), P(ws[k]), ws[k].numel(), sp2), "wf_block_sums")
-        summed[k].record(side)
+        _lib.check(L.wf_block_sums(P(lp), B, P(sums), P(ws), ws.numel(), sp), "wf_block_sums")
         if use_dist and collective:   # one RCCL all-reduce of 3 doubles per step, asynchronous: completed in fence(), inside the timed region
-            with torch.cuda.stream(side):
-                pending.append(dist.all_reduce(sums, op=dist.ReduceOp.SUM, async_op=True))
+            pending.append(dist.all_reduce(sums, op=dist.ReduceOp.SUM, async_op=True))
             if len(pending) > 32:      # bound the number of outstanding collectives: a stream-side wait on one that finished long ago
-                with torch.cuda.stream(side):
-                    pending.pop(0).wait()
+                pending.pop(0).wait()
 
     def fence():
-        with torch.cuda.stream(side):
-            for w in pending:
-                w.wait()
+        for w in pending:
+            w.wait()
         pending.clear()
         torch.cuda.synchronize(dev)
         if use_dist:
@@ -509,8 +513,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "1D He-like 2e- box L=10 (shipped He checkpoint: 3 IMADE layers k=6/23 knots + B-spline prior), "
-                                   f"log_pdf over {B} sorted U(-L,L)^2 walkers per GPU, + fp64 block sums (on a second stream: they overlap the next step's kernel; "
-                                   "everything completes inside the timed region)"
+                                   f"log_pdf over {B} sorted U(-L,L)^2 walkers per GPU, + fp64 block sums"
                                    + (" + 1 RCCL all-reduce of 3 doubles per step (overlapped with the next step's kernel)" if world > 1 else ""),
                        "walkers_per_gpu": B, "kernel": args.kernel, "mean_logp": mean_logp},
             # bound = the matrix cores: achieved = EXECUTED f16 / f32 MFMA FLOP per second of the dominant kernel, peak = the dense f16

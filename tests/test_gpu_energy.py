@@ -241,3 +241,49 @@ def test_local_energy_tile_path_other_models(monkeypatch):
     x = sorted_walkers(512, 2, 1.9, 3)
     (hp, _, _), (hw, _, _) = _tile_and_wave(m, x, [0.0, 0.0], monkeypatch)
     assert np.array_equal(hp, hw)
+
+
+@pytest.mark.parametrize("D", [3, 4, 8])
+def test_local_energy_on_the_matrix_cores_beyond_two_particles(D, monkeypatch):
+    """wf_hamiltonian_fwd of large batches of D-particle models: one coordinate direction at a time, Taylor triples on the matrix
+    cores (wf_kernels_etile_dir.hip).  Against the fp64 torch oracle with the yardstick of the two-particle test (3 x the fp32 torch oracle's own
+    deviation); against the wave kernel on a ragged batch up to the box edge; the switch; launch-to-launch bits."""
+    import torch
+    from oracle import energy_torch as et
+    from waveflow_amd import flatten_params, model_factory
+    init_fun = model_factory.get_waveflow_model(D, base_spline_degree=6, i_spline_degree=6, n_prior_internal_knots=23,
+                                                n_i_internal_knots=23, i_spline_reg=0.05, n_flow_layers=2 if D < 8 else 3, box_size=10.0)
+    params, psi, log_pdf, sample = init_fun(11, D)
+    m = psi.model
+    m.ensure_params(params)
+    flat = flatten_params(params)
+    protons = np.linspace(-3, 3, D)
+    n_layers = 2 if D < 8 else 3
+    x = sorted_walkers(300 if D < 8 else 120, D, 9.5, 3).astype(np.float32)
+    (hp, ps, lap), (hw, pw, lw) = _tile_and_wave(m, x, protons, monkeypatch)
+    assert not np.array_equal(lap, lw)                                  # the forced path is another kernel
+    mk = lambda dt: et.TorchWaveflow(D, n_layers, "mean", 10.0, 6, 23, 0.05, tuple(range(D - 1)), dtype=dt)
+    ho64, po64, lo64 = et.hamiltonian(mk(torch.float64), flat, x.astype(np.float64), protons)
+    ho32, po32, lo32 = et.hamiltonian(mk(torch.float32), flat, x, protons)
+    np.testing.assert_allclose(ps, po64, rtol=0, atol=3e-5 * np.abs(po64).max() + 3 * np.abs(po32 - po64).max())
+    scale = np.abs(lo64).max()
+    e_g, e_o = np.abs(lap - lo64), np.abs(lo32 - lo64)
+    print(f"[hpsi D={D}] laplacian vs fp64 torch oracle: tile max {e_g.max():.2e} median {np.median(e_g):.2e}; fp32 torch oracle max {e_o.max():.2e} median "
+          f"{np.median(e_o):.2e}; wave kernel max {np.abs(lw - lo64).max():.2e}; scale {scale:.2e}")
+    assert np.median(e_g) <= 3 * np.median(e_o) + 1e-6 * scale, (np.median(e_g), np.median(e_o))
+    assert e_g.max() <= 3 * e_o.max() + 2e-5 * scale, (e_g.max(), e_o.max(), scale)
+    np.testing.assert_allclose(hp, ho64, rtol=0, atol=3 * np.abs(ho32 - ho64).max() + 2e-5 * np.abs(ho64).max())
+    # a ragged batch, walkers up to the box edge (clipped prior arguments included): against the wave kernel
+    xb = sorted_walkers(20001, D, 10.0, 21)
+    (hp, ps, lap), (hw, pw, lw) = _tile_and_wave(m, xb, protons, monkeypatch)
+    assert np.isfinite(hp).all()
+    for a, b in ((ps, pw), (lap, lw), (hp, hw)):
+        d = np.abs(a - b)
+        assert d.max() <= 5e-4 * np.abs(b).max() and np.median(d) <= 1e-6 * np.abs(b).max(), (D, d.max() / np.abs(b).max(), np.median(d) / np.abs(b).max())
+    # default switch: 20 001 walkers take the tile path (same numbers as forcing it), 5 000 the wave kernel
+    assert np.array_equal(np.asarray(m.hamiltonian(xb, protons), dtype=np.float64), hp)
+    assert np.array_equal(np.asarray(m.hamiltonian(xb[:5000], protons), dtype=np.float64), hw[:5000])
+    xt = torch.as_tensor(xb).cuda()
+    first = m.hamiltonian(xt, protons).clone()
+    for _ in range(4):
+        assert torch.equal(m.hamiltonian(xt, protons), first)

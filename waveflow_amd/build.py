@@ -11,7 +11,7 @@ OBJ = os.path.join(CSRC, "_obj")
 
 SOURCES = ["wf_tables.cpp", "wf_model.cpp", "wf_kernels_scalar.hip", "wf_scalar_inst_d2.hip", "wf_scalar_inst_d3.hip", "wf_scalar_inst_d4.hip", "wf_scalar_inst_d56.hip",
            "wf_scalar_inst_d78.hip", "wf_scalar_inst_n64.hip", "wf_kernels_mfma.hip", "wf_mfma_inst_d2.hip", "wf_mfma_inst_d2t2.hip", "wf_mfma_inst_d34.hip",
-           "wf_mfma_inst_d567.hip", "wf_mfma_inst_d8.hip", "wf_mfma_inst_k2.hip", "wf_kernels_rqs.hip", "wf_kernels_grad.hip", "wf_kernels_wave.hip", "wf_kernels_etile.hip"]
+           "wf_mfma_inst_d567.hip", "wf_mfma_inst_d8.hip", "wf_mfma_inst_k2.hip", "wf_kernels_rqs.hip", "wf_kernels_grad.hip", "wf_kernels_wave.hip", "wf_kernels_etile.hip", "wf_kernels_etile_dir.hip"]
 # -ffp-contract=off: the index arithmetic and the table lerp keep the reference's separate
 # multiply / add roundings; dot products that may fuse say so with explicit fmaf / MFMA.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
@@ -39,6 +39,8 @@ def _deps(src):
     d = [os.path.join(CSRC, src), os.path.join(CSRC, "wf_internal.h"), os.path.join(HERE, "..", "include", "waveflow_hip.h")]
     if "mfma" in src or "etile" in src:
         d.append(os.path.join(CSRC, "wf_mfma_impl.h"))
+    if "etile" in src:
+        d += [os.path.join(CSRC, "wf_etile_common.h"), os.path.join(CSRC, "wf_etile_adjoint.h")]
     if "grad" in src or "wave" in src:
         d.append(os.path.join(CSRC, "wf_ring.h"))
     if "scalar" in src or "wave" in src or "rqs" in src:   # (the wave sampler shares Philox and the box reverse with the one-lane kernels)

@@ -1665,6 +1665,27 @@ int wf_hamiltonian_fwd(const wf_model* m, const float* x_dev, int64_t B, const f
             return WF_OK;
         }
     }
+    // Large batches beyond two particles: one coordinate direction at a time with Taylor triples on the matrix cores (wf_kernels_etile_dir.hip), the same
+    // switch point and knobs as the two-particle tile path
+    {
+        const char* e = getenv("WF_ENERGY_TILE_MIN");
+        const int64_t tile_min = e ? atoll(e) : kEnergyTileMin;
+        const wf_model_desc& d = m->desc;
+        const bool family = D >= 3 && m->nbp == 32 && m->mfma_ok && d.box_kind == WF_BOX_MEAN && d.layer_kind == WF_LAYER_IMADE && d.n_flow_layers > 0 && !m->dev.i_gate &&
+                            !m->dev.p_gate && m->d_tabI4c && m->d_tabP4c && energy_dir_capable(&m->mdev) && !getenv("WF_ENERGY_R3");
+        if (family && tile_min > 0 && B >= tile_min && !m->eval_tables_stale && !f16_overflow(m)) {
+            const int64_t dchunk = std::min<int64_t>(B, (int64_t)1 << 18);   // 12 D (D + 1) bytes of jets per walker: 226 MB at D = 8
+            rc = ensure_scratch(m, energy_dir_floats(dchunk, D));
+            if (rc) return rc;
+            for (int64_t c0 = 0; c0 < B; c0 += dchunk) {
+                const int64_t bc = std::min(dchunk, B - c0);
+                rc = launch_energy_dir(&m->mdev, m->dev, m->d_tabI4c, m->d_tabP4c, x_dev + c0 * D, bc, pr, hpsi_dev + c0, psi_dev ? psi_dev + c0 : nullptr,
+                                       laplacian_dev ? laplacian_dev + c0 : nullptr, m->d_scratch, stream);
+                if (rc) return rc;
+            }
+            return WF_OK;
+        }
+    }
     rc = ensure_scratch(m, chunk * wave_tail_floats(D, 1));
     if (rc) return rc;
     for (int64_t c0 = 0; c0 < B; c0 += chunk) {
