@@ -45,6 +45,9 @@ WF_MFMA_EXTERN(3, 1, 8, 1); WF_MFMA_EXTERN(4, 1, 8, 1); WF_MFMA_EXTERN(8, 1, 8, 
 WF_MFMA_EXTERN(5, 1, 8, 1); WF_MFMA_EXTERN(6, 1, 8, 1); WF_MFMA_EXTERN(7, 1, 8, 1);
 WF_MFMA_EXTERN(2, 2, 8, 1); WF_MFMA_EXTERN(3, 2, 8, 1); WF_MFMA_EXTERN(4, 2, 8, 1);
 WF_MFMA_EXTERN(2, 2, 12, 1); WF_MFMA_EXTERN(2, 2, 16, 1);
+#ifdef WF_D8_WAVES_ALL
+WF_MFMA_EXTERN(8, 1, 12, 1); WF_MFMA_EXTERN(8, 1, 16, 1);
+#endif
 #undef WF_MFMA_EXTERN
 }  // namespace mfma
 
@@ -303,7 +306,12 @@ int launch_mfma(int D, int nbk, const MfmaDev* mdev, int lds_bytes, int mode, co
             case 5: GO(5, 1, 8);
             case 6: GO(6, 1, 8);
             case 7: GO(7, 1, 8);
-            case 8: GO(8, 1, 8);   // (16 waves: 0.62 ms against 0.45 ms at 2^18 walkers -- register spills)
+            case 8:
+#ifdef WF_D8_WAVES_ALL
+                if (waves_per_group(1, 1) == 12 && getenv("WF_MFMA_WAVES")) GO(8, 1, 12);
+                if (waves_per_group(1, 1) == 16 && getenv("WF_MFMA_WAVES")) GO(8, 1, 16);
+#endif
+                GO(8, 1, 8);   // (16 waves: 0.62 ms against 0.45 ms at 2^18 walkers -- register spills)
             default: return WF_ERR_UNSUPPORTED;
         }
     }

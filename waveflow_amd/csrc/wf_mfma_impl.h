@@ -13,6 +13,16 @@
 
 #include "wf_internal.h"
 
+// the loops over a net's output dimensions: unrolled (kDimUnroll<D> = D).  -DWF_D8_ROLLED (experiment, round 4) rolls them for the long chains (D > 4):
+// no spilled registers at 8 waves instead of 10, 75 / 207 at 12 / 16 waves instead of 172 / 346 -- and 2 - 5 % SLOWER at 8 waves (D = 8, 2^18 walkers:
+// 0.319 against 0.314 ms), 12 and 16 waves slower still (0.365 / 0.472 ms): profiles/r04_c4_rolled_loops_and_waves.txt.  Same bits either way.
+template <int D>
+#ifdef WF_D8_ROLLED
+constexpr int kDimUnroll = D > 4 ? 1 : D;
+#else
+constexpr int kDimUnroll = D;
+#endif
+
 // WF_PIN(): keeps the hand-written order of [MFMA K step | activation of another block] units (hidden_layers, out_block_first): the
 // scheduler is free inside a unit, not across units.
 #ifdef WF_NO_PIN
@@ -765,7 +775,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
                 float gl[T];   // gate of dimension d: prod_{i<d} (layer input)_i^3
 #pragma unroll
                 for (int t = 0; t < T; ++t) gl[t] = 1.0f;
-#pragma unroll
+#pragma unroll (kDimUnroll<D>)
                 for (int d = 1; d < D; ++d) {
                     if (D > 4) __builtin_amdgcn_sched_barrier(0);   // long chains: one dimension at a time (the scheduler otherwise keeps the records of several dimensions in flight: 29 -> 218 spilled registers at 12 waves)
                     if (gate_i) {
@@ -853,7 +863,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_mfma(const MfmaDev mm, int mode
                 const bool gate_p = !SPEC && mm.p_gate != 0;   // gated head: prod_{i<d} u_i^3 of the conditioner's input, the unclipped u
 #pragma unroll
                 for (int t = 0; t < T; ++t) { lp[t] = 0.0f; prod[t] = 1.0f; gp[t] = 1.0f; }
-#pragma unroll
+#pragma unroll (kDimUnroll<D>)
                 for (int d = 0; d < D; ++d) {
                     if (D > 4) __builtin_amdgcn_sched_barrier(0);
                     if (gate_p && d > 0) {
