@@ -199,6 +199,7 @@ def vqmc_legs(model, n_h=20, n_g=10):
     ms_g = event_ms(lambda: model.vqmc_loss_grad(xg, protons, -1.8), n_g, 3)
     m33 = seeded_model(2, 33, "auto")   # BASELINE's "32-bin" variant: two 32-row blocks per dimension (k_efused<2>)
     ms_h33 = event_ms(lambda: m33.hamiltonian(xb, protons), 10, 5)
+    ms_g33 = event_ms(lambda: m33.vqmc_loss_grad(xg, protons, -1.8), n_g, 3)   # (round 4: k_ebwd<., 2>; the wave sweeps took 8.1 ms)
     del m33
     # the sampler (walkers ~ |psi|^2: prior columns by rejection, inverse flow) through the staged large-batch form
     seeds = iter(range(100, 200))
@@ -222,7 +223,9 @@ def vqmc_legs(model, n_h=20, n_g=10):
             **{"hpsi_2pow20": {"kernels": HPSI_KERNELS, "ms": ms_h, "walkers": 1 << 20, "walkers_per_s": (1 << 20) / (ms_h * 1e-3)},
             "hpsi_33knot_2pow20": {"kernels": "k_efused<2>", "ms": ms_h33, "walkers": 1 << 20, "walkers_per_s": (1 << 20) / (ms_h33 * 1e-3)},
             "loss_grad_2pow17": {"kernels": GRAD_KERNELS, "ms": ms_g, "walkers": 1 << 17,
-                                 "walkers_per_s": (1 << 17) / (ms_g * 1e-3)}}}
+                                 "walkers_per_s": (1 << 17) / (ms_g * 1e-3)},
+            "loss_grad_33knot_2pow17": {"kernels": "k_efused<2> + k_ebwd<., 2> per net + k_egrad_reduce", "ms": ms_g33, "walkers": 1 << 17,
+                                        "walkers_per_s": (1 << 17) / (ms_g33 * 1e-3)}}}
 
 
 def extra_legs(model, flat):

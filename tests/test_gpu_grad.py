@@ -132,6 +132,55 @@ def test_gradients_on_the_matrix_cores_vs_oracle_and_wave_sweeps(golden, he_flat
     assert rel_l2(gt.cpu().numpy(), gw.cpu().numpy()) < 2e-3, rel_l2(gt.cpu().numpy(), gw.cpu().numpy())
 
 
+@pytest.mark.gpu
+def test_gradients_on_the_matrix_cores_with_two_row_blocks_vs_autograd_oracle(monkeypatch):
+    """The 33-knot ("32-bin") variant of C3 -- 39 / 38 bases per dimension, two 32-row blocks of every head -- through the matrix-core gradient
+    path (k_ebwd<., 2>; round 3 left it to the wave sweeps: 8.1 ms per 2^17 walkers): psi / Laplacian weights and value_and_grad(loss_fn_efficient)
+    (vqmc.py:193-221) forced on a small ragged batch against the torch autograd oracle (fp64), a large ragged batch against the wave sweeps, the
+    default switch, bitwise reproducibility (the workgroup's shared accumulators take the tiles in a fixed order)."""
+    import torch
+    from oracle import energy_torch as et
+    from waveflow_amd import flatten_params, model_factory
+    init_fun = model_factory.get_waveflow_model(2, base_spline_degree=6, i_spline_degree=6, n_prior_internal_knots=33, n_i_internal_knots=33,
+                                                i_spline_reg=0.05, n_flow_layers=3, box_size=10.0)
+    params, psi, log_pdf, sample = init_fun(3, 2)
+    m = psi.model
+    m.ensure_params(params)
+    flat = flatten_params(params)
+    mo = et.TorchWaveflow(2, 3, "mean", 10.0, 6, 33, 0.05, (0,), dtype=torch.float64)
+    x = sorted_walkers(171, 2, 9.0, 21)
+    g = np.random.default_rng(8)
+    wp, wl = g.normal(size=171).astype(np.float32), (0.1 * g.normal(size=171)).astype(np.float32)
+    want = et.psi_vjp(mo, flat, x.astype(np.float64), wp, wl)
+    monkeypatch.setenv("WF_GRAD_TILE_MIN", "1")
+    got = m.psi_vjp(x, wp, wl).cpu().numpy().astype(np.float64)
+    monkeypatch.setenv("WF_GRAD_TILE_MIN", "0")
+    got_w = m.psi_vjp(x, wp, wl).cpu().numpy().astype(np.float64)
+    assert not np.array_equal(got, got_w)                      # the forced small batch did take the matrix-core path
+    # against the fp64 oracle the seeded 33-knot model sits at 2.4e-3 on EITHER fp32 path (the bound of test_gradients_other_shapes_vs_autograd_oracle);
+    # the two paths agree leaf by leaf to 2.4e-6 (scratch/r04_grad33_diag.py)
+    assert rel_l2(got, want) < 3e-3, rel_l2(got, want)
+    assert rel_l2(got_w, want) < 3e-3, rel_l2(got_w, want)
+    assert rel_l2(got, got_w) < 5e-5, rel_l2(got, got_w)
+    protons = np.array([0.0, 0.0])
+    monkeypatch.setenv("WF_GRAD_TILE_MIN", "1")
+    sums, grad = m.vqmc_loss_grad(x, protons, running_average=-2.5)
+    lo, go, elo = et.vqmc_loss_grad(mo, flat, x.astype(np.float64), protons, -2.5)
+    s = sums.cpu().numpy()
+    assert abs(s[0] / s[2] - lo) < 1e-3 * max(1.0, np.abs(elo).mean())
+    assert rel_l2(grad.cpu().numpy().astype(np.float64), go) < 3e-3, rel_l2(grad.cpu().numpy().astype(np.float64), go)
+    xb = torch.as_tensor(sorted_walkers(50001, 2, 9.5, 7)).cuda()
+    wb1 = torch.as_tensor(g.normal(size=50001).astype(np.float32)).cuda()
+    wb2 = torch.as_tensor((0.1 * g.normal(size=50001)).astype(np.float32)).cuda()
+    tile = m.psi_vjp(xb, wb1, wb2)
+    assert torch.equal(tile, m.psi_vjp(xb, wb1, wb2))
+    monkeypatch.setenv("WF_GRAD_TILE_MIN", "0")
+    wave = m.psi_vjp(xb, wb1, wb2)
+    monkeypatch.delenv("WF_GRAD_TILE_MIN")
+    assert torch.equal(m.psi_vjp(xb, wb1, wb2), tile)           # default switch: 50 001 walkers take the matrix-core path
+    assert rel_l2(tile.cpu().numpy(), wave.cpu().numpy()) < 2e-4 and not torch.equal(tile, wave)
+
+
 def _leaves(tree):
     if isinstance(tree, (tuple, list)):
         return [a for t in tree for a in _leaves(t)]
@@ -142,8 +191,8 @@ def _leaves(tree):
 def test_gradient_tile_path_other_models(monkeypatch):
     """The matrix-core gradient path on models the He checkpoint does not exercise (derivative boundary constraints, one and two layers, other
     boxes, degrees and knot counts), forced on 4 097 walkers against the reverse wave sweeps -- overall and LEAF BY LEAF (a wrong small leaf
-    would hide behind the large ones), a non-zero boundary value on the prior included; models outside its family (two row blocks per dimension,
-    first-type box) keep the wave sweeps bit for bit."""
+    would hide behind the large ones), a non-zero boundary value on the prior included, and since round 4 the models with two row blocks per
+    dimension (33 .. 64 bases: the 33-knot "32-bin" variant of C3); models outside its family (first-type box) keep the wave sweeps bit for bit."""
     import torch
     from waveflow_amd import checkpoint, flows, model_factory, wavefunctions
     mt = model_factory.get_masked_transform
@@ -152,8 +201,10 @@ def test_gradient_tile_path_other_models(monkeypatch):
         dict(L=3.0, n=2, k=6, kn=23, il=il, ir=ir, pl=pl, pr=pr, family=True),
         dict(L=2.0, n=1, k=5, kn=16, il={0: 0.0}, ir={0: 1.0}, pl={0: 0}, pr={0: 0}, family=True),
         dict(L=6.0, n=3, k=3, kn=10, il={0: 0.0}, ir={0: 1.0}, pl={0: 0}, pr={0: 0}, family=True),
-        dict(L=10.0, n=3, k=6, kn=33, il={0: 0.0}, ir={0: 1.0}, pl={0: 0}, pr={0: 0}, family=False),     # 39 / 38 bases: two row blocks
+        dict(L=10.0, n=3, k=6, kn=33, il={0: 0.0}, ir={0: 1.0}, pl={0: 0}, pr={0: 0}, family=True),      # 39 / 38 bases: two row blocks per dimension (round 4)
         dict(L=3.0, n=1, k=5, kn=16, il={0: 0.0}, ir={0: 1.0}, pl={0: 0.3}, pr={0: 0}, family=True),      # boundary value 0.3 on the prior (constant term)
+        dict(L=3.0, n=2, k=5, kn=40, il=il, ir=ir, pl={0: 0.3, 2: 0}, pr=pr, family=True),                # two row blocks, derivative constraints, constant term
+        dict(L=4.0, n=1, k=3, kn=58, il={0: 0.0}, ir={0: 1.0}, pl={0: 0}, pr={0: 0}, family=True),        # 61 / 60 bases: the second row block nearly full
     ]
     g = np.random.default_rng(17)
     for c in cases:

@@ -161,12 +161,12 @@ int launch_energy_dir(const MfmaDev* mdev, const ModelDev& md, const float* tabI
 // parameter gradients of psi and its Laplacian on the matrix cores (two-particle family, <= 32 bases; wf_kernels_etile.hip: k_ebwd, k_ewgrad)
 bool energy_vjp_capable(const MfmaDev* mdev);
 int64_t energy_vjp_floats_per_walker(int n_nets);
-int64_t energy_vjp_fixed_floats(int n_nets);
-int energy_vjp_gacc_floats(int n_nets);
+int64_t energy_vjp_fixed_floats(int n_nets, int nbk);
+int energy_vjp_gacc_floats(int n_nets, int nbk);
 int launch_energy_vjp(const MfmaDev* mdev, const ModelDev& md, const float* tabI4, const float* tabP4, const float* x, int64_t B, int mode, const float* w_psi,
                       const float* w_lap, const Protons& pr, float running_avg, const float* running_avg_dev, float inv_count, float* e_loc, float* ws,
                       float* gacc, int accumulate, void* stream);
-int launch_energy_vjp_finish(const float* gacc, int n_nets, const int* offs, const float* c2, float* flat, int64_t n_params, void* stream);   // the one-kernel form applies (nets resident in LDS; WF_ENERGY_FUSED=0 switches it off per call)
+int launch_energy_vjp_finish(const float* gacc, int n_nets, int nbk, const int* offs, const float* c2, float* flat, int64_t n_params, void* stream);   // the one-kernel form applies (nets resident in LDS; WF_ENERGY_FUSED=0 switches it off per call)
 int launch_energy_tile(const MfmaDev* mdev, const ModelDev& md, const float* tabI4, const float* tabP4, const float* fk_nat, const float* x, int64_t B,
                        const Protons& pr, float* hpsi, float* psi, float* lap, float* ws, void* stream, float* st_out = nullptr);
 // The sweeps run over a coefficient ring (wf_ring.h).  kind 0: R1 (first order); 1: R3 (one sample per walker and direction,

@@ -557,13 +557,18 @@ using TA = adj::T2t<float>;
 #define WF_BWD_WAVES 4
 #endif
 constexpr int kBwdWaves = WF_BWD_WAVES;
-// Gradient block of a net (floats, in the units of the MFMA image):
-//   GW0 [64] (d / d W0'[0][u]), Gb0 [64], GW1 [64][64] (k, u), Gb1 [64], GW2 [64][32] (k, row), Gb2 of dimension 1 [32], of dimension 0 [32]
-constexpr int kGW0 = 0, kGb0 = 64, kGW1 = 128, kGb1 = 4224, kGW2 = 4288, kGb21 = 6336, kGb20 = 6368, kGFloats = 6400;
+// Gradient block of a net (floats, in the units of the MFMA image; NBK = 32-row blocks of the head per dimension):
+//   GW0 [64] (d / d W0'[0][u]), Gb0 [64], GW1 [64][64] (k, u), Gb1 [64], GW2 [64][32 NBK] (k, row), Gb2 of dimension 1 [32 NBK], of dimension 0 [32 NBK]
+template <int NBK>
+struct GL {
+    static constexpr int W0 = 0, b0 = 64, W1 = 128, b1 = 4224, W2 = 4288, b21 = W2 + 2048 * NBK, b20 = b21 + 32 * NBK, floats = b20 + 32 * NBK;
+};
+constexpr int g_floats(int nbk) { return 4288 + 2048 * nbk + 64 * nbk; }
+static_assert(GL<1>::floats == g_floats(1) && GL<2>::floats == g_floats(2), "gradient block layout");
 constexpr int kESplit = 256;        // partial blocks per net: one per workgroup of k_ebwd (grid <= 256), summed in block order by k_egrad_reduce
-// LDS accumulators of one wave: blocks 0..3 = dW1 (k block mb = b >> 1, u block nb = b & 1), 4..5 = dW2 (k block b - 4), each [4 q][64 lanes][4]
-// (register 4 q + e of the lane: one conflict-free ds_read_b128 per q)
-constexpr int kAccBlocks = 6, kAccFloats = kAccBlocks * 1024;
+// LDS accumulators of a workgroup: blocks 0..3 = dW1 (k block mb = b >> 1, u block nb = b & 1), 4.. = dW2 (k block (b - 4) / NBK, row block (b - 4) % NBK),
+// each [4 q][64 lanes][4] (register 4 q + e of the lane: one conflict-free ds_read_b128 per q)
+constexpr int acc_blocks(int nbk) { return 4 + 2 * nbk; }
 __device__ __forceinline__ int acc_rho(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }   // row of register r in lane half h (accumulator layout)
 __device__ __forceinline__ f32x16 acc_load(const float* aw, int b, int lane) {
     f32x16 a;
@@ -676,6 +681,29 @@ __device__ __forceinline__ void to_frags_all(const f32x16 (&blk0)[NCH], const f3
             }
     }
 }
+// the NBK row blocks of the adjoint head triples -> fragments [channel][row block] (the K steps of the product with W2'), one power of two per (tile, channel)
+template <int NBK>
+__device__ __forceinline__ void to_frags_kb(const f32x16 (&blk)[NBK][NCH], Frag (&f)[NCH][2], int (&e)[NCH]) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        float amax = 0.0f;
+#pragma unroll
+        for (int kb = 0; kb < NBK; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) amax = fmaxf(amax, fabsf(blk[kb][c][r]));
+        e[c] = exponent_of(wave_max(amax));
+        const float sc = __builtin_amdgcn_ldexpf(1.0f, -e[c]);
+#pragma unroll
+        for (int kb = 0; kb < NBK; ++kb)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float r8[8];
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) r8[jj] = blk[kb][c][8 * s + jj] * sc;
+                split8(r8, f[c][kb].hi[s], f[c][kb].lo[s]);
+            }
+    }
+}
 __device__ __forceinline__ void unscale_all(f32x16 (&acc)[NCH], const int (&e)[NCH]) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -695,12 +723,12 @@ __device__ __forceinline__ void act_block_bwd(const f32x16 (&x)[NCH], f32x16 (&g
 }
 // extended row sums of a flow head over the lane's 16 rows (dimension 1: triples from the conditioner; CONST: dimension 0, (bias, 0, 0))
 template <bool CONST>
-__device__ __forceinline__ void flow_rows_ext(adj::FlowSumsT<float>& a, const f32x16 (&o)[NCH], const f32x16& g16, const float* __restrict__ tabI, const int* bnd,
-                                              const LerpN& L, int h) {
+__device__ __forceinline__ void flow_rows_ext(adj::FlowSumsT<float>& a, const f32x16 (&o)[NCH], const f32x16& g16, const float* __restrict__ tabI, int mesh_stride,
+                                              const int* bnd, const LerpN& L, int kb, int h) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         float4_t ta[4], tb[4];
-        chunk_rows<4>(tabI, 128, bnd, L, 2 * q + h, ta, tb);
+        chunk_rows<4>(tabI, mesh_stride, bnd, L, 8 * kb + 2 * q + h, ta, tb);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int r = 4 * q + e;
@@ -734,11 +762,11 @@ __device__ __forceinline__ void flow_sums_xhalf(adj::FlowSumsT<float>& a) {
 // adjoint head triples of the lane's rows from the adjoints of the row sums (ab: summed over the halves already, the same in both)
 template <bool CONST>
 __device__ __forceinline__ void flow_rows_bwd(const adj::FlowSumsT<float>& ab, const f32x16 (&o)[NCH], const f32x16& g16, const float* __restrict__ tabI,
-                                              const int* bnd, const LerpN& L, int h, f32x16 (&ob)[NCH]) {
+                                              int mesh_stride, const int* bnd, const LerpN& L, int kb, int h, f32x16 (&ob)[NCH]) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         float4_t ta[4], tb[4];
-        chunk_rows<4>(tabI, 128, bnd, L, 2 * q + h, ta, tb);
+        chunk_rows<4>(tabI, mesh_stride, bnd, L, 8 * kb + 2 * q + h, ta, tb);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int r = 4 * q + e;
@@ -768,11 +796,12 @@ __device__ __forceinline__ void flow_rows_bwd(const adj::FlowSumsT<float>& ab, c
 }
 // the prior's rows: extended sums from the triples of c (CONST: channel 0 only), and back
 template <bool CONST>
-__device__ __forceinline__ void prior_rows_ext(adj::PriorSumsT<float>& a, const f32x16 (&c)[NCH], const float* __restrict__ tabP, const int* bnd, const LerpN& L, int h) {
+__device__ __forceinline__ void prior_rows_ext(adj::PriorSumsT<float>& a, const f32x16 (&c)[NCH], const float* __restrict__ tabP, int mesh_stride, const int* bnd,
+                                               const LerpN& L, int kb, int h) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         float4_t ta[4], tb[4];
-        chunk_rows<4>(tabP, 128, bnd, L, 2 * q + h, ta, tb);
+        chunk_rows<4>(tabP, mesh_stride, bnd, L, 8 * kb + 2 * q + h, ta, tb);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int r = 4 * q + e;
@@ -802,12 +831,12 @@ __device__ __forceinline__ void prior_sums_xhalf(adj::PriorSumsT<float>& a) {
     a.cc = xhalf_sum(a.cc); a.cc1 = xhalf_sum(a.cc1); a.c1c1 = xhalf_sum(a.c1c1); a.cc2 = xhalf_sum(a.cc2);
 }
 template <bool CONST>
-__device__ __forceinline__ void prior_rows_bwd(const adj::PriorSumsT<float>& ab, const f32x16 (&c)[NCH], const float* __restrict__ tabP, const int* bnd,
-                                               const LerpN& L, int h, f32x16 (&cb)[NCH]) {
+__device__ __forceinline__ void prior_rows_bwd(const adj::PriorSumsT<float>& ab, const f32x16 (&c)[NCH], const float* __restrict__ tabP, int mesh_stride,
+                                               const int* bnd, const LerpN& L, int kb, int h, f32x16 (&cb)[NCH]) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         float4_t ta[3], tb[3];
-        chunk_rows<3>(tabP, 128, bnd, L, 2 * q + h, ta, tb);
+        chunk_rows<3>(tabP, mesh_stride, bnd, L, 8 * kb + 2 * q + h, ta, tb);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int r = 4 * q + e;
@@ -829,35 +858,76 @@ __device__ __forceinline__ void prior_rows_bwd(const adj::PriorSumsT<float>& ab,
         }
     }
 }
-// w @ ob_to_b for one 32-row block of triples (every channel scaled); obh: hi halves, lo at + 1024
-__device__ __forceinline__ void ob_product(const _Float16* obh, f32x16 (&w)[NCH], int lane, f32x16 (&c)[NCH]) {
-    Frag f[NCH][2];
-    int e[NCH];
-    to_frags1(w, f, e);
+// NB blocks of triples -> fragments [block][channel], one power of two per (walker, channel) over the NB blocks (the operand of a product over the ROWS)
+template <int NB>
+__device__ __forceinline__ void to_frags_n(const f32x16 (&blk)[NB][NCH], Frag (&f)[NB][NCH], int (&e)[NCH]) {
 #pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
-        f32x16 acc = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int c = 0; c < NCH; ++c) {
+        float amax = 0.0f;
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) amax = fmaxf(amax, fabsf(blk[b][c][r]));
+        e[c] = col_exponent(amax);
+        const float sc = __builtin_amdgcn_ldexpf(1.0f, -e[c]);
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float r8[8];
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) r8[jj] = blk[b][c][8 * s + jj] * sc;
+                split8(r8, f[b][c].hi[s], f[b][c].lo[s]);
+            }
+    }
+}
+// ... of one channel
+template <int NB>
+__device__ __forceinline__ void to_frags_n1(const f32x16 (&blk)[NB], Frag (&f)[NB], int& e) {
+    float amax = 0.0f;
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) amax = fmaxf(amax, fabsf(blk[b][r]));
+    e = col_exponent(amax);
+    const float sc = __builtin_amdgcn_ldexpf(1.0f, -e);
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const f16x8 ah = *reinterpret_cast<const f16x8*>(obh + (s * 64 + lane) * 8);
-            const f16x8 al = *reinterpret_cast<const f16x8*>(obh + 1024 + (s * 64 + lane) * 8);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, f[ch][0].hi[s], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, f[ch][0].lo[s], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, f[ch][0].hi[s], acc, 0, 0, 0);
-        }
-        const float sc = __builtin_amdgcn_ldexpf(1.0f, e[ch]);
+            float r8[8];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) c[ch][r] = acc[r] * sc;
-    }
+            for (int jj = 0; jj < 8; ++jj) r8[jj] = blk[b][8 * s + jj] * sc;
+            split8(r8, f[b].hi[s], f[b].lo[s]);
+        }
+}
+// block ko of w @ M for ONE channel (M's image as prior_c_block takes it: [ko][ki]{hi 1024, lo 1024})
+template <int NBK>
+__device__ __forceinline__ void c_block1(const _Float16* obh, const Frag (&wf)[NBK], int e, int ko, int lane, f32x16& out) {
+    f32x16 acc = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int ki = 0; ki < NBK; ++ki)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const _Float16* blk = obh + (size_t)(ko * NBK + ki) * 2048;
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(blk + (s * 64 + lane) * 8);
+            const f16x8 al = *reinterpret_cast<const f16x8*>(blk + 1024 + (s * 64 + lane) * 8);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wf[ki].hi[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wf[ki].lo[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wf[ki].hi[s], acc, 0, 0, 0);
+        }
+    const float sc = __builtin_amdgcn_ldexpf(1.0f, e);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[r] = acc[r] * sc;
 }
 
 // forward of one conditioner from its input (u0, u1) to the second hidden layer's pre-activation triples z2 (two 32-unit blocks).  HEAD: on to the head
-// triples o.
-template <bool HEAD>
-__device__ __forceinline__ void cond_fwd(const float* net, float u0v, float u1v, int lane, f32x16 (&z2a)[NCH], f32x16 (&z2b)[NCH], f32x16 (&o)[NCH]) {
+// triples o (NBK row blocks).
+template <bool HEAD, int NBK>
+__device__ __forceinline__ void cond_fwd(const float* net, float u0v, float u1v, int lane, f32x16 (&z2a)[NCH], f32x16 (&z2b)[NCH], f32x16 (&o)[NBK][NCH]) {
     Frag f2[NCH][2];
     int e2[NCH];
-    using O = NetOff<2, 1>;
+    using O = NetOff<2, NBK>;
     const int h = lane >> 5;
     const float in0[2] = {u0v, 1.0f}, in1[2] = {u1v, 0.0f};
     f32x16 a0[NCH], a1[NCH];
@@ -886,7 +956,8 @@ __device__ __forceinline__ void cond_fwd(const float* net, float u0v, float u1v,
         act_block(a0);
         act_block(a1);
         to_frags(a0, a1, f2, e2);
-        cond_out<1>(net, f2, e2, 0, lane, o);
+#pragma unroll
+        for (int kb = 0; kb < NBK; ++kb) cond_out<NBK>(net, f2, e2, kb, lane, o[kb]);
     }
 }
 // X operand of a product over the walker axis: one 32-unit block of ACTIVATION jets (channel 0 = r in (0, 1)) -> fragments scaled by 2^-ex[c], one power
@@ -927,104 +998,167 @@ __device__ __forceinline__ void wgrad_block(f32x16& p, const Frag& xt, const Fra
 #pragma unroll
     for (int s = 0; s < 2; ++s) mfma3(p, xt.hi[s], xt.lo[s], yt.hi[s], yt.lo[s]);
 }
-__device__ __forceinline__ void acc_fma(f32x16& acc, const f32x16& p, float un) {
+// block b of the workgroup's accumulators += p * un, in TILE ORDER: the tiles of a workgroup are numbered k = 0, 1, .. (tile = block + k * grid, wave
+// k % waves), ticket[b] counts the tiles whose product has been added to block b, and tile k's wave adds when the count stands at k.  The sum of every
+// block is therefore formed in the same order whatever the timing (bitwise reproducible gradients) although the waves share ONE set of blocks.  Progress:
+// tile k waits only for tile k - 1's wave to pass the same point, tile 0 for nobody; the waves of a workgroup are resident together and each works
+// through its tiles in increasing k, so every wait ends (the waves fall into step one add apart: ~200 cycles in a tile of ~10^5).
+__device__ __forceinline__ void acc_add(float* acc, int* ticket, int b, int k, int lane, const f32x16& p, float un) {
+    while (__hip_atomic_load(ticket + b, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != k) __builtin_amdgcn_s_sleep(1);
+    f32x16 a = acc_load(acc, b, lane);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = __builtin_fmaf(p[r], un, acc[r]);
+    for (int r = 0; r < 16; ++r) a[r] = __builtin_fmaf(p[r], un, a[r]);
+    acc_store(acc, b, lane, a);
+    __hip_atomic_store(ticket + b, k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <bool PRIOR>
+template <bool PRIOR, int NBK>
 __global__ __launch_bounds__(kBwdWaves * 64) void k_ebwd(const MfmaDev mm, int net_index, const float* __restrict__ tabI, const float* __restrict__ tabP,
                                                           const float* __restrict__ st_in, float* __restrict__ adjb, const float* __restrict__ w_psi,
                                                           const float* __restrict__ w_lap, int64_t B, float* __restrict__ partial) {
-    // partial: [gridDim.x][kGFloats] -- this workgroup's block of the net's gradient (image units), written once at the end
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    __shared__ int bnd_s[32];
+    // partial: [gridDim.x][GL<NBK>::floats] -- this workgroup's block of the net's gradient (image units), written once at the end
+    using O = NetOff<2, NBK>;
+    using G = GL<NBK>;
     constexpr int kThreads = kBwdWaves * 64;
-    if (threadIdx.x < 16) bnd_s[threadIdx.x] = reinterpret_cast<const int*>(tabI + (size_t)mm.n_mesh * 128)[threadIdx.x];
-    else if (threadIdx.x < 32) bnd_s[threadIdx.x] = reinterpret_cast<const int*>(tabP + (size_t)mm.n_mesh * 128)[threadIdx.x - 16];
+    constexpr int kMeshStride = 128 * NBK;   // floats per mesh point of the regrouped tables (k_efused)
+    constexpr int kAcc = acc_blocks(NBK);
+    constexpr int kKinds = 4 + 2 * NBK;      // per-lane sums: Gb1 (two unit blocks), Gb2 of dimension 1 (NBK), of dimension 0 (NBK), Gb0, GW0
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ int bnd_s[32 * NBK];
+    __shared__ int ticket[kAcc];
+    __shared__ __attribute__((aligned(16))) float c0s[32 * NBK + 16];   // prior: c of dimension 0 ([NBK][2][16], the same for every walker), + the sum of its raw outputs
+    if (threadIdx.x < 16 * NBK) bnd_s[threadIdx.x] = reinterpret_cast<const int*>(tabI + (size_t)mm.n_mesh * kMeshStride)[threadIdx.x];
+    else if (threadIdx.x < 32 * NBK) bnd_s[threadIdx.x] = reinterpret_cast<const int*>(tabP + (size_t)mm.n_mesh * kMeshStride)[threadIdx.x - 16 * NBK];
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + kAcc) ticket[threadIdx.x - 64] = 0;
     float* net_l = lds + mm.const_floats;
     float* tnet_l = net_l + mm.net_floats;
     float* tcon_l = tnet_l + mm.tnet_floats;
     stage_floats<kThreads>(mm.image + mm.const_img_off, lds, mm.const_floats);
     stage_floats<kThreads>(mm.image + (size_t)net_index * mm.net_floats, net_l, mm.net_floats);
     stage_floats<kThreads>(mm.image + mm.timg_off + (size_t)net_index * mm.tnet_floats, tnet_l, mm.tnet_floats);
-    stage_floats<kThreads>(mm.image + mm.tconst_off, tcon_l, 1024);
-    // the waves' private accumulators of (dW1, dW2) behind the images
-    float* acc_all = tcon_l + 1024;
-    for (int i = threadIdx.x; i < kBwdWaves * kAccFloats; i += kThreads) acc_all[i] = 0.0f;
+    stage_floats<kThreads>(mm.image + mm.tconst_off, tcon_l, NBK * NBK * 1024);
+    // the workgroup's accumulators of (dW1, dW2) behind the images
+    float* acc = tcon_l + NBK * NBK * 1024;
+    for (int i = threadIdx.x; i < kAcc * 1024; i += kThreads) acc[i] = 0.0f;
     __syncthreads();
-    float* accw = acc_all + (threadIdx.x >> 6) * kAccFloats;
-    // bias / input-layer sums of this lane over its wave's tiles: Gb1 and Gb2 (dimension 1) of unit / row (lane & 31) of its u block (transposed operands:
+    // bias / input-layer sums of this lane over its wave's tiles: Gb1 and Gb2 (dimension 1) of unit / row (lane & 31) of its block (transposed operands:
     // partial over the lane half's 16 walkers), Gb2 of dimension 0, Gb0, GW0 in the lane assignment of the DPP sums below
-    float gb1[2] = {0.0f, 0.0f}, gb21 = 0.0f, gb20 = 0.0f, gb0s = 0.0f, gw0s = 0.0f;
+    float gb1[2] = {0.0f, 0.0f}, gb21[NBK], gb20[NBK], gb0s = 0.0f, gw0s = 0.0f;
+#pragma unroll
+    for (int kb = 0; kb < NBK; ++kb) { gb21[kb] = 0.0f; gb20[kb] = 0.0f; }
     f16x8 pm[2];
     make_perm(threadIdx.x & 63, pm);
     const float* net = net_l;
     const float* fkI = lds;
-    const float* fkP = lds + 32;
-    const _Float16* obh = reinterpret_cast<const _Float16*>(lds + 64);
+    const float* fkP = lds + 32 * NBK;
+    const _Float16* obh = reinterpret_cast<const _Float16*>(lds + 64 * NBK);
+    const float* cbP = lds + 64 * NBK + NBK * NBK * 1024 + 64 * NBK;   // [NBK][2][16] constant term of the B prior's boundary map times ob_to_b (mm.p_bias)
     const _Float16* TW1h = reinterpret_cast<const _Float16*>(tnet_l);
     const _Float16* TW1l = reinterpret_cast<const _Float16*>(tnet_l + 2048);
     const _Float16* TW2h = reinterpret_cast<const _Float16*>(tnet_l + 4096);
-    const _Float16* TW2l = reinterpret_cast<const _Float16*>(tnet_l + 5120);
-    const float* TW0 = tnet_l + 6144;
+    const _Float16* TW2l = reinterpret_cast<const _Float16*>(tnet_l + 4096 + 1024 * NBK);
+    const float* TW0 = tnet_l + 4096 + 2048 * NBK;
     const _Float16* obT = reinterpret_cast<const _Float16*>(tcon_l);
     const int lane = threadIdx.x & 63;
     const int j = lane & 31, h = lane >> 5;
     const int n_mesh = mm.n_mesh;
     const int64_t n_tiles = (B + 31) >> 5;
-    // tiles are dealt statically (tile = block + (round * waves + wave) * grid): which wave sums which tiles -- and so every bit of the gradient --
-    // does not depend on timing (one wave per SIMD: no issue arbitration to balance, unlike k_mfma's tile counter)
-    for (int64_t tile = (int64_t)blockIdx.x + (int64_t)(threadIdx.x >> 6) * gridDim.x; tile < n_tiles; tile += (int64_t)kBwdWaves * gridDim.x) {
+    if (PRIOR) {
+        // dimension 0 of the prior sees the bias alone (empty mask): c = (b2 * keep) @ ob_to_b (+ the constant term) is the same for every walker
+        if (threadIdx.x < 64) {
+            f32x16 w0[NBK];
+            float s0 = 0.0f;
+#pragma unroll
+            for (int kb = 0; kb < NBK; ++kb) {
+                const f32x16 b20 = load16(net + O::b2 + ((0 * NBK + kb) * 2 + h) * 16), keep = load16(fkP + (kb * 2 + h) * 16);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s0 += b20[r]; w0[kb][r] = b20[r] * keep[r]; }
+            }
+            s0 = xhalf_sum(s0);
+            Frag wf[NBK];
+            int e0;
+            to_frags_n1<NBK>(w0, wf, e0);
+#pragma unroll
+            for (int ko = 0; ko < NBK; ++ko) {
+                f32x16 c;
+                c_block1<NBK>(obh, wf, e0, ko, lane, c);
+                if (mm.p_bias) {
+                    const f32x16 cbv = load16(cbP + (ko * 2 + h) * 16);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) c[r] = __builtin_fmaf(s0, cbv[r], c[r]);
+                }
+                if (j == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) c0s[(ko * 2 + h) * 16 + r] = c[r];
+                }
+            }
+            if (lane == 0) c0s[32 * NBK] = s0;
+        }
+        __syncthreads();
+    }
+    // tiles are dealt statically (tile = block + k * grid, k = round * waves + wave): which wave sums which tiles does not depend on timing, and the
+    // shared accumulator blocks take the tiles' products in the order of k (acc_add)
+    for (int k = (int)(threadIdx.x >> 6);; k += kBwdWaves) {
+        const int64_t tile = (int64_t)blockIdx.x + (int64_t)k * gridDim.x;
+        if (tile >= n_tiles) break;
         const int64_t w = tile * 32 + j;
         const bool valid = w < B;
         const int64_t wl = valid ? w : B - 1;
         // (padding lanes of the last tile repeat walker B - 1 with zero adjoints: their columns add nothing to the sums over walkers)
         const JA u0 = ja_load(st_in, 0, B, wl), u1 = ja_load(st_in, 1, B, wl);
-        // ---- the net's forward to the head triples o (the second hidden layer's activations go to the dump on the way).  The second hidden layer's
-        // pre-activations z2, which the reverse needs, are computed again behind the head: 96 registers less across the head algebra
-        f32x16 o[NCH];
+        // ---- the net's forward to the head triples o.  The second hidden layer's pre-activations z2, which the reverse needs, are computed again
+        // behind the head: 96 registers less across the head algebra
+        f32x16 o[NBK][NCH];
         {
             f32x16 z2a[NCH], z2b[NCH];
-            cond_fwd<true>(net, u0.v, u1.v, lane, z2a, z2b, o);
+            cond_fwd<true, NBK>(net, u0.v, u1.v, lane, z2a, z2b, o);
         }
         // ---- head: forward sums, pullback to adjoint head triples ob (dimension 1) and ob0 (dimension 0, channel 0)
-        f32x16 ob[NCH], ob0;
+        f32x16 ob[NBK][NCH], ob0[NBK];
         JA u0b = adj::jzero<float>(), u1b = adj::jzero<float>(), ldb = adj::jzero<float>();
         if (!PRIOR) {
             const JA y1b = valid ? ja_load(adjb, 0, B, wl) : adj::jzero<float>(), y0b = valid ? ja_load(adjb, 1, B, wl) : adj::jzero<float>();
             ldb = valid ? ja_load(adjb, 2, B, wl) : adj::jzero<float>();
-            const f32x16 g16 = load16(fkI + h * 16);
             const LerpN L1 = nlerp(u1.v, n_mesh), L0 = nlerp(u0.v, n_mesh);
-            f32x16 o0[NCH];
-            o0[0] = load16(net + NetOff<2, 1>::b2 + (0 * 2 + h) * 16);   // dimension 0: the bias alone (empty mask)
-            // dimension 0 first, then dimension 1: the two heads share nothing but the incoming adjoints, and their sums / intermediates need not be live together
+            // dimension 0 (the bias alone: empty mask) first, then dimension 1: the two heads share nothing but the incoming adjoints, and their sums /
+            // intermediates need not be live together
             JA sb0 = adj::jzero<float>(), tb0 = adj::jzero<float>();
             float tv0 = 0.0f;
             {
                 adj::FlowSumsT<float> s0 = adj::flow_sums_zero<float>();
-                flow_rows_ext<true>(s0, o0, g16, tabI, bnd_s, L0, h);
+#pragma unroll
+                for (int kb = 0; kb < NBK; ++kb) {
+                    f32x16 o0[NCH];
+                    o0[0] = load16(net + O::b2 + ((0 * NBK + kb) * 2 + h) * 16);
+                    flow_rows_ext<true>(s0, o0, load16(fkI + (kb * 2 + h) * 16), tabI, kMeshStride, bnd_s, L0, kb, h);
+                }
                 flow_sums_xhalf(s0);
                 JA y0, dl0;
                 const adj::FlowHeadFwd<float> f0 = adj::flow_head_fwd(s0, mm.F_I, mm.i_reg, u0, u0, y0, dl0);
                 adj::FlowSumsT<float> ab0 = adj::flow_sums_zero<float>();
                 adj::flow_head_bwd(s0, f0, mm.F_I, mm.i_reg, u0, u0, y0b, ldb, ab0, sb0, tb0, tv0);
-                f32x16 t0[NCH];
-                flow_rows_bwd<true>(ab0, o0, g16, tabI, bnd_s, L0, h, t0);
-                ob0 = t0[0];
+#pragma unroll
+                for (int kb = 0; kb < NBK; ++kb) {
+                    f32x16 o0[NCH], t0[NCH];
+                    o0[0] = load16(net + O::b2 + ((0 * NBK + kb) * 2 + h) * 16);
+                    flow_rows_bwd<true>(ab0, o0, load16(fkI + (kb * 2 + h) * 16), tabI, kMeshStride, bnd_s, L0, kb, h, t0);
+                    ob0[kb] = t0[0];
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             JA sb = adj::jzero<float>(), tb = adj::jzero<float>();
             float tv1 = 0.0f;
             {
                 adj::FlowSumsT<float> s1 = adj::flow_sums_zero<float>();
-                flow_rows_ext<false>(s1, o, g16, tabI, bnd_s, L1, h);
+#pragma unroll
+                for (int kb = 0; kb < NBK; ++kb) flow_rows_ext<false>(s1, o[kb], load16(fkI + (kb * 2 + h) * 16), tabI, kMeshStride, bnd_s, L1, kb, h);
                 flow_sums_xhalf(s1);
                 JA y1, dl1;
                 const adj::FlowHeadFwd<float> f1 = adj::flow_head_fwd(s1, mm.F_I, mm.i_reg, u0, u1, y1, dl1);
                 adj::FlowSumsT<float> ab1 = adj::flow_sums_zero<float>();
                 adj::flow_head_bwd(s1, f1, mm.F_I, mm.i_reg, u0, u1, y1b, ldb, ab1, sb, tb, tv1);
-                flow_rows_bwd<false>(ab1, o, g16, tabI, bnd_s, L1, h, ob);
+#pragma unroll
+                for (int kb = 0; kb < NBK; ++kb) flow_rows_bwd<false>(ab1, o[kb], load16(fkI + (kb * 2 + h) * 16), tabI, kMeshStride, bnd_s, L1, kb, h, ob[kb]);
             }
             u0b = JA{tv0, sb.a + sb0.a + tb0.a, sb.b + sb0.b + tb0.b, sb.h + sb0.h + tb0.h};
             u1b = JA{tv1, tb.a, tb.b, tb.h};
@@ -1032,44 +1166,41 @@ __global__ __launch_bounds__(kBwdWaves * 64) void k_ebwd(const MfmaDev mm, int n
             const float wp = valid ? w_psi[wl] : 0.0f, wlp = valid ? w_lap[wl] : 0.0f;
             const JA ld = ja_load(st_in, 2, B, wl);
             const JA psib = JA{wp, 0.0f, 0.0f, 2.0f * wlp};
-            const f32x16 keep = load16(fkP + h * 16);
-            // dimension 1: c = (o keep) @ ob_to_b as triples; dimension 0: the bias alone
-            float s1 = 0.0f, s0 = 0.0f;
-            f32x16 wv[NCH], c1[NCH], w0v[NCH], c0[NCH];
-            const f32x16 b20 = load16(net + NetOff<2, 1>::b2 + (0 * 2 + h) * 16);
+            // dimension 1: c = (o keep) @ ob_to_b as triples (+ the constant term of a boundary constraint with a non-zero value, mm.p_bias: c += (sum o) *
+            // (b @ ob_to_b), channel by channel, as k_efused<.., true>); dimension 0: c0s
+            float s1 = 0.0f, sder[2] = {0.0f, 0.0f};
+            f32x16 c1[NBK][NCH];
+            {
+                Frag of[NBK][NCH];
+                int eo[NCH];
+                prior_frags<NBK>(o, fkP, lane, of, eo, s1, sder);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s1 += o[0][r]; s0 += b20[r]; }
-            s1 = xhalf_sum(s1);
-            s0 = xhalf_sum(s0);
+                for (int ko = 0; ko < NBK; ++ko) {
+                    prior_c_block<NBK>(obh, of, eo, ko, lane, c1[ko]);
+                    if (mm.p_bias) {
+                        const f32x16 cbv = load16(cbP + (ko * 2 + h) * 16);
 #pragma unroll
-            for (int c = 0; c < NCH; ++c)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { wv[c][r] = o[c][r] * keep[r]; w0v[c][r] = c == 0 ? b20[r] * keep[r] : 0.0f; }
-            ob_product(obh, wv, lane, c1);
-            ob_product(obh, w0v, lane, c0);
-            // a boundary constraint with a non-zero value on the prior (mm.p_bias): c += (sum o) * (b @ ob_to_b), channel by channel (as k_efused<.., true>)
-            const f32x16 cbv = mm.p_bias ? load16(lds + 64 + 1024 + 64 + h * 16) : f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            if (mm.p_bias) {
-                float sd1 = 0.0f, sd2 = 0.0f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { sd1 += o[1][r]; sd2 += o[2][r]; }
-                sd1 = xhalf_sum(sd1);
-                sd2 = xhalf_sum(sd2);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    c1[0][r] = __builtin_fmaf(s1, cbv[r], c1[0][r]);
-                    c1[1][r] = __builtin_fmaf(sd1, cbv[r], c1[1][r]);
-                    c1[2][r] = __builtin_fmaf(sd2, cbv[r], c1[2][r]);
-                    c0[0][r] = __builtin_fmaf(s0, cbv[r], c0[0][r]);
+                        for (int r = 0; r < 16; ++r) {
+                            c1[ko][0][r] = __builtin_fmaf(s1, cbv[r], c1[ko][0][r]);
+                            c1[ko][1][r] = __builtin_fmaf(sder[0], cbv[r], c1[ko][1][r]);
+                            c1[ko][2][r] = __builtin_fmaf(sder[1], cbv[r], c1[ko][2][r]);
+                        }
+                    }
                 }
             }
+            const float s0 = c0s[32 * NBK];
             const float sg1 = s1 < 0.0f ? -1.0f : 1.0f, sg0 = s0 < 0.0f ? -1.0f : 1.0f;
             const bool in0 = u0.v >= 0.0f && u0.v <= 1.0f, in1 = u1.v >= 0.0f && u1.v <= 1.0f;
             const JA uc0 = in0 ? u0 : JA{u0.v < 0.0f ? 0.0f : 1.0f, 0.0f, 0.0f, 0.0f}, uc1 = in1 ? u1 : JA{u1.v < 0.0f ? 0.0f : 1.0f, 0.0f, 0.0f, 0.0f};
             const LerpN L1 = nlerp(uc1.v, n_mesh), L0 = nlerp(uc0.v, n_mesh);
             adj::PriorSumsT<float> p1 = adj::prior_sums_zero<float>(), p0 = adj::prior_sums_zero<float>();
-            prior_rows_ext<false>(p1, c1, tabP, bnd_s + 16, L1, h);
-            prior_rows_ext<true>(p0, c0, tabP, bnd_s + 16, L0, h);
+#pragma unroll
+            for (int ko = 0; ko < NBK; ++ko) {
+                prior_rows_ext<false>(p1, c1[ko], tabP, kMeshStride, bnd_s + 16 * NBK, L1, ko, h);
+                f32x16 c0[NCH];
+                c0[0] = load16(c0s + (ko * 2 + h) * 16);
+                prior_rows_ext<true>(p0, c0, tabP, kMeshStride, bnd_s + 16 * NBK, L0, ko, h);
+            }
             prior_sums_xhalf(p1);
             prior_sums_xhalf(p0);
             JA val1, val0;
@@ -1092,63 +1223,101 @@ __global__ __launch_bounds__(kBwdWaves * 64) void k_ebwd(const MfmaDev mm, int n
             adj::prior_head_bwd(p0, f0, sg0, u0, uc0, Ab * sc0, ab0, sb0, tb0, tv0);
             u0b = JA{in0 ? tv0 : 0.0f, sb.a + sb0.a + (in0 ? tb0.a : 0.0f), sb.b + sb0.b + (in0 ? tb0.b : 0.0f), sb.h + sb0.h + (in0 ? tb0.h : 0.0f)};
             u1b = in1 ? JA{tv1, tb1.a, tb1.b, tb1.h} : adj::jzero<float>();
-            // rows back: adjoint of c -> through ob_to_b transposed -> adjoint of the raw outputs
-            f32x16 cb[NCH], wb[NCH];
-            prior_rows_bwd<false>(ab1, c1, tabP, bnd_s + 16, L1, h, cb);
-            ob_product(obT, cb, lane, wb);
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                float sbar = 0.0f;     // adjoint of the channel's sum of raw outputs (the constant term reaches every one of them)
-                if (mm.p_bias) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) sbar = __builtin_fmaf(cb[c][r], cbv[r], sbar);
-                    sbar = xhalf_sum(sbar);
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) ob[c][r] = __builtin_fmaf(wb[c][r], keep[r], sbar);
-            }
-            prior_rows_bwd<true>(ab0, c0, tabP, bnd_s + 16, L0, h, cb);
-            ob_product(obT, cb, lane, wb);
+            // rows back: adjoint of c -> through ob_to_b transposed -> adjoint of the raw outputs (the constant term reaches every one of a channel's
+            // raw outputs through their sum: sbar)
             {
-                float sbar = 0.0f;
+                f32x16 cb[NBK][NCH];
+                float sbar[NCH] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int ko = 0; ko < NBK; ++ko) {
+                    prior_rows_bwd<false>(ab1, c1[ko], tabP, kMeshStride, bnd_s + 16 * NBK, L1, ko, h, cb[ko]);
+                    if (mm.p_bias) {
+                        const f32x16 cbv = load16(cbP + (ko * 2 + h) * 16);
+#pragma unroll
+                        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) sbar[c] = __builtin_fmaf(cb[ko][c][r], cbv[r], sbar[c]);
+                    }
+                }
                 if (mm.p_bias) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) sbar = __builtin_fmaf(cb[0][r], cbv[r], sbar);
-                    sbar = xhalf_sum(sbar);
+                    for (int c = 0; c < NCH; ++c) sbar[c] = xhalf_sum(sbar[c]);
                 }
+                Frag fcb[NBK][NCH];
+                int ecb[NCH];
+                to_frags_n<NBK>(cb, fcb, ecb);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) ob0[r] = __builtin_fmaf(wb[0][r], keep[r], sbar);
+                for (int ki = 0; ki < NBK; ++ki) {
+                    f32x16 wb[NCH];
+                    prior_c_block<NBK>(obT, fcb, ecb, ki, lane, wb);
+                    const f32x16 keep = load16(fkP + (ki * 2 + h) * 16);
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) ob[ki][c][r] = __builtin_fmaf(wb[c][r], keep[r], sbar[c]);
+                }
+            }
+            {
+                f32x16 cb0[NBK];
+                float sbar = 0.0f;
+#pragma unroll
+                for (int ko = 0; ko < NBK; ++ko) {
+                    f32x16 c0[NCH], t[NCH];
+                    c0[0] = load16(c0s + (ko * 2 + h) * 16);
+                    prior_rows_bwd<true>(ab0, c0, tabP, kMeshStride, bnd_s + 16 * NBK, L0, ko, h, t);
+                    cb0[ko] = t[0];
+                    if (mm.p_bias) {
+                        const f32x16 cbv = load16(cbP + (ko * 2 + h) * 16);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) sbar = __builtin_fmaf(cb0[ko][r], cbv[r], sbar);
+                    }
+                }
+                if (mm.p_bias) sbar = xhalf_sum(sbar);
+                Frag f0b[NBK];
+                int e0b;
+                to_frags_n1<NBK>(cb0, f0b, e0b);
+#pragma unroll
+                for (int ki = 0; ki < NBK; ++ki) {
+                    f32x16 wb0;
+                    c_block1<NBK>(obT, f0b, e0b, ki, lane, wb0);
+                    const f32x16 keep = load16(fkP + (ki * 2 + h) * 16);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ob0[ki][r] = __builtin_fmaf(wb0[r], keep[r], sbar);
+                }
             }
         }
         // Gb2 of dimension 0: sum over the tile's walkers of obar0 (16 registers per half: DPP sums; lane (j, h) keeps register j & 15 where j < 16)
-        {
+#pragma unroll
+        for (int kb = 0; kb < NBK; ++kb) {
             float sb = 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float a = half32_sum(ob0[r]);
+                const float a = half32_sum(ob0[kb][r]);
                 sb = (j & 15) == r ? a : sb;
             }
-            gb20 += sb;
+            gb20[kb] += sb;
         }
         // ---- conditioner, reverse: hbar2 = W2' obar, zbar2 = act'(z2) hbar2, hbar1 = W1' zbar2, zbar1 = act'(z1) hbar1
         __builtin_amdgcn_sched_barrier(0);
         f32x16 z2a[NCH], z2b[NCH];
-        Frag f[NCH][2];       // fragments of the tensor the next product contracts: obar, then zbar2
+        Frag f[NCH][2];       // fragments of the tensor the next product contracts: obar ([channel][row block]), then zbar2 ([channel][unit block])
         int e[NCH];
-        to_frags1<true>(ob, f, e);
+        to_frags_kb<NBK>(ob, f, e);
         {
-            f32x16 o2[NCH];
-            cond_fwd<false>(net, u0.v, u1.v, lane, z2a, z2b, o2);
+            f32x16 o2[NBK][NCH];
+            cond_fwd<false, NBK>(net, u0.v, u1.v, lane, z2a, z2b, o2);
         }
         // dW2[k][row] = sum_c sum_w X2_c[k][w] obar_c[row][w]: X2 = act(z2), block by block (32 units: 48 registers of fragments at a time); both operands
-        // transposed on the matrix cores; the two 32 x 32 blocks of the product accumulate in this wave's LDS blocks 4, 5.  Gb2 rides on obar's transposes.
+        // transposed on the matrix cores; the 2 x NBK blocks of the product go to the accumulator blocks 4 + (k block) NBK + (row block).  Gb2 rides on
+        // obar's transposes.
         {
-            Frag yt[NCH];      // obar^T, once for both k blocks
-            {
+            Frag yt[NBK][NCH];      // obar^T, once for both k blocks
+#pragma unroll
+            for (int kb = 0; kb < NBK; ++kb) {
                 float rs = 0.0f;
 #pragma unroll
-                for (int c = 0; c < NCH; ++c) tr_frag(f[c][0], pm, yt[c], c == 0 ? &rs : nullptr);
-                gb21 = __builtin_fmaf(rs, __builtin_amdgcn_ldexpf(1.0f, e[0]), gb21);
+                for (int c = 0; c < NCH; ++c) tr_frag(f[c][kb], pm, yt[kb][c], c == 0 ? &rs : nullptr);
+                gb21[kb] = __builtin_fmaf(rs, __builtin_amdgcn_ldexpf(1.0f, e[0]), gb21[kb]);
             }
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) {
@@ -1158,16 +1327,18 @@ __global__ __launch_bounds__(kBwdWaves * 64) void k_ebwd(const MfmaDev mm, int n
                 act_block(t);
                 Frag fx[NCH];
                 const int E = block_frags_x(t, e, fx);
-                f32x16 p = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                f32x16 p[NBK];
+#pragma unroll
+                for (int kb = 0; kb < NBK; ++kb) p[kb] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
                     Frag xt;
                     tr_frag(fx[c], pm, xt);
-                    wgrad_block(p, xt, yt[c]);
+#pragma unroll
+                    for (int kb = 0; kb < NBK; ++kb) wgrad_block(p[kb], xt, yt[kb][c]);
                 }
-                f32x16 a = acc_load(accw, 4 + mb, lane);
-                acc_fma(a, p, __builtin_amdgcn_ldexpf(1.0f, E));
-                acc_store(accw, 4 + mb, lane, a);
+#pragma unroll
+                for (int kb = 0; kb < NBK; ++kb) acc_add(acc, ticket, 4 + mb * NBK + kb, k, lane, p[kb], __builtin_amdgcn_ldexpf(1.0f, E));
             }
         }
         f32x16 g0[NCH], g1[NCH];
@@ -1175,10 +1346,12 @@ __global__ __launch_bounds__(kBwdWaves * 64) void k_ebwd(const MfmaDev mm, int n
 #pragma unroll
             for (int c = 0; c < NCH; ++c) { g0[c] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; g1[c] = g0[c]; }
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                mfma_step<NCH>(TW2h, TW2l, 0, s, f, g0, lane);
-                mfma_step<NCH>(TW2h + 1024, TW2l + 1024, 0, s, f, g1, lane);
-            }
+            for (int kt = 0; kt < NBK; ++kt)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    mfma_step<NCH>(TW2h, TW2l, kt, s, f, g0, lane);
+                    mfma_step<NCH>(TW2h + NBK * 1024, TW2l + NBK * 1024, kt, s, f, g1, lane);
+                }
             unscale_all(g0, e);
             unscale_all(g1, e);
             act_block_bwd(z2a, g0);
@@ -1186,9 +1359,8 @@ __global__ __launch_bounds__(kBwdWaves * 64) void k_ebwd(const MfmaDev mm, int n
             to_frags_all<true>(g0, g1, f, e);
             // dW1[k][u] = sum_c sum_w X1_c[k][w] zbar2_c[u][w] while the fragments of zbar2 (f, exponents e) are at hand and before the product that
             // consumes them: X1, the first hidden layer's activation triples, is recomputed block by block from (s, 1, 0) (two f32 MFMAs and 16
-            // activations per lane and block).  LDS blocks 0 .. 3 = (k block mb, u block nb); Gb1 rides on the transposes of zbar2.
+            // activations per lane and block).  Accumulator blocks 0 .. 3 = (k block mb, u block nb); Gb1 rides on the transposes of zbar2.
             {
-                using O = NetOff<2, 1>;
                 const float in0[2] = {u0.v, 1.0f}, in1[2] = {u1.v, 0.0f};
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb) {
@@ -1216,9 +1388,7 @@ __global__ __launch_bounds__(kBwdWaves * 64) void k_ebwd(const MfmaDev mm, int n
                             wgrad_block(p, xt[c], yt);
                             if (bias) gb1[nb] = __builtin_fmaf(rs, __builtin_amdgcn_ldexpf(1.0f, e[0]), gb1[nb]);
                         }
-                        f32x16 c0 = acc_load(accw, 2 * mb + nb, lane);
-                        acc_fma(c0, p, un);
-                        acc_store(accw, 2 * mb + nb, lane, c0);
+                        acc_add(acc, ticket, 2 * mb + nb, k, lane, p, un);
                     }
                 }
             }
@@ -1230,7 +1400,6 @@ __global__ __launch_bounds__(kBwdWaves * 64) void k_ebwd(const MfmaDev mm, int n
             unscale_all(g1, e);
         }
         {
-            using O = NetOff<2, 1>;
             const float in0[2] = {u0.v, 1.0f}, in1[2] = {u1.v, 0.0f};
             f32x16 a0[NCH], a1[NCH];
             init_acc(a0, net + O::b0 + (0 * 2 + h) * 16);
@@ -1272,63 +1441,66 @@ __global__ __launch_bounds__(kBwdWaves * 64) void k_ebwd(const MfmaDev mm, int n
             ja_store(adjb, 2, B, w, ldb);
         }
     }
-    // ---- the waves' sums -> this workgroup's block of the net's gradient, waves added in wave order
+    // ---- this workgroup's block of the net's gradient: the accumulator blocks as they stand, the per-lane sums added over the waves in wave order
     __syncthreads();                       // every wave is done with its tiles: the operand images are dead, the accumulators complete
-    float* red = lds;                      // [wave][6 kinds][64 lanes] over the image area
+    float* red = lds;                      // [wave][kKinds][64 lanes] over the image area
     {
-        float* mine = red + (threadIdx.x >> 6) * 6 * 64 + lane;
-        mine[0] = gb1[0]; mine[64] = gb1[1]; mine[128] = gb21; mine[192] = gb20; mine[256] = gb0s; mine[320] = gw0s;
+        float* mine = red + (threadIdx.x >> 6) * kKinds * 64 + lane;
+        mine[0] = gb1[0]; mine[64] = gb1[1];
+#pragma unroll
+        for (int kb = 0; kb < NBK; ++kb) { mine[(2 + kb) * 64] = gb21[kb]; mine[(2 + NBK + kb) * 64] = gb20[kb]; }
+        mine[(2 + 2 * NBK) * 64] = gb0s; mine[(3 + 2 * NBK) * 64] = gw0s;
     }
     __syncthreads();
-    float* g = partial + (size_t)blockIdx.x * kGFloats;
+    float* g = partial + (size_t)blockIdx.x * G::floats;
     auto wsum = [&](int kind, int ln) {    // sum over the waves of a lane's value
         float a = 0.0f;
 #pragma unroll
-        for (int wv = 0; wv < kBwdWaves; ++wv) a += red[(wv * 6 + kind) * 64 + ln];
+        for (int wv = 0; wv < kBwdWaves; ++wv) a += red[(wv * kKinds + kind) * 64 + ln];
         return a;
     };
-    for (int i = threadIdx.x; i < kAccFloats; i += kThreads) {
-        float a = 0.0f;
-#pragma unroll
-        for (int wv = 0; wv < kBwdWaves; ++wv) a += acc_all[wv * kAccFloats + i];
+    for (int i = threadIdx.x; i < kAcc * 1024; i += kThreads) {
         const int b = i >> 10, q = (i >> 8) & 3, ln = (i >> 2) & 63, r = 4 * q + (i & 3);
         const int row = acc_rho(r, ln >> 5), n = ln & 31;
-        if (b < 4) g[kGW1 + (32 * (b >> 1) + row) * 64 + 32 * (b & 1) + n] = a;
-        else g[kGW2 + (32 * (b - 4) + row) * 32 + n] = a;
+        if (b < 4) g[G::W1 + (32 * (b >> 1) + row) * 64 + 32 * (b & 1) + n] = acc[i];
+        else g[G::W2 + (32 * ((b - 4) / NBK) + row) * (32 * NBK) + 32 * ((b - 4) % NBK) + n] = acc[i];
     }
-    if (threadIdx.x < 64) {                // Gb1[u]: u block = thread >> 5; the two lane halves hold the two halves of the tile's walkers
-        const int nb = threadIdx.x >> 5, n = threadIdx.x & 31;
-        g[kGb1 + threadIdx.x] = wsum(nb, n) + wsum(nb, n + 32);
-    } else if (threadIdx.x < 96) {
-        const int n = threadIdx.x - 64;
-        g[kGb21 + n] = wsum(2, n) + wsum(2, n + 32);
-    } else if (threadIdx.x < 128) {        // Gb2 of dimension 0: lane (j < 16, h) keeps register j of half h
-        const int t = threadIdx.x - 96, jj = t & 15, hh = t >> 4;
-        g[kGb20 + acc_rho(jj, hh)] = wsum(3, jj + 32 * hh);
-    } else if (threadIdx.x < 192) {        // Gb0 / GW0: lane (j, h) keeps register j & 15 of block j >> 4
-        const int ln = threadIdx.x - 128, jj = ln & 31, hh = ln >> 5;
-        const int u = 32 * (jj >> 4) + acc_rho(jj & 15, hh);
-        g[kGb0 + u] = wsum(4, ln);
-        g[kGW0 + u] = wsum(5, ln);
+    for (int i = threadIdx.x; i < 128 + 64 * NBK; i += kThreads) {
+        if (i < 64) {                      // Gb1[u]: u block = i >> 5; the two lane halves hold the two halves of the tile's walkers
+            const int nb = i >> 5, n = i & 31;
+            g[G::b1 + i] = wsum(nb, n) + wsum(nb, n + 32);
+        } else if (i < 64 + 32 * NBK) {    // Gb2 of dimension 1
+            const int t = i - 64, kb = t >> 5, n = t & 31;
+            g[G::b21 + t] = wsum(2 + kb, n) + wsum(2 + kb, n + 32);
+        } else if (i < 64 + 64 * NBK) {    // Gb2 of dimension 0: lane (j < 16, h) keeps register j of half h
+            const int t = i - 64 - 32 * NBK, kb = t >> 5, jj = t & 15, hh = (t >> 4) & 1;
+            g[G::b20 + 32 * kb + acc_rho(jj, hh)] = wsum(2 + NBK + kb, jj + 32 * hh);
+        } else {                           // Gb0 / GW0: lane (j, h) keeps register j & 15 of block j >> 4
+            const int ln = i - 64 - 64 * NBK, jj = ln & 31, hh = ln >> 5;
+            const int u = 32 * (jj >> 4) + acc_rho(jj & 15, hh);
+            g[G::b0 + u] = wsum(2 + 2 * NBK, ln);
+            g[G::W0 + u] = wsum(3 + 2 * NBK, ln);
+        }
     }
 }
 
-// (one launch for the nets of a chunk: blockIdx.y = net; partial [n_nets][kESplit][kGFloats] of which the first n_part blocks are live, gacc [n_nets][kGFloats])
-__global__ void k_egrad_reduce(const float* __restrict__ partial, int n_part, int accumulate, float* __restrict__ gacc) {
+// (one launch for the nets of a chunk: blockIdx.y = net; partial [n_nets][kESplit][gf] of which the first n_part blocks are live, gacc [n_nets][gf];
+// gf = g_floats(row blocks of the model))
+__global__ void k_egrad_reduce(const float* __restrict__ partial, int n_part, int accumulate, float* __restrict__ gacc, int gf) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= kGFloats) return;
-    const float* pn = partial + (size_t)blockIdx.y * kESplit * kGFloats;
-    float* gn = gacc + (size_t)blockIdx.y * kGFloats;
+    if (i >= gf) return;
+    const float* pn = partial + (size_t)blockIdx.y * kESplit * gf;
+    float* gn = gacc + (size_t)blockIdx.y * gf;
     float sacc = accumulate ? gn[i] : 0.0f;
     int p = 0;
     for (; p + 8 <= n_part; p += 8) {   // eight loads in flight, added in block order (a runtime trip count alone left one dependent load per ~230 ns: 60 us)
         float v[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = pn[(size_t)(p + k) * kGFloats + i];
+        for (int k = 0; k < 8; ++k) v[k] = pn[(size_t)(p + k) * gf + i];
 #pragma unroll
         for (int k = 0; k < 8; ++k) sacc += v[k];
     }
-    for (; p < n_part; ++p) sacc += pn[(size_t)p * kGFloats + i];
+    for (; p < n_part; ++p) sacc += pn[(size_t)p * gf + i];
     gn[i] = sacc;
 }
 struct ENetOff {
@@ -1343,21 +1515,23 @@ __global__ void k_fill_zero(float* __restrict__ p, int64_t n) {
     if (i < n) p[i] = 0.0f;
 }
 // image units -> the reference's leaves: scales of describe_mfma_image, and the column sums folded into the biases behind a tanh (k_fold_bias)
-__global__ void k_egrad_scatter(const float* __restrict__ gacc, int n_nets, const ENetOffs offs, float* __restrict__ flat) {
+__global__ void k_egrad_scatter(const float* __restrict__ gacc, int n_nets, const ENetOffs offs, float* __restrict__ flat, int nbk) {
+    const int gf = g_floats(nbk), rows = 32 * nbk;
+    const int W1 = 128, b1 = 4224, W2 = 4288, b21 = W2 + 64 * rows, b20 = b21 + rows;   // (GL<nbk>)
     const int net = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (net >= n_nets || i >= kGFloats) return;
+    if (net >= n_nets || i >= gf) return;
     const ENetOff q = offs.n[net];
-    const float* g = gacc + (size_t)net * kGFloats;
+    const float* g = gacc + (size_t)net * gf;
     const float c1 = 2.8853900817779268f;
-    if (i < 64) flat[q.W0 + i] = c1 * g[kGW0 + i];                                  // W0[0][u]
+    if (i < 64) flat[q.W0 + i] = c1 * g[i];                                          // W0[0][u]
     else if (i < 128) flat[q.b0 + (i - 64)] = c1 * g[i];
-    else if (i < kGb1) { const int e = i - kGW1, u = e & 63; flat[q.W1 + e] = -2.0f * c1 * g[i] + c1 * g[kGb1 + u]; }
-    else if (i < kGW2) flat[q.b1 + (i - kGb1)] = c1 * g[i];
-    else if (i < kGb21) {
-        const int e = i - kGW2, k = e >> 5, jb = e & 31;
-        if (jb < q.n_out) flat[q.W2 + k * q.NO + (jb * 2 + 1)] = -2.0f * q.c2 * g[i] + q.c2 * g[kGb21 + jb];
-    } else if (i < kGb20) { const int jb = i - kGb21; if (jb < q.n_out) flat[q.b2 + jb * 2 + 1] = q.c2 * g[i]; }
-    else { const int jb = i - kGb20; if (jb < q.n_out) flat[q.b2 + jb * 2 + 0] = q.c2 * g[i]; }
+    else if (i < b1) { const int e = i - W1, u = e & 63; flat[q.W1 + e] = -2.0f * c1 * g[i] + c1 * g[b1 + u]; }
+    else if (i < W2) flat[q.b1 + (i - b1)] = c1 * g[i];
+    else if (i < b21) {
+        const int e = i - W2, k = e / rows, jb = e % rows;
+        if (jb < q.n_out) flat[q.W2 + k * q.NO + (jb * 2 + 1)] = -2.0f * q.c2 * g[i] + q.c2 * g[b21 + jb];
+    } else if (i < b20) { const int jb = i - b21; if (jb < q.n_out) flat[q.b2 + jb * 2 + 1] = q.c2 * g[i]; }
+    else { const int jb = i - b20; if (jb < q.n_out) flat[q.b2 + jb * 2 + 0] = q.c2 * g[i]; }
 }
 
 // ============================================================================ inverse / sampler of large batches (two-particle family)
@@ -1772,25 +1946,47 @@ int launch_energy_tile(const MfmaDev* mdev, const ModelDev& md, const float* tab
 
 
 // ---- host side of the matrix-core gradient path
+static int64_t ebwd_lds_floats(const MfmaDev* mdev) {
+    // the reverse kernel's LDS: constants, one net's forward and transposed images, the transposed ob_to_b, the workgroup's accumulators of (dW1, dW2)
+    return (int64_t)mdev->const_floats + mdev->net_floats + mdev->tnet_floats + mdev->nbk * mdev->nbk * 1024 + acc_blocks(mdev->nbk) * 1024;
+}
 bool energy_vjp_capable(const MfmaDev* mdev) {
-    // (the reverse kernel's LDS: constants, one net's forward and transposed images, the transposed ob_to_b, the four waves' accumulators of (dW1, dW2))
-    const int64_t lds = ((int64_t)mdev->const_floats + mdev->net_floats + mdev->tnet_floats + 1024 + kBwdWaves * kAccFloats) * (int64_t)sizeof(float);
-    return mdev->timg_off >= 0 && mdev->nbk == 1 && energy_tile_fused(mdev) && !mdev->i_gate && !mdev->p_gate && lds <= 160 * 1024 - 512;
+    return mdev->timg_off >= 0 && (mdev->nbk == 1 || mdev->nbk == 2) && energy_tile_fused(mdev) && !mdev->i_gate && !mdev->p_gate &&
+           ebwd_lds_floats(mdev) * (int64_t)sizeof(float) <= 160 * 1024 - 1024;
 }
 // floats of workspace per walker of a chunk (whole tiles), + the fixed part
 int64_t energy_vjp_floats_per_walker(int n_nets) { return (int64_t)n_nets * 12 + 12 + 4; }   // per-net input jets, adjoint jets, H psi / psi / seeds
-int64_t energy_vjp_fixed_floats(int n_nets) { return (int64_t)n_nets * kESplit * kGFloats + 128; }   // the workgroups' gradient blocks
-int energy_vjp_gacc_floats(int n_nets) { return n_nets * kGFloats; }
+int64_t energy_vjp_fixed_floats(int n_nets, int nbk) { return (int64_t)n_nets * kESplit * g_floats(nbk) + 128; }   // the workgroups' gradient blocks
+int energy_vjp_gacc_floats(int n_nets, int nbk) { return n_nets * g_floats(nbk); }
+
+template <int NBK>
+static int launch_ebwd_t(const MfmaDev* mdev, const float* tabI4, const float* tabP4, const float* st, float* adjb, const float* w_psi, const float* w_lap, int64_t B,
+                         float* partial, unsigned blocks, hipStream_t s) {
+    const int n_nets = mdev->n_nets;
+    const int lds_bytes = (int)(ebwd_lds_floats(mdev) * (int64_t)sizeof(float));
+    static DynLdsSlots cfg_p{}, cfg_f{};
+    if (int r2 = ensure_dynamic_lds(reinterpret_cast<const void*>(k_ebwd<true, NBK>), lds_bytes, &cfg_p)) return r2;
+    if (int r2 = ensure_dynamic_lds(reinterpret_cast<const void*>(k_ebwd<false, NBK>), lds_bytes, &cfg_f)) return r2;
+    for (int n = n_nets - 1; n >= 0; --n) {
+        const float* st_n = st + (size_t)n * 12 * B;
+        float* part_n = partial + (size_t)n * kESplit * GL<NBK>::floats;
+        if (n == n_nets - 1)
+            hipLaunchKernelGGL((k_ebwd<true, NBK>), dim3(blocks), dim3(kBwdWaves * 64), lds_bytes, s, *mdev, n, tabI4, tabP4, st_n, adjb, w_psi, w_lap, B, part_n);
+        else
+            hipLaunchKernelGGL((k_ebwd<false, NBK>), dim3(blocks), dim3(kBwdWaves * 64), lds_bytes, s, *mdev, n, tabI4, tabP4, st_n, adjb, w_psi, w_lap, B, part_n);
+    }
+    return WF_OK;
+}
 
 // One chunk of walkers (B a multiple of 32 except for the last chunk of a batch): forward with the per-net input jets, seeds (mode 2: from H psi of
 // this very sweep, e_loc is written; mode 1: w_psi / w_lap given), reverse net by net with the weight-gradient products behind each net.
-// gacc [n_nets][kGFloats]: accumulated over the chunks of a batch (accumulate = 0 for the first one).
+// gacc [n_nets][g_floats(nbk)]: accumulated over the chunks of a batch (accumulate = 0 for the first one).
 int launch_energy_vjp(const MfmaDev* mdev, const ModelDev& md, const float* tabI4, const float* tabP4, const float* x, int64_t B, int mode, const float* w_psi,
                       const float* w_lap, const Protons& pr, float running_avg, const float* running_avg_dev, float inv_count, float* e_loc, float* ws,
                       float* gacc, int accumulate, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (B == 0) return WF_OK;
-    const int n_nets = mdev->n_nets;
+    const int n_nets = mdev->n_nets, gf = g_floats(mdev->nbk);
     const int64_t n_tiles = (B + 31) / 32;
     float* st = ws;                                  // [n_nets][12][B]
     float* adjb = st + (size_t)n_nets * 12 * B;      // [12][B]
@@ -1798,7 +1994,7 @@ int launch_energy_vjp(const MfmaDev* mdev, const ModelDev& md, const float* tabI
     float* psi = hpsi + B;
     float* wp = psi + B;
     float* wl = wp + B;
-    float* partial = ws + (((size_t)(n_nets * 12 + 12 + 4) * B + 63) / 64) * 64;   // [n_nets][kESplit][kGFloats]
+    float* partial = ws + (((size_t)(n_nets * 12 + 12 + 4) * B + 63) / 64) * 64;   // [n_nets][kESplit][gf]
     int rc = launch_energy_tile(mdev, md, tabI4, tabP4, nullptr, x, B, pr, hpsi, psi, nullptr, nullptr, stream, st);
     if (rc) return rc;
     if (mode == 2) {
@@ -1807,26 +2003,16 @@ int launch_energy_vjp(const MfmaDev* mdev, const ModelDev& md, const float* tabI
         w_psi = wp;
         w_lap = wl;
     }
-    const int lds_bytes = (mdev->const_floats + mdev->net_floats + mdev->tnet_floats + 1024 + kBwdWaves * kAccFloats) * (int)sizeof(float);
-    static DynLdsSlots cfg_p{}, cfg_f{};
-    if (int r2 = ensure_dynamic_lds(reinterpret_cast<const void*>(k_ebwd<true>), lds_bytes, &cfg_p)) return r2;
-    if (int r2 = ensure_dynamic_lds(reinterpret_cast<const void*>(k_ebwd<false>), lds_bytes, &cfg_f)) return r2;
     const unsigned blocks = (unsigned)std::min<int64_t>((n_tiles + kBwdWaves - 1) / kBwdWaves, 256);
-    for (int n = n_nets - 1; n >= 0; --n) {
-        const float* st_n = st + (size_t)n * 12 * B;
-        if (n == n_nets - 1)
-            hipLaunchKernelGGL(k_ebwd<true>, dim3(blocks), dim3(kBwdWaves * 64), lds_bytes, s, *mdev, n, tabI4, tabP4, st_n, adjb, w_psi, w_lap, B,
-                               partial + (size_t)n * kESplit * kGFloats);
-        else
-            hipLaunchKernelGGL(k_ebwd<false>, dim3(blocks), dim3(kBwdWaves * 64), lds_bytes, s, *mdev, n, tabI4, tabP4, st_n, adjb, w_psi, w_lap, B,
-                               partial + (size_t)n * kESplit * kGFloats);
-    }
-    hipLaunchKernelGGL(k_egrad_reduce, dim3((kGFloats + 255) / 256, n_nets), dim3(256), 0, s, (const float*)partial, (int)blocks, accumulate, gacc);
+    rc = mdev->nbk == 1 ? launch_ebwd_t<1>(mdev, tabI4, tabP4, st, adjb, w_psi, w_lap, B, partial, blocks, s)
+                        : launch_ebwd_t<2>(mdev, tabI4, tabP4, st, adjb, w_psi, w_lap, B, partial, blocks, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_egrad_reduce, dim3((gf + 255) / 256, n_nets), dim3(256), 0, s, (const float*)partial, (int)blocks, accumulate, gacc, gf);
     return check();
 }
 
 // gacc -> flat gradient in the reference's leaf order (every entry written: zero first, then the live leaves)
-int launch_energy_vjp_finish(const float* gacc, int n_nets, const int* offs /* [n_nets][8]: W0, b0, W1, b1, W2, b2, NO, n_out */, const float* c2, float* flat,
+int launch_energy_vjp_finish(const float* gacc, int n_nets, int nbk, const int* offs /* [n_nets][8]: W0, b0, W1, b1, W2, b2, NO, n_out */, const float* c2, float* flat,
                              int64_t n_params, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     ENetOffs o{};
@@ -1835,7 +2021,7 @@ int launch_energy_vjp_finish(const float* gacc, int n_nets, const int* offs /* [
         o.n[n] = ENetOff{q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], c2[n]};
     }
     hipLaunchKernelGGL(k_fill_zero, dim3((unsigned)((n_params + 255) / 256)), dim3(256), 0, s, flat, n_params);
-    hipLaunchKernelGGL(k_egrad_scatter, dim3((kGFloats + 255) / 256, n_nets), dim3(256), 0, s, gacc, n_nets, o, flat);
+    hipLaunchKernelGGL(k_egrad_scatter, dim3((g_floats(nbk) + 255) / 256, n_nets), dim3(256), 0, s, gacc, n_nets, o, flat, nbk);
     return check();
 }
 

@@ -887,14 +887,14 @@ static void describe_mfma_image(const wf_model* m, int n, uint32_t base, std::ve
 
 // Decides whether the MFMA kernel covers this model and builds its parameter-independent parts.
 // i64 / p64: the fp64 tables already built by model_build (I: [4][nb][n_mesh]; prior: OB or M), o2b: [nb][nb].
-// Transposed operand images of net n for the reverse sweep of the matrix-core gradient path (k_ebwd, wf_kernels_etile.hip; D = 2, <= 32 bases):
+// Transposed operand images of net n for the reverse sweep of the matrix-core gradient path (k_ebwd, wf_kernels_etile.hip; D = 2, <= 64 bases):
 // hbar_1[k] = sum_u W1'[k][u] zbar_2[u] and hbar_2[k] = sum_j W2'[k][j] obar[j] are MFMA products whose A operand is the weight matrix with the
-// INPUT unit on the row, same entries and scales as the forward image.  Layout (floats, base = float offset inside d_mfma):
-//   TW1 hi [ob 2][t 2][s 2][lane 64][8 halves] (2048 floats), TW1 lo (2048), TW2 hi [ob 2][s 2][64][8] (1024), TW2 lo (1024), W0'[0][unit] in
+// INPUT unit on the row, same entries and scales as the forward image.  Layout (floats, base = float offset inside d_mfma; nbk = 32-row blocks of the head):
+//   TW1 hi [ob 2][t 2][s 2][lane 64][8 halves] (2048 floats), TW1 lo (2048), TW2 hi [ob 2][kb nbk][s 2][64][8] (1024 nbk), TW2 lo (1024 nbk), W0'[0][unit] in
 //   accumulator layout [ob][h][16] (64): the adjoint of the conditioner's input s is sum_u W0'[0][u] zbar_1[u].
-constexpr int kTNetFloats = 2048 + 2048 + 1024 + 1024 + 64;
+static int tnet_floats_of(int nbk) { return 2048 + 2048 + 2048 * nbk + 64; }
 static void describe_mfma_image_t(const wf_model* m, int n, uint32_t base, std::vector<PackRec>& out) {
-    const int D = m->desc.n_dim, H = kHidden;
+    const int D = m->desc.n_dim, H = kHidden, nbk = m->mdev.nbk;
     const NetLayout& nl = m->nets[n];
     const NetOffsets q = net_offsets(m, n);
     const double c1 = 2.0 * 1.4426950408889634074;
@@ -914,10 +914,10 @@ static void describe_mfma_image_t(const wf_model* m, int n, uint32_t base, std::
         const int k = 32 * ob + (lane & 31), u = 32 * t + acc_row(8 * s_ + j, lane >> 5);
         return std::make_pair(deg_hidden(u, D) >= deg_hidden(k, D) ? q.W1 + (int64_t)k * H + u : (int64_t)-1, -2.0 * c1);
     });
-    // A[m = hidden unit k][kk = basis row jb = acc_row(8 s + j, lane >> 5)] = W2'[k][(jb, d = 1)]
-    f16_block(2048, [&](uint32_t e) {
-        const int j = e & 7, lane = (e >> 3) & 63, s_ = (e >> 9) & 1, ob = (e >> 10) & 1;
-        const int k = 32 * ob + (lane & 31), jb = acc_row(8 * s_ + j, lane >> 5);
+    // A[m = hidden unit k][kk = basis row jb = 32 kb + acc_row(8 s + j, lane >> 5)] = W2'[k][(jb, d = 1)]
+    f16_block((uint32_t)(2048 * nbk), [&](uint32_t e) {
+        const int j = e & 7, lane = (e >> 3) & 63, s_ = (e >> 9) & 1, blk = e >> 10, kb = blk % nbk, ob = blk / nbk;
+        const int k = 32 * ob + (lane & 31), jb = 32 * kb + acc_row(8 * s_ + j, lane >> 5);
         const bool live = jb < nl.n_out && deg_out(1) >= deg_hidden(k, D);
         return std::make_pair(live ? q.W2 + (int64_t)k * q.NO + (jb * D + 1) : (int64_t)-1, -2.0 * c2);
     });
@@ -945,9 +945,10 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
     else if ((int64_t)consts + net_floats + 16 * kStagedGroups * (D + 1) * 32 <= lds_cap) staged = 1;   // one slot + the state area, re-staged per super-chunk
     else return WF_OK;
     // the matrix-core gradient path (two particles, <= 32 bases, Waveflow prior, IMADE layers): transposed operand images behind the constants block
-    const bool timg = D == 2 && nbk == 1 && d.prior_kind == WF_PRIOR_WAVEFLOW && (d.layer_kind == WF_LAYER_IMADE || d.n_flow_layers == 0);
-    const int tconsts = 1024;   // ob_to_b transposed: hi [s 2][lane 64][8 halves] (512 floats), lo (512)
-    const int64_t total = (int64_t)net_floats * n_nets + consts + (timg ? (int64_t)kTNetFloats * n_nets + tconsts : 0);
+    const bool timg = D == 2 && (nbk == 1 || nbk == 2) && d.prior_kind == WF_PRIOR_WAVEFLOW && (d.layer_kind == WF_LAYER_IMADE || d.n_flow_layers == 0);
+    const int tconsts = nbk * nbk * 1024;   // ob_to_b transposed: blocks [ka][ki]{hi [s 2][lane 64][8 halves] (512 floats), lo (512)}
+    const int tnet_floats = tnet_floats_of(nbk);
+    const int64_t total = (int64_t)net_floats * n_nets + consts + (timg ? (int64_t)tnet_floats * n_nets + tconsts : 0);
 
     MfmaDev& md = m->mdev;
     md = MfmaDev{};
@@ -960,8 +961,8 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
     md.i_gate = m->dev.i_gate; md.p_gate = m->dev.p_gate;
     md.p_bias = (d.prior_kind == WF_PRIOR_WAVEFLOW && !m->p_cb.empty()) ? 1 : 0;
     md.timg_off = timg ? net_floats * n_nets + consts : -1;
-    md.tnet_floats = kTNetFloats;
-    md.tconst_off = timg ? md.timg_off + kTNetFloats * n_nets : -1;
+    md.tnet_floats = tnet_floats;
+    md.tconst_off = timg ? md.timg_off + tnet_floats * n_nets : -1;
     // staged mode: one net slot + the state area of the super-chunk (16 waves x kStagedGroups tile groups x (D + 1) x 32 floats: the
     // built staged shapes run 8 waves of one tile; sized for the largest workgroup)
     m->mfma_lds_floats = consts + (staged ? net_floats + 16 * kStagedGroups * (D + 1) * 32 : net_floats * n_nets);
@@ -1062,19 +1063,24 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
     WF_HIP(hipMemset(m->d_mfma, 0, (size_t)total * sizeof(float)));
     WF_HIP(hipMemcpy(m->d_mfma + md.const_img_off, m->mfma_consts.data(), m->mfma_consts.size() * sizeof(float), hipMemcpyHostToDevice));
     if (timg && spline_prior) {
-        // wbar[a] = sum_i M[a][i] cbar[i] (M = ob_to_b with the boundary map folded in, as the forward image holds it): A[m = a = lane & 31][kk = i = acc_row(8 s + j, lane >> 5)]
+        // wbar[a] = sum_i M[a][i] cbar[i] (M = ob_to_b with the boundary map folded in, as the forward image holds it): block (ka, ki) in the order
+        // prior_c_block reads (output block first): A[m = a = 32 ka + (lane & 31)][kk = i = 32 ki + acc_row(8 s + j, lane >> 5)]
         std::vector<float> tc(tconsts, 0.0f);
         _Float16* o = reinterpret_cast<_Float16*>(tc.data());
         const int nb = m->p_nb;
-        for (int s_ = 0; s_ < 2; ++s_)
-            for (int lane = 0; lane < 64; ++lane)
-                for (int j = 0; j < 8; ++j) {
-                    const int a = lane & 31, i = acc_row(8 * s_ + j, lane >> 5);
-                    const float v = (i < nb && a < nb) ? (float)o2b[(size_t)a * nb + i] : 0.0f;
-                    const _Float16 hi = (_Float16)v;
-                    o[(s_ * 64 + lane) * 8 + j] = hi;
-                    o[1024 + (s_ * 64 + lane) * 8 + j] = (_Float16)(v - (float)hi);
-                }
+        for (int ka = 0; ka < nbk; ++ka)
+            for (int ki = 0; ki < nbk; ++ki) {
+                _Float16* blk = o + (size_t)(ka * nbk + ki) * 2048;
+                for (int s_ = 0; s_ < 2; ++s_)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int a = 32 * ka + (lane & 31), i = 32 * ki + acc_row(8 * s_ + j, lane >> 5);
+                            const float v = (i < nb && a < nb) ? (float)o2b[(size_t)a * nb + i] : 0.0f;
+                            const _Float16 hi = (_Float16)v;
+                            blk[(s_ * 64 + lane) * 8 + j] = hi;
+                            blk[1024 + (s_ * 64 + lane) * 8 + j] = (_Float16)(v - (float)hi);
+                        }
+            }
         WF_HIP(hipMemcpy(m->d_mfma + md.tconst_off, tc.data(), tc.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     return WF_OK;
@@ -1153,7 +1159,7 @@ static int grad_prepare(wf_model* m) {
     // Fixed per model, because workspace sizes depend on it; WF_GRAD_R3 (read here) selects R3 for A/B tests.
     m->ring2 = (getenv("WF_GRAD_R3") || D > kTapedLaplacianMaxD) ? 1 : 2;
     if (m->grad_psi_ok && m->mfma_ok && energy_vjp_capable(&m->mdev)) {
-        int rc = dev_alloc(m, &m->d_egacc, (size_t)energy_vjp_gacc_floats((int)m->nets.size()));
+        int rc = dev_alloc(m, &m->d_egacc, (size_t)energy_vjp_gacc_floats((int)m->nets.size(), m->mdev.nbk));
         if (rc) return rc;
     }
     const int n_nets = (int)m->nets.size();
@@ -1713,7 +1719,7 @@ static bool grad_tile_capable_at(const wf_model* m, int64_t B) {
     const char* e = getenv("WF_GRAD_TILE_MIN");
     const int64_t tile_min = e ? atoll(e) : kGradTileMin;
     const wf_model_desc& d = m->desc;
-    return tile_min > 0 && B >= tile_min && d.n_dim == 2 && m->nbp == 32 && m->mfma_ok && d.box_kind == WF_BOX_MEAN && d.layer_kind == WF_LAYER_IMADE && d.n_flow_layers > 0 &&
+    return tile_min > 0 && B >= tile_min && d.n_dim == 2 && (m->nbp == 32 || m->nbp == 64) && m->mfma_ok && d.box_kind == WF_BOX_MEAN && d.layer_kind == WF_LAYER_IMADE && d.n_flow_layers > 0 &&
            d.prior_kind == WF_PRIOR_WAVEFLOW && m->d_tabI4c && m->d_tabP4c && energy_vjp_capable(&m->mdev);
 }
 
@@ -1724,7 +1730,7 @@ static int64_t vjp_ws_bytes(const wf_model* m, int64_t B, bool second_order) {
     int64_t bytes = chunk * vjp_bytes_per_walker(m, second_order);
     if (second_order && grad_tile_capable_at(m, B)) {   // the matrix-core gradient path has a fixed part (the partial gradient blocks of every net): only where the path applies (a smaller WF_GRAD_TILE_MIN at query time moves it)
         const int n_nets = (int)m->nets.size();
-        bytes = std::max<int64_t>(bytes, (energy_vjp_fixed_floats(n_nets) + ((chunk + 31) / 32 * 32) * energy_vjp_floats_per_walker(n_nets)) * (int64_t)sizeof(float));
+        bytes = std::max<int64_t>(bytes, (energy_vjp_fixed_floats(n_nets, m->mdev.nbk) + ((chunk + 31) / 32 * 32) * energy_vjp_floats_per_walker(n_nets)) * (int64_t)sizeof(float));
     }
     return bytes;
 }
@@ -1759,7 +1765,7 @@ static int run_vjp_chunks(const wf_model* m, int mode, bool second_order, const 
     if ((mode == 1 || mode == 2) && second_order && m->d_egacc) {
         const int64_t tile_min = 1;
         const bool family = grad_tile_capable_at(m, B) && !m->eval_tables_stale && !f16_overflow(m);
-        const int64_t per = energy_vjp_floats_per_walker(n_nets) * (int64_t)sizeof(float), fixed = energy_vjp_fixed_floats(n_nets) * (int64_t)sizeof(float);
+        const int64_t per = energy_vjp_floats_per_walker(n_nets) * (int64_t)sizeof(float), fixed = energy_vjp_fixed_floats(n_nets, m->mdev.nbk) * (int64_t)sizeof(float);
         const int64_t tchunk = workspace_bytes > fixed ? ((workspace_bytes - fixed) / per) / 32 * 32 : 0;
         if (family && tile_min > 0 && B >= tile_min && tchunk >= 32) {
             Protons none{};
@@ -1779,7 +1785,7 @@ static int run_vjp_chunks(const wf_model* m, int mode, bool second_order, const 
                 c2[n] = net_has_sigmoid_head(m, n) ? -1.4426950408889634f : 1.0f;
             }
             if (defer_gather_split) *defer_gather_split = 0;   // the gradient is in grad_dev
-            return launch_energy_vjp_finish(m->d_egacc, n_nets, offs.data(), c2.data(), grad_dev, m->n_params, stream);
+            return launch_energy_vjp_finish(m->d_egacc, n_nets, m->mdev.nbk, offs.data(), c2.data(), grad_dev, m->n_params, stream);
         }
     }
     const bool single = B <= chunk;   // one chunk: the partial images are summed by the gather itself (one launch less)
