@@ -556,6 +556,7 @@ using TA = adj::T2t<float>;
 #ifndef WF_BWD_WAVES
 #define WF_BWD_WAVES 4
 #endif
+#define WF_BWD_WAVES_ WF_BWD_WAVES
 constexpr int kBwdWaves = WF_BWD_WAVES;
 // Gradient block of a net (floats, in the units of the MFMA image; NBK = 32-row blocks of the head per dimension):
 //   GW0 [64] (d / d W0'[0][u]), Gb0 [64], GW1 [64][64] (k, u), Gb1 [64], GW2 [64][32 NBK] (k, row), Gb2 of dimension 1 [32 NBK], of dimension 0 [32 NBK]
@@ -569,6 +570,15 @@ constexpr int kESplit = 256;        // partial blocks per net: one per workgroup
 // LDS accumulators of a workgroup: blocks 0..3 = dW1 (k block mb = b >> 1, u block nb = b & 1), 4.. = dW2 (k block (b - 4) / NBK, row block (b - 4) % NBK),
 // each [4 q][64 lanes][4] (register 4 q + e of the lane: one conflict-free ds_read_b128 per q)
 constexpr int acc_blocks(int nbk) { return 4 + 2 * nbk; }
+// sets of accumulator blocks per workgroup.  One row block: a private set per wave (4 x 24 KB beside 66 KB of images), summed in wave order at the end.
+// Two row blocks: the four private sets (128 KB) do not fit beside 103 KB of images -- ONE shared set filled in tile order (acc_add).  -DWF_ACC_SHARED
+// (experiment) shares the set for one row block too: 1.040 ms per loss + gradient of 2^17 walkers against 0.985 ms (the waves move in step, one add apart:
+// any jitter of one holds up the other three); profiles/r04_grad33_times.txt
+#ifdef WF_ACC_SHARED
+constexpr int acc_sets(int) { return 1; }
+#else
+constexpr int acc_sets(int nbk) { return nbk == 1 ? WF_BWD_WAVES_ : 1; }
+#endif
 __device__ __forceinline__ int acc_rho(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }   // row of register r in lane half h (accumulator layout)
 __device__ __forceinline__ f32x16 acc_load(const float* aw, int b, int lane) {
     f32x16 a;
@@ -1003,15 +1013,28 @@ __device__ __forceinline__ void wgrad_block(f32x16& p, const Frag& xt, const Fra
 // block is therefore formed in the same order whatever the timing (bitwise reproducible gradients) although the waves share ONE set of blocks.  Progress:
 // tile k waits only for tile k - 1's wave to pass the same point, tile 0 for nobody; the waves of a workgroup are resident together and each works
 // through its tiles in increasing k, so every wait ends (the waves fall into step one add apart: ~200 cycles in a tile of ~10^5).
+template <bool SHARED_>
 __device__ __forceinline__ void acc_add(float* acc, int* ticket, int b, int k, int lane, const f32x16& p, float un) {
-    while (__hip_atomic_load(ticket + b, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != k) __builtin_amdgcn_s_sleep(1);
+#ifdef WF_ACC_NOTICKET   // timing experiment only (racy sums): what the tile order costs
+    constexpr bool SHARED = false;
+#else
+    constexpr bool SHARED = SHARED_;
+#endif
+    if (SHARED)
+        while (__hip_atomic_load(ticket + b, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != k) __builtin_amdgcn_s_sleep(1);
     f32x16 a = acc_load(acc, b, lane);
 #pragma unroll
     for (int r = 0; r < 16; ++r) a[r] = __builtin_fmaf(p[r], un, a[r]);
     acc_store(acc, b, lane, a);
-    __hip_atomic_store(ticket + b, k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (SHARED) __hip_atomic_store(ticket + b, k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// -DWF_MARKS: comment lines in the assembly at the phase boundaries of k_ebwd (scratch/r04_spill_phases.py counts the spill traffic per phase)
+#ifdef WF_MARKS
+#define WF_MARK(name) asm volatile("; WF_MARK " name)
+#else
+#define WF_MARK(name)
+#endif
 template <bool PRIOR, int NBK>
 __global__ __launch_bounds__(kBwdWaves * 64) void k_ebwd(const MfmaDev mm, int net_index, const float* __restrict__ tabI, const float* __restrict__ tabP,
                                                           const float* __restrict__ st_in, float* __restrict__ adjb, const float* __restrict__ w_psi,
@@ -1022,6 +1045,8 @@ __global__ __launch_bounds__(kBwdWaves * 64) void k_ebwd(const MfmaDev mm, int n
     constexpr int kThreads = kBwdWaves * 64;
     constexpr int kMeshStride = 128 * NBK;   // floats per mesh point of the regrouped tables (k_efused)
     constexpr int kAcc = acc_blocks(NBK);
+    constexpr int kSets = acc_sets(NBK);
+    constexpr bool kShared = kSets == 1;
     constexpr int kKinds = 4 + 2 * NBK;      // per-lane sums: Gb1 (two unit blocks), Gb2 of dimension 1 (NBK), of dimension 0 (NBK), Gb0, GW0
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ int bnd_s[32 * NBK];
@@ -1038,9 +1063,10 @@ __global__ __launch_bounds__(kBwdWaves * 64) void k_ebwd(const MfmaDev mm, int n
     stage_floats<kThreads>(mm.image + mm.timg_off + (size_t)net_index * mm.tnet_floats, tnet_l, mm.tnet_floats);
     stage_floats<kThreads>(mm.image + mm.tconst_off, tcon_l, NBK * NBK * 1024);
     // the workgroup's accumulators of (dW1, dW2) behind the images
-    float* acc = tcon_l + NBK * NBK * 1024;
-    for (int i = threadIdx.x; i < kAcc * 1024; i += kThreads) acc[i] = 0.0f;
+    float* acc_all = tcon_l + NBK * NBK * 1024;
+    for (int i = threadIdx.x; i < kSets * kAcc * 1024; i += kThreads) acc_all[i] = 0.0f;
     __syncthreads();
+    float* acc = acc_all + (kShared ? 0 : (threadIdx.x >> 6) * kAcc * 1024);
     // bias / input-layer sums of this lane over its wave's tiles: Gb1 and Gb2 (dimension 1) of unit / row (lane & 31) of its block (transposed operands:
     // partial over the lane half's 16 walkers), Gb2 of dimension 0, Gb0, GW0 in the lane assignment of the DPP sums below
     float gb1[2] = {0.0f, 0.0f}, gb21[NBK], gb20[NBK], gb0s = 0.0f, gw0s = 0.0f;
@@ -1106,6 +1132,7 @@ __global__ __launch_bounds__(kBwdWaves * 64) void k_ebwd(const MfmaDev mm, int n
         const int64_t wl = valid ? w : B - 1;
         // (padding lanes of the last tile repeat walker B - 1 with zero adjoints: their columns add nothing to the sums over walkers)
         const JA u0 = ja_load(st_in, 0, B, wl), u1 = ja_load(st_in, 1, B, wl);
+        WF_MARK("tile_start");
         // ---- the net's forward to the head triples o.  The second hidden layer's pre-activations z2, which the reverse needs, are computed again
         // behind the head: 96 registers less across the head algebra
         f32x16 o[NBK][NCH];
@@ -1113,6 +1140,7 @@ __global__ __launch_bounds__(kBwdWaves * 64) void k_ebwd(const MfmaDev mm, int n
             f32x16 z2a[NCH], z2b[NCH];
             cond_fwd<true, NBK>(net, u0.v, u1.v, lane, z2a, z2b, o);
         }
+        WF_MARK("fwd_done");
         // ---- head: forward sums, pullback to adjoint head triples ob (dimension 1) and ob0 (dimension 0, channel 0)
         f32x16 ob[NBK][NCH], ob0[NBK];
         JA u0b = adj::jzero<float>(), u1b = adj::jzero<float>(), ldb = adj::jzero<float>();
@@ -1286,6 +1314,7 @@ __global__ __launch_bounds__(kBwdWaves * 64) void k_ebwd(const MfmaDev mm, int n
                 }
             }
         }
+        WF_MARK("head_done");
         // Gb2 of dimension 0: sum over the tile's walkers of obar0 (16 registers per half: DPP sums; lane (j, h) keeps register j & 15 where j < 16)
 #pragma unroll
         for (int kb = 0; kb < NBK; ++kb) {
@@ -1307,6 +1336,7 @@ __global__ __launch_bounds__(kBwdWaves * 64) void k_ebwd(const MfmaDev mm, int n
             f32x16 o2[NBK][NCH];
             cond_fwd<false, NBK>(net, u0.v, u1.v, lane, z2a, z2b, o2);
         }
+        WF_MARK("refwd_done");
         // dW2[k][row] = sum_c sum_w X2_c[k][w] obar_c[row][w]: X2 = act(z2), block by block (32 units: 48 registers of fragments at a time); both operands
         // transposed on the matrix cores; the 2 x NBK blocks of the product go to the accumulator blocks 4 + (k block) NBK + (row block).  Gb2 rides on
         // obar's transposes.
@@ -1338,9 +1368,10 @@ __global__ __launch_bounds__(kBwdWaves * 64) void k_ebwd(const MfmaDev mm, int n
                     for (int kb = 0; kb < NBK; ++kb) wgrad_block(p[kb], xt, yt[kb][c]);
                 }
 #pragma unroll
-                for (int kb = 0; kb < NBK; ++kb) acc_add(acc, ticket, 4 + mb * NBK + kb, k, lane, p[kb], __builtin_amdgcn_ldexpf(1.0f, E));
+                for (int kb = 0; kb < NBK; ++kb) acc_add<kShared>(acc, ticket, 4 + mb * NBK + kb, k, lane, p[kb], __builtin_amdgcn_ldexpf(1.0f, E));
             }
         }
+        WF_MARK("dW2_done");
         f32x16 g0[NCH], g1[NCH];
         {
 #pragma unroll
@@ -1357,6 +1388,7 @@ __global__ __launch_bounds__(kBwdWaves * 64) void k_ebwd(const MfmaDev mm, int n
             act_block_bwd(z2a, g0);
             act_block_bwd(z2b, g1);
             to_frags_all<true>(g0, g1, f, e);
+            WF_MARK("zbar2_done");
             // dW1[k][u] = sum_c sum_w X1_c[k][w] zbar2_c[u][w] while the fragments of zbar2 (f, exponents e) are at hand and before the product that
             // consumes them: X1, the first hidden layer's activation triples, is recomputed block by block from (s, 1, 0) (two f32 MFMAs and 16
             // activations per lane and block).  Accumulator blocks 0 .. 3 = (k block mb, u block nb); Gb1 rides on the transposes of zbar2.
@@ -1388,10 +1420,11 @@ __global__ __launch_bounds__(kBwdWaves * 64) void k_ebwd(const MfmaDev mm, int n
                             wgrad_block(p, xt[c], yt);
                             if (bias) gb1[nb] = __builtin_fmaf(rs, __builtin_amdgcn_ldexpf(1.0f, e[0]), gb1[nb]);
                         }
-                        acc_add(acc, ticket, 2 * mb + nb, k, lane, p, un);
+                        acc_add<kShared>(acc, ticket, 2 * mb + nb, k, lane, p, un);
                     }
                 }
             }
+            WF_MARK("dW1_done");
 #pragma unroll
             for (int c = 0; c < NCH; ++c) { g0[c] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; g1[c] = g0[c]; }
             dense64_block<NCH>(TW1h, TW1l, f, g0, lane);
@@ -1435,6 +1468,7 @@ __global__ __launch_bounds__(kBwdWaves * 64) void k_ebwd(const MfmaDev mm, int n
             for (int r = 0; r < 16; ++r) sbar = __builtin_fmaf(wa[r], g0[0][r], __builtin_fmaf(wb2[r], g1[0][r], sbar));
             u0b.v += xhalf_sum(sbar);
         }
+        WF_MARK("tile_end");
         if (valid && h == 0) {
             ja_store(adjb, 0, B, w, u0b);
             ja_store(adjb, 1, B, w, u1b);
@@ -1462,8 +1496,11 @@ __global__ __launch_bounds__(kBwdWaves * 64) void k_ebwd(const MfmaDev mm, int n
     for (int i = threadIdx.x; i < kAcc * 1024; i += kThreads) {
         const int b = i >> 10, q = (i >> 8) & 3, ln = (i >> 2) & 63, r = 4 * q + (i & 3);
         const int row = acc_rho(r, ln >> 5), n = ln & 31;
-        if (b < 4) g[G::W1 + (32 * (b >> 1) + row) * 64 + 32 * (b & 1) + n] = acc[i];
-        else g[G::W2 + (32 * ((b - 4) / NBK) + row) * (32 * NBK) + 32 * ((b - 4) % NBK) + n] = acc[i];
+        float a = 0.0f;
+#pragma unroll
+        for (int st = 0; st < kSets; ++st) a += acc_all[st * kAcc * 1024 + i];
+        if (b < 4) g[G::W1 + (32 * (b >> 1) + row) * 64 + 32 * (b & 1) + n] = a;
+        else g[G::W2 + (32 * ((b - 4) / NBK) + row) * (32 * NBK) + 32 * ((b - 4) % NBK) + n] = a;
     }
     for (int i = threadIdx.x; i < 128 + 64 * NBK; i += kThreads) {
         if (i < 64) {                      // Gb1[u]: u block = i >> 5; the two lane halves hold the two halves of the tile's walkers
@@ -1948,7 +1985,7 @@ int launch_energy_tile(const MfmaDev* mdev, const ModelDev& md, const float* tab
 // ---- host side of the matrix-core gradient path
 static int64_t ebwd_lds_floats(const MfmaDev* mdev) {
     // the reverse kernel's LDS: constants, one net's forward and transposed images, the transposed ob_to_b, the workgroup's accumulators of (dW1, dW2)
-    return (int64_t)mdev->const_floats + mdev->net_floats + mdev->tnet_floats + mdev->nbk * mdev->nbk * 1024 + acc_blocks(mdev->nbk) * 1024;
+    return (int64_t)mdev->const_floats + mdev->net_floats + mdev->tnet_floats + mdev->nbk * mdev->nbk * 1024 + acc_sets(mdev->nbk) * acc_blocks(mdev->nbk) * 1024;
 }
 bool energy_vjp_capable(const MfmaDev* mdev) {
     return mdev->timg_off >= 0 && (mdev->nbk == 1 || mdev->nbk == 2) && energy_tile_fused(mdev) && !mdev->i_gate && !mdev->p_gate &&
