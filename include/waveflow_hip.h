@@ -245,7 +245,9 @@ int wf_hamiltonian_fwd(const wf_model* m, const float* x_dev, int64_t B, const f
  * reference where they only enter multiplied by their mask).  The table lerp differentiates to the next cached table and
  * the order beyond the last cached one clamps to it (JAX's out-of-range index semantics at isplines_jax.py:65).
  * workspace: wf_psi_vjp_workspace_bytes(m, B) bytes suffice for any B (larger batches are processed in chunks of what the
- * workspace holds).  Same model coverage as wf_hamiltonian_fwd. */
+ * workspace holds).  Same model coverage as wf_hamiltonian_fwd.  Batches >= 16384 (WF_GRAD_TILE_MIN, read per call) of ungated two-particle
+ * models with <= 64 bases take the matrix-core path (wf_kernels_etile.hip: k_efused, k_ebwd per net; <= 32 bases since round 3, 33..64 since
+ * round 4); everything else the reverse wave sweeps.  Bitwise reproducible on either path. */
 int64_t wf_psi_vjp_workspace_bytes(const wf_model* m, int64_t B);
 int wf_psi_vjp(const wf_model* m, const float* x_dev, int64_t B, const float* w_psi_dev, const float* w_lap_dev, float* grad_dev,
                void* workspace_dev, int64_t workspace_bytes, void* stream);
