@@ -14,7 +14,29 @@ import os
 import sys
 import time
 
-import numpy as np
+
+def cpu_share():
+    """CPUs this process may use: the scheduler affinity, cut to the cgroup's quota (cpu.max) when there is one."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+# The GPU box shows every hardware thread of the host (256) under a 16-CPU quota.  Thread pools sized by the former (OpenMP of numpy / torch)
+# overrun the quota, and their idle workers keep spinning for KMP_BLOCKTIME (200 ms) after a parallel region: the cgroup then stalls the whole
+# process -- the launching thread included -- until the next period.  Seen as a 40 ms hole in a 6 ms timed region, in one run out of five
+# (cpu.stat: nr_throttled 4, throttled_usec 9.7e6 after one bench run).  Size the pools by the share, and let idle workers sleep; set before
+# numpy / torch load their runtimes.
+for _k, _v in (("OMP_NUM_THREADS", str(min(cpu_share(), 16))), ("MKL_NUM_THREADS", str(min(cpu_share(), 16))), ("OMP_WAIT_POLICY", "PASSIVE"),
+               ("KMP_BLOCKTIME", "0"), ("GOMP_SPINCOUNT", "0")):
+    os.environ.setdefault(_k, _v)
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -304,14 +326,7 @@ def walkers(B, seed):
 
 def host_cores():
     """Cores this process may really use: the affinity mask capped by the cgroup CPU quota."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        if quota != "max":
-            n = min(n, max(1, int(int(quota) / int(period))))
-    except Exception:
-        pass
-    return max(1, n)
+    return cpu_share()
 
 
 def cpu_baseline(flat, x_host, budget_s=10.0):

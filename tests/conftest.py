@@ -1,8 +1,25 @@
 import os
 import sys
 
-import numpy as np
-import pytest
+
+def _cpu_share():
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+# (bench.py, top: thread pools sized by the host's 256 hardware threads overrun the GPU box's 16-CPU quota and the cgroup stalls the process)
+# (the pools only: a passive wait policy triples the CPU suite's time -- the torch autograd oracle is thousands of small parallel regions)
+for _k, _v in (("OMP_NUM_THREADS", str(min(_cpu_share(), 16))), ("MKL_NUM_THREADS", str(min(_cpu_share(), 16)))):
+    os.environ.setdefault(_k, _v)
+
+import numpy as np  # noqa: E402
+import pytest  # noqa: E402
 
 os.environ.setdefault("WF_POISON", "1")   # NaN-fill fresh device allocations of the library: unwritten reads cannot pass by luck
 
