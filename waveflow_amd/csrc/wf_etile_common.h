@@ -95,31 +95,37 @@ __device__ __forceinline__ int col_exponent(float amax) {
     const float m = xhalf_max(amax);
     return m > 0.0f ? __builtin_amdgcn_frexp_expf(m) : 0;
 }
-// (x, x', x'') of one 32-unit block (3 channels x 16 registers) -> (r, r' x', r' x'' + r'' x'^2), in place
-__device__ __forceinline__ void act_block(f32x16 (&x)[NCH]) {
+// (x, x', x'') of one 32-unit block (3 channels x 16 registers) -> (r, r' x', r' x'' + r'' x'^2), in place.  CH = 1: the value channel alone (the staged
+// sampler's conditioner launches, which read nothing else)
+template <int CH = NCH>
+__device__ __forceinline__ void act_block(f32x16 (&x)[CH]) {
+    static_assert(CH == 1 || CH == NCH, "value channel alone, or the Taylor triple");
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const float rr = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x[0][r]) + 1.0f);
-        const float r1 = -0.6931471805599453f * __builtin_fmaf(-rr, rr, rr);                      // r' = -ln2 r (1 - r)
-        const float k = __builtin_fmaf(1.3862943611198906f, rr, -0.6931471805599453f);           // r'' / r' = -ln2 (1 - 2 r)
-        const float x1 = x[1][r], x2 = x[2][r];
         x[0][r] = rr;
-        x[1][r] = r1 * x1;
-        x[2][r] = r1 * __builtin_fmaf(k * x1, x1, x2);                                            // r' x'' + r'' x'^2
+        if (CH == NCH) {
+            const float r1 = -0.6931471805599453f * __builtin_fmaf(-rr, rr, rr);                      // r' = -ln2 r (1 - r)
+            const float k = __builtin_fmaf(1.3862943611198906f, rr, -0.6931471805599453f);           // r'' / r' = -ln2 (1 - 2 r)
+            const float x1 = x[CH - 2][r], x2 = x[CH - 1][r];
+            x[CH - 2][r] = r1 * x1;
+            x[CH - 1][r] = r1 * __builtin_fmaf(k * x1, x1, x2);                                        // r' x'' + r'' x'^2
+        }
     }
 }
 // two blocks of r jets -> B fragments of the next layer, derivative channels scaled by 2^-e[c] (e[0] = 0: r lies in (0, 1))
-__device__ __forceinline__ void to_frags(const f32x16 (&blk0)[NCH], const f32x16 (&blk1)[NCH], Frag (&f)[NCH][2], int (&e)[NCH]) {
+template <int CH = NCH>
+__device__ __forceinline__ void to_frags(const f32x16 (&blk0)[CH], const f32x16 (&blk1)[CH], Frag (&f)[CH][2], int (&e)[CH]) {
     e[0] = 0;
 #pragma unroll
-    for (int c = 1; c < NCH; ++c) {
+    for (int c = 1; c < CH; ++c) {
         float amax = 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) amax = fmaxf(amax, fmaxf(fabsf(blk0[c][r]), fabsf(blk1[c][r])));
         e[c] = col_exponent(amax);
     }
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
+    for (int c = 0; c < CH; ++c) {
         const float sc = __builtin_amdgcn_ldexpf(1.0f, -e[c]);
 #pragma unroll
         for (int ob = 0; ob < 2; ++ob)
@@ -132,18 +138,20 @@ __device__ __forceinline__ void to_frags(const f32x16 (&blk0)[NCH], const f32x16
             }
     }
 }
-__device__ __forceinline__ void unscale(f32x16 (&acc)[NCH], const int (&e)[NCH]) {
+template <int CH = NCH>
+__device__ __forceinline__ void unscale(f32x16 (&acc)[CH], const int (&e)[CH]) {
 #pragma unroll
-    for (int c = 1; c < NCH; ++c) {
+    for (int c = 1; c < CH; ++c) {
         const float sc = __builtin_amdgcn_ldexpf(1.0f, e[c]);
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[c][r] = acc[c][r] * sc;
     }
 }
-__device__ __forceinline__ void init_acc(f32x16 (&acc)[NCH], const float* bias16) {
+template <int CH = NCH>
+__device__ __forceinline__ void init_acc(f32x16 (&acc)[CH], const float* bias16) {
     acc[0] = load16(bias16);
 #pragma unroll
-    for (int c = 1; c < NCH; ++c) acc[c] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int c = 1; c < CH; ++c) acc[c] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 }
 
 
@@ -244,18 +252,20 @@ __device__ __forceinline__ void prior_rows(PriorSums& a, const f32x16 (&c)[NCH],
 
 // the prior head behind cond_out: of[ki][c] = fragments of w = o * keep (every (walker, channel) column of the 32 * NBK rows scaled by one power of
 // two: the head is unbounded), eo[c] the exponents, s1 = sum of the raw outputs (model_factory.py:69: its sign, as in k_mfma)
-template <int NBK>
-__device__ __forceinline__ void prior_frags(f32x16 (&o)[NBK][NCH], const float* fkP, int lane, Frag (&of)[NBK][NCH], int (&eo)[NCH], float& s1,
+template <int NBK, int CH = NCH>
+__device__ __forceinline__ void prior_frags(f32x16 (&o)[NBK][CH], const float* fkP, int lane, Frag (&of)[NBK][CH], int (&eo)[CH], float& s1,
                                             float* sder = nullptr /* [2]: the sums of the derivative channels (a boundary map with a constant term needs them) */) {
     const int h = lane >> 5;
     s1 = 0.0f;
-    float amax[NCH] = {0.0f, 0.0f, 0.0f};
-    if (sder) {
+    float amax[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) amax[c] = 0.0f;
+    if (CH == NCH && sder) {
         float d1 = 0.0f, d2 = 0.0f;
 #pragma unroll
         for (int kb = 0; kb < NBK; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { d1 += o[kb][1][r]; d2 += o[kb][2][r]; }
+            for (int r = 0; r < 16; ++r) { d1 += o[kb][CH - 2][r]; d2 += o[kb][CH - 1][r]; }
         sder[0] = xhalf_sum(d1);
         sder[1] = xhalf_sum(d2);
     }
@@ -265,7 +275,7 @@ __device__ __forceinline__ void prior_frags(f32x16 (&o)[NBK][NCH], const float* 
 #pragma unroll
         for (int r = 0; r < 16; ++r) s1 += o[kb][0][r];
 #pragma unroll
-        for (int c = 0; c < NCH; ++c)
+        for (int c = 0; c < CH; ++c)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 o[kb][c][r] = o[kb][c][r] * keep[r];
@@ -274,7 +284,7 @@ __device__ __forceinline__ void prior_frags(f32x16 (&o)[NBK][NCH], const float* 
     }
     s1 = xhalf_sum(s1);
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
+    for (int c = 0; c < CH; ++c) {
         eo[c] = col_exponent(amax[c]);
         const float sc = __builtin_amdgcn_ldexpf(1.0f, -eo[c]);
 #pragma unroll
@@ -289,10 +299,10 @@ __device__ __forceinline__ void prior_frags(f32x16 (&o)[NBK][NCH], const float* 
     }
 }
 // block ko of c = w @ ob_to_b (obh: [ko][ki]{hi 1024, lo 1024} halves in f16-MFMA A order), three channels
-template <int NBK>
-__device__ __forceinline__ void prior_c_block(const _Float16* obh, const Frag (&of)[NBK][NCH], const int (&eo)[NCH], int ko, int lane, f32x16 (&cblk)[NCH]) {
+template <int NBK, int CH = NCH>
+__device__ __forceinline__ void prior_c_block(const _Float16* obh, const Frag (&of)[NBK][CH], const int (&eo)[CH], int ko, int lane, f32x16 (&cblk)[CH]) {
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
+    for (int c = 0; c < CH; ++c) {
         f32x16 acc = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int ki = 0; ki < NBK; ++ki)

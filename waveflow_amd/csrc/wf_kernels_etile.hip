@@ -45,73 +45,73 @@ using O2 = NetOff<2, 1>;
 //   cond_hidden   the two hidden layers: B fragments (split fp16, derivative channels scaled by 2^-e) of the second hidden layer's activations
 //   cond_out      one 32-row output block of dimension 1: Taylor triples (f, f', f'') in u_0 of the head's pre-activations, accumulator layout
 //   prior_c       the prior head's c = (o * keep) @ ob_to_b as triples, one 32-row block of c at a time, + the sum of the raw outputs (sign)
-template <int NBK>
-__device__ __forceinline__ void cond_hidden(const float* net, float u0v, float u1v, int lane, Frag (&f)[NCH][2], int (&e)[NCH]) {
+template <int NBK, int CH = NCH>
+__device__ __forceinline__ void cond_hidden(const float* net, float u0v, float u1v, int lane, Frag (&f)[CH][2], int (&e)[CH]) {
     using O = NetOff<2, NBK>;
     const int h = lane >> 5;
     // the conditioner's inputs: (u_0, u_1) values; the Taylor seed in u_0 is (u_0, 1, 0) (u_1 reaches no hidden unit: masked weights)
     const float in0[2] = {u0v, 1.0f}, in1[2] = {u1v, 0.0f};
     // ---- layer 1 (f32 MFMA, K = 2: the two coordinates), both 32-unit blocks; the second-derivative channel starts at zero
-    f32x16 a0[NCH], a1[NCH];
-    init_acc(a0, net + O::b0 + (0 * 2 + h) * 16);
-    init_acc(a1, net + O::b0 + (1 * 2 + h) * 16);
+    f32x16 a0[CH], a1[CH];
+    init_acc<CH>(a0, net + O::b0 + (0 * 2 + h) * 16);
+    init_acc<CH>(a1, net + O::b0 + (1 * 2 + h) * 16);
     {
         const float w0 = net[O::W0 + 0 * 64 + lane], w1 = net[O::W0 + 1 * 64 + lane];
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
+        for (int c = 0; c < (CH < 2 ? CH : 2); ++c) {
             a0[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, h ? in1[c] : in0[c], a0[c], 0, 0, 0);
             a1[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, h ? in1[c] : in0[c], a1[c], 0, 0, 0);
         }
     }
-    act_block(a0);
-    act_block(a1);
-    to_frags(a0, a1, f, e);
+    act_block<CH>(a0);
+    act_block<CH>(a1);
+    to_frags<CH>(a0, a1, f, e);
     // ---- layer 2
     const _Float16* W1h = reinterpret_cast<const _Float16*>(net + O::W1h);
     const _Float16* W1l = reinterpret_cast<const _Float16*>(net + O::W1l);
-    init_acc(a0, net + O::b1 + (0 + h) * 16);
-    init_acc(a1, net + O::b1 + (2 + h) * 16);
-    dense64_block<NCH>(W1h, W1l, f, a0, lane);
-    dense64_block<NCH>(W1h + 2048, W1l + 2048, f, a1, lane);
-    unscale(a0, e);
-    unscale(a1, e);
-    act_block(a0);
-    act_block(a1);
-    to_frags(a0, a1, f, e);
+    init_acc<CH>(a0, net + O::b1 + (0 + h) * 16);
+    init_acc<CH>(a1, net + O::b1 + (2 + h) * 16);
+    dense64_block<CH>(W1h, W1l, f, a0, lane);
+    dense64_block<CH>(W1h + 2048, W1l + 2048, f, a1, lane);
+    unscale<CH>(a0, e);
+    unscale<CH>(a1, e);
+    act_block<CH>(a0);
+    act_block<CH>(a1);
+    to_frags<CH>(a0, a1, f, e);
 }
 // output block kb of dimension 1 (dimension 0 is table-driven: k_prepare_dim0)
-template <int NBK>
-__device__ __forceinline__ void cond_out(const float* net, const Frag (&f)[NCH][2], const int (&e)[NCH], int kb, int lane, f32x16 (&a0)[NCH]) {
+template <int NBK, int CH = NCH>
+__device__ __forceinline__ void cond_out(const float* net, const Frag (&f)[CH][2], const int (&e)[CH], int kb, int lane, f32x16 (&a0)[CH]) {
     using O = NetOff<2, NBK>;
     const int h = lane >> 5;
     const _Float16* W2h = reinterpret_cast<const _Float16*>(net + O::W2h);
     const _Float16* W2l = reinterpret_cast<const _Float16*>(net + O::W2l);
-    init_acc(a0, net + O::b2 + ((1 * NBK + kb) * 2 + h) * 16);
-    dense64_block<NCH>(W2h + kb * 2048, W2l + kb * 2048, f, a0, lane);
-    unscale(a0, e);
+    init_acc<CH>(a0, net + O::b2 + ((1 * NBK + kb) * 2 + h) * 16);
+    dense64_block<CH>(W2h + kb * 2048, W2l + kb * 2048, f, a0, lane);
+    unscale<CH>(a0, e);
 }
-// the whole conditioner for <= 32 bases (the launch-per-net path): head triples (PRIOR: of c) in a0, the sum of the raw outputs in s1
+// the whole conditioner (the launch-per-net path): head triples (PRIOR: of c) in a0, the sum of the raw outputs in s1
 // cbP: the constant term of the B prior's boundary map times ob_to_b ([NBK][2][16], accumulator layout) or null; it is added to the VALUE channel only --
 // the staged sampler, which reads nothing else, is the one caller with such models (the launch-per-net energy path leaves them to k_efused)
-template <bool PRIOR, int NBK = 1>
-__device__ __forceinline__ void cond_net(const float* net, const float* fkP, const _Float16* obh, float u0v, float u1v, int lane, f32x16 (&a0)[NBK][NCH], float& s1,
+template <bool PRIOR, int NBK = 1, int CH = NCH>
+__device__ __forceinline__ void cond_net(const float* net, const float* fkP, const _Float16* obh, float u0v, float u1v, int lane, f32x16 (&a0)[NBK][CH], float& s1,
                                          const float* cbP = nullptr) {
-    Frag f[NCH][2];
-    int e[NCH];
-    cond_hidden<NBK>(net, u0v, u1v, lane, f, e);
+    Frag f[CH][2];
+    int e[CH];
+    cond_hidden<NBK, CH>(net, u0v, u1v, lane, f, e);
     if (!PRIOR) {
 #pragma unroll
-        for (int kb = 0; kb < NBK; ++kb) cond_out<NBK>(net, f, e, kb, lane, a0[kb]);
+        for (int kb = 0; kb < NBK; ++kb) cond_out<NBK, CH>(net, f, e, kb, lane, a0[kb]);
     } else {
-        f32x16 o[NBK][NCH];
+        f32x16 o[NBK][CH];
 #pragma unroll
-        for (int kb = 0; kb < NBK; ++kb) cond_out<NBK>(net, f, e, kb, lane, o[kb]);
-        Frag of[NBK][NCH];
-        int eo[NCH];
-        prior_frags<NBK>(o, fkP, lane, of, eo, s1);
+        for (int kb = 0; kb < NBK; ++kb) cond_out<NBK, CH>(net, f, e, kb, lane, o[kb]);
+        Frag of[NBK][CH];
+        int eo[CH];
+        prior_frags<NBK, CH>(o, fkP, lane, of, eo, s1);
 #pragma unroll
         for (int kb = 0; kb < NBK; ++kb) {
-            prior_c_block<NBK>(obh, of, eo, kb, lane, a0[kb]);
+            prior_c_block<NBK, CH>(obh, of, eo, kb, lane, a0[kb]);
             if (cbP) {
                 const f32x16 cb = load16(cbP + (kb * 2 + (lane >> 5)) * 16);
 #pragma unroll
@@ -121,8 +121,10 @@ __device__ __forceinline__ void cond_net(const float* net, const float* fkP, con
     }
 }
 
-// NBK row blocks per dimension: the head outputs go out as oj[tile][row 0 .. 32 NBK)[channel][32 walkers] (NBK = 2: the staged sampler of 33 .. 64 bases)
-template <bool PRIOR, int NBK = 1>
+// NBK row blocks per dimension: the head outputs go out as oj[tile][row 0 .. 32 NBK)[channel][32 walkers] (NBK = 2: the staged sampler of 33 .. 64 bases).
+// CH = 1 (the staged sampler: round 4): the value channel alone -- a third of the matrix products, no derivative algebra in the activations, 128 instead of
+// 384 B per walker and row block out (oj[tile][row][32 walkers])
+template <bool PRIOR, int NBK = 1, int CH = NCH>
 __global__ __launch_bounds__(kCondWaves * 64, WF_ETILE_OCC) void k_etile_cond(const MfmaDev mm, int net_index, const float* __restrict__ st, int64_t B,
                                                                 float* __restrict__ oj, float* __restrict__ s1buf) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -150,9 +152,9 @@ __global__ __launch_bounds__(kCondWaves * 64, WF_ETILE_OCC) void k_etile_cond(co
         const bool valid = w < B;
         const int64_t wl = valid ? w : B - 1;
         const float u0v = st[wl], u1v = st[(int64_t)4 * B + wl];
-        f32x16 a0[NBK][NCH];
+        f32x16 a0[NBK][CH];
         float s1 = 0.0f;
-        cond_net<PRIOR, NBK>(net, fkP, obh, u0v, u1v, lane, a0, s1, (PRIOR && mm.p_bias) ? lds + 64 * NBK + NBK * NBK * 1024 + 64 * NBK : nullptr);
+        cond_net<PRIOR, NBK, CH>(net, fkP, obh, u0v, u1v, lane, a0, s1, (PRIOR && mm.p_bias) ? lds + 64 * NBK + NBK * NBK * 1024 + 64 * NBK : nullptr);
         if (PRIOR && valid && h == 0) s1buf[w] = s1;
         // ---- store: oj[tile][row][c][32 walkers] (one contiguous block per tile), row = accumulator row of register r in lane half h of block kb
 #ifdef WF_ABL_OJ   // ablation build (timing only): the head triples are computed, not stored
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(kCondWaves * 64, WF_ETILE_OCC) void k_etile_cond(co
                 for (int r = 0; r < 16; ++r) {
                     const int row = 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * h;
 #pragma unroll
-                    for (int c = 0; c < NCH; ++c) oj[(tile * (32 * NBK * NCH) + row * NCH + c) * 32 + j] = a0[kb][c][r];
+                    for (int c = 0; c < CH; ++c) oj[(tile * (32 * NBK * CH) + row * CH + c) * 32 + j] = a0[kb][c][r];
                 }
         }
     }
@@ -1705,7 +1707,7 @@ __device__ __forceinline__ float inv_rows(const float* __restrict__ tab0, const 
 }
 // channel 0 of the head outputs of walker b: oj[tile][row 0 .. NB)[channel][32 walkers]
 template <int NB>
-__device__ __forceinline__ float oj0(const float* __restrict__ oj, int64_t b, int row) { return oj[((b >> 5) * (NB * NCH) + row * NCH) * 32 + (b & 31)]; }
+__device__ __forceinline__ float oj0(const float* __restrict__ oj, int64_t b, int row) { return oj[((b >> 5) * NB + row) * 32 + (b & 31)]; }   // (k_etile_cond<., ., 1>: the value channel alone)
 
 // phase 0: prior column 0;  1: prior column 1, then the last layer's dimension 0;  2: dimension 1 of layer `layer`, then dimension 0 of the layer before it
 // (layer 0: the box reverse and the result);  3: entry of a plain inverse (latent given): the last layer's dimension 0.
@@ -2068,7 +2070,7 @@ bool tile_sample_capable(const MfmaDev* mdev) {
            mdev->comp != nullptr && (mdev->const_floats + mdev->net_floats) * 4 <= 160 * 1024 - 64;
 }
 // floats of workspace: conditioner input (5 B: the slot of the second input sits 4 B behind the first), cur0, cur1, the latent pair, the prior's sign sums,
-// the head outputs of whole tiles (32 nbk rows x 3 channels)
+// the head outputs of whole tiles (32 nbk rows; sized for three channels -- the conditioner launches have written the value channel alone since round 4)
 int64_t tile_sample_floats(int64_t B, int nbk) { return B * 10 + ((B + 31) / 32) * 32 * (32 * nbk * NCH) + 64; }
 
 namespace {
@@ -2084,20 +2086,20 @@ int launch_tile_sample_t(const MfmaDev* mdev, const ModelDev& md, const TsArgs& 
     const unsigned lane_blocks = (unsigned)((B + 255) / 256);
     const int lds_bytes = (mdev->const_floats + mdev->net_floats) * (int)sizeof(float);
     static DynLdsSlots cfg_flow{}, cfg_prior{};
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(k_etile_cond<false, NBK>), lds_bytes, &cfg_flow)) return rc;
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(k_etile_cond<true, NBK>), lds_bytes, &cfg_prior)) return rc;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(k_etile_cond<false, NBK, 1>), lds_bytes, &cfg_flow)) return rc;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(k_etile_cond<true, NBK, 1>), lds_bytes, &cfg_prior)) return rc;
     const int64_t n_tiles = (B + 31) / 32;
     const unsigned cond_blocks = (unsigned)std::min<int64_t>((n_tiles + kCondWaves - 1) / kCondWaves, 256 * 4);
     const int L = md.n_layers;
     if (draw) {
         hipLaunchKernelGGL((k_tsample<0, NB>), dim3(lane_blocks), dim3(256), 0, s, a, 0, (const float*)oj, u, B, cur0, cur1, cin, lat, latent, x);
-        hipLaunchKernelGGL((k_etile_cond<true, NBK>), dim3(cond_blocks), dim3(kCondWaves * 64), lds_bytes, s, *mdev, L, (const float*)cin, B, oj, s1);
+        hipLaunchKernelGGL((k_etile_cond<true, NBK, 1>), dim3(cond_blocks), dim3(kCondWaves * 64), lds_bytes, s, *mdev, L, (const float*)cin, B, oj, s1);
         hipLaunchKernelGGL((k_tsample<1, NB>), dim3(lane_blocks), dim3(256), 0, s, a, 0, (const float*)oj, u, B, cur0, cur1, cin, lat, latent, x);
     } else {
         hipLaunchKernelGGL((k_tsample<3, NB>), dim3(lane_blocks), dim3(256), 0, s, a, 0, (const float*)oj, u, B, cur0, cur1, cin, lat, latent, x);
     }
     for (int l = L - 1; l >= 0; --l) {
-        hipLaunchKernelGGL((k_etile_cond<false, NBK>), dim3(cond_blocks), dim3(kCondWaves * 64), lds_bytes, s, *mdev, l, (const float*)cin, B, oj, s1);
+        hipLaunchKernelGGL((k_etile_cond<false, NBK, 1>), dim3(cond_blocks), dim3(kCondWaves * 64), lds_bytes, s, *mdev, l, (const float*)cin, B, oj, s1);
         hipLaunchKernelGGL((k_tsample<2, NB>), dim3(lane_blocks), dim3(256), 0, s, a, l, (const float*)oj, u, B, cur0, cur1, cin, lat, latent, x);
     }
     return check();
