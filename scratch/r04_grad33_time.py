@@ -9,6 +9,8 @@ protons = physics.system_catalogue[1]["He"][0].reshape(-1)
 xg = bench.walkers(1 << 17, 1234).cuda()
 m23, _ = bench.he_model("auto")
 m33 = bench.seeded_model(2, 33, "auto")
+if os.environ.get("SAMPLED"):   # walkers from the shipped model's own |psi|^2 (the training step's input) instead of uniform ones
+    xg = m23.sample(11, 1 << 17, exact=True)
 for name, m in (("23 knots", m23), ("33 knots", m33)):
     for tile_min in (None, "0"):
         if tile_min is None: os.environ.pop("WF_GRAD_TILE_MIN", None)

@@ -21,8 +21,12 @@
 // walker and net.  Same function as k_wave_fwd<2, RF<2>> + k_energy_out (same derivative rule of the table lerp: order nd -> table nd + 1),
 // checked against it and against the torch oracle (tests/test_gpu_energy.py).  Coverage: D = 2, <= 32 bases, mean-type box, IMADE layers,
 // Waveflow prior, ungated heads (every homogeneous boundary dictionary: the tables carry the map); everything else stays on the wave kernel.
-#include "wf_etile_common.h"
+// (the adjoint header first: its head algebra is compiled WITHOUT the contraction pragma of the common header -- with it the reverse kernel came out 10 %
+// slower, 189 instead of 138 spilled registers: profiles/r04_grad33_times.txt, "adjoint header under fp contract")
+#include <hip/hip_runtime.h>
+
 #include "wf_etile_adjoint.h"
+#include "wf_etile_common.h"
 
 // The jet / Taylor algebra of this file is checked against oracles by tolerance, not by operation order: multiply-add pairs may fuse (the build's
 // default is -ffp-contract=off).  The pragma is lexical: the index arithmetic of the table lerp (make_lerp, div_by_n in wf_mfma_impl.h, included
@@ -1022,8 +1026,17 @@ __device__ __forceinline__ void acc_add(float* acc, int* ticket, int b, int k, i
 #else
     constexpr bool SHARED = SHARED_;
 #endif
-    if (SHARED)
+    if (SHARED) {
+        // Nothing of the matrix pipe may be in flight across the branch of the wait below.  hipcc (ROCm 7.2) counts the wait states between an MFMA and a
+        // vector read of its result correctly in straight-line code, but at the join behind this loop it let v_accvgpr_read follow the product's last
+        // MFMA by four instructions where eleven are due (ISA of k_ebwd<true, 2>, seventh wait): when the ticket was already there the last rows of
+        // the product (registers 12 .. 15) were read before the pipe had written them -- 128 entries of one gradient block changed from run to run
+        // by 4e-5 relative (scratch/r04_repro_diag.py).  24 idle issue slots in front of the branch, fenced against the scheduler, retire every MFMA.
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
         while (__hip_atomic_load(ticket + b, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != k) __builtin_amdgcn_s_sleep(1);
+    }
     f32x16 a = acc_load(acc, b, lane);
 #pragma unroll
     for (int r = 0; r < 16; ++r) a[r] = __builtin_fmaf(p[r], un, a[r]);
@@ -1126,9 +1139,8 @@ __global__ __launch_bounds__(kBwdWaves * 64) void k_ebwd(const MfmaDev mm, int n
     }
     // tiles are dealt statically (tile = block + k * grid, k = round * waves + wave): which wave sums which tiles does not depend on timing, and the
     // shared accumulator blocks take the tiles' products in the order of k (acc_add)
-    for (int k = (int)(threadIdx.x >> 6);; k += kBwdWaves) {
-        const int64_t tile = (int64_t)blockIdx.x + (int64_t)k * gridDim.x;
-        if (tile >= n_tiles) break;
+    int k = (int)(threadIdx.x >> 6);
+    for (int64_t tile = (int64_t)blockIdx.x + (int64_t)(threadIdx.x >> 6) * gridDim.x; tile < n_tiles; tile += (int64_t)kBwdWaves * gridDim.x, k += kBwdWaves) {
         const int64_t w = tile * 32 + j;
         const bool valid = w < B;
         const int64_t wl = valid ? w : B - 1;
@@ -1150,8 +1162,17 @@ __global__ __launch_bounds__(kBwdWaves * 64) void k_ebwd(const MfmaDev mm, int n
             const JA y1b = valid ? ja_load(adjb, 0, B, wl) : adj::jzero<float>(), y0b = valid ? ja_load(adjb, 1, B, wl) : adj::jzero<float>();
             ldb = valid ? ja_load(adjb, 2, B, wl) : adj::jzero<float>();
             const LerpN L1 = nlerp(u1.v, n_mesh), L0 = nlerp(u0.v, n_mesh);
-            // dimension 0 (the bias alone: empty mask) first, then dimension 1: the two heads share nothing but the incoming adjoints, and their sums /
-            // intermediates need not be live together
+            // the row factors and the biases of dimension 0 (its head sees the bias alone: empty mask).  One row block: loaded once per tile and held (the
+            // compiler then also hoists what depends on them alone); two row blocks: loaded where they are used -- holding 64 registers of them across the
+            // head costs more than it saves there (1.550 against 1.575 ms per loss + gradient of 2^17 walkers; one block: 0.937 against 0.973 the other way)
+            f32x16 g16h[NBK], o0h[NBK];
+            if (NBK == 1) {
+                g16h[0] = load16(fkI + h * 16);
+                o0h[0] = load16(net + O::b2 + h * 16);
+            }
+            auto g16 = [&](int kb) { return NBK == 1 ? g16h[0] : load16(fkI + (kb * 2 + h) * 16); };
+            auto bias0 = [&](int kb) { return NBK == 1 ? o0h[0] : load16(net + O::b2 + ((0 * NBK + kb) * 2 + h) * 16); };
+            // dimension 0 first, then dimension 1: the two heads share nothing but the incoming adjoints, and their sums / intermediates need not be live together
             JA sb0 = adj::jzero<float>(), tb0 = adj::jzero<float>();
             float tv0 = 0.0f;
             {
@@ -1159,8 +1180,8 @@ __global__ __launch_bounds__(kBwdWaves * 64) void k_ebwd(const MfmaDev mm, int n
 #pragma unroll
                 for (int kb = 0; kb < NBK; ++kb) {
                     f32x16 o0[NCH];
-                    o0[0] = load16(net + O::b2 + ((0 * NBK + kb) * 2 + h) * 16);
-                    flow_rows_ext<true>(s0, o0, load16(fkI + (kb * 2 + h) * 16), tabI, kMeshStride, bnd_s, L0, kb, h);
+                    o0[0] = bias0(kb);
+                    flow_rows_ext<true>(s0, o0, g16(kb), tabI, kMeshStride, bnd_s, L0, kb, h);
                 }
                 flow_sums_xhalf(s0);
                 JA y0, dl0;
@@ -1170,8 +1191,8 @@ __global__ __launch_bounds__(kBwdWaves * 64) void k_ebwd(const MfmaDev mm, int n
 #pragma unroll
                 for (int kb = 0; kb < NBK; ++kb) {
                     f32x16 o0[NCH], t0[NCH];
-                    o0[0] = load16(net + O::b2 + ((0 * NBK + kb) * 2 + h) * 16);
-                    flow_rows_bwd<true>(ab0, o0, load16(fkI + (kb * 2 + h) * 16), tabI, kMeshStride, bnd_s, L0, kb, h, t0);
+                    o0[0] = bias0(kb);
+                    flow_rows_bwd<true>(ab0, o0, g16(kb), tabI, kMeshStride, bnd_s, L0, kb, h, t0);
                     ob0[kb] = t0[0];
                 }
             }
@@ -1181,14 +1202,14 @@ __global__ __launch_bounds__(kBwdWaves * 64) void k_ebwd(const MfmaDev mm, int n
             {
                 adj::FlowSumsT<float> s1 = adj::flow_sums_zero<float>();
 #pragma unroll
-                for (int kb = 0; kb < NBK; ++kb) flow_rows_ext<false>(s1, o[kb], load16(fkI + (kb * 2 + h) * 16), tabI, kMeshStride, bnd_s, L1, kb, h);
+                for (int kb = 0; kb < NBK; ++kb) flow_rows_ext<false>(s1, o[kb], g16(kb), tabI, kMeshStride, bnd_s, L1, kb, h);
                 flow_sums_xhalf(s1);
                 JA y1, dl1;
                 const adj::FlowHeadFwd<float> f1 = adj::flow_head_fwd(s1, mm.F_I, mm.i_reg, u0, u1, y1, dl1);
                 adj::FlowSumsT<float> ab1 = adj::flow_sums_zero<float>();
                 adj::flow_head_bwd(s1, f1, mm.F_I, mm.i_reg, u0, u1, y1b, ldb, ab1, sb, tb, tv1);
 #pragma unroll
-                for (int kb = 0; kb < NBK; ++kb) flow_rows_bwd<false>(ab1, o[kb], load16(fkI + (kb * 2 + h) * 16), tabI, kMeshStride, bnd_s, L1, kb, h, ob[kb]);
+                for (int kb = 0; kb < NBK; ++kb) flow_rows_bwd<false>(ab1, o[kb], g16(kb), tabI, kMeshStride, bnd_s, L1, kb, h, ob[kb]);
             }
             u0b = JA{tv0, sb.a + sb0.a + tb0.a, sb.b + sb0.b + tb0.b, sb.h + sb0.h + tb0.h};
             u1b = JA{tv1, tb.a, tb.b, tb.h};
