@@ -72,3 +72,8 @@ def test_the_join_rule_sees_the_sequence_that_failed_and_accepts_the_padded_one(
     # straight-line code is the compiler's own count: not second-guessed
     straight = "\n".join(l for l in _JOIN_BUG.splitlines() if "s_cbranch" not in l)
     assert isa_guard.join_hits_in_text(straight, guarded) == {}
+
+
+def test_every_kernel_that_issues_mfma_is_guarded():
+    """A new matrix-core kernel under a name the guard's pattern does not match would escape both rules."""
+    assert isa_guard.unguarded_mfma_kernels(wf_build.build()) == []

@@ -160,6 +160,27 @@ def scan_mfma_joins(lib):
     return hits
 
 
+def unguarded_mfma_kernels(lib):
+    """Kernels of `lib` that issue MFMA instructions but are not matched by GUARDED (the rules above would not see them)."""
+    od = _objdump()
+    out = set()
+    with tempfile.TemporaryDirectory(prefix="wf_isa_") as tmp:
+        local = os.path.join(tmp, "lib.so")
+        shutil.copy(lib, local)
+        subprocess.run([od, "--offloading", local], cwd=tmp, check=True, capture_output=True)
+        for f in sorted(os.listdir(tmp)):
+            if "amdgcn" not in f:
+                continue
+            cur = None
+            for line in subprocess.run([od, "-d", "--no-show-raw-insn", os.path.join(tmp, f)], capture_output=True, text=True, check=True).stdout.splitlines():
+                m = _SYM.match(line)
+                if m:
+                    cur = m.group(1)
+                elif cur and "v_mfma" in line and not GUARDED.search(cur):
+                    out.add(cur)
+    return sorted(out)
+
+
 def check(lib):
     joins = scan_mfma_joins(lib)
     if joins:
