@@ -179,6 +179,20 @@ def test_gradients_on_the_matrix_cores_with_two_row_blocks_vs_autograd_oracle(mo
     monkeypatch.delenv("WF_GRAD_TILE_MIN")
     assert torch.equal(m.psi_vjp(xb, wb1, wb2), tile)           # default switch: 50 001 walkers take the matrix-core path
     assert rel_l2(tile.cpu().numpy(), wave.cpu().numpy()) < 2e-4 and not torch.equal(tile, wave)
+    # several chunks of a small workspace (the partial blocks of a two-row-block net are 8 512 floats each: 35 MB fixed for the four nets, + 256 B per walker)
+    from waveflow_amd import _lib
+    L = _lib.lib()
+    ws = torch.empty(40 * 1024 * 1024, device="cuda", dtype=torch.uint8)    # room for ~ 19 000 walkers per chunk
+    grad = torch.empty(m.n_params, device="cuda")
+    monkeypatch.setenv("WF_GRAD_TILE_MIN", "1")
+    rc = L.wf_psi_vjp(m._h, xb.data_ptr(), 50001, wb1.data_ptr(), wb2.data_ptr(), grad.data_ptr(), ws.data_ptr(), ws.numel(), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert not torch.equal(grad, wave) and rel_l2(grad.cpu().numpy(), tile.cpu().numpy()) < 1e-4      # (chunk sums in another order)
+    grad2 = torch.empty_like(grad)
+    assert L.wf_psi_vjp(m._h, xb.data_ptr(), 50001, wb1.data_ptr(), wb2.data_ptr(), grad2.data_ptr(), ws.data_ptr(), ws.numel(), None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(grad, grad2)
 
 
 def _leaves(tree):
