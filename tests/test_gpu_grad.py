@@ -75,7 +75,7 @@ def test_vqmc_loss_grad_vs_oracle(golden, he_flat):
 
 def test_gradients_on_the_matrix_cores_vs_oracle_and_wave_sweeps(golden, he_flat, monkeypatch):
     """value_and_grad(loss_fn_efficient) (vqmc.py:193-221) for large two-particle batches: forward, per-net reverse kernels and weight-gradient
-    products on the matrix cores (wf_kernels_etile.hip: k_efused, k_ebwd, k_ewgrad; head pullbacks: wf_etile_adjoint.h, checked on the CPU by
+    products on the matrix cores (wf_kernels_etile.hip: k_efused, k_ebwd; head pullbacks: wf_etile_adjoint.h, checked on the CPU by
     tests/test_etile_adjoint.py).  Forced on a small batch (partial tile included) against the torch autograd oracle; on 50 001 walkers against the
     wave sweeps (psi_vjp with random weights, and the loss + gradient entry point on walkers from the model's own sampler); several chunks; the
     switch itself; bitwise reproducibility."""

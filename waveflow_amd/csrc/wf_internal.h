@@ -149,7 +149,7 @@ struct Protons {
     float pos[8];
     int n;
 };
-// local energy of large batches on the matrix cores (wf_kernels_etile.hip): D = 2, <= 32 bases, mean box, IMADE + Waveflow prior, ungated
+// local energy of large batches on the matrix cores (wf_kernels_etile.hip): D = 2, <= 64 bases, mean box, IMADE + Waveflow prior, ungated
 int64_t energy_tile_floats(int64_t B);
 bool energy_tile_fused(const MfmaDev* mdev);
 // local energy of large batches beyond two particles (wf_kernels_etile_dir.hip): D = 3 .. 8, <= 32 bases, mean box, IMADE + Waveflow prior, ungated;
@@ -158,7 +158,7 @@ bool energy_dir_capable(const MfmaDev* mdev);
 int64_t energy_dir_floats(int64_t B, int D);
 int launch_energy_dir(const MfmaDev* mdev, const ModelDev& md, const float* tabI4, const float* tabP4, const float* x, int64_t B, const Protons& pr,
                       float* hpsi, float* psi, float* lap, float* ws, void* stream);
-// parameter gradients of psi and its Laplacian on the matrix cores (two-particle family, <= 32 bases; wf_kernels_etile.hip: k_ebwd, k_ewgrad)
+// parameter gradients of psi and its Laplacian on the matrix cores (two-particle family, <= 64 bases; wf_kernels_etile.hip: k_efused, k_ebwd per net, k_egrad_reduce)
 bool energy_vjp_capable(const MfmaDev* mdev);
 int64_t energy_vjp_floats_per_walker(int n_nets);
 int64_t energy_vjp_fixed_floats(int n_nets, int nbk);

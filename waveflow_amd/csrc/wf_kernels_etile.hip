@@ -19,7 +19,7 @@
 //
 // State between launches (SoA, walker fastest): u_0, u_1, log det as jets; 12 floats per walker.  Head triples through HBM: 2 x 384 B per
 // walker and net.  Same function as k_wave_fwd<2, RF<2>> + k_energy_out (same derivative rule of the table lerp: order nd -> table nd + 1),
-// checked against it and against the torch oracle (tests/test_gpu_energy.py).  Coverage: D = 2, <= 32 bases, mean-type box, IMADE layers,
+// checked against it and against the torch oracle (tests/test_gpu_energy.py).  Coverage: D = 2, <= 64 bases (launch-per-net form: <= 32), mean-type box, IMADE layers,
 // Waveflow prior, ungated heads (every homogeneous boundary dictionary: the tables carry the map); everything else stays on the wave kernel.
 // (the adjoint header first: its head algebra is compiled WITHOUT the contraction pragma of the common header -- with it the reverse kernel came out 10 %
 // slower, 189 instead of 138 spilled registers: profiles/r04_grad33_times.txt, "adjoint header under fp contract")
@@ -532,7 +532,7 @@ __global__ __launch_bounds__(kFusedWaves * 64) void k_efused(const MfmaDev mm, c
 }
 
 // ============================================================================ parameter gradients on the matrix cores (vqmc.py:193-221)
-// grad[p] = sum_b ( w_psi[b] d psi_b / d theta_p + w_lap[b] d laplacian_b / d theta_p ) for the two-particle family (<= 32 bases), batch by batch:
+// grad[p] = sum_b ( w_psi[b] d psi_b / d theta_p + w_lap[b] d laplacian_b / d theta_p ) for the two-particle family (<= 64 bases: NBK = 1 or 2 row blocks per dimension), batch by batch:
 //   k_efused (st_out)   forward, leaves the (u_0, u_1, log det) jets at the input of every net
 //   k_ebwd<PRIOR>       one launch per net, last net first: recomputes the net's forward from its input jets, pulls the adjoint of its output
 //                       jets back through the head algebra (wf_etile_adjoint.h) to adjoint head triples, through the conditioner with TRANSPOSED

@@ -328,7 +328,7 @@ static int wave_passes(int D, int nbp) { return nbp == 32 ? (D + 1) / 2 : D; }  
 static int ensure_scratch(const wf_model* cm, int64_t floats);
 static constexpr int kTapedLaplacianMaxD = 8;    // largest D whose reverse sweep runs in RF (measured, scratch/grad_ab.py)
 static constexpr int64_t kWaveEvalMax = 6144;   // measured crossover ~7000 walkers (scratch/crossover.py)
-static constexpr int64_t kGradTileMin = 16384;    // psi / Laplacian gradients: the matrix-core path (k_ebwd, k_ewgrad) from here on
+static constexpr int64_t kGradTileMin = 16384;    // psi / Laplacian gradients: the matrix-core path (k_efused, k_ebwd) from here on
 static constexpr int64_t kEnergyTileMin = 16384; // H psi: the tile path (8 launches, staged weight images) from here on
 static constexpr int64_t kEnergyTileChunk = (int64_t)1 << 19;   // walkers per pass of the tile path (WF_ENERGY_TILE_CHUNK; 2^20 walkers: 1.20 ms in two passes, 1.30 in one, 1.34 in four)
 namespace wf {
@@ -944,7 +944,7 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
     if ((int64_t)consts + (int64_t)net_floats * n_nets <= lds_cap) staged = 0;        // every net resident
     else if ((int64_t)consts + net_floats + 16 * kStagedGroups * (D + 1) * 32 <= lds_cap) staged = 1;   // one slot + the state area, re-staged per super-chunk
     else return WF_OK;
-    // the matrix-core gradient path (two particles, <= 32 bases, Waveflow prior, IMADE layers): transposed operand images behind the constants block
+    // the matrix-core gradient path (two particles, <= 64 bases, Waveflow prior, IMADE layers): transposed operand images behind the constants block
     const bool timg = D == 2 && (nbk == 1 || nbk == 2) && d.prior_kind == WF_PRIOR_WAVEFLOW && (d.layer_kind == WF_LAYER_IMADE || d.n_flow_layers == 0);
     const int tconsts = nbk * nbk * 1024;   // ob_to_b transposed: blocks [ka][ki]{hi [s 2][lane 64][8 halves] (512 floats), lo (512)}
     const int tnet_floats = tnet_floats_of(nbk);
@@ -1533,7 +1533,7 @@ static int64_t wave_sample_max() {   // tuning knob (read at every call): WF_WAV
     return e ? atoll(e) : kWaveSampleMax;
 }
 
-// Large batches of the two-particle family (the family of the matrix-core local energy, <= 32 bases): the staged inverse / sampler of
+// Large batches of the two-particle family (the family of the matrix-core local energy, <= 64 bases): the staged inverse / sampler of
 // wf_kernels_etile.hip (conditioners on the matrix cores, one lane per walker for the searches).  WF_SAMPLE_TILE_MIN (read per call) moves the switch
 // point; 0 disables the path.  It reads the MFMA image and the composite dimension-0 tables: not while they are stale (deferred training steps).
 static constexpr int64_t kTileSampleMin = 16384;
@@ -1759,8 +1759,8 @@ static int run_vjp_chunks(const wf_model* m, int mode, bool second_order, const 
         WF_HIP(hipMemsetAsync(grad_dev, 0, (size_t)m->n_params * sizeof(float), s));
         return WF_OK;
     }
-    // Large batches of the two-particle family (the family of the one-kernel H psi, <= 32 bases): forward, reverse and weight-gradient products on the
-    // matrix cores (wf_kernels_etile.hip: k_efused with the per-net input jets, k_ebwd per net, k_ewgrad).  WF_GRAD_TILE_MIN (read per call) moves the
+    // Large batches of the two-particle family (the family of the one-kernel H psi, <= 64 bases): forward, reverse and weight-gradient products on the
+    // matrix cores (wf_kernels_etile.hip: k_efused with the per-net input jets, k_ebwd per net with the weight-gradient products inside).  WF_GRAD_TILE_MIN (read per call) moves the
     // switch point; 0 disables the path.
     if ((mode == 1 || mode == 2) && second_order && m->d_egacc) {
         const int64_t tile_min = 1;

@@ -15,7 +15,7 @@ import subprocess
 import tempfile
 
 LLVM_BIN = os.environ.get("WF_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
-GUARDED = re.compile(r"k_mfma|k_etile|k_efused|k_ebwd|k_ewgrad|k_edir")                      # kernels of the translation units built with MFMA_FLAGS
+GUARDED = re.compile(r"k_mfma|k_etile|k_efused|k_ebwd|k_edir")                      # kernels of the translation units built with MFMA_FLAGS
 FORBIDDEN = re.compile(r"\bv_pk_(fma|add|mul)_f32\b")
 _SYM = re.compile(r"^[0-9a-f]+ <(.+)>:\s*$")
 
