@@ -85,10 +85,10 @@ VQMC_BWD_SHARE = 0.54   # of the loss + gradient time (profiles/r01h_loss_grad_k
 # Batches >= 16 384 walkers of the two-particle family take the matrix-core gradient path.  Its dominant kernel is the per-net reverse
 # kernel k_ebwd<false> (three launches per call): 480 v_mfma_f32_32x32x16_f16 (288 of the sweep itself, 192 of the transposes and weight-gradient
 # products it has formed itself since round 4) + 16 v_mfma_f32_32x32x2_f32 per 32-walker tile (disassembly of the linked library).  Its time is not
-# measured by this line (the C call is one unit): DERIVED from its share of the call in the committed rocprofv3 run, 3 x 201.0 us of 947 us
+# measured by this line (the C call is one unit): DERIVED from its share of the call in the committed rocprofv3 run, 3 x 209.9 us of 1 006 us
 # (profiles/r04_grad_tile_kernel_stats.csv, r04_grad_tile_check.txt).
 GRAD_TILE_MFMA_FLOP_PER_WALKER_NET = (480 * 32768 + 16 * 4096) / 32
-GRAD_TILE_BWD_SHARE = 0.637
+GRAD_TILE_BWD_SHARE = 0.626
 GRAD_TILE_MIN = 16384
 # Executed matrix-core work of the other two log_pdf shapes (static MFMA counts of the linked kernels x their trip counts, scratch/isa/isa_stats.py):
 # 33-knot He (k_mfma<2,2,12,1>: two output blocks per net, 2 x 2 blocks of the prior's change of basis): per tile and flow net 24 + 24, prior net
@@ -701,7 +701,7 @@ def main_vqmc(args):
                 "kernel": "k_ebwd<false>", "kernel_ms": k_ms,
                 "kernel_ms_is": "derived: share of the call in profiles/r04_grad_tile_kernel_stats.csv x the call's event time / 3 launches",
                 "note": "executed matrix FLOP of one reverse launch (split-fp16 products, three Taylor channels, the transposes and weight-gradient "
-                        "products) / its share of the call (63.7 %, three launches); the kernel runs one wave per SIMD and is bound by vector issue "
+                        "products) / its share of the call (62.6 %, three launches); the kernel runs one wave per SIMD and is bound by vector issue "
                         "and register spills, not by the matrix pipe (profiles/r04_grad_tile_pmc.txt)"}
     else:
         ach = B * VQMC_BWD_FLOP_PER_WALKER / (VQMC_BWD_SHARE * step_ms * 1e-3) / 1e12

@@ -10,5 +10,5 @@ for c in WRITE_SIZE FETCH_SIZE; do
 done
 WF_PMC_KERNELS=k_ebwd,k_efused,k_egrad python3 scratch/pmc_summary.py $O > $O/grad_tile_pmc.txt 2>&1; rm -rf $O/pmc_WRITE_SIZE $O/pmc_FETCH_SIZE
 timeout 600 python3 bench.py --workload vqmc --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_line_vqmc.json 2>$O/bench_vqmc.err
-timeout 900 python3 scratch/train_converge.py > $O/train_converge.txt 2>&1
-grep -E "finite|vqmc|loss-grad" $O/egrad_check.txt; head -7 $O/grad_tile_kernel_stats.csv | cut -c1-70,150-260; cat $O/grad_tile_pmc.txt; tail -c 600 $O/bench_line_vqmc.json; tail -8 $O/train_converge.txt
+
+grep -E "finite|vqmc|loss-grad" $O/egrad_check.txt; head -7 $O/grad_tile_kernel_stats.csv | cut -c1-70,150-260; cat $O/grad_tile_pmc.txt; tail -c 600 $O/bench_line_vqmc.json
