@@ -741,10 +741,14 @@ __device__ __forceinline__ void act_block_bwd(const f32x16 (&x)[NCH], f32x16 (&g
 template <bool CONST>
 __device__ __forceinline__ void flow_rows_ext(adj::FlowSumsT<float>& a, const f32x16 (&o)[NCH], const f32x16& g16, const float* __restrict__ tabI, int mesh_stride,
                                               const int* bnd, const LerpN& L, int kb, int h) {
+    // the records of chunk q + 1 are requested before the rows of chunk q are worked on (two sets of 4 + 4 records in flight: the compiler's own order
+    // waited for every set right behind its request -- one exposed L2 round trip per chunk)
+    float4_t tq[2][2][4];
+    chunk_rows<4>(tabI, mesh_stride, bnd, L, 8 * kb + h, tq[0][0], tq[0][1]);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        float4_t ta[4], tb[4];
-        chunk_rows<4>(tabI, mesh_stride, bnd, L, 8 * kb + 2 * q + h, ta, tb);
+        if (q < 3) chunk_rows<4>(tabI, mesh_stride, bnd, L, 8 * kb + 2 * (q + 1) + h, tq[(q + 1) & 1][0], tq[(q + 1) & 1][1]);
+        const float4_t (&ta)[4] = tq[q & 1][0], (&tb)[4] = tq[q & 1][1];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int r = 4 * q + e;
@@ -779,10 +783,14 @@ __device__ __forceinline__ void flow_sums_xhalf(adj::FlowSumsT<float>& a) {
 template <bool CONST>
 __device__ __forceinline__ void flow_rows_bwd(const adj::FlowSumsT<float>& ab, const f32x16 (&o)[NCH], const f32x16& g16, const float* __restrict__ tabI,
                                               int mesh_stride, const int* bnd, const LerpN& L, int kb, int h, f32x16 (&ob)[NCH]) {
+    // the records of chunk q + 1 are requested before the rows of chunk q are worked on (two sets of 4 + 4 records in flight: the compiler's own order
+    // waited for every set right behind its request -- one exposed L2 round trip per chunk)
+    float4_t tq[2][2][4];
+    chunk_rows<4>(tabI, mesh_stride, bnd, L, 8 * kb + h, tq[0][0], tq[0][1]);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        float4_t ta[4], tb[4];
-        chunk_rows<4>(tabI, mesh_stride, bnd, L, 8 * kb + 2 * q + h, ta, tb);
+        if (q < 3) chunk_rows<4>(tabI, mesh_stride, bnd, L, 8 * kb + 2 * (q + 1) + h, tq[(q + 1) & 1][0], tq[(q + 1) & 1][1]);
+        const float4_t (&ta)[4] = tq[q & 1][0], (&tb)[4] = tq[q & 1][1];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int r = 4 * q + e;
@@ -814,10 +822,14 @@ __device__ __forceinline__ void flow_rows_bwd(const adj::FlowSumsT<float>& ab, c
 template <bool CONST>
 __device__ __forceinline__ void prior_rows_ext(adj::PriorSumsT<float>& a, const f32x16 (&c)[NCH], const float* __restrict__ tabP, int mesh_stride, const int* bnd,
                                                const LerpN& L, int kb, int h) {
+    // the records of chunk q + 1 are requested before the rows of chunk q are worked on (two sets of 4 + 4 records in flight: the compiler's own order
+    // waited for every set right behind its request -- one exposed L2 round trip per chunk)
+    float4_t tq[2][2][4];
+    chunk_rows<4>(tabP, mesh_stride, bnd, L, 8 * kb + h, tq[0][0], tq[0][1]);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        float4_t ta[4], tb[4];
-        chunk_rows<4>(tabP, mesh_stride, bnd, L, 8 * kb + 2 * q + h, ta, tb);
+        if (q < 3) chunk_rows<4>(tabP, mesh_stride, bnd, L, 8 * kb + 2 * (q + 1) + h, tq[(q + 1) & 1][0], tq[(q + 1) & 1][1]);
+        const float4_t (&ta)[4] = tq[q & 1][0], (&tb)[4] = tq[q & 1][1];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int r = 4 * q + e;
@@ -849,10 +861,14 @@ __device__ __forceinline__ void prior_sums_xhalf(adj::PriorSumsT<float>& a) {
 template <bool CONST>
 __device__ __forceinline__ void prior_rows_bwd(const adj::PriorSumsT<float>& ab, const f32x16 (&c)[NCH], const float* __restrict__ tabP, int mesh_stride,
                                                const int* bnd, const LerpN& L, int kb, int h, f32x16 (&cb)[NCH]) {
+    // the records of chunk q + 1 are requested before the rows of chunk q are worked on (two sets of 3 + 3 records in flight: the compiler's own order
+    // waited for every set right behind its request -- one exposed L2 round trip per chunk)
+    float4_t tq[2][2][3];
+    chunk_rows<3>(tabP, mesh_stride, bnd, L, 8 * kb + h, tq[0][0], tq[0][1]);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        float4_t ta[3], tb[3];
-        chunk_rows<3>(tabP, mesh_stride, bnd, L, 8 * kb + 2 * q + h, ta, tb);
+        if (q < 3) chunk_rows<3>(tabP, mesh_stride, bnd, L, 8 * kb + 2 * (q + 1) + h, tq[(q + 1) & 1][0], tq[(q + 1) & 1][1]);
+        const float4_t (&ta)[3] = tq[q & 1][0], (&tb)[3] = tq[q & 1][1];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int r = 4 * q + e;
