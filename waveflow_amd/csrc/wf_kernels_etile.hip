@@ -657,29 +657,11 @@ __device__ __forceinline__ void ja_store(float* __restrict__ st, int slot, int64
     p[0] = x.v; p[B] = x.a; p[2 * B] = x.b; p[3 * B] = x.h;
 }
 __device__ __forceinline__ float r_of(float x) { return __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(x) + 1.0f); }
-// one 32-row block of triples -> fragments of K = 32 (two K steps), every channel scaled (as to_frags, one block).  UNI: one power of two per
-// (TILE, channel) instead of per (walker, channel) -- the wave's largest.  The adjoint tensors of the reverse kernel take it: what they feed are sums
-// over walkers (the weight gradients; the input adjoints, which the next net's reverse again only sums), so a walker far below the tile's largest
-// loses bits that do not show in any sum, and the same fragments serve as operands of the products over the walker axis, which need one scale per tile.
-template <bool UNI = false>
-__device__ __forceinline__ void to_frags1(const f32x16 (&blk)[NCH], Frag (&f)[NCH][2], int (&e)[NCH]) {
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        float amax = 0.0f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) amax = fmaxf(amax, fabsf(blk[c][r]));
-        e[c] = UNI ? exponent_of(wave_max(amax)) : col_exponent(amax);
-        const float sc = __builtin_amdgcn_ldexpf(1.0f, -e[c]);
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            float r8[8];
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) r8[jj] = blk[c][8 * s + jj] * sc;
-            split8(r8, f[c][0].hi[s], f[c][0].lo[s]);
-        }
-    }
-}
-// two blocks, every channel scaled (adjoints are unbounded in every channel); UNI as above
+// Fragments of ADJOINT tensors.  UNI: one power of two per (TILE, channel) instead of per (walker, channel) -- the wave's largest.  The adjoint tensors
+// of the reverse kernel take it: what they feed are sums over walkers (the weight gradients; the input adjoints, which the next net's reverse again only
+// sums), so a walker far below the tile's largest loses bits that do not show in any sum, and the same fragments serve as operands of the products over
+// the walker axis, which need one scale per tile.
+// two blocks, every channel scaled (adjoints are unbounded in every channel)
 template <bool UNI = false>
 __device__ __forceinline__ void to_frags_all(const f32x16 (&blk0)[NCH], const f32x16 (&blk1)[NCH], Frag (&f)[NCH][2], int (&e)[NCH]) {
 #pragma unroll
