@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) void k_etile_prior(const float4_t* __restrict_
 // those 16 rows per lane with the separable row sums of T2 (scalars, no jet per row); the two lane halves are combined with one
 // v_permlane32_swap per sum; quotients, logarithms and the change to (x0, x1) jets once per walker.  No exchange buffer, no state in HBM:
 // 8 B per walker in, 4 .. 12 B out.  One persistent workgroup of 8 waves per CU (two per SIMD, 256 registers), tiles from an LDS counter.
-#ifndef WF_FUSED_WAVES   // (experiment switch; round 4, 2^20 walkers, one / two row blocks: 8 waves 0.81 / 1.16 ms, 6 waves 0.88 / 1.36, 4 waves -- no spills -- 0.98 / 1.31)
+#ifndef WF_FUSED_WAVES   // (experiment switch; round 4, 2^20 walkers, one / two row blocks: 8 waves 0.81 / 1.16 ms, 6 waves 0.88 / 1.36, 4 waves -- no spills -- 0.98 / 1.31, 12 waves -- 133 / 330 spilled -- 0.96 / 2.21, 16 waves 2.31 / 3.98)
 #define WF_FUSED_WAVES 8
 #endif
 constexpr int kFusedWaves = WF_FUSED_WAVES;
