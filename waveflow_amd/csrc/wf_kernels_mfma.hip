@@ -133,37 +133,36 @@ __device__ __forceinline__ float row_dot(const float* __restrict__ row, const fl
 // wave kernels' d_tabI4 / d_tabP3) -- identical to ModelDev's plain ones when the constraints only zero end coefficients
 __global__ void k_prepare_dim0(const ModelDev* __restrict__ mdp, int nm, const float* __restrict__ coef, const float* __restrict__ tab_i,
                                const float* __restrict__ tab_p, f32x4* __restrict__ comp) {
+    // one thread per (net, mesh point, derivative order) since round 4 (one per (net, mesh point) before: 32 workgroups, four dependent row sums per thread,
+    // 20 us of every training step); each row sum in the same order as before: the tables keep their bits
     const ModelDev& md = *mdp;
     const int n_nets = md.n_layers + ((md.prior_kind == WF_PRIOR_WAVEFLOW || md.prior_kind == WF_PRIOR_MFLOW) ? 1 : 0);
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int gid = tid >> 2, o = tid & 3;
     if (nm <= 0 || gid >= n_nets * nm) return;
     const int n = gid / nm, m = gid % nm;
     const bool is_prior = n == md.n_layers;
     const float* __restrict__ c = coef + (size_t)n * kCoefStride;
-    f32x4 out = {0.0f, 0.0f, 0.0f, 0.0f};
+    float out = 0.0f;
     if (!is_prior && md.layer_kind == WF_LAYER_MADE) {
-        out[0] = c[0];
-        out[1] = c[1];
+        if (o < 2) out = c[o];
     } else if (is_prior && md.prior_kind == WF_PRIOR_WAVEFLOW) {
         const SplineDev& sp = md.psp;
         const int nb = sp.nb, nbp = sp.nbp;
-        out[0] = (c[64] < 0.0f ? -row_dot(tab_p + (size_t)m * nbp, c, nb) : row_dot(tab_p + (size_t)m * nbp, c, nb)) * __builtin_amdgcn_rsqf(c[65]);
-        // derivative orders 1, 2 with the same sign and norm: the jet of psi_0 (local energy on the matrix cores, wf_kernels_etile.hip)
-        const float sn = (c[64] < 0.0f ? -1.0f : 1.0f) * __builtin_amdgcn_rsqf(c[65]);
-        out[1] = row_dot(tab_p + ((size_t)sp.n_mesh + m) * nbp, c, nb) * sn;
-        out[2] = row_dot(tab_p + ((size_t)2 * sp.n_mesh + m) * nbp, c, nb) * sn;
+        if (o == 0) out = (c[64] < 0.0f ? -row_dot(tab_p + (size_t)m * nbp, c, nb) : row_dot(tab_p + (size_t)m * nbp, c, nb)) * __builtin_amdgcn_rsqf(c[65]);
+        else if (o < 3) {
+            // derivative orders 1, 2 with the same sign and norm: the jet of psi_0 (local energy on the matrix cores, wf_kernels_etile.hip)
+            const float sn = (c[64] < 0.0f ? -1.0f : 1.0f) * __builtin_amdgcn_rsqf(c[65]);
+            out = row_dot(tab_p + ((size_t)o * sp.n_mesh + m) * nbp, c, nb) * sn;
+        }
     } else {
         const SplineDev& sp = is_prior ? md.psp : md.isp;
         const float* __restrict__ tab = is_prior ? tab_p : tab_i;
         const int nb = sp.nb, nbp = sp.nbp;
-        out[0] = row_dot(tab + (size_t)m * nbp, c, nb) * c[64];
-        if (!is_prior) {
-            out[1] = row_dot(tab + ((size_t)sp.n_mesh + m) * nbp, c, nb) * c[64];
-            out[2] = row_dot(tab + ((size_t)2 * sp.n_mesh + m) * nbp, c, nb) * c[64];   // orders 2, 3: jets of y_0 and of log dy_0
-            out[3] = row_dot(tab + ((size_t)3 * sp.n_mesh + m) * nbp, c, nb) * c[64];
-        }
+        // (orders 2, 3 of a flow layer: jets of y_0 and of log dy_0; an M-spline prior has the value alone)
+        if (o == 0 || !is_prior) out = row_dot(tab + ((size_t)o * sp.n_mesh + m) * nbp, c, nb) * c[64];
     }
-    comp[gid] = out;
+    reinterpret_cast<float*>(comp)[(size_t)gid * 4 + o] = out;
 }
 
 // comp2[n][m] = {comp[n][m].xy, comp[n][m + 1].xy}: the two lerp ends k_mfma needs of a composite table in one 16-byte record
@@ -271,7 +270,7 @@ int launch_prepare_dim0(const ModelDev* md_dev, int n_nets, int n_mesh, const fl
     // the coefficient block sits behind the tables in the same allocation (wf_model.cpp reserves dim0_coef_floats)
     float* coef = reinterpret_cast<float*>(comp_dev) + (size_t)total * 4;
     hipLaunchKernelGGL(k_dim0_coeffs, dim3(n_nets), dim3(64), 0, (hipStream_t)stream, md_dev, fk_nat_dev, F_I, F_P, coef);
-    hipLaunchKernelGGL(k_prepare_dim0, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, md_dev, n_mesh, (const float*)coef,
+    hipLaunchKernelGGL(k_prepare_dim0, dim3((4 * total + 255) / 256), dim3(256), 0, (hipStream_t)stream, md_dev, n_mesh, (const float*)coef,
                        tab_i_dev, tab_p_dev, reinterpret_cast<f32x4*>(comp_dev));
     f32x4* comp2 = reinterpret_cast<f32x4*>(coef + ((dim0_coef_floats(n_nets) + 3) & ~3));
     hipLaunchKernelGGL(k_pair_dim0, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const f32x4*>(comp_dev), n_nets,
