@@ -234,6 +234,17 @@ def test_staged_sampler_of_large_batches(he_flat, monkeypatch):
         for a, b in ((xa, xb), (la, lb)):
             p = stats.ks_2samp(a[:, c].cpu().numpy(), b[:, c].cpu().numpy()).pvalue
             assert p > 1e-4, (c, p)
+    # the envelope of the prior's second column from the conditioner launch's o * keep (round 4: they ARE the plain B-spline coefficients where the boundary
+    # map only zeroes coefficients) against the dense product e @ b_to_ob (WF_SAMPLE_DENSE_ENVELOPE): the same proposals, the same decisions but for
+    # roundings of the bounds
+    monkeypatch.setenv("WF_SAMPLE_TILE_MIN", "16384")
+    monkeypatch.setenv("WF_SAMPLE_DENSE_ENVELOPE", "1")
+    xd = m.sample(11, 60000, exact=True)
+    monkeypatch.delenv("WF_SAMPLE_DENSE_ENVELOPE")
+    # (98 % are the same bits, 99.5 % the same proposal: the dense product forms each coefficient from 28 cancelling terms -- its bounds carry ~1e-5 of the
+    # largest coefficient, enough to move one acceptance in a few thousand; the law is checked by the Kolmogorov-Smirnov lines above, which ran on the new form)
+    close = ((xd - xa).abs().max(dim=1).values < 1e-4).float().mean().item()
+    assert close > 0.99 and (xd == xa).all(dim=1).float().mean().item() > 0.9, close
     # more walkers than one pass of the scratch holds (2^18): the same walkers as a prefix of the larger batch drew
     monkeypatch.setenv("WF_SAMPLE_TILE_MIN", "16384")
     big = m.sample(21, (1 << 18) + 5000, exact=True)

@@ -99,7 +99,7 @@ __device__ __forceinline__ void cond_out(const float* net, const Frag (&f)[CH][2
 // the staged sampler, which reads nothing else, is the one caller with such models (the launch-per-net energy path leaves them to k_efused)
 template <bool PRIOR, int NBK = 1, int CH = NCH>
 __device__ __forceinline__ void cond_net(const float* net, const float* fkP, const _Float16* obh, float u0v, float u1v, int lane, f32x16 (&a0)[NBK][CH], float& s1,
-                                         const float* cbP = nullptr) {
+                                         const float* cbP = nullptr, f32x16* wkeep = nullptr /* PRIOR: [NBK] the value channel of o * keep, or null */) {
     Frag f[CH][2];
     int e[CH];
     cond_hidden<NBK, CH>(net, u0v, u1v, lane, f, e);
@@ -113,6 +113,10 @@ __device__ __forceinline__ void cond_net(const float* net, const float* fkP, con
         Frag of[NBK][CH];
         int eo[CH];
         prior_frags<NBK, CH>(o, fkP, lane, of, eo, s1);
+        if (wkeep) {
+#pragma unroll
+            for (int kb = 0; kb < NBK; ++kb) wkeep[kb] = o[kb][0];
+        }
 #pragma unroll
         for (int kb = 0; kb < NBK; ++kb) {
             prior_c_block<NBK, CH>(obh, of, eo, kb, lane, a0[kb]);
@@ -130,7 +134,9 @@ __device__ __forceinline__ void cond_net(const float* net, const float* fkP, con
 // 384 B per walker and row block out (oj[tile][row][32 walkers])
 template <bool PRIOR, int NBK = 1, int CH = NCH>
 __global__ __launch_bounds__(kCondWaves * 64, WF_ETILE_OCC) void k_etile_cond(const MfmaDev mm, int net_index, const float* __restrict__ st, int64_t B,
-                                                                float* __restrict__ oj, float* __restrict__ s1buf) {
+                                                                float* __restrict__ oj, float* __restrict__ s1buf, float* __restrict__ ow = nullptr) {
+    // ow (PRIOR, CH = 1; may be null): the value channel of o * keep, [tile][row][32 walkers] -- where the boundary map only zeroes coefficients these ARE the
+    // plain B-spline coefficients of c (c = (o keep) @ ob_to_b, and ob_to_b @ b_to_ob = 1): the staged sampler's envelope reads them instead of forming c @ b_to_ob
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ int next_tile;
     constexpr int kThreads = kCondWaves * 64;
@@ -156,10 +162,17 @@ __global__ __launch_bounds__(kCondWaves * 64, WF_ETILE_OCC) void k_etile_cond(co
         const bool valid = w < B;
         const int64_t wl = valid ? w : B - 1;
         const float u0v = st[wl], u1v = st[(int64_t)4 * B + wl];
-        f32x16 a0[NBK][CH];
+        f32x16 a0[NBK][CH], wk[NBK];
         float s1 = 0.0f;
-        cond_net<PRIOR, NBK, CH>(net, fkP, obh, u0v, u1v, lane, a0, s1, (PRIOR && mm.p_bias) ? lds + 64 * NBK + NBK * NBK * 1024 + 64 * NBK : nullptr);
+        cond_net<PRIOR, NBK, CH>(net, fkP, obh, u0v, u1v, lane, a0, s1, (PRIOR && mm.p_bias) ? lds + 64 * NBK + NBK * NBK * 1024 + 64 * NBK : nullptr,
+                                 (PRIOR && CH == 1 && ow) ? wk : nullptr);
         if (PRIOR && valid && h == 0) s1buf[w] = s1;
+        if (PRIOR && CH == 1 && ow && valid) {
+#pragma unroll
+            for (int kb = 0; kb < NBK; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ow[(tile * (32 * NBK) + 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * h) * 32 + j] = wk[kb][r];
+        }
         // ---- store: oj[tile][row][c][32 walkers] (one contiguous block per tile), row = accumulator row of register r in lane half h of block kb
 #ifdef WF_ABL_OJ   // ablation build (timing only): the head triples are computed, not stored
         if (valid && a0[0][0][0] == 12345.678f) {
@@ -1639,6 +1652,7 @@ struct TsArgs {
     const float* tabP0;        // order-0 rows of the prior's table [n_mesh][32]
     const float* gI;           // [32] row factors of the flow heads (boundary map; 0 beyond the bases)
     const float* b_to_ob;      // [32][32]
+    const float* ow;           // the prior's o * keep of the conditioner launch ([tile][row][32 walkers]) where they are the plain B-spline coefficients of c, or null
     int n_mesh, nbI, nbP, n_layers, degP;
     float i_reg, tol, box_L;
     unsigned long long seed;
@@ -1803,12 +1817,20 @@ __global__ __launch_bounds__(256, 2) void k_tsample(const TsArgs a, int layer, c
         // |f| <= M_s = max(|q_s| .. |q_{s + k}|).  Proposals are drawn from the piecewise-constant envelope M_s^2 (one uniform picks the interval and the
         // point in it) and accepted against M_s^2: the same law as the reference's uniform proposals under the global bound, at 5 - 8 x its acceptance rate.
         float aq[NB];
+        if (a.ow) {   // (the boundary map only zeroes coefficients: q = e @ b_to_ob = (o keep) / |c|, the product is the identity; round 4)
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            float acc = 0.0f;
+            for (int i = 0; i < NB; ++i) {
+                const float qi = i < a.nbP ? oj0<NB>(a.ow, b, i) * rn : 0.0f;
+                aq[i] = qi * qi;
+            }
+        } else {
 #pragma unroll
-            for (int j = 0; j < NB; ++j) acc = __builtin_fmaf(e[j], a.b_to_ob[j * NB + i], acc);
-            aq[i] = i < a.nbP ? acc * acc : 0.0f;
+            for (int i = 0; i < NB; ++i) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int j = 0; j < NB; ++j) acc = __builtin_fmaf(e[j], a.b_to_ob[j * NB + i], acc);
+                aq[i] = i < a.nbP ? acc * acc : 0.0f;
+            }
         }
         const int n_int = a.nbP - a.degP;       // knot intervals of equal width on [0, 1] (knots: linspace, the end knots (k + 1)-fold)
         float msq[NB], tot = 0.0f;
@@ -2097,7 +2119,7 @@ int64_t tile_sample_floats(int64_t B, int nbk) { return B * 10 + ((B + 31) / 32)
 
 namespace {
 template <int NBK>
-int launch_tile_sample_t(const MfmaDev* mdev, const ModelDev& md, const TsArgs& a, int draw, const float* u, int64_t B, float* x, float* latent, float* ws, hipStream_t s) {
+int launch_tile_sample_t(const MfmaDev* mdev, const ModelDev& md, const TsArgs& a_in, int draw, const float* u, int64_t B, float* x, float* latent, float* ws, hipStream_t s) {
     constexpr int NB = 32 * NBK;
     float* cin = ws;                 // [5][B]
     float* cur0 = cin + 5 * B;
@@ -2105,6 +2127,9 @@ int launch_tile_sample_t(const MfmaDev* mdev, const ModelDev& md, const TsArgs& 
     float* lat = cur1 + B;           // [B] (column 0 between the two prior phases)
     float* s1 = lat + 2 * B;
     float* oj = ws + (((size_t)10 * B + 63) / 64) * 64;
+    float* ow = (mdev->p_plain_bc && !getenv("WF_SAMPLE_DENSE_ENVELOPE")) ? oj + (size_t)((B + 31) / 32) * 32 * NB : nullptr;   // (behind the one channel oj holds: sized for three)
+    TsArgs a = a_in;
+    a.ow = ow;
     const unsigned lane_blocks = (unsigned)((B + 255) / 256);
     const int lds_bytes = (mdev->const_floats + mdev->net_floats) * (int)sizeof(float);
     static DynLdsSlots cfg_flow{}, cfg_prior{};
@@ -2115,7 +2140,7 @@ int launch_tile_sample_t(const MfmaDev* mdev, const ModelDev& md, const TsArgs& 
     const int L = md.n_layers;
     if (draw) {
         hipLaunchKernelGGL((k_tsample<0, NB>), dim3(lane_blocks), dim3(256), 0, s, a, 0, (const float*)oj, u, B, cur0, cur1, cin, lat, latent, x);
-        hipLaunchKernelGGL((k_etile_cond<true, NBK, 1>), dim3(cond_blocks), dim3(kCondWaves * 64), lds_bytes, s, *mdev, L, (const float*)cin, B, oj, s1);
+        hipLaunchKernelGGL((k_etile_cond<true, NBK, 1>), dim3(cond_blocks), dim3(kCondWaves * 64), lds_bytes, s, *mdev, L, (const float*)cin, B, oj, s1, ow);
         hipLaunchKernelGGL((k_tsample<1, NB>), dim3(lane_blocks), dim3(256), 0, s, a, 0, (const float*)oj, u, B, cur0, cur1, cin, lat, latent, x);
     } else {
         hipLaunchKernelGGL((k_tsample<3, NB>), dim3(lane_blocks), dim3(256), 0, s, a, 0, (const float*)oj, u, B, cur0, cur1, cin, lat, latent, x);

@@ -137,6 +137,7 @@ struct wf_model {
     std::vector<double> bc_i_colsum, bc_p_colsum;
     std::vector<float> p_cb;          // constant term of the B prior's boundary map times ob_to_b, natural order [nbp] (empty: homogeneous constraints)
     bool bc_i_ok = true, bc_p_ok = true;
+    bool bc_p_plain = false;   // B prior: the boundary map only zeroes coefficients (a masked identity, no constant term): (o keep) ARE the plain B-spline coefficients of c
     bool grad_psi_ok = false;        // wf_psi_vjp (Waveflow prior, IMADE layers)
     int ring2 = 2;                   // coefficient ring of the second-order sweeps (ring_coefs, wf_internal.h): 2 = RF, 1 = R3
     int32_t* d_grad_map = nullptr;   // [n_params]: forward-image entry (over all nets) that holds each parameter, -1 = none
@@ -473,6 +474,10 @@ static int model_build(wf_model* m) {
         {   // the constraints act on the net's outputs w before c = w @ ob_to_b: fold the map into the matrix's rows (row a = coefficient a)
             std::vector<double> A, bconst;
             m->bc_p_ok = bc_map(md.psp, WF_SPLINE_B, nb, A, m->bc_p_colsum, &bconst);
+            m->bc_p_plain = m->bc_p_ok && bconst.empty();
+            for (int i = 0; i < nb && m->bc_p_plain; ++i)
+                for (int j = 0; j < nb; ++j)
+                    if (A[(size_t)i * nb + j] != ((i == j && m->bc_p_colsum[j] != 0.0) ? 1.0 : 0.0)) { m->bc_p_plain = false; break; }
             if (m->bc_p_ok && !bconst.empty()) {   // constant term: cb = b @ ob_to_b (the matrix as it is, before the map is folded into its rows)
                 m->p_cb.assign(m->nbp, 0.0f);
                 for (int i = 0; i < nb; ++i) {
@@ -960,6 +965,7 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
     md.prior_quotient = (getenv("WF_PRIOR_QUOTIENT") && atoi(getenv("WF_PRIOR_QUOTIENT")) != 0) ? 1 : 0;
     md.i_gate = m->dev.i_gate; md.p_gate = m->dev.p_gate;
     md.p_bias = (d.prior_kind == WF_PRIOR_WAVEFLOW && !m->p_cb.empty()) ? 1 : 0;
+    md.p_plain_bc = (d.prior_kind == WF_PRIOR_WAVEFLOW && m->bc_p_plain) ? 1 : 0;
     md.timg_off = timg ? net_floats * n_nets + consts : -1;
     md.tnet_floats = tnet_floats;
     md.tconst_off = timg ? md.timg_off + tnet_floats * n_nets : -1;
