@@ -1867,7 +1867,10 @@ __global__ __launch_bounds__(256, 2) void k_tsample(const TsArgs a, int layer, c
         // Stage A: every lane proposes for its own walker, kTsOwn times at most (88 % of the walkers are done by then).  Stage B: the wave's remaining
         // walkers get eight lanes each, eight consecutive proposals of a walker's sequence per round, the first accepted one in sequence order taken --
         // the same draws as one lane proposing on alone, without the wave waiting 80 rounds for its unluckiest lane.
-        constexpr int kTsOwn = 16;
+#ifndef WF_TS_OWN   // (experiment switch; the draws do not depend on it.  2^17 draws, round 4: 16 own proposals 0.281 ms, 12: 0.283, 8: 0.287, 4: 0.294)
+#define WF_TS_OWN 16
+#endif
+        constexpr int kTsOwn = WF_TS_OWN;
         int n_prop = 0;
         float xs = __builtin_nanf("");
         bool done = false;
