@@ -245,6 +245,13 @@ def test_staged_sampler_of_large_batches(he_flat, monkeypatch):
     # largest coefficient, enough to move one acceptance in a few thousand; the law is checked by the Kolmogorov-Smirnov lines above, which ran on the new form)
     close = ((xd - xa).abs().max(dim=1).values < 1e-4).float().mean().item()
     assert close > 0.99 and (xd == xa).all(dim=1).float().mean().item() > 0.9, close
+    # ... and a proposal's value from the k + 1 plain B-splines alive on its knot interval (three table records per row) against the full rows of the
+    # orthogonal table (WF_SAMPLE_FULL_ROWS): sum_i q_i b_i(x) = sum_j e_j ob_j(x) up to the fp32 roundings of the two tables
+    monkeypatch.setenv("WF_SAMPLE_FULL_ROWS", "1")
+    xf = m.sample(11, 60000, exact=True)
+    monkeypatch.delenv("WF_SAMPLE_FULL_ROWS")
+    closef = ((xf - xa).abs().max(dim=1).values < 1e-4).float().mean().item()
+    assert closef > 0.995 and (xf == xa).all(dim=1).float().mean().item() > 0.99, closef
     # more walkers than one pass of the scratch holds (2^18): the same walkers as a prefix of the larger batch drew
     monkeypatch.setenv("WF_SAMPLE_TILE_MIN", "16384")
     big = m.sample(21, (1 << 18) + 5000, exact=True)

@@ -1652,6 +1652,7 @@ struct TsArgs {
     const float* tabP0;        // order-0 rows of the prior's table [n_mesh][32]
     const float* gI;           // [32] row factors of the flow heads (boundary map; 0 beyond the bases)
     const float* b_to_ob;      // [32][32]
+    const float* tabB0;        // plain B-splines of the prior, order 0 [n_mesh][NB] (with ow: the band-limited evaluation of a proposal), or null
     const float* ow;           // the prior's o * keep of the conditioner launch ([tile][row][32 walkers]) where they are the plain B-spline coefficients of c, or null
     int n_mesh, nbI, nbP, n_layers, degP;
     float i_reg, tol, box_L;
@@ -1724,8 +1725,13 @@ __device__ __forceinline__ float rows_lerp(const float* __restrict__ tab0, const
     const float4_t* ra = reinterpret_cast<const float4_t*>(tab0 + (size_t)L.il * NB);
     const float4_t* rb = reinterpret_cast<const float4_t*>(tab0 + (size_t)L.ir * NB);
     float acc = 0.0f;
+#ifdef WF_TS_FAKE_BAND   // timing experiment only (wrong values): three of the NB / 4 records per row, as a band-limited evaluation would read
+    constexpr int kQ = 3;
+#else
+    constexpr int kQ = NB / 4;
+#endif
 #pragma unroll
-    for (int q = 0; q < NB / 4; ++q) {
+    for (int q = 0; q < kQ; ++q) {
         const float4_t a = ra[q], b = rb[q];
         acc = __builtin_fmaf(c[4 * q], __builtin_fmaf(b.x - a.x, L.t, a.x), acc);
         acc = __builtin_fmaf(c[4 * q + 1], __builtin_fmaf(b.y - a.y, L.t, a.y), acc);
@@ -1755,6 +1761,10 @@ __global__ __launch_bounds__(256, 2) void k_tsample(const TsArgs a, int layer, c
                                                  float* __restrict__ cur0, float* __restrict__ cur1, float* __restrict__ cin, float* __restrict__ lat,
                                                  float* __restrict__ latent_out, float* __restrict__ xg) {
     __shared__ float red[256];
+    // phase 1, band form: the plain B-spline coefficients q of every walker of the workgroup, one row per lane (+ 4: rows stay 16-byte aligned and
+    // fall on different banks)
+    constexpr int kQStride = NB + 4;
+    __shared__ __attribute__((aligned(16))) float qs[PHASE == 1 ? 256 * kQStride : 4];
     constexpr int phase = PHASE;
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int n_mesh = a.n_mesh;
@@ -1817,11 +1827,13 @@ __global__ __launch_bounds__(256, 2) void k_tsample(const TsArgs a, int layer, c
         // |f| <= M_s = max(|q_s| .. |q_{s + k}|).  Proposals are drawn from the piecewise-constant envelope M_s^2 (one uniform picks the interval and the
         // point in it) and accepted against M_s^2: the same law as the reference's uniform proposals under the global bound, at 5 - 8 x its acceptance rate.
         float aq[NB];
+        const bool band = a.ow != nullptr && a.tabB0 != nullptr;
         if (a.ow) {   // (the boundary map only zeroes coefficients: q = e @ b_to_ob = (o keep) / |c|, the product is the identity; round 4)
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
                 const float qi = i < a.nbP ? oj0<NB>(a.ow, b, i) * rn : 0.0f;
                 aq[i] = qi * qi;
+                if (PHASE == 1) qs[threadIdx.x * kQStride + i] = qi;
             }
         } else {
 #pragma unroll
@@ -1845,7 +1857,7 @@ __global__ __launch_bounds__(256, 2) void k_tsample(const TsArgs a, int layer, c
         }
         const float wI = 1.0f / (float)n_int;
         // one proposal (number n of walker wb's sequence) against the envelope (mq, mtot) of the factor with coefficients ec
-        auto propose = [&](unsigned long long wb, int n, const float (&ec)[NB], const float (&mq)[NB], float mtot, float& xc) {
+        auto propose = [&](unsigned long long wb, int n, const float (&ec)[NB], const float (&mq)[NB], float mtot, float& xc, int qrow) {
             Philox4 prop(seed, wb);
             prop.c0 = (unsigned)n;
             prop.c1 = 2u;
@@ -1861,7 +1873,28 @@ __global__ __launch_bounds__(256, 2) void k_tsample(const TsArgs a, int layer, c
                 run += mq[sI];
             }
             xc = fminf(((float)ssel + fminf((t - base) / msel, 1.0f)) * wI, 0.99999994f);
-            const float v = rows_lerp<NB>(a.tabP0, ec, xc, n_mesh);
+            float v;
+            if (band) {
+                // f(x) = sum_i q_i b_i(x) over the k + 1 plain B-splines alive on knot interval ssel (b_ssel .. b_{ssel + k}, k <= 8): a window of 12
+                // coefficients from a multiple of four (the rest of the window multiplies zeros of the table) -- three 16-byte records per table row
+                // and lerp end instead of NB / 4, three of the walker's row in LDS (qrow: its own lane's, or the lane's it is served by)
+                const int a0 = min(ssel & ~3, NB - 12);
+                const LerpN Lx = nlerp(xc, n_mesh);
+                const float4_t* ra = reinterpret_cast<const float4_t*>(a.tabB0 + (size_t)Lx.il * NB + a0);
+                const float4_t* rb = reinterpret_cast<const float4_t*>(a.tabB0 + (size_t)Lx.ir * NB + a0);
+                const float4_t* qr = reinterpret_cast<const float4_t*>(qs + qrow * kQStride + a0);
+                v = 0.0f;
+#pragma unroll
+                for (int qq = 0; qq < 3; ++qq) {
+                    const float4_t ta = ra[qq], tb = rb[qq], qv = qr[qq];
+                    v = __builtin_fmaf(qv.x, __builtin_fmaf(tb.x - ta.x, Lx.t, ta.x), v);
+                    v = __builtin_fmaf(qv.y, __builtin_fmaf(tb.y - ta.y, Lx.t, ta.y), v);
+                    v = __builtin_fmaf(qv.z, __builtin_fmaf(tb.z - ta.z, Lx.t, ta.z), v);
+                    v = __builtin_fmaf(qv.w, __builtin_fmaf(tb.w - ta.w, Lx.t, ta.w), v);
+                }
+            } else {
+                v = rows_lerp<NB>(a.tabP0, ec, xc, n_mesh);
+            }
             return u2 * msel < v * v;
         };
         // Stage A: every lane proposes for its own walker, kTsOwn times at most (88 % of the walkers are done by then).  Stage B: the wave's remaining
@@ -1878,7 +1911,7 @@ __global__ __launch_bounds__(256, 2) void k_tsample(const TsArgs a, int layer, c
         for (int n = 0; n < kTsOwn; ++n) {
             float xc;
             n_prop = n + 1;
-            if (propose(wb_own, n, e, msq, tot, xc)) { xs = xc; done = true; break; }
+            if (propose(wb_own, n, e, msq, tot, xc, (int)threadIdx.x)) { xs = xc; done = true; break; }
         }
         if (NB > 32 || __ballot(true) != ~0ull) {
             // the batch's last, partial wave: lanes are missing from the groups, every walker keeps its own lane (and with two row blocks the
@@ -1886,7 +1919,7 @@ __global__ __launch_bounds__(256, 2) void k_tsample(const TsArgs a, int layer, c
             for (int n = kTsOwn; n < 100000 && !done; ++n) {
                 float xc;
                 n_prop = n + 1;
-                if (propose(wb_own, n, e, msq, tot, xc)) { xs = xc; done = true; }
+                if (propose(wb_own, n, e, msq, tot, xc, (int)threadIdx.x)) { xs = xc; done = true; }
             }
         } else {
             const int lane = threadIdx.x & 63, g = lane >> 3, r = lane & 7;
@@ -1899,7 +1932,7 @@ __global__ __launch_bounds__(256, 2) void k_tsample(const TsArgs a, int layer, c
                 const int src = has ? __ffsll((long long)mm) - 1 : lane;
                 float ew[NB], mw[NB];
 #pragma unroll
-                for (int j = 0; j < NB; ++j) { ew[j] = __shfl(e[j], src); mw[j] = __shfl(msq[j], src); }
+                for (int j = 0; j < NB; ++j) { ew[j] = band ? 0.0f : __shfl(e[j], src); mw[j] = __shfl(msq[j], src); }   // (band form: the served walker's coefficients are read from its LDS row)
                 const float totw = __shfl(tot, src);
                 const unsigned wlo = __shfl((unsigned)(wb_own & 0xFFFFFFFFull), src), whi = __shfl((unsigned)(wb_own >> 32), src);
                 const unsigned long long wbw = ((unsigned long long)whi << 32) | wlo;
@@ -1908,7 +1941,7 @@ __global__ __launch_bounds__(256, 2) void k_tsample(const TsArgs a, int layer, c
                 int rounds = 0;
                 for (int round = 0; round < (100000 - kTsOwn) / 8; ++round) {
                     float xc = 0.0f;
-                    const bool acc = !found && propose(wbw, kTsOwn + round * 8 + r, ew, mw, totw, xc);
+                    const bool acc = !found && propose(wbw, kTsOwn + round * 8 + r, ew, mw, totw, xc, (int)(threadIdx.x & ~63u) + src);
                     const unsigned long long hits = __ballot(acc);
                     const unsigned gh = (unsigned)(hits >> (8 * g)) & 0xFFu;
                     const float xfirst = __shfl(xc, 8 * g + (gh ? __ffs((int)gh) - 1 : 0));
@@ -2133,6 +2166,7 @@ int launch_tile_sample_t(const MfmaDev* mdev, const ModelDev& md, const TsArgs& 
     float* ow = (mdev->p_plain_bc && !getenv("WF_SAMPLE_DENSE_ENVELOPE")) ? oj + (size_t)((B + 31) / 32) * 32 * NB : nullptr;   // (behind the one channel oj holds: sized for three)
     TsArgs a = a_in;
     a.ow = ow;
+    a.tabB0 = (ow && !getenv("WF_SAMPLE_FULL_ROWS")) ? mdev->tabB0 : nullptr;
     const unsigned lane_blocks = (unsigned)((B + 255) / 256);
     const int lds_bytes = (mdev->const_floats + mdev->net_floats) * (int)sizeof(float);
     static DynLdsSlots cfg_flow{}, cfg_prior{};

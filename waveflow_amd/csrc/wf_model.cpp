@@ -116,6 +116,7 @@ struct wf_model {
     void* d_comp = nullptr;          // composite tables [n_nets][n_mesh] float4
     const float* d_tabI4 = nullptr;  // [4][n_mesh][nbp]: I-spline derivative orders 0..3 (local energy)
     const float* d_tabP3 = nullptr;  // [4][n_mesh][nbp]: orthogonal-B derivative orders 0..3 (the energy uses 0..2)
+    const float* d_tabB0 = nullptr;  // [n_mesh][nbp]: the PLAIN B-splines (order 0): the staged sampler's band-limited evaluation of a proposal
     // the same two tables regrouped for the lane-per-walker heads of wf_kernels_etile.hip (nbp == 32 only): [n_mesh][8 row chunks][4 orders][4 rows],
     // so that the four orders of four rows of one mesh point are one 64-byte segment
     const float* d_tabI4c = nullptr;
@@ -463,6 +464,12 @@ static int model_build(wf_model* m) {
             rc = upload_table(m, rows3, &m->d_tabP3);
             if (rc) return rc;
             rc = upload_chunked(m, rows3, d.n_mesh, m->nbp, &m->d_tabP4c);
+            if (rc) return rc;
+        }
+        {
+            std::vector<float> rowsB;
+            pack_rows(b64, nb, d.n_mesh, 1, m->nbp, rowsB);
+            rc = upload_table(m, rowsB, &m->d_tabB0);
             if (rc) return rc;
         }
         fill_bc(md.psp, d.p_left, d.p_right, b64, nb, d.n_mesh);  // BCs use the plain-B table, bsplines_jax.py:176-189
@@ -966,6 +973,7 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
     md.i_gate = m->dev.i_gate; md.p_gate = m->dev.p_gate;
     md.p_bias = (d.prior_kind == WF_PRIOR_WAVEFLOW && !m->p_cb.empty()) ? 1 : 0;
     md.p_plain_bc = (d.prior_kind == WF_PRIOR_WAVEFLOW && m->bc_p_plain) ? 1 : 0;
+    md.tabB0 = m->d_tabB0;
     md.timg_off = timg ? net_floats * n_nets + consts : -1;
     md.tnet_floats = tnet_floats;
     md.tconst_off = timg ? md.timg_off + tnet_floats * n_nets : -1;
