@@ -210,6 +210,11 @@ def test_staged_sampler_of_large_batches(he_flat, monkeypatch):
     for exact in (True, False):
         monkeypatch.setenv("WF_SAMPLE_TILE_MIN", "16384")
         xs = m.inverse(u, exact=exact)
+        # (round 4: the spline sums of the inverse read a window of 12 rows around the band of k + 1 that are neither 1 nor 0, + the prefix sum of the
+        # coefficients left of it: the full rows give the same bits)
+        monkeypatch.setenv("WF_SAMPLE_FULL_ROWS", "1")
+        assert np.array_equal(xs, m.inverse(u, exact=exact))
+        monkeypatch.delenv("WF_SAMPLE_FULL_ROWS")
         monkeypatch.setenv("WF_SAMPLE_TILE_MIN", "0")
         xw = m.inverse(u, exact=exact)                       # one wave per walker
         assert np.isfinite(xs).all() and not np.array_equal(xs, xw)

@@ -120,7 +120,8 @@ struct MfmaDev {
     int prior_quotient;        // debug (env WF_PRIOR_QUOTIENT=1 at model creation): Waveflow prior head in the reference's quotient form
     int i_gate, p_gate;        // gated heads (wf_model_desc.i_gate / p_gate): zero_params blocks of the net images are live
     int timg_off, tnet_floats, tconst_off;   // transposed operand images of the gradient path behind the constants block (float offsets in `image`; -1: not built)
-    int p_plain_bc;            // B prior: the boundary map only zeroes coefficients (the staged sampler then reads the plain B-spline coefficients of the prior's second factor off the conditioner launch)
+int i_plain_bc;            // I layers: the boundary map only zeroes coefficients (the staged sampler's band form of the spline sums)
+        int p_plain_bc;            // B prior: the boundary map only zeroes coefficients (the staged sampler then reads the plain B-spline coefficients of the prior's second factor off the conditioner launch)
     const float* tabB0;        // [n_mesh][32 nbk] plain B-splines of the prior, order 0 (the staged sampler: the k + 1 of them alive on a knot interval give a proposal's value)
     int p_bias;                // the B prior's boundary map has a constant term: cbP[nbk][2][16] (accumulator layout) sits at the end of the constants block
     const int* f16_ovf;        // [n_nets] 1 = a packed weight of that net is outside the fp16 range (k_fold_bias, rewritten at every upload): outputs are poisoned with NaN

@@ -1655,6 +1655,7 @@ struct TsArgs {
     const float* tabB0;        // plain B-splines of the prior, order 0 [n_mesh][NB] (with ow: the band-limited evaluation of a proposal), or null
     const float* ow;           // the prior's o * keep of the conditioner launch ([tile][row][32 walkers]) where they are the plain B-spline coefficients of c, or null
     int n_mesh, nbI, nbP, n_layers, degP;
+    int i_band_int;            // > 0: knot intervals of the I-splines, and their rows are plain (exactly 1 left of a band of k + 1 <= 8 rows, 0 right of it): the band form of phase 2
     float i_reg, tol, box_L;
     unsigned long long seed;
     const unsigned long long* seed_offset_dev;
@@ -1747,6 +1748,50 @@ __device__ __forceinline__ float inv_rows(const float* __restrict__ tab0, const 
     mesh_search([&](int i) { return rows_dot<NB>(tab0 + (size_t)i * NB, c); }, n_mesh - 1, y, m, yl, yr);
     return grid_root([&](float x) { return rows_lerp<NB>(tab0, c, x, n_mesh); }, m, yl, yr, y, n_mesh - 1, tol);
 }
+// ... with plain I-spline rows (TsArgs::i_band_int): at mesh point i only the rows s .. s + k of knot interval s = floor(x_i n_int) are neither 1 nor 0, so
+// sum_j c_j T[i][j] = (sum of the c_j left of a window of 12 rows from a multiple of four) + (the window's terms): three 16-byte records per row instead of
+// NB / 4, in the order of the full sum -- the same bits (a row of ones adds c_j, a row of zeros nothing).  cs: the walker's coefficients, p4: their prefix
+// sums at the multiples of four, both in LDS (the window moves with the mesh point).  A lerp between neighbouring mesh points needs s .. s + k + 1: k <= 7.
+template <int NB>
+__device__ __forceinline__ float inv_rows_band(const float* __restrict__ tab0, const float* cs, const float* p4, int n_int, int n_mesh, float y, float tol) {
+    auto window = [&](int i) { return min(min((i * n_int) / (n_mesh - 1), n_int - 1) & ~3, NB - 12); };
+    auto dot_at = [&](int i) {
+        const int a0 = window(i);
+        const float4_t* r = reinterpret_cast<const float4_t*>(tab0 + (size_t)i * NB + a0);
+        const float4_t* cq = reinterpret_cast<const float4_t*>(cs + a0);
+        float acc = p4[a0 >> 2];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const float4_t t = r[q], c = cq[q];
+            acc = __builtin_fmaf(c.x, t.x, acc);
+            acc = __builtin_fmaf(c.y, t.y, acc);
+            acc = __builtin_fmaf(c.z, t.z, acc);
+            acc = __builtin_fmaf(c.w, t.w, acc);
+        }
+        return acc;
+    };
+    auto lerp_at = [&](float x) {
+        const LerpN L = nlerp(x, n_mesh);
+        const int a0 = window(min(L.il, L.ir));
+        const float4_t* ra = reinterpret_cast<const float4_t*>(tab0 + (size_t)L.il * NB + a0);
+        const float4_t* rb = reinterpret_cast<const float4_t*>(tab0 + (size_t)L.ir * NB + a0);
+        const float4_t* cq = reinterpret_cast<const float4_t*>(cs + a0);
+        float acc = p4[a0 >> 2];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const float4_t ta = ra[q], tb = rb[q], c = cq[q];
+            acc = __builtin_fmaf(c.x, __builtin_fmaf(tb.x - ta.x, L.t, ta.x), acc);
+            acc = __builtin_fmaf(c.y, __builtin_fmaf(tb.y - ta.y, L.t, ta.y), acc);
+            acc = __builtin_fmaf(c.z, __builtin_fmaf(tb.z - ta.z, L.t, ta.z), acc);
+            acc = __builtin_fmaf(c.w, __builtin_fmaf(tb.w - ta.w, L.t, ta.w), acc);
+        }
+        return acc;
+    };
+    int m;
+    float yl, yr;
+    mesh_search(dot_at, n_mesh - 1, y, m, yl, yr);
+    return grid_root(lerp_at, m, yl, yr, y, n_mesh - 1, tol);
+}
 // channel 0 of the head outputs of walker b: oj[tile][row 0 .. NB)[channel][32 walkers]
 template <int NB>
 __device__ __forceinline__ float oj0(const float* __restrict__ oj, int64_t b, int row) { return oj[((b >> 5) * NB + row) * 32 + (b & 31)]; }   // (k_etile_cond<., ., 1>: the value channel alone)
@@ -1764,7 +1809,10 @@ __global__ __launch_bounds__(256, 2) void k_tsample(const TsArgs a, int layer, c
     // phase 1, band form: the plain B-spline coefficients q of every walker of the workgroup, one row per lane (+ 4: rows stay 16-byte aligned and
     // fall on different banks)
     constexpr int kQStride = NB + 4;
-    __shared__ __attribute__((aligned(16))) float qs[PHASE == 1 ? 256 * kQStride : 4];
+    constexpr bool kBand2 = PHASE == 2 && NB == 32;   // phase 2, band form (inv_rows_band): the walker's spline coefficients and their prefix sums (one row block: two
+                                                      // row blocks would take the LDS of the second workgroup per CU)
+    __shared__ __attribute__((aligned(16))) float qs[(PHASE == 1 || kBand2) ? 256 * kQStride : 4];
+    __shared__ __attribute__((aligned(16))) float p4s[kBand2 ? 256 * (NB / 4 + 4) : 4];
     constexpr int phase = PHASE;
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int n_mesh = a.n_mesh;
@@ -1982,7 +2030,21 @@ __global__ __launch_bounds__(256, 2) void k_tsample(const TsArgs a, int layer, c
 #pragma unroll
     for (int j = 0; j < NB; ++j) c[j] = j < a.nbI ? (a.gI[j] * __builtin_fmaf(c[j], rS, a.i_reg)) * rQ : 0.0f;
     const float o0 = cur0[b];
-    const float o1 = inv_rows<NB>(a.tabI0, c, n_mesh, cur1[b], a.tol);
+    float o1;
+    if (kBand2 && a.i_band_int > 0) {
+        float* cs = qs + threadIdx.x * kQStride;
+        float* p4 = p4s + threadIdx.x * (NB / 4 + 4);
+        float run = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            if ((j & 3) == 0) p4[j >> 2] = run;
+            cs[j] = c[j];
+            run = __builtin_fmaf(c[j], 1.0f, run);     // (as the full sum meets a row of ones)
+        }
+        o1 = inv_rows_band<NB>(a.tabI0, cs, p4, a.i_band_int, n_mesh, cur1[b], a.tol);
+    } else {
+        o1 = inv_rows<NB>(a.tabI0, c, n_mesh, cur1[b], a.tol);
+    }
     if (layer > 0) {
         start_layer(layer - 1, o0, o1);
         return;
@@ -2204,6 +2266,7 @@ int launch_tile_sample(const MfmaDev* mdev, const ModelDev& md, const float* tab
     a.nbI = md.isp.nb;
     a.nbP = md.psp.nb;
     a.degP = md.psp.degree;
+    a.i_band_int = (mdev->i_plain_bc && md.isp.degree <= 7 && !getenv("WF_SAMPLE_FULL_ROWS")) ? md.isp.nb - md.isp.degree : 0;
     a.n_layers = md.n_layers;
     a.i_reg = md.i_reg;
     a.tol = md.reverse_tol;

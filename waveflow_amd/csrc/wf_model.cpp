@@ -138,6 +138,7 @@ struct wf_model {
     std::vector<double> bc_i_colsum, bc_p_colsum;
     std::vector<float> p_cb;          // constant term of the B prior's boundary map times ob_to_b, natural order [nbp] (empty: homogeneous constraints)
     bool bc_i_ok = true, bc_p_ok = true;
+    bool bc_i_plain = false;   // I layers: the same of their boundary map (the rows of the evaluation table are then the plain I-splines: exactly 1 left of a band of k + 1, 0 right of it)
     bool bc_p_plain = false;   // B prior: the boundary map only zeroes coefficients (a masked identity, no constant term): (o keep) ARE the plain B-spline coefficients of c
     bool grad_psi_ok = false;        // wf_psi_vjp (Waveflow prior, IMADE layers)
     int ring2 = 2;                   // coefficient ring of the second-order sweeps (ring_coefs, wf_internal.h): 2 = RF, 1 = R3
@@ -427,6 +428,10 @@ static int model_build(wf_model* m) {
         {   // the table-driven kernels read the rows with the boundary map folded in (identical rows for zero-only constraints)
             std::vector<double> A;
             m->bc_i_ok = bc_map(md.isp, WF_SPLINE_I, nb, A, m->bc_i_colsum);
+            m->bc_i_plain = m->bc_i_ok;
+            for (int i = 0; i < nb && m->bc_i_plain; ++i)
+                for (int j = 0; j < nb; ++j)
+                    if (A[(size_t)i * nb + j] != ((i == j && m->bc_i_colsum[j] != 0.0) ? 1.0 : 0.0)) { m->bc_i_plain = false; break; }
             if (m->bc_i_ok) bc_transform_rows(A, m->bc_i_colsum, nb, 4, d.n_mesh, t64);
         }
         {   // derivative orders 0..3 for the wave kernels
@@ -974,6 +979,7 @@ static int mfma_prepare(wf_model* m, const std::vector<double>& i64, const std::
     md.p_bias = (d.prior_kind == WF_PRIOR_WAVEFLOW && !m->p_cb.empty()) ? 1 : 0;
     md.p_plain_bc = (d.prior_kind == WF_PRIOR_WAVEFLOW && m->bc_p_plain) ? 1 : 0;
     md.tabB0 = m->d_tabB0;
+    md.i_plain_bc = (imade && m->bc_i_plain) ? 1 : 0;
     md.timg_off = timg ? net_floats * n_nets + consts : -1;
     md.tnet_floats = tnet_floats;
     md.tconst_off = timg ? md.timg_off + tnet_floats * n_nets : -1;
