@@ -1809,7 +1809,7 @@ __global__ __launch_bounds__(256, 2) void k_tsample(const TsArgs a, int layer, c
     // phase 1, band form: the plain B-spline coefficients q of every walker of the workgroup, one row per lane (+ 4: rows stay 16-byte aligned and
     // fall on different banks)
     constexpr int kQStride = NB + 4;
-        constexpr bool kBand2 = PHASE == 2;   // phase 2, band form (inv_rows_band): the walker's spline coefficients and their prefix sums (two row blocks: 90 KB, one
+    constexpr bool kBand2 = PHASE == 2;   // phase 2, band form (inv_rows_band): the walker's spline coefficients and their prefix sums (two row blocks: 90 KB, one
                                                       // workgroup per CU instead of two -- and still 0.537 -> 0.450 ms per 2^17 draws of the 33-knot model)
     __shared__ __attribute__((aligned(16))) float qs[(PHASE == 1 || kBand2) ? 256 * kQStride : 4];
     __shared__ __attribute__((aligned(16))) float p4s[kBand2 ? 256 * (NB / 4 + 4) : 4];
