@@ -1818,18 +1818,26 @@ __global__ __launch_bounds__(256, 2) void k_tsample(const TsArgs a, int layer, c
     const int n_mesh = a.n_mesh;
     unsigned long long seed = a.seed;
     if (a.seed_offset_dev) seed += *a.seed_offset_dev * 0x9E3779B97F4A7C15ull;
-    float ymax0 = 0.0f;
-    if (phase == 0) {   // the first column's bound: the largest P^2 on the mesh
+    // phase 0: piecewise-constant envelope of the first column's density P^2 (the same for every walker): kBins equal bins of [0, 1], M_j = the largest P^2 at
+    // the mesh points of the cells that meet bin j (the lerp of P is piecewise linear: P^2 peaks at a mesh point), red[j] = M_j, red[kBins + j] = sum_{i < j} M_i.
+    // Round 3 proposed uniformly under the global maximum: the same law at a fifth of the acceptance rate (34 us of the sampler's 228 at 2^17 walkers).
+    constexpr int kBins = 64;
+    if (phase == 0) {
         const float4_t* cp = a.comp + (size_t)a.n_layers * n_mesh;
-        float mx = 0.0f;
-        for (int i = threadIdx.x; i < n_mesh; i += blockDim.x) { const float p = cp[i].x; mx = fmaxf(mx, p * p); }
-        red[threadIdx.x] = mx;
-        __syncthreads();
-        for (int s = 128; s > 0; s >>= 1) {
-            if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
-            __syncthreads();
+        if (threadIdx.x < kBins) {
+            const int j = threadIdx.x;
+            const int m0 = max((int)floorf((float)j / kBins * (float)(n_mesh - 1)) - 1, 0), m1 = min((int)ceilf((float)(j + 1) / kBins * (float)(n_mesh - 1)) + 1, n_mesh - 1);
+            float mx = 0.0f;
+            for (int i = m0; i <= m1; ++i) { const float pv = cp[i].x; mx = fmaxf(mx, pv * pv); }
+            red[j] = mx;
         }
-        ymax0 = red[0];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float run = 0.0f;
+            for (int j = 0; j < kBins; ++j) { red[kBins + j] = run; run += red[j]; }
+            red[2 * kBins] = run;
+        }
+        __syncthreads();
     }
     if (b >= B) return;
     // the next layer's dimension 0 from the pair (va, vb) that leaves a layer (or the prior): Reverse.inverse_fun, then the composite table
@@ -1842,14 +1850,21 @@ __global__ __launch_bounds__(256, 2) void k_tsample(const TsArgs a, int layer, c
     };
     if (phase == 0) {
         const float4_t* cp = a.comp + (size_t)a.n_layers * n_mesh;
+        const float tot = red[2 * kBins];
         float xs = __builtin_nanf("");
         for (int n = 0; n < 100000; ++n) {
             Philox4 prop(seed, (unsigned long long)(a.b0 + b));
             prop.c0 = (unsigned)n;
             prop.c1 = 1u;
-            const float xc = prop.uniform(), yc = prop.uniform() * ymax0;
+            const float t = prop.uniform() * tot, u2 = prop.uniform();
+            int j = 0;      // the last bin whose prefix sum does not exceed t
+#pragma unroll
+            for (int step = kBins / 2; step > 0; step >>= 1) j = red[kBins + j + step] <= t ? j + step : j;
+            const float mj = red[j];
+            if (!(mj > 0.0f)) continue;
+            const float xc = fminf(((float)j + fminf((t - red[kBins + j]) / mj, 1.0f)) * (1.0f / kBins), 0.99999994f);
             const float p = comp_lerp_x(cp, xc, n_mesh);
-            if (yc < p * p) { xs = xc; break; }
+            if (u2 * mj < p * p) { xs = xc; break; }
         }
         lat[b] = xs;
         cin[b] = xs;
