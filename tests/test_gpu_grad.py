@@ -348,7 +348,9 @@ def test_large_batch_training_steps_take_the_matrix_core_gradient(tmp_path, monk
     assert len(a) == 12 and np.isfinite(a).all() and np.isfinite(b).all()
     assert not np.array_equal(a, b)                       # two different kernels ...
     if knots == 23:
-        np.testing.assert_allclose(a, b, rtol=2e-3)       # ... one training run (the walkers are the same: same sampler, same seeds)
+        # ... one training run (the walkers are the same: same sampler, same seeds): the two runs part at 2e-5 and drift (3.5e-3 at step 11 with round 4's draws)
+        np.testing.assert_allclose(a[:2], b[:2], rtol=2e-4)
+        np.testing.assert_allclose(a, b, rtol=2e-2)
     else:
         # the seeded 33-knot start is a rough one (batch means of E_L between 14 and 150 over these 12 steps): the two runs part at 1e-5 and
         # the differences grow with the steps (measured 1.4e-5, 2.3e-4, 1.7e-3, ... 3e-2 at step 11)
