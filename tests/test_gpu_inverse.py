@@ -257,6 +257,12 @@ def test_staged_sampler_of_large_batches(he_flat, monkeypatch):
     monkeypatch.delenv("WF_SAMPLE_FULL_ROWS")
     closef = ((xf - xa).abs().max(dim=1).values < 1e-4).float().mean().item()
     assert closef > 0.995 and (xf == xa).all(dim=1).float().mean().item() > 0.99, closef
+    # eight lanes per walker from the first proposal on (k_tsample_p1g) against the walker's own lane walking its proposals (WF_SAMPLE_ONE_LANE): the first
+    # accepted proposal in sequence order either way -- the same draws, bit for bit
+    monkeypatch.setenv("WF_SAMPLE_ONE_LANE", "1")
+    xo, lo = m.sample(11, 60000, return_latent=True, exact=True)
+    monkeypatch.delenv("WF_SAMPLE_ONE_LANE")
+    assert torch.equal(xo, xa) and torch.equal(lo, la)
     # more walkers than one pass of the scratch holds (2^18): the same walkers as a prefix of the larger batch drew
     monkeypatch.setenv("WF_SAMPLE_TILE_MIN", "16384")
     big = m.sample(21, (1 << 18) + 5000, exact=True)

@@ -1924,7 +1924,8 @@ __global__ __launch_bounds__(256, 2) void k_tsample(const TsArgs a, int layer, c
             Philox4 prop(seed, wb);
             prop.c0 = (unsigned)n;
             prop.c1 = 2u;
-            const float t = prop.uniform() * mtot, u2 = prop.uniform();
+            // (__fmul_rn: the product must not contract into the subtraction t - base below -- k_tsample_p1g draws the same numbers only if both round it)
+            const float t = __fmul_rn(prop.uniform(), mtot), u2 = prop.uniform();
             float run = 0.0f, base = 0.0f, msel = mq[0];
             int ssel = 0;
 #pragma unroll
@@ -2026,6 +2027,9 @@ __global__ __launch_bounds__(256, 2) void k_tsample(const TsArgs a, int layer, c
 #else
         if (latent_out) { latent_out[b * 2] = l0; latent_out[b * 2 + 1] = xs; }
 #endif
+#ifdef WF_TS_DEBUG   // (diagnostics: an intermediate instead of the first column in the reported latent)
+        if (latent_out) latent_out[b * 2] = WF_TS_DEBUG == 1 ? tot : (WF_TS_DEBUG == 2 ? rn : msq[WF_TS_DEBUG - 3]);
+#endif
         start_layer(a.n_layers - 1, l0, xs);
         return;
     }
@@ -2068,6 +2072,115 @@ __global__ __launch_bounds__(256, 2) void k_tsample(const TsArgs a, int layer, c
     const float mean = 0.5f * o0, pm = o1 * (1.0f - o0) - (0.5f - mean);
     xg[b * 2] = ((0.0f - mean) + pm) * 2.0f * a.box_L;
     xg[b * 2 + 1] = ((o0 - mean) + pm) * 2.0f * a.box_L;
+}
+
+// Phase 1 of the staged sampler with EIGHT LANES PER WALKER from the start (band form only: TsArgs::ow and ::tabB0 set).  k_tsample<1> walks a walker's
+// proposals one after the other on its own lane -- ~20 dependent table round trips per wave at two waves per SIMD (64 % of its cycles wait on memory).  Here lane
+// r of a walker's group tests proposal 8 * round + r; the first accepted one in sequence order is taken: the same draws, ~3 round trips, sixteen waves per SIMD.
+// Everything whose rounding depends on the order of a sum (|c|^2, the prefix sums of the envelope) is summed by the group's first lane in k_tsample<1>'s order.
+template <int NB>
+__global__ __launch_bounds__(256) void k_tsample_p1g(const TsArgs a, const float* __restrict__ oj, int64_t B, float* __restrict__ cur0, float* __restrict__ cur1,
+                                                    float* __restrict__ cin, const float* __restrict__ lat, float* __restrict__ latent_out) {
+    constexpr int kStride = NB + 12;     // (+ 8: the envelope reads aq[s .. s + 8]; rows stay 16-byte aligned)
+    __shared__ __attribute__((aligned(16))) float qs[32 * kStride], aqs[32 * kStride], mqs[32 * kStride], cums[32 * kStride];
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t b = t >> 3;
+    const int r = threadIdx.x & 7, gl = (threadIdx.x & 63) >> 3, wrow = threadIdx.x >> 3, lane = threadIdx.x & 63;
+    const bool valid = b < B;
+    const int64_t bl = valid ? b : B - 1;
+    const int n_mesh = a.n_mesh;
+    unsigned long long seed = a.seed;
+    if (a.seed_offset_dev) seed += *a.seed_offset_dev * 0x9E3779B97F4A7C15ull;
+    float* q = qs + wrow * kStride;
+    float* aq = aqs + wrow * kStride;
+    float* mq = mqs + wrow * kStride;
+    float* cum = cums + wrow * kStride;
+    // |c|^2 in k_tsample<1>'s order (j ascending, fused multiply-adds) by the group's first lane
+    float rn = 0.0f;
+    if (r == 0) {
+        float ss = 0.0f;
+#pragma unroll 8
+        for (int j = 0; j < NB; ++j) { const float cj = j < a.nbP ? oj0<NB>(oj, bl, j) : 0.0f; ss = __builtin_fmaf(cj, cj, ss); }
+        rn = 1.0f / sqrtf(ss);
+    }
+    rn = __shfl(rn, lane & ~7);
+#pragma unroll
+    for (int jj = 0; jj < NB / 8 + 1; ++jj) {       // (+ 1: the eight slots behind the row, zeros for the envelope's look-ahead)
+        const int j = r + 8 * jj;
+        const float qi = (j < a.nbP) ? oj0<NB>(a.ow, bl, j) * rn : 0.0f;
+        q[j] = qi;
+        aq[j] = qi * qi;
+    }
+    const int n_int = a.nbP - a.degP;
+#pragma unroll
+    for (int jj = 0; jj < NB / 8; ++jj) {
+        const int sI = r + 8 * jj;
+        float mx = 0.0f;
+#pragma unroll
+        for (int d = 0; d <= 8; ++d)
+            if (sI + d < NB && d <= a.degP) mx = fmaxf(mx, aq[sI + d]);
+        mq[sI] = sI < n_int ? mx : 0.0f;
+    }
+    float tot = 0.0f;
+    if (r == 0) {
+#pragma unroll 8
+        for (int sI = 0; sI < NB; ++sI) { cum[sI] = tot; tot += mq[sI]; }
+    }
+    tot = __shfl(tot, lane & ~7);
+    const float wI = 1.0f / (float)n_int;
+    const unsigned long long wb = (unsigned long long)(a.b0 + bl);
+    bool found = !valid;
+    float xw = __builtin_nanf("");
+    for (int round = 0; round < 12500; ++round) {
+        bool acc = false;
+        float xc = 0.0f;
+        if (!found) {
+            Philox4 prop(seed, wb);
+            prop.c0 = (unsigned)(round * 8 + r);
+            prop.c1 = 2u;
+            const float tt = __fmul_rn(prop.uniform(), tot), u2 = prop.uniform();
+            // the last interval with cum <= tt and a positive bound (k_tsample<1>'s scan)
+            int sI = 0;
+#pragma unroll
+            for (int step = NB / 2; step > 0; step >>= 1) sI = cum[sI + step] <= tt ? sI + step : sI;
+            while (sI > 0 && !(mq[sI] > 0.0f)) --sI;
+            const float msel = mq[sI], base = cum[sI];
+            xc = fminf(((float)sI + fminf((tt - base) / msel, 1.0f)) * wI, 0.99999994f);
+            const int a0 = min(sI & ~3, NB - 12);
+            const LerpN Lx = nlerp(xc, n_mesh);
+            const float4_t* ra = reinterpret_cast<const float4_t*>(a.tabB0 + (size_t)Lx.il * NB + a0);
+            const float4_t* rb = reinterpret_cast<const float4_t*>(a.tabB0 + (size_t)Lx.ir * NB + a0);
+            const float4_t* qr = reinterpret_cast<const float4_t*>(q + a0);
+            float v = 0.0f;
+#pragma unroll
+            for (int qq = 0; qq < 3; ++qq) {
+                const float4_t ta = ra[qq], tb = rb[qq], qv = qr[qq];
+                v = __builtin_fmaf(qv.x, __builtin_fmaf(tb.x - ta.x, Lx.t, ta.x), v);
+                v = __builtin_fmaf(qv.y, __builtin_fmaf(tb.y - ta.y, Lx.t, ta.y), v);
+                v = __builtin_fmaf(qv.z, __builtin_fmaf(tb.z - ta.z, Lx.t, ta.z), v);
+                v = __builtin_fmaf(qv.w, __builtin_fmaf(tb.w - ta.w, Lx.t, ta.w), v);
+            }
+            acc = u2 * msel < v * v;
+        }
+        const unsigned long long hits = __ballot(acc);
+        const unsigned gh = (unsigned)(hits >> (8 * gl)) & 0xFFu;
+        const float xfirst = __shfl(xc, 8 * gl + (gh ? __ffs((int)gh) - 1 : 0));
+        if (!found && gh) { xw = xfirst; found = true; }
+        if (__ballot(!found) == 0ull) break;
+    }
+    if (valid && r == 0) {
+        const float l0 = lat[b];
+        if (latent_out) { latent_out[b * 2] = l0; latent_out[b * 2 + 1] = xw; }
+#ifdef WF_TS_DEBUG
+        if (latent_out) latent_out[b * 2] = WF_TS_DEBUG == 1 ? tot : (WF_TS_DEBUG == 2 ? rn : mq[WF_TS_DEBUG - 3]);
+#endif
+        // the last layer's dimension 0 from the pair that leaves the prior (k_tsample: start_layer)
+        const int l = a.n_layers - 1;
+        const float o0 = inv_comp(a.comp + (size_t)l * n_mesh, n_mesh, xw, a.tol);
+        cur0[b] = o0;
+        cur1[b] = l0;
+        cin[b] = a.exact ? o0 : xw;
+    }
 }
 
 int check() {
@@ -2255,7 +2368,10 @@ int launch_tile_sample_t(const MfmaDev* mdev, const ModelDev& md, const TsArgs& 
     if (draw) {
         hipLaunchKernelGGL((k_tsample<0, NB>), dim3(lane_blocks), dim3(256), 0, s, a, 0, (const float*)oj, u, B, cur0, cur1, cin, lat, latent, x);
         hipLaunchKernelGGL((k_etile_cond<true, NBK, 1>), dim3(cond_blocks), dim3(kCondWaves * 64), lds_bytes, s, *mdev, L, (const float*)cin, B, oj, s1, ow);
-        hipLaunchKernelGGL((k_tsample<1, NB>), dim3(lane_blocks), dim3(256), 0, s, a, 0, (const float*)oj, u, B, cur0, cur1, cin, lat, latent, x);
+        if (a.ow && a.tabB0 && !getenv("WF_SAMPLE_ONE_LANE"))   // (the band form: eight lanes per walker)
+            hipLaunchKernelGGL((k_tsample_p1g<NB>), dim3((unsigned)((B * 8 + 255) / 256)), dim3(256), 0, s, a, (const float*)oj, B, cur0, cur1, cin, (const float*)lat, latent);
+        else
+            hipLaunchKernelGGL((k_tsample<1, NB>), dim3(lane_blocks), dim3(256), 0, s, a, 0, (const float*)oj, u, B, cur0, cur1, cin, lat, latent, x);
     } else {
         hipLaunchKernelGGL((k_tsample<3, NB>), dim3(lane_blocks), dim3(256), 0, s, a, 0, (const float*)oj, u, B, cur0, cur1, cin, lat, latent, x);
     }
