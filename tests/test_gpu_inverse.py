@@ -215,6 +215,10 @@ def test_staged_sampler_of_large_batches(he_flat, monkeypatch):
         monkeypatch.setenv("WF_SAMPLE_FULL_ROWS", "1")
         assert np.array_equal(xs, m.inverse(u, exact=exact))
         monkeypatch.delenv("WF_SAMPLE_FULL_ROWS")
+        # ... and so do eight lanes per walker with eight-way mesh searches (k_tsample_p2g: the default with two row blocks, forced here)
+        monkeypatch.setenv("WF_SAMPLE_GROUP_PHASE2", "1")
+        assert np.array_equal(xs, m.inverse(u, exact=exact))
+        monkeypatch.delenv("WF_SAMPLE_GROUP_PHASE2")
         monkeypatch.setenv("WF_SAMPLE_TILE_MIN", "0")
         xw = m.inverse(u, exact=exact)                       # one wave per walker
         assert np.isfinite(xs).all() and not np.array_equal(xs, xw)
@@ -298,6 +302,11 @@ def test_staged_sampler_with_two_row_blocks(monkeypatch):
     for exact in (True, False):
         monkeypatch.setenv("WF_SAMPLE_TILE_MIN", "16384")
         xs = m.inverse(u, exact=exact)
+        # (two row blocks: eight lanes per walker and eight-way mesh searches by default; the walker's own lane and the full table rows give the same bits)
+        for switch in ("WF_SAMPLE_ONE_LANE", "WF_SAMPLE_FULL_ROWS"):
+            monkeypatch.setenv(switch, "1")
+            assert np.array_equal(xs, m.inverse(u, exact=exact)), switch
+            monkeypatch.delenv(switch)
         monkeypatch.setenv("WF_SAMPLE_TILE_MIN", "0")
         monkeypatch.setenv("WF_WAVE_SAMPLE_MAX", "100000000")
         xw = m.inverse(u, exact=exact)
@@ -310,6 +319,9 @@ def test_staged_sampler_with_two_row_blocks(monkeypatch):
     monkeypatch.setenv("WF_SAMPLE_TILE_MIN", "16384")
     xa, la = m.sample(11, 60001, return_latent=True, exact=True)
     assert torch.equal(xa, m.sample(11, 60001, exact=True)) and torch.isfinite(xa).all() and torch.isfinite(la).all()
+    monkeypatch.setenv("WF_SAMPLE_ONE_LANE", "1")      # (the same draws from the walker's own lane)
+    assert torch.equal(xa, m.sample(11, 60001, exact=True))
+    monkeypatch.delenv("WF_SAMPLE_ONE_LANE")
     ub, _ = m.flow(xa)
     assert np.median(np.abs(ub.cpu().numpy() - la.cpu().numpy())) < 2e-5
     monkeypatch.setenv("WF_SAMPLE_TILE_MIN", "0")

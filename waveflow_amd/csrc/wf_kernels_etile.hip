@@ -2183,6 +2183,161 @@ __global__ __launch_bounds__(256) void k_tsample_p1g(const TsArgs a, const float
     }
 }
 
+// mesh_search with the eight lanes of a walker's group (lane r of the group; all eight call it together): eight probes per round between lo and hi instead of the
+// midpoint -- four rounds for 2 000 mesh points instead of eleven.  F is monotone on the mesh, so the result (the largest m with F(m) <= y, F(m), F(m + 1)) is the
+// one mesh_search finds, bit for bit.
+template <class F>
+__device__ __forceinline__ void group_mesh_search(F f, int last, float y, int r, int gbase, int& m, float& yl, float& yr) {
+    int lo = 0, hi = last;
+    const float fe = r == 0 ? f(0) : (r == 1 ? f(last) : 0.0f);
+    float flo = __shfl(fe, gbase), fhi = __shfl(fe, gbase + 1);
+    const bool beyond = fhi <= y;
+    while (hi - lo > 1) {
+        const int span = hi - lo;
+        const int p = span > 8 ? lo + (int)(((long long)span * (r + 1)) / 9) : lo + 1 + r;      // (distinct, ascending in r, strictly between lo and hi where used)
+        const bool use = p < hi;
+        const float fp = use ? f(p) : 0.0f;
+        const unsigned le = (unsigned)(__ballot(use && fp <= y) >> (gbase & 63)) & 0xFFu;         // monotone: the lanes with F <= y are the first few
+        const unsigned usem = (unsigned)(__ballot(use) >> (gbase & 63)) & 0xFFu;
+        const int k = __popc(le);                                                                  // probes 0 .. k - 1 lie at or below y
+        const int n_use = __popc(usem);
+        const int plo = __shfl(p, gbase + (k > 0 ? k - 1 : 0)), phi = __shfl(p, gbase + (k < 8 ? k : 7));
+        const float vlo = __shfl(fp, gbase + (k > 0 ? k - 1 : 0)), vhi = __shfl(fp, gbase + (k < 8 ? k : 7));
+        if (k > 0) { lo = plo; flo = vlo; }
+        if (k < n_use) { hi = phi; fhi = vhi; }
+    }
+    m = beyond ? last : lo;
+    yl = beyond ? fhi : flo;
+    yr = fhi;
+}
+// grid_root with the group: the two lerp values on lanes 0 and 1
+template <class FL>
+__device__ __forceinline__ float group_grid_root(FL flerp, int m, float yl, float yr, float y, int last, float tol, int r, int gbase) {
+    const float n = (float)last;
+    float xs = (float)m / n;
+    if (yr > yl) xs = xs + (y - yl) / ((yr - yl) * n);
+    int K = 0;
+    float w = 1.0f;
+    while (K < 64 && w * 0.5f > tol * 0.5f) { w *= 0.5f; ++K; }
+    const float scale = ldexpf(1.0f, K);
+    float q = floorf(xs * scale);
+    q = fminf(fmaxf(q, 0.0f), scale - 1.0f);
+    const float fv = r == 0 ? flerp(q / scale) - y : (r == 1 ? flerp(fminf(q + 1.0f, scale - 1.0f) / scale) - y : 0.0f);
+    const float f_lo = __shfl(fv, gbase), f_hi = __shfl(fv, gbase + 1);
+    if (f_hi <= 0.0f && q + 1.0f <= scale - 1.0f) q = q + 1.0f;
+    else if (f_lo > 0.0f && q >= 1.0f) q = q - 1.0f;
+    return q / scale;
+}
+// Phase 2 of the staged sampler / inverse with eight lanes per walker (band form of the spline sums: TsArgs::i_band_int > 0): the coefficients of dimension 1 in
+// k_tsample<2>'s arithmetic (order-dependent sums by the group's first lane), both mesh searches of the phase as eight-way searches: 12 table round trips instead of 30,
+// sixteen waves per SIMD instead of two; the same bits.
+template <int NB>
+__global__ __launch_bounds__(256) void k_tsample_p2g(const TsArgs a, int layer, const float* __restrict__ oj, int64_t B, float* __restrict__ cur0, float* __restrict__ cur1,
+                                                    float* __restrict__ cin, float* __restrict__ xg) {
+    constexpr int kStride = NB + 4;
+    __shared__ __attribute__((aligned(16))) float cs_all[32 * kStride], p4_all[32 * (NB / 4 + 4)];
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t b = t >> 3;
+    const int r = threadIdx.x & 7, lane = threadIdx.x & 63, gbase = lane & ~7, wrow = threadIdx.x >> 3;
+    const bool valid = b < B;
+    const int64_t bl = valid ? b : B - 1;
+    const int n_mesh = a.n_mesh;
+    float* cs = cs_all + wrow * kStride;
+    float* p4 = p4_all + wrow * (NB / 4 + 4);
+    // v_j = 1 / (2^o_j + 1) on the group's lanes, the sums S0, Qv, G in j order by its first lane (k_tsample<2>)
+#pragma unroll
+    for (int jj = 0; jj < NB / 8; ++jj) {
+        const int j = r + 8 * jj;
+        cs[j] = j < a.nbI ? r_of(oj0<NB>(oj, bl, j)) : 0.0f;
+    }
+    float rS = 0.0f, rQ = 0.0f;
+    if (r == 0) {
+        float S0 = 0.0f, Qv = 0.0f, G = 0.0f;
+#pragma unroll 8
+        for (int j = 0; j < NB; ++j) {
+            const float g = a.gI[j], v = cs[j];
+            S0 += v;
+            Qv = __builtin_fmaf(v, g, Qv);
+            G += j < a.nbI ? g : 0.0f;
+        }
+        rS = 1.0f / S0;
+        rQ = 1.0f / __builtin_fmaf(Qv, rS, a.i_reg * G);
+    }
+    rS = __shfl(rS, gbase);
+    rQ = __shfl(rQ, gbase);
+#pragma unroll
+    for (int jj = 0; jj < NB / 8; ++jj) {
+        const int j = r + 8 * jj;
+        cs[j] = j < a.nbI ? (a.gI[j] * __builtin_fmaf(cs[j], rS, a.i_reg)) * rQ : 0.0f;
+    }
+    if (r == 0) {
+        float run = 0.0f;
+#pragma unroll 8
+        for (int j = 0; j < NB; ++j) {
+            if ((j & 3) == 0) p4[j >> 2] = run;
+            run = __builtin_fmaf(cs[j], 1.0f, run);
+        }
+    }
+    const int n_int = a.i_band_int;
+    auto window = [&](int i) { return min(min((i * n_int) / (n_mesh - 1), n_int - 1) & ~3, NB - 12); };
+    auto dot_at = [&](int i) {
+        const int a0 = window(i);
+        const float4_t* rr = reinterpret_cast<const float4_t*>(a.tabI0 + (size_t)i * NB + a0);
+        const float4_t* cq = reinterpret_cast<const float4_t*>(cs + a0);
+        float acc = p4[a0 >> 2];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const float4_t tv = rr[q], c = cq[q];
+            acc = __builtin_fmaf(c.x, tv.x, acc);
+            acc = __builtin_fmaf(c.y, tv.y, acc);
+            acc = __builtin_fmaf(c.z, tv.z, acc);
+            acc = __builtin_fmaf(c.w, tv.w, acc);
+        }
+        return acc;
+    };
+    auto lerp_at = [&](float x) {
+        const LerpN L = nlerp(x, n_mesh);
+        const int a0 = window(min(L.il, L.ir));
+        const float4_t* ra = reinterpret_cast<const float4_t*>(a.tabI0 + (size_t)L.il * NB + a0);
+        const float4_t* rb = reinterpret_cast<const float4_t*>(a.tabI0 + (size_t)L.ir * NB + a0);
+        const float4_t* cq = reinterpret_cast<const float4_t*>(cs + a0);
+        float acc = p4[a0 >> 2];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const float4_t ta = ra[q], tb = rb[q], c = cq[q];
+            acc = __builtin_fmaf(c.x, __builtin_fmaf(tb.x - ta.x, L.t, ta.x), acc);
+            acc = __builtin_fmaf(c.y, __builtin_fmaf(tb.y - ta.y, L.t, ta.y), acc);
+            acc = __builtin_fmaf(c.z, __builtin_fmaf(tb.z - ta.z, L.t, ta.z), acc);
+            acc = __builtin_fmaf(c.w, __builtin_fmaf(tb.w - ta.w, L.t, ta.w), acc);
+        }
+        return acc;
+    };
+    const float o0 = cur0[bl], y1 = cur1[bl];
+    int m;
+    float yl, yr;
+    group_mesh_search(dot_at, n_mesh - 1, y1, r, gbase, m, yl, yr);
+    const float o1 = group_grid_root(lerp_at, m, yl, yr, y1, n_mesh - 1, a.tol, r, gbase);
+    if (layer > 0) {
+        // the layer below: Reverse.inverse_fun, then its dimension 0 through the composite table (k_tsample: start_layer(layer - 1, o0, o1))
+        const float4_t* comp = a.comp + (size_t)(layer - 1) * n_mesh;
+        const float n0 = o1, n1 = o0;
+        group_mesh_search([&](int i) { return comp[i].x; }, n_mesh - 1, n0, r, gbase, m, yl, yr);
+        const float od = group_grid_root([&](float x) { return comp_lerp_x(comp, x, n_mesh); }, m, yl, yr, n0, n_mesh - 1, a.tol, r, gbase);
+        if (valid && r == 0) {
+            cur0[b] = od;
+            cur1[b] = n1;
+            cin[b] = a.exact ? od : n0;
+        }
+        return;
+    }
+    if (valid && r == 0) {
+        // BoxTransformLayer.reverse_fun_mean (made.py:186-197), two particles
+        const float mean = 0.5f * o0, pm = o1 * (1.0f - o0) - (0.5f - mean);
+        xg[b * 2] = ((0.0f - mean) + pm) * 2.0f * a.box_L;
+        xg[b * 2 + 1] = ((o0 - mean) + pm) * 2.0f * a.box_L;
+    }
+}
+
 int check() {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -2377,7 +2532,12 @@ int launch_tile_sample_t(const MfmaDev* mdev, const ModelDev& md, const TsArgs& 
     }
     for (int l = L - 1; l >= 0; --l) {
         hipLaunchKernelGGL((k_etile_cond<false, NBK, 1>), dim3(cond_blocks), dim3(kCondWaves * 64), lds_bytes, s, *mdev, l, (const float*)cin, B, oj, s1);
-        hipLaunchKernelGGL((k_tsample<2, NB>), dim3(lane_blocks), dim3(256), 0, s, a, l, (const float*)oj, u, B, cur0, cur1, cin, lat, latent, x);
+        // (the band form with eight lanes per walker: two row blocks only -- 2^17 draws 0.320 -> 0.290 ms; with one row block the walker's own lane is faster,
+        // 0.201 against 0.225: WF_SAMPLE_GROUP_PHASE2 forces it, WF_SAMPLE_ONE_LANE the other form)
+        if (a.i_band_int > 0 && !getenv("WF_SAMPLE_ONE_LANE") && (NB > 32 || getenv("WF_SAMPLE_GROUP_PHASE2")))
+            hipLaunchKernelGGL((k_tsample_p2g<NB>), dim3((unsigned)((B * 8 + 255) / 256)), dim3(256), 0, s, a, l, (const float*)oj, B, cur0, cur1, cin, x);
+        else
+            hipLaunchKernelGGL((k_tsample<2, NB>), dim3(lane_blocks), dim3(256), 0, s, a, l, (const float*)oj, u, B, cur0, cur1, cin, lat, latent, x);
     }
     return check();
 }
