@@ -1058,6 +1058,9 @@ __device__ __forceinline__ void acc_add(float* acc, int* ticket, int b, int k, i
     if (SHARED) __hip_atomic_store(ticket + b, k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+}  // namespace
+// (k_ebwd has external linkage: its two-row-block instantiations are compiled in a translation unit of their own, wf_etile_bwd_k2.hip -- this file again with
+// WF_ETILE_ONLY_K2 -- under the max-ilp scheduling strategy, which is worth 6 % to them and costs the one-row-block form 1 %: DESIGN 4.9)
 // -DWF_MARKS: comment lines in the assembly at the phase boundaries of k_ebwd (scratch/r04_spill_phases.py counts the spill traffic per phase)
 #ifdef WF_MARKS
 #define WF_MARK(name) asm volatile("; WF_MARK " name)
@@ -1558,6 +1561,14 @@ __global__ __launch_bounds__(kBwdWaves * 64) void k_ebwd(const MfmaDev mm, int n
     }
 }
 
+#ifdef WF_ETILE_ONLY_K2
+template __global__ void k_ebwd<true, 2>(const MfmaDev, int, const float*, const float*, const float*, float*, const float*, const float*, int64_t, float*);
+template __global__ void k_ebwd<false, 2>(const MfmaDev, int, const float*, const float*, const float*, float*, const float*, const float*, int64_t, float*);
+#else
+extern template __global__ void k_ebwd<true, 2>(const MfmaDev, int, const float*, const float*, const float*, float*, const float*, const float*, int64_t, float*);
+extern template __global__ void k_ebwd<false, 2>(const MfmaDev, int, const float*, const float*, const float*, float*, const float*, const float*, int64_t, float*);
+#endif
+namespace {
 // (one launch for the nets of a chunk: blockIdx.y = net; partial [n_nets][kESplit][gf] of which the first n_part blocks are live, gacc [n_nets][gf];
 // gf = g_floats(row blocks of the model))
 __global__ void k_egrad_reduce(const float* __restrict__ partial, int n_part, int accumulate, float* __restrict__ gacc, int gf) {
@@ -2348,6 +2359,7 @@ int check() {
 }
 
 }  // namespace
+#ifndef WF_ETILE_ONLY_K2   // (the host side: in the main translation unit only)
 
 bool energy_tile_fused(const MfmaDev* mdev) {
     const char* e = getenv("WF_ENERGY_FUSED");
@@ -2498,6 +2510,7 @@ bool tile_sample_capable(const MfmaDev* mdev) {
 // the head outputs of whole tiles (32 nbk rows; sized for three channels -- the conditioner launches have written the value channel alone since round 4)
 int64_t tile_sample_floats(int64_t B, int nbk) { return B * 10 + ((B + 31) / 32) * 32 * (32 * nbk * NCH) + 64; }
 
+#endif   // WF_ETILE_ONLY_K2
 namespace {
 template <int NBK>
 int launch_tile_sample_t(const MfmaDev* mdev, const ModelDev& md, const TsArgs& a_in, int draw, const float* u, int64_t B, float* x, float* latent, float* ws, hipStream_t s) {
@@ -2542,6 +2555,7 @@ int launch_tile_sample_t(const MfmaDev* mdev, const ModelDev& md, const TsArgs& 
     return check();
 }
 }  // namespace
+#ifndef WF_ETILE_ONLY_K2
 
 // draw == 0: x = inverse(u);  draw == 1: latent ~ prior (reported in `latent` if given), x = inverse(latent)
 int launch_tile_sample(const MfmaDev* mdev, const ModelDev& md, const float* tabI0, const float* tabP0, const float* fk_nat, int draw, unsigned long long seed,
@@ -2570,4 +2584,5 @@ int launch_tile_sample(const MfmaDev* mdev, const ModelDev& md, const float* tab
                           : launch_tile_sample_t<2>(mdev, md, a, draw, u, B, x, latent, ws, (hipStream_t)stream);
 }
 
+#endif   // WF_ETILE_ONLY_K2
 }  // namespace wf
